@@ -1,0 +1,398 @@
+/*
+ * mpm.c -- CPU restatement of the MLS-MPM particle<->grid transfer path of zpc.
+ * TEST INFRASTRUCTURE ONLY (see zpc_oracle.h).
+ *
+ *   orc_svd3                  math/matrix/SVD.hpp:15-1030 (McAdams et al. 2011: 4 cyclic Jacobi sweeps
+ *                             with the approximate Givens angle on A^T A, quaternion accumulation,
+ *                             singular-value sort, Givens QR)
+ *   orc_stress_fixedcorotated physics/ConstitutiveModel_Vol_dP.hpp:10-47
+ *   orc_stress_sand           physics/ConstitutiveModel_Vol_dP.hpp:246-326
+ *   orc_arena                 simulation/Utils.hpp:47-75 + math/curve/InterpolationKernel.hpp:47-55,93-130
+ *   orc_mpm_build_partition   simulation/sparsity/SparsityOp.hpp:59-115
+ *   orc_mpm_p2g               simulation/transfer/P2G.hpp:51-125
+ *   orc_mpm_grid_update       simulation/grid/GridOp.hpp:71-108
+ *   orc_mpm_g2p               simulation/transfer/G2P.hpp:44-83
+ *
+ * Matrices are 9-vectors in column-major order (M[r + 3*c]) exactly as the reference stores F and C.
+ * Build with -ffp-contract=off so that float arithmetic is not fused (the reference is built
+ * by plain g++ -O3 on x86-64, which does not contract).
+ */
+#include "zpc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#  include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ SVD */
+#define GAMMA 5.8284273147583007813f /* 3 + 2 sqrt 2  (SVD.hpp:33) */
+#define CSTAR 0.9238795325112867f    /* cos(pi/8)     (SVD.hpp:30, bits 1064076127) */
+#define SSTAR 0.3826834323650898f    /* sin(pi/8)     (SVD.hpp:29, bits 1053028117) */
+#define TINY 1.e-20f                 /* SVD.hpp:32 */
+#define SMALL 1.e-12f                /* SVD.hpp:31 */
+
+static inline float rsqrtf_(float x) { return 1.0f / sqrtf(x); } /* zs::rsqrt on host */
+
+/* one Jacobi conjugation in the (x,y) plane (rotation about axis z = 3-x-y) of the symmetric
+ * matrix S (full storage), accumulating the rotation into quaternion q = (w, v0, v1, v2) */
+static void jacobi_conj(int x, int y, int z, float S[3][3], float q[4]) {
+  /* approximate Givens half-angle: ch : sh = (s_xx - s_yy) : s_xy / 2  (SVD.hpp:103-131) */
+  float sh = S[x][y] * 0.5f;
+  float ch = S[x][x] - S[y][y];
+  if (!(sh * sh >= TINY)) { sh = 0.f; ch = 1.f; }
+  float sh2 = sh * sh, ch2 = ch * ch;
+  float w = rsqrtf_(sh2 + ch2);
+  sh *= w;
+  ch *= w;
+  if (ch2 <= GAMMA * sh2) { sh = SSTAR; ch = CSTAR; }
+  /* full-angle rotation from the half-angle pair */
+  sh2 = sh * sh; ch2 = ch * ch;
+  float c = ch2 - sh2, s = 2.f * sh * ch; /* |(c,s)| = ch2 + sh2 = 1 */
+  /* S <- Q^T S Q with Q = rotation by (c,s) in the (x,y) plane */
+  float sxx = S[x][x], sxy = S[x][y], syy = S[y][y], sxz = S[x][z], syz = S[y][z];
+  float t1 = c * sxx + s * sxy, t2 = c * sxy + s * syy;
+  float t3 = -s * sxx + c * sxy, t4 = -s * sxy + c * syy;
+  S[x][x] = c * t1 + s * t2;
+  S[x][y] = S[y][x] = c * t3 + s * t4;
+  S[y][y] = -s * t3 + c * t4;
+  S[x][z] = S[z][x] = c * sxz + s * syz;
+  S[y][z] = S[z][y] = -s * sxz + c * syz;
+  /* q <- q * (ch, sh e_z) */
+  float qw = q[0], qx = q[1 + x], qy = q[1 + y], qz = q[1 + z];
+  q[0] = qw * ch - qz * sh;
+  q[1 + x] = qx * ch + qy * sh;
+  q[1 + y] = qy * ch - qx * sh;
+  q[1 + z] = qz * ch + qw * sh;
+}
+
+/* Givens rotation (c,s) zeroing a2 against a1: [c s; -s c]^T [a1;a2] = [r;0]  (SVD.hpp QR stage) */
+static void qr_givens(float a1, float a2, float *c, float *s) {
+  float rho = sqrtf(a1 * a1 + a2 * a2);
+  if (rho > SMALL) { *c = a1 / rho; *s = a2 / rho; }
+  else { *c = 1.f; *s = 0.f; }
+}
+
+void orc_svd3(const float A[9], float U[9], float Sg[3], float V[9]) {
+  /* normal equations S = A^T A (SVD.hpp:52-91) */
+  float S[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      S[i][j] = A[0 + 3 * i] * A[0 + 3 * j] + A[1 + 3 * i] * A[1 + 3 * j] + A[2 + 3 * i] * A[2 + 3 * j];
+  float q[4] = {1.f, 0.f, 0.f, 0.f};
+  for (int sweep = 0; sweep < 4; ++sweep) { /* SVD.hpp:101 */
+    jacobi_conj(0, 1, 2, S, q);
+    jacobi_conj(1, 2, 0, S, q);
+    jacobi_conj(2, 0, 1, S, q);
+  }
+  /* normalise quaternion -> V */
+  float n = rsqrtf_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  float w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
+  float Vm[3][3]; /* Vm[r][c] */
+  Vm[0][0] = 1 - 2 * (y * y + z * z); Vm[0][1] = 2 * (x * y - w * z);     Vm[0][2] = 2 * (x * z + w * y);
+  Vm[1][0] = 2 * (x * y + w * z);     Vm[1][1] = 1 - 2 * (x * x + z * z); Vm[1][2] = 2 * (y * z - w * x);
+  Vm[2][0] = 2 * (x * z - w * y);     Vm[2][1] = 2 * (y * z + w * x);     Vm[2][2] = 1 - 2 * (x * x + y * y);
+  /* B = A V */
+  float B[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      B[r][c] = A[r + 0] * Vm[0][c] + A[r + 3] * Vm[1][c] + A[r + 6] * Vm[2][c];
+  /* sort columns by decreasing norm; each swap negates one column so det(V) stays +1 */
+  float rho[3];
+  for (int c = 0; c < 3; ++c) rho[c] = B[0][c] * B[0][c] + B[1][c] * B[1][c] + B[2][c] * B[2][c];
+#define CSWAP(a, b)                                                             \
+  if (rho[a] < rho[b]) {                                                        \
+    float tr = rho[a]; rho[a] = rho[b]; rho[b] = tr;                            \
+    for (int r = 0; r < 3; ++r) {                                               \
+      float tb = B[r][a]; B[r][a] = B[r][b]; B[r][b] = -tb;                     \
+      float tv = Vm[r][a]; Vm[r][a] = Vm[r][b]; Vm[r][b] = -tv;                 \
+    }                                                                           \
+  }
+  CSWAP(0, 1) CSWAP(0, 2) CSWAP(1, 2)
+#undef CSWAP
+  /* QR by three Givens rotations: zero B10, B20, B21; U accumulates the rotations */
+  float Um[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+  for (int k = 0; k < 3; ++k) {
+    int p = pr[k][0], r2 = pr[k][1];
+    float c, s;
+    qr_givens(B[p][p], B[r2][p], &c, &s);
+    for (int col = 0; col < 3; ++col) { /* rows p, r2 of B <- G^T B */
+      float bp = B[p][col], br = B[r2][col];
+      B[p][col] = c * bp + s * br;
+      B[r2][col] = -s * bp + c * br;
+    }
+    for (int row = 0; row < 3; ++row) { /* columns p, r2 of U <- U G */
+      float up = Um[row][p], ur = Um[row][r2];
+      Um[row][p] = c * up + s * ur;
+      Um[row][r2] = -s * up + c * ur;
+    }
+  }
+  Sg[0] = B[0][0]; Sg[1] = B[1][1]; Sg[2] = B[2][2];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { U[r + 3 * c] = Um[r][c]; V[r + 3 * c] = Vm[r][c]; }
+}
+
+/* ------------------------------------------------------------------------ constitutive models */
+void orc_lame(float E, float nu, float *mu, float *lam) { /* ConstitutiveModel.hpp:34-38: double math, float result */
+  *mu = (float)(0.5 * E / (1 + nu));
+  *lam = (float)(E * nu / ((1 + nu) * (1 - 2 * nu)));
+}
+
+/* out = M1 diag(d) M2^T  (math/matrix/MatrixUtils.h:26-47) */
+static void mat_diag_matT(float *out, const float *m1, const float *d, const float *m2) {
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r)
+      out[r + 3 * c] = m1[r] * d[0] * m2[c] + m1[r + 3] * d[1] * m2[c + 3] + m1[r + 6] * d[2] * m2[c + 6];
+}
+/* PF^T * volume (ConstitutiveModel_Vol_dP.hpp:37-46) */
+static void pft_vol(const float *P, const float *F, float volume, float *PF) {
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r)
+      PF[r + 3 * c] = (P[r] * F[c] + P[r + 3] * F[c + 3] + P[r + 6] * F[c + 6]) * volume;
+}
+
+void orc_stress_fixedcorotated(float volume, float mu, float lam, const float F[9], float PF[9]) {
+  float U[9], S[3], V[9];
+  orc_svd3(F, U, S, V);
+  float J = S[0] * S[1] * S[2];
+  float scaled_mu = 2.f * mu;
+  float scaled_lambda = lam * (J - 1.f);
+  float Ph[3];
+  Ph[0] = scaled_mu * (S[0] - 1.f) + scaled_lambda * (S[1] * S[2]);
+  Ph[1] = scaled_mu * (S[1] - 1.f) + scaled_lambda * (S[0] * S[2]);
+  Ph[2] = scaled_mu * (S[2] - 1.f) + scaled_lambda * (S[0] * S[1]);
+  float P[9];
+  /* P = U diag(Ph) V^T written as Ph_k * U_rk * V_ck (:24-33) */
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r)
+      P[r + 3 * c] = Ph[0] * U[r] * V[c] + Ph[1] * U[r + 3] * V[c + 3] + Ph[2] * U[r + 6] * V[c + 6];
+  pft_vol(P, F, volume, PF);
+}
+
+void orc_stress_sand(float volume, float mu, float lam, float cohesion, float beta, float yieldSurface,
+                     int volCorrection, float *logJp, float F[9], float PF[9]) {
+  float U[9], S[3], V[9];
+  orc_svd3(F, U, S, V);
+  float scaled_mu = 2.f * mu;
+  float epsilon[3], New_S[3] = {0, 0, 0}, New_F[9];
+  for (int i = 0; i < 3; ++i) {
+    float abs_S = S[i] > 0 ? S[i] : -S[i];
+    abs_S = abs_S > 1e-4 ? abs_S : 1e-4; /* double literal as in the reference (:262) */
+    epsilon[i] = logf(abs_S) - cohesion;
+  }
+  float sum_epsilon = epsilon[0] + epsilon[1] + epsilon[2];
+  float trace_epsilon = sum_epsilon + *logJp;
+  float epsilon_hat[3];
+  for (int i = 0; i < 3; ++i) epsilon_hat[i] = epsilon[i] - (trace_epsilon / 3.f);
+  float epsilon_hat_norm = sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1]
+                                 + epsilon_hat[2] * epsilon_hat[2]);
+  if (trace_epsilon >= 0.f) { /* case II: cone tip */
+    New_S[0] = New_S[1] = New_S[2] = expf(cohesion);
+    mat_diag_matT(New_F, U, New_S, V);
+    memcpy(F, New_F, sizeof(New_F));
+    if (volCorrection) *logJp = beta * sum_epsilon + *logJp;
+  } else if (mu != 0) {
+    *logJp = 0;
+    float delta_gamma = epsilon_hat_norm + (3.f * lam + scaled_mu) / scaled_mu * trace_epsilon * yieldSurface;
+    float H[3];
+    if (delta_gamma <= 0) { /* case I: inside the cone */
+      for (int i = 0; i < 3; ++i) H[i] = epsilon[i] + cohesion;
+    } else { /* case III: project to the cone surface */
+      for (int i = 0; i < 3; ++i) H[i] = epsilon[i] - (delta_gamma / epsilon_hat_norm) * epsilon_hat[i] + cohesion;
+    }
+    for (int i = 0; i < 3; ++i) New_S[i] = expf(H[i]);
+    mat_diag_matT(New_F, U, New_S, V);
+    memcpy(F, New_F, sizeof(New_F));
+  }
+  float New_S_log[3] = {logf(New_S[0]), logf(New_S[1]), logf(New_S[2])};
+  float trace_log_S = New_S_log[0] + New_S_log[1] + New_S_log[2];
+  float P_hat[3];
+  for (int i = 0; i < 3; ++i) P_hat[i] = (scaled_mu * New_S_log[i] + lam * trace_log_S) / New_S[i];
+  float P[9];
+  mat_diag_matT(P, U, P_hat, V);
+  pft_vol(P, F, volume, PF);
+}
+
+/* ------------------------------------------------------------------------------------ arena */
+/* LocalArena<collocated, quadratic>::init: X = pos/dx; corner = floor(X - 0.5); d0 = X - corner;
+ * w = {0.5(1.5-d0)^2, 0.75-(d0-1)^2, 0.5(d0-0.5)^2}; localPos = d0*dx.   w[3*d + k] */
+void orc_arena(float dx, const float pos[3], int32_t corner[3], float localPos[3], float w[9]) {
+  for (int d = 0; d < 3; ++d) {
+    float X = pos[d] / dx;
+    corner[d] = (int32_t)floorf(X - 0.5f);
+    float lp = X - (float)corner[d];
+    /* quadratic_bspline_weights re-derives d0 = x - floor(x - 0.5) from lp (InterpolationKernel.hpp:107) */
+    float d0 = lp - (float)((int32_t)floorf(lp - 0.5f));
+    w[3 * d + 0] = 0.5f * (1.5f - d0) * (1.5f - d0);
+    float d1 = d0 - 1.0f;
+    w[3 * d + 1] = 0.75f - d1 * d1;
+    float zz = 0.5f + d1;
+    w[3 * d + 2] = 0.5f * zz * zz;
+    localPos[d] = lp * dx;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ partition */
+static int32_t floordiv(int32_t a, int32_t b) { /* blockid: coord + (coord<0 ? -b+1 : 0), then C division */
+  return (a + (a < 0 ? -b + 1 : 0)) / b;
+}
+
+void orc_mpm_build_partition(orc_bht *table, const float *pos, size_t n, float dx, int side) {
+  float dxinv = 1.0f / dx;
+  for (size_t i = 0; i < n; ++i) { /* ComputeSparsity (SparsityOp.hpp:75-84), offset -2, displacement 0.5 */
+    int32_t b[3];
+    for (int d = 0; d < 3; ++d) {
+      int32_t coord = (int32_t)floorf(pos[3 * i + d] * dxinv + 0.5f) + (-2);
+      b[d] = floordiv(coord, side);
+    }
+    orc_bht_insert(table, b);
+  }
+  int32_t nb = orc_bht_size(table); /* EnlargeSparsity lo=0, hi=2 over the blocks present so far (:95-110) */
+  for (int32_t i = 0; i < nb; ++i) {
+    int32_t base[3];
+    memcpy(base, orc_bht_active_keys(table) + 3 * (size_t)i, 12);
+    for (int ddx = 0; ddx < 2; ++ddx)
+      for (int ddy = 0; ddy < 2; ++ddy)
+        for (int ddz = 0; ddz < 2; ++ddz) {
+          int32_t k[3] = {base[0] + ddx, base[1] + ddy, base[2] + ddz};
+          orc_bht_insert(table, k);
+        }
+  }
+}
+
+/* ------------------------------------------------------------------------------------ transfers */
+static inline void atomic_add_f32(float *dst, float val, int atomic) {
+  if (!atomic) { *dst += val; return; }
+  /* CAS loop like host atomic_add (execution/Atomics.hpp:61-73) */
+  uint32_t *p = (uint32_t *)dst;
+  uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED), neu;
+  do {
+    float f;
+    memcpy(&f, &old, 4);
+    f += val;
+    memcpy(&neu, &f, 4);
+  } while (!__atomic_compare_exchange_n(p, &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
+/* unpack_coord_in_grid (simulation/Utils.hpp:12-31) + grid_traits::coord_to_cellid (Structure.hpp:323-333) */
+static inline int locate(const orc_bht *table, const int32_t coord[3], int side, int32_t *cellid) {
+  int32_t loc[3], blk[3];
+  for (int d = 0; d < 3; ++d) {
+    loc[d] = coord[d] & (side - 1);
+    blk[d] = (coord[d] - loc[d]) / side;
+  }
+  *cellid = (loc[0] * side + loc[1]) * side + loc[2];
+  return orc_bht_query(table, blk);
+}
+
+void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const float *mass,
+                 const float *pos, const float *vel, const float *Cm, const float *Fm, float *logJp,
+                 float *grid) {
+  const float dx = p->dx, dx_inv = 1.0f / dx;
+  const float D_inv = 4.f * dx_inv * dx_inv;
+  const int side = p->side, ncell = side * side * side;
+  const int atomic = p->nthreads > 1;
+  float mu, lam;
+  orc_lame(p->E, p->nu, &mu, &lam);
+#pragma omp parallel for num_threads(p->nthreads > 1 ? p->nthreads : 1) schedule(static) if (p->nthreads > 1)
+  for (size_t i = 0; i < n; ++i) {
+    float contrib[9], F[9];
+    const float *C = Cm + 9 * i;
+    memcpy(F, Fm + 9 * i, 36);
+    if (p->model == 0) {
+      orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
+    } else {
+      float lj = logJp[i];
+      orc_stress_sand(p->volume, mu, lam, p->cohesion, p->beta, p->yieldSurface, p->volCorrection, &lj, F, contrib);
+      logJp[i] = lj; /* P2G.hpp:101 -- note: the projected F is NOT written back */
+    }
+    for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -p->dt * D_inv; /* P2G.hpp:105 */
+    int32_t corner[3];
+    float lp[3], w[9];
+    orc_arena(dx, pos + 3 * i, corner, lp, w);
+    const float m = mass[i];
+    const float *v = vel + 3 * i;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        for (int c = 0; c < 3; ++c) {
+          int32_t coord[3] = {corner[0] + a, corner[1] + b, corner[2] + c};
+          int32_t cellid;
+          int blockno = locate(table, coord, side, &cellid);
+          float *blk = grid + (size_t)blockno * 7 * (size_t)ncell;
+          float xixp[3] = {(float)a * dx - lp[0], (float)b * dx - lp[1], (float)c * dx - lp[2]};
+          float W = 1.f; /* weight_impl: ret = 1; ret *= w_x; ret *= w_y; ret *= w_z */
+          W *= w[0 + a]; W *= w[3 + b]; W *= w[6 + c];
+          atomic_add_f32(&blk[0 * ncell + cellid], m * W, atomic);
+          for (int d = 0; d < 3; ++d) {
+            atomic_add_f32(&blk[(1 + d) * ncell + cellid],
+                           W * m * (v[d] + (C[d] * xixp[0] + C[3 + d] * xixp[1] + C[6 + d] * xixp[2])), atomic);
+            atomic_add_f32(&blk[(4 + d) * ncell + cellid],
+                           (contrib[d] * xixp[0] + contrib[3 + d] * xixp[1] + contrib[6 + d] * xixp[2]) * W, atomic);
+          }
+        }
+  }
+}
+
+void orc_mpm_grid_update(const orc_mpm_params *p, size_t nblocks, float *grid, const float extf[3],
+                         float *maxVelSqr) {
+  const int ncell = p->side * p->side * p->side;
+  float mx = maxVelSqr ? *maxVelSqr : 0.f;
+  for (size_t b = 0; b < nblocks; ++b) {
+    float *blk = grid + b * 7 * (size_t)ncell;
+    for (int c = 0; c < ncell; ++c) {
+      float mass = blk[c];
+      if (mass != 0.f) {
+        mass = 1.f / mass;
+        float vsq = 0.f;
+        for (int d = 0; d < 3; ++d) {
+          float v = blk[(1 + d) * ncell + c] * mass + extf[d] * p->dt;
+          blk[(1 + d) * ncell + c] = v;
+          vsq += v * v;
+        }
+        if (vsq > mx) mx = vsq;
+      }
+    }
+  }
+  if (maxVelSqr) *maxVelSqr = mx;
+}
+
+void orc_mpm_g2p(const orc_mpm_params *p, const orc_bht *table, size_t n, float *pos, float *vel,
+                 float *Cm, float *Fm, const float *grid) {
+  const float dx = p->dx, dx_inv = 1.0f / dx;
+  const float D_inv = 4.f * dx_inv * dx_inv;
+  const int side = p->side, ncell = side * side * side;
+#pragma omp parallel for num_threads(p->nthreads > 1 ? p->nthreads : 1) schedule(static) if (p->nthreads > 1)
+  for (size_t i = 0; i < n; ++i) {
+    float v[3] = {0, 0, 0}, C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t corner[3];
+    float lp[3], w[9];
+    orc_arena(dx, pos + 3 * i, corner, lp, w);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        for (int c = 0; c < 3; ++c) {
+          int32_t coord[3] = {corner[0] + a, corner[1] + b, corner[2] + c};
+          int32_t cellid;
+          int blockno = locate(table, coord, side, &cellid);
+          const float *blk = grid + (size_t)blockno * 7 * (size_t)ncell;
+          float xixp[3] = {(float)a * dx - lp[0], (float)b * dx - lp[1], (float)c * dx - lp[2]};
+          float W = 1.f;
+          W *= w[0 + a]; W *= w[3 + b]; W *= w[6 + c];
+          float vi[3] = {blk[1 * ncell + cellid], blk[2 * ncell + cellid], blk[3 * ncell + cellid]};
+          for (int d = 0; d < 3; ++d) v[d] += vi[d] * W;
+          for (int d = 0; d < 9; ++d) C[d] += W * vi[d % 3] * xixp[d / 3] * D_inv;
+        }
+    for (int d = 0; d < 3; ++d) pos[3 * i + d] += v[d] * p->dt;
+    /* F <- (I + dt C) F   (G2P.hpp:74-78, MatrixUtils.h:136-146) */
+    float tmp[9], oldF[9], F[9];
+    memcpy(oldF, Fm + 9 * i, 36);
+    for (int d = 0; d < 9; ++d) tmp[d] = C[d] * p->dt + ((d & 0x3) ? 0.f : 1.f);
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r)
+        F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+    memcpy(Fm + 9 * i, F, 36);
+    memcpy(vel + 3 * i, v, 12);
+    memcpy(Cm + 9 * i, C, 36);
+  }
+}
