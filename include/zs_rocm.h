@@ -1,0 +1,334 @@
+/*
+ * zs_rocm.h -- C ABI of libzsrocm.so, the MI355X (gfx950) backend for zpc's data-parallel hot path.
+ *
+ * Two groups of entry points:
+ *
+ *  (A) the reference's own C ABI (include/zensim/py_interop/, the `zpc_py_interop` target that Python
+ *      `zpc_jit` binds through ctypes), re-exported 1:1 with `cuda` -> `rocm` in the symbol names:
+ *      policy handles, launch__device, typed parallel primitives over `aosoa_iterator_port`s,
+ *      Vector / TileVector / bht container handles.  Each declaration cites the file:line it replaces.
+ *
+ *  (B) `zs_rocm_*` entry points for work that in the reference only exists as C++ template
+ *      instantiations inside user translation units (`pol(range(n), P2GTransfer{...})`,
+ *      `tb.insert(key)` in a lambda, ...).  A C++ caller reaches them through the header-only face in
+ *      include/zensim_rocm/; each declaration cites the functor it replaces.
+ *
+ * Conventions (same as the reference): every create returns a heap object owned by the
+ * caller and released with the matching del_*; views are non-owning; functions return void and report
+ * device errors by printing the first error per device to stderr and latching it
+ * (zs_rocm_last_error), never by throwing across the ABI.  All device pointers are plain HIP device
+ * pointers; no framework types appear in any signature.
+ */
+#ifndef ZS_ROCM_H
+#define ZS_ROCM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#  define ZS_ROCM_EXPORT __attribute__((visibility("default")))
+#else
+#  define ZS_ROCM_EXPORT
+#endif
+
+/* ======================================================================== (A) policy & launch */
+/* zs::CudaExecutionPolicy (cuda/execution/ExecutionPolicy.cuh:345-911) -> RocmExecutionPolicy */
+typedef struct zs_rocm_policy zs_rocm_policy;
+
+/* py_interop/cuda/ExecutionPolicy.cpp:8-9 */
+ZS_ROCM_EXPORT zs_rocm_policy *policy__device(void);
+ZS_ROCM_EXPORT void del_policy__device(zs_rocm_policy *);
+/* fluent setters of ExecutionPolicyInterface / CudaExecutionPolicy
+ * (execution/ExecutionPolicy.hpp:110-126, cuda/execution/ExecutionPolicy.cuh:362-385).
+ * Defaults: sync = 1, profile = 0, device = -1 (current), stream = -1 (null stream), block = 0. */
+ZS_ROCM_EXPORT void zs_rocm_policy_sync(zs_rocm_policy *, int sync);
+ZS_ROCM_EXPORT void zs_rocm_policy_profile(zs_rocm_policy *, int profile);
+ZS_ROCM_EXPORT void zs_rocm_policy_device(zs_rocm_policy *, int procid);
+ZS_ROCM_EXPORT void zs_rocm_policy_stream(zs_rocm_policy *, int streamid); /* -1 | 0..31 spare streams (cuda/Cuda.h:39,115-120) */
+ZS_ROCM_EXPORT void zs_rocm_policy_listen(zs_rocm_policy *, int incomingProc, int incomingStreamid);
+ZS_ROCM_EXPORT void zs_rocm_policy_shmem(zs_rocm_policy *, size_t bytes);
+ZS_ROCM_EXPORT void zs_rocm_policy_block(zs_rocm_policy *, int tpb);
+/* run on a stream owned by the caller (e.g. the framework's current stream); NULL restores streamid */
+ZS_ROCM_EXPORT void zs_rocm_policy_external_stream(zs_rocm_policy *, void *hipStream);
+ZS_ROCM_EXPORT void *zs_rocm_policy_get_stream(const zs_rocm_policy *); /* getStream(), :379 */
+ZS_ROCM_EXPORT int zs_rocm_policy_should_sync(const zs_rocm_policy *);
+ZS_ROCM_EXPORT void zs_rocm_policy_sync_ctx(const zs_rocm_policy *);   /* syncCtx(), :396-399 */
+ZS_ROCM_EXPORT float zs_rocm_policy_last_elapsed_ms(const zs_rocm_policy *); /* profile(true): hipEvent pair */
+/* latched error status of the device context (cuda/Cuda.h:291-312); 0 = hipSuccess */
+ZS_ROCM_EXPORT int zs_rocm_last_error(int device);
+ZS_ROCM_EXPORT void zs_rocm_clear_error(int device);
+ZS_ROCM_EXPORT int zs_rocm_device_count(void);
+/* frees the grow-only per-stream temporary arenas (stand-in for streamMemFree, cuda/Cuda.cu:169-176) */
+ZS_ROCM_EXPORT void zs_rocm_release_temporaries(void);
+
+/* py_interop/cuda/ExecutionPolicy.cpp:11-39: launch a module function (hipFunction_t) over `dim`
+ * threads, block 128, grid ceil(dim/128), on the policy's stream, sync if shouldSync() */
+ZS_ROCM_EXPORT void launch__device(zs_rocm_policy *, void *kernel, size_t dim, void **args);
+
+/* ======================================================================== (A) iterator ABI */
+/* py_interop/GenericIterator.hpp:11-16: element address =
+ *   base + ((((idx >> numTileBits) * numChns) << numTileBits) | (idx & tileMask));
+ * AoS form: numTileBits = tileMask = 0.  Passed BY VALUE. */
+#define ZS_ROCM_DECL_PORT(T, NAME)                                   \
+  typedef struct {                                                   \
+    T *base;                                                         \
+    uint32_t idx, numTileBits, tileMask, numChns;                    \
+  } NAME;
+ZS_ROCM_DECL_PORT(int, aosoa_iterator_int_1)
+ZS_ROCM_DECL_PORT(const int, aosoa_iterator_const_int_1)
+ZS_ROCM_DECL_PORT(float, aosoa_iterator_float_1)
+ZS_ROCM_DECL_PORT(const float, aosoa_iterator_const_float_1)
+ZS_ROCM_DECL_PORT(double, aosoa_iterator_double_1)
+ZS_ROCM_DECL_PORT(const double, aosoa_iterator_const_double_1)
+
+/* ======================================================================== (A) parallel primitives */
+/* py_interop/cuda/ExecutionPolicy.cpp:41-131 (ZS_DEFINE_PARALLEL_PRIMITIVES for int, float, double).
+ * reduce: out[0] = fold(op, init, [first,last)) with init = 0 / 1 / numeric max / numeric lowest;
+ * scans with init = identity; radix sort over all key bits (integral T only, as in the reference). */
+#define ZS_ROCM_DECL_PRIMITIVES(T)                                                                          \
+  ZS_ROCM_EXPORT void reduce_sum__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1 first,        \
+                                               aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1);  \
+  ZS_ROCM_EXPORT void reduce_prod__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1 first,       \
+                                                aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void reduce_min__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1 first,        \
+                                               aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1);  \
+  ZS_ROCM_EXPORT void reduce_max__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1 first,        \
+                                               aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1);  \
+  ZS_ROCM_EXPORT void exclusive_scan_sum__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1,      \
+                                                       aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void exclusive_scan_prod__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1,     \
+                                                        aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void inclusive_scan_sum__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1,      \
+                                                       aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void inclusive_scan_prod__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1,     \
+                                                        aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void radix_sort__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 first,              \
+                                               aosoa_iterator_##T##_1 last, aosoa_iterator_##T##_1 out);    \
+  ZS_ROCM_EXPORT void radix_sort_pair__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 keysIn,        \
+                                                    aosoa_iterator_int_1 valsIn, aosoa_iterator_##T##_1 keysOut, \
+                                                    aosoa_iterator_int_1 valsOut, size_t count);
+ZS_ROCM_DECL_PRIMITIVES(int)
+ZS_ROCM_DECL_PRIMITIVES(float)
+ZS_ROCM_DECL_PRIMITIVES(double)
+
+/* (B) primitives on contiguous device arrays with the full argument set of the C++ face
+ * (execution/ExecutionPolicy.hpp:698-781: init, bit window [sbit, ebit), other key widths). */
+ZS_ROCM_EXPORT void zs_rocm_reduce_i32(zs_rocm_policy *, const int32_t *in, size_t n, int32_t *out, int32_t init, int op);
+ZS_ROCM_EXPORT void zs_rocm_reduce_i64(zs_rocm_policy *, const int64_t *in, size_t n, int64_t *out, int64_t init, int op);
+ZS_ROCM_EXPORT void zs_rocm_reduce_f32(zs_rocm_policy *, const float *in, size_t n, float *out, float init, int op);
+ZS_ROCM_EXPORT void zs_rocm_reduce_f64(zs_rocm_policy *, const double *in, size_t n, double *out, double init, int op);
+/* op: 0 = plus, 1 = multiplies, 2 = getmin, 3 = getmax (ZpcFunctional.hpp) */
+ZS_ROCM_EXPORT void zs_rocm_scan_i32(zs_rocm_policy *, const int32_t *in, size_t n, int32_t *out, int32_t init, int op, int exclusive);
+ZS_ROCM_EXPORT void zs_rocm_scan_i64(zs_rocm_policy *, const int64_t *in, size_t n, int64_t *out, int64_t init, int op, int exclusive);
+ZS_ROCM_EXPORT void zs_rocm_scan_f32(zs_rocm_policy *, const float *in, size_t n, float *out, float init, int op, int exclusive);
+ZS_ROCM_EXPORT void zs_rocm_scan_f64(zs_rocm_policy *, const double *in, size_t n, double *out, double init, int op, int exclusive);
+/* stable LSD radix sort on bits [sbit, ebit); vals may be NULL for keys-only */
+ZS_ROCM_EXPORT void zs_rocm_radix_sort_i32(zs_rocm_policy *, const int32_t *kin, const int32_t *vin, int32_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
+ZS_ROCM_EXPORT void zs_rocm_radix_sort_u32(zs_rocm_policy *, const uint32_t *kin, const int32_t *vin, uint32_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
+ZS_ROCM_EXPORT void zs_rocm_radix_sort_i64(zs_rocm_policy *, const int64_t *kin, const int32_t *vin, int64_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
+ZS_ROCM_EXPORT void zs_rocm_radix_sort_u64(zs_rocm_policy *, const uint64_t *kin, const int32_t *vin, uint64_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
+
+/* ======================================================================== (A) allocators & Vector */
+/* py_interop/Allocator.cpp:5-21; memsrc_e: 0 = host, 1 = device, 2 = um (types/Property.h:7) */
+typedef struct zs_rocm_allocator zs_rocm_allocator;
+ZS_ROCM_EXPORT zs_rocm_allocator *allocator(int memsrc, int8_t devid);
+ZS_ROCM_EXPORT void del_allocator(zs_rocm_allocator *);
+ZS_ROCM_EXPORT int mem_enum__host(void);
+ZS_ROCM_EXPORT int mem_enum__device(void);
+ZS_ROCM_EXPORT int mem_enum__um(void);
+
+/* py_interop/VectorInstantiations.cpp:8-80: zs::Vector<T> (container/Vector.hpp:11-421) */
+#define ZS_ROCM_DECL_VECTOR(T)                                                                    \
+  typedef struct zs_rocm_vector_##T zs_rocm_vector_##T;                                           \
+  ZS_ROCM_EXPORT zs_rocm_vector_##T *container__v_##T(zs_rocm_allocator *, size_t n);             \
+  ZS_ROCM_EXPORT void del_container__v_##T(zs_rocm_vector_##T *);                                 \
+  ZS_ROCM_EXPORT void relocate_container__v_##T(zs_rocm_vector_##T *, int memsrc, int8_t devid);  \
+  ZS_ROCM_EXPORT void resize_container__v_##T(zs_rocm_vector_##T *, size_t n);                    \
+  ZS_ROCM_EXPORT void reset_container__v_##T(zs_rocm_vector_##T *, int byteVal);                  \
+  ZS_ROCM_EXPORT size_t container_size__v_##T(const zs_rocm_vector_##T *);                        \
+  ZS_ROCM_EXPORT size_t container_capacity__v_##T(const zs_rocm_vector_##T *);                    \
+  ZS_ROCM_EXPORT T get_val_container__v_##T(zs_rocm_vector_##T *, size_t i);                      \
+  ZS_ROCM_EXPORT void set_val_container__v_##T(zs_rocm_vector_##T *, size_t i, T v);              \
+  ZS_ROCM_EXPORT T *container_data__v_##T(zs_rocm_vector_##T *);
+ZS_ROCM_DECL_VECTOR(int)
+ZS_ROCM_DECL_VECTOR(float)
+ZS_ROCM_DECL_VECTOR(double)
+
+/* ======================================================================== (A) TileVector */
+/* py_interop/TileVectorInstantiations.cpp:8-110: property tags + zs::TileVector<T, L>
+ * (container/TileVector.hpp:14-561).  Storage: element (chn, i) at (i/L*C + chn)*L + i%L. */
+typedef struct zs_rocm_property_tags zs_rocm_property_tags;
+ZS_ROCM_EXPORT zs_rocm_property_tags *property_tags(const char *const *names, const int *sizes, size_t n);
+ZS_ROCM_EXPORT void del_property_tags(zs_rocm_property_tags *);
+#define ZS_ROCM_DECL_TILEVECTOR(T, L)                                                                      \
+  typedef struct zs_rocm_tv_##T##_##L zs_rocm_tv_##T##_##L;                                                \
+  ZS_ROCM_EXPORT zs_rocm_tv_##T##_##L *container__tv_##T##_##L(zs_rocm_allocator *,                        \
+                                                              const zs_rocm_property_tags *, size_t n);   \
+  ZS_ROCM_EXPORT void del_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *);                                 \
+  ZS_ROCM_EXPORT void relocate_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, int memsrc, int8_t devid);  \
+  ZS_ROCM_EXPORT void resize_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, size_t n);                    \
+  ZS_ROCM_EXPORT void reset_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, int byteVal);                  \
+  ZS_ROCM_EXPORT size_t container_size__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                        \
+  ZS_ROCM_EXPORT size_t container_capacity__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                    \
+  ZS_ROCM_EXPORT size_t container_num_channels__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                \
+  ZS_ROCM_EXPORT int property_offset__tv_##T##_##L(const zs_rocm_tv_##T##_##L *, const char *name);        \
+  ZS_ROCM_EXPORT int property_size__tv_##T##_##L(const zs_rocm_tv_##T##_##L *, const char *name);          \
+  ZS_ROCM_EXPORT T *container_data__tv_##T##_##L(zs_rocm_tv_##T##_##L *);                                  \
+  ZS_ROCM_EXPORT aosoa_iterator_##T##_1 get_iterator_1__tv_##T##_##L(zs_rocm_tv_##T##_##L *, uint32_t id,  \
+                                                                     uint32_t chnOffset);                 \
+  /* py_interop/cuda/TileVectorUtility.cpp:7-30 -> append_channels (TileVector.hpp:583-623) */            \
+  ZS_ROCM_EXPORT void append_properties__rocm_tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *,       \
+                                                          const zs_rocm_property_tags *);                 \
+  /* (B) TileVector::reset(pol, val) TileVector.hpp:624-640 */                                            \
+  ZS_ROCM_EXPORT void zs_rocm_fill__tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *, T val);         \
+  /* (B) TileVector::reorderTiles-style element reorder (TileVector.hpp:641-691): dst(:, i) = src(:, map[i]) \
+     when gather != 0, dst(:, map[i]) = src(:, i) otherwise; all channels */                              \
+  ZS_ROCM_EXPORT void zs_rocm_reorder__tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *,              \
+                                                   const int *map, int gather);
+ZS_ROCM_DECL_TILEVECTOR(int, 8)
+ZS_ROCM_DECL_TILEVECTOR(int, 32)
+ZS_ROCM_DECL_TILEVECTOR(int, 64)
+ZS_ROCM_DECL_TILEVECTOR(int, 512)
+ZS_ROCM_DECL_TILEVECTOR(float, 8)
+ZS_ROCM_DECL_TILEVECTOR(float, 32)
+ZS_ROCM_DECL_TILEVECTOR(float, 64)
+ZS_ROCM_DECL_TILEVECTOR(float, 512)
+ZS_ROCM_DECL_TILEVECTOR(double, 8)
+ZS_ROCM_DECL_TILEVECTOR(double, 32)
+ZS_ROCM_DECL_TILEVECTOR(double, 64)
+ZS_ROCM_DECL_TILEVECTOR(double, 512)
+
+/* (B) raw AoSoA kernels on plain device pointers (what `pol(range(n), [tv = view<space>(tv)](i){...})`
+ * load/store lambdas do, test/cuda/basic.cu:118-144).  tv has C channels of tile width L (power of 2). */
+ZS_ROCM_EXPORT void zs_rocm_tv_from_aos_f32(zs_rocm_policy *, const float *aos, size_t n, int C, int L, float *tv);
+ZS_ROCM_EXPORT void zs_rocm_tv_to_aos_f32(zs_rocm_policy *, const float *tv, size_t n, int C, int L, float *aos);
+/* load every channel, scale by `alpha`, store back (BASELINE config 2 "AoSoA load/store": 8*C bytes/element) */
+ZS_ROCM_EXPORT void zs_rocm_tv_scale_f32(zs_rocm_policy *, float *tv, size_t n, int C, int L, float alpha);
+ZS_ROCM_EXPORT void zs_rocm_tv_gather_f32(zs_rocm_policy *, const float *src, float *dst, size_t n, int C, int L, const int *map);
+
+/* ======================================================================== (A) bht */
+/* py_interop/BhtInstantiations.cpp:6-128: zs::bht<int, dim, int, 16> (container/Bht.hpp:16-272).
+ * Table layout identical to the reference: keys [tableSize] of next_2pow(dim) ints (unused/padding
+ * ints hold 0x3f3f3f3f), indices [tableSize], status [tableSize] (all -1 outside of a build),
+ * activeKeys [tableSize][dim], cnt, buildSuccess; tableSize = evaluateTableSize(n) (Bht.hpp:154-158);
+ * hash functions seeded from std::mt19937(2) (Bht.hpp:165-169). */
+typedef struct {
+  void *keys;       /* storage_key_type* */
+  int *indices;
+  int *status;
+  void *activeKeys; /* key_type* */
+  int *cnt;
+  int *success;
+  size_t tableSize;
+  uint32_t hf0x, hf0y, hf1x, hf1y, hf2x, hf2y;
+} zs_rocm_bht_view_lite; /* py_interop/BhtView.hpp:96-111 (BhtViewLite) */
+#define ZS_ROCM_DECL_BHT(D)                                                                              \
+  typedef struct zs_rocm_bht_##D zs_rocm_bht_##D;                                                        \
+  ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_16(zs_rocm_allocator *, size_t n);        \
+  ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_16(zs_rocm_bht_##D *);                            \
+  ZS_ROCM_EXPORT size_t container_size__bht_int_##D##_int_16(const zs_rocm_bht_##D *);                   \
+  ZS_ROCM_EXPORT size_t container_capacity__bht_int_##D##_int_16(const zs_rocm_bht_##D *);               \
+  ZS_ROCM_EXPORT void reset_container__bht_int_##D##_int_16(zs_rocm_bht_##D *, int clearCnt);            \
+  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_16(zs_rocm_bht_##D *);                 \
+  ZS_ROCM_EXPORT void del_pyview__bht_int_##D##_int_16(zs_rocm_bht_view_lite *);                         \
+  /* py_interop/cuda/BhtUtility.cpp:7-26 -> bht::resize (Bht.hpp:320-340) */                            \
+  ZS_ROCM_EXPORT void resize_container__rocm_bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,   \
+                                                                 size_t newCapacity);                   \
+  /* (B) pol(range(n), [tb](i){ ret[i] = tb.insert(keys[i]); })  BHTView::insert, Bht.hpp:490-542 */     \
+  ZS_ROCM_EXPORT void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,          \
+                                                          const int *keys, size_t n, int *ret);         \
+  /* (B) pol(range(n), [tb](i){ ret[i] = tb.query(keys[i]); })  BHTView::query, Bht.hpp:667-698 */       \
+  ZS_ROCM_EXPORT void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *, const zs_rocm_bht_##D *,     \
+                                                         const int *keys, size_t n, int *ret);          \
+  /* (B) bht::reorder(pol, map, scatter|gather), Bht.hpp:377-400 */                                      \
+  ZS_ROCM_EXPORT void zs_rocm_reorder__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,         \
+                                                           const int *map, int scatter);                \
+  /* (B) canonical form for bit-exact comparison (SURVEY.md 8a note): sort active keys               \
+     lexicographically and renumber */                                                                  \
+  ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *);
+ZS_ROCM_DECL_BHT(1)
+ZS_ROCM_DECL_BHT(2)
+ZS_ROCM_DECL_BHT(3)
+
+/* ======================================================================== (B) MPM transfers */
+/* A particle attribute stored in an AoS zs::Vector<vec<T,N>> (geometry/Structurefree.hpp:21-237) or in
+ * a TileVector channel group: component d of particle i lives at
+ *   base + ((((i >> numTileBits) * numChns) << numTileBits) | (i & tileMask)) + d * (tileMask + 1)
+ * (py_interop/GenericIterator.hpp:95-101). */
+typedef aosoa_iterator_float_1 zs_rocm_attr;
+
+typedef struct {
+  zs_rocm_attr mass;  /* 1 */
+  zs_rocm_attr pos;   /* 3 */
+  zs_rocm_attr vel;   /* 3 */
+  zs_rocm_attr C;     /* 9, column-major */
+  zs_rocm_attr F;     /* 9, column-major */
+  zs_rocm_attr logJp; /* 1, plastic models only (base may be NULL otherwise) */
+  size_t n;
+} zs_rocm_particles;
+
+enum { ZS_MPM_FIXED_COROTATED = 0, ZS_MPM_DRUCKER_PRAGER = 1 };
+typedef struct {
+  int model;          /* FixedCorotatedConfig | DruckerPragerConfig (physics/ConstitutiveModel.hpp:739-757) */
+  float dx, dt;
+  float volume, E, nu;
+  float cohesion, beta, yieldSurface;
+  int volCorrection;
+  int side;           /* grid block side: 4 = Grids<f32,3,4> (geometry/Structure.hpp), 8 = SparseGrid<3,f32,8> */
+} zs_rocm_mpm_params;
+
+/* grid: TileVector<f32, side^3> with 7 channels {m:1, v:3, rhs:3} (simulation/mpm/Simulator.cpp:116-122),
+ * block b channel c cell k at grid[(b*7 + c)*side^3 + k], cell id = (x*side + y)*side + z
+ * (geometry/Structure.hpp:323-333).  The partition is a bht<int,3,int,16> keyed by block coordinate
+ * (cell coordinate / side), block number = table index. */
+
+/* pol(range(n), ComputeSparsity{dx, side, table, X}) (sparsity/SparsityOp.hpp:59-87) */
+ZS_ROCM_EXPORT void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n,
+                                                 float dx, int side);
+/* pol(range(nblocks), EnlargeSparsity{table, lo, hi}) (sparsity/SparsityOp.hpp:89-115) */
+ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3]);
+
+/* particle -> block binning (the role of IndexBuckets / SpatiallyCount+Distribute,
+ * sparsity/SparsityOp.hpp:117-196, simulation/particle/Query.tpp:9-58): computes for every block the
+ * range [blockStart[b], blockStart[b+1]) of a permutation `order` listing the particles whose base node
+ * (floor(x/dx - 0.5)) lies in block b, arranged round-robin over the block's cells so that
+ * consecutive lanes hit distinct grid nodes.  order: [n], blockStart: [nblocks+1] device ints. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_bin_particles(zs_rocm_policy *, const zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n,
+                                              float dx, int side, int *order, int *blockStart);
+/* nbr[b][8]: block numbers of b + {0,1}^3 (x-major), -1 when absent */
+ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr);
+
+/* pol(range(n), P2GTransfer{apic, dt, model, particles, table, grids})
+ * (simulation/transfer/P2G.hpp:27-132, cuda/simulation/transfer/P2G.hpp:13-123).
+ * blockStart/nbr == NULL: particle-order path (hash query + global float atomics per node);
+ * otherwise the binned path (particles physically ordered by `order` of zs_rocm_mpm_bin_particles):
+ * one workgroup per block accumulates in LDS and flushes once. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_p2g(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
+                                    const zs_rocm_bht_3 *, float *grid, const int *blockStart, const int *nbr);
+/* pol(Collapse{nblocks, side^3}, ComputeGridBlockVelocity{grids, dt, extf, maxVel})
+ * (simulation/grid/GridOp.hpp:71-108).  maxVelSqr may be NULL. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_grid_update(zs_rocm_policy *, const zs_rocm_mpm_params *, float *grid, size_t nblocks,
+                                            const float extf[3], float *maxVelSqr);
+/* pol(range(n), G2PTransfer{apic, dt, model, grids, table, particles}) (simulation/transfer/G2P.hpp:24-90) */
+ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
+                                    const zs_rocm_bht_3 *, const float *grid, const int *blockStart, const int *nbr);
+/* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
+ * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, float *F, float *logJp, size_t n, float *PF);
+ZS_ROCM_EXPORT void zs_rocm_svd3(zs_rocm_policy *, const float *F, size_t n, float *U, float *S, float *V);
+
+/* ghost-block halo exchange helpers for the multi-GPU domain decomposition (no reference counterpart:
+ * zpc has no collective layer).  pack: buf[i][c][k] = grid[blocks[i]][chn0+c][k];
+ * unpack_add / unpack_set the reverse. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_halo_pack(zs_rocm_policy *, const float *grid, const int *blocks, size_t nb, int side,
+                                          int chn0, int nchn, float *buf);
+ZS_ROCM_EXPORT void zs_rocm_mpm_halo_unpack(zs_rocm_policy *, float *grid, const int *blocks, size_t nb, int side,
+                                            int chn0, int nchn, const float *buf, int add);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZS_ROCM_H */

@@ -1,0 +1,187 @@
+"""GPU parity: zs::reduce / exclusive_scan / inclusive_scan / radix_sort(_pair) through the C ABI vs the CPU
+oracle (SequentialExecutionPolicy semantics).  Integers bit-exact; floats with the reference test's own
+relative tolerance 1e-6 scaled by the condition of the sum (test/utils/parallel_primitives.hpp:27-31)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import rng
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+# sizes of the reference's own reduce test (test/parallel_primitives.cpp:24) + tile-edge cases
+SIZES = [1, 2, 7, 16, 128, 1024, 4095, 4096, 4097, 65537, 2_000_000]
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def c_int(x):
+    return C.c_int(int(x))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_reduce_int_matches_serial_fold(pol, oracle, n):
+    import zpc_amd as zs
+    g = rng(1)
+    a = g.integers(-2**30, 2**30, n, dtype=np.int32)
+    d = dev(a)
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for op, name in ((zs.plus, "sum"), (zs.getmin, "min"), (zs.getmax, "max"), (zs.multiplies, "prod")):
+        zs.reduce(pol, d, None, out, op=op)
+        exp = np.zeros(1, np.int32)
+        getattr(oracle, "orc_reduce_%s_i32" % name)(a.ctypes.data_as(C.c_void_p), C.c_size_t(n), exp.ctypes.data_as(C.c_void_p))
+        assert int(out.item()) == int(exp[0]), (name, n)
+
+
+@pytest.mark.parametrize("n", [1, 7, 1024, 65537, 1_000_000])
+def test_reduce_i64_f32_f64(pol, oracle, n):
+    import zpc_amd as zs
+    g = rng(2)
+    a64 = g.integers(-2**40, 2**40, n, dtype=np.int64)
+    out = torch.zeros(1, dtype=torch.int64, device="cuda")
+    zs.reduce(pol, dev(a64), None, out)
+    assert int(out.item()) == int(a64.sum())
+    for dt, tdt, tol in ((np.float32, torch.float32, 1e-6), (np.float64, torch.float64, 1e-14)):
+        a = g.standard_normal(n).astype(dt)
+        out = torch.zeros(1, dtype=tdt, device="cuda")
+        zs.reduce(pol, dev(a), None, out)
+        ref = np.sum(a.astype(np.float64))
+        assert abs(float(out.item()) - ref) <= tol * np.sum(np.abs(a.astype(np.float64))) + 1e-30
+        zs.reduce(pol, dev(a), None, out, op=zs.getmax)
+        assert float(out.item()) == float(a.max())
+        zs.reduce(pol, dev(a), None, out, op=zs.getmin)
+        assert float(out.item()) == float(a.min())
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_scan_int_bit_exact(pol, oracle, n):
+    import zpc_amd as zs
+    g = rng(3)
+    a = g.integers(-2**30, 2**30, n, dtype=np.int32)
+    d = dev(a)
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    exp = np.zeros(n, np.int32)
+    zs.exclusive_scan(pol, d, out)
+    oracle.orc_exclusive_scan_sum_i32(a.ctypes.data_as(C.c_void_p), C.c_size_t(n), exp.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out.cpu().numpy(), exp)
+    zs.inclusive_scan(pol, d, out)
+    oracle.orc_inclusive_scan_sum_i32(a.ctypes.data_as(C.c_void_p), C.c_size_t(n), exp.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out.cpu().numpy(), exp)
+    # in place + non-identity init (C++ face: exclusive_scan(pol, first, last, d_first, init))
+    d2 = d.clone()
+    zs.exclusive_scan(pol, d2, d2, init=17)
+    assert np.array_equal(d2.cpu().numpy(), (np.cumsum(np.concatenate([[17], a[:-1]]), dtype=np.int64)).astype(np.int32))
+
+
+@pytest.mark.parametrize("n", [1, 5, 2048, 2049, 300_001])
+def test_scan_i64_f64_f32(pol, oracle, n):
+    import zpc_amd as zs
+    g = rng(4)
+    a = g.integers(-2**40, 2**40, n, dtype=np.int64)
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    zs.inclusive_scan(pol, dev(a), out)
+    assert np.array_equal(out.cpu().numpy(), np.cumsum(a))
+    zs.exclusive_scan(pol, dev(a), out)
+    assert np.array_equal(out.cpu().numpy(), np.cumsum(a) - a)
+    f = g.random(n)
+    outf = torch.empty(n, dtype=torch.float64, device="cuda")
+    zs.inclusive_scan(pol, dev(f), outf)
+    assert np.allclose(outf.cpu().numpy(), np.cumsum(f), rtol=1e-12)
+    f32 = g.random(n).astype(np.float32)
+    outf = torch.empty(n, dtype=torch.float32, device="cuda")
+    zs.exclusive_scan(pol, dev(f32), outf)
+    exp = np.cumsum(f32.astype(np.float64)) - f32
+    assert np.allclose(outf.cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 16, 128, 1024, 4096, 4097, 65537, 1_000_000])
+def test_radix_sort_int_bit_exact(pol, oracle, n):
+    import zpc_amd as zs
+    g = rng(5)
+    a = g.integers(-2**30, 2**30, n, dtype=np.int32)
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    zs.radix_sort(pol, dev(a), out)
+    exp = np.zeros(n, np.int32)
+    oracle.orc_radix_sort_i32(a.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(n), c_int(0), c_int(32))
+    assert np.array_equal(exp, np.sort(a))  # oracle == mathematical definition
+    assert np.array_equal(out.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("variant", ["all_equal", "sorted", "negatives", "dups"])
+def test_radix_sort_variants(pol, oracle, variant):
+    import zpc_amd as zs
+    n = 100_003
+    g = rng(6)
+    a = {"all_equal": np.full(n, 12345, np.int32), "sorted": (np.arange(n, dtype=np.int32) - n // 2),
+         "negatives": -g.integers(0, 2**31 - 1, n, dtype=np.int64).astype(np.int32),
+         "dups": g.integers(-3, 3, n, dtype=np.int32)}[variant]
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    zs.radix_sort(pol, dev(a), out)
+    assert np.array_equal(out.cpu().numpy(), np.sort(a))
+
+
+@pytest.mark.parametrize("n,sbit,ebit", [(1, 0, 32), (1000, 0, 32), (70_001, 0, 32), (70_001, 8, 24), (70_001, 3, 13), (5000, 0, 4), (5000, 31, 32)])
+def test_radix_sort_pair_stable_and_window(pol, oracle, n, sbit, ebit):
+    import zpc_amd as zs
+    g = rng(7)
+    k = g.integers(-50, 50, n, dtype=np.int32) if sbit == 0 and ebit == 32 else g.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    v = np.arange(n, dtype=np.int32)
+    ko = torch.empty(n, dtype=torch.int32, device="cuda")
+    vo = torch.empty(n, dtype=torch.int32, device="cuda")
+    zs.radix_sort_pair(pol, dev(k), dev(v), ko, vo, sbit=sbit, ebit=ebit)
+    ek, ev = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    oracle.orc_radix_sort_pair_i32(k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), ek.ctypes.data_as(C.c_void_p),
+                                   ev.ctypes.data_as(C.c_void_p), C.c_size_t(n), c_int(sbit), c_int(ebit))
+    assert np.array_equal(ko.cpu().numpy(), ek)
+    assert np.array_equal(vo.cpu().numpy(), ev)  # stability: unique permutation
+
+
+@pytest.mark.parametrize("dtype", ["u32", "i64", "u64"])
+def test_radix_sort_other_key_widths(pol, oracle, dtype):
+    import zpc_amd as zs
+    n = 200_001
+    g = rng(8)
+    npdt, tdt, lo, hi = {"u32": (np.uint32, torch.uint32, 0, 2**32), "i64": (np.int64, torch.int64, -2**62, 2**62),
+                         "u64": (np.uint64, torch.uint64, 0, 2**63)}[dtype]
+    k = g.integers(lo, hi, n, dtype=np.int64 if dtype != "u64" else np.uint64).astype(npdt)
+    v = np.arange(n, dtype=np.int32)
+    ko = torch.empty(n, dtype=tdt, device="cuda")
+    vo = torch.empty(n, dtype=torch.int32, device="cuda")
+    zs.radix_sort_pair(pol, dev(k), dev(v), ko, vo)
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(ko.cpu().numpy(), k[order])
+    assert np.array_equal(vo.cpu().numpy(), v[order])
+
+
+def test_tilevector_channel_iterators(pol, oracle):
+    """reduce over the "b" channel of TileVector<int,32>{a:3,b:2,c:1}: the reference's own test
+    (test/parallel_primitives.cpp:7-30, test/utils/initialization.hpp:75-93) through the iterator ABI."""
+    import zpc_amd as zs
+    from zpc_amd.primitives import Iter
+    L_, C_ = 32, 6
+    for n in (1, 2, 7, 16, 128, 1024, 200_000):
+        g = rng(9)
+        tiles = (n + L_ - 1) // L_
+        buf = g.integers(-1000, 1000, tiles * L_ * C_, dtype=np.int32)
+        d = dev(buf)
+        chn = 3  # offset of "b"
+        idx = np.arange(n)
+        vals = buf[(idx // L_ * C_ + chn) * L_ + idx % L_]
+        out = torch.zeros(1, dtype=torch.int32, device="cuda")
+        it = Iter.aosoa(d, 0, L_, chn, C_)
+        zs.reduce(pol, it, n, out, op=zs.plus)
+        assert int(out.item()) == int(vals.sum(dtype=np.int64).astype(np.int32))
+        zs.reduce(pol, it, n, out, op=zs.getmax)
+        assert int(out.item()) == int(vals.max())
+        zs.reduce(pol, it, n, out, op=zs.getmin)
+        assert int(out.item()) == int(vals.min())
+        # scan + sort from the channel iterator into a contiguous vector
+        o = torch.empty(n, dtype=torch.int32, device="cuda")
+        zs.exclusive_scan(pol, it, o, n=n)
+        assert np.array_equal(o.cpu().numpy(), (np.cumsum(vals, dtype=np.int64) - vals).astype(np.int32))
+        zs.radix_sort(pol, it, o, n=n)
+        assert np.array_equal(o.cpu().numpy(), np.sort(vals))

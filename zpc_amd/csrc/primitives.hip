@@ -1,0 +1,628 @@
+// primitives.hip -- zs::reduce / inclusive_scan / exclusive_scan / radix_sort(_pair) for gfx950.
+//
+// Replaces the cub calls of CudaExecutionPolicy (cuda/execution/ExecutionPolicy.cuh:560-867):
+//   reduce      two-level: 16-byte vector loads, wave64 shuffle tree, LDS across the 4 waves of a
+//               block, <= 2048 partials, one finishing block.                       4 B/elem (i32)
+//   scan        single pass, decoupled look-back (Merrill & Garland) over 4096-element tiles:
+//               tiles take a dynamic ticket (no dispatch-order assumption), publish
+//               {status,value} as ONE 8-byte agent-scope store (write-through, no fence needed;
+//               guide G16 "R2 granule"), wave 0 looks back 64 tiles at a time.        8 B/elem (i32)
+//   radix sort  8-bit LSD passes on the bit window [sbit, ebit); signed keys are ordered by
+//               XOR-ing the sign bit inside the digit extraction (execution/ExecutionPolicy.hpp:
+//               485-490) so no copy-in/copy-out kernels exist (the reference spends 4 extra
+//               kernels + 4 temp vectors on that, ExecutionPolicy.cuh:794-820); the first pass
+//               reads the caller's iterator and the last pass writes the caller's iterator.
+//               Per pass: tile histogram -> scan of (digit, tile) counts -> stable scatter with
+//               wave-level multisplit ranking (ballot match) + per-wave LDS digit counters.
+// All kernels address memory through `Port`s (py_interop/GenericIterator.hpp:88-104), so Vector,
+// AoS and TileVector-channel iterators take the same path.
+#include <algorithm>
+#include <limits>
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace zsr {
+
+template <int OP, class T> __host__ __device__ __forceinline__ T combine(T a, T b) {
+  if constexpr (std::is_integral_v<T> && (OP == OP_PLUS || OP == OP_MUL)) {
+    using U = std::make_unsigned_t<T>;  // wrap-around, no signed-overflow UB
+    if constexpr (OP == OP_PLUS) return (T)((U)a + (U)b);
+    else return (T)((U)a * (U)b);
+  } else
+    return apply<OP>(a, b);
+}
+
+template <int OP, class T> constexpr T identity_of() {
+  if constexpr (OP == OP_PLUS) return (T)0;
+  else if constexpr (OP == OP_MUL) return (T)1;
+  else if constexpr (OP == OP_MIN) return std::numeric_limits<T>::max();
+  else return std::numeric_limits<T>::lowest();
+}
+
+template <int OP, class T> __device__ __forceinline__ T wave_reduce(T v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = combine<OP>(v, shfl_down(v, d));
+  return v;  // lane 0 holds the result
+}
+
+// ======================================================================================= reduce
+constexpr int RED_BLOCK = 256;
+constexpr int RED_MAX_BLOCKS = 2048;  // 256 CUs x 8 blocks (guide G11)
+
+template <int OP, class T> __device__ __forceinline__ T block_reduce(T v) {
+  __shared__ T sm[RED_BLOCK / 64];
+  v = wave_reduce<OP>(v);
+  if (lane_id() == 0) sm[wave_id()] = v;
+  __syncthreads();
+  T r = identity_of<OP, T>();
+  if (threadIdx.x < RED_BLOCK / 64) r = sm[threadIdx.x];
+  if (wave_id() == 0) {
+#pragma unroll
+    for (int d = RED_BLOCK / 128; d > 0; d >>= 1) r = combine<OP>(r, shfl_down(r, d));
+  }
+  return r;  // thread 0
+}
+
+template <int OP, class T, bool VEC>
+__global__ __launch_bounds__(RED_BLOCK) void reduce_partial_kernel(Port<const T> in, size_t n, T *partials) {
+  T acc = identity_of<OP, T>();
+  const size_t tid = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * RED_BLOCK;
+  if constexpr (VEC) {  // contiguous + 16-byte aligned: 16 B per lane per load
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T v[V]; };
+    const Vec *p = reinterpret_cast<const Vec *>(in.base + in.idx);
+    const size_t nv = n / V;
+    for (size_t i = tid; i < nv; i += nthreads) {
+      Vec x = p[i];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc = combine<OP>(acc, x.v[j]);
+    }
+    for (size_t i = nv * V + tid; i < n; i += nthreads) acc = combine<OP>(acc, in[i]);
+  } else {
+    for (size_t i = tid; i < n; i += nthreads) acc = combine<OP>(acc, in[i]);
+  }
+  acc = block_reduce<OP>(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+template <int OP, class T>
+__global__ __launch_bounds__(RED_BLOCK) void reduce_final_kernel(const T *partials, int np, T init, Port<T> out) {
+  T acc = identity_of<OP, T>();
+  for (int i = threadIdx.x; i < np; i += RED_BLOCK) acc = combine<OP>(acc, partials[i]);
+  acc = block_reduce<OP>(acc);
+  if (threadIdx.x == 0) out[0] = combine<OP>(init, acc);
+}
+
+template <int OP, class T> static void reduce_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
+  size_t perBlock = (size_t)RED_BLOCK * (64 / sizeof(T));  // 64 B per thread per grid-stride round
+  int nb = (int)std::min<size_t>(RED_MAX_BLOCKS, std::max<size_t>(1, (n + perBlock - 1) / perBlock));
+  T *partials = (T *)L.temp(sizeof(T) * RED_MAX_BLOCKS);
+  const bool vec = in.contiguous() && (((uintptr_t)(in.base + in.idx)) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((reduce_partial_kernel<OP, T, true>), dim3(nb), dim3(RED_BLOCK), 0, L.stream, in, n, partials);
+  else
+    hipLaunchKernelGGL((reduce_partial_kernel<OP, T, false>), dim3(nb), dim3(RED_BLOCK), 0, L.stream, in, n, partials);
+  hipLaunchKernelGGL((reduce_final_kernel<OP, T>), dim3(1), dim3(RED_BLOCK), 0, L.stream, (const T *)partials, nb, init, out);
+}
+
+template <class T> static void reduce_dispatch(Launch &L, Port<const T> in, size_t n, Port<T> out, T init, int op) {
+  switch (op) {
+    case OP_PLUS: reduce_impl<OP_PLUS>(L, in, n, out, init); break;
+    case OP_MUL: reduce_impl<OP_MUL>(L, in, n, out, init); break;
+    case OP_MIN: reduce_impl<OP_MIN>(L, in, n, out, init); break;
+    default: reduce_impl<OP_MAX>(L, in, n, out, init); break;
+  }
+}
+
+// ======================================================================================= scan
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ROWS = 4;
+enum : unsigned { ST_INVALID = 0, ST_AGG = 1, ST_PREFIX = 2 };
+
+// tile descriptor storage.  4-byte values: one packed u64 {status<<32 | bits}.  8-byte values: a flag
+// word plus separate aggregate / prefix slots, value written through and drained before the flag.
+template <class T, int W = sizeof(T)> struct Desc;
+template <class T> struct Desc<T, 4> {
+  unsigned long long *d;
+  static size_t bytes(size_t tiles) { return tiles * 8; }
+  __host__ __device__ explicit Desc(void *p, size_t) : d((unsigned long long *)p) {}
+  __device__ __forceinline__ void publish(size_t tile, unsigned st, T v) const {
+    unsigned bits;
+    __builtin_memcpy(&bits, &v, 4);
+    __hip_atomic_store(&d[tile], ((unsigned long long)st << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ unsigned poll(size_t tile, T &v) const {
+    unsigned long long x = __hip_atomic_load(&d[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned bits = (unsigned)x;
+    __builtin_memcpy(&v, &bits, 4);
+    return (unsigned)(x >> 32);
+  }
+};
+template <class T> struct Desc<T, 8> {
+  unsigned *flag;
+  unsigned long long *agg, *pre;
+  static size_t bytes(size_t tiles) { return tiles * 24; }
+  __host__ __device__ explicit Desc(void *p, size_t tiles)
+      : flag((unsigned *)p + 0), agg((unsigned long long *)p + tiles), pre((unsigned long long *)p + 2 * tiles) {}
+  // layout: [tiles x u64 region used for flags (first 4 B of each 8)] [agg] [pre]; flags indexed densely
+  __device__ __forceinline__ void publish(size_t tile, unsigned st, T v) const {
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &v, 8);
+    __hip_atomic_store(st == ST_AGG ? &agg[tile] : &pre[tile], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // value is at the coherence point before the flag
+    __hip_atomic_store(&flag[tile], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ unsigned poll(size_t tile, T &v) const {
+    unsigned st = __hip_atomic_load(&flag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st != ST_INVALID) {
+      unsigned long long bits =
+          __hip_atomic_load(st == ST_AGG ? &agg[tile] : &pre[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_memcpy(&v, &bits, 8);
+    }
+    return st;
+  }
+};
+
+template <int OP, class T, bool EXCL>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(Port<const T> in, Port<T> out, size_t n, T init, void *descMem,
+                                                          size_t numTiles, unsigned *ticket) {
+  constexpr int V = 16 / sizeof(T);
+  constexpr int ROWW = SCAN_BLOCK * V;       // elements per row
+  constexpr int TILE = ROWW * SCAN_ROWS;     // 4096 (4-byte) / 2048 (8-byte)
+  constexpr int NW = SCAN_BLOCK / 64;
+  const T ident = identity_of<OP, T>();
+  Desc<T> desc(descMem, numTiles);
+
+  __shared__ unsigned sTile;
+  __shared__ T sWave[SCAN_ROWS][NW];
+  __shared__ T sTilePrefix;
+  if (threadIdx.x == 0) sTile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const size_t tile = sTile;
+  const size_t tileBase = tile * (size_t)TILE;
+  const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+
+  // ---- load: row k, thread t holds V consecutive elements at tileBase + k*ROWW + t*V
+  T x[SCAN_ROWS][V];
+  const bool full = tileBase + TILE <= n;
+  const bool vec = in.contiguous() && (((uintptr_t)(in.base + in.idx)) % 16 == 0);
+#pragma unroll
+  for (int k = 0; k < SCAN_ROWS; ++k) {
+    const size_t e0 = tileBase + (size_t)k * ROWW + (size_t)t * V;
+    if (full && vec) {
+      struct alignas(16) Vec { T v[V]; };
+      Vec q = *reinterpret_cast<const Vec *>(in.base + in.idx + e0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) x[k][j] = q.v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) x[k][j] = (e0 + j < n) ? in[e0 + j] : ident;
+    }
+  }
+  // ---- thread-local inclusive scan per row, wave scan of the row totals
+  T inc[SCAN_ROWS];  // inclusive scan over lanes of thread totals
+  T tot[SCAN_ROWS];
+#pragma unroll
+  for (int k = 0; k < SCAN_ROWS; ++k) {
+#pragma unroll
+    for (int j = 1; j < V; ++j) x[k][j] = combine<OP>(x[k][j - 1], x[k][j]);
+    tot[k] = x[k][V - 1];
+    T s = tot[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      T o = shfl_up(s, d);
+      if (lane >= d) s = combine<OP>(o, s);
+    }
+    inc[k] = s;
+    if (lane == 63) sWave[k][w] = s;
+  }
+  __syncthreads();
+  // ---- exclusive prefix of (row k, wave w) in row-major order + tile aggregate (16 LDS broadcasts)
+  T base[SCAN_ROWS];
+  T run = ident;
+#pragma unroll
+  for (int k = 0; k < SCAN_ROWS; ++k) {
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      if (ww == w) base[k] = run;
+      run = combine<OP>(run, sWave[k][ww]);
+    }
+  }
+  const T aggregate = run;
+  // ---- decoupled look-back by wave 0
+  if (w == 0) {
+    if (tile == 0) {
+      if (lane == 0) {
+        desc.publish(0, ST_PREFIX, aggregate);
+        sTilePrefix = ident;
+      }
+    } else {
+      if (lane == 0) desc.publish(tile, ST_AGG, aggregate);
+      T running = ident;
+      long long pred = (long long)tile - 1 - lane;
+      while (true) {
+        T v = ident;
+        unsigned st = ST_PREFIX;  // before the first tile: prefix = identity
+        if (pred >= 0) st = desc.poll((size_t)pred, v);
+        if (__any(st == ST_INVALID)) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        unsigned long long pm = __ballot(st == ST_PREFIX);
+        if (pm) {
+          int first = __ffsll((long long)pm) - 1;  // nearest predecessor holding an inclusive prefix
+          T c = lane <= first ? v : ident;
+          c = wave_reduce<OP>(c);
+          running = combine<OP>(running, shfl(c, 0));
+          break;
+        }
+        T c = wave_reduce<OP>(v);
+        running = combine<OP>(running, shfl(c, 0));
+        pred -= 64;
+      }
+      if (lane == 0) {
+        desc.publish(tile, ST_PREFIX, combine<OP>(running, aggregate));
+        sTilePrefix = running;
+      }
+    }
+  }
+  __syncthreads();
+  const T tp = EXCL ? combine<OP>(init, sTilePrefix) : sTilePrefix;
+  // ---- write
+#pragma unroll
+  for (int k = 0; k < SCAN_ROWS; ++k) {
+    T lanePrev = shfl_up(inc[k], 1);
+    if (lane == 0) lanePrev = ident;
+    const T pfx = combine<OP>(tp, combine<OP>(base[k], lanePrev));  // everything before this thread's V elements
+    T y[V];
+    if constexpr (EXCL) {
+      y[0] = pfx;
+#pragma unroll
+      for (int j = 1; j < V; ++j) y[j] = combine<OP>(pfx, x[k][j - 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) y[j] = combine<OP>(pfx, x[k][j]);
+    }
+    const size_t e0 = tileBase + (size_t)k * ROWW + (size_t)t * V;
+    const bool ovec = out.contiguous() && (((uintptr_t)(out.base + out.idx)) % 16 == 0);
+    if (full && ovec) {
+      struct alignas(16) Vec { T v[V]; };
+      Vec q;
+#pragma unroll
+      for (int j = 0; j < V; ++j) q.v[j] = y[j];
+      *reinterpret_cast<Vec *>(out.base + out.idx + e0) = q;
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (e0 + j < n) out[e0 + j] = y[j];
+    }
+  }
+}
+
+template <int OP, class T, bool EXCL> static void scan_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
+  if (n == 0) return;
+  constexpr size_t TILE = (size_t)SCAN_BLOCK * (16 / sizeof(T)) * SCAN_ROWS;
+  const size_t numTiles = (n + TILE - 1) / TILE;
+  const size_t dbytes = Desc<T>::bytes(numTiles);
+  char *mem = (char *)L.temp(dbytes + 256);
+  ZSR_CHECK(hipMemsetAsync(mem, 0, dbytes + 256, L.stream));  // descriptors + ticket re-initialised every call
+  unsigned *ticket = (unsigned *)(mem + dbytes);
+  hipLaunchKernelGGL((scan_kernel<OP, T, EXCL>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                     (void *)mem, numTiles, ticket);
+}
+
+template <class T>
+static void scan_dispatch(Launch &L, Port<const T> in, size_t n, Port<T> out, T init, int op, bool excl) {
+  // the reference's scans are only instantiated for plus / multiplies through the C ABI; min/max are
+  // reachable through the C++ face (any associative op)
+  switch (op) {
+    case OP_PLUS: excl ? scan_impl<OP_PLUS, T, true>(L, in, n, out, init) : scan_impl<OP_PLUS, T, false>(L, in, n, out, init); break;
+    case OP_MUL: excl ? scan_impl<OP_MUL, T, true>(L, in, n, out, init) : scan_impl<OP_MUL, T, false>(L, in, n, out, init); break;
+    case OP_MIN: excl ? scan_impl<OP_MIN, T, true>(L, in, n, out, init) : scan_impl<OP_MIN, T, false>(L, in, n, out, init); break;
+    default: excl ? scan_impl<OP_MAX, T, true>(L, in, n, out, init) : scan_impl<OP_MAX, T, false>(L, in, n, out, init); break;
+  }
+}
+
+// internal entry used by other translation units (bht canonicalisation, MPM binning)
+void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out) {
+  scan_impl<OP_PLUS, unsigned, true>(L, contiguous_port<const unsigned>(in), n, contiguous_port<unsigned>(out), 0u);
+}
+
+// ======================================================================================= radix sort
+constexpr int RS_BLOCK = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_BLOCK * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_NW = RS_BLOCK / 64;
+
+template <class K> struct KeyBits {
+  using U = std::make_unsigned_t<K>;
+  static constexpr U flip = std::is_signed_v<K> ? (U)((U)1 << (sizeof(K) * 8 - 1)) : (U)0;
+  __device__ __forceinline__ static unsigned digit(K k, int st, unsigned mask) {
+    return (unsigned)((((U)k) ^ flip) >> st) & mask;
+  }
+};
+
+// position of (wave w, item k, lane l) inside a tile: w*(64*ITEMS) + k*64 + l -> coalesced and order preserving
+template <class K>
+__global__ __launch_bounds__(RS_BLOCK) void radix_hist_kernel(Port<const K> keys, size_t n, int st, unsigned mask,
+                                                              unsigned *counts, unsigned numTiles) {
+  __shared__ unsigned hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    size_t i = base + (size_t)k * 64;
+    if (i < n) atomicAdd(&hist[KeyBits<K>::digit(keys[i], st, mask)], 1u);
+  }
+  __syncthreads();
+  counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];  // digit-major for the scan
+}
+
+template <class K, bool PAIR>
+__global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(Port<const K> kin, Port<const int> vin, Port<K> kout,
+                                                                 Port<int> vout, size_t n, int st, unsigned mask,
+                                                                 const unsigned *offsets, unsigned numTiles) {
+  __shared__ unsigned cnt[RS_NW][256];  // per-wave digit counters, then per-wave exclusive offsets
+  __shared__ unsigned gbase[256];
+  const int lane = lane_id(), w = wave_id();
+#pragma unroll
+  for (int i = 0; i < RS_NW; ++i) cnt[i][threadIdx.x] = 0;
+  gbase[threadIdx.x] = offsets[(size_t)threadIdx.x * numTiles + blockIdx.x];
+  __syncthreads();
+
+  K key[RS_ITEMS];
+  int val[RS_ITEMS];
+  unsigned rank[RS_ITEMS];
+  const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS) + lane;
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    size_t i = base + (size_t)k * 64;
+    if (i < n) {
+      key[k] = kin[i];
+      if constexpr (PAIR) val[k] = vin[i];
+    }
+  }
+  volatile unsigned *wc = cnt[w];
+  const unsigned long long lt = lanemask_lt();
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const bool valid = base + (size_t)k * 64 < n;
+    const unsigned d = valid ? KeyBits<K>::digit(key[k], st, mask) : 0u;
+    // lanes of this wave holding the same digit (multisplit by 8 ballots)
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    unsigned old = 0;
+    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+    if (valid && lane == leader) {
+      old = wc[d];
+      wc[d] = old + (unsigned)__popcll(peers);
+    }
+    old = shfl(old, leader);
+    rank[k] = old + (unsigned)__popcll(peers & lt);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {  // per digit: exclusive prefix over the waves of this tile
+    unsigned run = 0;
+#pragma unroll
+    for (int i = 0; i < RS_NW; ++i) {
+      unsigned c = cnt[i][threadIdx.x];
+      cnt[i][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    if (base + (size_t)k * 64 < n) {
+      const unsigned d = KeyBits<K>::digit(key[k], st, mask);
+      const size_t dst = (size_t)gbase[d] + cnt[w][d] + rank[k];
+      kout[dst] = key[k];
+      if constexpr (PAIR) vout[dst] = val[k];
+    }
+  }
+}
+
+template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> kin, Port<const int> vin, Port<K> kout,
+                                                                Port<int> vout, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    kout[i] = kin[i];
+    if constexpr (PAIR) vout[i] = vin[i];
+  }
+}
+
+template <class K, bool PAIR>
+static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, Port<K> kout, Port<int> vout, size_t n,
+                            int sbit, int ebit) {
+  if (n == 0) return;
+  if (sbit < 0) sbit = 0;
+  if (ebit > (int)sizeof(K) * 8) ebit = (int)sizeof(K) * 8;
+  const int passes = ebit > sbit ? (ebit - sbit + 7) / 8 : 0;
+  if (passes == 0) {
+    hipLaunchKernelGGL((radix_copy_kernel<K, PAIR>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, kin, vin, kout, vout, n);
+    return;
+  }
+  if (passes == 1 && (const void *)kin.base == (const void *)kout.base) {
+    // single pass with output aliasing the input: sort into a temporary, then copy (the reference always
+    // stages through temporaries, so in-place calls are legal there)
+    K *tmpK = (K *)L.temp(sizeof(K) * n);
+    int *tmpV = PAIR ? (int *)L.temp(sizeof(int) * n) : nullptr;
+    radix_sort_impl<K, PAIR>(L, kin, vin, contiguous_port<K>(tmpK), contiguous_port<int>(tmpV), n, sbit, ebit);
+    hipLaunchKernelGGL((radix_copy_kernel<K, PAIR>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream,
+                       contiguous_port<const K>(tmpK), contiguous_port<const int>(tmpV), kout, vout, n);
+    return;
+  }
+  const unsigned numTiles = ceil_div(n, RS_TILE);
+  unsigned *counts = (unsigned *)L.temp(sizeof(unsigned) * 256 * (size_t)numTiles);
+  K *tk[2] = {nullptr, nullptr};
+  int *tv[2] = {nullptr, nullptr};
+  const int ntemp = passes >= 3 ? 2 : passes - 1;
+  for (int i = 0; i < ntemp; ++i) {
+    tk[i] = (K *)L.temp(sizeof(K) * n);
+    if (PAIR) tv[i] = (int *)L.temp(sizeof(int) * n);
+  }
+  Port<const K> srcK = kin;
+  Port<const int> srcV = vin;
+  for (int p = 0; p < passes; ++p) {
+    const int st = sbit + 8 * p;
+    const int bits = std::min(8, ebit - st);  // narrowed last pass (execution/ExecutionPolicy.hpp:493-496)
+    const unsigned mask = (1u << bits) - 1u;
+    Port<K> dstK = kout;
+    Port<int> dstV = vout;
+    if (p != passes - 1) {
+      // temporaries alternate so that a pass never writes the buffer it reads
+      int which = p & 1;
+      dstK = contiguous_port<K>(tk[which]);
+      if (PAIR) dstV = contiguous_port<int>(tv[which]);
+    }
+    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, n, st, mask, counts, numTiles);
+    exclusive_scan_u32(L, counts, 256 * (size_t)numTiles, counts);
+    hipLaunchKernelGGL((radix_scatter_kernel<K, PAIR>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, srcV, dstK, dstV, n,
+                       st, mask, (const unsigned *)counts, numTiles);
+    srcK = Port<const K>{dstK.base, dstK.idx, dstK.bits, dstK.mask, dstK.chns};
+    if (PAIR) srcV = Port<const int>{dstV.base, dstV.idx, dstV.bits, dstV.mask, dstV.chns};
+  }
+}
+
+// internal entry for other translation units
+void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit,
+                         int ebit) {
+  radix_sort_impl<unsigned, true>(L, contiguous_port<const unsigned>(kin), contiguous_port<const int>(vin),
+                                  contiguous_port<unsigned>(kout), contiguous_port<int>(vout), n, sbit, ebit);
+}
+void radix_sort_pair_u64(Launch &L, const unsigned long long *kin, const int *vin, unsigned long long *kout, int *vout,
+                         size_t n, int sbit, int ebit) {
+  radix_sort_impl<unsigned long long, true>(L, contiguous_port<const unsigned long long>(kin),
+                                            contiguous_port<const int>(vin), contiguous_port<unsigned long long>(kout),
+                                            contiguous_port<int>(vout), n, sbit, ebit);
+}
+
+template <class K>
+static void radix_sort_api(zs_rocm_policy *pol, const K *kin, const int *vin, K *kout, int *vout, size_t n, int sbit, int ebit) {
+  Launch L(pol, "radix_sort");
+  if (vin && vout)
+    radix_sort_impl<K, true>(L, contiguous_port<const K>(kin), contiguous_port<const int>(vin), contiguous_port<K>(kout),
+                             contiguous_port<int>(vout), n, sbit, ebit);
+  else
+    radix_sort_impl<K, false>(L, contiguous_port<const K>(kin), Port<const int>{}, contiguous_port<K>(kout), Port<int>{}, n,
+                              sbit, ebit);
+}
+
+}  // namespace zsr
+
+using namespace zsr;
+
+// ======================================================================================= C ABI
+extern "C" {
+
+// ---- (A) py_interop/cuda/ExecutionPolicy.cpp:41-131
+#define ZSR_DEFINE_PRIMITIVES(T)                                                                                   \
+  void reduce_sum__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                           \
+                                aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {                   \
+    Launch L(pol, "reduce_sum");                                                                                   \
+    reduce_impl<OP_PLUS, T>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)0);  \
+  }                                                                                                                \
+  void reduce_prod__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                          \
+                                 aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {                  \
+    Launch L(pol, "reduce_prod");                                                                                  \
+    reduce_impl<OP_MUL, T>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)1); \
+  }                                                                                                                \
+  void reduce_min__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                           \
+                                aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {                   \
+    Launch L(pol, "reduce_min");                                                                                   \
+    reduce_impl<OP_MIN, T>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out),        \
+                           std::numeric_limits<T>::max());                                                         \
+  }                                                                                                                \
+  void reduce_max__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                           \
+                                aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {                   \
+    Launch L(pol, "reduce_max");                                                                                   \
+    reduce_impl<OP_MAX, T>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out),        \
+                           std::numeric_limits<T>::lowest());                                                      \
+  }                                                                                                                \
+  void exclusive_scan_sum__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                   \
+                                        aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {           \
+    Launch L(pol, "exclusive_scan_sum");                                                                           \
+    scan_impl<OP_PLUS, T, true>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)0); \
+  }                                                                                                                \
+  void exclusive_scan_prod__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                  \
+                                         aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {          \
+    Launch L(pol, "exclusive_scan_prod");                                                                          \
+    scan_impl<OP_MUL, T, true>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)1); \
+  }                                                                                                                \
+  void inclusive_scan_sum__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                   \
+                                        aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {           \
+    Launch L(pol, "inclusive_scan_sum");                                                                           \
+    scan_impl<OP_PLUS, T, false>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)0); \
+  }                                                                                                                \
+  void inclusive_scan_prod__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_const_##T##_1 first,                  \
+                                         aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {          \
+    Launch L(pol, "inclusive_scan_prod");                                                                          \
+    scan_impl<OP_MUL, T, false>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)1); \
+  }
+
+ZSR_DEFINE_PRIMITIVES(int)
+ZSR_DEFINE_PRIMITIVES(float)
+ZSR_DEFINE_PRIMITIVES(double)
+
+// radix sort: integral T only; for float/double the reference instantiates an empty body
+// (py_interop/cuda/ExecutionPolicy.cpp:112-126, `if constexpr (is_integral_v<T>)`)
+void radix_sort__rocm_int_1(zs_rocm_policy *pol, aosoa_iterator_int_1 first, aosoa_iterator_int_1 last,
+                            aosoa_iterator_int_1 out) {
+  Launch L(pol, "radix_sort");
+  radix_sort_impl<int, false>(L, make_port<const int>(first), Port<const int>{}, make_port<int>(out), Port<int>{},
+                              (size_t)(last.idx - first.idx), 0, 32);
+}
+void radix_sort_pair__rocm_int_1(zs_rocm_policy *pol, aosoa_iterator_int_1 keysIn, aosoa_iterator_int_1 valsIn,
+                                 aosoa_iterator_int_1 keysOut, aosoa_iterator_int_1 valsOut, size_t count) {
+  Launch L(pol, "radix_sort_pair");
+  radix_sort_impl<int, true>(L, make_port<const int>(keysIn), make_port<const int>(valsIn), make_port<int>(keysOut),
+                             make_port<int>(valsOut), count, 0, 32);
+}
+void radix_sort__rocm_float_1(zs_rocm_policy *, aosoa_iterator_float_1, aosoa_iterator_float_1, aosoa_iterator_float_1) {}
+void radix_sort_pair__rocm_float_1(zs_rocm_policy *, aosoa_iterator_float_1, aosoa_iterator_int_1, aosoa_iterator_float_1,
+                                   aosoa_iterator_int_1, size_t) {}
+void radix_sort__rocm_double_1(zs_rocm_policy *, aosoa_iterator_double_1, aosoa_iterator_double_1, aosoa_iterator_double_1) {}
+void radix_sort_pair__rocm_double_1(zs_rocm_policy *, aosoa_iterator_double_1, aosoa_iterator_int_1,
+                                    aosoa_iterator_double_1, aosoa_iterator_int_1, size_t) {}
+
+// ---- (B)
+#define ZSR_DEFINE_RAW(T, S)                                                                                      \
+  void zs_rocm_reduce_##S(zs_rocm_policy *pol, const T *in, size_t n, T *out, T init, int op) {                   \
+    Launch L(pol, "reduce");                                                                                      \
+    reduce_dispatch<T>(L, contiguous_port<const T>(in), n, contiguous_port<T>(out), init, op);                    \
+  }                                                                                                               \
+  void zs_rocm_scan_##S(zs_rocm_policy *pol, const T *in, size_t n, T *out, T init, int op, int exclusive) {      \
+    Launch L(pol, exclusive ? "exclusive_scan" : "inclusive_scan");                                               \
+    scan_dispatch<T>(L, contiguous_port<const T>(in), n, contiguous_port<T>(out), init, op, exclusive != 0);      \
+  }
+ZSR_DEFINE_RAW(int32_t, i32)
+ZSR_DEFINE_RAW(int64_t, i64)
+ZSR_DEFINE_RAW(float, f32)
+ZSR_DEFINE_RAW(double, f64)
+
+void zs_rocm_radix_sort_i32(zs_rocm_policy *p, const int32_t *kin, const int32_t *vin, int32_t *kout, int32_t *vout,
+                            size_t n, int sbit, int ebit) {
+  radix_sort_api<int32_t>(p, kin, vin, kout, vout, n, sbit, ebit);
+}
+void zs_rocm_radix_sort_u32(zs_rocm_policy *p, const uint32_t *kin, const int32_t *vin, uint32_t *kout, int32_t *vout,
+                            size_t n, int sbit, int ebit) {
+  radix_sort_api<uint32_t>(p, kin, vin, kout, vout, n, sbit, ebit);
+}
+void zs_rocm_radix_sort_i64(zs_rocm_policy *p, const int64_t *kin, const int32_t *vin, int64_t *kout, int32_t *vout,
+                            size_t n, int sbit, int ebit) {
+  radix_sort_api<int64_t>(p, kin, vin, kout, vout, n, sbit, ebit);
+}
+void zs_rocm_radix_sort_u64(zs_rocm_policy *p, const uint64_t *kin, const int32_t *vin, uint64_t *kout, int32_t *vout,
+                            size_t n, int sbit, int ebit) {
+  radix_sort_api<uint64_t>(p, kin, vin, kout, vout, n, sbit, ebit);
+}
+
+}  // extern "C"
