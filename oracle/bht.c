@@ -145,7 +145,7 @@ static int32_t insert_impl(orc_bht *t, const int32_t *key, int32_t insertion_ind
       if (insertion_index == -1) localno = t->cnt++;
       t->indices[bucketOffset + (size_t)load] = localno;
       if (enqueue) memcpy(t->activeKeys + (size_t)localno * (size_t)t->dim, key, (size_t)t->dim * 4);
-      if ((size_t)localno + 20 >= t->tableSize) { /* proximity guard :522-526 */
+      if ((uint32_t)localno >= (uint32_t)((uint32_t)t->tableSize - 20u)) { /* proximity guard :522-526, u32 arithmetic (size_type = make_unsigned<Index>, :30) */
         t->success = 0;
         localno = INT32_MIN;
       }

@@ -1,0 +1,99 @@
+"""GPU parity for bht<int, dim, int, 16>: set-exact against the CPU oracle (sequential insertion), byte-exact
+after canonicalisation (SURVEY.md 8a note), hash constants pinned, heavy same-key contention."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import rng
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_table(oracle, dim, keys, nexp):
+    oracle.orc_bht_create.restype = C.c_void_p
+    oracle.orc_bht_size.restype = C.c_int32
+    oracle.orc_bht_get_table_size.restype = C.c_size_t
+    oracle.orc_bht_active_keys.restype = C.POINTER(C.c_int32)
+    t = C.c_void_p(oracle.orc_bht_create(dim, C.c_size_t(nexp)))
+    oracle.orc_bht_insert_many(t, keys.ctypes.data_as(C.c_void_p), C.c_size_t(keys.shape[0]), None)
+    n = oracle.orc_bht_size(t)
+    act = np.ctypeslib.as_array(oracle.orc_bht_active_keys(t), shape=(n, dim)).copy()
+    return t, n, act
+
+
+def _d2h(ptr, nbytes):
+    out = np.empty(nbytes // 4, np.int32)
+    C.CDLL("libamdhip64.so").hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2)
+    return out
+
+
+@pytest.mark.parametrize("dim,n,span", [(3, 4096, 32), (3, 200_000, 40), (2, 50_000, 300), (1, 30_000, 20_000), (3, 1, 5), (3, 100_000, 2)])
+def test_build_query_set_exact(pol, oracle, dim, n, span):
+    from zpc_amd.containers import Bht
+    g = rng(20 + dim)
+    keys = g.integers(-span, span, (n, dim), dtype=np.int32)
+    tab = Bht(dim, n)
+    t, on, oact = _oracle_table(oracle, dim, keys, n)
+    assert tab.tableSize() == oracle.orc_bht_get_table_size(t)
+    v = tab.view()
+    hp = (C.c_uint32 * 6)()
+    oracle.orc_bht_hash_params(hp)
+    assert [v.hf0x, v.hf0y, v.hf1x, v.hf1y, v.hf2x, v.hf2y] == list(hp) == [1872583848, 794921487, 111352301, 4000937544, 2360782358, 4070471979]
+    dk = torch.from_numpy(keys).cuda()
+    ret = torch.empty(n, dtype=torch.int32, device="cuda")
+    tab.insert(pol, dk.data_ptr(), n, ret.data_ptr())
+    assert tab.size() == on
+    r = ret.cpu().numpy()
+    # exactly one inserter per distinct key got a dense index, everyone else sentinel_v (-1)
+    won = r[r >= 0]
+    assert won.size == on and np.array_equal(np.sort(won), np.arange(on))
+    act = _d2h(tab.view().activeKeys, on * dim * 4).reshape(on, dim)
+    assert set(map(tuple, act)) == set(map(tuple, oact))
+    assert np.array_equal(act[r[r >= 0]], keys[r >= 0])  # activeKeys[index] == key for the winners
+    # query: present keys -> index with activeKeys[i] == k ; absent -> -1
+    q = np.concatenate([keys[: min(n, 5000)], g.integers(span + 1, span + 50, (500, dim), dtype=np.int32)])
+    qr = torch.empty(q.shape[0], dtype=torch.int32, device="cuda")
+    tab.query(pol, torch.from_numpy(q).cuda().data_ptr(), q.shape[0], qr.data_ptr())
+    qr = qr.cpu().numpy()
+    npres = min(n, 5000)
+    assert (qr[:npres] >= 0).all() and np.array_equal(act[qr[:npres]], q[:npres])
+    assert (qr[npres:] == -1).all()
+    # status words all -1, padding ints untouched (reference table format)
+    tsz = tab.tableSize()
+    assert (_d2h(tab.view().status, tsz * 4) == -1).all()
+    if dim == 3:
+        raw = _d2h(tab.view().keys, tsz * 16).reshape(tsz, 4)
+        assert (raw[:, 3] == 0x3f3f3f3f).all()
+        filled = raw[(raw[:, :3] != 0x3f3f3f3f).any(axis=1)][:, :3]
+        assert filled.shape[0] == on and len(set(map(tuple, filled))) == on  # no duplicate slots
+    # canonical form is byte-identical to canonicalised oracle numbering
+    tab.canonicalize(pol)
+    act2 = _d2h(tab.view().activeKeys, on * dim * 4).reshape(on, dim)
+    order = np.lexsort(tuple(oact[:, d] for d in range(dim - 1, -1, -1)))
+    assert np.array_equal(act2, oact[order])
+    tab.query(pol, torch.from_numpy(act2.copy()).cuda().data_ptr(), on, ret.data_ptr())
+    assert np.array_equal(ret.cpu().numpy()[:on], np.arange(on))
+    oracle.orc_bht_destroy(t)
+
+
+def test_resize_and_reset(pol, oracle):
+    from zpc_amd.containers import Bht
+    g = rng(29)
+    keys = g.integers(-20, 20, (3000, 3), dtype=np.int32)
+    tab = Bht(3, 3000)
+    dk = torch.from_numpy(keys).cuda()
+    tab.insert(pol, dk.data_ptr(), 3000)
+    n0 = tab.size()
+    act0 = _d2h(tab.view().activeKeys, n0 * 12).reshape(n0, 3)
+    tab.resize(pol, 100_000)
+    oracle.orc_bht_table_size.restype = C.c_size_t
+    assert tab.tableSize() == oracle.orc_bht_table_size(C.c_size_t(100_000)) and tab.size() == n0
+    ret = torch.empty(n0, dtype=torch.int32, device="cuda")
+    tab.query(pol, torch.from_numpy(act0.copy()).cuda().data_ptr(), n0, ret.data_ptr())
+    assert np.array_equal(ret.cpu().numpy(), np.arange(n0))  # indices preserved (Bht.hpp:320-340)
+    tab.reset(True)
+    assert tab.size() == 0
+    tab.query(pol, dk.data_ptr(), 100, ret.data_ptr())
+    assert (ret.cpu().numpy()[:100] == -1).all()

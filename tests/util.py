@@ -40,3 +40,77 @@ def orc_call(oracle, name, *args):
         else:
             conv.append(a)
     return f(*conv)
+
+
+# ---------------------------------------------------------------------------------------- oracle MPM helpers
+class OrcMpmParams(C.Structure):
+    _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
+                ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
+                ("volCorrection", C.c_int), ("side", C.c_int), ("nthreads", C.c_int)]
+
+
+YIELD_SURFACE = 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5)  # DruckerPragerConfig default
+
+
+def make_cloud(n_side, dx, ppc_side=2, origin=(0.30, 0.31, 0.29), seed=3, noise=0.01, vel_scale=0.5):
+    """Jittered lattice of particles: ppc_side^3 particles per cell in an n_side^3-cell cube."""
+    g = rng(seed)
+    k = n_side * ppc_side
+    idx = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)
+    h = dx / ppc_side
+    pos = (np.asarray(origin) + (idx + 0.5) * h + (g.random(idx.shape) - 0.5) * h * 0.8).astype(np.float32)
+    n = pos.shape[0]
+    vel = (vel_scale * g.standard_normal((n, 3))).astype(np.float32)
+    F = (np.eye(3).reshape(1, 9) + noise * g.standard_normal((n, 9))).astype(np.float32)
+    Cm = (0.1 * g.standard_normal((n, 9))).astype(np.float32)
+    mass = np.full(n, 1000.0 * dx ** 3 / ppc_side ** 3, np.float32)
+    return mass, pos, vel, Cm, F
+
+
+class OracleMpm:
+    """Drives oracle/mpm.c + oracle/bht.c: the CPU restatement of partition build, P2G, grid update, G2P."""
+
+    def __init__(self, oracle, model, dx, dt, side, volume, E=5e4, nu=0.4, nthreads=1, cohesion=0.0, beta=1.0):
+        self.o = oracle
+        self.p = OrcMpmParams(model, dx, dt, volume, E, nu, cohesion, beta, YIELD_SURFACE, 1, side, nthreads)
+        self.side = side
+        self.o.orc_bht_create.restype = C.c_void_p
+        self.o.orc_bht_active_keys.restype = C.POINTER(C.c_int32)
+        self.o.orc_bht_size.restype = C.c_int32
+        self.table = None
+
+    def build_partition(self, pos, expected_blocks):
+        n = pos.shape[0]
+        self.table = C.c_void_p(self.o.orc_bht_create(3, C.c_size_t(expected_blocks)))
+        self.o.orc_mpm_build_partition(self.table, ptr(pos), C.c_size_t(n), C.c_float(self.p.dx), self.side)
+        self.nblocks = self.o.orc_bht_size(self.table)
+        keys = np.ctypeslib.as_array(self.o.orc_bht_active_keys(self.table), shape=(self.nblocks, 3)).copy()
+        self.keys = keys
+        self.grid = np.zeros((self.nblocks, 7, self.side ** 3), np.float32)
+        return self.nblocks
+
+    def p2g(self, mass, pos, vel, Cm, F, logJp=None):
+        n = pos.shape[0]
+        lj = np.zeros(n, np.float32) if logJp is None else logJp
+        self.o.orc_mpm_p2g(C.byref(self.p), self.table, C.c_size_t(n), ptr(mass), ptr(pos), ptr(vel), ptr(Cm), ptr(F), ptr(lj), ptr(self.grid))
+        return lj
+
+    def grid_update(self, extf=(0.0, 0.0, 0.0)):
+        e = (C.c_float * 3)(*extf)
+        mx = C.c_float(0.0)
+        self.o.orc_mpm_grid_update(C.byref(self.p), C.c_size_t(self.nblocks), ptr(self.grid), e, C.byref(mx))
+        return mx.value
+
+    def g2p(self, pos, vel, Cm, F):
+        n = pos.shape[0]
+        self.o.orc_mpm_g2p(C.byref(self.p), self.table, C.c_size_t(n), ptr(pos), ptr(vel), ptr(Cm), ptr(F), ptr(self.grid))
+
+    def grid_by_key(self):
+        return {tuple(int(x) for x in self.keys[i]): self.grid[i] for i in range(self.nblocks)}
+
+    def __del__(self):
+        try:
+            if self.table:
+                self.o.orc_bht_destroy(self.table)
+        except Exception:
+            pass

@@ -74,3 +74,93 @@ def _declare(L):
         getattr(L, "zs_rocm_scan_" + S).argtypes = [vp, vp, sz, vp, ct, i32, i32]
     for S in ("i32", "u32", "i64", "u64"):
         getattr(L, "zs_rocm_radix_sort_" + S).argtypes = [vp, vp, vp, vp, vp, sz, i32, i32]
+
+
+def _declare_containers(L):
+    vp, sz, i32, f32, i8 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int8
+    L.allocator.argtypes = [i32, i8]
+    L.allocator.restype = vp
+    L.del_allocator.argtypes = [vp]
+    L.property_tags.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), sz]
+    L.property_tags.restype = vp
+    L.del_property_tags.argtypes = [vp]
+    for T, ct in (("int", C.c_int), ("float", C.c_float), ("double", C.c_double)):
+        g = lambda n: getattr(L, n % T)
+        g("container__v_%s").argtypes = [vp, sz]
+        g("container__v_%s").restype = vp
+        g("del_container__v_%s").argtypes = [vp]
+        g("relocate_container__v_%s").argtypes = [vp, i32, i8]
+        g("resize_container__v_%s").argtypes = [vp, sz]
+        g("reset_container__v_%s").argtypes = [vp, i32]
+        g("container_size__v_%s").argtypes = [vp]
+        g("container_size__v_%s").restype = sz
+        g("container_capacity__v_%s").argtypes = [vp]
+        g("container_capacity__v_%s").restype = sz
+        g("get_val_container__v_%s").argtypes = [vp, sz]
+        g("get_val_container__v_%s").restype = ct
+        g("set_val_container__v_%s").argtypes = [vp, sz, ct]
+        g("container_data__v_%s").argtypes = [vp]
+        g("container_data__v_%s").restype = vp
+        for Lw in (8, 32, 64, 512):
+            s = "%s_%d" % (T, Lw)
+            h = lambda n: getattr(L, n % s)
+            h("container__tv_%s").argtypes = [vp, vp, sz]
+            h("container__tv_%s").restype = vp
+            h("del_container__tv_%s").argtypes = [vp]
+            h("relocate_container__tv_%s").argtypes = [vp, i32, i8]
+            h("resize_container__tv_%s").argtypes = [vp, sz]
+            h("reset_container__tv_%s").argtypes = [vp, i32]
+            for q in ("container_size__tv_%s", "container_capacity__tv_%s", "container_num_channels__tv_%s"):
+                h(q).argtypes = [vp]
+                h(q).restype = sz
+            h("property_offset__tv_%s").argtypes = [vp, C.c_char_p]
+            h("property_size__tv_%s").argtypes = [vp, C.c_char_p]
+            h("container_data__tv_%s").argtypes = [vp]
+            h("container_data__tv_%s").restype = vp
+            h("get_iterator_1__tv_%s").argtypes = [vp, C.c_uint32, C.c_uint32]
+            h("get_iterator_1__tv_%s").restype = Port
+            h("append_properties__rocm_tv_%s").argtypes = [vp, vp, vp]
+            h("zs_rocm_fill__tv_%s").argtypes = [vp, vp, ct]
+            h("zs_rocm_reorder__tv_%s").argtypes = [vp, vp, vp, i32]
+    L.zs_rocm_tv_from_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_tv_to_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_tv_scale_f32.argtypes = [vp, vp, sz, i32, i32, f32]
+    L.zs_rocm_tv_gather_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+    for D in (1, 2, 3):
+        s = "bht_int_%d_int_16" % D
+        getattr(L, "container__" + s).argtypes = [vp, sz]
+        getattr(L, "container__" + s).restype = vp
+        getattr(L, "del_container__" + s).argtypes = [vp]
+        getattr(L, "container_size__" + s).argtypes = [vp]
+        getattr(L, "container_size__" + s).restype = sz
+        getattr(L, "container_capacity__" + s).argtypes = [vp]
+        getattr(L, "container_capacity__" + s).restype = sz
+        getattr(L, "reset_container__" + s).argtypes = [vp, i32]
+        getattr(L, "pyview__" + s).argtypes = [vp]
+        getattr(L, "pyview__" + s).restype = C.POINTER(BhtViewLite)
+        getattr(L, "del_pyview__" + s).argtypes = [C.POINTER(BhtViewLite)]
+        getattr(L, "resize_container__rocm_" + s).argtypes = [vp, vp, sz]
+        getattr(L, "zs_rocm_insert__" + s).argtypes = [vp, vp, vp, sz, vp]
+        getattr(L, "zs_rocm_query__" + s).argtypes = [vp, vp, vp, sz, vp]
+        getattr(L, "zs_rocm_reorder__" + s).argtypes = [vp, vp, vp, i32]
+        getattr(L, "zs_rocm_canonicalize__" + s).argtypes = [vp, vp]
+    PP = C.POINTER(MpmParams)
+    L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32]
+    L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, vp, vp]
+    L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp]
+    L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, vp, vp]
+    L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
+    L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, vp, vp]
+    L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
+    L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_mpm_halo_pack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp]
+    L.zs_rocm_mpm_halo_unpack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp, i32]
+
+
+_declare_base = _declare
+
+
+def _declare(L):  # noqa: F811
+    _declare_base(L)
+    _declare_containers(L)

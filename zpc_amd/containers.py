@@ -1,0 +1,191 @@
+"""Host mirrors of zs::Vector / zs::TileVector / zs::bht as the reference's ctypes layer sees them
+(include/zensim/py_interop/{Vector,TileVector,Bht}Instantiations.cpp).  Thin handles over the C ABI."""
+import ctypes as C
+
+from ._lib import lib, Port
+
+memsrc_host, memsrc_device, memsrc_um = 0, 1, 2  # memsrc_e (types/Property.h:7)
+_CT = {"int": C.c_int, "float": C.c_float, "double": C.c_double}
+_ES = {"int": 4, "float": 4, "double": 8}
+
+
+class Allocator:
+    """allocator(memsrc_e, ProcID) -- py_interop/Allocator.cpp:5-21"""
+
+    def __init__(self, memsrc=memsrc_device, devid=0):
+        self.memsrc, self.devid = memsrc, devid
+        self._h = lib().allocator(memsrc, devid)
+
+    def __del__(self):
+        try:
+            lib().del_allocator(self._h)
+        except Exception:
+            pass
+
+
+class Vector:
+    """zs::Vector<T> (container/Vector.hpp:11-421) through container__v_T & friends."""
+
+    def __init__(self, dtype, n, alloc=None):
+        self.T = dtype
+        self.alloc = alloc or Allocator()
+        self._h = getattr(lib(), "container__v_" + dtype)(self.alloc._h, n)
+
+    def __del__(self):
+        try:
+            getattr(lib(), "del_container__v_" + self.T)(self._h)
+        except Exception:
+            pass
+
+    def _f(self, name):
+        return getattr(lib(), name % self.T)
+
+    def size(self):
+        return self._f("container_size__v_%s")(self._h)
+
+    def capacity(self):
+        return self._f("container_capacity__v_%s")(self._h)
+
+    def resize(self, n):
+        self._f("resize_container__v_%s")(self._h, n)
+
+    def reset(self, byte):
+        self._f("reset_container__v_%s")(self._h, byte)
+
+    def relocate(self, memsrc, devid):
+        self._f("relocate_container__v_%s")(self._h, memsrc, devid)
+
+    def getVal(self, i=0):
+        return self._f("get_val_container__v_%s")(self._h, i)
+
+    def setVal(self, v, i=0):
+        self._f("set_val_container__v_%s")(self._h, i, v)
+
+    def data(self):
+        return self._f("container_data__v_%s")(self._h)
+
+    def begin(self, idx=0):
+        return Port(self.data(), idx, 0, 0, 1)
+
+
+class TileVector:
+    """zs::TileVector<T, L> (container/TileVector.hpp:14-561) through container__tv_T_L & friends."""
+
+    def __init__(self, dtype, lane_width, tags, n, alloc=None):
+        self.T, self.L = dtype, lane_width
+        self.alloc = alloc or Allocator()
+        self.s = "%s_%d" % (dtype, lane_width)
+        t = self._make_tags(tags)
+        self._h = getattr(lib(), "container__tv_" + self.s)(self.alloc._h, t, n)
+        lib().del_property_tags(t)
+
+    @staticmethod
+    def _make_tags(tags):
+        names = (C.c_char_p * len(tags))(*[k.encode() for k, _ in tags])
+        sizes = (C.c_int * len(tags))(*[v for _, v in tags])
+        return lib().property_tags(names, sizes, len(tags))
+
+    def __del__(self):
+        try:
+            getattr(lib(), "del_container__tv_" + self.s)(self._h)
+        except Exception:
+            pass
+
+    def _f(self, name):
+        return getattr(lib(), name % self.s)
+
+    def size(self):
+        return self._f("container_size__tv_%s")(self._h)
+
+    def capacity(self):
+        return self._f("container_capacity__tv_%s")(self._h)
+
+    def numChannels(self):
+        return self._f("container_num_channels__tv_%s")(self._h)
+
+    def getPropertyOffset(self, name):
+        return self._f("property_offset__tv_%s")(self._h, name.encode())
+
+    def getPropertySize(self, name):
+        return self._f("property_size__tv_%s")(self._h, name.encode())
+
+    def resize(self, n):
+        self._f("resize_container__tv_%s")(self._h, n)
+
+    def reset(self, byte):
+        self._f("reset_container__tv_%s")(self._h, byte)
+
+    def data(self):
+        return self._f("container_data__tv_%s")(self._h)
+
+    def iterator(self, prop_or_chn, idx=0):
+        """get_iterator_1__tv_T_L(v, id, chnOffset) -- TileVectorInstantiations.cpp"""
+        chn = self.getPropertyOffset(prop_or_chn) if isinstance(prop_or_chn, str) else int(prop_or_chn)
+        return self._f("get_iterator_1__tv_%s")(self._h, idx, chn)
+
+    def append_channels(self, pol, tags):
+        t = self._make_tags(tags)
+        self._f("append_properties__rocm_tv_%s")(pol.handle, self._h, t)
+        lib().del_property_tags(t)
+
+    def fill(self, pol, val):
+        self._f("zs_rocm_fill__tv_%s")(pol.handle, self._h, val)
+
+    def reorder(self, pol, map_ptr, gather=True):
+        self._f("zs_rocm_reorder__tv_%s")(pol.handle, self._h, map_ptr, int(gather))
+
+    def nbytes(self):
+        tiles = (self.size() + self.L - 1) // self.L
+        return tiles * self.L * self.numChannels() * _ES[self.T]
+
+
+class Bht:
+    """zs::bht<int, dim, int, 16> (container/Bht.hpp:16-272) through container__bht_int_D_int_16 & friends."""
+
+    def __init__(self, dim, n, alloc=None):
+        self.dim = dim
+        self.alloc = alloc or Allocator()
+        self.s = "bht_int_%d_int_16" % dim
+        self._h = getattr(lib(), "container__" + self.s)(self.alloc._h, n)
+
+    def __del__(self):
+        try:
+            getattr(lib(), "del_container__" + self.s)(self._h)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def size(self):
+        return getattr(lib(), "container_size__" + self.s)(self._h)
+
+    def tableSize(self):
+        return getattr(lib(), "container_capacity__" + self.s)(self._h)
+
+    def reset(self, clear_cnt=True):
+        getattr(lib(), "reset_container__" + self.s)(self._h, int(clear_cnt))
+
+    def view(self):
+        """pyview__bht_...: BhtViewLite (py_interop/BhtView.hpp:96-111); returned as a plain copy."""
+        p = getattr(lib(), "pyview__" + self.s)(self._h)
+        v = type(p.contents)()
+        C.pointer(v)[0] = p.contents
+        getattr(lib(), "del_pyview__" + self.s)(p)
+        return v
+
+    def resize(self, pol, new_capacity):
+        getattr(lib(), "resize_container__rocm_" + self.s)(pol.handle, self._h, new_capacity)
+
+    def insert(self, pol, keys_ptr, n, ret_ptr=None):
+        getattr(lib(), "zs_rocm_insert__" + self.s)(pol.handle, self._h, keys_ptr, n, ret_ptr)
+
+    def query(self, pol, keys_ptr, n, ret_ptr):
+        getattr(lib(), "zs_rocm_query__" + self.s)(pol.handle, self._h, keys_ptr, n, ret_ptr)
+
+    def reorder(self, pol, map_ptr, scatter=False):
+        getattr(lib(), "zs_rocm_reorder__" + self.s)(pol.handle, self._h, map_ptr, int(scatter))
+
+    def canonicalize(self, pol):
+        getattr(lib(), "zs_rocm_canonicalize__" + self.s)(pol.handle, self._h)

@@ -1,0 +1,252 @@
+// bht.hip -- zs::bht<int, dim, int, 16> container handles (py_interop/BhtInstantiations.cpp:6-128,
+// py_interop/cuda/BhtUtility.cpp:7-26) and the bulk insert / query / reorder kernels that replace the
+// `pol(range(n), [tb = view<space>(tab)](i){ tb.insert(key_i); })` idiom of the C++ face.
+#include <random>
+
+#include "bht.hpp"
+
+namespace zsr {
+
+void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
+void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit, int ebit);
+
+static size_t next_2pow(size_t n) {  // math/bit/Bits.h:177-184
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+static size_t evaluate_table_size(size_t entryCnt) {  // Bht.hpp:154-158
+  if (entryCnt == 0) return 0;
+  size_t n = next_2pow(entryCnt) * 2;
+  return n + (BHT_BUCKET - n % BHT_BUCKET);
+}
+
+static void *bht_alloc(const BhtHost &t, size_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (t.memsrc == 2) ZSR_CHECK(hipMallocManaged(&p, bytes));
+  else ZSR_CHECK(hipMalloc(&p, bytes));
+  return p;
+}
+
+static void bht_reset_table(BhtHost &t, hipStream_t s) {  // Table::reset, Bht.hpp:107-112
+  const int ks = t.dim == 1 ? 1 : (t.dim == 2 ? 2 : 4);
+  if (t.tableSize) {
+    ZSR_CHECK(hipMemsetAsync(t.keys, 0x3f, t.tableSize * ks * sizeof(int), s));
+    ZSR_CHECK(hipMemsetAsync(t.status, 0xff, t.tableSize * sizeof(int), s));
+  }
+}
+
+static void bht_create(BhtHost &t, int dim, int memsrc, int8_t devid, size_t n) {
+  t.dim = dim;
+  t.memsrc = memsrc == 0 ? 1 : memsrc;  // a host-resident bht cannot be used by a device policy
+  t.devid = devid;
+  t.tableSize = evaluate_table_size(n);
+  const int ks = dim == 1 ? 1 : (dim == 2 ? 2 : 4);
+  t.keys = (int *)bht_alloc(t, t.tableSize * ks * sizeof(int));
+  t.indices = (int *)bht_alloc(t, t.tableSize * sizeof(int));
+  t.status = (int *)bht_alloc(t, t.tableSize * sizeof(int));
+  t.activeKeys = (int *)bht_alloc(t, t.tableSize * dim * sizeof(int));
+  t.cnt = (int *)bht_alloc(t, sizeof(int));
+  t.success = (int *)bht_alloc(t, sizeof(int));
+  std::mt19937 rng(2);  // Bht.hpp:165-169; universal_hash(std::mt19937&) Bcht.hpp:39-43
+  for (int f = 0; f < 3; ++f) {
+    unsigned hx = (unsigned)(rng() % BHT_PRIME);
+    if (hx < 1) hx = 1;
+    unsigned hy = (unsigned)(rng() % BHT_PRIME);
+    t.hf[2 * f] = hx;
+    t.hf[2 * f + 1] = hy;
+  }
+  ZSR_CHECK(hipMemset(t.cnt, 0, sizeof(int)));
+  int one = 1;
+  ZSR_CHECK(hipMemcpy(t.success, &one, sizeof(int), hipMemcpyHostToDevice));
+  bht_reset_table(t, nullptr);
+  ZSR_CHECK(hipDeviceSynchronize());
+}
+static void bht_destroy(BhtHost &t) {
+  (void)hipFree(t.keys); (void)hipFree(t.indices); (void)hipFree(t.status);
+  (void)hipFree(t.activeKeys); (void)hipFree(t.cnt); (void)hipFree(t.success);
+}
+int bht_size(const BhtHost &t, hipStream_t s) {
+  int n = 0;
+  ZSR_CHECK(hipMemcpyAsync(&n, t.cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+  ZSR_CHECK(hipStreamSynchronize(s));
+  return n;
+}
+
+// ------------------------------------------------------------------------------------ kernels
+template <int DIM> __global__ __launch_bounds__(256) void bht_insert_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int key[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) key[d] = keys[i * DIM + d];
+  int r = bht_insert<DIM>(t, key);
+  if (ret) ret[i] = r;
+}
+template <int DIM> __global__ __launch_bounds__(256) void bht_query_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int key[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) key[d] = keys[i * DIM + d];
+  ret[i] = bht_query<DIM>(t, key);
+}
+// BhtInsertionOp (Bht.hpp:312-318): re-insert activeKeys[i] with fixed index i
+template <int DIM> __global__ __launch_bounds__(256) void bht_reinsert_kernel(BhtDev t, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int key[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) key[d] = t.activeKeys[(size_t)i * DIM + d];
+  bht_insert<DIM>(t, key, i, false);
+}
+// ReorderBht (Bht.hpp:342-375)
+template <int DIM, bool SCATTER>
+__global__ __launch_bounds__(256) void bht_reorder_kernel(BhtDev t, int *orderedKeys, const int *map, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int j = map[i];
+  int key[DIM];
+  const int src = SCATTER ? i : j, dst = SCATTER ? j : i;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    key[d] = t.activeKeys[(size_t)src * DIM + d];
+    orderedKeys[(size_t)dst * DIM + d] = key[d];
+  }
+  int entry = bht_query<DIM, true>(t, key);
+  if (entry != 0x7fffffff) t.indices[entry] = dst;
+  else *t.success = 0;
+}
+__global__ void iota_kernel(int *p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+// gather component d of activeKeys through perm, biased to unsigned order
+template <int DIM> __global__ void bht_gather_comp_kernel(const int *activeKeys, const int *perm, int n, int d, unsigned *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (unsigned)activeKeys[(size_t)perm[i] * DIM + d] ^ 0x80000000u;
+}
+
+template <int DIM> static void bht_insert_many(zs_rocm_policy *pol, BhtHost &t, const int *keys, size_t n, int *ret) {
+  Launch L(pol, "bht_insert");
+  if (!n) return;
+  hipLaunchKernelGGL((bht_insert_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, n, ret);
+}
+template <int DIM> static void bht_query_many(zs_rocm_policy *pol, const BhtHost &t, const int *keys, size_t n, int *ret) {
+  Launch L(pol, "bht_query");
+  if (!n) return;
+  hipLaunchKernelGGL((bht_query_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, n, ret);
+}
+
+// bht::resize (Bht.hpp:320-340)
+template <int DIM> static void bht_resize(zs_rocm_policy *pol, BhtHost &t, size_t newCapacity) {
+  size_t ns = evaluate_table_size(newCapacity);
+  if (ns <= t.tableSize) return;
+  Launch L(pol, "bht_resize");
+  const int n = bht_size(t, L.stream);
+  const int ks = DIM == 1 ? 1 : (DIM == 2 ? 2 : 4);
+  int *oldKeys = t.keys, *oldIdx = t.indices, *oldSt = t.status, *oldActive = t.activeKeys;
+  const size_t oldSize = t.tableSize;
+  t.tableSize = ns;
+  t.keys = (int *)bht_alloc(t, ns * ks * sizeof(int));
+  t.indices = (int *)bht_alloc(t, ns * sizeof(int));
+  t.status = (int *)bht_alloc(t, ns * sizeof(int));
+  t.activeKeys = (int *)bht_alloc(t, ns * DIM * sizeof(int));
+  if (n) ZSR_CHECK(hipMemcpyAsync(t.activeKeys, oldActive, (size_t)n * DIM * sizeof(int), hipMemcpyDeviceToDevice, L.stream));
+  bht_reset_table(t, L.stream);
+  if (n) hipLaunchKernelGGL((bht_reinsert_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), n);
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  (void)oldSize;
+  (void)hipFree(oldKeys); (void)hipFree(oldIdx); (void)hipFree(oldSt); (void)hipFree(oldActive);
+}
+
+// bht::reorder (Bht.hpp:377-400)
+template <int DIM> static void bht_reorder_impl(Launch &L, BhtHost &t, const int *map, bool scatter, int n) {
+  if (!n) return;
+  int *ordered = (int *)bht_alloc(t, t.tableSize * DIM * sizeof(int));
+  if (scatter)
+    hipLaunchKernelGGL((bht_reorder_kernel<DIM, true>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), ordered, map, n);
+  else
+    hipLaunchKernelGGL((bht_reorder_kernel<DIM, false>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), ordered, map, n);
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  (void)hipFree(t.activeKeys);
+  t.activeKeys = ordered;
+}
+
+// canonical numbering: active keys in lexicographic order (component 0 most significant), LSD over components
+template <int DIM> static void bht_canonicalize(zs_rocm_policy *pol, BhtHost &t) {
+  Launch L(pol, "bht_canonicalize");
+  const int n = bht_size(t, L.stream);
+  if (n <= 1) return;
+  int *perm[2] = {(int *)L.temp(sizeof(int) * n), (int *)L.temp(sizeof(int) * n)};
+  unsigned *comp = (unsigned *)L.temp(sizeof(unsigned) * n), *sorted = (unsigned *)L.temp(sizeof(unsigned) * n);
+  hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, perm[0], n);
+  int cur = 0;
+  for (int d = DIM - 1; d >= 0; --d) {
+    hipLaunchKernelGGL((bht_gather_comp_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.activeKeys, perm[cur], n,
+                       d, comp);
+    radix_sort_pair_u32(L, comp, perm[cur], sorted, perm[cur ^ 1], (size_t)n, 0, 32);
+    cur ^= 1;
+  }
+  bht_reorder_impl<DIM>(L, t, perm[cur], /*scatter=*/false, n);  // new key i = old key perm[i]
+}
+
+}  // namespace zsr
+
+using namespace zsr;
+
+extern "C" {
+
+#define ZSR_DEFINE_BHT(D)                                                                                   \
+  zs_rocm_bht_##D *container__bht_int_##D##_int_16(zs_rocm_allocator *a, size_t n) {                        \
+    auto *b = new zs_rocm_bht_##D;                                                                          \
+    bht_create(b->t, D, a ? a->memsrc : 1, a ? a->devid : 0, n);                                            \
+    return b;                                                                                               \
+  }                                                                                                         \
+  void del_container__bht_int_##D##_int_16(zs_rocm_bht_##D *b) {                                            \
+    bht_destroy(b->t);                                                                                      \
+    delete b;                                                                                               \
+  }                                                                                                         \
+  size_t container_size__bht_int_##D##_int_16(const zs_rocm_bht_##D *b) { return (size_t)bht_size(b->t, nullptr); } \
+  size_t container_capacity__bht_int_##D##_int_16(const zs_rocm_bht_##D *b) { return b->t.tableSize; }      \
+  void reset_container__bht_int_##D##_int_16(zs_rocm_bht_##D *b, int clearCnt) { /* Bht.hpp:306-318 */      \
+    bht_reset_table(b->t, nullptr);                                                                         \
+    if (clearCnt) ZSR_CHECK(hipMemsetAsync(b->t.cnt, 0, sizeof(int), nullptr));                             \
+    int one = 1;                                                                                            \
+    ZSR_CHECK(hipMemcpy(b->t.success, &one, sizeof(int), hipMemcpyHostToDevice));                           \
+    ZSR_CHECK(hipDeviceSynchronize());                                                                      \
+  }                                                                                                         \
+  zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_16(zs_rocm_bht_##D *b) {                                 \
+    auto *v = new zs_rocm_bht_view_lite;                                                                    \
+    v->keys = b->t.keys; v->indices = b->t.indices; v->status = b->t.status; v->activeKeys = b->t.activeKeys; \
+    v->cnt = b->t.cnt; v->success = b->t.success; v->tableSize = b->t.tableSize;                            \
+    v->hf0x = b->t.hf[0]; v->hf0y = b->t.hf[1]; v->hf1x = b->t.hf[2]; v->hf1y = b->t.hf[3];                 \
+    v->hf2x = b->t.hf[4]; v->hf2y = b->t.hf[5];                                                             \
+    return v;                                                                                               \
+  }                                                                                                         \
+  void del_pyview__bht_int_##D##_int_16(zs_rocm_bht_view_lite *v) { delete v; }                             \
+  void resize_container__rocm_bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, size_t cap) {   \
+    bht_resize<D>(pol, b->t, cap);                                                                          \
+  }                                                                                                         \
+  void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys,       \
+                                            size_t n, int *ret) {                                           \
+    bht_insert_many<D>(pol, b->t, keys, n, ret);                                                            \
+  }                                                                                                         \
+  void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *pol, const zs_rocm_bht_##D *b, const int *keys,  \
+                                           size_t n, int *ret) {                                            \
+    bht_query_many<D>(pol, b->t, keys, n, ret);                                                             \
+  }                                                                                                         \
+  void zs_rocm_reorder__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *map,       \
+                                             int scatter) {                                                 \
+    Launch L(pol, "bht_reorder");                                                                           \
+    bht_reorder_impl<D>(L, b->t, map, scatter != 0, bht_size(b->t, L.stream));                              \
+  }                                                                                                         \
+  void zs_rocm_canonicalize__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
+    bht_canonicalize<D>(pol, b->t);                                                                         \
+  }
+ZSR_DEFINE_BHT(1)
+ZSR_DEFINE_BHT(2)
+ZSR_DEFINE_BHT(3)
+
+}  // extern "C"

@@ -52,6 +52,12 @@ void report_error(hipError_t e, const char *what, const char *file, int line);
 
 }  // namespace zsr
 
+// ------------------------------------------------------------------------------------ allocator handle
+struct zs_rocm_allocator {
+  int memsrc;    // memsrc_e: 0 host, 1 device, 2 um (types/Property.h:7)
+  int8_t devid;  // ProcID, -1 = host
+};
+
 // ------------------------------------------------------------------------------------ policy
 struct zs_rocm_policy {
   int sync = 1;          // execution/ExecutionPolicy.hpp:125

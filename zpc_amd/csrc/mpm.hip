@@ -1,0 +1,962 @@
+// mpm.hip -- MLS-MPM particle<->grid transfers for gfx950.
+//
+// Replaces, behind include/zs_rocm.h:
+//   ComputeSparsity / EnlargeSparsity        simulation/sparsity/SparsityOp.hpp:59-115
+//   P2GTransfer::operator()                  simulation/transfer/P2G.hpp:51-125 (+ cuda/simulation/transfer/P2G.hpp:38-116)
+//   compute_stress_fixedcorotated / _sand    cuda/physics/ConstitutiveModel.hpp:10-326, math::svd cuda/math/matrix/svd.cuh
+//   ComputeGridBlockVelocity                 simulation/grid/GridOp.hpp:71-108
+//   G2PTransfer::operator()                  simulation/transfer/G2P.hpp:44-83
+//
+// The reference's CUDA P2G issues 27 hash queries + 189 global float atomics per particle.  Here:
+//   * particles are binned by the grid block of their base node (count -> scan -> distribute, the
+//     IndexBuckets idea of simulation/particle/Query.tpp:9-58) and laid out round-robin over the cells
+//     of a block, so the 64 lanes of a wave hit 64 different grid nodes;
+//   * one workgroup per grid block accumulates its particles into an LDS arena of (side+2)^3 nodes x 7
+//     channels with ds_add_f32 (LDS strides padded so that the lane<->cell map is bank-conflict free),
+//     then flushes the arena ONCE to the 2x2x2 neighbouring blocks with global_atomic_add_f32:
+//     3 global atomics per particle instead of 189, zero hash queries (a per-block neighbour table);
+//   * the 3x3 SVD is per-lane scalar VALU (quaternion Jacobi, v_rsq_f32): it is not a dense
+//     contraction, so no MFMA;
+//   * G2P stages the block's velocity arena in LDS once and gathers from there.
+// Algorithmic HBM bytes per particle: P2G 100 B read (+ 7 B grid), G2P 48 B read + 96 B write (+1.5 B grid).
+#include "bht.hpp"
+
+namespace zsr {
+
+void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
+
+// ======================================================================================= small math
+__device__ __forceinline__ float rsq(float x) { return __frsqrt_rn(x); }
+
+#define SVD_GAMMA 5.8284273147583007813f
+#define SVD_CSTAR 0.9238795325112867f
+#define SVD_SSTAR 0.3826834323650898f
+
+// one Jacobi conjugation in the (X,Y) plane of the symmetric matrix S, accumulated into quaternion q=(w,v)
+template <int X, int Y, int Z> __device__ __forceinline__ void jacobi_conj(float (&S)[3][3], float (&q)[4]) {
+  float sh = S[X][Y] * 0.5f;
+  float ch = S[X][X] - S[Y][Y];
+  const bool ok = sh * sh >= 1.e-20f;
+  sh = ok ? sh : 0.f;
+  ch = ok ? ch : 1.f;
+  float sh2 = sh * sh, ch2 = ch * ch;
+  const float w = rsq(sh2 + ch2);
+  sh *= w;
+  ch *= w;
+  const bool fix = ch2 <= SVD_GAMMA * sh2;  // angle too large for the approximation: use pi/8
+  sh = fix ? SVD_SSTAR : sh;
+  ch = fix ? SVD_CSTAR : ch;
+  sh2 = sh * sh;
+  ch2 = ch * ch;
+  const float c = ch2 - sh2, s = 2.f * sh * ch;
+  const float sxx = S[X][X], sxy = S[X][Y], syy = S[Y][Y], sxz = S[X][Z], syz = S[Y][Z];
+  const float t1 = c * sxx + s * sxy, t2 = c * sxy + s * syy;
+  const float t3 = -s * sxx + c * sxy, t4 = -s * sxy + c * syy;
+  S[X][X] = c * t1 + s * t2;
+  S[X][Y] = S[Y][X] = c * t3 + s * t4;
+  S[Y][Y] = -s * t3 + c * t4;
+  S[X][Z] = S[Z][X] = c * sxz + s * syz;
+  S[Y][Z] = S[Z][Y] = -s * sxz + c * syz;
+  const float qw = q[0], qx = q[1 + X], qy = q[1 + Y], qz = q[1 + Z];
+  q[0] = qw * ch - qz * sh;
+  q[1 + X] = qx * ch + qy * sh;
+  q[1 + Y] = qy * ch - qx * sh;
+  q[1 + Z] = qz * ch + qw * sh;
+}
+
+template <int A, int B> __device__ __forceinline__ void cond_swap_cols(float (&rho)[3], float (&Bm)[3][3], float (&Vm)[3][3]) {
+  const bool sw = rho[A] < rho[B];
+  const float ra = rho[A], rb = rho[B];
+  rho[A] = sw ? rb : ra;
+  rho[B] = sw ? ra : rb;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float ba = Bm[r][A], bb = Bm[r][B];
+    Bm[r][A] = sw ? bb : ba;
+    Bm[r][B] = sw ? -ba : bb;
+    const float va = Vm[r][A], vb = Vm[r][B];
+    Vm[r][A] = sw ? vb : va;
+    Vm[r][B] = sw ? -va : vb;
+  }
+}
+
+template <int P, int R> __device__ __forceinline__ void qr_step(float (&Bm)[3][3], float (&Um)[3][3]) {
+  const float a1 = Bm[P][P], a2 = Bm[R][P];
+  const float rho2 = a1 * a1 + a2 * a2;
+  const bool ok = rho2 > 1.e-24f;
+  const float ir = rsq(ok ? rho2 : 1.f);
+  const float c = ok ? a1 * ir : 1.f, s = ok ? a2 * ir : 0.f;
+#pragma unroll
+  for (int col = 0; col < 3; ++col) {
+    const float bp = Bm[P][col], br = Bm[R][col];
+    Bm[P][col] = c * bp + s * br;
+    Bm[R][col] = -s * bp + c * br;
+  }
+#pragma unroll
+  for (int row = 0; row < 3; ++row) {
+    const float up = Um[row][P], ur = Um[row][R];
+    Um[row][P] = c * up + s * ur;
+    Um[row][R] = -s * up + c * ur;
+  }
+}
+
+// A = U diag(S) V^T, column-major 9-vectors; U, V rotations, |S0| >= |S1| >= |S2| (math::svd convention)
+__device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (&Sg)[3], float (&V)[9]) {
+  float S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[i][j] = A[3 * i] * A[3 * j] + A[1 + 3 * i] * A[1 + 3 * j] + A[2 + 3 * i] * A[2 + 3 * j];
+  float q[4] = {1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sweep = 0; sweep < 4; ++sweep) {
+    jacobi_conj<0, 1, 2>(S, q);
+    jacobi_conj<1, 2, 0>(S, q);
+    jacobi_conj<2, 0, 1>(S, q);
+  }
+  const float n = rsq(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
+  float Vm[3][3];
+  Vm[0][0] = 1 - 2 * (y * y + z * z); Vm[0][1] = 2 * (x * y - w * z);     Vm[0][2] = 2 * (x * z + w * y);
+  Vm[1][0] = 2 * (x * y + w * z);     Vm[1][1] = 1 - 2 * (x * x + z * z); Vm[1][2] = 2 * (y * z - w * x);
+  Vm[2][0] = 2 * (x * z - w * y);     Vm[2][1] = 2 * (y * z + w * x);     Vm[2][2] = 1 - 2 * (x * x + y * y);
+  float Bm[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Bm[r][c] = A[r] * Vm[0][c] + A[r + 3] * Vm[1][c] + A[r + 6] * Vm[2][c];
+  float rho[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rho[c] = Bm[0][c] * Bm[0][c] + Bm[1][c] * Bm[1][c] + Bm[2][c] * Bm[2][c];
+  cond_swap_cols<0, 1>(rho, Bm, Vm);
+  cond_swap_cols<0, 2>(rho, Bm, Vm);
+  cond_swap_cols<1, 2>(rho, Bm, Vm);
+  float Um[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  qr_step<0, 1>(Bm, Um);
+  qr_step<0, 2>(Bm, Um);
+  qr_step<1, 2>(Bm, Um);
+  Sg[0] = Bm[0][0]; Sg[1] = Bm[1][1]; Sg[2] = Bm[2][2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      U[r + 3 * c] = Um[r][c];
+      V[r + 3 * c] = Vm[r][c];
+    }
+}
+
+// out = M1 diag(d) M2^T (math/matrix/MatrixUtils.h:26-47)
+__device__ __forceinline__ void mat_diag_matT(float (&out)[9], const float (&m1)[9], const float (&d)[3], const float (&m2)[9]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out[r + 3 * c] = m1[r] * d[0] * m2[c] + m1[r + 3] * d[1] * m2[c + 3] + m1[r + 6] * d[2] * m2[c + 6];
+}
+__device__ __forceinline__ void pft_vol(const float (&P)[9], const float (&F)[9], float volume, float (&PF)[9]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) PF[r + 3 * c] = (P[r] * F[c] + P[r + 3] * F[c + 3] + P[r + 6] * F[c + 6]) * volume;
+}
+
+struct Material {
+  float volume, mu, lam, cohesion, beta, yieldSurface;
+  int volCorrection;
+};
+
+// compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47)
+__device__ __forceinline__ void stress_fixedcorotated(const Material &m, const float (&F)[9], float (&PF)[9]) {
+  float U[9], S[3], V[9];
+  svd3(F, U, S, V);
+  const float J = S[0] * S[1] * S[2];
+  const float smu = 2.f * m.mu, slam = m.lam * (J - 1.f);
+  float Ph[3];
+  Ph[0] = smu * (S[0] - 1.f) + slam * (S[1] * S[2]);
+  Ph[1] = smu * (S[1] - 1.f) + slam * (S[0] * S[2]);
+  Ph[2] = smu * (S[2] - 1.f) + slam * (S[0] * S[1]);
+  float P[9];
+  mat_diag_matT(P, U, Ph, V);
+  pft_vol(P, F, m.volume, PF);
+}
+
+// compute_stress_sand (cuda/physics/ConstitutiveModel.hpp:246-326): Drucker-Prager return mapping in
+// log-strain; F is projected in place, logJp updated.
+__device__ __forceinline__ void stress_sand(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
+  float U[9], S[3], V[9];
+  svd3(F, U, S, V);
+  const float smu = 2.f * m.mu;
+  float eps[3], NS[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = fabsf(S[i]);
+    a = a > 1e-4f ? a : 1e-4f;
+    eps[i] = logf(a) - m.cohesion;
+  }
+  const float sum_eps = eps[0] + eps[1] + eps[2];
+  const float tr = sum_eps + logJp;
+  float eh[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) eh[i] = eps[i] - (tr / 3.f);
+  const float ehn = sqrtf(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
+  bool newF = false;
+  if (tr >= 0.f) {  // case II: cone tip
+    NS[0] = NS[1] = NS[2] = expf(m.cohesion);
+    newF = true;
+    if (m.volCorrection) logJp = m.beta * sum_eps + logJp;
+  } else if (m.mu != 0.f) {
+    logJp = 0.f;
+    const float dg = ehn + (3.f * m.lam + smu) / smu * tr * m.yieldSurface;
+    float H[3];
+    if (dg <= 0.f) {  // case I: inside the cone
+#pragma unroll
+      for (int i = 0; i < 3; ++i) H[i] = eps[i] + m.cohesion;
+    } else {  // case III: onto the cone surface
+#pragma unroll
+      for (int i = 0; i < 3; ++i) H[i] = eps[i] - (dg / ehn) * eh[i] + m.cohesion;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) NS[i] = expf(H[i]);
+    newF = true;
+  }
+  if (newF) mat_diag_matT(F, U, NS, V);
+  const float l0 = logf(NS[0]), l1 = logf(NS[1]), l2 = logf(NS[2]);
+  const float trl = l0 + l1 + l2;
+  float Ph[3];
+  Ph[0] = (smu * l0 + m.lam * trl) / NS[0];
+  Ph[1] = (smu * l1 + m.lam * trl) / NS[1];
+  Ph[2] = (smu * l2 + m.lam * trl) / NS[2];
+  float P[9];
+  mat_diag_matT(P, U, Ph, V);
+  pft_vol(P, F, m.volume, PF);
+}
+
+// ======================================================================================= arena
+// LocalArena<collocated, quadratic> (simulation/Utils.hpp:47-75, InterpolationKernel.hpp:47-55,93-130)
+struct Arena {
+  int corner[3];
+  float lp[3];    // local position * dx
+  float w[3][3];  // w[axis][k]
+};
+__device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Arena &a) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float X = pos[d] / dx;
+    const float fl = floorf(X - 0.5f);
+    a.corner[d] = (int)fl;
+    const float lpn = X - fl;
+    const float d0 = lpn - floorf(lpn - 0.5f);
+    a.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
+    const float d1 = d0 - 1.0f;
+    a.w[d][1] = 0.75f - d1 * d1;
+    const float zz = 0.5f + d1;
+    a.w[d][2] = 0.5f * zz * zz;
+    a.lp[d] = lpn * dx;
+  }
+}
+
+__device__ __forceinline__ int floordiv(int a, int b) { return (a + (a < 0 ? -b + 1 : 0)) / b; }
+
+template <int N> __device__ __forceinline__ void load_attr(const Port<float> &p, size_t i, float (&out)[N]) {
+  const float *b = p.base + p.off(i);
+  const size_t cs = p.cstride();
+#pragma unroll
+  for (int d = 0; d < N; ++d) out[d] = b[d * cs];
+}
+template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p, size_t i, const float (&v)[N]) {
+  float *b = p.base + p.off(i);
+  const size_t cs = p.cstride();
+#pragma unroll
+  for (int d = 0; d < N; ++d) b[d * cs] = v[d];
+}
+
+struct ParticlesDev {
+  Port<float> mass, pos, vel, C, F, logJp;
+  size_t n;
+};
+struct MpmDev {
+  Material mat;
+  int model;
+  float dx, dt;
+};
+
+// per-particle constitutive update -> contrib = -dt * D_inv * (P F^T vol)   (P2G.hpp:60-105)
+template <int MODEL>
+__device__ __forceinline__ void particle_contrib(const MpmDev &mp, const ParticlesDev &ps, size_t i, float D_inv, float (&contrib)[9]) {
+  float F[9];
+  load_attr<9>(ps.F, i, F);
+  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
+    stress_fixedcorotated(mp.mat, F, contrib);
+  } else {
+    float lj = ps.logJp.base[ps.logJp.off(i)];
+    stress_sand(mp.mat, lj, F, contrib);
+    ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back (as in the reference)
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
+}
+
+// ======================================================================================= sparsity
+__global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<float> pos, size_t n, float dxinv, int side) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int b[3] = {0, 0, 0};
+  if (valid) {
+    float p[3];
+    load_attr<3>(pos, i, p);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side);
+  }
+  // neighbouring lanes usually carry the same block: let only the first lane of a run insert (the others
+  // would get sentinel_v back from insert anyway)
+  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
+  const bool pvalid = shfl_up((int)valid, 1) != 0;
+  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
+  if (valid && !dup) bht_insert<3>(t, b);
+}
+__global__ __launch_bounds__(256) void enlarge_sparsity_kernel(BhtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2) {
+  // thread per (block, offset)
+  const int per = e0 * e1 * e2;
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nblocks * per) return;
+  const int i = (int)(g / per), o = (int)(g % per);
+  const int dx = lo0 + o / (e1 * e2), dy = lo1 + (o / e2) % e1, dz = lo2 + o % e2;
+  int k[3] = {t.activeKeys[3 * (size_t)i] + dx, t.activeKeys[3 * (size_t)i + 1] + dy, t.activeKeys[3 * (size_t)i + 2] + dz};
+  bht_insert<3>(t, k);
+}
+__global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nblocks * 8) return;
+  const int i = (int)(g >> 3), o = (int)(g & 7);
+  int k[3] = {t.activeKeys[3 * (size_t)i] + (o >> 2), t.activeKeys[3 * (size_t)i + 1] + ((o >> 1) & 1),
+              t.activeKeys[3 * (size_t)i + 2] + (o & 1)};
+  nbr[g] = bht_query<3>(t, k);
+}
+
+// ======================================================================================= binning
+template <int SIDE>
+__global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> pos, size_t n, float dx, unsigned *cellCount,
+                                                        unsigned *cellOf, unsigned *rankOf, int *err) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[3];
+  load_attr<3>(pos, i, p);
+  int key[3], loc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int c = (int)floorf(p[d] / dx - 0.5f);
+    loc[d] = c & (SIDE - 1);
+    key[d] = (c - loc[d]) / SIDE;
+  }
+  const int b = bht_query<3>(t, key);
+  if (b < 0) {
+    *err = 1;
+    cellOf[i] = 0xffffffffu;
+    return;
+  }
+  const unsigned cell = (unsigned)b * (SIDE * SIDE * SIDE) + (unsigned)((loc[0] * SIDE + loc[1]) * SIDE + loc[2]);
+  cellOf[i] = cell;
+  rankOf[i] = atomicAdd(&cellCount[cell], 1u);
+}
+__global__ __launch_bounds__(256) void bin_place_kernel(size_t n, const unsigned *cellStart, const unsigned *cellOf,
+                                                        const unsigned *rankOf, int *byCell) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned c = cellOf[i];
+  if (c != 0xffffffffu) byCell[cellStart[c] + rankOf[i]] = (int)i;
+}
+// one workgroup (SIDE^3 threads, thread = cell) per grid block: (cell, rank) order -> (rank, cell) order
+template <int SIDE>
+__global__ void bin_roundrobin_kernel(int nblocks, const unsigned *cellStart, const unsigned *cellCount, const int *byCell,
+                                      int *order, int *blockStart, unsigned total) {
+  constexpr int NC = SIDE * SIDE * SIDE, NW = NC / 64;
+  __shared__ unsigned sWave[NW > 1 ? NW : 1];
+  __shared__ unsigned sMax;
+  const int b = blockIdx.x, c = threadIdx.x;
+  const unsigned cnt = cellCount[(size_t)b * NC + c], st = cellStart[(size_t)b * NC + c];
+  const unsigned bstart = cellStart[(size_t)b * NC];
+  if (c == 0) {
+    blockStart[b] = (int)bstart;
+    if (b == nblocks - 1) blockStart[nblocks] = (int)total;
+    sMax = 0;
+  }
+  __syncthreads();
+  atomicMax(&sMax, cnt);
+  __syncthreads();
+  const unsigned maxc = sMax;
+  unsigned base = bstart;
+  const unsigned long long lt = lanemask_lt();
+  for (unsigned r = 0; r < maxc; ++r) {
+    const bool has = cnt > r;
+    const unsigned long long m = __ballot(has);
+    unsigned before = (unsigned)__popcll(m & lt), tot = (unsigned)__popcll(m);
+    if constexpr (NW > 1) {
+      if (lane_id() == 0) sWave[wave_id()] = tot;
+      __syncthreads();
+      unsigned all = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        if (w == wave_id()) before += all;
+        all += sWave[w];
+      }
+      tot = all;
+      __syncthreads();
+    }
+    if (has) order[base + before] = byCell[st + r];
+    base += tot;
+  }
+}
+
+// ======================================================================================= P2G
+// ---- particle-order path: the reference's algorithm (hash query + global float atomics per node), with the
+//      27 queries folded into the <= 8 distinct blocks a stencil can touch.
+template <int SIDE, int MODEL>
+__device__ __forceinline__ void p2g_scatter_global(const MpmDev &mp, const ParticlesDev &ps, size_t i, const BhtDev &t, float *grid,
+                                                   float D_inv) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  float pos[3], vel[3], C[9], contrib[9];
+  load_attr<3>(ps.pos, i, pos);
+  load_attr<3>(ps.vel, i, vel);
+  load_attr<9>(ps.C, i, C);
+  const float mass = ps.mass.base[ps.mass.off(i)];
+  particle_contrib<MODEL>(mp, ps, i, D_inv, contrib);
+  Arena ar;
+  make_arena(mp.dx, pos, ar);
+  int loc[3], key[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    loc[d] = ar.corner[d] & (SIDE - 1);
+    key[d] = (ar.corner[d] - loc[d]) / SIDE;
+  }
+  int blk[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
+    int k[3] = {key[0] + (o >> 2), key[1] + ((o >> 1) & 1), key[2] + (o & 1)};
+    blk[o] = need ? bht_query<3>(t, k) : -1;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int x = loc[0] + a, y = loc[1] + b, z = loc[2] + c;
+        const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+        int bn = blk[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) bn = (o == q) ? blk[q] : bn;
+        if (bn < 0) continue;  // the reference does not check (P2G.hpp:109-110); a valid partition never gets here
+        const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
+        float *g = grid + (size_t)bn * 7 * NC + cell;
+        const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)b * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
+        float W = ar.w[0][a];
+        W *= ar.w[1][b];
+        W *= ar.w[2][c];
+        unsafeAtomicAdd(g, mass * W);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          unsafeAtomicAdd(g + (1 + d) * NC, W * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2)));
+          unsafeAtomicAdd(g + (4 + d) * NC, (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * W);
+        }
+      }
+}
+
+template <int SIDE, int MODEL>
+__global__ __launch_bounds__(256) void p2g_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float dxi = 1.0f / mp.dx;
+  p2g_scatter_global<SIDE, MODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
+}
+
+// ---- binned path
+template <int SIDE> struct ArenaLds {
+  static constexpr int W = SIDE + 2;
+  // strides (in floats).  SIDE 4: a wave's lanes are the 64 cells (x,y,z) of the block; z + 8 y + 52 x maps each
+  // 32-lane group onto 32 distinct banks for any fixed stencil offset.  SIDE 8: rows padded to 12.
+  static constexpr int SY = SIDE == 4 ? 8 : 12;
+  static constexpr int SX = SIDE == 4 ? 52 : W * 12;
+  static constexpr int CH = W * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+
+template <int SIDE> constexpr int binned_wg() { return SIDE == 4 ? 256 : 512; }
+
+template <int SIDE, int MODEL>
+__global__ __launch_bounds__(binned_wg<SIDE>()) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *blockStart,
+                                                         const int *nbr) {
+  using AL = ArenaLds<SIDE>;
+  constexpr int NC = SIDE * SIDE * SIDE, W = AL::W;
+  __shared__ float arena[7 * AL::CH];
+  const int b = blockIdx.x;
+  const int start = blockStart[b], end = blockStart[b + 1];
+  if (start == end) return;  // ghost / empty block: nothing to scatter (uniform exit)
+  for (int k = threadIdx.x; k < 7 * AL::CH; k += blockDim.x) arena[k] = 0.f;
+  const int bk0 = t.activeKeys[3 * (size_t)b] * SIDE, bk1 = t.activeKeys[3 * (size_t)b + 1] * SIDE,
+            bk2 = t.activeKeys[3 * (size_t)b + 2] * SIDE;
+  __syncthreads();
+  const float dxi = 1.0f / mp.dx;
+  const float D_inv = 4.f * dxi * dxi;
+  for (int i = start + (int)threadIdx.x; i < end; i += (int)blockDim.x) {
+    float pos[3];
+    load_attr<3>(ps.pos, (size_t)i, pos);
+    Arena ar;
+    make_arena(mp.dx, pos, ar);
+    const int lx = ar.corner[0] - bk0, ly = ar.corner[1] - bk1, lz = ar.corner[2] - bk2;
+    if ((unsigned)lx >= (unsigned)SIDE || (unsigned)ly >= (unsigned)SIDE || (unsigned)lz >= (unsigned)SIDE) {
+      // particle has left its bin since the last re-binning: exact but slow path
+      p2g_scatter_global<SIDE, MODEL>(mp, ps, (size_t)i, t, grid, D_inv);
+      continue;
+    }
+    float vel[3], C[9], contrib[9];
+    load_attr<3>(ps.vel, (size_t)i, vel);
+    load_attr<9>(ps.C, (size_t)i, C);
+    const float mass = ps.mass.base[ps.mass.off((size_t)i)];
+    particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
+    float *a0 = arena + AL::at(lx, ly, lz);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
+          float Wt = ar.w[0][a];
+          Wt *= ar.w[1][bb];
+          Wt *= ar.w[2][c];
+          float *g = a0 + AL::at(a, bb, c);
+          atomicAdd(g, mass * Wt);  // ds_add_f32
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            atomicAdd(g + (1 + d) * AL::CH, Wt * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2)));
+            atomicAdd(g + (4 + d) * AL::CH, (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * Wt);
+          }
+        }
+  }
+  __syncthreads();
+  // flush: consecutive threads -> consecutive z of one (channel, x, y) row
+  int nb[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)b * 8 + o];
+  for (int k = threadIdx.x; k < 7 * W * W * W; k += blockDim.x) {
+    const int ch = k / (W * W * W), node = k % (W * W * W);
+    const int x = node / (W * W), y = (node / W) % W, z = node % W;
+    const float v = arena[ch * AL::CH + AL::at(x, y, z)];
+    if (v == 0.f) continue;
+    const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+    int bn = nb[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) bn = (o == q) ? nb[q] : bn;
+    if (bn < 0) continue;
+    const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
+    unsafeAtomicAdd(grid + ((size_t)bn * 7 + ch) * NC + cell, v);
+  }
+}
+
+// ======================================================================================= grid update
+template <int SIDE>
+__global__ __launch_bounds__(256) void grid_update_kernel(float *grid, size_t nblocks, float dt, float e0, float e1, float e2,
+                                                          float *maxVelSqr) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float vsq = 0.f;
+  if (g < nblocks * NC) {
+    const size_t b = g / NC, c = g % NC;
+    float *blk = grid + b * 7 * NC + c;
+    float mass = blk[0];
+    if (mass != 0.f) {
+      mass = 1.f / mass;
+      const float v0 = blk[1 * NC] * mass + e0 * dt, v1 = blk[2 * NC] * mass + e1 * dt, v2 = blk[3 * NC] * mass + e2 * dt;
+      blk[1 * NC] = v0;
+      blk[2 * NC] = v1;
+      blk[3 * NC] = v2;
+      vsq = v0 * v0 + v1 * v1 + v2 * v2;
+    }
+  }
+  if (maxVelSqr) {  // atomic_max(maxVel, |v|^2) (GridOp.hpp:103-104): wave max, then one int-ordered atomic
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vsq = fmaxf(vsq, shfl_down(vsq, d));
+    if (lane_id() == 0 && vsq > 0.f) atomicMax((int *)maxVelSqr, __float_as_int(vsq));
+  }
+}
+
+// ======================================================================================= G2P
+template <int SIDE>
+__device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&vel)[3],
+                                           const float (&C)[9]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
+  float oldF[9], tmp[9], F[9];
+  load_attr<9>(ps.F, i, oldF);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+  store_attr<9>(ps.F, i, F);
+  store_attr<3>(ps.pos, i, pos);
+  store_attr<3>(ps.vel, i, vel);
+  store_attr<9>(ps.C, i, C);
+}
+
+template <int SIDE>
+__device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const ParticlesDev &ps, size_t i, const BhtDev &t, const float *grid,
+                                                  float D_inv) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  float pos[3];
+  load_attr<3>(ps.pos, i, pos);
+  Arena ar;
+  make_arena(mp.dx, pos, ar);
+  int loc[3], key[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    loc[d] = ar.corner[d] & (SIDE - 1);
+    key[d] = (ar.corner[d] - loc[d]) / SIDE;
+  }
+  int blk[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
+    int k[3] = {key[0] + (o >> 2), key[1] + ((o >> 1) & 1), key[2] + (o & 1)};
+    blk[o] = need ? bht_query<3>(t, k) : -1;
+  }
+  float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int x = loc[0] + a, y = loc[1] + b, z = loc[2] + c;
+        const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+        int bn = blk[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) bn = (o == q) ? blk[q] : bn;
+        float vi[3] = {0.f, 0.f, 0.f};
+        if (bn >= 0) {
+          const float *g = grid + (size_t)bn * 7 * NC + ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
+          vi[0] = g[1 * NC];
+          vi[1] = g[2 * NC];
+          vi[2] = g[3 * NC];
+        }
+        const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)b * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
+        float W = ar.w[0][a];
+        W *= ar.w[1][b];
+        W *= ar.w[2][c];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) vel[d] += vi[d] * W;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) C[d] += W * vi[d % 3] * xi[d / 3] * D_inv;
+      }
+  g2p_finish<SIDE>(mp, ps, i, pos, vel, C);
+}
+
+template <int SIDE> __global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float dxi = 1.0f / mp.dx;
+  g2p_gather_global<SIDE>(mp, ps, i, t, grid, 4.f * dxi * dxi);
+}
+
+template <int SIDE>
+__global__ __launch_bounds__(binned_wg<SIDE>()) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *blockStart,
+                                                         const int *nbr) {
+  using AL = ArenaLds<SIDE>;
+  constexpr int NC = SIDE * SIDE * SIDE, W = AL::W;
+  __shared__ float arena[3 * AL::CH];
+  const int b = blockIdx.x;
+  const int start = blockStart[b], end = blockStart[b + 1];
+  if (start == end) return;
+  int nb[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)b * 8 + o];
+  for (int k = threadIdx.x; k < 3 * W * W * W; k += blockDim.x) {
+    const int ch = k / (W * W * W), node = k % (W * W * W);
+    const int x = node / (W * W), y = (node / W) % W, z = node % W;
+    const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+    int bn = nb[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) bn = (o == q) ? nb[q] : bn;
+    float v = 0.f;
+    if (bn >= 0) v = grid[((size_t)bn * 7 + 1 + ch) * NC + ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1))];
+    arena[ch * AL::CH + AL::at(x, y, z)] = v;
+  }
+  const int bk0 = t.activeKeys[3 * (size_t)b] * SIDE, bk1 = t.activeKeys[3 * (size_t)b + 1] * SIDE,
+            bk2 = t.activeKeys[3 * (size_t)b + 2] * SIDE;
+  __syncthreads();
+  const float dxi = 1.0f / mp.dx;
+  const float D_inv = 4.f * dxi * dxi;
+  for (int i = start + (int)threadIdx.x; i < end; i += (int)blockDim.x) {
+    float pos[3];
+    load_attr<3>(ps.pos, (size_t)i, pos);
+    Arena ar;
+    make_arena(mp.dx, pos, ar);
+    const int lx = ar.corner[0] - bk0, ly = ar.corner[1] - bk1, lz = ar.corner[2] - bk2;
+    if ((unsigned)lx >= (unsigned)SIDE || (unsigned)ly >= (unsigned)SIDE || (unsigned)lz >= (unsigned)SIDE) {
+      g2p_gather_global<SIDE>(mp, ps, (size_t)i, t, grid, D_inv);
+      continue;
+    }
+    const float *a0 = arena + AL::at(lx, ly, lz);
+    float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float *g = a0 + AL::at(a, bb, c);
+          const float vi[3] = {g[0], g[AL::CH], g[2 * AL::CH]};
+          const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)bb * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
+          float Wt = ar.w[0][a];
+          Wt *= ar.w[1][bb];
+          Wt *= ar.w[2][c];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) vel[d] += vi[d] * Wt;
+#pragma unroll
+          for (int d = 0; d < 9; ++d) C[d] += Wt * vi[d % 3] * xi[d / 3] * D_inv;
+        }
+    g2p_finish<SIDE>(mp, ps, (size_t)i, pos, vel, C);
+  }
+}
+
+// ======================================================================================= misc kernels
+template <int MODEL> __global__ void stress_kernel(MpmDev mp, float *F, float *logJp, size_t n, float *PF) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float f[9], pf[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
+  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(mp.mat, f, pf);
+  else {
+    float lj = logJp[i];
+    stress_sand(mp.mat, lj, f, pf);
+    logJp[i] = lj;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) F[9 * i + d] = f[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) PF[9 * i + d] = pf[d];
+}
+__global__ void svd_kernel(const float *F, size_t n, float *U, float *S, float *V) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float f[9], u[9], s[3], v[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
+  svd3(f, u, s, v);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {
+    U[9 * i + d] = u[d];
+    V[9 * i + d] = v[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) S[3 * i + d] = s[d];
+}
+__global__ void halo_pack_kernel(const float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, float *buf) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)nchn * nc;
+  if (g >= nb * per) return;
+  const size_t i = g / per, r = g % per;
+  buf[g] = grid[((size_t)blocks[i] * 7 + chn0) * nc + r];
+}
+template <bool ADD> __global__ void halo_unpack_kernel(float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, const float *buf) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)nchn * nc;
+  if (g >= nb * per) return;
+  const size_t i = g / per, r = g % per;
+  float *dst = grid + ((size_t)blocks[i] * 7 + chn0) * nc + r;
+  if (ADD) *dst += buf[g];  // each (block, channel, cell) appears once per message: no atomics needed
+  else *dst = buf[g];
+}
+
+// ======================================================================================= host helpers
+static MpmDev make_dev(const zs_rocm_mpm_params *p) {
+  MpmDev d;
+  d.model = p->model;
+  d.dx = p->dx;
+  d.dt = p->dt;
+  d.mat.volume = p->volume;
+  d.mat.mu = (float)(0.5 * p->E / (1 + p->nu));  // lame_parameters (physics/ConstitutiveModel.hpp:34-38)
+  d.mat.lam = (float)(p->E * p->nu / ((1 + p->nu) * (1 - 2 * p->nu)));
+  d.mat.cohesion = p->cohesion;
+  d.mat.beta = p->beta;
+  d.mat.yieldSurface = p->yieldSurface;
+  d.mat.volCorrection = p->volCorrection;
+  return d;
+}
+static ParticlesDev make_particles(const zs_rocm_particles &p) {
+  ParticlesDev d;
+  d.mass = make_port<float>(p.mass);
+  d.pos = make_port<float>(p.pos);
+  d.vel = make_port<float>(p.vel);
+  d.C = make_port<float>(p.C);
+  d.F = make_port<float>(p.F);
+  d.logJp = make_port<float>(p.logJp);
+  d.n = p.n;
+  return d;
+}
+
+#define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                                        \
+  do {                                                                                    \
+    if ((side) == 4 && (model) == ZS_MPM_FIXED_COROTATED) { CALL(4, ZS_MPM_FIXED_COROTATED); } \
+    else if ((side) == 4) { CALL(4, ZS_MPM_DRUCKER_PRAGER); }                             \
+    else if ((model) == ZS_MPM_FIXED_COROTATED) { CALL(8, ZS_MPM_FIXED_COROTATED); }      \
+    else { CALL(8, ZS_MPM_DRUCKER_PRAGER); }                                              \
+  } while (0)
+
+}  // namespace zsr
+
+using namespace zsr;
+
+extern "C" {
+
+void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side) {
+  Launch L(pol, "ComputeSparsity");
+  if (!n) return;
+  hipLaunchKernelGGL(compute_sparsity_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->t.dev(), make_port<float>(pos), n,
+                     1.0f / dx, side);
+}
+void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, const int lo[3], const int hi[3]) {
+  Launch L(pol, "EnlargeSparsity");
+  const int nb = bht_size(tab->t, L.stream);
+  const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+  if (nb == 0 || e0 <= 0 || e1 <= 0 || e2 <= 0) return;
+  hipLaunchKernelGGL(enlarge_sparsity_kernel, dim3(ceil_div((size_t)nb * e0 * e1 * e2, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb,
+                     lo[0], lo[1], lo[2], e0, e1, e2);
+}
+void zs_rocm_mpm_build_neighbors(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, int *nbr) {
+  Launch L(pol, "build_neighbors");
+  const int nb = bht_size(tab->t, L.stream);
+  if (!nb) return;
+  hipLaunchKernelGGL(build_neighbors_kernel, dim3(ceil_div((size_t)nb * 8, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb, nbr);
+}
+
+void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side,
+                               int *order, int *blockStart) {
+  Launch L(pol, "bin_particles");
+  const int nb = bht_size(tab->t, L.stream);
+  if (nb == 0) return;
+  const size_t nc = (size_t)side * side * side, ncells = (size_t)nb * nc;
+  unsigned *cellCount = (unsigned *)L.temp(sizeof(unsigned) * (ncells + 1));
+  unsigned *cellStart = (unsigned *)L.temp(sizeof(unsigned) * (ncells + 1));
+  unsigned *cellOf = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
+  unsigned *rankOf = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
+  int *byCell = (int *)L.temp(sizeof(int) * (n + 1));
+  int *err = (int *)L.temp(sizeof(int));
+  ZSR_CHECK(hipMemsetAsync(cellCount, 0, sizeof(unsigned) * (ncells + 1), L.stream));
+  ZSR_CHECK(hipMemsetAsync(err, 0, sizeof(int), L.stream));
+  BhtDev t = tab->t.dev();
+  Port<float> pp = make_port<float>(pos);
+  if (n) {
+    if (side == 4)
+      hipLaunchKernelGGL((bin_count_kernel<4>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err);
+    else
+      hipLaunchKernelGGL((bin_count_kernel<8>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err);
+  }
+  exclusive_scan_u32(L, cellCount, ncells + 1, cellStart);
+  if (n)
+    hipLaunchKernelGGL(bin_place_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, (const unsigned *)cellStart,
+                       (const unsigned *)cellOf, (const unsigned *)rankOf, byCell);
+  if (side == 4)
+    hipLaunchKernelGGL((bin_roundrobin_kernel<4>), dim3(nb), dim3(64), 0, L.stream, nb, (const unsigned *)cellStart,
+                       (const unsigned *)cellCount, (const int *)byCell, order, blockStart, (unsigned)n);
+  else
+    hipLaunchKernelGGL((bin_roundrobin_kernel<8>), dim3(nb), dim3(512), 0, L.stream, nb, (const unsigned *)cellStart,
+                       (const unsigned *)cellCount, (const int *)byCell, order, blockStart, (unsigned)n);
+  int herr = 0;
+  ZSR_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  if (herr) fprintf(stderr, "[zs_rocm] bin_particles: particles outside the partition were dropped from the bins\n");
+}
+
+void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, float *grid,
+                     const int *blockStart, const int *nbr) {
+  Launch L(pol, "P2GTransfer");
+  if (!ps.n) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  if (blockStart && nbr) {
+    const int nb = bht_size(tab->t, L.stream);
+    if (!nb) return;
+#define CALL_P2G_BINNED(S, M) \
+  hipLaunchKernelGGL((p2g_binned_kernel<S, M>), dim3(nb), dim3(binned_wg<S>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr)
+    ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_P2G_BINNED);
+  } else {
+#define CALL_P2G_GLOBAL(S, M) \
+  hipLaunchKernelGGL((p2g_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
+    ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_P2G_GLOBAL);
+  }
+}
+
+void zs_rocm_mpm_grid_update(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *grid, size_t nblocks, const float extf[3],
+                             float *maxVelSqr) {
+  Launch L(pol, "ComputeGridBlockVelocity");
+  if (!nblocks) return;
+  const size_t nc = (size_t)p->side * p->side * p->side;
+  if (p->side == 4)
+    hipLaunchKernelGGL((grid_update_kernel<4>), dim3(ceil_div(nblocks * nc, 256)), dim3(256), 0, L.stream, grid, nblocks, p->dt, extf[0],
+                       extf[1], extf[2], maxVelSqr);
+  else
+    hipLaunchKernelGGL((grid_update_kernel<8>), dim3(ceil_div(nblocks * nc, 256)), dim3(256), 0, L.stream, grid, nblocks, p->dt, extf[0],
+                       extf[1], extf[2], maxVelSqr);
+}
+
+void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *grid,
+                     const int *blockStart, const int *nbr) {
+  Launch L(pol, "G2PTransfer");
+  if (!ps.n) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  if (blockStart && nbr) {
+    const int nb = bht_size(tab->t, L.stream);
+    if (!nb) return;
+    if (p->side == 4)
+      hipLaunchKernelGGL((g2p_binned_kernel<4>), dim3(nb), dim3(binned_wg<4>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr);
+    else
+      hipLaunchKernelGGL((g2p_binned_kernel<8>), dim3(nb), dim3(binned_wg<8>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr);
+  } else {
+    if (p->side == 4)
+      hipLaunchKernelGGL((g2p_global_kernel<4>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid);
+    else
+      hipLaunchKernelGGL((g2p_global_kernel<8>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid);
+  }
+}
+
+void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *F, float *logJp, size_t n, float *PF) {
+  Launch L(pol, "compute_stress");
+  if (!n) return;
+  MpmDev mp = make_dev(p);
+  if (p->model == ZS_MPM_FIXED_COROTATED)
+    hipLaunchKernelGGL((stress_kernel<ZS_MPM_FIXED_COROTATED>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF);
+  else
+    hipLaunchKernelGGL((stress_kernel<ZS_MPM_DRUCKER_PRAGER>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF);
+}
+void zs_rocm_svd3(zs_rocm_policy *pol, const float *F, size_t n, float *U, float *S, float *V) {
+  Launch L(pol, "svd3");
+  if (!n) return;
+  hipLaunchKernelGGL(svd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, F, n, U, S, V);
+}
+
+void zs_rocm_mpm_halo_pack(zs_rocm_policy *pol, const float *grid, const int *blocks, size_t nb, int side, int chn0, int nchn, float *buf) {
+  Launch L(pol, "halo_pack");
+  const int nc = side * side * side;
+  if (!nb) return;
+  hipLaunchKernelGGL(halo_pack_kernel, dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0, nchn, buf);
+}
+void zs_rocm_mpm_halo_unpack(zs_rocm_policy *pol, float *grid, const int *blocks, size_t nb, int side, int chn0, int nchn, const float *buf,
+                             int add) {
+  Launch L(pol, "halo_unpack");
+  const int nc = side * side * side;
+  if (!nb) return;
+  if (add)
+    hipLaunchKernelGGL((halo_unpack_kernel<true>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
+                       nchn, buf);
+  else
+    hipLaunchKernelGGL((halo_unpack_kernel<false>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
+                       nchn, buf);
+}
+
+}  // extern "C"

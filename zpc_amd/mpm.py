@@ -1,0 +1,138 @@
+"""Host-side driver of the MPM particle<->grid hot path: the sequence a downstream zpc application runs per
+sub-step (sparsity/partition -> grid reset -> P2G -> grid update -> G2P), expressed over the
+C ABI of libzsrocm.  torch only owns device memory and streams here; every kernel is hand-written HIP.
+
+Particle storage is one TileVector<f32, L> (AoSoA) with channels
+    m:1  x:3  v:3  C:9  F:9  [logJp:1]
+(the attribute set of zs::Particles, geometry/Structurefree.hpp:21-237, in the TileVector layout of
+container/TileVector.hpp:108); the grid is TileVector<f32, side^3> with channels {m:1, v:3, rhs:3}
+(simulation/mpm/Simulator.cpp:116-122) over blocks keyed in a bht<int,3,int,16>.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, Port, Particles, MpmParams
+from .containers import Bht
+
+FIXED_COROTATED, DRUCKER_PRAGER = 0, 1
+
+
+class MpmTransfer:
+    def __init__(self, pol, n, dx, dt, model=FIXED_COROTATED, side=4, lane_width=64, E=5e4, nu=0.4, volume=1.0,
+                 cohesion=0.0, beta=1.0, yield_surface=0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), vol_correction=True,
+                 device="cuda"):
+        self.pol, self.n, self.L, self.side = pol, int(n), int(lane_width), int(side)
+        self.device = torch.device(device)
+        self.model = model
+        self.nchn = 25 + (1 if model == DRUCKER_PRAGER else 0)
+        self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
+        self.tiles = (self.n + self.L - 1) // self.L
+        self.buf = torch.zeros(self.tiles * self.L * self.nchn, dtype=torch.float32, device=self.device)
+        self.buf2 = None  # second buffer for re-binning (ping-pong)
+        self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side)
+        self.table = None
+        self.grid = None
+        self.nblocks = 0
+        self.order = self.block_start = self.nbr = None
+        self.binned = False
+
+    # ------------------------------------------------------------------ particle access
+    def _port(self, name, buf=None):
+        buf = self.buf if buf is None else buf
+        bits = self.L.bit_length() - 1
+        return Port(buf.data_ptr() + self.off[name] * self.L * 4, 0, bits, self.L - 1, self.nchn)
+
+    def particles(self):
+        null = Port(None, 0, 0, 0, 1)
+        return Particles(self._port("m"), self._port("x"), self._port("v"), self._port("C"), self._port("F"),
+                         self._port("logJp") if self.model == DRUCKER_PRAGER else null, self.n)
+
+    def upload(self, mass, pos, vel, Cm, F, logJp=None):
+        """AoS host/device arrays -> AoSoA particle buffer (zs_rocm_tv_from_aos_f32)."""
+        cols = [torch.as_tensor(mass, dtype=torch.float32).reshape(self.n, 1), torch.as_tensor(pos, dtype=torch.float32).reshape(self.n, 3),
+                torch.as_tensor(vel, dtype=torch.float32).reshape(self.n, 3), torch.as_tensor(Cm, dtype=torch.float32).reshape(self.n, 9),
+                torch.as_tensor(F, dtype=torch.float32).reshape(self.n, 9)]
+        if self.model == DRUCKER_PRAGER:
+            lj = torch.zeros(self.n) if logJp is None else torch.as_tensor(logJp, dtype=torch.float32)
+            cols.append(lj.reshape(self.n, 1))
+        aos = torch.cat([c.to(self.device) for c in cols], dim=1).contiguous()
+        lib().zs_rocm_tv_from_aos_f32(self.pol.handle, aos.data_ptr(), self.n, self.nchn, self.L, self.buf.data_ptr())
+        self.pol.syncCtx()
+        self.binned = False
+
+    def download(self):
+        aos = torch.empty(self.n, self.nchn, dtype=torch.float32, device=self.device)
+        lib().zs_rocm_tv_to_aos_f32(self.pol.handle, self.buf.data_ptr(), self.n, self.nchn, self.L, aos.data_ptr())
+        self.pol.syncCtx()
+        a = aos.cpu().numpy()
+        out = {"m": a[:, 0].copy(), "x": a[:, 1:4].copy(), "v": a[:, 4:7].copy(), "C": a[:, 7:16].copy(), "F": a[:, 16:25].copy()}
+        if self.model == DRUCKER_PRAGER:
+            out["logJp"] = a[:, 25].copy()
+        return out
+
+    # ------------------------------------------------------------------ partition (SparsityCompute.tpp:5-24)
+    def build_partition(self, expected_blocks):
+        self.table = Bht(3, int(expected_blocks))
+        L = lib()
+        L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side)
+        lo, hi = (C.c_int * 3)(0, 0, 0), (C.c_int * 3)(2, 2, 2)
+        L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi)
+        self.pol.syncCtx()
+        self.nblocks = self.table.size()
+        nc = self.side ** 3
+        self.grid = torch.zeros(self.nblocks * 7 * nc, dtype=torch.float32, device=self.device)
+        self.nbr = torch.empty(self.nblocks * 8, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr())
+        self.binned = False
+        return self.nblocks
+
+    def rebin(self):
+        """particle -> block binning + physical reorder of the AoSoA buffer (count / scan / distribute)."""
+        L = lib()
+        if self.order is None or self.order.numel() != self.n:
+            self.order = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.block_start = torch.empty(self.nblocks + 1, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_bin_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
+                                    self.order.data_ptr(), self.block_start.data_ptr())
+        if self.buf2 is None:
+            self.buf2 = torch.empty_like(self.buf)
+        L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
+                                self.order.data_ptr())
+        self.pol.syncCtx()
+        self.buf, self.buf2 = self.buf2, self.buf
+        self.binned = True
+
+    # ------------------------------------------------------------------ one sub-step
+    def clear_grid(self):
+        self.grid.zero_()  # TileVector::reset(pol, 0) (TileVector.hpp:636-640)
+
+    def p2g(self, binned=None):
+        binned = self.binned if binned is None else binned
+        bs = self.block_start.data_ptr() if binned else None
+        nb = self.nbr.data_ptr() if binned else None
+        lib().zs_rocm_mpm_p2g(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(), bs, nb)
+
+    def grid_update(self, extf=(0.0, 0.0, 0.0), max_vel=None):
+        e = (C.c_float * 3)(*extf)
+        lib().zs_rocm_mpm_grid_update(self.pol.handle, C.byref(self.params), self.grid.data_ptr(), self.nblocks, e,
+                                      max_vel.data_ptr() if max_vel is not None else None)
+
+    def g2p(self, binned=None):
+        binned = self.binned if binned is None else binned
+        bs = self.block_start.data_ptr() if binned else None
+        nb = self.nbr.data_ptr() if binned else None
+        lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(), bs, nb)
+
+    def grid_by_key(self):
+        """{(bx,by,bz): ndarray[7, side^3]} -- for comparisons that must not depend on block numbering."""
+        v = self.table.view()
+        nb = self.nblocks
+        keys = torch.empty(nb * 3, dtype=torch.int32, device=self.device)
+        import ctypes
+        # activeKeys is a device pointer owned by the table: copy through hipMemcpy via torch's from-pointer-free path
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy(ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(v.activeKeys), ctypes.c_size_t(nb * 12), 3)
+        k = keys.cpu().numpy().reshape(nb, 3)
+        g = self.grid.cpu().numpy().reshape(nb, 7, self.side ** 3)
+        return {tuple(int(x) for x in k[i]): g[i] for i in range(nb)}
