@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the zpc hot path on MI355X.
+
+Metric (BASELINE.json): particle*steps/s of the MPM particle<->grid transfer step (grid reset + P2G + grid
+update + G2P) on the 64M-particle sand column (DruckerPrager, 8 particles/cell, dx = 1/512, 512^3 sparse grid),
+on 1/2/4/8 GPUs of one node (strong scaling: the 64M particles are split spatially, ghost grid blocks exchanged
+over RCCL/xGMI).  Inputs are generated on the device and are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel (binned P2G) algorithmic bytes / launch duration (HIP events on the launch stream)
+  "cpu_baseline": the CPU oracle's OpenMP port of the reference P2G+G2P timed on this box's host cores on a
+                  bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+P2G_BYTES = {0: 107.0, 1: 115.0}  # algorithmic B/particle: 100 B particle read + 7 B grid (+8 B logJp r/w)
+G2P_BYTES = 145.5
+YIELD_SURFACE = 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=str, default="125,512,125", help="sand column extent in cells (8 particles each)")
+    ap.add_argument("--model", type=str, default="sand", choices=["sand", "jello"])
+    ap.add_argument("--side", type=int, default=4, choices=[4, 8])
+    ap.add_argument("--lane-width", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--unbinned", action="store_true", help="particle-order path (reference algorithm) instead of the binned path")
+    return ap.parse_args()
+
+
+def generate_particles(box_lo, box_hi, dx, seed, device, model):
+    """8 particles per cell on a jittered 2x2x2 sub-lattice, generated on the device in chunks.
+    Returns AoS [n, C] float32: m, x3, v3, C9, F9, (logJp)."""
+    ext = [box_hi[d] - box_lo[d] for d in range(3)]
+    ncell = ext[0] * ext[1] * ext[2]
+    n = ncell * 8
+    nch = 26 if model == 1 else 25
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    aos = torch.empty(n, nch, dtype=torch.float32, device=device)
+    h = dx / 2
+    chunk = 1 << 22
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        pid = torch.arange(s, e, device=device, dtype=torch.int64)
+        cell, sub = pid // 8, pid % 8
+        cx = cell // (ext[1] * ext[2]) + box_lo[0]
+        cy = (cell // ext[2]) % ext[1] + box_lo[1]
+        cz = cell % ext[2] + box_lo[2]
+        sx, sy, sz = sub // 4, (sub // 2) % 2, sub % 2
+        jit = (torch.rand(e - s, 3, device=device, generator=g) - 0.5) * (h * 0.8)
+        aos[s:e, 1] = (cx * 2 + sx + 0.5).float() * h + jit[:, 0]
+        aos[s:e, 2] = (cy * 2 + sy + 0.5).float() * h + jit[:, 1]
+        aos[s:e, 3] = (cz * 2 + sz + 0.5).float() * h + jit[:, 2]
+        aos[s:e, 0] = 1000.0 * dx ** 3 / 8
+        aos[s:e, 4:7] = 0.05 * torch.randn(e - s, 3, device=device, generator=g)
+        aos[s:e, 7:16] = 0.1 * torch.randn(e - s, 9, device=device, generator=g)
+        F = 0.01 * torch.randn(e - s, 9, device=device, generator=g)
+        F[:, 0] += 1.0
+        F[:, 4] += 1.0
+        F[:, 8] += 1.0
+        aos[s:e, 16:25] = F
+        if model == 1:
+            aos[s:e, 25] = 0.0
+    return aos
+
+
+def cpu_baseline(sample, dx, dt, model, side, vol):
+    """OpenMP port of the reference's OmpExecutionPolicy P2G+G2P (oracle/mpm.c) on a bounded sample of the workload."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "libzpc_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libzpc_oracle.so"])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import OracleMpm
+    o = C.CDLL(so)
+    cores = os.cpu_count() or 1
+    nth = max(1, cores - 1)  # omp_exec() = hardware_concurrency() - 1 (omp/execution/ExecutionPolicy.hpp:1192-1194)
+    ncell = max(1, sample // 8)
+    ey = max(1, ncell // (40 * 40))
+    aos = generate_particles((100, 0, 100), (140, ey, 140), dx, 7, "cpu", model).numpy()
+    n = aos.shape[0]
+    mass, pos, vel = aos[:, 0].copy(), aos[:, 1:4].copy(), aos[:, 4:7].copy()
+    Cm, F = aos[:, 7:16].copy(), aos[:, 16:25].copy()
+    lj = np.zeros(n, np.float32)
+    om = OracleMpm(o, model, dx, dt, side, vol, nthreads=nth)
+    om.build_partition(pos, max(1024, n // 64))
+    reps, t_total = 0, 0.0
+    while t_total < 8.0 and reps < 20:
+        om.grid[:] = 0
+        t0 = time.perf_counter()
+        om.p2g(mass, pos, vel, Cm, F, lj)
+        om.grid_update((0.0, -9.8, 0.0))
+        om.g2p(pos, vel, Cm, F)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": n * reps / t_total, "unit": "particle*steps/s", "cores": cores, "threads": nth, "kind": "port",
+            "sample": "%d particles of the same sand column, %d steps (P2G + grid update + G2P), oracle/mpm.c OpenMP port" % (n, reps)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus, "launch with --nproc-per-node == --gpus"
+
+    import zpc_amd
+    from zpc_amd import lib
+    from zpc_amd.mpm import MpmTransfer
+    from zpc_amd.dist import cell_box, HaloExchange
+
+    model = 1 if a.model == "sand" else 0
+    dx, dt = 1.0 / 512, 1e-4
+    ext = [int(x) for x in a.cells.split(",")]
+    glo = [(512 - ext[0]) // 2 // a.side * a.side, 0, (512 - ext[2]) // 2 // a.side * a.side]
+    ghi = [glo[d] + ext[d] for d in range(3)]
+    lo, hi = cell_box(rank, world, glo, ghi, align=a.side)
+    vol = dx ** 3 / 8
+
+    pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
+    aos = generate_particles(lo, hi, dx, 1234 + rank, device, model)
+    n_local = aos.shape[0]
+    mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device)
+    lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n_local, mt.nchn, mt.L, mt.buf.data_ptr())
+    torch.cuda.synchronize()
+    del aos
+    nblocks = mt.build_partition(max(4096, n_local // 128))
+    t0 = time.perf_counter()
+    if not a.unbinned:
+        mt.rebin()
+    torch.cuda.synchronize()
+    rebin_ms = (time.perf_counter() - t0) * 1e3
+
+    # ---- halo exchange setup
+    halo = None
+    nc = a.side ** 3
+    if world > 1:
+        hip = C.CDLL("libamdhip64.so")
+        v = mt.table.view()
+        keys = torch.empty(nblocks * 3, dtype=torch.int32, device=device)
+        hip.hipMemcpy(C.c_void_p(keys.data_ptr()), C.c_void_p(v.activeKeys), C.c_size_t(nblocks * 12), 3)
+        my_keys = keys.cpu().numpy().reshape(nblocks, 3)
+
+        def lookup(sk):
+            d = torch.from_numpy(np.ascontiguousarray(sk)).to(device)
+            r = torch.empty(sk.shape[0], dtype=torch.int32, device=device)
+            mt.table.query(pol, d.data_ptr(), sk.shape[0], r.data_ptr())
+            torch.cuda.synchronize()
+            return r.cpu().numpy()
+
+        halo = HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
+                            lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=device), 7 * nc)
+
+        def pack(blocks, nb, buf):
+            lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, buf.data_ptr())
+
+        def unpack_add(blocks, nb, buf):
+            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, buf.data_ptr(), 1)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    p2g_ev, g2p_ev = [], []
+
+    def step(timed):
+        mt.clear_grid()
+        if timed:
+            e0, e1 = ev(), ev()
+            e0.record()
+        mt.p2g(binned=not a.unbinned)
+        if timed:
+            e1.record()
+            p2g_ev.append((e0, e1))
+        if halo is not None:
+            halo.exchange(pack, unpack_add)
+        mt.grid_update((0.0, -9.8, 0.0))
+        if timed:
+            e2, e3 = ev(), ev()
+            e2.record()
+        mt.g2p(binned=not a.unbinned)
+        if timed:
+            e3.record()
+            g2p_ev.append((e2, e3))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    err = lib().zs_rocm_last_error(-1)
+
+    n_total = n_local
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nt = torch.tensor([n_local], dtype=torch.int64, device=device)
+        dist.all_reduce(nt)
+        n_total = int(nt.item())
+    p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev]))
+    g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev]))
+
+    if rank == 0:
+        value = n_total * a.steps / elapsed
+        ach = P2G_BYTES[model] * n_local / (p2g_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_p2g.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out = {
+            "metric": "particle*steps/s (P2G+G2P)", "value": value, "unit": "particle*steps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MPM sand column %dx%dx%d cells, 8 particles/cell = %d particles, dx=1/512 (512^3 sparse grid), "
+                                   "%s, Grids<f32,3,%d> blocks, TileVector<f32,%d> particles; step = grid reset + P2G + grid update + G2P%s"
+                       % (ext[0], ext[1], ext[2], n_total, "DruckerPrager" if model else "FixedCorotated", a.side, a.lane_width,
+                          "" if not a.unbinned else " [particle-order path]"),
+                       "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
+                       "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
+                       "rebin_ms_once": rebin_ms},
+            "roofline": {"bound": "hbm", "kernel": "p2g_binned_kernel" if not a.unbinned else "p2g_global_kernel",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_particle": P2G_BYTES[model], "particles_per_launch": n_local, "launch_ms": p2g_ms,
+                         "g2p": {"achieved": G2P_BYTES * n_local / (g2p_ms * 1e-3) / 1e9, "launch_ms": g2p_ms,
+                                 "bytes_per_particle": G2P_BYTES}},
+            "hip_error": err,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, dx, dt, model, a.side, vol)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

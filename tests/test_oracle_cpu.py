@@ -1,0 +1,232 @@
+"""CPU tests (no GPU): pin the oracle (oracle/*.c) against (1) golden vectors produced by the reference's own
+code compiled in place (tests/golden/*.npz, tools/gen_golden.py), (2) the live oracle/_ref build when present
+(this container only), (3) numpy for the integer primitives whose results are mathematically unique, and
+(4) replay of the reference's own reduce test (test/utils/parallel_primitives.hpp:9-32)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from util import rng, ptr, YIELD_SURFACE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_svd_matches_reference_golden(oracle):
+    g = np.load(os.path.join(GOLD, "svd_stress.npz"))
+    F, Sref, Uref, Vref = g["F"], g["S"], g["U"], g["V"]
+    n = F.shape[0]
+    U, S, V = np.zeros(9, np.float32), np.zeros((n, 3), np.float32), np.zeros(9, np.float32)
+    worst_rec = 0.0
+    for i in range(n):
+        oracle.orc_svd3(ptr(F[i]), ptr(U), ptr(S[i]), ptr(V))
+        # same approximate decomposition as the reference: compare the reconstructions U S V^T
+        rec = U.reshape(3, 3).T @ np.diag(S[i]) @ V.reshape(3, 3)
+        rref = Uref[i].reshape(3, 3).T @ np.diag(Sref[i]) @ Vref[i].reshape(3, 3)
+        worst_rec = max(worst_rec, np.abs(rec - rref).max() / max(1.0, np.abs(F[i]).max()))
+    assert np.abs(S - Sref).max() <= 2e-6 * max(1.0, np.abs(Sref).max())
+    assert worst_rec < 1e-5
+
+
+def test_stress_matches_reference_golden(oracle):
+    g = np.load(os.path.join(GOLD, "svd_stress.npz"))
+    F, mu, lam, vol = g["F"], float(g["mu"]), float(g["lam"]), float(g["vol"])
+    n = F.shape[0]
+    m, l = C.c_float(), C.c_float()
+    oracle.orc_lame(C.c_float(5e4), C.c_float(0.4), C.byref(m), C.byref(l))
+    assert m.value == mu and l.value == lam
+    scale = (2 * mu + lam) * vol
+    pf = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        oracle.orc_stress_fixedcorotated(C.c_float(vol), m, l, ptr(F[i]), ptr(pf[i]))
+    dev = np.abs(F - np.eye(3).reshape(1, 9)).max(axis=1, keepdims=True)
+    assert (np.abs(pf - g["PF_fixedcorotated"]) <= 2e-5 * scale * np.maximum(1.0, dev ** 2 * 10)).all()
+    Fs, lj = F.copy(), g["logJp_in"].copy()
+    pfs = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        x = C.c_float(lj[i])
+        oracle.orc_stress_sand(C.c_float(vol), m, l, C.c_float(0.0), C.c_float(1.0), C.c_float(float(g["yieldSurface"])), 1,
+                               C.byref(x), ptr(Fs[i]), ptr(pfs[i]))
+        lj[i] = x.value
+    assert np.abs(lj - g["logJp_out"]).max() < 1e-5
+    assert np.abs(Fs - g["F_sand_out"]).max() < 2e-5 * max(1.0, np.abs(g["F_sand_out"]).max())
+    assert np.abs(pfs - g["PF_sand"]).max() <= 5e-5 * scale * max(1.0, np.abs(np.log(np.abs(g["S"]) + 1e-4)).max())
+
+
+def test_bspline_matches_reference_golden(oracle):
+    g = np.load(os.path.join(GOLD, "bspline.npz"))
+    x, base, w = g["x"], g["base_node"], g["weights"]
+    # orc_arena(dx=1, pos=x): corner == base_node<1>(x), weights of the local position
+    corner, lp, ww = np.zeros(3, np.int32), np.zeros(3, np.float32), np.zeros(9, np.float32)
+    for i in range(x.shape[0]):
+        oracle.orc_arena(C.c_float(1.0), ptr(x[i]), ptr(corner), ptr(lp), ptr(ww))
+        assert np.array_equal(corner, base[i])
+        # the golden weights are quadratic_bspline_weights(x) itself; the arena evaluates them at x - corner
+        # (InterpolationKernel.hpp:107 re-derives d0 = x - floor(x - 0.5), identical for both arguments)
+        assert np.abs(ww - w[i]).max() <= 2e-6
+
+
+def test_hash_matches_reference_golden(oracle):
+    g = np.load(os.path.join(GOLD, "hash.npz"))
+    hp = (C.c_uint32 * 6)()
+    oracle.orc_bht_hash_params(hp)
+    assert np.array_equal(np.array(list(hp), np.uint32), g["hash_params"])
+    assert list(hp) == [1872583848, 794921487, 111352301, 4000937544, 2360782358, 4070471979]
+    oracle.orc_universal_hash_vec.restype = C.c_uint32
+    oracle.orc_universal_hash_i32.restype = C.c_uint32
+    for i, k in enumerate(g["keys"]):
+        for f in range(3):
+            assert oracle.orc_universal_hash_vec(hp[2 * f], hp[2 * f + 1], ptr(k), 3) == g["h3"][i, f]
+            assert oracle.orc_universal_hash_vec(hp[2 * f], hp[2 * f + 1], ptr(k), 2) == g["h2"][i, f]
+            assert oracle.orc_universal_hash_i32(hp[2 * f], hp[2 * f + 1], int(k[0])) == g["h1"][i, f]
+    oracle.orc_bht_table_size.restype = C.c_size_t
+    for n, p in zip(g["next_2pow_in"], g["next_2pow_out"]):
+        assert oracle.orc_bht_table_size(C.c_size_t(int(n))) == int(p) * 2 + (16 - (int(p) * 2) % 16)
+    assert oracle.orc_bht_table_size(C.c_size_t(200000)) == 524304
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libzpcref.so")), reason="reference build only exists in the build container")
+def test_oracle_vs_live_reference_build(oracle):
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libzpcref.so"))
+    g = rng(50)
+    F = (np.eye(3).reshape(1, 9) + 0.15 * g.standard_normal((3000, 9))).astype(np.float32)
+    S1, S2 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    U, V = np.zeros(9, np.float32), np.zeros(9, np.float32)
+    for i in range(F.shape[0]):
+        oracle.orc_svd3(ptr(F[i]), ptr(U), ptr(S1), ptr(V))
+        ref.ref_svd3(ptr(F[i]), ptr(U), ptr(S2), ptr(V))
+        assert np.abs(S1 - S2).max() < 3e-6
+
+
+# ---------------------------------------------------------------------------------------- primitives
+SIZES = [0, 1, 2, 7, 16, 128, 1024, 65537]
+
+
+def test_reference_reduce_test_replayed(oracle):
+    """test/parallel_primitives.cpp:7-30 + test/utils/parallel_primitives.hpp:9-32: reduce(getmax/getmin/plus) over the
+    "b" channel of TileVector<int,32>{a:3,b:2,c:1} equals a serial fold; sizes {1,2,7,16,128,1024,2e6}, exact for ints."""
+    oracle.orc_tv_offset.restype = C.c_size_t
+    for n in (1, 2, 7, 16, 128, 1024, 200_000):
+        tiles = (n + 31) // 32
+        buf = rng(51).integers(-1000, 1000, tiles * 32 * 6, dtype=np.int32)
+        idx = np.arange(n)
+        vals = np.ascontiguousarray(buf[(idx // 32 * 6 + 3) * 32 + idx % 32])
+        assert int(vals[-1]) == int(buf[oracle.orc_tv_offset(C.c_size_t(n - 1), C.c_size_t(3), C.c_size_t(32), C.c_size_t(6))])
+        out = np.zeros(1, np.int32)
+        for name, exp in (("sum", vals.sum(dtype=np.int64).astype(np.int32)), ("min", vals.min()), ("max", vals.max())):
+            getattr(oracle, "orc_reduce_%s_i32" % name)(ptr(vals), C.c_size_t(n), ptr(out))
+            assert out[0] == exp
+            if name == "sum":
+                oracle.orc_omp_reduce_sum_i32(ptr(vals), C.c_size_t(n), ptr(out), 7)
+                assert out[0] == exp
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_scan_and_sort_oracle_vs_numpy(oracle, n):
+    g = rng(52)
+    a = g.integers(-2**30, 2**30, n, dtype=np.int32)
+    out = np.zeros(n, np.int32)
+    cs = np.cumsum(a, dtype=np.int64).astype(np.int32) if n else a
+    oracle.orc_inclusive_scan_sum_i32(ptr(a), C.c_size_t(n), ptr(out))
+    assert np.array_equal(out, cs)
+    oracle.orc_exclusive_scan_sum_i32(ptr(a), C.c_size_t(n), ptr(out))
+    assert np.array_equal(out, (cs.astype(np.int64) - a).astype(np.int32))
+    for nth in (1, 3, 7):
+        oracle.orc_omp_exclusive_scan_sum_i32(ptr(a), C.c_size_t(n), ptr(out), nth)
+        assert np.array_equal(out, (cs.astype(np.int64) - a).astype(np.int32))
+        oracle.orc_omp_inclusive_scan_sum_i32(ptr(a), C.c_size_t(n), ptr(out), nth)
+        assert np.array_equal(out, cs)
+    oracle.orc_radix_sort_i32(ptr(a), ptr(out), C.c_size_t(n), 0, 32)
+    assert np.array_equal(out, np.sort(a))
+    oracle.orc_omp_radix_sort_i32(ptr(a), ptr(out), C.c_size_t(n), 0, 32, 7)
+    assert np.array_equal(out, np.sort(a))
+    # pairs: stable permutation, duplicates pin stability
+    k = g.integers(-5, 5, n, dtype=np.int32)
+    v = np.arange(n, dtype=np.int32)
+    ko, vo = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    oracle.orc_radix_sort_pair_i32(ptr(k), ptr(v), ptr(ko), ptr(vo), C.c_size_t(n), 0, 32)
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(ko, k[order]) and np.array_equal(vo, v[order])
+    oracle.orc_omp_radix_sort_pair_i32(ptr(k), ptr(v), ptr(ko), ptr(vo), C.c_size_t(n), 0, 32, 5)
+    assert np.array_equal(ko, k[order]) and np.array_equal(vo, v[order])
+
+
+def test_radix_window_and_skip_path(oracle):
+    """[sbit, ebit) window and the all-in-one-bin pass skip (execution/ExecutionPolicy.hpp:493-509)."""
+    g = rng(53)
+    n = 5000
+    a = g.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    out = np.zeros(n, np.int32)
+    oracle.orc_radix_sort_i32(ptr(a), ptr(out), C.c_size_t(n), 8, 24)
+    key = ((a.view(np.uint32) ^ np.uint32(0x80000000)) >> 8) & 0xFFFF
+    assert np.array_equal(out, a[np.argsort(key, kind="stable")])
+    oracle.orc_radix_sort_i32(ptr(a), ptr(out), C.c_size_t(n), 3, 13)
+    key = ((a.view(np.uint32) ^ np.uint32(0x80000000)) >> 3) & 0x3FF
+    assert np.array_equal(out, a[np.argsort(key, kind="stable")])
+    same = np.full(n, 77, np.int32)
+    oracle.orc_radix_sort_i32(ptr(same), ptr(out), C.c_size_t(n), 0, 32)
+    assert np.array_equal(out, same)
+    u = g.integers(0, 2**64 - 1, n, dtype=np.uint64)
+    ou = np.zeros(n, np.uint64)
+    oracle.orc_radix_sort_u64(ptr(u), ptr(ou), C.c_size_t(n), 0, 64)
+    assert np.array_equal(ou, np.sort(u))
+
+
+def test_bht_oracle_semantics(oracle):
+    oracle.orc_bht_create.restype = C.c_void_p
+    oracle.orc_bht_size.restype = C.c_int32
+    oracle.orc_bht_insert.restype = C.c_int32
+    oracle.orc_bht_query.restype = C.c_int32
+    oracle.orc_bht_active_keys.restype = C.POINTER(C.c_int32)
+    g = rng(54)
+    keys = g.integers(-32, 32, (4096, 3), dtype=np.int32)  # SURVEY.md 8c fixture (3)
+    t = C.c_void_p(oracle.orc_bht_create(3, C.c_size_t(4096)))
+    ret = np.zeros(4096, np.int32)
+    oracle.orc_bht_insert_many(t, ptr(keys), C.c_size_t(4096), ptr(ret))
+    uniq = {}
+    for i, k in enumerate(map(tuple, keys)):
+        if k not in uniq:
+            uniq[k] = len(uniq)
+            assert ret[i] == uniq[k]          # dense index in first-occurrence order
+        else:
+            assert ret[i] == -1               # sentinel_v for an existing key
+    assert oracle.orc_bht_size(t) == len(uniq)
+    for k, i in list(uniq.items())[:500]:
+        kk = np.array(k, np.int32)
+        assert oracle.orc_bht_query(t, ptr(kk)) == i
+    miss = np.array([1000, 0, 0], np.int32)
+    assert oracle.orc_bht_query(t, ptr(miss)) == -1
+    oracle.orc_bht_resize(t, C.c_size_t(100000))
+    for k, i in list(uniq.items())[:500]:
+        kk = np.array(k, np.int32)
+        assert oracle.orc_bht_query(t, ptr(kk)) == i
+    oracle.orc_bht_destroy(t)
+
+
+def test_mpm_oracle_conservation(oracle):
+    """size-independent properties of the restated P2G/G2P: mass & momentum conservation, affine velocity field
+    reproduced exactly by P2G -> grid update -> G2P (APIC/MLS-MPM property)."""
+    from util import make_cloud, OracleMpm
+    dx, dt = 1.0 / 32, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(5, dx, 2, seed=55, vel_scale=0.0)
+    n = pos.shape[0]
+    A = np.array([[0.1, -0.2, 0.05], [0.3, 0.02, -0.1], [0.0, 0.15, -0.07]], np.float32)
+    b = np.array([0.5, -0.25, 0.125], np.float32)
+    vel = (pos @ A.T + b).astype(np.float32)
+    Cm = np.tile(A.T.reshape(1, 9), (n, 1)).astype(np.float32)   # column-major C = A
+    F = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    for side in (4, 8):
+        om = OracleMpm(oracle, 0, dx, dt, side, dx ** 3 / 8)
+        om.build_partition(pos, n)
+        om.p2g(mass, pos, vel, Cm, F)
+        g = om.grid
+        assert abs(g[:, 0].sum() - mass.sum()) < 1e-5 * mass.sum()
+        assert np.abs(g[:, 1:4].sum(axis=(0, 2)) - (mass[:, None] * vel).sum(0)).max() < 1e-4 * np.abs(mass[:, None] * vel).sum()
+        assert np.abs(g[:, 4:7]).max() < 1e-6 * (2 * 17857 + 71428) * dx ** 3 / 8 / dx  # F = I: zero stress up to SVD rounding
+        om.grid_update((0, 0, 0))
+        p2, v2, C2, F2 = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+        om.g2p(p2, v2, C2, F2)
+        assert np.abs(v2 - vel).max() < 2e-5
+        assert np.abs(C2 - Cm).max() < 2e-3

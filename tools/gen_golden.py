@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE's own code compiled in place (oracle/_ref/libzpcref.so,
+recipe oracle/Makefile `make ref`).  Runs only where /root/reference exists; the fixtures (inputs + the
+reference's outputs) are committed, the reference itself never travels.
+
+    python tools/gen_golden.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libzpcref.so"))
+fp = C.POINTER(C.c_float)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    g = np.random.Generator(np.random.PCG64(0x9E3779B97F4A7C15 ^ 77))
+    # ---- 3x3 SVD + constitutive models (math/matrix/SVD.hpp, physics/ConstitutiveModel_Vol_dP.hpp)
+    n = 512
+    F = np.concatenate([
+        np.eye(3).reshape(1, 9) + 0.01 * g.standard_normal((n // 4, 9)),   # jello-like (C3)
+        np.eye(3).reshape(1, 9) + 0.2 * g.standard_normal((n // 4, 9)),    # strongly deformed
+        g.standard_normal((n // 4, 9)),                                    # generic, some inverted
+        np.eye(3).reshape(1, 9) * g.uniform(0.6, 1.4, (n // 4, 1)) + 0.05 * g.standard_normal((n // 4, 9)),
+    ]).astype(np.float32)
+    U, S, V = np.zeros((n, 9), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 9), np.float32)
+    for i in range(n):
+        ref.ref_svd3(P(F[i]), P(U[i]), P(S[i]), P(V[i]))
+    mu, lam = C.c_float(), C.c_float()
+    ref.ref_lame(C.c_float(5e4), C.c_float(0.4), C.byref(mu), C.byref(lam))
+    vol = 1.0 / 256 ** 3 / 8
+    PF_fc = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        ref.ref_stress_fixedcorotated(C.c_float(vol), mu, lam, P(F[i]), P(PF_fc[i]))
+    ys = np.float32(0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5))
+    logJp_in = (0.02 * g.standard_normal(n)).astype(np.float32)
+    logJp_out = logJp_in.copy()
+    F_sand = F.copy()
+    PF_sand = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        l = C.c_float(logJp_out[i])
+        ref.ref_stress_sand(C.c_float(vol), mu, lam, C.c_float(0.0), C.c_float(1.0), C.c_float(ys), 1, C.byref(l),
+                            P(F_sand[i]), P(PF_sand[i]))
+        logJp_out[i] = l.value
+    np.savez_compressed(os.path.join(OUT, "svd_stress.npz"), F=F, U=U, S=S, V=V, mu=np.float32(mu.value),
+                        lam=np.float32(lam.value), vol=np.float32(vol), PF_fixedcorotated=PF_fc, yieldSurface=ys,
+                        logJp_in=logJp_in, logJp_out=logJp_out, F_sand_out=F_sand, PF_sand=PF_sand)
+    # ---- quadratic B-spline weights + base node (math/curve/InterpolationKernel.hpp:47-55,93-130)
+    x = np.concatenate([g.uniform(-3, 3, (300, 3)), g.uniform(0.5, 1.5, (212, 3))]).astype(np.float32)
+    ref.ref_base_node_quadratic.argtypes = [C.c_float]
+    base = np.array([[ref.ref_base_node_quadratic(float(v)) for v in r] for r in x], np.int32)
+    w = np.zeros((x.shape[0], 9), np.float32)
+    for i in range(x.shape[0]):
+        ref.ref_quadratic_weights(P(x[i]), P(w[i]))
+    np.savez_compressed(os.path.join(OUT, "bspline.npz"), x=x, base_node=base, weights=w)
+    # ---- hash functions (py_interop/HashUtils.hpp, math/Hash.hpp) + bht seeds (Bht.hpp:165-169)
+    hp = (C.c_uint * 6)()
+    ref.ref_bht_hash_params(hp)
+    keys = np.concatenate([g.integers(-32, 32, (64, 3)), g.integers(-2 ** 31, 2 ** 31 - 1, (64, 3))]).astype(np.int32)
+    ref.ref_universal_hash3.restype = C.c_uint
+    ref.ref_universal_hash2.restype = C.c_uint
+    ref.ref_universal_hash1.restype = C.c_uint
+    h3 = np.array([[ref.ref_universal_hash3(hp[2 * f], hp[2 * f + 1], P(k)) for f in range(3)] for k in keys], np.uint32)
+    h2 = np.array([[ref.ref_universal_hash2(hp[2 * f], hp[2 * f + 1], P(k)) for f in range(3)] for k in keys], np.uint32)
+    h1 = np.array([[ref.ref_universal_hash1(hp[2 * f], hp[2 * f + 1], int(k[0])) for f in range(3)] for k in keys], np.uint32)
+    ref.ref_next_2pow.restype = C.c_ulonglong
+    ref.ref_next_2pow.argtypes = [C.c_ulonglong]
+    ns = np.array([1, 2, 3, 4, 5, 7, 8, 9, 1000, 4096, 4097, 200000, 1 << 20, (1 << 20) + 1], np.uint64)
+    n2 = np.array([ref.ref_next_2pow(int(v)) for v in ns], np.uint64)
+    np.savez_compressed(os.path.join(OUT, "hash.npz"), hash_params=np.array(list(hp), np.uint32), keys=keys, h3=h3, h2=h2, h1=h1,
+                        next_2pow_in=ns, next_2pow_out=n2)
+    print("wrote", os.listdir(OUT))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -277,6 +277,7 @@ struct MpmDev {
   Material mat;
   int model;
   float dx, dt;
+  int dbg;  // investigation switches (env ZS_ROCM_DEBUG): 1 skip LDS atomics, 2 skip flush, 4 skip stress
 };
 
 // per-particle constitutive update -> contrib = -dt * D_inv * (P F^T vol)   (P2G.hpp:60-105)
@@ -512,8 +513,17 @@ __global__ __launch_bounds__(binned_wg<SIDE>()) void p2g_binned_kernel(MpmDev mp
     load_attr<3>(ps.vel, (size_t)i, vel);
     load_attr<9>(ps.C, (size_t)i, C);
     const float mass = ps.mass.base[ps.mass.off((size_t)i)];
-    particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
+    if (!(mp.dbg & 4)) particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
+    else load_attr<9>(ps.F, (size_t)i, contrib);
     float *a0 = arena + AL::at(lx, ly, lz);
+    if (mp.dbg & 1) {
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) acc += contrib[d] + C[d];
+      acc += vel[0] + vel[1] + vel[2] + mass + ar.w[0][0] + ar.w[1][1] + ar.w[2][2];
+      if (acc == 1.2345e30f) atomicAdd(a0, acc);
+      continue;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(binned_wg<SIDE>()) void p2g_binned_kernel(MpmDev mp
         }
   }
   __syncthreads();
+  if (mp.dbg & 2) return;
   // flush: consecutive threads -> consecutive z of one (channel, x, y) row
   int nb[8];
 #pragma unroll
@@ -783,6 +794,8 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.beta = p->beta;
   d.mat.yieldSurface = p->yieldSurface;
   d.mat.volCorrection = p->volCorrection;
+  static const int dbg = getenv("ZS_ROCM_DEBUG") ? atoi(getenv("ZS_ROCM_DEBUG")) : 0;
+  d.dbg = dbg;
   return d;
 }
 static ParticlesDev make_particles(const zs_rocm_particles &p) {

@@ -1,0 +1,110 @@
+"""Multi-GPU domain decomposition for the MPM transfer path: one process per GPU, torch.distributed
+("nccl" == RCCL on ROCm) for the ghost-block halo exchange over xGMI.
+
+The reference has no collective layer at all (only per-device contexts + peer access), so this is
+new, designed for the MI355X node topology: 8 GPUs, fully connected point-to-point xGMI links.  A spatial
+split into 1/2/4/8 boxes gives every rank at most 7 peers -- one direct link each -- so the exchange is a single
+grouped send/recv (ncclGroupStart .. ncclSend/ncclRecv .. ncclGroupEnd via batch_isend_irecv), never a ring
+collective.
+
+Exchange scheme (one phase per step): every rank runs P2G for its own particles into its own copy of every
+grid block its particles can touch (owned + ghost blocks).  For each pair of ranks the set of blocks BOTH hold
+is fixed at partition-build time; after P2G the two ranks swap their partial sums {m, mv, rhs} for exactly
+those blocks and add the peer's partials.  A block held by k ranks ends up with the k-way total on each
+holder, so the grid update and G2P need no second exchange.  (Totals on different holders may differ in the
+last ulp -- the additions happen in a different order -- which is inside the stated P2G tolerance.)
+"""
+import numpy as np
+
+
+def split_dims(world_size):
+    """1 -> (1,1,1), 2 -> (1,2,1) [split the column height], 4 -> (2,2,1), 8 -> (2,2,2)."""
+    return {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world_size]
+
+
+def rank_coords(rank, dims):
+    return (rank // (dims[1] * dims[2]), (rank // dims[2]) % dims[1], rank % dims[2])
+
+
+def cell_box(rank, world_size, lo, hi, align=1):
+    """Sub-box [lo_r, hi_r) of cell coordinates owned by `rank`: the global box [lo, hi) cut at planes aligned
+    to `align` cells (block side) so that grid blocks are never split between owners."""
+    dims = split_dims(world_size)
+    rc = rank_coords(rank, dims)
+    blo, bhi = [], []
+    for d in range(3):
+        n = hi[d] - lo[d]
+        cuts = [lo[d]]
+        for k in range(1, dims[d]):
+            c = lo[d] + (n * k) // dims[d]
+            c = (c // align) * align
+            cuts.append(c)
+        cuts.append(hi[d])
+        blo.append(cuts[rc[d]])
+        bhi.append(cuts[rc[d] + 1])
+    return tuple(blo), tuple(bhi)
+
+
+def shared_keys(my_keys, peer_keys):
+    """Lexicographically sorted intersection of two [n,3] int32 block-key arrays (identical on both sides)."""
+    if my_keys.shape[0] == 0 or peer_keys.shape[0] == 0:
+        return np.zeros((0, 3), np.int32)
+    dt = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32)])
+    a = np.ascontiguousarray(my_keys.astype(np.int32)).view(dt).reshape(-1)
+    b = np.ascontiguousarray(peer_keys.astype(np.int32)).view(dt).reshape(-1)
+    s = np.intersect1d(a, b)  # sorted by (x, y, z)
+    return s.view(np.int32).reshape(-1, 3)
+
+
+class HaloExchange:
+    """Ghost-block partial-sum exchange.  `lookup(keys[n,3]) -> local block numbers` , `pack(blocks_t, nb, buf)`,
+    `unpack_add(blocks_t, nb, buf)` are supplied by the caller (HIP kernels in production: zs_rocm_query__bht /
+    zs_rocm_mpm_halo_pack / zs_rocm_mpm_halo_unpack)."""
+
+    def __init__(self, dist, rank, world_size, my_keys, lookup, make_index_tensor, make_buffer, block_floats):
+        self.dist, self.rank, self.world = dist, rank, world_size
+        self.peers = []  # (peer, blocks_tensor, nb, sendbuf, recvbuf)
+        if world_size == 1:
+            return
+        # every rank learns every rank's key list (variable length -> pad to the max)
+        import torch
+        n = np.array([my_keys.shape[0]], np.int64)
+        backend_dev = make_buffer(1).device
+        cnt_t = torch.from_numpy(n).to(backend_dev)
+        counts = [torch.zeros_like(cnt_t) for _ in range(world_size)]
+        dist.all_gather(counts, cnt_t)
+        counts = [int(c.item()) for c in counts]
+        mx = max(max(counts), 1)
+        mine = torch.zeros(mx, 3, dtype=torch.int32, device=backend_dev)
+        if my_keys.shape[0]:
+            mine[: my_keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(my_keys.astype(np.int32))).to(backend_dev)
+        allk = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(allk, mine)
+        for p in range(world_size):
+            if p == rank:
+                continue
+            pk = allk[p][: counts[p]].cpu().numpy()
+            sk = shared_keys(my_keys, pk)
+            if sk.shape[0] == 0:
+                continue
+            local = lookup(sk)
+            assert (local >= 0).all()
+            nb = sk.shape[0]
+            self.peers.append((p, make_index_tensor(local.astype(np.int32)), nb, make_buffer(nb * block_floats),
+                               make_buffer(nb * block_floats)))
+        self.bytes_per_exchange = sum(x[2] for x in self.peers) * block_floats * 4
+
+    def exchange(self, pack, unpack_add):
+        if not self.peers:
+            return
+        d = self.dist
+        ops = []
+        for p, blocks, nb, sbuf, rbuf in self.peers:
+            pack(blocks, nb, sbuf)
+        for p, blocks, nb, sbuf, rbuf in self.peers:
+            ops.append(d.P2POp(d.isend, sbuf, p))
+            ops.append(d.P2POp(d.irecv, rbuf, p))
+        for w in d.batch_isend_irecv(ops):
+            w.wait()
+        for p, blocks, nb, sbuf, rbuf in self.peers:
+            unpack_add(blocks, nb, rbuf)
