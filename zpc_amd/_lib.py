@@ -40,6 +40,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libzsrocm.so not built (%s): run `python -m zpc_amd.build` -- zpc_amd has no CPU fallback" % LIB_PATH)
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64.so; it must be the first HIP runtime mapped into the process,
+            # otherwise libzsrocm binds /opt/rocm's copy and torch tensors / streams live in a different runtime
+            # instance (observed: kernels then read stale data).  torch is only memory + stream plumbing here.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib
