@@ -291,30 +291,35 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *, zs_rocm_bht_3
 /* pol(range(nblocks), EnlargeSparsity{table, lo, hi}) (sparsity/SparsityOp.hpp:89-115) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3]);
 
-/* particle -> block binning (the role of IndexBuckets / SpatiallyCount+Distribute,
- * sparsity/SparsityOp.hpp:117-196, simulation/particle/Query.tpp:9-58): computes for every block the
- * range [blockStart[b], blockStart[b+1]) of a permutation `order` listing the particles whose base node
- * (floor(x/dx - 0.5)) lies in block b, arranged round-robin over the block's cells so that
- * consecutive lanes hit distinct grid nodes.  order: [n], blockStart: [nblocks+1] device ints. */
+/* particle -> bin binning (the role of IndexBuckets / SpatiallyCount+Distribute,
+ * sparsity/SparsityOp.hpp:117-196, simulation/particle/Query.tpp:9-58).  A bin is a 4x4x4 group of cells
+ * (side 4: bin == grid block b; side 8: bin = 8*b + sub-cube).  Output: `order` [n], a permutation listing for
+ * every bin, in [binStart[k], binStart[k+1]), the particles whose base node floor(x/dx - 0.5) lies in bin k,
+ * round-robin over the bin's 64 cells (round r = the r-th particle of every cell that has one, cells in
+ * x-major order); `cellCount` [nbins*64] particles per cell; binStart [nbins+1].  nbins = nblocks * (side/4)^3. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_bin_particles(zs_rocm_policy *, const zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n,
-                                              float dx, int side, int *order, int *blockStart);
+                                              float dx, int side, int *order, int *binStart, unsigned *cellCount);
 /* nbr[b][8]: block numbers of b + {0,1}^3 (x-major), -1 when absent */
 ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr);
 
 /* pol(range(n), P2GTransfer{apic, dt, model, particles, table, grids})
  * (simulation/transfer/P2G.hpp:27-132, cuda/simulation/transfer/P2G.hpp:13-123).
- * blockStart/nbr == NULL: particle-order path (hash query + global float atomics per node);
- * otherwise the binned path (particles physically ordered by `order` of zs_rocm_mpm_bin_particles):
- * one workgroup per block accumulates in LDS and flushes once. */
+ * binStart/cellCount/nbr == NULL: particle-order path (hash query + global float atomics per node, the
+ * reference algorithm); otherwise the binned path: particles must be physically ordered by `order` of
+ * zs_rocm_mpm_bin_particles; one wavefront per bin accumulates in registers + LDS and flushes once.  Particles
+ * that moved out of their cell since binning are detected and take the particle-order path: results do not
+ * depend on the freshness of the bins.  nblocks = number of grid blocks (table size). */
 ZS_ROCM_EXPORT void zs_rocm_mpm_p2g(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
-                                    const zs_rocm_bht_3 *, float *grid, const int *blockStart, const int *nbr);
+                                    const zs_rocm_bht_3 *, float *grid, size_t nblocks, const int *binStart,
+                                    const unsigned *cellCount, const int *nbr);
 /* pol(Collapse{nblocks, side^3}, ComputeGridBlockVelocity{grids, dt, extf, maxVel})
  * (simulation/grid/GridOp.hpp:71-108).  maxVelSqr may be NULL. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_grid_update(zs_rocm_policy *, const zs_rocm_mpm_params *, float *grid, size_t nblocks,
                                             const float extf[3], float *maxVelSqr);
 /* pol(range(n), G2PTransfer{apic, dt, model, grids, table, particles}) (simulation/transfer/G2P.hpp:24-90) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
-                                    const zs_rocm_bht_3 *, const float *grid, const int *blockStart, const int *nbr);
+                                    const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,
+                                    const unsigned *cellCount, const int *nbr);
 /* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
  * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, float *F, float *logJp, size_t n, float *PF);

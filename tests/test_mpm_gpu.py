@@ -90,8 +90,10 @@ def test_p2g_g2p_vs_oracle(pol, oracle, side, model, binned):
     assert nb == nb_o
     if binned:
         mt.rebin()
-        bs = mt.block_start.cpu().numpy()
+        bs = mt.bin_start.cpu().numpy()
         assert bs[0] == 0 and bs[-1] == n and (np.diff(bs) >= 0).all()
+        cc = mt.cell_count.cpu().numpy().reshape(-1, 64)
+        assert np.array_equal(cc.sum(1), np.diff(bs))
         assert np.array_equal(np.sort(mt.order.cpu().numpy()), np.arange(n))  # a permutation
     mt.clear_grid()
     mt.p2g()
@@ -144,7 +146,7 @@ def test_stale_bins_fall_back_exactly(pol, oracle):
     mt2 = MpmTransfer(pol, n, dx, dt, model=0, side=4, volume=vol)
     mt2.upload(mass[order], pos2, vel[order], Cm[order], F[order])
     mt2.table, mt2.nblocks, mt2.grid, mt2.nbr = mt.table, mt.nblocks, torch.zeros_like(mt.grid), mt.nbr
-    mt2.block_start, mt2.binned = mt.block_start, True
+    mt2.bin_start, mt2.cell_count, mt2.binned = mt.bin_start, mt.cell_count, True
     mt2.p2g()
     pol.syncCtx()
     binned_grid = mt2.grid.cpu().numpy().copy()

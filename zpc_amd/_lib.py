@@ -154,11 +154,11 @@ def _declare_containers(L):
     PP = C.POINTER(MpmParams)
     L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32]
     L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, vp, vp]
+    L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, vp, vp, vp]
     L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp]
-    L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, vp, vp]
+    L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
-    L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, vp, vp]
+    L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_halo_pack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp]

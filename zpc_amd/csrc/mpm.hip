@@ -8,16 +8,23 @@
 //   G2PTransfer::operator()                  simulation/transfer/G2P.hpp:44-83
 //
 // The reference's CUDA P2G issues 27 hash queries + 189 global float atomics per particle.  Here:
-//   * particles are binned by the grid block of their base node (count -> scan -> distribute, the
-//     IndexBuckets idea of simulation/particle/Query.tpp:9-58) and laid out round-robin over the cells
-//     of a block, so the 64 lanes of a wave hit 64 different grid nodes;
-//   * one workgroup per grid block accumulates its particles into an LDS arena of (side+2)^3 nodes x 7
-//     channels with ds_add_f32 (LDS strides padded so that the lane<->cell map is bank-conflict free),
-//     then flushes the arena ONCE to the 2x2x2 neighbouring blocks with global_atomic_add_f32:
-//     3 global atomics per particle instead of 189, zero hash queries (a per-block neighbour table);
+//   * particles are binned by the 4x4x4 cell group ("bin") of their base node (count -> scan -> distribute,
+//     the IndexBuckets idea of simulation/particle/Query.tpp:9-58) and stored round-robin over the 64 cells
+//     of a bin: round r holds the r-th particle of every cell that has one;
+//   * one wavefront owns one bin, lane c owns cell c.  All particles of a cell share the same 27 stencil
+//     nodes, so the lane accumulates its 27 x 7 node contributions IN REGISTERS across its particles, then
+//     adds them into a per-wave LDS arena of 6^3 nodes x 7 channels in 27 conflict-free phases (plain
+//     ds_read/ds_write: for a fixed stencil offset the 64 cells map to 64 distinct nodes on 32 distinct
+//     banks per half-wave), and the arena is flushed ONCE to the grid with global_atomic_add_f32.
+//     LDS float atomics are deliberately NOT used: ds_add_f32 measures 193 cycles per wave-instruction on
+//     gfx950 (3 cycles per lane, serialised) against 4.2 for ds_add_u32 and 11 for a read-add-write pair
+//     (tools/lds_bench.hip, profiles/); the first version of this kernel spent 94 % of its time in them;
+//   * particles that left their cell since the last re-binning are queued and handled by the exact
+//     particle-order kernel afterwards, so results never depend on how fresh the bins are;
 //   * the 3x3 SVD is per-lane scalar VALU (quaternion Jacobi, v_rsq_f32): it is not a dense
 //     contraction, so no MFMA;
-//   * G2P stages the block's velocity arena in LDS once and gathers from there.
+//   * G2P: the lane loads the 27 x 3 node velocities of its cell from the LDS arena once and keeps them in
+//     registers for all its particles.
 // Algorithmic HBM bytes per particle: P2G 100 B read (+ 7 B grid), G2P 48 B read + 96 B write (+1.5 B grid).
 #include "bht.hpp"
 
@@ -277,7 +284,6 @@ struct MpmDev {
   Material mat;
   int model;
   float dx, dt;
-  int dbg;  // investigation switches (env ZS_ROCM_DEBUG): 1 skip LDS atomics, 2 skip flush, 4 skip stress
 };
 
 // per-particle constitutive update -> contrib = -dt * D_inv * (P F^T vol)   (P2G.hpp:60-105)
@@ -334,6 +340,10 @@ __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblo
 }
 
 // ======================================================================================= binning
+// A "bin" is a 4x4x4 group of cells = 64 cells = one wavefront.  SIDE 4: bin == grid block.  SIDE 8: a grid
+// block holds 2x2x2 bins, bin = block * 8 + sub, sub = ((lx>>2)*2 + (ly>>2))*2 + (lz>>2).
+template <int SIDE> constexpr int bins_per_block() { return (SIDE / 4) * (SIDE / 4) * (SIDE / 4); }
+
 template <int SIDE>
 __global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> pos, size_t n, float dx, unsigned *cellCount,
                                                         unsigned *cellOf, unsigned *rankOf, int *err) {
@@ -354,7 +364,9 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> po
     cellOf[i] = 0xffffffffu;
     return;
   }
-  const unsigned cell = (unsigned)b * (SIDE * SIDE * SIDE) + (unsigned)((loc[0] * SIDE + loc[1]) * SIDE + loc[2]);
+  const int sub = SIDE == 4 ? 0 : (((loc[0] >> 2) * 2 + (loc[1] >> 2)) * 2 + (loc[2] >> 2));
+  const unsigned cell = ((unsigned)b * bins_per_block<SIDE>() + sub) * 64u +
+                        (unsigned)(((loc[0] & 3) * 4 + (loc[1] & 3)) * 4 + (loc[2] & 3));
   cellOf[i] = cell;
   rankOf[i] = atomicAdd(&cellCount[cell], 1u);
 }
@@ -365,45 +377,23 @@ __global__ __launch_bounds__(256) void bin_place_kernel(size_t n, const unsigned
   const unsigned c = cellOf[i];
   if (c != 0xffffffffu) byCell[cellStart[c] + rankOf[i]] = (int)i;
 }
-// one workgroup (SIDE^3 threads, thread = cell) per grid block: (cell, rank) order -> (rank, cell) order
-template <int SIDE>
-__global__ void bin_roundrobin_kernel(int nblocks, const unsigned *cellStart, const unsigned *cellCount, const int *byCell,
-                                      int *order, int *blockStart, unsigned total) {
-  constexpr int NC = SIDE * SIDE * SIDE, NW = NC / 64;
-  __shared__ unsigned sWave[NW > 1 ? NW : 1];
-  __shared__ unsigned sMax;
-  const int b = blockIdx.x, c = threadIdx.x;
-  const unsigned cnt = cellCount[(size_t)b * NC + c], st = cellStart[(size_t)b * NC + c];
-  const unsigned bstart = cellStart[(size_t)b * NC];
+// one wave per bin, lane = cell: (cell, rank) order -> (rank, cell) order
+__global__ __launch_bounds__(64) void bin_roundrobin_kernel(int nbins, const unsigned *cellStart, const unsigned *cellCount,
+                                                            const int *byCell, int *order, int *binStart, unsigned total) {
+  const int bin = blockIdx.x, c = threadIdx.x;
+  const unsigned cnt = cellCount[(size_t)bin * 64 + c], st = cellStart[(size_t)bin * 64 + c];
+  unsigned base = shfl(st, 0);
   if (c == 0) {
-    blockStart[b] = (int)bstart;
-    if (b == nblocks - 1) blockStart[nblocks] = (int)total;
-    sMax = 0;
+    binStart[bin] = (int)base;
+    if (bin == nbins - 1) binStart[nbins] = (int)total;
   }
-  __syncthreads();
-  atomicMax(&sMax, cnt);
-  __syncthreads();
-  const unsigned maxc = sMax;
-  unsigned base = bstart;
   const unsigned long long lt = lanemask_lt();
-  for (unsigned r = 0; r < maxc; ++r) {
+  for (unsigned r = 0;; ++r) {
     const bool has = cnt > r;
     const unsigned long long m = __ballot(has);
-    unsigned before = (unsigned)__popcll(m & lt), tot = (unsigned)__popcll(m);
-    if constexpr (NW > 1) {
-      if (lane_id() == 0) sWave[wave_id()] = tot;
-      __syncthreads();
-      unsigned all = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        if (w == wave_id()) before += all;
-        all += sWave[w];
-      }
-      tot = all;
-      __syncthreads();
-    }
-    if (has) order[base + before] = byCell[st + r];
-    base += tot;
+    if (!m) break;
+    if (has) order[base + (unsigned)__popcll(m & lt)] = byCell[st + r];
+    base += (unsigned)__popcll(m);
   }
 }
 
@@ -471,97 +461,181 @@ __global__ __launch_bounds__(256) void p2g_global_kernel(MpmDev mp, ParticlesDev
 }
 
 // ---- binned path
-template <int SIDE> struct ArenaLds {
-  static constexpr int W = SIDE + 2;
-  // strides (in floats).  SIDE 4: a wave's lanes are the 64 cells (x,y,z) of the block; z + 8 y + 52 x maps each
-  // 32-lane group onto 32 distinct banks for any fixed stencil offset.  SIDE 8: rows padded to 12.
-  static constexpr int SY = SIDE == 4 ? 8 : 12;
-  static constexpr int SX = SIDE == 4 ? 52 : W * 12;
-  static constexpr int CH = W * SX;
+// LDS arena of one bin: 6^3 nodes, strides (floats) z + 8 y + 52 x: for a fixed stencil offset the 64 cells of
+// a bin land on 32 distinct banks per 32-lane half.
+struct ArenaLds {
+  static constexpr int W = 6;
+  static constexpr int SY = 8, SX = 52, CH = W * SX;
   __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
 };
 
-template <int SIDE> constexpr int binned_wg() { return SIDE == 4 ? 256 : 512; }
+// geometry of bin `bin`: grid block, origin of the bin inside the block (cells), origin in world cells
+template <int SIDE> struct BinGeom {
+  int block, o[3], org[3];
+  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin) {
+    constexpr int BPB = bins_per_block<SIDE>();
+    block = bin / BPB;
+    const int sub = bin % BPB;
+    o[0] = SIDE == 4 ? 0 : ((sub >> 2) & 1) * 4;
+    o[1] = SIDE == 4 ? 0 : ((sub >> 1) & 1) * 4;
+    o[2] = SIDE == 4 ? 0 : (sub & 1) * 4;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) org[d] = t.activeKeys[3 * (size_t)block + d] * SIDE + o[d];
+  }
+};
+
+// arena node (x,y,z) of a bin -> (neighbour slot 0..7, cell id) in the grid block layout
+template <int SIDE> __device__ __forceinline__ void arena_to_grid(const int (&o)[3], int x, int y, int z, int &slot, int &cell) {
+  const int gx = o[0] + x, gy = o[1] + y, gz = o[2] + z;
+  slot = ((gx >= SIDE) << 2) | ((gy >= SIDE) << 1) | (gz >= SIDE);
+  cell = ((gx & (SIDE - 1)) * SIDE + (gy & (SIDE - 1))) * SIDE + (gz & (SIDE - 1));
+}
 
 template <int SIDE, int MODEL>
-__global__ __launch_bounds__(binned_wg<SIDE>()) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *blockStart,
-                                                         const int *nbr) {
-  using AL = ArenaLds<SIDE>;
-  constexpr int NC = SIDE * SIDE * SIDE, W = AL::W;
+__global__ __launch_bounds__(64) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+                                                        const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  using AL = ArenaLds;
+  constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float arena[7 * AL::CH];
-  const int b = blockIdx.x;
-  const int start = blockStart[b], end = blockStart[b + 1];
-  if (start == end) return;  // ghost / empty block: nothing to scatter (uniform exit)
-  for (int k = threadIdx.x; k < 7 * AL::CH; k += blockDim.x) arena[k] = 0.f;
-  const int bk0 = t.activeKeys[3 * (size_t)b] * SIDE, bk1 = t.activeKeys[3 * (size_t)b + 1] * SIDE,
-            bk2 = t.activeKeys[3 * (size_t)b + 2] * SIDE;
-  __syncthreads();
+  const int bin = blockIdx.x;
+  const int start = binStart[bin], end = binStart[bin + 1];
+  if (start == end) return;  // empty bin (ghost block): uniform exit
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
+  const BinGeom<SIDE> geo(t, bin);
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
-  for (int i = start + (int)threadIdx.x; i < end; i += (int)blockDim.x) {
-    float pos[3];
-    load_attr<3>(ps.pos, (size_t)i, pos);
-    Arena ar;
-    make_arena(mp.dx, pos, ar);
-    const int lx = ar.corner[0] - bk0, ly = ar.corner[1] - bk1, lz = ar.corner[2] - bk2;
-    if ((unsigned)lx >= (unsigned)SIDE || (unsigned)ly >= (unsigned)SIDE || (unsigned)lz >= (unsigned)SIDE) {
-      // particle has left its bin since the last re-binning: exact but slow path
-      p2g_scatter_global<SIDE, MODEL>(mp, ps, (size_t)i, t, grid, D_inv);
-      continue;
-    }
-    float vel[3], C[9], contrib[9];
-    load_attr<3>(ps.vel, (size_t)i, vel);
-    load_attr<9>(ps.C, (size_t)i, C);
-    const float mass = ps.mass.base[ps.mass.off((size_t)i)];
-    if (!(mp.dbg & 4)) particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
-    else load_attr<9>(ps.F, (size_t)i, contrib);
-    float *a0 = arena + AL::at(lx, ly, lz);
-    if (mp.dbg & 1) {
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < 9; ++d) acc += contrib[d] + C[d];
-      acc += vel[0] + vel[1] + vel[2] + mass + ar.w[0][0] + ar.w[1][1] + ar.w[2][2];
-      if (acc == 1.2345e30f) atomicAdd(a0, acc);
-      continue;
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
-          float Wt = ar.w[0][a];
-          Wt *= ar.w[1][bb];
-          Wt *= ar.w[2][c];
-          float *g = a0 + AL::at(a, bb, c);
-          atomicAdd(g, mass * Wt);  // ds_add_f32
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            atomicAdd(g + (1 + d) * AL::CH, Wt * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2)));
-            atomicAdd(g + (4 + d) * AL::CH, (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * Wt);
-          }
-        }
-  }
+
+  const unsigned long long lt = lanemask_lt();
+  float *a0 = arena + AL::at(cx, cy, cz);
   __syncthreads();
-  if (mp.dbg & 2) return;
-  // flush: consecutive threads -> consecutive z of one (channel, x, y) row
+  // Two sweeps over the bin's particles keep the register-resident stencil at 27 x 4 (mass, momentum) and
+  // 27 x 3 (stress) accumulators instead of 27 x 7 = 189, which would cap occupancy at one wave per SIMD;
+  // the price is reading x twice (+12 B/particle).
+  {  // ---- sweep A: m, m v + m C (xi - xp)
+    float acc[27][4];
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) acc[k][ch] = 0.f;
+    int base = start;
+    for (unsigned r = 0;; ++r) {
+      const bool has = cnt > r;
+      const unsigned long long m = __ballot(has);
+      if (!m) break;
+      const int i = base + __popcll(m & lt);
+      base += __popcll(m);
+      if (!has) continue;
+      float pos[3];
+      load_attr<3>(ps.pos, (size_t)i, pos);
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
+        stale[atomicAdd(staleCount, 1)] = i;  // left its cell since the last re-binning: exact path afterwards
+        continue;
+      }
+      float vel[3], C[9];
+      load_attr<3>(ps.vel, (size_t)i, vel);
+      load_attr<9>(ps.C, (size_t)i, C);
+      const float mass = ps.mass.base[ps.mass.off((size_t)i)];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
+            float Wt = ar.w[0][a];
+            Wt *= ar.w[1][bb];
+            Wt *= ar.w[2][c];
+            float(&A)[4] = acc[(a * 3 + bb) * 3 + c];
+            A[0] += mass * Wt;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) A[1 + d] += Wt * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2));
+          }
+    }
+    // 27 phases: in phase (a,b,c) lane (cx,cy,cz) owns node (cx+a, cy+b, cz+c) -- all 64 nodes distinct
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) g[ch * AL::CH] += acc[k][ch];
+      __syncthreads();
+    }
+  }
+  {  // ---- sweep B: rhs = -dt D_inv (P F^T vol) (xi - xp) W
+    float acc[27][3];
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) acc[k][ch] = 0.f;
+    int base = start;
+    for (unsigned r = 0;; ++r) {
+      const bool has = cnt > r;
+      const unsigned long long m = __ballot(has);
+      if (!m) break;
+      const int i = base + __popcll(m & lt);
+      base += __popcll(m);
+      if (!has) continue;
+      float pos[3];
+      load_attr<3>(ps.pos, (size_t)i, pos);
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) continue;
+      float contrib[9];
+      particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
+            float Wt = ar.w[0][a];
+            Wt *= ar.w[1][bb];
+            Wt *= ar.w[2][c];
+            float(&A)[3] = acc[(a * 3 + bb) * 3 + c];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) A[d] += (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * Wt;
+          }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3) + 4 * AL::CH;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) g[ch * AL::CH] += acc[k][ch];
+      __syncthreads();
+    }
+  }
+  // flush: consecutive lanes -> consecutive z of one (channel, x, y) row
   int nb[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)b * 8 + o];
-  for (int k = threadIdx.x; k < 7 * W * W * W; k += blockDim.x) {
-    const int ch = k / (W * W * W), node = k % (W * W * W);
-    const int x = node / (W * W), y = (node / W) % W, z = node % W;
+  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)geo.block * 8 + o];
+  for (int k = lane; k < 7 * 216; k += 64) {
+    const int ch = k / 216, node = k % 216;
+    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
     const float v = arena[ch * AL::CH + AL::at(x, y, z)];
     if (v == 0.f) continue;
-    const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+    int slot, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
     int bn = nb[0];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) bn = (o == q) ? nb[q] : bn;
+    for (int q = 1; q < 8; ++q) bn = (slot == q) ? nb[q] : bn;
     if (bn < 0) continue;
-    const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
     unsafeAtomicAdd(grid + ((size_t)bn * 7 + ch) * NC + cell, v);
   }
+}
+
+// exact path for the queued particles (persistent grid-stride over a device-side count)
+template <int SIDE, int MODEL>
+__global__ __launch_bounds__(256) void p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *stale,
+                                                        const int *staleCount) {
+  const int n = *staleCount;
+  const float dxi = 1.0f / mp.dx;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    p2g_scatter_global<SIDE, MODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
 }
 
 // ======================================================================================= grid update
@@ -671,44 +745,63 @@ template <int SIDE> __global__ __launch_bounds__(256) void g2p_global_kernel(Mpm
 }
 
 template <int SIDE>
-__global__ __launch_bounds__(binned_wg<SIDE>()) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *blockStart,
-                                                         const int *nbr) {
-  using AL = ArenaLds<SIDE>;
-  constexpr int NC = SIDE * SIDE * SIDE, W = AL::W;
+__global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *binStart,
+                                                        const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  using AL = ArenaLds;
+  constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float arena[3 * AL::CH];
-  const int b = blockIdx.x;
-  const int start = blockStart[b], end = blockStart[b + 1];
+  const int bin = blockIdx.x;
+  const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
+  const int lane = threadIdx.x;
+  const BinGeom<SIDE> geo(t, bin);
   int nb[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)b * 8 + o];
-  for (int k = threadIdx.x; k < 3 * W * W * W; k += blockDim.x) {
-    const int ch = k / (W * W * W), node = k % (W * W * W);
-    const int x = node / (W * W), y = (node / W) % W, z = node % W;
-    const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)geo.block * 8 + o];
+  for (int k = lane; k < 3 * 216; k += 64) {
+    const int ch = k / 216, node = k % 216;
+    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
+    int slot, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
     int bn = nb[0];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) bn = (o == q) ? nb[q] : bn;
-    float v = 0.f;
-    if (bn >= 0) v = grid[((size_t)bn * 7 + 1 + ch) * NC + ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1))];
-    arena[ch * AL::CH + AL::at(x, y, z)] = v;
+    for (int q = 1; q < 8; ++q) bn = (slot == q) ? nb[q] : bn;
+    arena[ch * AL::CH + AL::at(x, y, z)] = bn >= 0 ? grid[((size_t)bn * 7 + 1 + ch) * NC + cell] : 0.f;
   }
-  const int bk0 = t.activeKeys[3 * (size_t)b] * SIDE, bk1 = t.activeKeys[3 * (size_t)b + 1] * SIDE,
-            bk2 = t.activeKeys[3 * (size_t)b + 2] * SIDE;
   __syncthreads();
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  // the 27 x 3 node velocities of this lane's cell, register resident for all its particles
+  float nv[27][3];
+  {
+    const float *a0 = arena + AL::at(cx, cy, cz);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+      nv[k][0] = g[0];
+      nv[k][1] = g[AL::CH];
+      nv[k][2] = g[2 * AL::CH];
+    }
+  }
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
-  for (int i = start + (int)threadIdx.x; i < end; i += (int)blockDim.x) {
+  int base = start;
+  const unsigned long long lt = lanemask_lt();
+  for (unsigned r = 0;; ++r) {
+    const bool has = cnt > r;
+    const unsigned long long m = __ballot(has);
+    if (!m) break;
+    const int i = base + __popcll(m & lt);
+    base += __popcll(m);
+    if (!has) continue;
     float pos[3];
     load_attr<3>(ps.pos, (size_t)i, pos);
     Arena ar;
     make_arena(mp.dx, pos, ar);
-    const int lx = ar.corner[0] - bk0, ly = ar.corner[1] - bk1, lz = ar.corner[2] - bk2;
-    if ((unsigned)lx >= (unsigned)SIDE || (unsigned)ly >= (unsigned)SIDE || (unsigned)lz >= (unsigned)SIDE) {
-      g2p_gather_global<SIDE>(mp, ps, (size_t)i, t, grid, D_inv);
+    if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
+      stale[atomicAdd(staleCount, 1)] = i;
       continue;
     }
-    const float *a0 = arena + AL::at(lx, ly, lz);
     float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -716,8 +809,7 @@ __global__ __launch_bounds__(binned_wg<SIDE>()) void g2p_binned_kernel(MpmDev mp
       for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float *g = a0 + AL::at(a, bb, c);
-          const float vi[3] = {g[0], g[AL::CH], g[2 * AL::CH]};
+          const float(&vi)[3] = nv[(a * 3 + bb) * 3 + c];
           const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)bb * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
           float Wt = ar.w[0][a];
           Wt *= ar.w[1][bb];
@@ -729,6 +821,15 @@ __global__ __launch_bounds__(binned_wg<SIDE>()) void g2p_binned_kernel(MpmDev mp
         }
     g2p_finish<SIDE>(mp, ps, (size_t)i, pos, vel, C);
   }
+}
+
+template <int SIDE>
+__global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *stale,
+                                                        const int *staleCount) {
+  const int n = *staleCount;
+  const float dxi = 1.0f / mp.dx;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    g2p_gather_global<SIDE>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
 }
 
 // ======================================================================================= misc kernels
@@ -794,8 +895,6 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.beta = p->beta;
   d.mat.yieldSurface = p->yieldSurface;
   d.mat.volCorrection = p->volCorrection;
-  static const int dbg = getenv("ZS_ROCM_DEBUG") ? atoi(getenv("ZS_ROCM_DEBUG")) : 0;
-  d.dbg = dbg;
   return d;
 }
 static ParticlesDev make_particles(const zs_rocm_particles &p) {
@@ -846,18 +945,18 @@ void zs_rocm_mpm_build_neighbors(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, 
 }
 
 void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side,
-                               int *order, int *blockStart) {
+                               int *order, int *binStart, unsigned *cellCount) {
   Launch L(pol, "bin_particles");
   const int nb = bht_size(tab->t, L.stream);
   if (nb == 0) return;
-  const size_t nc = (size_t)side * side * side, ncells = (size_t)nb * nc;
-  unsigned *cellCount = (unsigned *)L.temp(sizeof(unsigned) * (ncells + 1));
+  const int nbins = nb * (side == 4 ? 1 : 8);
+  const size_t ncells = (size_t)nbins * 64;
   unsigned *cellStart = (unsigned *)L.temp(sizeof(unsigned) * (ncells + 1));
   unsigned *cellOf = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
   unsigned *rankOf = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
   int *byCell = (int *)L.temp(sizeof(int) * (n + 1));
   int *err = (int *)L.temp(sizeof(int));
-  ZSR_CHECK(hipMemsetAsync(cellCount, 0, sizeof(unsigned) * (ncells + 1), L.stream));
+  ZSR_CHECK(hipMemsetAsync(cellCount, 0, sizeof(unsigned) * ncells, L.stream));
   ZSR_CHECK(hipMemsetAsync(err, 0, sizeof(int), L.stream));
   BhtDev t = tab->t.dev();
   Port<float> pp = make_port<float>(pos);
@@ -867,16 +966,12 @@ void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs
     else
       hipLaunchKernelGGL((bin_count_kernel<8>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err);
   }
-  exclusive_scan_u32(L, cellCount, ncells + 1, cellStart);
+  exclusive_scan_u32(L, cellCount, ncells, cellStart);
   if (n)
     hipLaunchKernelGGL(bin_place_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, (const unsigned *)cellStart,
                        (const unsigned *)cellOf, (const unsigned *)rankOf, byCell);
-  if (side == 4)
-    hipLaunchKernelGGL((bin_roundrobin_kernel<4>), dim3(nb), dim3(64), 0, L.stream, nb, (const unsigned *)cellStart,
-                       (const unsigned *)cellCount, (const int *)byCell, order, blockStart, (unsigned)n);
-  else
-    hipLaunchKernelGGL((bin_roundrobin_kernel<8>), dim3(nb), dim3(512), 0, L.stream, nb, (const unsigned *)cellStart,
-                       (const unsigned *)cellCount, (const int *)byCell, order, blockStart, (unsigned)n);
+  hipLaunchKernelGGL(bin_roundrobin_kernel, dim3(nbins), dim3(64), 0, L.stream, nbins, (const unsigned *)cellStart,
+                     (const unsigned *)cellCount, (const int *)byCell, order, binStart, (unsigned)n);
   int herr = 0;
   ZSR_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, L.stream));
   ZSR_CHECK(hipStreamSynchronize(L.stream));
@@ -884,17 +979,23 @@ void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs
 }
 
 void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, float *grid,
-                     const int *blockStart, const int *nbr) {
+                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
   Launch L(pol, "P2GTransfer");
   if (!ps.n) return;
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
-  if (blockStart && nbr) {
-    const int nb = bht_size(tab->t, L.stream);
-    if (!nb) return;
-#define CALL_P2G_BINNED(S, M) \
-  hipLaunchKernelGGL((p2g_binned_kernel<S, M>), dim3(nb), dim3(binned_wg<S>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr)
+  if (binStart && cellCount && nbr) {
+    if (!nblocks) return;
+    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
+    int *staleCount = stale + ps.n + 32;
+    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
+#define CALL_P2G_BINNED(S, M)                                                                                              \
+  hipLaunchKernelGGL((p2g_binned_kernel<S, M>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
+                     stale, staleCount);                                                                                   \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,       \
+                     (const int *)staleCount)
     ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_P2G_BINNED);
   } else {
 #define CALL_P2G_GLOBAL(S, M) \
@@ -917,19 +1018,25 @@ void zs_rocm_mpm_grid_update(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, f
 }
 
 void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *grid,
-                     const int *blockStart, const int *nbr) {
+                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
   Launch L(pol, "G2PTransfer");
   if (!ps.n) return;
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
-  if (blockStart && nbr) {
-    const int nb = bht_size(tab->t, L.stream);
-    if (!nb) return;
-    if (p->side == 4)
-      hipLaunchKernelGGL((g2p_binned_kernel<4>), dim3(nb), dim3(binned_wg<4>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr);
-    else
-      hipLaunchKernelGGL((g2p_binned_kernel<8>), dim3(nb), dim3(binned_wg<8>()), 0, L.stream, mp, pd, t, grid, blockStart, nbr);
+  if (binStart && cellCount && nbr) {
+    if (!nblocks) return;
+    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
+    int *staleCount = stale + ps.n + 32;
+    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
+    if (p->side == 4) {
+      hipLaunchKernelGGL((g2p_binned_kernel<4>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, staleCount);
+      hipLaunchKernelGGL((g2p_stale_kernel<4>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale, (const int *)staleCount);
+    } else {
+      hipLaunchKernelGGL((g2p_binned_kernel<8>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, staleCount);
+      hipLaunchKernelGGL((g2p_stale_kernel<8>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale, (const int *)staleCount);
+    }
   } else {
     if (p->side == 4)
       hipLaunchKernelGGL((g2p_global_kernel<4>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid);

@@ -34,7 +34,7 @@ class MpmTransfer:
         self.table = None
         self.grid = None
         self.nblocks = 0
-        self.order = self.block_start = self.nbr = None
+        self.order = self.bin_start = self.cell_count = self.nbr = None
         self.binned = False
 
     # ------------------------------------------------------------------ particle access
@@ -92,9 +92,11 @@ class MpmTransfer:
         L = lib()
         if self.order is None or self.order.numel() != self.n:
             self.order = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        self.block_start = torch.empty(self.nblocks + 1, dtype=torch.int32, device=self.device)
+        self.nbins = self.nblocks * (self.side // 4) ** 3  # a bin = 4x4x4 cells = one wavefront
+        self.bin_start = torch.empty(self.nbins + 1, dtype=torch.int32, device=self.device)
+        self.cell_count = torch.empty(self.nbins * 64, dtype=torch.int32, device=self.device)
         L.zs_rocm_mpm_bin_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
-                                    self.order.data_ptr(), self.block_start.data_ptr())
+                                    self.order.data_ptr(), self.bin_start.data_ptr(), self.cell_count.data_ptr())
         if self.buf2 is None:
             self.buf2 = torch.empty_like(self.buf)
         L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
@@ -109,9 +111,11 @@ class MpmTransfer:
 
     def p2g(self, binned=None):
         binned = self.binned if binned is None else binned
-        bs = self.block_start.data_ptr() if binned else None
+        bs = self.bin_start.data_ptr() if binned else None
+        cc = self.cell_count.data_ptr() if binned else None
         nb = self.nbr.data_ptr() if binned else None
-        lib().zs_rocm_mpm_p2g(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(), bs, nb)
+        lib().zs_rocm_mpm_p2g(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
+                              self.nblocks, bs, cc, nb)
 
     def grid_update(self, extf=(0.0, 0.0, 0.0), max_vel=None):
         e = (C.c_float * 3)(*extf)
@@ -120,9 +124,11 @@ class MpmTransfer:
 
     def g2p(self, binned=None):
         binned = self.binned if binned is None else binned
-        bs = self.block_start.data_ptr() if binned else None
+        bs = self.bin_start.data_ptr() if binned else None
+        cc = self.cell_count.data_ptr() if binned else None
         nb = self.nbr.data_ptr() if binned else None
-        lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(), bs, nb)
+        lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
+                              self.nblocks, bs, cc, nb)
 
     def grid_by_key(self):
         """{(bx,by,bz): ndarray[7, side^3]} -- for comparisons that must not depend on block numbering."""
