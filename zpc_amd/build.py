@@ -16,6 +16,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
 
 
+# per-file flags.  mpm.hip: the SLP vectoriser packs independent scalar f32 ops of the per-lane 3x3 SVD / stencil code
+# into v_pk_*_f32 (same FLOP rate as two scalar ops on CDNA4) and pays ~25 % extra v_mov to form the register pairs:
+# 901 -> 772 instructions and ~2390 -> ~1540 issue cycles for the SVD alone (MI355X guide, 5.6: "an anti-lever").
+EXTRA_FLAGS = {"mpm.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -31,8 +37,8 @@ def build_hip(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs) or _newer(os.path.abspath(__file__), obj):
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

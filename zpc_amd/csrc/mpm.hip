@@ -203,11 +203,13 @@ __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, flo
   const float tr = sum_eps + logJp;
   float eh[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) eh[i] = eps[i] - (tr / 3.f);
+  for (int i = 0; i < 3; ++i) eh[i] = eps[i] - (tr * (1.f / 3.f));
   const float ehn = sqrtf(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
   bool newF = false;
+  float Hs[3] = {0.f, 0.f, 0.f};  // log of the projected singular values
   if (tr >= 0.f) {  // case II: cone tip
     NS[0] = NS[1] = NS[2] = expf(m.cohesion);
+    Hs[0] = Hs[1] = Hs[2] = m.cohesion;
     newF = true;
     if (m.volCorrection) logJp = m.beta * sum_eps + logJp;
   } else if (m.mu != 0.f) {
@@ -218,20 +220,27 @@ __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, flo
 #pragma unroll
       for (int i = 0; i < 3; ++i) H[i] = eps[i] + m.cohesion;
     } else {  // case III: onto the cone surface
+      const float sc = dg * __frcp_rn(ehn);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) H[i] = eps[i] - (dg / ehn) * eh[i] + m.cohesion;
+      for (int i = 0; i < 3; ++i) H[i] = eps[i] - sc * eh[i] + m.cohesion;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) NS[i] = expf(H[i]);
+    for (int i = 0; i < 3; ++i) {
+      NS[i] = expf(H[i]);
+      Hs[i] = H[i];
+    }
     newF = true;
   }
   if (newF) mat_diag_matT(F, U, NS, V);
-  const float l0 = logf(NS[0]), l1 = logf(NS[1]), l2 = logf(NS[2]);
-  const float trl = l0 + l1 + l2;
+  // New_S_log = log(New_S) (ConstitutiveModel.hpp:309): New_S = exp(H) was just computed, so log(New_S) == H up to
+  // one rounding; the mu == 0 && trace < 0 corner keeps the reference's log(0) = -inf
+  float lg[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) lg[i] = NS[i] > 0.f ? Hs[i] : -INFINITY;
+  const float trl = lg[0] + lg[1] + lg[2];
   float Ph[3];
-  Ph[0] = (smu * l0 + m.lam * trl) / NS[0];
-  Ph[1] = (smu * l1 + m.lam * trl) / NS[1];
-  Ph[2] = (smu * l2 + m.lam * trl) / NS[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Ph[i] = (smu * lg[i] + m.lam * trl) * __frcp_rn(NS[i]);
   float P[9];
   mat_diag_matT(P, U, Ph, V);
   pft_vol(P, F, m.volume, PF);
@@ -244,10 +253,14 @@ struct Arena {
   float lp[3];    // local position * dx
   float w[3][3];  // w[axis][k]
 };
+// X = pos * (1/dx): the reference divides (simulation/Utils.hpp:52-55); the product differs by <= 1 ulp, which moves
+// a weight by O(1e-7) and never changes which bin a particle is stored in because the binning kernel uses this
+// same expression.
 __device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Arena &a) {
+  const float dxinv = 1.0f / dx;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const float X = pos[d] / dx;
+    const float X = pos[d] * dxinv;
     const float fl = floorf(X - 0.5f);
     a.corner[d] = (int)fl;
     const float lpn = X - fl;
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> po
   int key[3], loc[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const int c = (int)floorf(p[d] / dx - 0.5f);
+    const int c = (int)floorf(p[d] * (1.0f / dx) - 0.5f);
     loc[d] = c & (SIDE - 1);
     key[d] = (c - loc[d]) / SIDE;
   }
@@ -491,8 +504,46 @@ template <int SIDE> __device__ __forceinline__ void arena_to_grid(const int (&o)
   cell = ((gx & (SIDE - 1)) * SIDE + (gy & (SIDE - 1))) * SIDE + (gz & (SIDE - 1));
 }
 
+// round-robin walk of one bin: round r visits the r-th particle of every cell (lane) that has one; the lanes
+// that take part in a round read consecutive particles (coalesced), the index needs only ballots on the counts,
+// so the loads of round r+1 can be issued before round r is computed (software pipelining: with ~220 VGPRs only
+// two waves share a SIMD and memory latency must be hidden inside the wave).
+struct RoundWalk {
+  unsigned cnt, r = 0;
+  int base;
+  unsigned long long lt;
+  __device__ __forceinline__ RoundWalk(unsigned cnt_, int start) : cnt(cnt_), base(start), lt(lanemask_lt()) {}
+  // returns whether this lane has a particle in the next round; any = some lane has
+  __device__ __forceinline__ bool next(int &i, bool &any) {
+    const bool has = cnt > r;
+    const unsigned long long m = __ballot(has);
+    any = m != 0ull;
+    i = base + __popcll(m & lt);
+    base += __popcll(m);
+    ++r;
+    return has;
+  }
+};
+struct RecA {  // sweep A inputs: x, v, C, m (16 floats)
+  float pos[3], vel[3], C[9], mass;
+  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
+    load_attr<3>(ps.pos, i, pos);
+    load_attr<3>(ps.vel, i, vel);
+    load_attr<9>(ps.C, i, C);
+    mass = ps.mass.base[ps.mass.off(i)];
+  }
+};
+template <int MODEL> struct RecB {  // sweep B inputs: x, F (, logJp)
+  float pos[3], F[9], logJp;
+  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
+    load_attr<3>(ps.pos, i, pos);
+    load_attr<9>(ps.F, i, F);
+    if constexpr (MODEL != ZS_MPM_FIXED_COROTATED) logJp = ps.logJp.base[ps.logJp.off(i)];
+  }
+};
+
 template <int SIDE, int MODEL>
-__global__ __launch_bounds__(64) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+__global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
                                                         const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -508,7 +559,6 @@ __global__ __launch_bounds__(64) void p2g_binned_kernel(MpmDev mp, ParticlesDev 
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
 
-  const unsigned long long lt = lanemask_lt();
   float *a0 = arena + AL::at(cx, cy, cz);
   __syncthreads();
   // Two sweeps over the bin's particles keep the register-resident stencil at 27 x 4 (mass, momentum) and
@@ -520,41 +570,58 @@ __global__ __launch_bounds__(64) void p2g_binned_kernel(MpmDev mp, ParticlesDev 
     for (int k = 0; k < 27; ++k)
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) acc[k][ch] = 0.f;
-    int base = start;
-    for (unsigned r = 0;; ++r) {
-      const bool has = cnt > r;
-      const unsigned long long m = __ballot(has);
-      if (!m) break;
-      const int i = base + __popcll(m & lt);
-      base += __popcll(m);
-      if (!has) continue;
-      float pos[3];
-      load_attr<3>(ps.pos, (size_t)i, pos);
-      Arena ar;
-      make_arena(mp.dx, pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-        stale[atomicAdd(staleCount, 1)] = i;  // left its cell since the last re-binning: exact path afterwards
-        continue;
-      }
-      float vel[3], C[9];
-      load_attr<3>(ps.vel, (size_t)i, vel);
-      load_attr<9>(ps.C, (size_t)i, C);
-      const float mass = ps.mass.base[ps.mass.off((size_t)i)];
+    RoundWalk walk(cnt, start);
+    int i0, i1;
+    bool any, any1;
+    bool has0 = walk.next(i0, any);
+    RecA cur, nxt;
+    if (has0) cur.load(ps, (size_t)i0);
+    while (any) {
+      const bool has1 = walk.next(i1, any1);
+      if (has1) nxt.load(ps, (size_t)i1);  // in flight while the current round is computed
+      if (has0) {
+        Arena ar;
+        make_arena(mp.dx, cur.pos, ar);
+        if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
+          stale[atomicAdd(staleCount, 1)] = i0;  // left its cell since the last re-binning: exact path afterwards
+        } else {
+          // W m (v + C (xi - xp)) is affine in the node offset: evaluate it as (Px[a] + Py[b]) + Pz[c] with the
+          // per-axis products hoisted -> 8 VALU ops per node instead of ~20 (rounding differs from the
+          // reference's association by O(1 ulp), inside the stated tolerance)
+          float Px[3][3], Py[3][3], Pz[3][3], wzm[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < 3; ++k) {
+            const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
-            float Wt = ar.w[0][a];
-            Wt *= ar.w[1][bb];
-            Wt *= ar.w[2][c];
-            float(&A)[4] = acc[(a * 3 + bb) * 3 + c];
-            A[0] += mass * Wt;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) A[1 + d] += Wt * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2));
+            for (int d = 0; d < 3; ++d) {
+              Px[k][d] = cur.C[d] * x0;
+              Py[k][d] = cur.C[3 + d] * x1;
+              Pz[k][d] = fmaf(cur.C[6 + d], x2, cur.vel[d]);
+            }
+            wzm[k] = ar.w[2][k] * cur.mass;
           }
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+              const float wxy = ar.w[0][a] * ar.w[1][bb];
+              const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float Wm = wxy * wzm[c];
+                float(&A)[4] = acc[(a * 3 + bb) * 3 + c];
+                A[0] += Wm;
+                A[1] = fmaf(Wm, q0 + Pz[c][0], A[1]);
+                A[2] = fmaf(Wm, q1 + Pz[c][1], A[2]);
+                A[3] = fmaf(Wm, q2 + Pz[c][2], A[3]);
+              }
+            }
+        }
+      }
+      cur = nxt;
+      has0 = has1;
+      i0 = i1;
+      any = any1;
     }
     // 27 phases: in phase (a,b,c) lane (cx,cy,cz) owns node (cx+a, cy+b, cz+c) -- all 64 nodes distinct
 #pragma unroll
@@ -571,35 +638,61 @@ __global__ __launch_bounds__(64) void p2g_binned_kernel(MpmDev mp, ParticlesDev 
     for (int k = 0; k < 27; ++k)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) acc[k][ch] = 0.f;
-    int base = start;
-    for (unsigned r = 0;; ++r) {
-      const bool has = cnt > r;
-      const unsigned long long m = __ballot(has);
-      if (!m) break;
-      const int i = base + __popcll(m & lt);
-      base += __popcll(m);
-      if (!has) continue;
-      float pos[3];
-      load_attr<3>(ps.pos, (size_t)i, pos);
-      Arena ar;
-      make_arena(mp.dx, pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) continue;
-      float contrib[9];
-      particle_contrib<MODEL>(mp, ps, (size_t)i, D_inv, contrib);
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)bb * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
-            float Wt = ar.w[0][a];
-            Wt *= ar.w[1][bb];
-            Wt *= ar.w[2][c];
-            float(&A)[3] = acc[(a * 3 + bb) * 3 + c];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) A[d] += (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * Wt;
+    RoundWalk walk(cnt, start);
+    int i0, i1;
+    bool any, any1;
+    bool has0 = walk.next(i0, any);
+    RecB<MODEL> cur, nxt;
+    if (has0) cur.load(ps, (size_t)i0);
+    while (any) {
+      const bool has1 = walk.next(i1, any1);
+      if (has1) nxt.load(ps, (size_t)i1);
+      if (has0) {
+        Arena ar;
+        make_arena(mp.dx, cur.pos, ar);
+        if (ar.corner[0] - geo.org[0] == cx && ar.corner[1] - geo.org[1] == cy && ar.corner[2] - geo.org[2] == cz) {
+          float contrib[9];
+          if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
+            stress_fixedcorotated(mp.mat, cur.F, contrib);
+          } else {
+            float lj = cur.logJp;
+            stress_sand(mp.mat, lj, cur.F, contrib);
+            ps.logJp.base[ps.logJp.off((size_t)i0)] = lj;  // P2G.hpp:101 (the projected F is not written back)
           }
+#pragma unroll
+          for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
+          float Qx[3][3], Qy[3][3], Qz[3][3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              Qx[k][d] = contrib[d] * x0;
+              Qy[k][d] = contrib[3 + d] * x1;
+              Qz[k][d] = contrib[6 + d] * x2;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+              const float wxy = ar.w[0][a] * ar.w[1][bb];
+              const float q0 = Qx[a][0] + Qy[bb][0], q1 = Qx[a][1] + Qy[bb][1], q2 = Qx[a][2] + Qy[bb][2];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float Wt = wxy * ar.w[2][c];
+                float(&A)[3] = acc[(a * 3 + bb) * 3 + c];
+                A[0] = fmaf(Wt, q0 + Qz[c][0], A[0]);
+                A[1] = fmaf(Wt, q1 + Qz[c][1], A[1]);
+                A[2] = fmaf(Wt, q2 + Qz[c][2], A[2]);
+              }
+            }
+        }
+      }
+      cur = nxt;
+      has0 = has1;
+      i0 = i1;
+      any = any1;
     }
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -673,6 +766,24 @@ __device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev 
   for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
   float oldF[9], tmp[9], F[9];
   load_attr<9>(ps.F, i, oldF);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+  store_attr<9>(ps.F, i, F);
+  store_attr<3>(ps.pos, i, pos);
+  store_attr<3>(ps.vel, i, vel);
+  store_attr<9>(ps.C, i, C);
+}
+
+template <int SIDE>
+__device__ __forceinline__ void g2p_finish_loaded(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&oldF)[9],
+                                                  const float (&vel)[3], const float (&C)[9]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
+  float tmp[9], F[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
 #pragma unroll
@@ -785,41 +896,45 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
-  int base = start;
-  const unsigned long long lt = lanemask_lt();
-  for (unsigned r = 0;; ++r) {
-    const bool has = cnt > r;
-    const unsigned long long m = __ballot(has);
-    if (!m) break;
-    const int i = base + __popcll(m & lt);
-    base += __popcll(m);
-    if (!has) continue;
-    float pos[3];
-    load_attr<3>(ps.pos, (size_t)i, pos);
-    Arena ar;
-    make_arena(mp.dx, pos, ar);
-    if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-      stale[atomicAdd(staleCount, 1)] = i;
-      continue;
+  RoundWalk walk(cnt, start);
+  int i0, i1;
+  bool any, any1;
+  bool has0 = walk.next(i0, any);
+  RecB<ZS_MPM_FIXED_COROTATED> cur, nxt;  // x, F
+  if (has0) cur.load(ps, (size_t)i0);
+  while (any) {
+    const bool has1 = walk.next(i1, any1);
+    if (has1) nxt.load(ps, (size_t)i1);
+    if (has0) {
+      Arena ar;
+      make_arena(mp.dx, cur.pos, ar);
+      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
+        stale[atomicAdd(staleCount, 1)] = i0;
+      } else {
+        float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float(&vi)[3] = nv[(a * 3 + bb) * 3 + c];
+              const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)bb * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
+              float Wt = ar.w[0][a];
+              Wt *= ar.w[1][bb];
+              Wt *= ar.w[2][c];
+#pragma unroll
+              for (int d = 0; d < 3; ++d) vel[d] += vi[d] * Wt;
+#pragma unroll
+              for (int d = 0; d < 9; ++d) C[d] += Wt * vi[d % 3] * xi[d / 3] * D_inv;
+            }
+        g2p_finish_loaded<SIDE>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
+      }
     }
-    float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float(&vi)[3] = nv[(a * 3 + bb) * 3 + c];
-          const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)bb * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
-          float Wt = ar.w[0][a];
-          Wt *= ar.w[1][bb];
-          Wt *= ar.w[2][c];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) vel[d] += vi[d] * Wt;
-#pragma unroll
-          for (int d = 0; d < 9; ++d) C[d] += Wt * vi[d % 3] * xi[d / 3] * D_inv;
-        }
-    g2p_finish<SIDE>(mp, ps, (size_t)i, pos, vel, C);
+    cur = nxt;
+    has0 = has1;
+    i0 = i1;
+    any = any1;
   }
 }
 
