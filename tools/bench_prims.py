@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks (BASELINE.json configs 1, 2 and the sort stress of config 5): reduce / exclusive_scan /
+radix_sort(_pair) throughput, TileVector AoSoA load/store, bht build -- each with its algorithmic bytes and the
+achieved fraction of the 8 TB/s HBM roofline.  python tools/bench_prims.py [--json out.json]"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zpc_amd as zs  # noqa: E402
+from zpc_amd.containers import Bht  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    pol = zs.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
+    rows = []
+
+    def add(name, n, unit_bytes, ms):
+        gbs = unit_bytes * n / (ms * 1e-3) / 1e9
+        rows.append({"name": name, "n": n, "ms": ms, "units_per_s": n / (ms * 1e-3), "algorithmic_bytes_per_unit": unit_bytes,
+                     "GBps": gbs, "frac_of_8TBps": gbs / PEAK})
+        print("%-44s n=%-10d %9.4f ms  %9.2f G/s  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, n, ms, n / ms / 1e6, gbs, 100 * gbs / PEAK), flush=True)
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for n in (1_000_000, 16_000_000, 64_000_000):
+        a = torch.randint(-2**30, 2**30, (n,), dtype=torch.int32, device="cuda", generator=g)
+        out1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out = torch.empty_like(a)
+        v = torch.arange(n, dtype=torch.int32, device="cuda")
+        vo = torch.empty_like(v)
+        add("reduce<i32,plus>", n, 4, timeit(lambda: zs.reduce(pol, a, None, out1)))
+        add("exclusive_scan<i32>", n, 8, timeit(lambda: zs.exclusive_scan(pol, a, out)))
+        add("radix_sort<i32> (32 bit)", n, 32, timeit(lambda: zs.radix_sort(pol, a, out), reps=5))
+        add("radix_sort_pair<i32,i32> (32 bit)", n, 64, timeit(lambda: zs.radix_sort_pair(pol, a, v, out, vo), reps=5))
+        del a, out, v, vo
+    # config 2: TileVector<f32,32>{m:1,x:3,v:3,F:9,C:9} load-all/store-all at 16M
+    for n, L, Cn in ((16_000_000, 32, 25), (64_000_000, 64, 26)):
+        tiles = (n + L - 1) // L
+        tv = torch.rand(tiles * L * Cn, dtype=torch.float32, device="cuda", generator=g)
+        add("TileVector<f32,%d> %d ch load+store" % (L, Cn), n, 8 * Cn, timeit(lambda: zs.lib().zs_rocm_tv_scale_f32(pol.handle, tv.data_ptr(), n, Cn, L, C.c_float(1.0001))))
+        del tv
+    # config 2: bht build, 16M random particles in [0,1)^3, dx = 1/256: cell keys (~10.6M distinct) and 8^3-block keys
+    n = 16_000_000
+    pos = torch.rand(n, 3, device="cuda", generator=g)
+    for name, keys in (("cell keys", torch.floor(pos * 256).to(torch.int32)), ("8^3-block keys", torch.floor(pos * 32).to(torch.int32))):
+        keys = keys.contiguous()
+        tab = Bht(3, n)
+
+        def build():
+            tab.reset(True)
+            tab.insert(pol, keys.data_ptr(), n)
+        ms = timeit(build, reps=3, warm=1)
+        torch.cuda.synchronize()
+        distinct = tab.size()
+        add("bht<int,3,int,16> build, %s (%d distinct)" % (name, distinct), n, 12 + 32.0 * distinct / n, ms)
+        del tab
+    if "--json" in sys.argv:
+        json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
