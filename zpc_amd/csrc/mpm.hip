@@ -71,7 +71,7 @@ template <int X, int Y, int Z> __device__ __forceinline__ void jacobi_conj(float
   q[1 + Z] = qz * ch + qw * sh;
 }
 
-template <int A, int B> __device__ __forceinline__ void cond_swap_cols(float (&rho)[3], float (&Bm)[3][3], float (&Vm)[3][3]) {
+template <int A, int B, bool SWAPV> __device__ __forceinline__ void cond_swap_cols(float (&rho)[3], float (&Bm)[3][3], float (&Vm)[3][3]) {
   const bool sw = rho[A] < rho[B];
   const float ra = rho[A], rb = rho[B];
   rho[A] = sw ? rb : ra;
@@ -81,9 +81,11 @@ template <int A, int B> __device__ __forceinline__ void cond_swap_cols(float (&r
     const float ba = Bm[r][A], bb = Bm[r][B];
     Bm[r][A] = sw ? bb : ba;
     Bm[r][B] = sw ? -ba : bb;
-    const float va = Vm[r][A], vb = Vm[r][B];
-    Vm[r][A] = sw ? vb : va;
-    Vm[r][B] = sw ? -va : vb;
+    if constexpr (SWAPV) {
+      const float va = Vm[r][A], vb = Vm[r][B];
+      Vm[r][A] = sw ? vb : va;
+      Vm[r][B] = sw ? -va : vb;
+    }
   }
 }
 
@@ -107,8 +109,11 @@ template <int P, int R> __device__ __forceinline__ void qr_step(float (&Bm)[3][3
   }
 }
 
-// A = U diag(S) V^T, column-major 9-vectors; U, V rotations, |S0| >= |S1| >= |S2| (math::svd convention)
-__device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (&Sg)[3], float (&V)[9]) {
+// A = U diag(S) V^T; U, V rotations, |S0| >= |S1| >= |S2| (math::svd convention).  Outputs as [row][col] arrays:
+// Um, Sg, and -- only when asked for -- Vm (sorted) and Bs = A V (sorted, before the QR), which lets the caller form
+// P F^T = U diag(Phat) (F V)^T without ever building P or re-multiplying by F.
+template <bool NEED_V, bool NEED_B>
+__device__ __forceinline__ void svd3_core(const float (&A)[9], float (&Um)[3][3], float (&Sg)[3], float (&Vm)[3][3], float (&Bs)[3][3]) {
   float S[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -123,7 +128,6 @@ __device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (
   }
   const float n = rsq(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const float w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
-  float Vm[3][3];
   Vm[0][0] = 1 - 2 * (y * y + z * z); Vm[0][1] = 2 * (x * y - w * z);     Vm[0][2] = 2 * (x * z + w * y);
   Vm[1][0] = 2 * (x * y + w * z);     Vm[1][1] = 1 - 2 * (x * x + z * z); Vm[1][2] = 2 * (y * z - w * x);
   Vm[2][0] = 2 * (x * z - w * y);     Vm[2][1] = 2 * (y * z + w * x);     Vm[2][2] = 1 - 2 * (x * x + y * y);
@@ -135,14 +139,29 @@ __device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (
   float rho[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) rho[c] = Bm[0][c] * Bm[0][c] + Bm[1][c] * Bm[1][c] + Bm[2][c] * Bm[2][c];
-  cond_swap_cols<0, 1>(rho, Bm, Vm);
-  cond_swap_cols<0, 2>(rho, Bm, Vm);
-  cond_swap_cols<1, 2>(rho, Bm, Vm);
-  float Um[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  cond_swap_cols<0, 1, NEED_V>(rho, Bm, Vm);
+  cond_swap_cols<0, 2, NEED_V>(rho, Bm, Vm);
+  cond_swap_cols<1, 2, NEED_V>(rho, Bm, Vm);
+  if constexpr (NEED_B) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Bs[r][c] = Bm[r][c];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Um[r][c] = r == c ? 1.f : 0.f;
   qr_step<0, 1>(Bm, Um);
   qr_step<0, 2>(Bm, Um);
   qr_step<1, 2>(Bm, Um);
   Sg[0] = Bm[0][0]; Sg[1] = Bm[1][1]; Sg[2] = Bm[2][2];
+}
+
+// column-major 9-vector interface (diagnostic entry point zs_rocm_svd3)
+__device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (&Sg)[3], float (&V)[9]) {
+  float Um[3][3], Vm[3][3], Bs[3][3];
+  svd3_core<true, false>(A, Um, Sg, Vm, Bs);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -171,26 +190,33 @@ struct Material {
   int volCorrection;
 };
 
-// compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47)
+// compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47).  The reference forms P = U diag(Phat) V^T and
+// then P F^T; since (F V) is already available from the SVD, P F^T = U diag(Phat) (F V)^T is formed directly.
 __device__ __forceinline__ void stress_fixedcorotated(const Material &m, const float (&F)[9], float (&PF)[9]) {
-  float U[9], S[3], V[9];
-  svd3(F, U, S, V);
+  float U[3][3], S[3], V[3][3], B[3][3];
+  svd3_core<false, true>(F, U, S, V, B);
   const float J = S[0] * S[1] * S[2];
   const float smu = 2.f * m.mu, slam = m.lam * (J - 1.f);
   float Ph[3];
-  Ph[0] = smu * (S[0] - 1.f) + slam * (S[1] * S[2]);
-  Ph[1] = smu * (S[1] - 1.f) + slam * (S[0] * S[2]);
-  Ph[2] = smu * (S[2] - 1.f) + slam * (S[0] * S[1]);
-  float P[9];
-  mat_diag_matT(P, U, Ph, V);
-  pft_vol(P, F, m.volume, PF);
+  Ph[0] = (smu * (S[0] - 1.f) + slam * (S[1] * S[2])) * m.volume;
+  Ph[1] = (smu * (S[1] - 1.f) + slam * (S[0] * S[2])) * m.volume;
+  Ph[2] = (smu * (S[2] - 1.f) + slam * (S[0] * S[1])) * m.volume;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float u0 = U[r][0] * Ph[0], u1 = U[r][1] * Ph[1], u2 = U[r][2] * Ph[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) PF[r + 3 * c] = u0 * B[c][0] + u1 * B[c][1] + u2 * B[c][2];
+  }
 }
 
-// compute_stress_sand (cuda/physics/ConstitutiveModel.hpp:246-326): Drucker-Prager return mapping in
-// log-strain; F is projected in place, logJp updated.
+// compute_stress_sand (cuda/physics/ConstitutiveModel.hpp:246-326): Drucker-Prager return mapping in log-strain.
+// logJp is updated.  The reference overwrites F with the projected F_e = U diag(New_S) V^T and then forms
+// P F_e^T * vol with P = U diag(Phat) V^T; with V^T V = I that product is U diag(Phat_i New_S_i) U^T * vol -- the
+// Kirchhoff stress -- so neither P nor V is needed for the force.  WRITE_F: also return the projected F (test entry).
+template <bool WRITE_F>
 __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
-  float U[9], S[3], V[9];
-  svd3(F, U, S, V);
+  float U[3][3], S[3], V[3][3], B[3][3];
+  svd3_core<WRITE_F, false>(F, U, S, V, B);
   const float smu = 2.f * m.mu;
   float eps[3], NS[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -226,24 +252,44 @@ __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, flo
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      NS[i] = expf(H[i]);
+      if constexpr (WRITE_F) NS[i] = expf(H[i]);
+      else NS[i] = 1.f;  // only its positivity matters below
       Hs[i] = H[i];
     }
     newF = true;
   }
-  if (newF) mat_diag_matT(F, U, NS, V);
-  // New_S_log = log(New_S) (ConstitutiveModel.hpp:309): New_S = exp(H) was just computed, so log(New_S) == H up to
-  // one rounding; the mu == 0 && trace < 0 corner keeps the reference's log(0) = -inf
-  float lg[3];
+  // New_S_log = log(New_S) (ConstitutiveModel.hpp:309): New_S = exp(H), so log(New_S) == H up to one rounding; the
+  // mu == 0 && trace < 0 corner keeps the reference's log(0) = -inf
+  float tau[3];
+  {
+    float lg[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) lg[i] = NS[i] > 0.f ? Hs[i] : -INFINITY;
-  const float trl = lg[0] + lg[1] + lg[2];
-  float Ph[3];
+    for (int i = 0; i < 3; ++i) lg[i] = NS[i] > 0.f ? Hs[i] : -INFINITY;
+    const float trl = lg[0] + lg[1] + lg[2];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) Ph[i] = (smu * lg[i] + m.lam * trl) * __frcp_rn(NS[i]);
-  float P[9];
-  mat_diag_matT(P, U, Ph, V);
-  pft_vol(P, F, m.volume, PF);
+    for (int i = 0; i < 3; ++i) tau[i] = (smu * lg[i] + m.lam * trl) * m.volume;  // Phat_i * New_S_i * vol
+  }
+  if (newF) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float u0 = U[r][0] * tau[0], u1 = U[r][1] * tau[1], u2 = U[r][2] * tau[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) PF[r + 3 * c] = u0 * U[c][0] + u1 * U[c][1] + u2 * U[c][2];
+    }
+    if constexpr (WRITE_F) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float u0 = U[r][0] * NS[0], u1 = U[r][1] * NS[1], u2 = U[r][2] * NS[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) F[r + 3 * c] = u0 * V[c][0] + u1 * V[c][1] + u2 * V[c][2];
+      }
+    }
+  } else {
+    // mu == 0 && trace < 0: F is not projected and New_S = 0 (reference corner case): P = U diag(-inf/0) V^T -> NaN/inf;
+    // reproduce "non-finite" without caring about the exact pattern
+#pragma unroll
+    for (int d = 0; d < 9; ++d) PF[d] = tau[0];
+  }
 }
 
 // ======================================================================================= arena
@@ -308,7 +354,7 @@ __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const Particl
     stress_fixedcorotated(mp.mat, F, contrib);
   } else {
     float lj = ps.logJp.base[ps.logJp.off(i)];
-    stress_sand(mp.mat, lj, F, contrib);
+    stress_sand<false>(mp.mat, lj, F, contrib);
     ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back (as in the reference)
   }
 #pragma unroll
@@ -656,7 +702,7 @@ __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesD
             stress_fixedcorotated(mp.mat, cur.F, contrib);
           } else {
             float lj = cur.logJp;
-            stress_sand(mp.mat, lj, cur.F, contrib);
+            stress_sand<false>(mp.mat, lj, cur.F, contrib);
             ps.logJp.base[ps.logJp.off((size_t)i0)] = lj;  // P2G.hpp:101 (the projected F is not written back)
           }
 #pragma unroll
@@ -957,7 +1003,7 @@ template <int MODEL> __global__ void stress_kernel(MpmDev mp, float *F, float *l
   if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(mp.mat, f, pf);
   else {
     float lj = logJp[i];
-    stress_sand(mp.mat, lj, f, pf);
+    stress_sand<true>(mp.mat, lj, f, pf);
     logJp[i] = lj;
 #pragma unroll
     for (int d = 0; d < 9; ++d) F[9 * i + d] = f[d];
