@@ -1,0 +1,179 @@
+// bht_device.hpp -- device view + probe/insert protocol of zs::bht<int, dim, int, 16> for gfx950.
+//
+// Table layout is byte-identical to the reference (container/Bht.hpp:86-112): `keys` holds
+// next_2pow(dim) ints per slot (unused ints stay 0x3f3f3f3f), `indices`, `status` (all -1; this
+// implementation never needs the per-slot spin lock of Bht.hpp:821-834,885-894), `activeKeys`
+// [tableSize][dim], `cnt`, `success`.  Hashing: universal_hash per component folded with hash_combine
+// (py_interop/HashUtils.hpp:23-43, math/Hash.hpp:19-28), three functions seeded from std::mt19937(2).
+//
+// Insert protocol (replaces atomicSwitchIfEqual / atomicLoad, Bht.hpp:773-895):
+//   dim 1: 32-bit CAS sentinel -> key.          dim 2: 64-bit CAS sentinel -> key.
+//   dim 3: 16-byte slot {x, y, z, pad}.  The pad word doubles as the claim word:
+//          EMPTY (S,S,S,S) -CAS64 on {z,pad}-> (S,S,S,LOCK) -store64 {x,y}, drain, store64 {z,S}-> FULL.
+//          Probes take ONE 16-byte agent-scope load per slot (a naturally aligned dwordx4 is served by
+//          a single L2 line access; observed untorn on gfx950, see MI355X guide G16/R2) and see exactly
+//          one of those states: pad == LOCK means "being written, look again".  No lock is taken on
+//          the probe path, whereas the reference locks on every probe of a 3-D key.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace zsr {
+
+constexpr int BHT_BUCKET = 16;
+constexpr int BHT_THRESHOLD = BHT_BUCKET - 2;  // Bht.hpp:34
+constexpr int BHT_SENT = 0x3f3f3f3f;           // key sentinel bytes (Bht.hpp:108-112,126-131)
+constexpr int BHT_LOCK = (int)0x80000001;      // transient value of the pad word while a slot is written
+constexpr unsigned BHT_PRIME = 4294967291u;    // HashUtils.hpp:12
+constexpr int BHT_FAIL = (int)0x80000000;      // failure_token_v = numeric lowest (Bht.hpp:136)
+
+struct BhtDev {
+  int *keys;
+  int *indices;
+  int *status;
+  int *activeKeys;
+  int *cnt;
+  int *success;
+  unsigned tableSize, numBuckets;
+  unsigned hf[6];
+};
+
+__host__ __device__ __forceinline__ unsigned bht_hash1(unsigned hx, unsigned hy, int k) {
+  return (unsigned)(((hx ^ (unsigned)k) + hy) % BHT_PRIME);
+}
+template <int DIM> __host__ __device__ __forceinline__ unsigned bht_hash(unsigned hx, unsigned hy, const int *k) {
+  unsigned ret = bht_hash1(hx, hy, k[0]);
+#pragma unroll
+  for (int d = 1; d < DIM; ++d) {
+    unsigned v = bht_hash1(hx, hy, k[d]);
+    ret ^= (v + 0x9e3779b9u + (ret << 6) + (ret >> 2));
+  }
+  return ret;
+}
+template <int DIM> constexpr int bht_kstride() { return DIM == 1 ? 1 : (DIM == 2 ? 2 : 4); }
+
+typedef int bht_int4 __attribute__((ext_vector_type(4)));
+
+// agent-scope 16-byte snapshot of one slot (sc1: served by L2/fabric, never by this CU's L1)
+__device__ __forceinline__ bht_int4 bht_load_slot16(const int *p) {
+  bht_int4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// returns: 1 key found (slotKey == key), 0 slot empty, -1 other key, 2 busy (retry)
+template <int DIM> __device__ __forceinline__ int bht_probe(const int *slot, const int *key) {
+  if constexpr (DIM == 1) {
+    int k = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return k == key[0] ? 1 : (k == BHT_SENT ? 0 : -1);
+  } else if constexpr (DIM == 2) {
+    unsigned long long v = __hip_atomic_load((const unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int k0 = (int)(unsigned)v, k1 = (int)(unsigned)(v >> 32);
+    if (k0 == key[0] && k1 == key[1]) return 1;
+    return (k0 == BHT_SENT && k1 == BHT_SENT) ? 0 : -1;
+  } else {
+    bht_int4 v = bht_load_slot16(slot);
+    if (v.w == BHT_LOCK) return 2;
+    if (v.x == key[0] && v.y == key[1] && v.z == key[2]) return 1;
+    return (v.x == BHT_SENT && v.y == BHT_SENT && v.z == BHT_SENT) ? 0 : -1;
+  }
+}
+
+// try to turn an empty slot into `key`; true on success
+template <int DIM> __device__ __forceinline__ bool bht_claim(int *slot, const int *key) {
+  if constexpr (DIM == 1) {
+    return atomicCAS(slot, BHT_SENT, key[0]) == BHT_SENT;
+  } else if constexpr (DIM == 2) {
+    const unsigned long long sent = ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)BHT_SENT;
+    const unsigned long long want = ((unsigned long long)(unsigned)key[1] << 32) | (unsigned)key[0];
+    return atomicCAS((unsigned long long *)slot, sent, want) == sent;
+  } else {
+    unsigned long long *h0 = (unsigned long long *)slot, *h1 = h0 + 1;
+    const unsigned long long sent = ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)BHT_SENT;
+    const unsigned long long locked = ((unsigned long long)(unsigned)BHT_LOCK << 32) | (unsigned)BHT_SENT;
+    if (atomicCAS(h1, sent, locked) != sent) return false;
+    // {z,pad} == sentinel does not prove emptiness when a stored key has z == 0x3f3f3f3f: re-check {x,y}
+    if (__hip_atomic_load(h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sent) {
+      __hip_atomic_store(h1, sent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __hip_atomic_store(h0, ((unsigned long long)(unsigned)key[1] << 32) | (unsigned)key[0], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // {x,y} is at the coherence point before {z,pad} unlocks
+    __hip_atomic_store(h1, ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)key[2], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+}
+
+// BHTView::insert (Bht.hpp:490-542).  insertion_index == -1: take the next dense index from cnt.
+template <int DIM>
+__device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int insertion_index = -1, bool enqueue = true) {
+  if (t.numBuckets == 0) return BHT_FAIL;
+  constexpr int KS = bht_kstride<DIM>();
+  int iter = 0, load = 0;
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * BHT_BUCKET;
+  while (iter < 3) {
+    int st = 0;
+    for (; load != BHT_BUCKET; ++load) {
+      st = bht_probe<DIM>(t.keys + (size_t)(bucket + load) * KS, key);
+      if (st == 2) {  // slot is being written by another lane/wave: look again (no inner spin: lanes of one
+        --load;       // wave may depend on each other)
+        continue;
+      }
+      if (st >= 0) break;  // found or empty
+    }
+    if (load != BHT_BUCKET && st == 1) return -1;  // sentinel_v: already present
+    if (load <= BHT_THRESHOLD) {
+      if (bht_claim<DIM>(t.keys + (size_t)(bucket + load) * KS, key)) {
+        int no = insertion_index;
+        if (insertion_index == -1) no = (int)atomicAdd((unsigned *)t.cnt, 1u);
+        t.indices[bucket + load] = no;
+        if (enqueue) {
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) t.activeKeys[(size_t)no * DIM + d] = key[d];
+        }
+        if ((unsigned)no >= t.tableSize - 20u) {  // proximity guard (Bht.hpp:522-526), u32 wrap-around as in the reference
+          *t.success = 0;
+          no = BHT_FAIL;
+        }
+        return no;
+      }
+      // lost the race for this slot: re-examine it (it now holds some key, maybe ours)
+    } else {
+      ++iter;
+      load = 0;
+      if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * BHT_BUCKET;
+      else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * BHT_BUCKET;
+      else break;
+    }
+  }
+  *t.success = 0;
+  return BHT_FAIL;
+}
+
+// BHTView::query (Bht.hpp:667-698): plain loads, table must be quiescent.  RETSLOT: slot instead of index.
+template <int DIM, bool RETSLOT = false> __device__ __forceinline__ int bht_query(const BhtDev &t, const int *key) {
+  if (t.numBuckets == 0) return RETSLOT ? 0x7fffffff : -1;
+  constexpr int KS = bht_kstride<DIM>();
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * BHT_BUCKET;
+  for (int iter = 0; iter < 3;) {
+    for (int loc = 0; loc != BHT_BUCKET; ++loc) {
+      const int *s = t.keys + (size_t)(bucket + loc) * KS;
+      bool eq;
+      if constexpr (DIM == 3) {
+        bht_int4 v = *reinterpret_cast<const bht_int4 *>(s);
+        eq = v.x == key[0] && v.y == key[1] && v.z == key[2];
+      } else if constexpr (DIM == 2) {
+        eq = s[0] == key[0] && s[1] == key[1];
+      } else
+        eq = s[0] == key[0];
+      if (eq) return RETSLOT ? (int)(bucket + loc) : t.indices[bucket + loc];
+    }
+    ++iter;
+    if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * BHT_BUCKET;
+    else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * BHT_BUCKET;
+  }
+  return RETSLOT ? 0x7fffffff : -1;
+}
+
+}  // namespace zsr

@@ -1,0 +1,160 @@
+// C++ template face test, mirroring the reference's own CUDA tests on the rocm slot:
+//   test/cuda/main.cu:7-32    reduce(getmax/getmin/plus) over the "b" channel of TileVector<int,32>{a:3,b:2,c:1}
+//   test/cuda/basic.cu:53-161 Vector fill on device + clone compare; TileVector<float,32> named channels, pack / tuple
+// plus the launcher shapes (Collapse 1/2/3-D, shmem-first lambdas), bht insert/query inside lambdas, atomics.
+// Build: hipcc --offload-arch=gfx950 -std=c++17 -I include tests/cpp/test_cpp_face.hip -L zpc_amd/lib -lzsrocm
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#include "zensim_rocm/zs_rocm.hpp"
+
+#define CHECK(c)                                                        \
+  do {                                                                  \
+    if (!(c)) {                                                         \
+      std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c);        \
+      std::exit(1);                                                     \
+    }                                                                   \
+  } while (0)
+
+using namespace zs;
+constexpr auto space = execspace_e::rocm;
+
+int main() {
+  auto pol = rocm_exec();
+  CHECK(pol.shouldSync());
+  // ---- Vector: fill on device, clone to host, compare (basic.cu:65-107)
+  {
+    const int n = 100000;
+    Vector<int> v(n, memsrc_e::device);
+    pol(range(n), [vv = view<space>(v)] ZS_LAMBDA(long long i) { vv[i] = (int)(i * 3 + 1); });
+    auto h = v.clone(memsrc_e::host);
+    for (int i = 0; i < n; ++i) CHECK(h.data()[i] == i * 3 + 1);
+    v.resize(120000);
+    CHECK(v.size() == 120000 && v.capacity() == 150000 && v.getVal(7) == 22);
+  }
+  // ---- TileVector<float,32>: named channels, pack / set (basic.cu:110-151)
+  {
+    const int n = 1000;
+    TileVector<float, 32> tv({{"m", 1}, {"x", 3}, {"v", 3}, {"F", 9}}, n, memsrc_e::um);
+    CHECK(tv.numChannels() == 16 && tv.getPropertyOffset("v") == 4 && tv.getPropertyOffset("nope") == -1);
+    const int xo = tv.getPropertyOffset("x"), mo = tv.getPropertyOffset("m");
+    pol(range(n), [t = view<space>({}, tv), xo, mo] ZS_LAMBDA(long long i) {
+      t(mo, i) = (float)i;
+      t.set(xo, i, small_vec<float, 3>{{(float)i, (float)i + 0.5f, -(float)i}});
+    });
+    for (int i = 0; i < n; ++i) {  // um: read on the host through the layout formula
+      const float *b = tv.data() + ((size_t)(i / 32) * 16 + xo) * 32 + i % 32;
+      CHECK(b[0] == (float)i && b[32] == (float)i + 0.5f && b[64] == -(float)i);
+    }
+    Vector<float> sum(1);
+    sum.setVal(0.f);
+    pol(range(n), [t = view<space>(tv), xo, s = view<space>(sum)] ZS_LAMBDA(long long i) {
+      auto p = t.pack(dim_c<3>, xo, i);
+      atomic_add(exec_rocm, &s[0], p[0] + p[1] + p[2]);
+    });
+    CHECK(std::abs(sum.getVal() - (0.5f * n + (float)n * (n - 1) / 2)) < 1.0f);
+  }
+  // ---- reduce over a TileVector channel through the iterator ABI (main.cu:7-32)
+  for (int n : {1, 2, 7, 16, 128, 1024, 200000}) {
+    TileVector<int, 32> tv({{"a", 3}, {"b", 2}, {"c", 1}}, n, memsrc_e::um);
+    std::srand(n);
+    const int C = 6, bo = tv.getPropertyOffset("b");
+    int mx = std::numeric_limits<int>::lowest(), mn = std::numeric_limits<int>::max();
+    long long s = 0;
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < C; ++c) {
+        int val = std::rand() % 2001 - 1000;
+        tv.data()[((size_t)(i / 32) * C + c) * 32 + i % 32] = val;
+        if (c == bo) { mx = std::max(mx, val); mn = std::min(mn, val); s += val; }
+      }
+    Vector<int> out(1, memsrc_e::um);
+    aosoa_iterator_const_int_1 first{tv.data() + bo * 32, 0u, 5u, 31u, (unsigned)C}, last = first;
+    last.idx = (unsigned)n;
+    aosoa_iterator_int_1 o{out.data(), 0u, 0u, 0u, 1u};
+    reduce_max__rocm_int_1(pol.handle(), first, last, o);
+    CHECK(out.data()[0] == mx);
+    reduce_min__rocm_int_1(pol.handle(), first, last, o);
+    CHECK(out.data()[0] == mn);
+    reduce_sum__rocm_int_1(pol.handle(), first, last, o);
+    CHECK(out.data()[0] == (int)s);
+  }
+  // ---- primitives on contiguous device ranges through the free functions
+  {
+    const int n = 300001;
+    std::vector<int> h(n);
+    for (int i = 0; i < n; ++i) h[i] = (i * 7919) % 100003 - 50000;
+    Vector<int> a(n), b(n);
+    Vector<int> out(1, memsrc_e::um);
+    hipMemcpy(a.data(), h.data(), n * 4, hipMemcpyHostToDevice);
+    reduce(pol, a.data(), a.data() + n, out.data(), 0, plus<int>{});
+    CHECK(out.data()[0] == (int)std::accumulate(h.begin(), h.end(), 0ll));
+    reduce(pol, a.data(), a.data() + n, out.data(), std::numeric_limits<int>::lowest(), getmax<int>{});
+    CHECK(out.data()[0] == *std::max_element(h.begin(), h.end()));
+    exclusive_scan(pol, a.data(), a.data() + n, b.data());
+    std::vector<int> r(n);
+    hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
+    int acc = 0;
+    for (int i = 0; i < n; ++i) { CHECK(r[i] == acc); acc += h[i]; }
+    radix_sort(pol, a.data(), a.data() + n, b.data());
+    hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    CHECK(r == h);
+  }
+  // ---- launcher shapes: Collapse{nb, nt}, Collapse{nb, ntiles, tileSize}, shmem-first lambdas
+  {
+    Vector<int> cnt(4, memsrc_e::um);
+    cnt.reset(0);
+    pol(Collapse{10, 128}, [c = view<space>(cnt)] ZS_LAMBDA(int block, int thread) { atomic_add(exec_rocm, &c[0], block * 128 + thread); });
+    CHECK(cnt.data()[0] == (1280 * 1279) / 2);
+    pol(Collapse{5, 4, 16}, [c = view<space>(cnt)] ZS_LAMBDA(int block, int tile, int lane) { atomic_add(exec_rocm, &c[1], block * 64 + tile * 16 + lane); });
+    CHECK(cnt.data()[1] == (320 * 319) / 2);
+    pol.shmem(256 * sizeof(int));
+    pol(Collapse{3, 256}, [c = view<space>(cnt)] ZS_LAMBDA(char *shm, int block, int thread) {
+      int *s = (int *)shm;
+      s[thread] = thread;
+      __syncthreads();
+      if (thread == 0) {
+        int t = 0;
+        for (int i = 0; i < 256; ++i) t += s[i];
+        atomic_add(exec_rocm, &c[2], t);
+      }
+    });
+    CHECK(cnt.data()[2] == 3 * (256 * 255) / 2);
+    pol.shmem(0);
+    pol(range(1000), [c = view<space>(cnt)] ZS_LAMBDA(long long i) { if (i % 3 == 0) atomic_inc(exec_rocm, &c[3]); });
+    CHECK(cnt.data()[3] == 334);
+  }
+  // ---- bht: insert / query inside lambdas (Bht.hpp:490-542, 667-698), set semantics
+  {
+    const int n = 50000;
+    bht<3> tab(n);
+    Vector<int> ret(n, memsrc_e::um);
+    pol(range(n), [tb = view<space>(tab), r = view<space>(ret)] ZS_LAMBDA(long long i) {
+      small_vec<int, 3> k{{(int)(i % 37) - 18, (int)((i / 37) % 11), (int)(i % 5)}};
+      r[i] = tb.insert(k);
+    });
+    std::vector<std::array<int, 3>> uniq;
+    {
+      std::vector<std::array<int, 3>> all;
+      for (int i = 0; i < n; ++i) all.push_back({i % 37 - 18, (i / 37) % 11, i % 5});
+      std::sort(all.begin(), all.end());
+      all.erase(std::unique(all.begin(), all.end()), all.end());
+      uniq = all;
+    }
+    CHECK(tab.size() == uniq.size());
+    int winners = 0;
+    for (int i = 0; i < n; ++i) winners += ret.data()[i] >= 0;
+    CHECK(winners == (int)uniq.size());
+    pol(range(n), [tb = view<space>(tab), r = view<space>(ret)] ZS_LAMBDA(long long i) {
+      small_vec<int, 3> k{{(int)(i % 37) - 18, (int)((i / 37) % 11), (int)(i % 5)}};
+      small_vec<int, 3> miss{{1000 + (int)i, 0, 0}};
+      r[i] = (tb.query(k) >= 0 && tb.query(miss) == -1) ? 1 : 0;
+    });
+    for (int i = 0; i < n; ++i) CHECK(ret.data()[i] == 1);
+  }
+  CHECK(zs_rocm_last_error(-1) == 0);
+  std::printf("cpp face ok\n");
+  return 0;
+}

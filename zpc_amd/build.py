@@ -53,6 +53,21 @@ def build_hip(force=False, verbose=True):
     return LIB
 
 
+def build_cpp_face_test(verbose=True):
+    """tests/cpp/test_cpp_face.hip: a user translation unit written against the header-only C++ face
+    (include/zensim_rocm/zs_rocm.hpp) -- proves that the face compiles with hipcc and links libzsrocm.so."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_cpp_face.hip")
+    out = os.path.join(LIBDIR, "test_cpp_face")
+    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "bht_device.hpp"), LIB]
+    if os.path.exists(src) and any(_newer(d, out) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "include"), src,
+               "-L", LIBDIR, "-lzsrocm", "-Wl,-rpath,$ORIGIN", "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_oracle(verbose=True):
     """CPU restatement (always) and, where /root/reference exists, the in-place build of the reference's
     header-only numerics (oracle/_ref).  Building the checker is not using it."""
@@ -65,4 +80,5 @@ def build_oracle(verbose=True):
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_hip(force=force))
+    build_cpp_face_test()
     build_oracle()
