@@ -105,9 +105,9 @@ template <int DIM> __device__ __forceinline__ bool bht_claim(int *slot, const in
   }
 }
 
-// BHTView::insert (Bht.hpp:490-542).  insertion_index == -1: take the next dense index from cnt.
-template <int DIM>
-__device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int insertion_index = -1, bool enqueue = true) {
+// first half of BHTView::insert (Bht.hpp:490-516): find `key` or claim a slot for it.
+// returns slot >= 0 when THIS thread claimed the slot, -1 when the key is already present, BHT_FAIL on overflow.
+template <int DIM> __device__ __forceinline__ int bht_find_or_claim(const BhtDev &t, const int *key) {
   if (t.numBuckets == 0) return BHT_FAIL;
   constexpr int KS = bht_kstride<DIM>();
   int iter = 0, load = 0;
@@ -116,7 +116,7 @@ __device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int i
     int st = 0;
     for (; load != BHT_BUCKET; ++load) {
       st = bht_probe<DIM>(t.keys + (size_t)(bucket + load) * KS, key);
-      if (st == 2) {  // slot is being written by another lane/wave: look again (no inner spin: lanes of one
+      if (st == 2) {  // slot is being written by another wave: look again (no inner spin: lanes of one
         --load;       // wave may depend on each other)
         continue;
       }
@@ -124,20 +124,7 @@ __device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int i
     }
     if (load != BHT_BUCKET && st == 1) return -1;  // sentinel_v: already present
     if (load <= BHT_THRESHOLD) {
-      if (bht_claim<DIM>(t.keys + (size_t)(bucket + load) * KS, key)) {
-        int no = insertion_index;
-        if (insertion_index == -1) no = (int)atomicAdd((unsigned *)t.cnt, 1u);
-        t.indices[bucket + load] = no;
-        if (enqueue) {
-#pragma unroll
-          for (int d = 0; d < DIM; ++d) t.activeKeys[(size_t)no * DIM + d] = key[d];
-        }
-        if ((unsigned)no >= t.tableSize - 20u) {  // proximity guard (Bht.hpp:522-526), u32 wrap-around as in the reference
-          *t.success = 0;
-          no = BHT_FAIL;
-        }
-        return no;
-      }
+      if (bht_claim<DIM>(t.keys + (size_t)(bucket + load) * KS, key)) return (int)(bucket + load);
       // lost the race for this slot: re-examine it (it now holds some key, maybe ours)
     } else {
       ++iter;
@@ -149,6 +136,56 @@ __device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int i
   }
   *t.success = 0;
   return BHT_FAIL;
+}
+// second half (Bht.hpp:517-528): record the dense index of a claimed slot
+template <int DIM> __device__ __forceinline__ int bht_commit(const BhtDev &t, int slot, const int *key, int no, bool enqueue) {
+  t.indices[slot] = no;
+  if (enqueue) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) t.activeKeys[(size_t)no * DIM + d] = key[d];
+  }
+  if ((unsigned)no >= t.tableSize - 20u) {  // proximity guard (Bht.hpp:522-526), u32 wrap-around as in the reference
+    *t.success = 0;
+    no = BHT_FAIL;
+  }
+  return no;
+}
+
+// BHTView::insert (Bht.hpp:490-542).  insertion_index == -1: take the next dense index from cnt.
+template <int DIM>
+__device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int insertion_index = -1, bool enqueue = true) {
+  const int slot = bht_find_or_claim<DIM>(t, key);
+  if (slot < 0) return slot;
+  int no = insertion_index;
+  if (insertion_index == -1) no = (int)atomicAdd((unsigned *)t.cnt, 1u);
+  return bht_commit<DIM>(t, slot, key, no, enqueue);
+}
+
+// Bulk form for kernels in which EVERY thread of the workgroup calls it (threads without a key pass valid = false):
+// the dense indices of all slots claimed by the workgroup are taken with ONE atomic on cnt (a single device-wide
+// counter saturates at ~90 atomics/us on MI355X: 10M distinct keys would spend > 2 ms there even wave-aggregated).
+// `smem` = 2 + blockDim/64 unsigned of LDS.
+template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev &t, const int *key, bool valid, unsigned *smem) {
+  const int slot = valid ? bht_find_or_claim<DIM>(t, key) : -1;
+  const bool won = slot >= 0;
+  const unsigned long long m = __ballot(won);
+  const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
+  if (lane == 0) smem[2 + w] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (int i = 0; i < nw; ++i) {
+      const unsigned c = smem[2 + i];
+      smem[2 + i] = tot;
+      tot += c;
+    }
+    smem[0] = tot ? atomicAdd((unsigned *)t.cnt, tot) : 0u;
+  }
+  __syncthreads();
+  int ret = slot;  // -1 (present) or BHT_FAIL
+  if (won) ret = bht_commit<DIM>(t, slot, key, (int)(smem[0] + smem[2 + w] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))), true);
+  __syncthreads();
+  return ret;
 }
 
 // BHTView::query (Bht.hpp:667-698): plain loads, table must be quiescent.  RETSLOT: slot instead of index.

@@ -240,6 +240,11 @@ typedef struct {
   /* (B) pol(range(n), [tb](i){ ret[i] = tb.insert(keys[i]); })  BHTView::insert, Bht.hpp:490-542 */     \
   ZS_ROCM_EXPORT void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,          \
                                                           const int *keys, size_t n, int *ret);         \
+  /* (B) table := { keys[i] -> index i }, cnt = n: adopt a partition numbered elsewhere (e.g. the _activeKeys of a  \
+     zs::HashTable, container/HashTable.hpp, which the reference's in-tree P2G/G2P use); insert(key, i, enqueue)   \
+     of Bht.hpp:490-542 with a fixed index */                                                                     \
+  ZS_ROCM_EXPORT void zs_rocm_assign__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,          \
+                                                          const int *keys, size_t n);                   \
   /* (B) pol(range(n), [tb](i){ ret[i] = tb.query(keys[i]); })  BHTView::query, Bht.hpp:667-698 */       \
   ZS_ROCM_EXPORT void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *, const zs_rocm_bht_##D *,     \
                                                          const int *keys, size_t n, int *ret);          \

@@ -97,3 +97,21 @@ def test_resize_and_reset(pol, oracle):
     assert tab.size() == 0
     tab.query(pol, dk.data_ptr(), 100, ret.data_ptr())
     assert (ret.cpu().numpy()[:100] == -1).all()
+
+
+def test_assign_adopts_external_numbering(pol, oracle):
+    """zs_rocm_assign: table := {keys[i] -> i} (adopting e.g. a zs::HashTable partition's _activeKeys order)."""
+    from zpc_amd.containers import Bht
+    g = rng(61)
+    keys = np.unique(g.integers(-50, 50, (20000, 3), dtype=np.int32), axis=0)
+    keys = keys[g.permutation(keys.shape[0])]
+    n = keys.shape[0]
+    tab = Bht(3, n)
+    dk = torch.from_numpy(np.ascontiguousarray(keys)).cuda()
+    tab.assign(pol, dk.data_ptr(), n)
+    assert tab.size() == n
+    ret = torch.empty(n, dtype=torch.int32, device="cuda")
+    tab.query(pol, dk.data_ptr(), n, ret.data_ptr())
+    assert np.array_equal(ret.cpu().numpy(), np.arange(n))
+    act = _d2h(tab.view().activeKeys, n * 12).reshape(n, 3)
+    assert np.array_equal(act, keys)

@@ -149,6 +149,7 @@ def _declare_containers(L):
         getattr(L, "resize_container__rocm_" + s).argtypes = [vp, vp, sz]
         getattr(L, "zs_rocm_insert__" + s).argtypes = [vp, vp, vp, sz, vp]
         getattr(L, "zs_rocm_query__" + s).argtypes = [vp, vp, vp, sz, vp]
+        getattr(L, "zs_rocm_assign__" + s).argtypes = [vp, vp, vp, sz]
         getattr(L, "zs_rocm_reorder__" + s).argtypes = [vp, vp, vp, i32]
         getattr(L, "zs_rocm_canonicalize__" + s).argtypes = [vp, vp]
     PP = C.POINTER(MpmParams)

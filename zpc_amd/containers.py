@@ -181,6 +181,10 @@ class Bht:
     def insert(self, pol, keys_ptr, n, ret_ptr=None):
         getattr(lib(), "zs_rocm_insert__" + self.s)(pol.handle, self._h, keys_ptr, n, ret_ptr)
 
+    def assign(self, pol, keys_ptr, n):
+        """table := {keys[i] -> i}: adopt a partition numbered elsewhere (e.g. a zs::HashTable's active keys)."""
+        getattr(lib(), "zs_rocm_assign__" + self.s)(pol.handle, self._h, keys_ptr, n)
+
     def query(self, pol, keys_ptr, n, ret_ptr):
         getattr(lib(), "zs_rocm_query__" + self.s)(pol.handle, self._h, keys_ptr, n, ret_ptr)
 

@@ -75,14 +75,27 @@ int bht_size(const BhtHost &t, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ kernels
-template <int DIM> __global__ __launch_bounds__(256) void bht_insert_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
+template <int DIM> __global__ __launch_bounds__(1024) void bht_insert_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
+  __shared__ unsigned smem[2 + 16];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int key[DIM] = {};
+  if (valid) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) key[d] = keys[i * DIM + d];
+  }
+  int r = bht_insert_block<DIM>(t, key, valid, smem);
+  if (valid && ret) ret[i] = r;
+}
+// assign: table := {keys[i] -> i} (what a partition built elsewhere, e.g. a zs::HashTable's _activeKeys, needs to be used
+// by the binned transfers); cnt = n
+template <int DIM> __global__ __launch_bounds__(256) void bht_assign_kernel(BhtDev t, const int *keys, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int key[DIM];
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) key[d] = keys[i * DIM + d];
-  int r = bht_insert<DIM>(t, key);
-  if (ret) ret[i] = r;
+  for (int d = 0; d < DIM; ++d) key[d] = keys[(size_t)i * DIM + d];
+  bht_insert<DIM>(t, key, i, true);
 }
 template <int DIM> __global__ __launch_bounds__(256) void bht_query_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,12 +144,22 @@ template <int DIM> __global__ void bht_gather_comp_kernel(const int *activeKeys,
 template <int DIM> static void bht_insert_many(zs_rocm_policy *pol, BhtHost &t, const int *keys, size_t n, int *ret) {
   Launch L(pol, "bht_insert");
   if (!n) return;
-  hipLaunchKernelGGL((bht_insert_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, n, ret);
+  hipLaunchKernelGGL((bht_insert_kernel<DIM>), dim3(ceil_div(n, 1024)), dim3(1024), 0, L.stream, t.dev(), keys, n, ret);
 }
 template <int DIM> static void bht_query_many(zs_rocm_policy *pol, const BhtHost &t, const int *keys, size_t n, int *ret) {
   Launch L(pol, "bht_query");
   if (!n) return;
   hipLaunchKernelGGL((bht_query_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, n, ret);
+}
+
+template <int DIM> static void bht_assign(zs_rocm_policy *pol, BhtHost &t, const int *keys, size_t n) {
+  Launch L(pol, "bht_assign");
+  bht_reset_table(t, L.stream);
+  int cnt = (int)n, one = 1;
+  ZSR_CHECK(hipMemcpyAsync(t.cnt, &cnt, sizeof(int), hipMemcpyHostToDevice, L.stream));
+  ZSR_CHECK(hipMemcpyAsync(t.success, &one, sizeof(int), hipMemcpyHostToDevice, L.stream));
+  if (n) hipLaunchKernelGGL((bht_assign_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, (int)n);
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
 }
 
 // bht::resize (Bht.hpp:320-340)
@@ -232,6 +255,9 @@ extern "C" {
   void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys,       \
                                             size_t n, int *ret) {                                           \
     bht_insert_many<D>(pol, b->t, keys, n, ret);                                                            \
+  }                                                                                                         \
+  void zs_rocm_assign__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys, size_t n) { \
+    bht_assign<D>(pol, b->t, keys, n);                                                                      \
   }                                                                                                         \
   void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *pol, const zs_rocm_bht_##D *b, const int *keys,  \
                                            size_t n, int *ret) {                                            \
