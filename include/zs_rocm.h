@@ -283,6 +283,8 @@ typedef struct {
   float cohesion, beta, yieldSurface;
   int volCorrection;
   int side;           /* grid block side: 4 = Grids<f32,3,4> (geometry/Structure.hpp), 8 = SparseGrid<3,f32,8> */
+  int keyIsOrigin;    /* 0: partition keys are block coordinates cell/side (Grids + HashTable/bht, simulation/Utils.hpp:24-31);
+                         1: keys are block origins in cells, multiples of side (SparseGrid, geometry/SparseGrid.hpp:305-309) */
 } zs_rocm_mpm_params;
 
 /* grid: TileVector<f32, side^3> with 7 channels {m:1, v:3, rhs:3} (simulation/mpm/Simulator.cpp:116-122),
@@ -292,9 +294,11 @@ typedef struct {
 
 /* pol(range(n), ComputeSparsity{dx, side, table, X}) (sparsity/SparsityOp.hpp:59-87) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n,
-                                                 float dx, int side);
+                                                 float dx, int side, int keyIsOrigin);
 /* pol(range(nblocks), EnlargeSparsity{table, lo, hi}) (sparsity/SparsityOp.hpp:89-115) */
-ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3]);
+/* keyStride: 1 for block-coordinate keys, side for block-origin keys */
+ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3],
+                                                 int keyStride);
 
 /* particle -> bin binning (the role of IndexBuckets / SpatiallyCount+Distribute,
  * sparsity/SparsityOp.hpp:117-196, simulation/particle/Query.tpp:9-58).  A bin is a 4x4x4 group of cells
@@ -303,9 +307,10 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3
  * round-robin over the bin's 64 cells (round r = the r-th particle of every cell that has one, cells in
  * x-major order); `cellCount` [nbins*64] particles per cell; binStart [nbins+1].  nbins = nblocks * (side/4)^3. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_bin_particles(zs_rocm_policy *, const zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n,
-                                              float dx, int side, int *order, int *binStart, unsigned *cellCount);
+                                              float dx, int side, int keyIsOrigin, int *order, int *binStart,
+                                              unsigned *cellCount);
 /* nbr[b][8]: block numbers of b + {0,1}^3 (x-major), -1 when absent */
-ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr);
+ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr, int keyStride);
 
 /* pol(range(n), P2GTransfer{apic, dt, model, particles, table, grids})
  * (simulation/transfer/P2G.hpp:27-132, cuda/simulation/transfer/P2G.hpp:13-123).

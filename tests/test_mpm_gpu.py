@@ -36,7 +36,7 @@ def test_svd_and_stress_blocks(pol, oracle):
     # stress: fixed corotated + sand
     mu, lam = 0.5 * 5e4 / 1.4, 5e4 * 0.4 / (1.4 * 0.2)
     for model in (0, 1):
-        p = MpmParams(model, 1 / 64, 1e-4, 2.5e-7, 5e4, 0.4, 0.0, 1.0, YIELD_SURFACE, 1, 4)
+        p = MpmParams(model, 1 / 64, 1e-4, 2.5e-7, 5e4, 0.4, 0.0, 1.0, YIELD_SURFACE, 1, 4, 0)
         Fd = dF.clone()
         lj = torch.from_numpy((0.01 * g.standard_normal(n)).astype(np.float32)).cuda()
         lj0 = lj.cpu().numpy().copy()
@@ -158,3 +158,74 @@ def test_stale_bins_fall_back_exactly(pol, oracle):
         a = binned_grid.reshape(-1, 7, 64)[:, ch]
         b = ref_grid.reshape(-1, 7, 64)[:, ch]
         assert np.abs(a - b).max() <= 2e-4 * (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("side,binned", [(8, True), (4, True), (8, False)])
+def test_sparsegrid_origin_keys(pol, oracle, side, binned):
+    """SparseGrid convention (geometry/SparseGrid.hpp:305-309): partition keys are block ORIGINS (multiples of side)."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(9, dx, 2, seed=71, origin=(-0.05, 0.31, 0.29))  # straddles negative coordinates
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    om = OracleMpm(oracle, 0, dx, dt, side, vol)
+    om.build_partition(pos, n)
+    om.p2g(mass, pos, vel, Cm, F)
+    mt = MpmTransfer(pol, n, dx, dt, model=0, side=side, volume=vol, key_is_origin=True)
+    mt.upload(mass, pos, vel, Cm, F)
+    assert mt.build_partition(n) == om.nblocks
+    if binned:
+        mt.rebin()
+    mt.clear_grid()
+    mt.p2g()
+    pol.syncCtx()
+    ga = {tuple(k // side for k in key): v for key, v in mt.grid_by_key().items()}
+    assert all(all(c % side == 0 for c in key) for key in mt.grid_by_key())
+    _compare_grids(ga, om.grid_by_key(), 2e-4)
+    mt.grid_update((0.0, -9.8, 0.0))
+    om.grid_update((0.0, -9.8, 0.0))
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    om.g2p(po, vo, Co, Fo)
+    mt.g2p()
+    pol.syncCtx()
+    d = mt.download()
+    inv = mt.order.cpu().numpy() if binned else np.arange(n)
+    assert np.abs(d["v"] - vo[inv]).max() < 2e-4 * np.abs(vo).max()
+    assert np.abs(d["F"] - Fo[inv]).max() < 2e-5
+
+
+@pytest.mark.parametrize("binned", [False, True])
+def test_aos_particles(pol, oracle, binned):
+    """AoS attribute storage (zs::Particles: Vector<vec3>, Vector<vec9>, geometry/Structurefree.hpp:21-237) through the
+    same iterator ports (numTileBits = tileMask = 0)."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=72)
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    lj0 = (0.01 * rng(73).standard_normal(n)).astype(np.float32)
+    om = OracleMpm(oracle, 1, dx, dt, 4, vol)
+    om.build_partition(pos, n)
+    lj_o = om.p2g(mass, pos, vel, Cm, F, lj0.copy())
+    mt = MpmTransfer(pol, n, dx, dt, model=1, side=4, volume=vol, aos=True)
+    aos = np.concatenate([mass[:, None], pos, vel, Cm, F, lj0[:, None]], axis=1).astype(np.float32)
+    mt.buf.copy_(torch.from_numpy(aos.reshape(-1)).cuda())
+    assert mt.build_partition(n) == om.nblocks
+    if binned:
+        mt.rebin()
+    mt.clear_grid()
+    mt.p2g()
+    pol.syncCtx()
+    _compare_grids(mt.grid_by_key(), om.grid_by_key(), 2e-4)
+    mt.grid_update((0.0, -9.8, 0.0))
+    om.grid_update((0.0, -9.8, 0.0))
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    om.g2p(po, vo, Co, Fo)
+    mt.g2p()
+    pol.syncCtx()
+    out = mt.buf.cpu().numpy().reshape(n, 26)
+    inv = mt.order.cpu().numpy() if binned else np.arange(n)
+    assert np.abs(out[:, 1:4] - po[inv]).max() < 1e-6
+    assert np.abs(out[:, 4:7] - vo[inv]).max() < 2e-4 * np.abs(vo).max()
+    assert np.abs(out[:, 16:25] - Fo[inv]).max() < 2e-5
+    assert np.abs(out[:, 25] - lj_o[inv]).max() < 2e-5

@@ -28,7 +28,7 @@ class Particles(C.Structure):
 class MpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
-                ("volCorrection", C.c_int), ("side", C.c_int)]
+                ("volCorrection", C.c_int), ("side", C.c_int), ("keyIsOrigin", C.c_int)]
 
 
 _lib = None
@@ -153,10 +153,10 @@ def _declare_containers(L):
         getattr(L, "zs_rocm_reorder__" + s).argtypes = [vp, vp, vp, i32]
         getattr(L, "zs_rocm_canonicalize__" + s).argtypes = [vp, vp]
     PP = C.POINTER(MpmParams)
-    L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32]
-    L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, vp, vp, vp]
-    L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp]
+    L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32, i32]
+    L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]
+    L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, i32, vp, vp, vp]
+    L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp, i32]
     L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

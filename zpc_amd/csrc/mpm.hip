@@ -343,6 +343,8 @@ struct MpmDev {
   Material mat;
   int model;
   float dx, dt;
+  int kscale;  // partition keys are block coordinates (1: Grids + HashTable/bht convention) or block ORIGINS in cells
+               // (SIDE: SparseGrid convention, geometry/SparseGrid.hpp:305-309)
 };
 
 // per-particle constitutive update -> contrib = -dt * D_inv * (P F^T vol)   (P2G.hpp:60-105)
@@ -362,7 +364,7 @@ __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const Particl
 }
 
 // ======================================================================================= sparsity
-__global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<float> pos, size_t n, float dxinv, int side) {
+__global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<float> pos, size_t n, float dxinv, int side, int kscale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
   int b[3] = {0, 0, 0};
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<fl
     float p[3];
     load_attr<3>(pos, i, p);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side);
+    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side) * kscale;
   }
   // neighbouring lanes usually carry the same block: let only the first lane of a run insert (the others
   // would get sentinel_v back from insert anyway)
@@ -379,22 +381,22 @@ __global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<fl
   const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
   if (valid && !dup) bht_insert<3>(t, b);
 }
-__global__ __launch_bounds__(256) void enlarge_sparsity_kernel(BhtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2) {
+__global__ __launch_bounds__(256) void enlarge_sparsity_kernel(BhtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2, int kscale) {
   // thread per (block, offset)
   const int per = e0 * e1 * e2;
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nblocks * per) return;
   const int i = (int)(g / per), o = (int)(g % per);
   const int dx = lo0 + o / (e1 * e2), dy = lo1 + (o / e2) % e1, dz = lo2 + o % e2;
-  int k[3] = {t.activeKeys[3 * (size_t)i] + dx, t.activeKeys[3 * (size_t)i + 1] + dy, t.activeKeys[3 * (size_t)i + 2] + dz};
+  int k[3] = {t.activeKeys[3 * (size_t)i] + dx * kscale, t.activeKeys[3 * (size_t)i + 1] + dy * kscale, t.activeKeys[3 * (size_t)i + 2] + dz * kscale};
   bht_insert<3>(t, k);
 }
-__global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr) {
+__global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr, int kscale) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nblocks * 8) return;
   const int i = (int)(g >> 3), o = (int)(g & 7);
-  int k[3] = {t.activeKeys[3 * (size_t)i] + (o >> 2), t.activeKeys[3 * (size_t)i + 1] + ((o >> 1) & 1),
-              t.activeKeys[3 * (size_t)i + 2] + (o & 1)};
+  int k[3] = {t.activeKeys[3 * (size_t)i] + (o >> 2) * kscale, t.activeKeys[3 * (size_t)i + 1] + ((o >> 1) & 1) * kscale,
+              t.activeKeys[3 * (size_t)i + 2] + (o & 1) * kscale};
   nbr[g] = bht_query<3>(t, k);
 }
 
@@ -405,7 +407,7 @@ template <int SIDE> constexpr int bins_per_block() { return (SIDE / 4) * (SIDE /
 
 template <int SIDE>
 __global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> pos, size_t n, float dx, unsigned *cellCount,
-                                                        unsigned *cellOf, unsigned *rankOf, int *err) {
+                                                        unsigned *cellOf, unsigned *rankOf, int *err, int kscale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float p[3];
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> po
   for (int d = 0; d < 3; ++d) {
     const int c = (int)floorf(p[d] * (1.0f / dx) - 0.5f);
     loc[d] = c & (SIDE - 1);
-    key[d] = (c - loc[d]) / SIDE;
+    key[d] = (c - loc[d]) / SIDE * kscale;
   }
   const int b = bht_query<3>(t, key);
   if (b < 0) {
@@ -475,13 +477,13 @@ __device__ __forceinline__ void p2g_scatter_global(const MpmDev &mp, const Parti
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     loc[d] = ar.corner[d] & (SIDE - 1);
-    key[d] = (ar.corner[d] - loc[d]) / SIDE;
+    key[d] = (ar.corner[d] - loc[d]) / SIDE * mp.kscale;
   }
   int blk[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
-    int k[3] = {key[0] + (o >> 2), key[1] + ((o >> 1) & 1), key[2] + (o & 1)};
+    int k[3] = {key[0] + (o >> 2) * mp.kscale, key[1] + ((o >> 1) & 1) * mp.kscale, key[2] + (o & 1) * mp.kscale};
     blk[o] = need ? bht_query<3>(t, k) : -1;
   }
 #pragma unroll
@@ -531,7 +533,7 @@ struct ArenaLds {
 // geometry of bin `bin`: grid block, origin of the bin inside the block (cells), origin in world cells
 template <int SIDE> struct BinGeom {
   int block, o[3], org[3];
-  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin) {
+  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin, int kscale) {
     constexpr int BPB = bins_per_block<SIDE>();
     block = bin / BPB;
     const int sub = bin % BPB;
@@ -539,7 +541,7 @@ template <int SIDE> struct BinGeom {
     o[1] = SIDE == 4 ? 0 : ((sub >> 1) & 1) * 4;
     o[2] = SIDE == 4 ? 0 : (sub & 1) * 4;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) org[d] = t.activeKeys[3 * (size_t)block + d] * SIDE + o[d];
+    for (int d = 0; d < 3; ++d) org[d] = t.activeKeys[3 * (size_t)block + d] * (SIDE / kscale) + o[d];
   }
 };
 
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesD
   if (start == end) return;  // empty bin (ghost block): uniform exit
   const int lane = threadIdx.x;
   for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
-  const BinGeom<SIDE> geo(t, bin);
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   const float dxi = 1.0f / mp.dx;
@@ -854,13 +856,13 @@ __device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const Partic
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     loc[d] = ar.corner[d] & (SIDE - 1);
-    key[d] = (ar.corner[d] - loc[d]) / SIDE;
+    key[d] = (ar.corner[d] - loc[d]) / SIDE * mp.kscale;
   }
   int blk[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
-    int k[3] = {key[0] + (o >> 2), key[1] + ((o >> 1) & 1), key[2] + (o & 1)};
+    int k[3] = {key[0] + (o >> 2) * mp.kscale, key[1] + ((o >> 1) & 1) * mp.kscale, key[2] + (o & 1) * mp.kscale};
     blk[o] = need ? bht_query<3>(t, k) : -1;
   }
   float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int lane = threadIdx.x;
-  const BinGeom<SIDE> geo(t, bin);
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
   int nb[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)geo.block * 8 + o];
@@ -1056,6 +1058,7 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.beta = p->beta;
   d.mat.yieldSurface = p->yieldSurface;
   d.mat.volCorrection = p->volCorrection;
+  d.kscale = p->keyIsOrigin ? p->side : 1;
   return d;
 }
 static ParticlesDev make_particles(const zs_rocm_particles &p) {
@@ -1084,29 +1087,30 @@ using namespace zsr;
 
 extern "C" {
 
-void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side) {
+void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side,
+                                  int keyIsOrigin) {
   Launch L(pol, "ComputeSparsity");
   if (!n) return;
   hipLaunchKernelGGL(compute_sparsity_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->t.dev(), make_port<float>(pos), n,
-                     1.0f / dx, side);
+                     1.0f / dx, side, keyIsOrigin ? side : 1);
 }
-void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, const int lo[3], const int hi[3]) {
+void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, const int lo[3], const int hi[3], int keyStride) {
   Launch L(pol, "EnlargeSparsity");
   const int nb = bht_size(tab->t, L.stream);
   const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
   if (nb == 0 || e0 <= 0 || e1 <= 0 || e2 <= 0) return;
   hipLaunchKernelGGL(enlarge_sparsity_kernel, dim3(ceil_div((size_t)nb * e0 * e1 * e2, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb,
-                     lo[0], lo[1], lo[2], e0, e1, e2);
+                     lo[0], lo[1], lo[2], e0, e1, e2, keyStride > 0 ? keyStride : 1);
 }
-void zs_rocm_mpm_build_neighbors(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, int *nbr) {
+void zs_rocm_mpm_build_neighbors(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, int *nbr, int keyStride) {
   Launch L(pol, "build_neighbors");
   const int nb = bht_size(tab->t, L.stream);
   if (!nb) return;
-  hipLaunchKernelGGL(build_neighbors_kernel, dim3(ceil_div((size_t)nb * 8, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb, nbr);
+  hipLaunchKernelGGL(build_neighbors_kernel, dim3(ceil_div((size_t)nb * 8, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb, nbr, keyStride > 0 ? keyStride : 1);
 }
 
 void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side,
-                               int *order, int *binStart, unsigned *cellCount) {
+                               int keyIsOrigin, int *order, int *binStart, unsigned *cellCount) {
   Launch L(pol, "bin_particles");
   const int nb = bht_size(tab->t, L.stream);
   if (nb == 0) return;
@@ -1123,9 +1127,9 @@ void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs
   Port<float> pp = make_port<float>(pos);
   if (n) {
     if (side == 4)
-      hipLaunchKernelGGL((bin_count_kernel<4>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err);
+      hipLaunchKernelGGL((bin_count_kernel<4>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err, keyIsOrigin ? side : 1);
     else
-      hipLaunchKernelGGL((bin_count_kernel<8>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err);
+      hipLaunchKernelGGL((bin_count_kernel<8>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t, pp, n, dx, cellCount, cellOf, rankOf, err, keyIsOrigin ? side : 1);
   }
   exclusive_scan_u32(L, cellCount, ncells, cellStart);
   if (n)

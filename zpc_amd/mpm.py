@@ -21,16 +21,22 @@ FIXED_COROTATED, DRUCKER_PRAGER = 0, 1
 class MpmTransfer:
     def __init__(self, pol, n, dx, dt, model=FIXED_COROTATED, side=4, lane_width=64, E=5e4, nu=0.4, volume=1.0,
                  cohesion=0.0, beta=1.0, yield_surface=0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), vol_correction=True,
-                 device="cuda"):
+                 device="cuda", key_is_origin=False, aos=False):
         self.pol, self.n, self.L, self.side = pol, int(n), int(lane_width), int(side)
         self.device = torch.device(device)
         self.model = model
         self.nchn = 25 + (1 if model == DRUCKER_PRAGER else 0)
         self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
+        self.aos = bool(aos)  # AoS storage (the zs::Particles / zs::Vector<vec<T,N>> form) instead of the AoSoA TileVector
+        if self.aos:
+            self.L = 1
         self.tiles = (self.n + self.L - 1) // self.L
         self.buf = torch.zeros(self.tiles * self.L * self.nchn, dtype=torch.float32, device=self.device)
         self.buf2 = None  # second buffer for re-binning (ping-pong)
-        self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side)
+        self.key_is_origin = bool(key_is_origin)  # SparseGrid convention: partition keys are block origins (multiples of side)
+        self.kstride = side if key_is_origin else 1
+        self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side,
+                                int(self.key_is_origin))
         self.table = None
         self.grid = None
         self.nblocks = 0
@@ -40,7 +46,7 @@ class MpmTransfer:
     # ------------------------------------------------------------------ particle access
     def _port(self, name, buf=None):
         buf = self.buf if buf is None else buf
-        bits = self.L.bit_length() - 1
+        bits = self.L.bit_length() - 1  # AoS: L == 1 -> numTileBits = tileMask = 0, component stride 1 (GenericIterator.hpp:71-72)
         return Port(buf.data_ptr() + self.off[name] * self.L * 4, 0, bits, self.L - 1, self.nchn)
 
     def particles(self):
@@ -75,15 +81,16 @@ class MpmTransfer:
     def build_partition(self, expected_blocks):
         self.table = Bht(3, int(expected_blocks))
         L = lib()
-        L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side)
+        L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
+                                       int(self.key_is_origin))
         lo, hi = (C.c_int * 3)(0, 0, 0), (C.c_int * 3)(2, 2, 2)
-        L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi)
+        L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
         self.nblocks = self.table.size()
         nc = self.side ** 3
         self.grid = torch.zeros(self.nblocks * 7 * nc, dtype=torch.float32, device=self.device)
         self.nbr = torch.empty(self.nblocks * 8, dtype=torch.int32, device=self.device)
-        L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr())
+        L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr(), self.kstride)
         self.binned = False
         return self.nblocks
 
@@ -96,7 +103,7 @@ class MpmTransfer:
         self.bin_start = torch.empty(self.nbins + 1, dtype=torch.int32, device=self.device)
         self.cell_count = torch.empty(self.nbins * 64, dtype=torch.int32, device=self.device)
         L.zs_rocm_mpm_bin_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
-                                    self.order.data_ptr(), self.bin_start.data_ptr(), self.cell_count.data_ptr())
+                                    int(self.key_is_origin), self.order.data_ptr(), self.bin_start.data_ptr(), self.cell_count.data_ptr())
         if self.buf2 is None:
             self.buf2 = torch.empty_like(self.buf)
         L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
