@@ -45,21 +45,43 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--unbinned", action="store_true", help="particle-order path (reference algorithm) instead of the binned path")
+    ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
+    ap.add_argument("--checksum", action="store_true", help="print global sums of particle state after the run (N-rank vs 1-rank check)")
     return ap.parse_args()
+
+
+def _hash_uniform(gid, stream):
+    """Counter-based uniform [0,1) from the GLOBAL particle id (splitmix64-style integer hash, computed in int64 with
+    wrap-around): every decomposition of the domain generates bit-identical particles."""
+    def s64(v):  # python int -> the int64 with the same low 64 bits
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    x = gid * s64(0x9E3779B97F4A7C15) + s64((stream + 1) * 0x632BE59BD9B4E019)  # int64 wrap-around is intended
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * s64(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * s64(0x94D049BB133111EB)
+    x = x ^ ((x >> 31) & ((1 << 33) - 1))
+    return ((x >> 11) & ((1 << 53) - 1)).double() * (1.0 / (1 << 53))
+
+
+def _hash_normal(gid, stream):
+    u1 = _hash_uniform(gid, 2 * stream).clamp_min(1e-12)
+    u2 = _hash_uniform(gid, 2 * stream + 1)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * 3.141592653589793 * u2)
 
 
 def generate_particles(box_lo, box_hi, dx, seed, device, model):
     """8 particles per cell on a jittered 2x2x2 sub-lattice, generated on the device in chunks.
-    Returns AoS [n, C] float32: m, x3, v3, C9, F9, (logJp)."""
+    Returns AoS [n, C] float32: m, x3, v3, C9, F9, (logJp).  Values depend only on the global particle id."""
     ext = [box_hi[d] - box_lo[d] for d in range(3)]
     ncell = ext[0] * ext[1] * ext[2]
     n = ncell * 8
     nch = 26 if model == 1 else 25
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
     aos = torch.empty(n, nch, dtype=torch.float32, device=device)
     h = dx / 2
-    chunk = 1 << 22
+    chunk = 1 << 21
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         pid = torch.arange(s, e, device=device, dtype=torch.int64)
@@ -67,19 +89,17 @@ def generate_particles(box_lo, box_hi, dx, seed, device, model):
         cx = cell // (ext[1] * ext[2]) + box_lo[0]
         cy = (cell // ext[2]) % ext[1] + box_lo[1]
         cz = cell % ext[2] + box_lo[2]
+        gid = (((cx + 4096) * 8192 + (cy + 4096)) * 8192 + (cz + 4096)) * 8 + sub + seed * 7919
         sx, sy, sz = sub // 4, (sub // 2) % 2, sub % 2
-        jit = (torch.rand(e - s, 3, device=device, generator=g) - 0.5) * (h * 0.8)
-        aos[s:e, 1] = (cx * 2 + sx + 0.5).float() * h + jit[:, 0]
-        aos[s:e, 2] = (cy * 2 + sy + 0.5).float() * h + jit[:, 1]
-        aos[s:e, 3] = (cz * 2 + sz + 0.5).float() * h + jit[:, 2]
+        aos[s:e, 1] = ((cx * 2 + sx).double() + 0.5 + (_hash_uniform(gid, 0) - 0.5) * 0.8).float() * h
+        aos[s:e, 2] = ((cy * 2 + sy).double() + 0.5 + (_hash_uniform(gid, 1) - 0.5) * 0.8).float() * h
+        aos[s:e, 3] = ((cz * 2 + sz).double() + 0.5 + (_hash_uniform(gid, 2) - 0.5) * 0.8).float() * h
         aos[s:e, 0] = 1000.0 * dx ** 3 / 8
-        aos[s:e, 4:7] = 0.05 * torch.randn(e - s, 3, device=device, generator=g)
-        aos[s:e, 7:16] = 0.1 * torch.randn(e - s, 9, device=device, generator=g)
-        F = 0.01 * torch.randn(e - s, 9, device=device, generator=g)
-        F[:, 0] += 1.0
-        F[:, 4] += 1.0
-        F[:, 8] += 1.0
-        aos[s:e, 16:25] = F
+        for k in range(3):
+            aos[s:e, 4 + k] = (0.05 * _hash_normal(gid, 3 + k)).float()
+        for k in range(9):
+            aos[s:e, 7 + k] = (0.1 * _hash_normal(gid, 6 + k)).float()
+            aos[s:e, 16 + k] = (0.01 * _hash_normal(gid, 15 + k) + (1.0 if k % 4 == 0 else 0.0)).float()
         if model == 1:
             aos[s:e, 25] = 0.0
     return aos
@@ -125,12 +145,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    comm_dev = device if a.backend == "nccl" else torch.device("cpu")
     assert world == a.gpus, "launch with --nproc-per-node == --gpus"
 
     import zpc_amd
@@ -147,7 +173,7 @@ def main():
     vol = dx ** 3 / 8
 
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
-    aos = generate_particles(lo, hi, dx, 1234 + rank, device, model)
+    aos = generate_particles(lo, hi, dx, 1234, device, model)
     n_local = aos.shape[0]
     mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device)
     lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n_local, mt.nchn, mt.L, mt.buf.data_ptr())
@@ -178,13 +204,27 @@ def main():
             return r.cpu().numpy()
 
         halo = HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
-                            lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=device), 7 * nc)
+                            lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), 7 * nc)
+        stage = {}
+
+        def dev_buf(buf):
+            if buf.device.type != "cpu":
+                return buf
+            if buf.data_ptr() not in stage:
+                stage[buf.data_ptr()] = torch.empty(buf.numel(), dtype=torch.float32, device=device)
+            return stage[buf.data_ptr()]
 
         def pack(blocks, nb, buf):
-            lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, buf.data_ptr())
+            d = dev_buf(buf)
+            lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
+            if d is not buf:
+                buf.copy_(d)  # gloo validation path: stage through host memory
 
         def unpack_add(blocks, nb, buf):
-            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, buf.data_ptr(), 1)
+            d = dev_buf(buf)
+            if d is not buf:
+                d.copy_(buf)
+            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 1)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     p2g_ev, g2p_ev = [], []
@@ -227,12 +267,23 @@ def main():
 
     n_total = n_local
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nt = torch.tensor([n_local], dtype=torch.int64, device=device)
+        nt = torch.tensor([n_local], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(nt)
         n_total = int(nt.item())
+    checksum = None
+    if a.checksum:
+        # order-independent global sums of the particle state (float64): equal for any number of ranks up to rounding
+        v = mt.buf.view(mt.tiles, mt.nchn, mt.L).double()
+        valid = (torch.arange(mt.tiles * mt.L, device=device) < n_local).view(mt.tiles, 1, mt.L)
+        sums = (v * valid).sum(dim=(0, 2))
+        sq = ((v * valid) ** 2).sum(dim=(0, 2))
+        cs = torch.cat([sums, sq]).to(comm_dev)
+        if dist is not None:
+            dist.all_reduce(cs)
+        checksum = [float(x) for x in cs.cpu()]
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev]))
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev]))
 
@@ -266,6 +317,8 @@ def main():
                                  "bytes_per_particle": G2P_BYTES}},
             "hip_error": err,
         }
+        if checksum is not None:
+            out["checksum"] = checksum
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, dx, dt, model, a.side, vol)
         print(json.dumps(out), flush=True)
