@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--unbinned", action="store_true", help="particle-order path (reference algorithm) instead of the binned path")
+    ap.add_argument("--no-cache-stress", action="store_true",
+                    help="evaluate the constitutive model inside P2G (reference order) instead of in the tail of the previous G2P")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -175,7 +177,10 @@ def main():
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
     n_local = aos.shape[0]
-    mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device)
+    mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device,
+                     cache_stress=not a.no_cache_stress)
+    if mt.cache_stress:
+        aos = torch.cat([aos, torch.zeros(n_local, 9, dtype=torch.float32, device=device)], dim=1).contiguous()
     lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n_local, mt.nchn, mt.L, mt.buf.data_ptr())
     torch.cuda.synchronize()
     del aos
@@ -185,6 +190,7 @@ def main():
         mt.rebin()
     torch.cuda.synchronize()
     rebin_ms = (time.perf_counter() - t0) * 1e3
+    mt.update_stress()  # constitutive state for the first P2G (later ones get it from the preceding G2P)
 
     # ---- halo exchange setup
     halo = None
@@ -289,13 +295,17 @@ def main():
 
     if rank == 0:
         value = n_total * a.steps / elapsed
-        ach = P2G_BYTES[model] * n_local / (p2g_ms * 1e-3) / 1e9
+        # cached stress: P2G reads m,x,v,C + P F^T (100 B) + 7 B grid; G2P additionally reads/writes logJp and writes P F^T
+        p2g_bytes = 107.0 if mt.cache_stress else P2G_BYTES[model]
+        g2p_bytes = G2P_BYTES + ((36.0 + (8.0 if model == 1 else 0.0)) if mt.cache_stress else 0.0)
+        ach = p2g_bytes * n_local / (p2g_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_p2g.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model:
+                if (j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model
+                        and j.get("cache_stress", False) == mt.cache_stress):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -312,9 +322,10 @@ def main():
                        "rebin_ms_once": rebin_ms},
             "roofline": {"bound": "hbm", "kernel": "p2g_binned_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_particle": P2G_BYTES[model], "particles_per_launch": n_local, "launch_ms": p2g_ms,
-                         "g2p": {"achieved": G2P_BYTES * n_local / (g2p_ms * 1e-3) / 1e9, "launch_ms": g2p_ms,
-                                 "bytes_per_particle": G2P_BYTES}},
+                         "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
+                         "constitutive_update": "tail of previous G2P (particles.stress)" if mt.cache_stress else "inside P2G",
+                         "g2p": {"achieved": g2p_bytes * n_local / (g2p_ms * 1e-3) / 1e9, "launch_ms": g2p_ms,
+                                 "bytes_per_particle": g2p_bytes}},
             "hip_error": err,
         }
         if checksum is not None:

@@ -272,6 +272,12 @@ typedef struct {
   zs_rocm_attr C;     /* 9, column-major */
   zs_rocm_attr F;     /* 9, column-major */
   zs_rocm_attr logJp; /* 1, plastic models only (base may be NULL otherwise) */
+  zs_rocm_attr stress; /* 9, optional (base NULL = off): cached P F^T * volume of the constitutive update.  When present,
+                          zs_rocm_mpm_g2p evaluates the model on the F it has just updated (and updates logJp) and stores the
+                          result here, and zs_rocm_mpm_p2g reads it instead of re-running the 3x3 SVD: the per-particle
+                          constitutive work of the reference's P2G (P2G.hpp:60-101) moves to the tail of the previous G2P, where
+                          the VALU is idle.  Call zs_rocm_mpm_update_stress once before the first P2G and after any host-side
+                          edit of F / logJp. */
   size_t n;
 } zs_rocm_particles;
 
@@ -330,6 +336,8 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_grid_update(zs_rocm_policy *, const zs_rocm_mpm_
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,
                                     const unsigned *cellCount, const int *nbr);
+/* particles.stress := model(F, logJp) * volume, logJp updated (no-op when particles.stress.base == NULL) */
+ZS_ROCM_EXPORT void zs_rocm_mpm_update_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
 /* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
  * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, float *F, float *logJp, size_t n, float *PF);

@@ -229,3 +229,54 @@ def test_aos_particles(pol, oracle, binned):
     assert np.abs(out[:, 4:7] - vo[inv]).max() < 2e-4 * np.abs(vo).max()
     assert np.abs(out[:, 16:25] - Fo[inv]).max() < 2e-5
     assert np.abs(out[:, 25] - lj_o[inv]).max() < 2e-5
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("side", [4, 8])
+def test_cached_stress_matches_recompute_over_steps(pol, oracle, model, side):
+    """Fusing the constitutive update into the tail of G2P (particles.stress) gives the same multi-step trajectory as the
+    reference order (stress inside P2G), and both follow the CPU oracle over 3 sub-steps."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=81 + model)
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    lj0 = (0.01 * rng(83).standard_normal(n)).astype(np.float32)
+    om = OracleMpm(oracle, model, dx, dt, side, vol)
+    om.build_partition(pos, n)
+    po, vo, Co, Fo, ljo = pos.copy(), vel.copy(), Cm.copy(), F.copy(), lj0.copy()
+    runs = {}
+    for cached in (False, True):
+        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=cached)
+        mt.upload(mass, pos, vel, Cm, F, lj0 if model == 1 else None)
+        assert mt.build_partition(n) == om.nblocks
+        mt.rebin()
+        mt.update_stress()
+        runs[cached] = mt
+    for step in range(3):
+        om.grid[:] = 0
+        ljo = om.p2g(mass, po, vo, Co, Fo, ljo)
+        om.grid_update((0.0, -9.8, 0.0))
+        om.g2p(po, vo, Co, Fo)
+        for mt in runs.values():
+            mt.clear_grid()
+            mt.p2g()
+            mt.grid_update((0.0, -9.8, 0.0))
+            mt.g2p()
+    pol.syncCtx()
+    def original_order(mt):  # binned storage -> original particle numbering (the rank inside a cell is race-ordered)
+        d, order = mt.download(), mt.order.cpu().numpy()
+        out = {}
+        for k, v in d.items():
+            o = np.empty_like(v)
+            o[order] = v
+            out[k] = o
+        return out
+    da, db = original_order(runs[False]), original_order(runs[True])
+    for k, tol in (("x", 2e-6), ("v", 3e-4 * np.abs(vo).max()), ("F", 5e-5), ("C", 5e-4 * np.abs(Co).max())):
+        assert np.abs(da[k] - db[k]).max() <= tol, k          # cached == recompute
+        ref = {"x": po, "v": vo, "F": Fo, "C": Co}[k]
+        assert np.abs(db[k] - ref).max() <= tol * 2, k         # both follow the oracle
+    if model == 1:
+        assert np.abs(da["logJp"] - db["logJp"]).max() < 5e-5
+        assert np.abs(db["logJp"] - ljo).max() < 1e-4

@@ -22,7 +22,7 @@ class BhtViewLite(C.Structure):
 
 class Particles(C.Structure):
     _fields_ = [("mass", Port), ("pos", Port), ("vel", Port), ("C", Port), ("F", Port), ("logJp", Port),
-                ("n", C.c_size_t)]
+                ("stress", Port), ("n", C.c_size_t)]
 
 
 class MpmParams(C.Structure):
@@ -161,6 +161,7 @@ def _declare_containers(L):
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
+    L.zs_rocm_mpm_update_stress.argtypes = [vp, PP, Particles]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_halo_pack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp]
     L.zs_rocm_mpm_halo_unpack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp, i32]

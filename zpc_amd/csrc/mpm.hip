@@ -336,9 +336,15 @@ template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p
 }
 
 struct ParticlesDev {
-  Port<float> mass, pos, vel, C, F, logJp;
+  Port<float> mass, pos, vel, C, F, logJp, stress;
   size_t n;
 };
+// third "model" of the P2G kernels: P F^T * vol is read from the particles' `stress` attribute (written by the G2P of
+// the previous step, or by zs_rocm_mpm_update_stress) instead of being recomputed
+constexpr int MPM_CACHED_STRESS = 2;
+
+template <int N> __device__ __forceinline__ void load_attr(const Port<float> &p, size_t i, float (&out)[N]);
+template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p, size_t i, const float (&v)[N]);
 struct MpmDev {
   Material mat;
   int model;
@@ -351,10 +357,13 @@ struct MpmDev {
 template <int MODEL>
 __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const ParticlesDev &ps, size_t i, float D_inv, float (&contrib)[9]) {
   float F[9];
-  load_attr<9>(ps.F, i, F);
-  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
+  if constexpr (MODEL == MPM_CACHED_STRESS) {
+    load_attr<9>(ps.stress, i, contrib);
+  } else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
+    load_attr<9>(ps.F, i, F);
     stress_fixedcorotated(mp.mat, F, contrib);
   } else {
+    load_attr<9>(ps.F, i, F);
     float lj = ps.logJp.base[ps.logJp.off(i)];
     stress_sand<false>(mp.mat, lj, F, contrib);
     ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back (as in the reference)
@@ -581,12 +590,13 @@ struct RecA {  // sweep A inputs: x, v, C, m (16 floats)
     mass = ps.mass.base[ps.mass.off(i)];
   }
 };
-template <int MODEL> struct RecB {  // sweep B inputs: x, F (, logJp)
+template <int MODEL> struct RecB {  // sweep B inputs: x, F (, logJp) -- or x, cached P F^T vol
   float pos[3], F[9], logJp;
   __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
     load_attr<3>(ps.pos, i, pos);
-    load_attr<9>(ps.F, i, F);
-    if constexpr (MODEL != ZS_MPM_FIXED_COROTATED) logJp = ps.logJp.base[ps.logJp.off(i)];
+    if constexpr (MODEL == MPM_CACHED_STRESS) load_attr<9>(ps.stress, i, F);
+    else load_attr<9>(ps.F, i, F);
+    if constexpr (MODEL == ZS_MPM_DRUCKER_PRAGER) logJp = ps.logJp.base[ps.logJp.off(i)];
   }
 };
 
@@ -700,7 +710,10 @@ __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesD
         make_arena(mp.dx, cur.pos, ar);
         if (ar.corner[0] - geo.org[0] == cx && ar.corner[1] - geo.org[1] == cy && ar.corner[2] - geo.org[2] == cz) {
           float contrib[9];
-          if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
+          if constexpr (MODEL == MPM_CACHED_STRESS) {
+#pragma unroll
+            for (int d = 0; d < 9; ++d) contrib[d] = cur.F[d];
+          } else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
             stress_fixedcorotated(mp.mat, cur.F, contrib);
           } else {
             float lj = cur.logJp;
@@ -807,26 +820,25 @@ __global__ __launch_bounds__(256) void grid_update_kernel(float *grid, size_t nb
 }
 
 // ======================================================================================= G2P
-template <int SIDE>
-__device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&vel)[3],
-                                           const float (&C)[9]) {
-#pragma unroll
-  for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
-  float oldF[9], tmp[9], F[9];
-  load_attr<9>(ps.F, i, oldF);
-#pragma unroll
-  for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
-  store_attr<9>(ps.F, i, F);
-  store_attr<3>(ps.pos, i, pos);
-  store_attr<3>(ps.vel, i, vel);
-  store_attr<9>(ps.C, i, C);
+// constitutive update for the NEXT P2G, fused into the tail of G2P where the VALU is otherwise idle (G2P is HBM-bound, P2G
+// is VALU-bound by the SVD): stress(F_new, logJp) -> particles.stress (P F^T vol, unscaled), logJp updated.  Exactly what the
+// next P2G would compute from the same F (P2G.hpp:60-101); SMODEL < 0: disabled.
+template <int SMODEL>
+__device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&F)[9]) {
+  if constexpr (SMODEL >= 0) {
+    float PF[9];
+    if constexpr (SMODEL == ZS_MPM_FIXED_COROTATED) {
+      stress_fixedcorotated(mp.mat, F, PF);
+    } else {
+      float lj = ps.logJp.base[ps.logJp.off(i)];
+      stress_sand<false>(mp.mat, lj, F, PF);
+      ps.logJp.base[ps.logJp.off(i)] = lj;
+    }
+    store_attr<9>(ps.stress, i, PF);
+  }
 }
 
-template <int SIDE>
+template <int SIDE, int SMODEL>
 __device__ __forceinline__ void g2p_finish_loaded(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&oldF)[9],
                                                   const float (&vel)[3], const float (&C)[9]) {
 #pragma unroll
@@ -842,9 +854,17 @@ __device__ __forceinline__ void g2p_finish_loaded(const MpmDev &mp, const Partic
   store_attr<3>(ps.pos, i, pos);
   store_attr<3>(ps.vel, i, vel);
   store_attr<9>(ps.C, i, C);
+  update_stress<SMODEL>(mp, ps, i, F);
+}
+template <int SIDE, int SMODEL>
+__device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&vel)[3],
+                                           const float (&C)[9]) {
+  float oldF[9];
+  load_attr<9>(ps.F, i, oldF);
+  g2p_finish_loaded<SIDE, SMODEL>(mp, ps, i, pos, oldF, vel, C);
 }
 
-template <int SIDE>
+template <int SIDE, int SMODEL>
 __device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const ParticlesDev &ps, size_t i, const BhtDev &t, const float *grid,
                                                   float D_inv) {
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -893,17 +913,18 @@ __device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const Partic
 #pragma unroll
         for (int d = 0; d < 9; ++d) C[d] += W * vi[d % 3] * xi[d / 3] * D_inv;
       }
-  g2p_finish<SIDE>(mp, ps, i, pos, vel, C);
+  g2p_finish<SIDE, SMODEL>(mp, ps, i, pos, vel, C);
 }
 
-template <int SIDE> __global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid) {
+template <int SIDE, int SMODEL>
+__global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
   const float dxi = 1.0f / mp.dx;
-  g2p_gather_global<SIDE>(mp, ps, i, t, grid, 4.f * dxi * dxi);
+  g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
 }
 
-template <int SIDE>
+template <int SIDE, int SMODEL>
 __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *binStart,
                                                         const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
   using AL = ArenaLds;
@@ -976,7 +997,7 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
 #pragma unroll
               for (int d = 0; d < 9; ++d) C[d] += Wt * vi[d % 3] * xi[d / 3] * D_inv;
             }
-        g2p_finish_loaded<SIDE>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
+        g2p_finish_loaded<SIDE, SMODEL>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
       }
     }
     cur = nxt;
@@ -986,13 +1007,22 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
   }
 }
 
-template <int SIDE>
+template <int SIDE, int SMODEL>
 __global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *stale,
                                                         const int *staleCount) {
   const int n = *staleCount;
   const float dxi = 1.0f / mp.dx;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    g2p_gather_global<SIDE>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
+    g2p_gather_global<SIDE, SMODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
+}
+
+// stand-alone constitutive update (first step, or after the host changed F / logJp)
+template <int SMODEL> __global__ __launch_bounds__(256) void update_stress_kernel(MpmDev mp, ParticlesDev ps) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  float F[9];
+  load_attr<9>(ps.F, i, F);
+  update_stress<SMODEL>(mp, ps, i, F);
 }
 
 // ======================================================================================= misc kernels
@@ -1069,6 +1099,7 @@ static ParticlesDev make_particles(const zs_rocm_particles &p) {
   d.C = make_port<float>(p.C);
   d.F = make_port<float>(p.F);
   d.logJp = make_port<float>(p.logJp);
+  d.stress = make_port<float>(p.stress);
   d.n = p.n;
   return d;
 }
@@ -1076,8 +1107,20 @@ static ParticlesDev make_particles(const zs_rocm_particles &p) {
 #define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                                        \
   do {                                                                                    \
     if ((side) == 4 && (model) == ZS_MPM_FIXED_COROTATED) { CALL(4, ZS_MPM_FIXED_COROTATED); } \
-    else if ((side) == 4) { CALL(4, ZS_MPM_DRUCKER_PRAGER); }                             \
+    else if ((side) == 4 && (model) == ZS_MPM_DRUCKER_PRAGER) { CALL(4, ZS_MPM_DRUCKER_PRAGER); } \
+    else if ((side) == 4) { CALL(4, MPM_CACHED_STRESS); }                                 \
     else if ((model) == ZS_MPM_FIXED_COROTATED) { CALL(8, ZS_MPM_FIXED_COROTATED); }      \
+    else if ((model) == ZS_MPM_DRUCKER_PRAGER) { CALL(8, ZS_MPM_DRUCKER_PRAGER); }        \
+    else { CALL(8, MPM_CACHED_STRESS); }                                                  \
+  } while (0)
+// G2P: third argument = stress model to evaluate at the end (-1: none)
+#define ZSR_DISPATCH_SIDE_SMODEL(side, smodel, CALL)                                      \
+  do {                                                                                    \
+    if ((side) == 4 && (smodel) < 0) { CALL(4, -1); }                                     \
+    else if ((side) == 4 && (smodel) == ZS_MPM_FIXED_COROTATED) { CALL(4, ZS_MPM_FIXED_COROTATED); } \
+    else if ((side) == 4) { CALL(4, ZS_MPM_DRUCKER_PRAGER); }                             \
+    else if ((smodel) < 0) { CALL(8, -1); }                                               \
+    else if ((smodel) == ZS_MPM_FIXED_COROTATED) { CALL(8, ZS_MPM_FIXED_COROTATED); }     \
     else { CALL(8, ZS_MPM_DRUCKER_PRAGER); }                                              \
   } while (0)
 
@@ -1150,6 +1193,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
+  const int kmodel = ps.stress.base ? MPM_CACHED_STRESS : p->model;  // cached P F^T vol (see zs_rocm_mpm_g2p) or recompute
   if (binStart && cellCount && nbr) {
     if (!nblocks) return;
     const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
@@ -1161,11 +1205,11 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
                      stale, staleCount);                                                                                   \
   hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,       \
                      (const int *)staleCount)
-    ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_P2G_BINNED);
+    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_BINNED);
   } else {
 #define CALL_P2G_GLOBAL(S, M) \
   hipLaunchKernelGGL((p2g_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
-    ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_P2G_GLOBAL);
+    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_GLOBAL);
   }
 }
 
@@ -1189,25 +1233,35 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
+  const int smodel = ps.stress.base ? p->model : -1;  // also evaluate the constitutive model for the next P2G
   if (binStart && cellCount && nbr) {
     if (!nblocks) return;
     const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
     int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    if (p->side == 4) {
-      hipLaunchKernelGGL((g2p_binned_kernel<4>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, staleCount);
-      hipLaunchKernelGGL((g2p_stale_kernel<4>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale, (const int *)staleCount);
-    } else {
-      hipLaunchKernelGGL((g2p_binned_kernel<8>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, staleCount);
-      hipLaunchKernelGGL((g2p_stale_kernel<8>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale, (const int *)staleCount);
-    }
+#define CALL_G2P_BINNED(S, M)                                                                                               \
+  hipLaunchKernelGGL((g2p_binned_kernel<S, M>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,  \
+                     stale, staleCount);                                                                                    \
+  hipLaunchKernelGGL((g2p_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,        \
+                     (const int *)staleCount)
+    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_BINNED);
   } else {
-    if (p->side == 4)
-      hipLaunchKernelGGL((g2p_global_kernel<4>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid);
-    else
-      hipLaunchKernelGGL((g2p_global_kernel<8>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid);
+#define CALL_G2P_GLOBAL(S, M) \
+  hipLaunchKernelGGL((g2p_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
+    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_GLOBAL);
   }
+}
+
+void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {
+  Launch L(pol, "update_stress");
+  if (!ps.n || !ps.stress.base) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  if (p->model == ZS_MPM_FIXED_COROTATED)
+    hipLaunchKernelGGL((update_stress_kernel<ZS_MPM_FIXED_COROTATED>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
+  else
+    hipLaunchKernelGGL((update_stress_kernel<ZS_MPM_DRUCKER_PRAGER>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
 }
 
 void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *F, float *logJp, size_t n, float *PF) {

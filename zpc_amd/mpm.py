@@ -21,12 +21,17 @@ FIXED_COROTATED, DRUCKER_PRAGER = 0, 1
 class MpmTransfer:
     def __init__(self, pol, n, dx, dt, model=FIXED_COROTATED, side=4, lane_width=64, E=5e4, nu=0.4, volume=1.0,
                  cohesion=0.0, beta=1.0, yield_surface=0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), vol_correction=True,
-                 device="cuda", key_is_origin=False, aos=False):
+                 device="cuda", key_is_origin=False, aos=False, cache_stress=False):
         self.pol, self.n, self.L, self.side = pol, int(n), int(lane_width), int(side)
         self.device = torch.device(device)
         self.model = model
         self.nchn = 25 + (1 if model == DRUCKER_PRAGER else 0)
         self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
+        # cache_stress: 9 extra channels "PF" hold P F^T vol, written by G2P (and update_stress), read by P2G
+        self.cache_stress = bool(cache_stress)
+        if self.cache_stress:
+            self.off["PF"] = self.nchn
+            self.nchn += 9
         self.aos = bool(aos)  # AoS storage (the zs::Particles / zs::Vector<vec<T,N>> form) instead of the AoSoA TileVector
         if self.aos:
             self.L = 1
@@ -52,7 +57,12 @@ class MpmTransfer:
     def particles(self):
         null = Port(None, 0, 0, 0, 1)
         return Particles(self._port("m"), self._port("x"), self._port("v"), self._port("C"), self._port("F"),
-                         self._port("logJp") if self.model == DRUCKER_PRAGER else null, self.n)
+                         self._port("logJp") if self.model == DRUCKER_PRAGER else null,
+                         self._port("PF") if self.cache_stress else null, self.n)
+
+    def update_stress(self):
+        """particles.PF := model(F, logJp) * vol (first step / after host edits of F); no-op without cache_stress."""
+        lib().zs_rocm_mpm_update_stress(self.pol.handle, C.byref(self.params), self.particles())
 
     def upload(self, mass, pos, vel, Cm, F, logJp=None):
         """AoS host/device arrays -> AoSoA particle buffer (zs_rocm_tv_from_aos_f32)."""
@@ -62,6 +72,8 @@ class MpmTransfer:
         if self.model == DRUCKER_PRAGER:
             lj = torch.zeros(self.n) if logJp is None else torch.as_tensor(logJp, dtype=torch.float32)
             cols.append(lj.reshape(self.n, 1))
+        if self.cache_stress:
+            cols.append(torch.zeros(self.n, 9))
         aos = torch.cat([c.to(self.device) for c in cols], dim=1).contiguous()
         lib().zs_rocm_tv_from_aos_f32(self.pol.handle, aos.data_ptr(), self.n, self.nchn, self.L, self.buf.data_ptr())
         self.pol.syncCtx()
