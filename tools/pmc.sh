@@ -9,7 +9,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$R/gpurun_out/pmc_$tag/$name
   mkdir -p $out
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py $args > $out/bench.json 2> $out/stderr.txt
+  rocprofv3 --kernel-trace --kernel-include-regex "binned_kernel|binned_split|tv_scale" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py $args > $out/bench.json 2> $out/stderr.txt
   f=$(find $out -name '*counter_collection.csv' | head -1)
   echo "== $grp -> $f"
   python3 - "$f" <<'PY'
