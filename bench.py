@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=str, default="125,512,125", help="sand column extent in cells (8 particles each)")
     ap.add_argument("--model", type=str, default="sand", choices=["sand", "jello"])
-    ap.add_argument("--side", type=int, default=4, choices=[4, 8])
+    ap.add_argument("--side", type=int, default=8, choices=[4, 8],
+                    help="grid block side: 8 = SparseGrid<3,f32,8> blocks (default, the '512^3 sparse grid' of BASELINE.json), 4 = Grids<f32,3,4>")
     ap.add_argument("--lane-width", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -314,8 +315,9 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MPM sand column %dx%dx%d cells, 8 particles/cell = %d particles, dx=1/512 (512^3 sparse grid), "
-                                   "%s, Grids<f32,3,%d> blocks, TileVector<f32,%d> particles; step = grid reset + P2G + grid update + G2P%s"
-                       % (ext[0], ext[1], ext[2], n_total, "DruckerPrager" if model else "FixedCorotated", a.side, a.lane_width,
+                                   "%s, %d^3-cell grid blocks (bht<int,3,int,16> + TileVector<f32,%d^3> {m,v,rhs}), TileVector<f32,%d> particles; "
+                                   "step = grid reset + P2G + grid update + G2P%s"
+                       % (ext[0], ext[1], ext[2], n_total, "DruckerPrager" if model else "FixedCorotated", a.side, a.side, a.lane_width,
                           "" if not a.unbinned else " [particle-order path]"),
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),

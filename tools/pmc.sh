@@ -20,6 +20,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r.get("Kernel_Name", "")
     if "p2g_binned" in k or "g2p_binned" in k or "tv_scale" in k:
+        k = k.split("(")[0]
         short = "p2g_binned" if "p2g_binned" in k else ("g2p_binned" if "g2p_binned" in k else "tv_scale")
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
