@@ -11,6 +11,7 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute("select %s, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by %s order by 3 desc" % (name_col, name_col)).fetchall()
+    rows = sorted(rows, key=lambda r: (0 if "zsr::" in r[0] else 1, -r[2]))  # this library's kernels first, then setup (torch) kernels
     total = sum(r[2] for r in rows) or 1
     lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for n, c, t, a, mn, mx in rows:
