@@ -231,7 +231,7 @@ def main():
             d = dev_buf(buf)
             if d is not buf:
                 d.copy_(buf)
-            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 1)
+            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     p2g_ev, g2p_ev = [], []

@@ -345,7 +345,8 @@ ZS_ROCM_EXPORT void zs_rocm_svd3(zs_rocm_policy *, const float *F, size_t n, flo
 
 /* ghost-block halo exchange helpers for the multi-GPU domain decomposition (no reference counterpart:
  * zpc has no collective layer).  pack: buf[i][c][k] = grid[blocks[i]][chn0+c][k];
- * unpack_add / unpack_set the reverse. */
+ * unpack: add = 0 set, 1 add (every block listed once), 2 atomic add (a block may be listed several times: concatenated
+ * messages of several peers). */
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_pack(zs_rocm_policy *, const float *grid, const int *blocks, size_t nb, int side,
                                           int chn0, int nchn, float *buf);
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_unpack(zs_rocm_policy *, float *grid, const int *blocks, size_t nb, int side,

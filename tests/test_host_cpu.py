@@ -76,7 +76,7 @@ def lookup(sk):
     return np.array([m[tuple(k)] for k in sk], np.int64)
 h = HaloExchange(dist, rank, world, keys, lookup, lambda x: torch.from_numpy(x.astype(np.int64)), lambda m: torch.zeros(max(m, 1)), bf)
 def pack(blocks, nb, buf): buf[: nb * bf] = grid[blocks].reshape(-1)
-def unpack_add(blocks, nb, buf): grid[blocks] += buf[: nb * bf].reshape(nb, 7, nc)
+def unpack_add(blocks, nb, buf): grid.index_add_(0, blocks, buf[: nb * bf].reshape(nb, 7, nc))
 h.exchange(pack, unpack_add)
 other = 1 - rank
 for i, k in enumerate(keys):
@@ -85,7 +85,7 @@ for i, k in enumerate(keys):
     else:
         exp = orig[i]
     assert torch.allclose(grid[i], exp), (rank, k)
-assert len(h.peers) == 1 and h.peers[0][2] == 2 and h.bytes_per_exchange == 2 * bf * 4
+assert len(h.peers) == 1 and h.peers[0][2] == 2 and h.total_blocks == 2 and h.bytes_per_exchange == 2 * bf * 4
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """

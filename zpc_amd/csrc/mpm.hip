@@ -1277,13 +1277,16 @@ __global__ void halo_pack_kernel(const float *grid, const int *blocks, size_t nb
   const size_t i = g / per, r = g % per;
   buf[g] = grid[((size_t)blocks[i] * 7 + chn0) * nc + r];
 }
-template <bool ADD> __global__ void halo_unpack_kernel(float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, const float *buf) {
+// MODE 0: set, 1: add (each block appears once in `blocks`), 2: atomic add (the list may name a block several times, e.g. the
+// concatenated messages of several peers that all share a corner block)
+template <int MODE> __global__ void halo_unpack_kernel(float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, const float *buf) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)nchn * nc;
   if (g >= nb * per) return;
   const size_t i = g / per, r = g % per;
   float *dst = grid + ((size_t)blocks[i] * 7 + chn0) * nc + r;
-  if (ADD) *dst += buf[g];  // each (block, channel, cell) appears once per message: no atomics needed
+  if constexpr (MODE == 2) unsafeAtomicAdd(dst, buf[g]);
+  else if constexpr (MODE == 1) *dst += buf[g];
   else *dst = buf[g];
 }
 
@@ -1538,11 +1541,14 @@ void zs_rocm_mpm_halo_unpack(zs_rocm_policy *pol, float *grid, const int *blocks
   Launch L(pol, "halo_unpack");
   const int nc = side * side * side;
   if (!nb) return;
-  if (add)
-    hipLaunchKernelGGL((halo_unpack_kernel<true>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
+  if (add == 2)
+    hipLaunchKernelGGL((halo_unpack_kernel<2>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
+                       nchn, buf);
+  else if (add)
+    hipLaunchKernelGGL((halo_unpack_kernel<1>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
                        nchn, buf);
   else
-    hipLaunchKernelGGL((halo_unpack_kernel<false>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
+    hipLaunchKernelGGL((halo_unpack_kernel<0>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
                        nchn, buf);
 }
 

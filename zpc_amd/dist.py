@@ -80,6 +80,7 @@ class HaloExchange:
             mine[: my_keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(my_keys.astype(np.int32))).to(backend_dev)
         allk = [torch.zeros_like(mine) for _ in range(world_size)]
         dist.all_gather(allk, mine)
+        found = []
         for p in range(world_size):
             if p == rank:
                 continue
@@ -89,22 +90,35 @@ class HaloExchange:
                 continue
             local = lookup(sk)
             assert (local >= 0).all()
-            nb = sk.shape[0]
-            self.peers.append((p, make_index_tensor(local.astype(np.int32)), nb, make_buffer(nb * block_floats),
-                               make_buffer(nb * block_floats)))
-        self.bytes_per_exchange = sum(x[2] for x in self.peers) * block_floats * 4
+            found.append((p, local.astype(np.int32)))
+        # one concatenated block list / send buffer / receive buffer: ONE pack launch and ONE unpack launch per exchange,
+        # the per-peer messages are contiguous slices of the two buffers
+        total = sum(x[1].shape[0] for x in found)
+        self.total_blocks = total
+        self.block_floats = block_floats
+        if total:
+            self.blocks_all = make_index_tensor(np.concatenate([x[1] for x in found]))
+            self.sendbuf = make_buffer(total * block_floats)
+            self.recvbuf = make_buffer(total * block_floats)
+            off = 0
+            for p, local in found:
+                nb = local.shape[0]
+                self.peers.append((p, off, nb))
+                off += nb
+        self.bytes_per_exchange = total * block_floats * 4
 
     def exchange(self, pack, unpack_add):
+        """pack(blocks, nb, buf): buf[i] = grid[blocks[i]];  unpack_add(blocks, nb, buf): grid[blocks[i]] += buf[i] with
+        ATOMIC adds (a corner block shared with several peers is listed once per peer)."""
         if not self.peers:
             return
         d = self.dist
+        bf = self.block_floats
+        pack(self.blocks_all, self.total_blocks, self.sendbuf)
         ops = []
-        for p, blocks, nb, sbuf, rbuf in self.peers:
-            pack(blocks, nb, sbuf)
-        for p, blocks, nb, sbuf, rbuf in self.peers:
-            ops.append(d.P2POp(d.isend, sbuf, p))
-            ops.append(d.P2POp(d.irecv, rbuf, p))
+        for p, off, nb in self.peers:
+            ops.append(d.P2POp(d.isend, self.sendbuf[off * bf:(off + nb) * bf], p))
+            ops.append(d.P2POp(d.irecv, self.recvbuf[off * bf:(off + nb) * bf], p))
         for w in d.batch_isend_irecv(ops):
             w.wait()
-        for p, blocks, nb, sbuf, rbuf in self.peers:
-            unpack_add(blocks, nb, rbuf)
+        unpack_add(self.blocks_all, self.total_blocks, self.recvbuf)
