@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", type=str, default="125,512,125", help="sand column extent in cells (8 particles each)")
+    ap.add_argument("--cells", type=str, default="128,512,128",
+                    help="sand column extent in cells, 8 particles each (default 128x512x128 = 64 Mi particles; splits evenly on block planes for 2/4/8 ranks)")
     ap.add_argument("--model", type=str, default="sand", choices=["sand", "jello"])
     ap.add_argument("--side", type=int, default=8, choices=[4, 8],
                     help="grid block side: 8 = SparseGrid<3,f32,8> blocks (default, the '512^3 sparse grid' of BASELINE.json), 4 = Grids<f32,3,4>")
