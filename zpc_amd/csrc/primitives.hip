@@ -338,7 +338,7 @@ void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out) 
 }
 
 // ======================================================================================= radix sort
-constexpr int RS_BLOCK = 256;
+constexpr int RS_BLOCK = 512;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_BLOCK * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_NW = RS_BLOCK / 64;
@@ -352,41 +352,83 @@ template <class K> struct KeyBits {
 };
 
 // position of (wave w, item k, lane l) inside a tile: w*(64*ITEMS) + k*64 + l -> coalesced and order preserving
-template <class K>
-__global__ __launch_bounds__(RS_BLOCK) void radix_hist_kernel(Port<const K> keys, size_t n, int st, unsigned mask,
-                                                              unsigned *counts, unsigned numTiles) {
-  __shared__ unsigned hist[256];
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
+// ---------------------------------------------------------------------------------------- onesweep
+// One kernel per 8-bit pass (Adinets & Merrill, "Onesweep"): the global digit histograms of ALL passes are taken in one
+// upfront read of the keys; in a pass every tile ranks its keys (ballot multisplit, as above), obtains the start of each of
+// its 256 digit runs by a chained scan over per-(tile, digit) descriptors (decoupled look-back, dynamic tile ticket) and
+// scatters.  Keys are first permuted into tile-local digit order in LDS so that a wave writes contiguous runs.
+// Traffic: 4 B/key (histograms) + passes x (4 R + 4 W) instead of passes x (4 + 4 + 4) + count scans.
+constexpr unsigned OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
+
+template <class K, int NPASS>
+__global__ __launch_bounds__(256) void radix_global_hist_kernel(Port<const K> keys, size_t n, int sbit, int ebit, unsigned *ghist) {
+  __shared__ unsigned h[NPASS][256];
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k) {
-    size_t i = base + (size_t)k * 64;
-    if (i < n) atomicAdd(&hist[KeyBits<K>::digit(keys[i], st, mask)], 1u);
+  for (int p = 0; p < NPASS; ++p) h[p][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const K k = keys[i];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int st = sbit + 8 * p;
+      if (st < ebit) {
+        const int bits = ebit - st < 8 ? ebit - st : 8;
+        atomicAdd(&h[p][KeyBits<K>::digit(k, st, (1u << bits) - 1u)], 1u);  // ds_add_u32: full rate (unlike ds_add_f32)
+      }
+    }
   }
   __syncthreads();
-  counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];  // digit-major for the scan
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p)
+    if (h[p][threadIdx.x]) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
+}
+// exclusive scan of each pass's 256-bin histogram (one block of 256 threads per pass)
+__global__ __launch_bounds__(256) void radix_hist_scan_kernel(unsigned *ghist) {
+  __shared__ unsigned sm[4];
+  unsigned *h = ghist + blockIdx.x * 256;
+  const unsigned v = h[threadIdx.x];
+  unsigned s = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = shfl_up(s, d);
+    if (lane_id() >= d) s += o;
+  }
+  if (lane_id() == 63) sm[wave_id()] = s;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wave_id(); ++w) base += sm[w];
+  h[threadIdx.x] = base + s - v;
 }
 
-template <class K, bool PAIR>
-__global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(Port<const K> kin, Port<const int> vin, Port<K> kout,
-                                                                 Port<int> vout, size_t n, int st, unsigned mask,
-                                                                 const unsigned *offsets, unsigned numTiles) {
-  __shared__ unsigned cnt[RS_NW][256];  // per-wave digit counters, then per-wave exclusive offsets
-  __shared__ unsigned gbase[256];
-  const int lane = lane_id(), w = wave_id();
-#pragma unroll
-  for (int i = 0; i < RS_NW; ++i) cnt[i][threadIdx.x] = 0;
-  gbase[threadIdx.x] = offsets[(size_t)threadIdx.x * numTiles + blockIdx.x];
+template <class K, bool PAIR, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin, Port<const int> vin, Port<K> kout, Port<int> vout,
+                                                               size_t n, int st, unsigned mask, const unsigned *gbase,
+                                                               unsigned *desc, unsigned *ticket) {
+  constexpr int NW = BLOCK / 64, TILE = BLOCK * ITEMS;
+  static_assert(BLOCK >= 256 && BLOCK % 256 == 0, "one thread per digit in the first 256 threads");
+  __shared__ unsigned cnt[NW][256];      // per-wave digit counters -> per-wave exclusive offsets inside the digit run
+  __shared__ unsigned tileStart[256];    // start of digit d inside the tile-local sorted order
+  __shared__ unsigned globalStart[256];  // start of this tile's run of digit d in the output
+  __shared__ unsigned sWave[4];
+  __shared__ unsigned sTile;
+  __shared__ K keyS[TILE];
+  __shared__ int valS[PAIR ? TILE : 1];
+  const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+  if (t == 0) sTile = atomicAdd(ticket, 1u);
+  for (int i = t; i < NW * 256; i += BLOCK) (&cnt[0][0])[i] = 0;
   __syncthreads();
+  const unsigned tile = sTile;
+  const size_t tileBase = (size_t)tile * TILE;
+  const unsigned tileCount = (unsigned)(n - tileBase < TILE ? n - tileBase : TILE);
 
-  K key[RS_ITEMS];
-  int val[RS_ITEMS];
-  unsigned rank[RS_ITEMS];
-  const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS) + lane;
+  K key[ITEMS];
+  int val[ITEMS];
+  unsigned rank[ITEMS];
+  const size_t base = tileBase + (size_t)w * (64 * ITEMS) + lane;
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k) {
-    size_t i = base + (size_t)k * 64;
+  for (int k = 0; k < ITEMS; ++k) {
+    const size_t i = base + (size_t)k * 64;
     if (i < n) {
       key[k] = kin[i];
       if constexpr (PAIR) val[k] = vin[i];
@@ -395,44 +437,97 @@ __global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(Port<const K> k
   volatile unsigned *wc = cnt[w];
   const unsigned long long lt = lanemask_lt();
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const bool valid = base + (size_t)k * 64 < n;
     const unsigned d = valid ? KeyBits<K>::digit(key[k], st, mask) : 0u;
-    // lanes of this wave holding the same digit (multisplit by 8 ballots)
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
-    unsigned old = 0;
-    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-    if (valid && lane == leader) {
-      old = wc[d];
-      wc[d] = old + (unsigned)__popcll(peers);
-    }
-    old = shfl(old, leader);
-    rank[k] = old + (unsigned)__popcll(peers & lt);
+    // every lane reads its digit's running count (same-address broadcast), then the lowest peer lane bumps it: LDS
+    // operations of one wave execute in order, so no cross-lane shuffle of the old value is needed
+    const unsigned below = (unsigned)__popcll(peers & lt);
+    const unsigned old = wc[d];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) wc[d] = old + (unsigned)__popcll(peers);
+    rank[k] = old + below;
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  {  // per digit: exclusive prefix over the waves of this tile
+  // thread t < 256 owns digit t: wave offsets, tile count, chained scan
+  unsigned myCount = 0, excl = 0;
+  unsigned *myDesc = desc + (size_t)tile * 256 + t;
+  if (t < 256) {
     unsigned run = 0;
 #pragma unroll
-    for (int i = 0; i < RS_NW; ++i) {
-      unsigned c = cnt[i][threadIdx.x];
-      cnt[i][threadIdx.x] = run;
+    for (int i = 0; i < NW; ++i) {
+      const unsigned c = cnt[i][t];
+      cnt[i][t] = run;
       run += c;
+    }
+    myCount = run;
+    __hip_atomic_store(myDesc, (tile == 0 ? OS_FLAG_PREFIX : OS_FLAG_AGG) | myCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // exclusive scan of the 256 tile counts -> tileStart (wave level, combined below)
+    unsigned s = myCount;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = shfl_up(s, d);
+      if (lane >= d) s += o;
+    }
+    if (lane == 63) sWave[w] = s;
+    tileStart[t] = s - myCount;
+    // look back over the predecessors' descriptors of digit t
+    if (tile != 0) {
+      long long p = (long long)tile - 1;
+      while (true) {
+        const unsigned v = __hip_atomic_load(desc + (size_t)p * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = v & ~OS_VAL_MASK;
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += v & OS_VAL_MASK;
+        if (f == OS_FLAG_PREFIX) break;
+        --p;
+      }
+      __hip_atomic_store(myDesc, OS_FLAG_PREFIX | (excl + myCount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    globalStart[t] = gbase[t] + excl;
+  }
+  __syncthreads();
+  if (t < 256) {
+    unsigned b = 0;
+    for (int i = 0; i < w; ++i) b += sWave[i];
+    const unsigned ts = tileStart[t] + b;
+    tileStart[t] = ts;
+    globalStart[t] -= ts;  // (wrapping) so that dst = globalStart[d] + position in the tile-sorted order
+#pragma unroll
+    for (int i = 0; i < NW; ++i) cnt[i][t] += ts;  // tile-sorted position = cnt[w][d] + rank
+  }
+  __syncthreads();
+  // tile-local digit order in LDS
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    if (base + (size_t)k * 64 < n) {
+      const unsigned d = KeyBits<K>::digit(key[k], st, mask);
+      const unsigned lp = cnt[w][d] + rank[k];
+      keyS[lp] = key[k];
+      if constexpr (PAIR) valS[lp] = val[k];
     }
   }
   __syncthreads();
+  // coalesced runs out
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k) {
-    if (base + (size_t)k * 64 < n) {
-      const unsigned d = KeyBits<K>::digit(key[k], st, mask);
-      const size_t dst = (size_t)gbase[d] + cnt[w][d] + rank[k];
-      kout[dst] = key[k];
-      if constexpr (PAIR) vout[dst] = val[k];
+  for (int k = 0; k < ITEMS; ++k) {
+    const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
+    if (lp < tileCount) {
+      const K kk = keyS[lp];
+      const unsigned d = KeyBits<K>::digit(kk, st, mask);
+      const size_t dst = (size_t)(globalStart[d] + lp);
+      kout[dst] = kk;
+      if constexpr (PAIR) vout[dst] = valS[lp];
     }
   }
 }
@@ -468,13 +563,24 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
     return;
   }
   const unsigned numTiles = ceil_div(n, RS_TILE);
-  unsigned *counts = (unsigned *)L.temp(sizeof(unsigned) * 256 * (size_t)numTiles);
+  constexpr int MAXPASS = (int)sizeof(K);
+  // [MAXPASS][256] global digit starts + per pass: ticket + [numTiles][256] descriptors (re-initialised every call)
+  const size_t descBytes = sizeof(unsigned) * (256 * (size_t)numTiles + 64);
+  unsigned *ghist = (unsigned *)L.temp(sizeof(unsigned) * 256 * MAXPASS);
+  char *descMem = (char *)L.temp(descBytes * (size_t)passes);
+  ZSR_CHECK(hipMemsetAsync(ghist, 0, sizeof(unsigned) * 256 * MAXPASS, L.stream));
+  ZSR_CHECK(hipMemsetAsync(descMem, 0, descBytes * (size_t)passes, L.stream));
   K *tk[2] = {nullptr, nullptr};
   int *tv[2] = {nullptr, nullptr};
   const int ntemp = passes >= 3 ? 2 : passes - 1;
   for (int i = 0; i < ntemp; ++i) {
     tk[i] = (K *)L.temp(sizeof(K) * n);
     if (PAIR) tv[i] = (int *)L.temp(sizeof(int) * n);
+  }
+  {
+    const unsigned hb = (unsigned)std::min<size_t>(ceil_div(n, 256 * 16), 2048);
+    hipLaunchKernelGGL((radix_global_hist_kernel<K, MAXPASS>), dim3(hb), dim3(256), 0, L.stream, kin, n, sbit, ebit, ghist);
+    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(256), 0, L.stream, ghist);
   }
   Port<const K> srcK = kin;
   Port<const int> srcV = vin;
@@ -490,10 +596,10 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
       dstK = contiguous_port<K>(tk[which]);
       if (PAIR) dstV = contiguous_port<int>(tv[which]);
     }
-    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, n, st, mask, counts, numTiles);
-    exclusive_scan_u32(L, counts, 256 * (size_t)numTiles, counts);
-    hipLaunchKernelGGL((radix_scatter_kernel<K, PAIR>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, srcV, dstK, dstV, n,
-                       st, mask, (const unsigned *)counts, numTiles);
+    unsigned *desc = (unsigned *)(descMem + descBytes * (size_t)p);
+    unsigned *ticket = desc + 256 * (size_t)numTiles;
+    hipLaunchKernelGGL((radix_onesweep_kernel<K, PAIR, RS_BLOCK, RS_ITEMS>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, srcV, dstK, dstV, n, st,
+                       mask, (const unsigned *)(ghist + 256 * p), desc, ticket);
     srcK = Port<const K>{dstK.base, dstK.idx, dstK.bits, dstK.mask, dstK.chns};
     if (PAIR) srcV = Port<const int>{dstV.base, dstV.idx, dstV.bits, dstV.mask, dstV.chns};
   }
