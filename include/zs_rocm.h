@@ -87,7 +87,8 @@ ZS_ROCM_DECL_PORT(const double, aosoa_iterator_const_double_1)
 /* ======================================================================== (A) parallel primitives */
 /* py_interop/cuda/ExecutionPolicy.cpp:41-131 (ZS_DEFINE_PARALLEL_PRIMITIVES for int, float, double).
  * reduce: out[0] = fold(op, init, [first,last)) with init = 0 / 1 / numeric max / numeric lowest;
- * scans with init = identity; radix sort over all key bits (integral T only, as in the reference). */
+ * scans with init = identity; merge sort = stable in-place sort by `<` (`:99-111`; pair form permutes int values);
+ * radix sort over all key bits (integral T only, as in the reference). */
 #define ZS_ROCM_DECL_PRIMITIVES(T)                                                                          \
   ZS_ROCM_EXPORT void reduce_sum__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1 first,        \
                                                aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1);  \
@@ -105,6 +106,10 @@ ZS_ROCM_DECL_PORT(const double, aosoa_iterator_const_double_1)
                                                        aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
   ZS_ROCM_EXPORT void inclusive_scan_prod__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_const_##T##_1,     \
                                                         aosoa_iterator_const_##T##_1, aosoa_iterator_##T##_1); \
+  ZS_ROCM_EXPORT void merge_sort__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 first,              \
+                                               aosoa_iterator_##T##_1 last);                                \
+  ZS_ROCM_EXPORT void merge_sort_pair__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 keys,          \
+                                                    aosoa_iterator_int_1 vals, size_t count);               \
   ZS_ROCM_EXPORT void radix_sort__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 first,              \
                                                aosoa_iterator_##T##_1 last, aosoa_iterator_##T##_1 out);    \
   ZS_ROCM_EXPORT void radix_sort_pair__rocm_##T##_1(zs_rocm_policy *, aosoa_iterator_##T##_1 keysIn,        \
@@ -130,6 +135,15 @@ ZS_ROCM_EXPORT void zs_rocm_radix_sort_i32(zs_rocm_policy *, const int32_t *kin,
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_u32(zs_rocm_policy *, const uint32_t *kin, const int32_t *vin, uint32_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_i64(zs_rocm_policy *, const int64_t *kin, const int32_t *vin, int64_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_u64(zs_rocm_policy *, const uint64_t *kin, const int32_t *vin, uint64_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
+/* stable in-place merge sort (zs::merge_sort / merge_sort_pair, execution/ExecutionPolicy.hpp:745-761,
+ * cuda/execution/ExecutionPolicy.cuh:698-752); `descending` != 0 sorts with `>`; vals may be NULL for keys-only.
+ * User comparators: include/zensim_rocm/merge_sort.hpp through the C++ face. */
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_i32(zs_rocm_policy *, int32_t *keys, int32_t *vals, size_t n, int descending);
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_u32(zs_rocm_policy *, uint32_t *keys, int32_t *vals, size_t n, int descending);
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_i64(zs_rocm_policy *, int64_t *keys, int32_t *vals, size_t n, int descending);
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_u64(zs_rocm_policy *, uint64_t *keys, int32_t *vals, size_t n, int descending);
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_f32(zs_rocm_policy *, float *keys, int32_t *vals, size_t n, int descending);
+ZS_ROCM_EXPORT void zs_rocm_merge_sort_f64(zs_rocm_policy *, double *keys, int32_t *vals, size_t n, int descending);
 
 /* ======================================================================== (A) allocators & Vector */
 /* py_interop/Allocator.cpp:5-21; memsrc_e: 0 = host, 1 = device, 2 = um (types/Property.h:7) */

@@ -333,3 +333,59 @@ DEF_SORT(int32_t, uint32_t, i32, 0x80000000u)
 DEF_SORT(uint32_t, uint32_t, u32, 0u)
 DEF_SORT(int64_t, uint64_t, i64, 0x8000000000000000ull)
 DEF_SORT(uint64_t, uint64_t, u64, 0ull)
+
+/* ------------------------------------------------------------------------------------------------
+ * merge_sort / merge_sort_pair, SequentialExecutionPolicy (execution/ExecutionPolicy.hpp:341-420):
+ * insertion sort of every run of 16 (`:347-361`: swap while comp(keys[k], keys[k-1])), then bottom-up
+ * passes halfStride = 16, 32, ... merging [ll, mid) and [mid, rr) into the other buffer, left element
+ * first unless comp(b, a) (`:378-386`), tails copied (`:387-394`); result copied back when the ping-pong
+ * ended in the temporary (`switched`, `:420`). */
+#define DEF_MSORT(T, S)                                                                            \
+  static int msort_lt_##S(T a, T b, int desc) { return desc ? (a > b) : (a < b); }                \
+  void orc_merge_sort_##S(T *keys, int32_t *vals, size_t n, int desc) {                            \
+    if (n == 0) return;                                                                            \
+    for (size_t ll = 0; ll < n;) {                                                                 \
+      size_t rr = ll + 16 < n ? ll + 16 : n;                                                       \
+      for (size_t i = ll + 1; i != rr; ++i)                                                        \
+        for (size_t k = i; k != ll; --k) {                                                         \
+          size_t j = k - 1;                                                                        \
+          if (!msort_lt_##S(keys[k], keys[j], desc)) break;                                        \
+          T tk = keys[k]; keys[k] = keys[j]; keys[j] = tk;                                         \
+          if (vals) { int32_t tv = vals[k]; vals[k] = vals[j]; vals[j] = tv; }                     \
+        }                                                                                          \
+      ll = rr;                                                                                     \
+    }                                                                                              \
+    T *ok = (T *)malloc(n * sizeof(T));                                                            \
+    int32_t *ov = vals ? (int32_t *)malloc(n * sizeof(int32_t)) : NULL;                            \
+    T *ck = keys, *nk = ok;                                                                        \
+    int32_t *cv = vals, *nv = ov;                                                                  \
+    for (size_t half = 16; half < n; half *= 2) {                                                  \
+      size_t stride = half * 2;                                                                    \
+      for (size_t ll = 0; ll < n; ll += stride) {                                                  \
+        size_t mid = ll + half < n ? ll + half : n, rr = ll + stride < n ? ll + stride : n;        \
+        size_t left = ll, right = mid, k = ll;                                                     \
+        while (left < mid && right < rr) {                                                         \
+          if (!msort_lt_##S(ck[right], ck[left], desc)) {                                          \
+            nk[k] = ck[left]; if (vals) nv[k] = cv[left]; ++k; ++left;                             \
+          } else {                                                                                 \
+            nk[k] = ck[right]; if (vals) nv[k] = cv[right]; ++k; ++right;                          \
+          }                                                                                        \
+        }                                                                                          \
+        while (left < mid) { nk[k] = ck[left]; if (vals) nv[k] = cv[left]; ++k; ++left; }          \
+        while (right < rr) { nk[k] = ck[right]; if (vals) nv[k] = cv[right]; ++k; ++right; }       \
+      }                                                                                            \
+      T *tk = ck; ck = nk; nk = tk;                                                                \
+      int32_t *tv = cv; cv = nv; nv = tv;                                                          \
+    }                                                                                              \
+    if (ck != keys) {                                                                              \
+      memcpy(keys, ck, n * sizeof(T));                                                             \
+      if (vals) memcpy(vals, cv, n * sizeof(int32_t));                                             \
+    }                                                                                              \
+    free(ok); free(ov);                                                                            \
+  }
+DEF_MSORT(int32_t, i32)
+DEF_MSORT(uint32_t, u32)
+DEF_MSORT(int64_t, i64)
+DEF_MSORT(uint64_t, u64)
+DEF_MSORT(float, f32)
+DEF_MSORT(double, f64)

@@ -62,6 +62,17 @@ ORC_DECL_SORT(uint32_t, u32)
 ORC_DECL_SORT(int64_t, i64)
 ORC_DECL_SORT(uint64_t, u64)
 
+/* stable merge sort (in place), keys by `<` (descending != 0: by `>`), optional int32 values:
+ * SequentialExecutionPolicy::merge_sort_pair, execution/ExecutionPolicy.hpp:341-420 -- insertion sort on runs of
+ * 16, then bottom-up merges that take the LEFT element on ties (`!comp(b, a)`). */
+#define ORC_DECL_MSORT(T, S) void orc_merge_sort_##S(T *keys, int32_t *vals, size_t n, int descending);
+ORC_DECL_MSORT(int32_t, i32)
+ORC_DECL_MSORT(uint32_t, u32)
+ORC_DECL_MSORT(int64_t, i64)
+ORC_DECL_MSORT(uint64_t, u64)
+ORC_DECL_MSORT(float, f32)
+ORC_DECL_MSORT(double, f64)
+
 /* ---------------------------------------------------------------- TileVector (tilevector.c) */
 /* element (chn, i) of TileVector<T, L> with C channels: container/TileVector.hpp:108,397 */
 size_t orc_tv_offset(size_t i, size_t chn, size_t L, size_t C);

@@ -174,6 +174,28 @@ def test_radix_window_and_skip_path(oracle):
     assert np.array_equal(ou, np.sort(u))
 
 
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 33, 1000, 4097, 65537])
+def test_merge_sort_oracle_is_the_stable_sort(oracle, n):
+    """orc_merge_sort_* (insertion runs of 16 + bottom-up merges, ExecutionPolicy.hpp:341-420) == the unique
+    stable order, for int / float / double keys, ascending and by `>`."""
+    g = rng(54)
+    for S, k in (("i32", g.integers(-7, 7, n, dtype=np.int32)), ("f32", g.integers(-9, 9, n).astype(np.float32) * 0.5),
+                 ("f64", g.standard_normal(n)), ("u64", g.integers(0, 2**64 - 1, n, dtype=np.uint64)),
+                 ("i64", g.integers(-4, 4, n, dtype=np.int64)), ("u32", g.integers(0, 50, n, dtype=np.uint32))):
+        for desc in (0, 1):
+            kk, v = k.copy(), np.arange(n, dtype=np.int32)
+            getattr(oracle, "orc_merge_sort_" + S)(ptr(kk), ptr(v), C.c_size_t(n), desc)
+            if desc:  # stable order by `>`: stable ascending order of the reversed-rank keys
+                rank = np.unique(k, return_inverse=True)[1]
+                order = np.argsort(-rank.astype(np.int64), kind="stable")
+            else:
+                order = np.argsort(k, kind="stable")
+            assert np.array_equal(kk, k[order]) and np.array_equal(v, order.astype(np.int32))
+            k2 = k.copy()
+            getattr(oracle, "orc_merge_sort_" + S)(ptr(k2), None, C.c_size_t(n), desc)
+            assert np.array_equal(k2, k[order])
+
+
 def test_bht_oracle_semantics(oracle):
     oracle.orc_bht_create.restype = C.c_void_p
     oracle.orc_bht_size.restype = C.c_int32

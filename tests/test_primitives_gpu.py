@@ -157,6 +157,88 @@ def test_radix_sort_other_key_widths(pol, oracle, dtype):
     assert np.array_equal(vo.cpu().numpy(), v[order])
 
 
+MS_DT = {"i32": (np.int32, torch.int32), "u32": (np.uint32, torch.uint32), "i64": (np.int64, torch.int64),
+         "u64": (np.uint64, torch.uint64), "f32": (np.float32, torch.float32), "f64": (np.float64, torch.float64)}
+
+
+def _ms_keys(g, S, n, dups):
+    if S in ("f32", "f64"):
+        k = (g.integers(-20, 20, n) * 0.25) if dups else g.standard_normal(n)
+    elif S == "u64":
+        k = g.integers(0, 40, n, dtype=np.uint64) if dups else g.integers(0, 2**64 - 1, n, dtype=np.uint64)
+    else:
+        k = g.integers(0 if S[0] == "u" else -20, 20, n) if dups else g.integers(0 if S[0] == "u" else -2**31, 2**31 - 1, n)
+    return np.ascontiguousarray(k.astype(MS_DT[S][0]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 255, 2047, 2048, 2049, 4096, 6145, 65537, 1_000_003])
+@pytest.mark.parametrize("S", ["i32", "f32"])
+def test_merge_sort_pair_bit_exact(pol, oracle, n, S):
+    """zs::merge_sort_pair (stable, in place) vs the oracle's restatement of the sequential routine; duplicate keys pin
+    stability (the values are the unique stable permutation)."""
+    import zpc_amd as zs
+    g = rng(31)
+    for dups in (True, False):
+        k = _ms_keys(g, S, n, dups)
+        v = np.arange(n, dtype=np.int32)
+        dk, dv = dev(k.copy()), dev(v.copy())
+        zs.merge_sort_pair(pol, dk, dv)
+        ek, ev = k.copy(), v.copy()
+        getattr(oracle, "orc_merge_sort_" + S)(ek.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p), C.c_size_t(n), c_int(0))
+        assert np.array_equal(dk.cpu().numpy(), ek)
+        assert np.array_equal(dv.cpu().numpy(), ev)
+
+
+@pytest.mark.parametrize("S", ["i32", "u32", "i64", "u64", "f32", "f64"])
+@pytest.mark.parametrize("desc", [0, 1])
+def test_merge_sort_types_and_descending(pol, oracle, S, desc):
+    import zpc_amd as zs
+    n = 300_001
+    g = rng(32)
+    k = _ms_keys(g, S, n, True)
+    v = np.arange(n, dtype=np.int32)
+    dk, dv = dev(k.copy()), dev(v.copy())
+    zs.merge_sort_pair(pol, dk, dv, descending=bool(desc))
+    ek, ev = k.copy(), v.copy()
+    getattr(oracle, "orc_merge_sort_" + S)(ek.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p), C.c_size_t(n), c_int(desc))
+    assert np.array_equal(dk.cpu().numpy(), ek) and np.array_equal(dv.cpu().numpy(), ev)
+    k2 = _ms_keys(g, S, n, False)
+    dk2 = dev(k2.copy())
+    zs.merge_sort(pol, dk2, descending=bool(desc))
+    exp = np.sort(k2)
+    assert np.array_equal(dk2.cpu().numpy(), exp[::-1] if desc else exp)
+
+
+def test_merge_sort_through_tilevector_iterators(pol, oracle):
+    """C ABI form merge_sort(_pair)__rocm_T_1 over aosoa iterators (py_interop/cuda/ExecutionPolicy.cpp:99-111): sort channel
+    1 of a TileVector<float,32>{a:3} in place, carrying an int permutation; the other channels stay untouched."""
+    import zpc_amd as zs
+    from zpc_amd.primitives import Iter
+    L, Cn, n = 32, 3, 10_000
+    g = rng(33)
+    tiles = (n + L - 1) // L
+    buf = g.standard_normal(tiles * L * Cn).astype(np.float32)
+    d = dev(buf.copy())
+    it = Iter.aosoa(d, 0, L, 1, Cn)
+    idx = np.arange(n)
+    off = (idx // L * Cn + 1) * L + idx % L
+    keys = buf[off].copy()
+    vals = dev(np.arange(n, dtype=np.int32))
+    zs.merge_sort_pair(pol, it, vals, n)
+    order = np.argsort(keys, kind="stable")
+    exp = buf.copy()
+    exp[off] = keys[order]
+    assert np.array_equal(d.cpu().numpy(), exp)
+    assert np.array_equal(vals.cpu().numpy(), order.astype(np.int32))
+    # keys-only form on an int AoS iterator with an index offset
+    a = g.integers(-1000, 1000, 5000, dtype=np.int32)
+    da = dev(a.copy())
+    zs.merge_sort(pol, Iter.aos(da, idx=100), 4000)
+    e = a.copy()
+    e[100:4100] = np.sort(a[100:4100])
+    assert np.array_equal(da.cpu().numpy(), e)
+
+
 def test_tilevector_channel_iterators(pol, oracle):
     """reduce over the "b" channel of TileVector<int,32>{a:3,b:2,c:1}: the reference's own test
     (test/parallel_primitives.cpp:7-30, test/utils/initialization.hpp:75-93) through the iterator ABI."""

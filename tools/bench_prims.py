@@ -51,6 +51,16 @@ def main():
         add("exclusive_scan<i32>", n, 8, timeit(lambda: zs.exclusive_scan(pol, a, out)))
         add("radix_sort<i32> (32 bit)", n, 32, timeit(lambda: zs.radix_sort(pol, a, out), reps=5))
         add("radix_sort_pair<i32,i32> (32 bit)", n, 64, timeit(lambda: zs.radix_sort_pair(pol, a, v, out, vo), reps=5))
+        if n <= 16_000_000:
+            import math
+            passes = 1 + max(0, math.ceil(math.log2(max(1, n / 2048))))  # tile sort + global merge passes, 16 B/pair each
+            def ms_pair():
+                out.copy_(a); vo.copy_(v)
+                zs.merge_sort_pair(pol, out, vo)
+            def ms_copy_only():
+                out.copy_(a); vo.copy_(v)
+            t_all, t_copy = timeit(ms_pair, reps=5), timeit(ms_copy_only, reps=5)
+            add("merge_sort_pair<i32,i32> (%d passes)" % passes, n, 16 * passes, t_all - t_copy)
         del a, out, v, vo
     # config 2: TileVector<f32,32>{m:1,x:3,v:3,F:9,C:9} load-all/store-all at 16M
     for n, L, Cn in ((16_000_000, 32, 25), (64_000_000, 64, 26)):

@@ -9,4 +9,5 @@ from ._lib import lib, LIB_PATH, Port, Particles, MpmParams, BhtViewLite  # noqa
 from .policy import RocmExecutionPolicy, rocm_exec  # noqa: F401
 from . import primitives  # noqa: F401
 from .primitives import (reduce, exclusive_scan, inclusive_scan, radix_sort, radix_sort_pair,  # noqa: F401
+                         merge_sort, merge_sort_pair,
                          plus, multiplies, getmin, getmax)

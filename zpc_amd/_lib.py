@@ -75,12 +75,16 @@ def _declare(L):
                    "exclusive_scan_prod", "inclusive_scan_sum", "inclusive_scan_prod"):
             getattr(L, "%s__rocm_%s_1" % (op, T)).argtypes = [vp, Port, Port, Port]
         getattr(L, "radix_sort__rocm_%s_1" % T).argtypes = [vp, Port, Port, Port]
+        getattr(L, "merge_sort__rocm_%s_1" % T).argtypes = [vp, Port, Port]
+        getattr(L, "merge_sort_pair__rocm_%s_1" % T).argtypes = [vp, Port, Port, sz]
         getattr(L, "radix_sort_pair__rocm_%s_1" % T).argtypes = [vp, Port, Port, Port, Port, sz]
     for S, ct in (("i32", C.c_int32), ("i64", C.c_int64), ("f32", C.c_float), ("f64", C.c_double)):
         getattr(L, "zs_rocm_reduce_" + S).argtypes = [vp, vp, sz, vp, ct, i32]
         getattr(L, "zs_rocm_scan_" + S).argtypes = [vp, vp, sz, vp, ct, i32, i32]
     for S in ("i32", "u32", "i64", "u64"):
         getattr(L, "zs_rocm_radix_sort_" + S).argtypes = [vp, vp, vp, vp, vp, sz, i32, i32]
+    for S in ("i32", "u32", "i64", "u64", "f32", "f64"):
+        getattr(L, "zs_rocm_merge_sort_" + S).argtypes = [vp, vp, vp, sz, i32]
 
 
 def _declare_containers(L):

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "../../include/zensim_rocm/merge_sort.hpp"
 
 namespace zsr {
 
@@ -629,6 +630,30 @@ static void radix_sort_api(zs_rocm_policy *pol, const K *kin, const int *vin, K 
                               sbit, ebit);
 }
 
+// ======================================================================================= merge sort
+template <class T> struct LessOp {
+  __device__ __forceinline__ bool operator()(const T &a, const T &b) const { return a < b; }
+};
+template <class T> struct GreaterOp {
+  __device__ __forceinline__ bool operator()(const T &a, const T &b) const { return a > b; }
+};
+template <class T, class Comp, class KIt, class VIt>
+static void merge_sort_impl(Launch &L, KIt keys, VIt vals, bool pair, size_t n, Comp comp) {
+  using namespace zs_rocm_ms;
+  if (pair) {
+    const size_t b = scratch_bytes<T, int, true>(n);
+    merge_sort_run<T, int, true>(L.stream, keys, vals, n, comp, b ? L.temp(b) : nullptr);
+  } else {
+    const size_t b = scratch_bytes<T, NoVal, false>(n);
+    merge_sort_run<T, NoVal, false>(L.stream, keys, (NoVal *)nullptr, n, comp, b ? L.temp(b) : nullptr);
+  }
+}
+template <class T> static void merge_sort_api(zs_rocm_policy *pol, T *keys, int *vals, size_t n, int descending) {
+  Launch L(pol, "merge_sort");
+  if (descending) merge_sort_impl<T>(L, keys, vals, vals != nullptr, n, GreaterOp<T>{});
+  else merge_sort_impl<T>(L, keys, vals, vals != nullptr, n, LessOp<T>{});
+}
+
 }  // namespace zsr
 
 using namespace zsr;
@@ -679,6 +704,16 @@ extern "C" {
                                          aosoa_iterator_const_##T##_1 last, aosoa_iterator_##T##_1 out) {          \
     Launch L(pol, "inclusive_scan_prod");                                                                          \
     scan_impl<OP_MUL, T, false>(L, make_port<const T>(first), (size_t)(last.idx - first.idx), make_port<T>(out), (T)1); \
+  }                                                                                                                \
+  /* merge sort: py_interop/cuda/ExecutionPolicy.cpp:99-111 */                                                     \
+  void merge_sort__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_##T##_1 first, aosoa_iterator_##T##_1 last) {  \
+    Launch L(pol, "merge_sort");                                                                                   \
+    merge_sort_impl<T>(L, make_port<T>(first), Port<int>{}, false, (size_t)(last.idx - first.idx), LessOp<T>{});   \
+  }                                                                                                                \
+  void merge_sort_pair__rocm_##T##_1(zs_rocm_policy *pol, aosoa_iterator_##T##_1 keys, aosoa_iterator_int_1 vals,  \
+                                     size_t count) {                                                               \
+    Launch L(pol, "merge_sort_pair");                                                                              \
+    merge_sort_impl<T>(L, make_port<T>(keys), make_port<int>(vals), true, count, LessOp<T>{});                     \
   }
 
 ZSR_DEFINE_PRIMITIVES(int)
@@ -737,5 +772,12 @@ void zs_rocm_radix_sort_u64(zs_rocm_policy *p, const uint64_t *kin, const int32_
                             size_t n, int sbit, int ebit) {
   radix_sort_api<uint64_t>(p, kin, vin, kout, vout, n, sbit, ebit);
 }
+
+void zs_rocm_merge_sort_i32(zs_rocm_policy *p, int32_t *k, int32_t *v, size_t n, int d) { merge_sort_api<int32_t>(p, k, v, n, d); }
+void zs_rocm_merge_sort_u32(zs_rocm_policy *p, uint32_t *k, int32_t *v, size_t n, int d) { merge_sort_api<uint32_t>(p, k, v, n, d); }
+void zs_rocm_merge_sort_i64(zs_rocm_policy *p, int64_t *k, int32_t *v, size_t n, int d) { merge_sort_api<int64_t>(p, k, v, n, d); }
+void zs_rocm_merge_sort_u64(zs_rocm_policy *p, uint64_t *k, int32_t *v, size_t n, int d) { merge_sort_api<uint64_t>(p, k, v, n, d); }
+void zs_rocm_merge_sort_f32(zs_rocm_policy *p, float *k, int32_t *v, size_t n, int d) { merge_sort_api<float>(p, k, v, n, d); }
+void zs_rocm_merge_sort_f64(zs_rocm_policy *p, double *k, int32_t *v, size_t n, int d) { merge_sort_api<double>(p, k, v, n, d); }
 
 }  // extern "C"

@@ -137,3 +137,33 @@ def radix_sort_pair(pol, keys_in, vals_in, keys_out, vals_out, n=None, sbit=0, e
     getattr(L, "zs_rocm_radix_sort_" + S)(_check(pol), keys_in.data_ptr(), vals_in.data_ptr(), keys_out.data_ptr(),
                                           vals_out.data_ptr(), n, sbit, ebit)
     return keys_out, vals_out
+
+
+_MSORT = {"torch.int32": "i32", "torch.uint32": "u32", "torch.int64": "i64", "torch.uint64": "u64", "torch.float32": "f32",
+          "torch.float64": "f64"}
+
+
+def merge_sort(pol, keys, n=None, descending=False):
+    """zs::merge_sort(pol, first, last[, comp]) -- stable, in place (execution/ExecutionPolicy.hpp:755-761).
+    Iterator form = the C ABI `merge_sort__rocm_T_1(pol, first, last)` (comparator `<`)."""
+    L = lib()
+    if isinstance(keys, Iter):
+        cname = _CNAME[str(keys.dtype)]
+        getattr(L, "merge_sort__rocm_%s_1" % cname)(_check(pol), keys.port, keys.advanced(n).port)
+        return keys
+    n = keys.numel() if n is None else n
+    getattr(L, "zs_rocm_merge_sort_" + _MSORT[str(keys.dtype)])(_check(pol), keys.data_ptr(), None, n, int(descending))
+    return keys
+
+
+def merge_sort_pair(pol, keys, vals, n=None, descending=False):
+    """zs::merge_sort_pair(pol, keys, vals, count[, comp]) -- stable, in place, int32 values
+    (execution/ExecutionPolicy.hpp:745-753; C ABI `merge_sort_pair__rocm_T_1(pol, keys, vals, count)`)."""
+    L = lib()
+    if isinstance(keys, Iter):
+        cname = _CNAME[str(keys.dtype)]
+        getattr(L, "merge_sort_pair__rocm_%s_1" % cname)(_check(pol), keys.port, _as_iter(vals).port, n)
+        return keys, vals
+    n = keys.numel() if n is None else n
+    getattr(L, "zs_rocm_merge_sort_" + _MSORT[str(keys.dtype)])(_check(pol), keys.data_ptr(), vals.data_ptr(), n, int(descending))
+    return keys, vals
