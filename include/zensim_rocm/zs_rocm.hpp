@@ -28,6 +28,7 @@
 
 #include "../zs_rocm.h"
 #include "bht_device.hpp"
+#include "merge_sort.hpp"
 
 #define ZS_LAMBDA __device__
 #define ZS_FUNCTION __forceinline__ __host__ __device__
@@ -50,6 +51,12 @@ using StreamID = int;
 // ------------------------------------------------------------------------------------ functors (ZpcFunctional.hpp)
 template <class T = void> struct plus { ZS_FUNCTION T operator()(T a, T b) const { return a + b; } };
 template <class T = void> struct multiplies { ZS_FUNCTION T operator()(T a, T b) const { return a * b; } };
+template <class T = void> struct less {
+  template <class A, class B> ZS_FUNCTION bool operator()(const A &a, const B &b) const { return a < b; }
+};
+template <class T = void> struct greater {
+  template <class A, class B> ZS_FUNCTION bool operator()(const A &a, const B &b) const { return a > b; }
+};
 template <class T = void> struct getmin { ZS_FUNCTION T operator()(T a, T b) const { return a < b ? a : b; } };
 template <class T = void> struct getmax { ZS_FUNCTION T operator()(T a, T b) const { return a > b ? a : b; } };
 namespace detail {
@@ -433,6 +440,25 @@ struct RocmExecutionPolicy {
     call_sort(kin, vin, kout, vout, n, sbit, ebit);
   }
 
+  // merge_sort / merge_sort_pair with a user comparator (cuda/execution/ExecutionPolicy.cuh:698-752): stable, in place;
+  // `first`/`keys`/`vals` are random-access device iterators (raw pointers, or views with operator[])
+  template <class KeyIter, class Comp = less<void>> void merge_sort(KeyIter first, KeyIter last, Comp comp = {}) const {
+    using K = std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>;
+    const std::size_t n = (std::size_t)(last - first);
+    const std::size_t b = zs_rocm_ms::scratch_bytes<K, zs_rocm_ms::NoVal, false>(n);
+    zs_rocm_ms::merge_sort_run<K, zs_rocm_ms::NoVal, false>((hipStream_t)getStream(), first, (zs_rocm_ms::NoVal *)nullptr, n, comp,
+                                                            b ? zs_rocm_policy_temporary(_h, b) : nullptr);
+    finish();
+  }
+  template <class KeyIter, class ValIter, class Comp = less<void>>
+  void merge_sort_pair(KeyIter keys, ValIter vals, std::size_t n, Comp comp = {}) const {
+    using K = std::remove_cv_t<std::remove_reference_t<decltype(keys[0])>>;
+    using V = std::remove_cv_t<std::remove_reference_t<decltype(vals[0])>>;
+    const std::size_t b = zs_rocm_ms::scratch_bytes<K, V, true>(n);
+    zs_rocm_ms::merge_sort_run<K, V, true>((hipStream_t)getStream(), keys, vals, n, comp, b ? zs_rocm_policy_temporary(_h, b) : nullptr);
+    finish();
+  }
+
 private:
   void finish() const {
     if (_sync) (void)hipStreamSynchronize((hipStream_t)getStream());
@@ -474,6 +500,22 @@ template <class K> void radix_sort(const RocmExecutionPolicy &pol, const K *firs
 template <class K> void radix_sort_pair(const RocmExecutionPolicy &pol, const K *kin, const int *vin, K *kout, int *vout, std::size_t n, int sbit = 0,
                                         int ebit = sizeof(K) * 8) {
   pol.radix_sort_pair(kin, vin, kout, vout, n, sbit, ebit);
+}
+
+template <class KeyIter, class Comp = less<void>> void merge_sort(const RocmExecutionPolicy &pol, KeyIter first, KeyIter last, Comp comp = {}) {
+  pol.merge_sort(first, last, comp);
+}
+template <class KeyIter, class ValIter, class Comp = less<void>>
+void merge_sort_pair(const RocmExecutionPolicy &pol, KeyIter keys, ValIter vals, std::size_t n, Comp comp = {}) {
+  pol.merge_sort_pair(keys, vals, n, comp);
+}
+// zs::sort / sort_pair (execution/ExecutionPolicy.hpp:730-748): "currently [unstable] adopts the [stable] routine" (:341)
+template <class KeyIter, class Comp = less<void>> void sort(const RocmExecutionPolicy &pol, KeyIter first, KeyIter last, Comp comp = {}) {
+  pol.merge_sort(first, last, comp);
+}
+template <class KeyIter, class ValIter, class Comp = less<void>>
+void sort_pair(const RocmExecutionPolicy &pol, KeyIter keys, ValIter vals, std::size_t n, Comp comp = {}) {
+  pol.merge_sort_pair(keys, vals, n, comp);
 }
 
 }  // namespace zs

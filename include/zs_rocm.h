@@ -62,6 +62,10 @@ ZS_ROCM_EXPORT int zs_rocm_last_error(int device);
 ZS_ROCM_EXPORT void zs_rocm_clear_error(int device);
 ZS_ROCM_EXPORT int zs_rocm_device_count(void);
 /* frees the grow-only per-stream temporary arenas (stand-in for streamMemFree, cuda/Cuda.cu:169-176) */
+/* scratch memory for a caller-side kernel sequence on the policy's stream: the stream-ordered temporary of
+ * get_temporary_memory_source(pol) (resource/cuda/ExecutionPolicy.cu:5-16, cuda/memory/Allocator.h:33-50).  One block of
+ * `bytes` bytes from the policy stream's grow-only arena; contents are valid until the next library call on that stream. */
+ZS_ROCM_EXPORT void *zs_rocm_policy_temporary(zs_rocm_policy *, size_t bytes);
 ZS_ROCM_EXPORT void zs_rocm_release_temporaries(void);
 
 /* py_interop/cuda/ExecutionPolicy.cpp:11-39: launch a module function (hipFunction_t) over `dim`

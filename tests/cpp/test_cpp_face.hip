@@ -5,6 +5,8 @@
 // Build: hipcc --offload-arch=gfx950 -std=c++17 -I include tests/cpp/test_cpp_face.hip -L zpc_amd/lib -lzsrocm
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <array>
 #include <numeric>
 #include <vector>
 
@@ -101,6 +103,48 @@ int main() {
     hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     CHECK(r == h);
+  }
+  // ---- merge_sort / merge_sort_pair with user comparators (ExecutionPolicy.cuh:698-752): stable, in place
+  {
+    const int n = 300007;
+    std::vector<int> hk(n), hv(n);
+    unsigned s = 12345u;
+    for (int i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; hk[i] = (int)(s >> 8) % 1000 - 500; hv[i] = i; }
+    Vector<int> k(n, memsrc_e::device), v(n, memsrc_e::device);
+    hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
+    // order by |key| descending: a comparator no radix sort can express directly
+    auto comp = [] ZS_LAMBDA(int a, int b) { return (a < 0 ? -a : a) > (b < 0 ? -b : b); };
+    merge_sort_pair(pol, k.data(), v.data(), (std::size_t)n, comp);
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::abs(hk[a]) > std::abs(hk[b]); });
+    std::vector<int> rk(n), rv(n);
+    hipMemcpy(rk.data(), k.data(), n * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; ++i) { CHECK(rv[i] == idx[i]); CHECK(rk[i] == hk[idx[i]]); }
+    // indirect sort: permutation ordered by an external key array captured in the comparator (LBvh-style)
+    hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
+    merge_sort(pol, v.data(), v.data() + n, [key = k.data()] ZS_LAMBDA(int a, int b) { return key[a] < key[b]; });
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hk[a] < hk[b]; });
+    hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
+    CHECK(rv == idx);
+    // struct keys (16 bytes) with the default zs::less through operator<
+    struct Key { double d; int tag; int pad;
+      __host__ __device__ bool operator<(const Key &o) const { return d < o.d; } };
+    std::vector<Key> hs(5000);
+    for (int i = 0; i < 5000; ++i) hs[i] = Key{(double)(hk[i] % 17), i, 0};
+    Key *ds;
+    hipMalloc((void **)&ds, sizeof(Key) * hs.size());
+    hipMemcpy(ds, hs.data(), sizeof(Key) * hs.size(), hipMemcpyHostToDevice);
+    sort(pol, ds, ds + hs.size());
+    std::stable_sort(hs.begin(), hs.end());
+    std::vector<Key> rs(hs.size());
+    hipMemcpy(rs.data(), ds, sizeof(Key) * hs.size(), hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < hs.size(); ++i) CHECK(rs[i].tag == hs[i].tag);
+    hipFree(ds);
   }
   // ---- launcher shapes: Collapse{nb, nt}, Collapse{nb, ntiles, tileSize}, shmem-first lambdas
   {

@@ -84,7 +84,10 @@ Launch::~Launch() {
   if (!pol->hasExternal) ZSR_CHECK(hipEventRecord(spare_event(c, pol->streamid), stream));
 }
 
-void *Launch::temp(size_t bytes) {
+static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes);
+void *Launch::temp(size_t bytes) { return arena_take(dev, stream, tempUsed, bytes); }
+
+static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes) {
   DeviceContext &c = context(dev);
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
@@ -125,6 +128,12 @@ void zs_rocm_policy_stream(zs_rocm_policy *p, int v) { p->streamid = v; }
 void zs_rocm_policy_listen(zs_rocm_policy *p, int proc, int sid) {
   p->listenProc = proc;
   p->listenStream = sid;
+}
+void *zs_rocm_policy_temporary(zs_rocm_policy *p, size_t bytes) {
+  const int dev = p->device >= 0 ? p->device : current_device();
+  hipStream_t stream = p->hasExternal ? p->external : spare_stream(context(dev), p->streamid);
+  std::vector<size_t> used;
+  return arena_take(dev, stream, used, bytes);
 }
 void zs_rocm_policy_shmem(zs_rocm_policy *p, size_t b) { p->shmem = b; }
 void zs_rocm_policy_block(zs_rocm_policy *p, int tpb) { p->block = tpb; }
