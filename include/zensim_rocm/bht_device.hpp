@@ -1,4 +1,4 @@
-// bht_device.hpp -- device view + probe/insert protocol of zs::bht<int, dim, int, 16> for gfx950.
+// bht_device.hpp -- device view + probe/insert protocol of zs::bht<int, dim, int, B> (dim 1-4, B 16|32) for gfx950.
 //
 // Table layout is byte-identical to the reference (container/Bht.hpp:86-112): `keys` holds
 // next_2pow(dim) ints per slot (unused ints stay 0x3f3f3f3f), `indices`, `status` (all -1; this
@@ -14,13 +14,17 @@
 //          a single L2 line access; observed untorn on gfx950, see MI355X guide G16/R2) and see exactly
 //          one of those states: pad == LOCK means "being written, look again".  No lock is taken on
 //          the probe path, whereas the reference locks on every probe of a 3-D key.
+//   dim 4: the 16-byte slot has no spare word, so writers serialise on status[slot] (-1 -> -2, the reference's own
+//          spin-lock word, Bht.hpp:821-834): lock, re-check emptiness, store {x,y} and {z,w}, drain, unlock.  Probes still
+//          take no lock: a 16-byte load that shows one 8-byte half equal to the sentinel and the other not is either a
+//          half-written slot or a genuine key with sentinel words; the probe then reads status (issued after the key load
+//          has returned): -2 => busy, -1 => the writer has drained, a second key load is complete.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace zsr {
 
-constexpr int BHT_BUCKET = 16;
-constexpr int BHT_THRESHOLD = BHT_BUCKET - 2;  // Bht.hpp:34
+constexpr int BHT_BUCKET = 16;                 // default bucket size; BhtDev::bucket carries the actual one (16 or 32)
 constexpr int BHT_SENT = 0x3f3f3f3f;           // key sentinel bytes (Bht.hpp:108-112,126-131)
 constexpr int BHT_LOCK = (int)0x80000001;      // transient value of the pad word while a slot is written
 constexpr unsigned BHT_PRIME = 4294967291u;    // HashUtils.hpp:12
@@ -35,6 +39,7 @@ struct BhtDev {
   int *success;
   unsigned tableSize, numBuckets;
   unsigned hf[6];
+  unsigned bucket;  // B: slots per bucket; threshold = B - 2 (Bht.hpp:34)
 };
 
 __host__ __device__ __forceinline__ unsigned bht_hash1(unsigned hx, unsigned hy, int k) {
@@ -61,7 +66,8 @@ __device__ __forceinline__ bht_int4 bht_load_slot16(const int *p) {
 }
 
 // returns: 1 key found (slotKey == key), 0 slot empty, -1 other key, 2 busy (retry)
-template <int DIM> __device__ __forceinline__ int bht_probe(const int *slot, const int *key) {
+template <int DIM> __device__ __forceinline__ int bht_probe(const BhtDev &t, unsigned si, const int *key) {
+  const int *slot = t.keys + (size_t)si * bht_kstride<DIM>();
   if constexpr (DIM == 1) {
     int k = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return k == key[0] ? 1 : (k == BHT_SENT ? 0 : -1);
@@ -70,23 +76,33 @@ template <int DIM> __device__ __forceinline__ int bht_probe(const int *slot, con
     int k0 = (int)(unsigned)v, k1 = (int)(unsigned)(v >> 32);
     if (k0 == key[0] && k1 == key[1]) return 1;
     return (k0 == BHT_SENT && k1 == BHT_SENT) ? 0 : -1;
-  } else {
+  } else if constexpr (DIM == 3) {
     bht_int4 v = bht_load_slot16(slot);
     if (v.w == BHT_LOCK) return 2;
     if (v.x == key[0] && v.y == key[1] && v.z == key[2]) return 1;
     return (v.x == BHT_SENT && v.y == BHT_SENT && v.z == BHT_SENT) ? 0 : -1;
+  } else {
+    bht_int4 v = bht_load_slot16(slot);
+    const bool lo = v.x == BHT_SENT && v.y == BHT_SENT, hi = v.z == BHT_SENT && v.w == BHT_SENT;
+    if (lo != hi) {  // possibly half written: status decides (the key load above has completed)
+      if (__hip_atomic_load(t.status + si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return 2;
+      v = bht_load_slot16(slot);
+    }
+    if (v.x == key[0] && v.y == key[1] && v.z == key[2] && v.w == key[3]) return 1;
+    return (v.x == BHT_SENT && v.y == BHT_SENT && v.z == BHT_SENT && v.w == BHT_SENT) ? 0 : -1;
   }
 }
 
 // try to turn an empty slot into `key`; true on success
-template <int DIM> __device__ __forceinline__ bool bht_claim(int *slot, const int *key) {
+template <int DIM> __device__ __forceinline__ bool bht_claim(const BhtDev &t, unsigned si, const int *key) {
+  int *slot = t.keys + (size_t)si * bht_kstride<DIM>();
   if constexpr (DIM == 1) {
     return atomicCAS(slot, BHT_SENT, key[0]) == BHT_SENT;
   } else if constexpr (DIM == 2) {
     const unsigned long long sent = ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)BHT_SENT;
     const unsigned long long want = ((unsigned long long)(unsigned)key[1] << 32) | (unsigned)key[0];
     return atomicCAS((unsigned long long *)slot, sent, want) == sent;
-  } else {
+  } else if constexpr (DIM == 3) {
     unsigned long long *h0 = (unsigned long long *)slot, *h1 = h0 + 1;
     const unsigned long long sent = ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)BHT_SENT;
     const unsigned long long locked = ((unsigned long long)(unsigned)BHT_LOCK << 32) | (unsigned)BHT_SENT;
@@ -102,6 +118,21 @@ template <int DIM> __device__ __forceinline__ bool bht_claim(int *slot, const in
     __hip_atomic_store(h1, ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)key[2], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     return true;
+  } else {
+    unsigned long long *h0 = (unsigned long long *)slot, *h1 = h0 + 1;
+    const unsigned long long sent = ((unsigned long long)(unsigned)BHT_SENT << 32) | (unsigned)BHT_SENT;
+    if (atomicCAS(t.status + si, -1, -2) != -1) return false;  // another writer holds the slot: re-examine
+    const bool empty = __hip_atomic_load(h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sent
+                       && __hip_atomic_load(h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sent;
+    if (empty) {
+      __hip_atomic_store(h0, ((unsigned long long)(unsigned)key[1] << 32) | (unsigned)key[0], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(h1, ((unsigned long long)(unsigned)key[3] << 32) | (unsigned)key[2], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the key is at the coherence point before the slot unlocks
+    __hip_atomic_store(t.status + si, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return empty;
   }
 }
 
@@ -109,28 +140,28 @@ template <int DIM> __device__ __forceinline__ bool bht_claim(int *slot, const in
 // returns slot >= 0 when THIS thread claimed the slot, -1 when the key is already present, BHT_FAIL on overflow.
 template <int DIM> __device__ __forceinline__ int bht_find_or_claim(const BhtDev &t, const int *key) {
   if (t.numBuckets == 0) return BHT_FAIL;
-  constexpr int KS = bht_kstride<DIM>();
+  const int B = (int)t.bucket;
   int iter = 0, load = 0;
-  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * BHT_BUCKET;
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * t.bucket;
   while (iter < 3) {
     int st = 0;
-    for (; load != BHT_BUCKET; ++load) {
-      st = bht_probe<DIM>(t.keys + (size_t)(bucket + load) * KS, key);
+    for (; load != B; ++load) {
+      st = bht_probe<DIM>(t, bucket + (unsigned)load, key);
       if (st == 2) {  // slot is being written by another wave: look again (no inner spin: lanes of one
         --load;       // wave may depend on each other)
         continue;
       }
       if (st >= 0) break;  // found or empty
     }
-    if (load != BHT_BUCKET && st == 1) return -1;  // sentinel_v: already present
-    if (load <= BHT_THRESHOLD) {
-      if (bht_claim<DIM>(t.keys + (size_t)(bucket + load) * KS, key)) return (int)(bucket + load);
+    if (load != B && st == 1) return -1;  // sentinel_v: already present
+    if (load <= B - 2) {                  // threshold = B - 2 (Bht.hpp:34)
+      if (bht_claim<DIM>(t, bucket + (unsigned)load, key)) return (int)(bucket + load);
       // lost the race for this slot: re-examine it (it now holds some key, maybe ours)
     } else {
       ++iter;
       load = 0;
-      if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * BHT_BUCKET;
-      else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * BHT_BUCKET;
+      if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * t.bucket;
+      else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * t.bucket;
       else break;
     }
   }
@@ -192,12 +223,16 @@ template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev 
 template <int DIM, bool RETSLOT = false> __device__ __forceinline__ int bht_query(const BhtDev &t, const int *key) {
   if (t.numBuckets == 0) return RETSLOT ? 0x7fffffff : -1;
   constexpr int KS = bht_kstride<DIM>();
-  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * BHT_BUCKET;
+  const int B = (int)t.bucket;
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * t.bucket;
   for (int iter = 0; iter < 3;) {
-    for (int loc = 0; loc != BHT_BUCKET; ++loc) {
+    for (int loc = 0; loc != B; ++loc) {
       const int *s = t.keys + (size_t)(bucket + loc) * KS;
       bool eq;
-      if constexpr (DIM == 3) {
+      if constexpr (DIM == 4) {
+        bht_int4 v = *reinterpret_cast<const bht_int4 *>(s);
+        eq = v.x == key[0] && v.y == key[1] && v.z == key[2] && v.w == key[3];
+      } else if constexpr (DIM == 3) {
         bht_int4 v = *reinterpret_cast<const bht_int4 *>(s);
         eq = v.x == key[0] && v.y == key[1] && v.z == key[2];
       } else if constexpr (DIM == 2) {
@@ -207,8 +242,8 @@ template <int DIM, bool RETSLOT = false> __device__ __forceinline__ int bht_quer
       if (eq) return RETSLOT ? (int)(bucket + loc) : t.indices[bucket + loc];
     }
     ++iter;
-    if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * BHT_BUCKET;
-    else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * BHT_BUCKET;
+    if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * t.bucket;
+    else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * t.bucket;
   }
   return RETSLOT ? 0x7fffffff : -1;
 }

@@ -283,45 +283,57 @@ template <class T, int L> struct TileVector {
   Vector<T> _buf;
 };
 
-// zs::bht<int, dim, int, 16> (container/Bht.hpp) -- owning handle over the C ABI, device view = zsr::BhtDev
-template <int dim> struct bht_traits;
-#define ZS_ROCM_BHT_TRAITS(D)                                                                            \
-  template <> struct bht_traits<D> {                                                                     \
+// zs::bht<int, dim, int, B> (container/Bht.hpp), dim 1-4, B 16|32 -- owning handle over the C ABI, device view = zsr::BhtDev
+template <int dim, int B> struct bht_traits;
+#define ZS_ROCM_BHT_TRAITS(D, B)                                                                          \
+  template <> struct bht_traits<D, B> {                                                                  \
     using handle = zs_rocm_bht_##D;                                                                      \
-    static handle *create(std::size_t n) { return container__bht_int_##D##_int_16(nullptr, n); }        \
-    static void destroy(handle *h) { del_container__bht_int_##D##_int_16(h); }                           \
-    static std::size_t size(const handle *h) { return container_size__bht_int_##D##_int_16(h); }         \
-    static void reset(handle *h, bool c) { reset_container__bht_int_##D##_int_16(h, c); }                \
-    static zs_rocm_bht_view_lite *view(handle *h) { return pyview__bht_int_##D##_int_16(h); }            \
-    static void delview(zs_rocm_bht_view_lite *v) { del_pyview__bht_int_##D##_int_16(v); }               \
-    static void resize(zs_rocm_policy *p, handle *h, std::size_t n) { resize_container__rocm_bht_int_##D##_int_16(p, h, n); } \
+    static handle *create(std::size_t n) { return container__bht_int_##D##_int_##B(nullptr, n); }       \
+    static void destroy(handle *h) { del_container__bht_int_##D##_int_##B(h); }                          \
+    static std::size_t size(const handle *h) { return container_size__bht_int_##D##_int_##B(h); }        \
+    static void reset(handle *h, bool c) { reset_container__bht_int_##D##_int_##B(h, c); }               \
+    static zs_rocm_bht_view_lite *view(handle *h) { return pyview__bht_int_##D##_int_##B(h); }           \
+    static void delview(zs_rocm_bht_view_lite *v) { del_pyview__bht_int_##D##_int_##B(v); }              \
+    static void resize(zs_rocm_policy *p, handle *h, std::size_t n) { resize_container__rocm_bht_int_##D##_int_##B(p, h, n); } \
   };
-ZS_ROCM_BHT_TRAITS(1)
-ZS_ROCM_BHT_TRAITS(2)
-ZS_ROCM_BHT_TRAITS(3)
+ZS_ROCM_BHT_TRAITS(1, 16)
+ZS_ROCM_BHT_TRAITS(2, 16)
+ZS_ROCM_BHT_TRAITS(3, 16)
+ZS_ROCM_BHT_TRAITS(4, 16)
+ZS_ROCM_BHT_TRAITS(1, 32)
+ZS_ROCM_BHT_TRAITS(2, 32)
+ZS_ROCM_BHT_TRAITS(3, 32)
+ZS_ROCM_BHT_TRAITS(4, 32)
 #undef ZS_ROCM_BHT_TRAITS
 
 template <int dim> struct BHTView {  // BHTView (Bht.hpp:403-1072): insert / query inside kernels
   zsr::BhtDev t;
   static constexpr int sentinel_v = -1;
   static constexpr int failure_token_v = zsr::BHT_FAIL;
-  __device__ __forceinline__ int insert(const small_vec<int, dim> &key) const { return zsr::bht_insert<dim>(t, key.v); }
+  // insert(key[, index, enqueue]) (Bht.hpp:490-542): index == sentinel_v takes the next dense index
+  __device__ __forceinline__ int insert(const small_vec<int, dim> &key, int index = -1, bool enqueue = true) const {
+    return zsr::bht_insert<dim>(t, key.v, index, enqueue);
+  }
   __device__ __forceinline__ int query(const small_vec<int, dim> &key) const { return zsr::bht_query<dim>(t, key.v); }
+  __device__ __forceinline__ int entry(const small_vec<int, dim> &key) const { return zsr::bht_query<dim, true>(t, key.v); }  // slot (:700-731)
   __device__ __forceinline__ int size() const { return *t.cnt; }
+  int *_activeKeys() const { return t.activeKeys; }
 };
-template <int dim> struct bht {
-  using traits = bht_traits<dim>;
+template <int dim, int B = 16> struct bht {
+  using traits = bht_traits<dim, B>;
   explicit bht(std::size_t n) : _h(traits::create(n)) {}
   ~bht() { traits::destroy(_h); }
   bht(const bht &) = delete;
   std::size_t size() const { return traits::size(_h); }
   void reset(bool clearCnt = true) { traits::reset(_h, clearCnt); }
+  void resize(const struct RocmExecutionPolicy &pol, std::size_t newCapacity);  // Bht.hpp:320-340
   BHTView<dim> view() {
     zs_rocm_bht_view_lite *v = traits::view(_h);
     BHTView<dim> r;
     r.t.keys = (int *)v->keys; r.t.indices = v->indices; r.t.status = v->status; r.t.activeKeys = (int *)v->activeKeys;
     r.t.cnt = v->cnt; r.t.success = v->success; r.t.tableSize = (unsigned)v->tableSize;
-    r.t.numBuckets = (unsigned)(v->tableSize / zsr::BHT_BUCKET);
+    r.t.bucket = (unsigned)B;
+    r.t.numBuckets = (unsigned)(v->tableSize / (std::size_t)B);
     r.t.hf[0] = v->hf0x; r.t.hf[1] = v->hf0y; r.t.hf[2] = v->hf1x; r.t.hf[3] = v->hf1y; r.t.hf[4] = v->hf2x; r.t.hf[5] = v->hf2y;
     traits::delview(v);
     return r;
@@ -336,7 +348,7 @@ template <execspace_e space, class T> VectorView<T> view(Vector<T> &v) {
 }
 template <execspace_e space, class T, int L> TileVectorView<T, L> view(TileVector<T, L> &v) { return {v.data(), v.size(), v.numChannels()}; }
 template <execspace_e space, class T, int L> TileVectorView<T, L> view(std::initializer_list<const char *>, TileVector<T, L> &v) { return view<space>(v); }
-template <execspace_e space, int dim> BHTView<dim> view(bht<dim> &t) { return t.view(); }
+template <execspace_e space, int dim, int B> BHTView<dim> view(bht<dim, B> &t) { return t.view(); }
 template <execspace_e space, class C> auto proxy(C &c) { return view<space>(c); }
 template <execspace_e space, class T, int L> auto proxy(std::initializer_list<const char *> l, TileVector<T, L> &v) { return view<space>(l, v); }
 
@@ -483,6 +495,9 @@ private:
   int _block = 0;
 };
 inline RocmExecutionPolicy rocm_exec() { return RocmExecutionPolicy{}; }
+template <int dim, int B> void bht<dim, B>::resize(const RocmExecutionPolicy &pol, std::size_t newCapacity) {
+  traits::resize(pol.handle(), _h, newCapacity);
+}
 
 // free functions (execution/ExecutionPolicy.hpp:684-781)
 template <class T, class Op = plus<T>> void reduce(const RocmExecutionPolicy &pol, const T *first, const T *last, T *out, T init = T{}, Op op = {}) {

@@ -228,7 +228,7 @@ ZS_ROCM_EXPORT void zs_rocm_tv_scale_f32(zs_rocm_policy *, float *tv, size_t n, 
 ZS_ROCM_EXPORT void zs_rocm_tv_gather_f32(zs_rocm_policy *, const float *src, float *dst, size_t n, int C, int L, const int *map);
 
 /* ======================================================================== (A) bht */
-/* py_interop/BhtInstantiations.cpp:6-128: zs::bht<int, dim, int, 16> (container/Bht.hpp:16-272).
+/* py_interop/BhtInstantiations.cpp:6-128: zs::bht<int, dim, int, B>, dim 1-4, B = 16 | 32 (container/Bht.hpp:16-272).
  * Table layout identical to the reference: keys [tableSize] of next_2pow(dim) ints (unused/padding
  * ints hold 0x3f3f3f3f), indices [tableSize], status [tableSize] (all -1 outside of a build),
  * activeKeys [tableSize][dim], cnt, buildSuccess; tableSize = evaluateTableSize(n) (Bht.hpp:154-158);
@@ -243,38 +243,46 @@ typedef struct {
   size_t tableSize;
   uint32_t hf0x, hf0y, hf1x, hf1y, hf2x, hf2y;
 } zs_rocm_bht_view_lite; /* py_interop/BhtView.hpp:96-111 (BhtViewLite) */
-#define ZS_ROCM_DECL_BHT(D)                                                                              \
-  typedef struct zs_rocm_bht_##D zs_rocm_bht_##D;                                                        \
-  ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_16(zs_rocm_allocator *, size_t n);        \
-  ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_16(zs_rocm_bht_##D *);                            \
-  ZS_ROCM_EXPORT size_t container_size__bht_int_##D##_int_16(const zs_rocm_bht_##D *);                   \
-  ZS_ROCM_EXPORT size_t container_capacity__bht_int_##D##_int_16(const zs_rocm_bht_##D *);               \
-  ZS_ROCM_EXPORT void reset_container__bht_int_##D##_int_16(zs_rocm_bht_##D *, int clearCnt);            \
-  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_16(zs_rocm_bht_##D *);                 \
-  ZS_ROCM_EXPORT void del_pyview__bht_int_##D##_int_16(zs_rocm_bht_view_lite *);                         \
+#define ZS_ROCM_DECL_BHT(D, B)                                                                           \
+  ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_##B(zs_rocm_allocator *, size_t n);        \
+  ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *);                            \
+  ZS_ROCM_EXPORT size_t container_size__bht_int_##D##_int_##B(const zs_rocm_bht_##D *);                   \
+  ZS_ROCM_EXPORT size_t container_capacity__bht_int_##D##_int_##B(const zs_rocm_bht_##D *);               \
+  ZS_ROCM_EXPORT void reset_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *, int clearCnt);            \
+  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B(zs_rocm_bht_##D *);                 \
+  ZS_ROCM_EXPORT void del_pyview__bht_int_##D##_int_##B(zs_rocm_bht_view_lite *);                         \
   /* py_interop/cuda/BhtUtility.cpp:7-26 -> bht::resize (Bht.hpp:320-340) */                            \
-  ZS_ROCM_EXPORT void resize_container__rocm_bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,   \
+  ZS_ROCM_EXPORT void resize_container__rocm_bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,   \
                                                                  size_t newCapacity);                   \
   /* (B) pol(range(n), [tb](i){ ret[i] = tb.insert(keys[i]); })  BHTView::insert, Bht.hpp:490-542 */     \
-  ZS_ROCM_EXPORT void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,          \
+  ZS_ROCM_EXPORT void zs_rocm_insert__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,          \
                                                           const int *keys, size_t n, int *ret);         \
   /* (B) table := { keys[i] -> index i }, cnt = n: adopt a partition numbered elsewhere (e.g. the _activeKeys of a  \
      zs::HashTable, container/HashTable.hpp, which the reference's in-tree P2G/G2P use); insert(key, i, enqueue)   \
      of Bht.hpp:490-542 with a fixed index */                                                                     \
-  ZS_ROCM_EXPORT void zs_rocm_assign__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,          \
+  ZS_ROCM_EXPORT void zs_rocm_assign__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,          \
                                                           const int *keys, size_t n);                   \
   /* (B) pol(range(n), [tb](i){ ret[i] = tb.query(keys[i]); })  BHTView::query, Bht.hpp:667-698 */       \
-  ZS_ROCM_EXPORT void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *, const zs_rocm_bht_##D *,     \
+  ZS_ROCM_EXPORT void zs_rocm_query__bht_int_##D##_int_##B(zs_rocm_policy *, const zs_rocm_bht_##D *,     \
                                                          const int *keys, size_t n, int *ret);          \
   /* (B) bht::reorder(pol, map, scatter|gather), Bht.hpp:377-400 */                                      \
-  ZS_ROCM_EXPORT void zs_rocm_reorder__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *,         \
+  ZS_ROCM_EXPORT void zs_rocm_reorder__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,         \
                                                            const int *map, int scatter);                \
   /* (B) canonical form for bit-exact comparison (SURVEY.md 8a note): sort active keys               \
      lexicographically and renumber */                                                                  \
-  ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_16(zs_rocm_policy *, zs_rocm_bht_##D *);
-ZS_ROCM_DECL_BHT(1)
-ZS_ROCM_DECL_BHT(2)
-ZS_ROCM_DECL_BHT(3)
+  ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *);
+typedef struct zs_rocm_bht_1 zs_rocm_bht_1; /* one handle type per dim; the bucket size is a field of the object */
+typedef struct zs_rocm_bht_2 zs_rocm_bht_2;
+typedef struct zs_rocm_bht_3 zs_rocm_bht_3;
+typedef struct zs_rocm_bht_4 zs_rocm_bht_4;
+ZS_ROCM_DECL_BHT(1, 16)
+ZS_ROCM_DECL_BHT(2, 16)
+ZS_ROCM_DECL_BHT(3, 16)
+ZS_ROCM_DECL_BHT(4, 16)
+ZS_ROCM_DECL_BHT(1, 32)
+ZS_ROCM_DECL_BHT(2, 32)
+ZS_ROCM_DECL_BHT(3, 32)
+ZS_ROCM_DECL_BHT(4, 32)
 
 /* ======================================================================== (B) MPM transfers */
 /* A particle attribute stored in an AoS zs::Vector<vec<T,N>> (geometry/Structurefree.hpp:21-237) or in

@@ -1,5 +1,5 @@
 /*
- * bht.c -- CPU restatement of zs::bht<int, dim, int, 16> (bucketed 3-hash table after BGHT).
+ * bht.c -- CPU restatement of zs::bht<int, dim, int, B> (dim 1-4, B 16|32) (bucketed 3-hash table after BGHT).
  * TEST INFRASTRUCTURE ONLY (see zpc_oracle.h).  Sequential insertion in input order, i.e. the
  * deterministic SequentialExecutionPolicy behaviour SURVEY.md 8(a) names as the canonical form.
  */
@@ -8,13 +8,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BUCKET 16
-#define THRESHOLD (BUCKET - 2)       /* container/Bht.hpp:34 */
+/* bucket size B (16 or 32) is a field; threshold = B - 2 (container/Bht.hpp:34) */
 #define KEY_SENTINEL 0x3f3f3f3f      /* bytes 0x3f, Bht.hpp:108-112,126-131 */
 #define PRIME 4294967291u            /* container/Bcht.hpp:37, py_interop/HashUtils.hpp:12 */
 
 struct orc_bht {
-  int dim, kstride;
+  int dim, kstride, bucket;
   size_t tableSize, numBuckets;
   int32_t *keys;    /* [tableSize][kstride], kstride = next_2pow(dim) (HashUtils.hpp:49-51) */
   int32_t *indices; /* [tableSize] */
@@ -78,25 +77,28 @@ static size_t next_2pow(size_t n) { /* math/bit/Bits.h next_2pow: smallest power
   return p;
 }
 /* Bht.hpp:154-158 */
-size_t orc_bht_table_size(size_t entryCnt) {
+size_t orc_bht_table_size_b(size_t entryCnt, int B) {
   if (entryCnt == 0) return 0;
   size_t n = next_2pow(entryCnt) * 2;
-  return n + (BUCKET - n % BUCKET);
+  return n + ((size_t)B - n % (size_t)B);
 }
+size_t orc_bht_table_size(size_t entryCnt) { return orc_bht_table_size_b(entryCnt, 16); }
 
 static void table_alloc(orc_bht *t, size_t tableSize) {
   t->tableSize = tableSize;
-  t->numBuckets = tableSize / BUCKET;
+  t->numBuckets = tableSize / (size_t)t->bucket;
   t->keys = (int32_t *)malloc(tableSize * (size_t)t->kstride * 4 + 16);
   t->indices = (int32_t *)malloc(tableSize * 4 + 16);
   t->status = (int32_t *)malloc(tableSize * 4 + 16);
 }
 
-orc_bht *orc_bht_create(int dim, size_t nExpected) {
+orc_bht *orc_bht_create(int dim, size_t nExpected) { return orc_bht_create_b(dim, nExpected, 16); }
+orc_bht *orc_bht_create_b(int dim, size_t nExpected, int bucket) {
   orc_bht *t = (orc_bht *)calloc(1, sizeof(orc_bht));
   t->dim = dim;
+  t->bucket = bucket;
   t->kstride = (int)next_2pow((size_t)dim);
-  table_alloc(t, orc_bht_table_size(nExpected));
+  table_alloc(t, orc_bht_table_size_b(nExpected, bucket));
   t->activeKeys = (int32_t *)malloc(t->tableSize * (size_t)dim * 4 + 16);
   orc_bht_hash_params(t->hf);
   orc_bht_reset(t, 1);
@@ -129,6 +131,7 @@ static int key_is_sentinel(const int32_t *a, int dim) {
 /* insert with optional fixed index (resize path) : Bht.hpp:612-664 (host), 490-542 (device) */
 static int32_t insert_impl(orc_bht *t, const int32_t *key, int32_t insertion_index, int enqueue) {
   if (t->numBuckets == 0) return INT32_MIN;
+  const int BUCKET = t->bucket, THRESHOLD = t->bucket - 2;
   int iter = 0, load = 0;
   size_t bucketOffset = (size_t)(hf(t, 0, key) % t->numBuckets) * BUCKET;
   while (iter < 3) {
@@ -165,6 +168,7 @@ int32_t orc_bht_insert(orc_bht *t, const int32_t *key) { return insert_impl(t, k
 /* Bht.hpp:667-698 */
 int32_t orc_bht_query(const orc_bht *t, const int32_t *key) {
   if (t->numBuckets == 0) return -1;
+  const int BUCKET = t->bucket;
   size_t bucketOffset = (size_t)(hf(t, 0, key) % t->numBuckets) * BUCKET;
   for (int iter = 0; iter < 3;) {
     int loc = 0;
@@ -196,7 +200,7 @@ int orc_bht_key_stride(const orc_bht *t) { return t->kstride; }
 
 /* bht::resize, Bht.hpp:320-340: grow, reset, re-insert activeKeys[i] with fixed index i */
 void orc_bht_resize(orc_bht *t, size_t newCapacity) {
-  size_t ns = orc_bht_table_size(newCapacity);
+  size_t ns = orc_bht_table_size_b(newCapacity, t->bucket);
   if (ns <= t->tableSize) return;
   free(t->keys); free(t->indices); free(t->status);
   table_alloc(t, ns);

@@ -90,7 +90,9 @@ uint32_t orc_universal_hash_i32(uint32_t hx, uint32_t hy, int32_t k);          /
 uint32_t orc_universal_hash_vec(uint32_t hx, uint32_t hy, const int32_t *k, int dim); /* :26-43 */
 void orc_bht_hash_params(uint32_t out[6]); /* std::mt19937(2): Bht.hpp:165-169, Bcht.hpp:39-43 */
 size_t orc_bht_table_size(size_t nExpected); /* evaluateTableSize, Bht.hpp:154-158 */
-orc_bht *orc_bht_create(int dim, size_t nExpected);
+orc_bht *orc_bht_create(int dim, size_t nExpected);                 /* B = 16 */
+orc_bht *orc_bht_create_b(int dim, size_t nExpected, int bucket);  /* B = 16 | 32 */
+size_t orc_bht_table_size_b(size_t nExpected, int bucket);
 void orc_bht_destroy(orc_bht *);
 void orc_bht_reset(orc_bht *, int clearCnt);                 /* Bht.hpp:306-318 */
 int32_t orc_bht_insert(orc_bht *, const int32_t *key);      /* host insert, Bht.hpp:612-664 */

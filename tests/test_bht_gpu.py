@@ -1,4 +1,4 @@
-"""GPU parity for bht<int, dim, int, 16>: set-exact against the CPU oracle (sequential insertion), byte-exact
+"""GPU parity for bht<int, dim, int, B> (dim 1-4, B 16|32): set-exact against the CPU oracle (sequential insertion), byte-exact
 after canonicalisation (SURVEY.md 8a note), hash constants pinned, heavy same-key contention."""
 import ctypes as C
 
@@ -11,12 +11,12 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_table(oracle, dim, keys, nexp):
-    oracle.orc_bht_create.restype = C.c_void_p
+def _oracle_table(oracle, dim, keys, nexp, bucket=16):
+    oracle.orc_bht_create_b.restype = C.c_void_p
     oracle.orc_bht_size.restype = C.c_int32
     oracle.orc_bht_get_table_size.restype = C.c_size_t
     oracle.orc_bht_active_keys.restype = C.POINTER(C.c_int32)
-    t = C.c_void_p(oracle.orc_bht_create(dim, C.c_size_t(nexp)))
+    t = C.c_void_p(oracle.orc_bht_create_b(dim, C.c_size_t(nexp), bucket))
     oracle.orc_bht_insert_many(t, keys.ctypes.data_as(C.c_void_p), C.c_size_t(keys.shape[0]), None)
     n = oracle.orc_bht_size(t)
     act = np.ctypeslib.as_array(oracle.orc_bht_active_keys(t), shape=(n, dim)).copy()
@@ -29,13 +29,23 @@ def _d2h(ptr, nbytes):
     return out
 
 
-@pytest.mark.parametrize("dim,n,span", [(3, 4096, 32), (3, 200_000, 40), (2, 50_000, 300), (1, 30_000, 20_000), (3, 1, 5), (3, 100_000, 2)])
-def test_build_query_set_exact(pol, oracle, dim, n, span):
+@pytest.mark.parametrize("dim,n,span,bucket", [(3, 4096, 32, 16), (3, 200_000, 40, 16), (2, 50_000, 300, 16), (1, 30_000, 20_000, 16),
+                                               (3, 1, 5, 16), (3, 100_000, 2, 16),
+                                               # dim 4 (status-lock protocol) and bucket 32 (py_interop/BhtInstantiations.cpp:120-127)
+                                               (4, 4096, 12, 16), (4, 200_000, 14, 16), (4, 100_000, 2, 16), (4, 1, 5, 32),
+                                               (1, 30_000, 20_000, 32), (2, 50_000, 300, 32), (3, 200_000, 40, 32), (4, 150_000, 10, 32)])
+def test_build_query_set_exact(pol, oracle, dim, n, span, bucket):
     from zpc_amd.containers import Bht
     g = rng(20 + dim)
     keys = g.integers(-span, span, (n, dim), dtype=np.int32)
-    tab = Bht(dim, n)
-    t, on, oact = _oracle_table(oracle, dim, keys, n)
+    if dim == 4 and n > 1000:
+        # keys holding sentinel words (0x3f3f3f3f) in either 8-byte half look like half-written slots to a probe
+        S = 0x3f3f3f3f
+        keys[0:64] = np.array([[S, S, i % 5, i % 3] for i in range(64)], np.int32)
+        keys[64:128] = np.array([[i % 5, i % 3, S, S] for i in range(64)], np.int32)
+        keys[128:160] = np.array([[S, i % 4, S, i % 2] for i in range(32)], np.int32)
+    tab = Bht(dim, n, bucket=bucket)
+    t, on, oact = _oracle_table(oracle, dim, keys, n, bucket)
     assert tab.tableSize() == oracle.orc_bht_get_table_size(t)
     v = tab.view()
     hp = (C.c_uint32 * 6)()
@@ -63,10 +73,11 @@ def test_build_query_set_exact(pol, oracle, dim, n, span):
     # status words all -1, padding ints untouched (reference table format)
     tsz = tab.tableSize()
     assert (_d2h(tab.view().status, tsz * 4) == -1).all()
-    if dim == 3:
+    if dim >= 3:
         raw = _d2h(tab.view().keys, tsz * 16).reshape(tsz, 4)
-        assert (raw[:, 3] == 0x3f3f3f3f).all()
-        filled = raw[(raw[:, :3] != 0x3f3f3f3f).any(axis=1)][:, :3]
+        if dim == 3:
+            assert (raw[:, 3] == 0x3f3f3f3f).all()
+        filled = raw[(raw[:, :dim] != 0x3f3f3f3f).any(axis=1)][:, :dim]
         assert filled.shape[0] == on and len(set(map(tuple, filled))) == on  # no duplicate slots
     # canonical form is byte-identical to canonicalised oracle numbering
     tab.canonicalize(pol)

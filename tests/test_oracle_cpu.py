@@ -227,6 +227,38 @@ def test_bht_oracle_semantics(oracle):
     oracle.orc_bht_destroy(t)
 
 
+@pytest.mark.parametrize("dim,bucket", [(1, 16), (2, 32), (3, 32), (4, 16), (4, 32)])
+def test_bht_oracle_dims_and_buckets(oracle, dim, bucket):
+    """bht<int, dim, int, B> for the instantiated dims 1-4 and B = 16 | 32 (py_interop/BhtInstantiations.cpp:120-127):
+    tableSize = 2*next_2pow(n) + (B - that % B) (Bht.hpp:154-158), first-occurrence numbering, query."""
+    oracle.orc_bht_create_b.restype = C.c_void_p
+    oracle.orc_bht_size.restype = C.c_int32
+    oracle.orc_bht_query.restype = C.c_int32
+    oracle.orc_bht_get_table_size.restype = C.c_size_t
+    g = rng(56)
+    n = 3000
+    keys = g.integers(-6, 6, (n, dim), dtype=np.int32)
+    t = C.c_void_p(oracle.orc_bht_create_b(dim, C.c_size_t(n), bucket))
+    p2 = 1 << (n - 1).bit_length()
+    assert oracle.orc_bht_get_table_size(t) == 2 * p2 + (bucket - (2 * p2) % bucket)
+    ret = np.zeros(n, np.int32)
+    oracle.orc_bht_insert_many(t, ptr(keys), C.c_size_t(n), ptr(ret))
+    uniq = {}
+    for i, k in enumerate(map(tuple, keys)):
+        if k not in uniq:
+            uniq[k] = len(uniq)
+            assert ret[i] == uniq[k]
+        else:
+            assert ret[i] == -1
+    assert oracle.orc_bht_size(t) == len(uniq)
+    for k, i in list(uniq.items())[:300]:
+        assert oracle.orc_bht_query(t, ptr(np.array(k, np.int32))) == i
+    # tiny tables: n = 1 -> 2 + (B - 2)
+    oracle.orc_bht_table_size_b.restype = C.c_size_t
+    assert oracle.orc_bht_table_size_b(C.c_size_t(1), bucket) == bucket
+    oracle.orc_bht_destroy(t)
+
+
 def test_mpm_oracle_conservation(oracle):
     """size-independent properties of the restated P2G/G2P: mass & momentum conservation, affine velocity field
     reproduced exactly by P2G -> grid update -> G2P (APIC/MLS-MPM property)."""

@@ -137,8 +137,8 @@ def _declare_containers(L):
     L.zs_rocm_tv_to_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_scale_f32.argtypes = [vp, vp, sz, i32, i32, f32]
     L.zs_rocm_tv_gather_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
-    for D in (1, 2, 3):
-        s = "bht_int_%d_int_16" % D
+    for D, B in ((d, b) for d in (1, 2, 3, 4) for b in (16, 32)):
+        s = "bht_int_%d_int_%d" % (D, B)
         getattr(L, "container__" + s).argtypes = [vp, sz]
         getattr(L, "container__" + s).restype = vp
         getattr(L, "del_container__" + s).argtypes = [vp]

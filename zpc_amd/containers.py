@@ -140,12 +140,13 @@ class TileVector:
 
 
 class Bht:
-    """zs::bht<int, dim, int, 16> (container/Bht.hpp:16-272) through container__bht_int_D_int_16 & friends."""
+    """zs::bht<int, dim, int, B> (container/Bht.hpp:16-272), dim 1-4, B 16|32, through container__bht_int_D_int_B & friends."""
 
-    def __init__(self, dim, n, alloc=None):
+    def __init__(self, dim, n, alloc=None, bucket=16):
         self.dim = dim
+        self.bucket = bucket
         self.alloc = alloc or Allocator()
-        self.s = "bht_int_%d_int_16" % dim
+        self.s = "bht_int_%d_int_%d" % (dim, bucket)
         self._h = getattr(lib(), "container__" + self.s)(self.alloc._h, n)
 
     def __del__(self):

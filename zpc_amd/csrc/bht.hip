@@ -1,4 +1,4 @@
-// bht.hip -- zs::bht<int, dim, int, 16> container handles (py_interop/BhtInstantiations.cpp:6-128,
+// bht.hip -- zs::bht<int, dim, int, B> (dim 1-4, B 16|32) container handles (py_interop/BhtInstantiations.cpp:6-128,
 // py_interop/cuda/BhtUtility.cpp:7-26) and the bulk insert / query / reorder kernels that replace the
 // `pol(range(n), [tb = view<space>(tab)](i){ tb.insert(key_i); })` idiom of the C++ face.
 #include <random>
@@ -15,10 +15,10 @@ static size_t next_2pow(size_t n) {  // math/bit/Bits.h:177-184
   while (p < n) p <<= 1;
   return p;
 }
-static size_t evaluate_table_size(size_t entryCnt) {  // Bht.hpp:154-158
+static size_t evaluate_table_size(size_t entryCnt, int B) {  // Bht.hpp:154-158
   if (entryCnt == 0) return 0;
   size_t n = next_2pow(entryCnt) * 2;
-  return n + (BHT_BUCKET - n % BHT_BUCKET);
+  return n + ((size_t)B - n % (size_t)B);
 }
 
 static void *bht_alloc(const BhtHost &t, size_t bytes) {
@@ -37,11 +37,12 @@ static void bht_reset_table(BhtHost &t, hipStream_t s) {  // Table::reset, Bht.h
   }
 }
 
-static void bht_create(BhtHost &t, int dim, int memsrc, int8_t devid, size_t n) {
+static void bht_create(BhtHost &t, int dim, int B, int memsrc, int8_t devid, size_t n) {
   t.dim = dim;
+  t.bucket = B;
   t.memsrc = memsrc == 0 ? 1 : memsrc;  // a host-resident bht cannot be used by a device policy
   t.devid = devid;
-  t.tableSize = evaluate_table_size(n);
+  t.tableSize = evaluate_table_size(n, B);
   const int ks = dim == 1 ? 1 : (dim == 2 ? 2 : 4);
   t.keys = (int *)bht_alloc(t, t.tableSize * ks * sizeof(int));
   t.indices = (int *)bht_alloc(t, t.tableSize * sizeof(int));
@@ -164,7 +165,7 @@ template <int DIM> static void bht_assign(zs_rocm_policy *pol, BhtHost &t, const
 
 // bht::resize (Bht.hpp:320-340)
 template <int DIM> static void bht_resize(zs_rocm_policy *pol, BhtHost &t, size_t newCapacity) {
-  size_t ns = evaluate_table_size(newCapacity);
+  size_t ns = evaluate_table_size(newCapacity, t.bucket);
   if (ns <= t.tableSize) return;
   Launch L(pol, "bht_resize");
   const int n = bht_size(t, L.stream);
@@ -221,26 +222,26 @@ using namespace zsr;
 
 extern "C" {
 
-#define ZSR_DEFINE_BHT(D)                                                                                   \
-  zs_rocm_bht_##D *container__bht_int_##D##_int_16(zs_rocm_allocator *a, size_t n) {                        \
+#define ZSR_DEFINE_BHT(D, B)                                                                                  \
+  zs_rocm_bht_##D *container__bht_int_##D##_int_##B(zs_rocm_allocator *a, size_t n) {                        \
     auto *b = new zs_rocm_bht_##D;                                                                          \
-    bht_create(b->t, D, a ? a->memsrc : 1, a ? a->devid : 0, n);                                            \
+    bht_create(b->t, D, B, a ? a->memsrc : 1, a ? a->devid : 0, n);                                            \
     return b;                                                                                               \
   }                                                                                                         \
-  void del_container__bht_int_##D##_int_16(zs_rocm_bht_##D *b) {                                            \
+  void del_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *b) {                                            \
     bht_destroy(b->t);                                                                                      \
     delete b;                                                                                               \
   }                                                                                                         \
-  size_t container_size__bht_int_##D##_int_16(const zs_rocm_bht_##D *b) { return (size_t)bht_size(b->t, nullptr); } \
-  size_t container_capacity__bht_int_##D##_int_16(const zs_rocm_bht_##D *b) { return b->t.tableSize; }      \
-  void reset_container__bht_int_##D##_int_16(zs_rocm_bht_##D *b, int clearCnt) { /* Bht.hpp:306-318 */      \
+  size_t container_size__bht_int_##D##_int_##B(const zs_rocm_bht_##D *b) { return (size_t)bht_size(b->t, nullptr); } \
+  size_t container_capacity__bht_int_##D##_int_##B(const zs_rocm_bht_##D *b) { return b->t.tableSize; }      \
+  void reset_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *b, int clearCnt) { /* Bht.hpp:306-318 */      \
     bht_reset_table(b->t, nullptr);                                                                         \
     if (clearCnt) ZSR_CHECK(hipMemsetAsync(b->t.cnt, 0, sizeof(int), nullptr));                             \
     int one = 1;                                                                                            \
     ZSR_CHECK(hipMemcpy(b->t.success, &one, sizeof(int), hipMemcpyHostToDevice));                           \
     ZSR_CHECK(hipDeviceSynchronize());                                                                      \
   }                                                                                                         \
-  zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_16(zs_rocm_bht_##D *b) {                                 \
+  zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B(zs_rocm_bht_##D *b) {                                 \
     auto *v = new zs_rocm_bht_view_lite;                                                                    \
     v->keys = b->t.keys; v->indices = b->t.indices; v->status = b->t.status; v->activeKeys = b->t.activeKeys; \
     v->cnt = b->t.cnt; v->success = b->t.success; v->tableSize = b->t.tableSize;                            \
@@ -248,31 +249,36 @@ extern "C" {
     v->hf2x = b->t.hf[4]; v->hf2y = b->t.hf[5];                                                             \
     return v;                                                                                               \
   }                                                                                                         \
-  void del_pyview__bht_int_##D##_int_16(zs_rocm_bht_view_lite *v) { delete v; }                             \
-  void resize_container__rocm_bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, size_t cap) {   \
+  void del_pyview__bht_int_##D##_int_##B(zs_rocm_bht_view_lite *v) { delete v; }                             \
+  void resize_container__rocm_bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, size_t cap) {   \
     bht_resize<D>(pol, b->t, cap);                                                                          \
   }                                                                                                         \
-  void zs_rocm_insert__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys,       \
+  void zs_rocm_insert__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys,       \
                                             size_t n, int *ret) {                                           \
     bht_insert_many<D>(pol, b->t, keys, n, ret);                                                            \
   }                                                                                                         \
-  void zs_rocm_assign__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys, size_t n) { \
+  void zs_rocm_assign__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys, size_t n) { \
     bht_assign<D>(pol, b->t, keys, n);                                                                      \
   }                                                                                                         \
-  void zs_rocm_query__bht_int_##D##_int_16(zs_rocm_policy *pol, const zs_rocm_bht_##D *b, const int *keys,  \
+  void zs_rocm_query__bht_int_##D##_int_##B(zs_rocm_policy *pol, const zs_rocm_bht_##D *b, const int *keys,  \
                                            size_t n, int *ret) {                                            \
     bht_query_many<D>(pol, b->t, keys, n, ret);                                                             \
   }                                                                                                         \
-  void zs_rocm_reorder__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *map,       \
+  void zs_rocm_reorder__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *map,       \
                                              int scatter) {                                                 \
     Launch L(pol, "bht_reorder");                                                                           \
     bht_reorder_impl<D>(L, b->t, map, scatter != 0, bht_size(b->t, L.stream));                              \
   }                                                                                                         \
-  void zs_rocm_canonicalize__bht_int_##D##_int_16(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
+  void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
     bht_canonicalize<D>(pol, b->t);                                                                         \
   }
-ZSR_DEFINE_BHT(1)
-ZSR_DEFINE_BHT(2)
-ZSR_DEFINE_BHT(3)
+ZSR_DEFINE_BHT(1, 16)
+ZSR_DEFINE_BHT(2, 16)
+ZSR_DEFINE_BHT(3, 16)
+ZSR_DEFINE_BHT(4, 16)
+ZSR_DEFINE_BHT(1, 32)
+ZSR_DEFINE_BHT(2, 32)
+ZSR_DEFINE_BHT(3, 32)
+ZSR_DEFINE_BHT(4, 32)
 
 }  // extern "C"
