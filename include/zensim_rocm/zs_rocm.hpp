@@ -29,6 +29,7 @@
 #include "../zs_rocm.h"
 #include "bht_device.hpp"
 #include "merge_sort.hpp"
+#include "hashtable_device.hpp"
 
 #define ZS_LAMBDA __device__
 #define ZS_FUNCTION __forceinline__ __host__ __device__
@@ -341,6 +342,170 @@ template <int dim, int B = 16> struct bht {
   typename traits::handle *_h;
 };
 
+// zs::HashTable<i32, dim, int> (container/HashTable.hpp): hash_combine hash, linear probing (stride 127)
+template <int dim> struct HashTableView {  // HashTableView (HashTable.hpp:313-592)
+  zsr::HtDev t;
+  static constexpr int sentinel_v = -1;
+  __device__ __forceinline__ int insert(const small_vec<int, dim> &key) const { return zsr::ht_insert<dim>(t, key.v); }           // :353-374
+  __device__ __forceinline__ bool insert(const small_vec<int, dim> &key, int id) const { return zsr::ht_insert_id<dim>(t, key.v, id); }  // :405-421
+  __device__ __forceinline__ int query(const small_vec<int, dim> &key) const { return zsr::ht_query<dim>(t, key.v); }             // :445-457
+  __device__ __forceinline__ int entry(const small_vec<int, dim> &key) const { return zsr::ht_query<dim, true>(t, key.v); }       // :458-470
+  __device__ __forceinline__ int size() const { return *t.cnt; }
+  int *_activeKeys() const { return t.activeKeys; }
+};
+template <int dim> struct HashTable {
+  explicit HashTable(std::size_t numExpectedEntries, memsrc_e mre = memsrc_e::device, ProcID devid = 0)
+      : _h(zs_rocm_hashtable_create(dim, numExpectedEntries, (int)mre, devid)) {}
+  ~HashTable() { zs_rocm_hashtable_destroy(_h); }
+  HashTable(const HashTable &) = delete;
+  int size() const { return zs_rocm_hashtable_size(_h); }
+  std::size_t tableSize() const { return zs_rocm_hashtable_table_size(_h); }
+  template <class Pol> void reset(const Pol &pol, bool clearCnt) { zs_rocm_hashtable_reset(pol.handle(), _h, clearCnt); }
+  template <class Pol> void resize(const Pol &pol, std::size_t n) { zs_rocm_hashtable_resize(pol.handle(), _h, n); }
+  template <class Pol> void preserve(const Pol &pol, std::size_t n) { zs_rocm_hashtable_preserve(pol.handle(), _h, n); }
+  HashTableView<dim> view() const {
+    zs_rocm_hashtable_view v;
+    zs_rocm_hashtable_get_view(_h, &v);
+    HashTableView<dim> r;
+    r.t.keys = v.keys; r.t.indices = v.indices; r.t.status = v.status; r.t.activeKeys = v.activeKeys; r.t.cnt = v.cnt;
+    r.t.tableSize = v.tableSize;
+    return r;
+  }
+  zs_rocm_hashtable *_h;
+};
+
+// zs::SparseGrid<3, f32, Side> (geometry/SparseGrid.hpp:16-188): bht<int,3,int,16> keyed by block ORIGIN coordinates
+// (multiples of Side) + TileVector<f32, Side^3>; index<->world transform restricted to uniform scale + translation
+// (what `scale(dx)` / `translate(t)` produce, :170-182).
+template <int Side = 8> struct SparseGridView {  // SparseGridView (geometry/SparseGrid.hpp:199-916)
+  static constexpr int dim = 3, side_length = Side, block_size = Side * Side * Side;
+  static constexpr int sentinel_v = -1;
+  using coord_t = small_vec<float, 3>;
+  using icoord_t = small_vec<int, 3>;
+  BHTView<3> _table;
+  TileVectorView<float, Side * Side * Side> _grid;
+  float _dx;
+  coord_t _origin;
+  float _background;
+  ZS_FUNCTION coord_t indexToWorld(const coord_t &X) const { return coord_t{{X[0] * _dx + _origin[0], X[1] * _dx + _origin[1], X[2] * _dx + _origin[2]}}; }
+  ZS_FUNCTION coord_t worldToIndex(const coord_t &x) const { return coord_t{{(x[0] - _origin[0]) / _dx, (x[1] - _origin[1]) / _dx, (x[2] - _origin[2]) / _dx}}; }
+  ZS_FUNCTION float voxelSize(int = 0) const { return _dx; }
+  __device__ __forceinline__ int numActiveBlocks() const { return _table.size(); }
+  // linear cell index <-> in-block coordinate (:266-292): offset = (x * Side + y) * Side + z
+  ZS_FUNCTION static icoord_t local_offset_to_coord(int offset) {
+    icoord_t r;
+    for (int d = 2; d >= 0; --d, offset /= Side) r[d] = offset % Side;
+    return r;
+  }
+  ZS_FUNCTION static int local_coord_to_offset(const icoord_t &c) { return (c[0] * Side + c[1]) * Side + c[2]; }
+  ZS_FUNCTION static int global_coord_to_local_offset(const icoord_t &c) {
+    return (((c[0] & (Side - 1)) * Side) + (c[1] & (Side - 1))) * Side + (c[2] & (Side - 1));
+  }
+  struct BlockCell { int bno, cno; };
+  // decomposeCoord (:305-309): cell = coord & (Side-1), block origin = coord - cell -> (table.query(origin), offset)
+  __device__ __forceinline__ BlockCell decomposeCoord(const icoord_t &c) const {
+    const icoord_t cell{{c[0] & (Side - 1), c[1] & (Side - 1), c[2] & (Side - 1)}};
+    const icoord_t org{{c[0] - cell[0], c[1] - cell[1], c[2] - cell[2]}};
+    return {_table.query(org), local_coord_to_offset(cell)};
+  }
+  ZS_FUNCTION float &operator()(int chn, int bno, int cno) const { return _grid(chn, (std::size_t)bno, cno); }
+  // valueOr (:344-367)
+  ZS_FUNCTION float valueOr(int chn, int bno, int cno, float defaultVal) const { return bno == sentinel_v ? defaultVal : _grid(chn, (std::size_t)bno, cno); }
+  __device__ __forceinline__ float valueOr(int chn, const icoord_t &c, float defaultVal) const {  // valueOr(false_c, ...)
+    const BlockCell bc = decomposeCoord(c);
+    return valueOr(chn, bc.bno, bc.cno, defaultVal);
+  }
+  __device__ __forceinline__ float valueOr(int chn, const icoord_t &c, int orientation, float defaultVal) const {  // valueOr(true_c, ...)
+    icoord_t cc = c;
+    const int f = orientation % 6;
+    if (f >= 3) ++cc[f - 3];
+    return valueOr(chn, cc, defaultVal);
+  }
+  // iCoord / wCoord (:404-417), staggered (:419-440)
+  __device__ __forceinline__ icoord_t iCoord(int bno, int cno) const {
+    const icoord_t l = local_offset_to_coord(cno);
+    const int *k = _table.t.activeKeys + 3 * (std::size_t)bno;
+    return icoord_t{{k[0] + l[0], k[1] + l[1], k[2] + l[2]}};
+  }
+  __device__ __forceinline__ icoord_t iCoord(std::size_t cellno) const { return iCoord((int)(cellno / block_size), (int)(cellno % block_size)); }
+  __device__ __forceinline__ coord_t wCoord(int bno, int cno) const {
+    const icoord_t c = iCoord(bno, cno);
+    return indexToWorld(coord_t{{(float)c[0], (float)c[1], (float)c[2]}});
+  }
+  __device__ __forceinline__ coord_t iStaggeredCoord(int bno, int cno, int f) const {
+    const icoord_t c = iCoord(bno, cno);
+    coord_t r{{(float)c[0], (float)c[1], (float)c[2]}};
+    r[f] -= 0.5f;
+    return r;
+  }
+  __device__ __forceinline__ coord_t wStaggeredCoord(int bno, int cno, int f) const { return indexToWorld(iStaggeredCoord(bno, cno, f)); }
+  // insert / query by world position (:442-457): X = floor(worldToIndex(x) + 0.5), block origin = X - (X & (Side-1))
+  __device__ __forceinline__ icoord_t blockOriginOf(const coord_t &x) const {
+    const coord_t X_ = worldToIndex(x);
+    icoord_t X;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      X[d] = (int)floorf(X_[d] + 0.5f);
+      X[d] -= X[d] & (Side - 1);
+    }
+    return X;
+  }
+  __device__ __forceinline__ int insert(const coord_t &x) const { return _table.insert(blockOriginOf(x)); }
+  __device__ __forceinline__ int query(const coord_t &x) const { return _table.query(blockOriginOf(x)); }
+  // iSample / wSample (:459-516) with the linear kernel: GridArena<linear> (math/curve/InterpolationKernel.hpp:271-456):
+  // corner = floor(X), w = {1 - d, d}, sum over the 2^3 nodes of w * valueOr(node, background)
+  __device__ __forceinline__ float iSample(int chn, const coord_t &X) const {
+    int c[3];
+    float w[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      c[d] = (int)floorf(X[d]);
+      const float t = X[d] - (float)c[d];
+      w[d][0] = 1.f - t;
+      w[d][1] = t;
+    }
+    float ret = 0.f;
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 2; ++k) ret += w[0][i] * w[1][j] * w[2][k] * valueOr(chn, icoord_t{{c[0] + i, c[1] + j, c[2] + k}}, _background);
+    return ret;
+  }
+  __device__ __forceinline__ float wSample(int chn, const coord_t &x) const { return iSample(chn, worldToIndex(x)); }
+  template <int N> __device__ __forceinline__ small_vec<float, N> iPack(dim_t<N>, int chn, const coord_t &X) const {  // :640-700
+    small_vec<float, N> r;
+#pragma unroll
+    for (int d = 0; d < N; ++d) r[d] = iSample(chn + d, X);
+    return r;
+  }
+  template <int N> __device__ __forceinline__ small_vec<float, N> wPack(dim_t<N> t, int chn, const coord_t &x) const { return iPack(t, chn, worldToIndex(x)); }
+};
+template <int Side = 8> struct SparseGrid {
+  static constexpr int dim = 3, side_length = Side, block_size = Side * Side * Side;
+  SparseGrid(const std::vector<PropertyTag> &tags, std::size_t numBlocks, memsrc_e mre = memsrc_e::device)
+      : _table(numBlocks), _grid(tags, numBlocks * (std::size_t)block_size, mre) {}
+  SparseGrid(int numChns, std::size_t numBlocks, memsrc_e mre = memsrc_e::device)
+      : SparseGrid(std::vector<PropertyTag>{{"unnamed", numChns}}, numBlocks, mre) {}
+  std::size_t numBlocks() const { return _table.size(); }
+  int numChannels() const { return _grid.numChannels(); }
+  int getPropertyOffset(const std::string &n) const { return _grid.getPropertyOffset(n); }
+  void scale(float s) { _dx *= s; }                                               // :181-182
+  void translate(float x, float y, float z) { _origin[0] += x; _origin[1] += y; _origin[2] += z; }  // :170-172
+  float voxelSize() const { return _dx; }
+  SparseGridView<Side> view() {
+    SparseGridView<Side> v;
+    v._table = _table.view();
+    v._grid = TileVectorView<float, block_size>{_grid.data(), _grid.size(), _grid.numChannels()};
+    v._dx = _dx;
+    v._origin = small_vec<float, 3>{{_origin[0], _origin[1], _origin[2]}};
+    v._background = _background;
+    return v;
+  }
+  bht<3, 16> _table;
+  TileVector<float, Side * Side * Side> _grid;
+  float _dx = 1.f, _origin[3] = {0.f, 0.f, 0.f};
+  float _background = 0.f;
+};
+
 // view<space>(container) / proxy<space>(container)  (container/Vector.hpp:455-615, TileVector.hpp:693-1540, Bht.hpp:403)
 template <execspace_e space, class T> VectorView<T> view(Vector<T> &v) {
   static_assert(space == execspace_e::rocm, "this header provides the rocm space only");
@@ -349,6 +514,8 @@ template <execspace_e space, class T> VectorView<T> view(Vector<T> &v) {
 template <execspace_e space, class T, int L> TileVectorView<T, L> view(TileVector<T, L> &v) { return {v.data(), v.size(), v.numChannels()}; }
 template <execspace_e space, class T, int L> TileVectorView<T, L> view(std::initializer_list<const char *>, TileVector<T, L> &v) { return view<space>(v); }
 template <execspace_e space, int dim, int B> BHTView<dim> view(bht<dim, B> &t) { return t.view(); }
+template <execspace_e space, int dim> HashTableView<dim> view(HashTable<dim> &t) { return t.view(); }
+template <execspace_e space, int Side> SparseGridView<Side> view(SparseGrid<Side> &g) { return g.view(); }
 template <execspace_e space, class C> auto proxy(C &c) { return view<space>(c); }
 template <execspace_e space, class T, int L> auto proxy(std::initializer_list<const char *> l, TileVector<T, L> &v) { return view<space>(l, v); }
 

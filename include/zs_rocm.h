@@ -284,6 +284,38 @@ ZS_ROCM_DECL_BHT(2, 32)
 ZS_ROCM_DECL_BHT(3, 32)
 ZS_ROCM_DECL_BHT(4, 32)
 
+/* ======================================================================== (B) HashTable */
+/* zs::HashTable<i32, dim, int> (container/HashTable.hpp:16-592), dim 1-4: the open-addressing table (64-bit hash_combine
+ * chain over the raw coordinates `:496-500`, home = ((h % size) + size) % size, linear probing with stride 127 `:362`)
+ * that `partition_for_particles` returns (simulation/sparsity/SparsityCompute.tpp:5-24) and the Grids-based MPM path keys
+ * its blocks with (simulation/mpm/Simulator.cpp:122).  The reference exposes it only as a C++ template; these entry
+ * points are the bulk forms of `pol(range(n), [t = proxy<space>(table)](i){ ... t.insert(key_i) ... })`.
+ * Layout as in the reference: keys [tableSize][dim] packed ints (empty = INT_MAX), indices (-1 = empty), status (-1),
+ * activeKeys [tableSize][dim], cnt; tableSize = next_2pow(n) * 16 (`:87-90`). */
+typedef struct zs_rocm_hashtable zs_rocm_hashtable;
+typedef struct {
+  int *keys, *indices, *status, *activeKeys, *cnt;
+  int tableSize;
+} zs_rocm_hashtable_view; /* HashTableView members, HashTable.hpp:472-476 */
+ZS_ROCM_EXPORT zs_rocm_hashtable *zs_rocm_hashtable_create(int dim, size_t numExpectedEntries, int memsrc, int devid);
+ZS_ROCM_EXPORT void zs_rocm_hashtable_destroy(zs_rocm_hashtable *);
+ZS_ROCM_EXPORT int zs_rocm_hashtable_dim(const zs_rocm_hashtable *);
+ZS_ROCM_EXPORT size_t zs_rocm_hashtable_table_size(const zs_rocm_hashtable *); /* _tableSize */
+ZS_ROCM_EXPORT int zs_rocm_hashtable_size(const zs_rocm_hashtable *);          /* size(): device -> host copy of cnt (:152) */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_get_view(const zs_rocm_hashtable *, zs_rocm_hashtable_view *out);
+/* HashTable::reset(pol, clearCnt) (:294-299) == CleanSparsity with clearCnt = 1 (sparsity/SparsityOp.hpp:42-57) */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_reset(zs_rocm_policy *, zs_rocm_hashtable *, int clearCnt);
+/* HashTableView::insert(key) (:353-374): ret[i] = dense index for the one inserter of a new key, -1 (sentinel_v) otherwise */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_insert(zs_rocm_policy *, zs_rocm_hashtable *, const int *keys, size_t n, int *ret);
+/* HashTableView::insert(key, id) (:405-421): indices[slot] = ids[i] (ids == NULL: i); ok[i] = 1 if this call created the entry */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_insert_ids(zs_rocm_policy *, zs_rocm_hashtable *, const int *keys, const int *ids, size_t n, int *ok);
+/* HashTableView::query / entry (:445-470): index / slot of a key, -1 if absent (table quiescent) */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_query(zs_rocm_policy *, const zs_rocm_hashtable *, const int *keys, size_t n, int *ret);
+ZS_ROCM_EXPORT void zs_rocm_hashtable_entry(zs_rocm_policy *, const zs_rocm_hashtable *, const int *keys, size_t n, int *ret);
+/* HashTable::resize / preserve (:258-292) */
+ZS_ROCM_EXPORT void zs_rocm_hashtable_resize(zs_rocm_policy *, zs_rocm_hashtable *, size_t numExpectedEntries);
+ZS_ROCM_EXPORT void zs_rocm_hashtable_preserve(zs_rocm_policy *, zs_rocm_hashtable *, size_t numExpectedEntries);
+
 /* ======================================================================== (B) MPM transfers */
 /* A particle attribute stored in an AoS zs::Vector<vec<T,N>> (geometry/Structurefree.hpp:21-237) or in
  * a TileVector channel group: component d of particle i lives at
@@ -331,6 +363,14 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *, zs_rocm_bht_3
 /* keyStride: 1 for block-coordinate keys, side for block-origin keys */
 ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3],
                                                  int keyStride);
+/* The same two functors on a zs::HashTable<i32,3,int> partition (their in-tree form: `partition_for_particles`,
+ * simulation/sparsity/SparsityCompute.tpp:5-24 = CleanSparsity + ComputeSparsity(dx, blocklen, table, x), offset -2,
+ * displacement 0.5; EnlargeSparsity sparsity/SparsityOp.hpp:89-115).  `zs_rocm_assign__bht_int_3_int_16(pol, bht,
+ * view.activeKeys, size)` then adopts the block numbering for the binned transfers. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_partition_for_particles(zs_rocm_policy *, zs_rocm_hashtable *, zs_rocm_attr pos, size_t n,
+                                                        float dx, int blocklen);
+ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity__hashtable(zs_rocm_policy *, zs_rocm_hashtable *, const int lo[3],
+                                                            const int hi[3]);
 
 /* particle -> bin binning (the role of IndexBuckets / SpatiallyCount+Distribute,
  * sparsity/SparsityOp.hpp:117-196, simulation/particle/Query.tpp:9-58).  A bin is a 4x4x4 group of cells

@@ -92,4 +92,12 @@ unsigned ref_hash_combine32(unsigned seed, unsigned val) {
   hash_combine(seed, val);
   return seed;
 }
+/* HashTableView::do_hash (container/HashTable.hpp:496-500) is three lines over hash_combine with a size_t seed; HashTable.hpp
+   itself pulls in the execution-policy headers (unbuildable here), so the fold is spelled out over the reference's own
+   64-bit hash_combine (math/Hash.hpp:19-28), which is what this pins. */
+int ref_hashtable_do_hash(const int *key, int dim) {
+  size_t ret = key[0];
+  for (int d = 1; d < dim; ++d) hash_combine(ret, key[d]);
+  return static_cast<int>(ret);
+}
 }

@@ -108,6 +108,26 @@ const int32_t *orc_bht_indices(const orc_bht *);
 int orc_bht_key_stride(const orc_bht *);
 void orc_bht_resize(orc_bht *, size_t newCapacity); /* Bht.hpp:320-340 */
 
+/* ---------------------------------------------------------------- HashTable (hashtable.c) */
+/* zs::HashTable<i32, dim, int>, container/HashTable.hpp:16-592: hash_combine hash, linear probing stride 127 */
+typedef struct orc_hashtable orc_hashtable;
+size_t orc_hashtable_table_size(size_t nExpected);                 /* :87-90 */
+int32_t orc_hashtable_do_hash(const int32_t *key, int dim);        /* :496-500 */
+orc_hashtable *orc_hashtable_create(int dim, size_t nExpected);
+void orc_hashtable_destroy(orc_hashtable *);
+void orc_hashtable_reset(orc_hashtable *, int clearCnt);           /* :212-228,294-299 */
+int32_t orc_hashtable_insert(orc_hashtable *, const int32_t *key); /* :376-397 */
+int orc_hashtable_insert_id(orc_hashtable *, const int32_t *key, int32_t id); /* :423-443 */
+int32_t orc_hashtable_query(const orc_hashtable *, const int32_t *key);       /* :445-457 */
+int32_t orc_hashtable_entry(const orc_hashtable *, const int32_t *key);       /* :458-470 */
+void orc_hashtable_insert_many(orc_hashtable *, const int32_t *keys, size_t n, int32_t *ret);
+void orc_hashtable_query_many(const orc_hashtable *, const int32_t *keys, size_t n, int32_t *ret);
+int32_t orc_hashtable_size(const orc_hashtable *);
+int32_t orc_hashtable_get_table_size(const orc_hashtable *);
+const int32_t *orc_hashtable_active_keys(const orc_hashtable *);
+void orc_hashtable_resize(orc_hashtable *, size_t nExpected);      /* :281-292 */
+void orc_hashtable_preserve(orc_hashtable *, size_t nExpected);    /* :258-279 */
+
 /* ---------------------------------------------------------------- MPM (mpm.c) */
 /* McAdams 3x3 SVD, column-major 9-vectors: math/matrix/SVD.hpp:15-1030 */
 void orc_svd3(const float F[9], float U[9], float S[3], float V[9]);

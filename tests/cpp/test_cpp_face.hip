@@ -198,6 +198,76 @@ int main() {
     });
     for (int i = 0; i < n; ++i) CHECK(ret.data()[i] == 1);
   }
+  // ---- HashTable: insert / query inside lambdas (HashTable.hpp:353-470), resize keeps indices
+  {
+    const int n = 40000;
+    HashTable<3> tab(n);
+    Vector<int> ret(n, memsrc_e::um);
+    pol(range(n), [tb = proxy<space>(tab), r = view<space>(ret)] ZS_LAMBDA(long long i) {
+      small_vec<int, 3> k{{(int)(i % 41) - 20, (int)((i / 41) % 13), (int)(i % 7)}};
+      r[i] = tb.insert(k);
+    });
+    std::vector<std::array<int, 3>> all;
+    for (int i = 0; i < n; ++i) all.push_back({i % 41 - 20, (i / 41) % 13, i % 7});
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    CHECK(tab.size() == (int)all.size());
+    int winners = 0;
+    for (int i = 0; i < n; ++i) winners += ret.data()[i] >= 0;
+    CHECK(winners == (int)all.size());
+    tab.resize(pol, 4 * n);
+    pol(range(n), [tb = proxy<space>(tab), r = view<space>(ret)] ZS_LAMBDA(long long i) {
+      small_vec<int, 3> k{{(int)(i % 41) - 20, (int)((i / 41) % 13), (int)(i % 7)}};
+      small_vec<int, 3> miss{{1000 + (int)i, 0, 0}};
+      const int q = tb.query(k);
+      r[i] = (q >= 0 && q < tb.size() && tb.query(miss) == -1 && !tb.insert(k, 5)) ? 1 : 0;
+    });
+    for (int i = 0; i < n; ++i) CHECK(ret.data()[i] == 1);
+  }
+  // ---- SparseGrid<8>: world-space insert / query, decomposeCoord, valueOr, trilinear wSample of a linear field
+  {
+    const float dx = 0.125f;
+    SparseGrid<8> sg(std::vector<PropertyTag>{{"sdf", 1}, {"v", 3}}, 64);
+    sg.scale(dx);
+    sg.translate(-1.f, -1.f, -1.f);
+    sg._background = 7.f;
+    const int np = 5000;
+    Vector<float> px(3 * np, memsrc_e::um);
+    unsigned s = 99u;
+    for (int i = 0; i < 3 * np; ++i) { s = s * 1664525u + 1013904223u; px.data()[i] = -0.5f + 1.0f * (float)(s >> 8) / (float)(1u << 24); }
+    pol(range(np), [g = view<space>(sg), p = view<space>(px)] ZS_LAMBDA(long long i) {
+      // a 2x2x2-cell neighbourhood of every sample so that the linear stencil of the point is allocated
+      for (int o = 0; o < 8; ++o)
+        g.insert(small_vec<float, 3>{{p[3 * i] + ((o >> 2) - 0.5f) * 0.125f, p[3 * i + 1] + (((o >> 1) & 1) - 0.5f) * 0.125f, p[3 * i + 2] + ((o & 1) - 0.5f) * 0.125f}});
+    });
+    const std::size_t nb = sg.numBlocks();
+    CHECK(nb > 0 && nb <= 64);
+    // fill: sdf = 2x - y + 0.5z + 1 at every node of every active block, v = world coordinate
+    pol(range((long long)nb * 512), [g = view<space>(sg)] ZS_LAMBDA(long long c) {
+      const int b = (int)(c / 512), k = (int)(c % 512);
+      const auto w = g.wCoord(b, k);
+      g(0, b, k) = 2.f * w[0] - w[1] + 0.5f * w[2] + 1.f;
+      for (int d = 0; d < 3; ++d) g(1 + d, b, k) = w[d];
+      const auto ic = g.iCoord(b, k);
+      const auto bc = g.decomposeCoord(ic);  // round trip through the table
+      if (bc.bno != b || bc.cno != k) g(0, b, k) = -1e30f;
+    });
+    Vector<float> err(np, memsrc_e::um);
+    pol(range(np), [g = view<space>(sg), p = view<space>(px), e = view<space>(err)] ZS_LAMBDA(long long i) {
+      const small_vec<float, 3> x{{p[3 * i], p[3 * i + 1], p[3 * i + 2]}};
+      const float f = g.wSample(0, x), ref = 2.f * x[0] - x[1] + 0.5f * x[2] + 1.f;
+      const auto v = g.wPack(dim_c<3>, 1, x);
+      float m = fabsf(f - ref);
+      for (int d = 0; d < 3; ++d) m = fmaxf(m, fabsf(v[d] - x[d]));
+      if (g.query(x) < 0) m = 1e30f;
+      // far outside: background through valueOr / sample
+      if (fabsf(g.wSample(0, small_vec<float, 3>{{50.f, 50.f, 50.f}}) - 7.f) > 0.f) m = 1e30f;
+      e[i] = m;
+    });
+    float worst = 0.f;
+    for (int i = 0; i < np; ++i) worst = std::max(worst, err.data()[i]);
+    CHECK(worst < 2e-5f);  // trilinear interpolation reproduces linear fields
+  }
   CHECK(zs_rocm_last_error(-1) == 0);
   std::printf("cpp face ok\n");
   return 0;

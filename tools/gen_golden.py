@@ -78,6 +78,13 @@ def main():
     n2 = np.array([ref.ref_next_2pow(int(v)) for v in ns], np.uint64)
     np.savez_compressed(os.path.join(OUT, "hash.npz"), hash_params=np.array(list(hp), np.uint32), keys=keys, h3=h3, h2=h2, h1=h1,
                         next_2pow_in=ns, next_2pow_out=n2)
+    # ---- HashTable hash (container/HashTable.hpp:496-500 over math/Hash.hpp:19-28, 64-bit seed), own generator so that the
+    # fixtures above stay byte-identical
+    g2 = np.random.default_rng(20250928)
+    hk = np.concatenate([g2.integers(-40, 40, (96, 4)), g2.integers(-2 ** 31, 2 ** 31 - 1, (96, 4))]).astype(np.int32)
+    ref.ref_hashtable_do_hash.restype = C.c_int
+    hh = np.array([[ref.ref_hashtable_do_hash(P(k), d) for d in (1, 2, 3, 4)] for k in hk], np.int32)
+    np.savez_compressed(os.path.join(OUT, "hashtable.npz"), keys=hk, do_hash=hh)
     print("wrote", os.listdir(OUT))
 
 

@@ -13,6 +13,12 @@ class Port(C.Structure):
                 ("tileMask", C.c_uint32), ("numChns", C.c_uint32)]
 
 
+class HashTableView(C.Structure):
+    """zs_rocm_hashtable_view (HashTableView members, container/HashTable.hpp:472-476)."""
+    _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
+                ("cnt", C.c_void_p), ("tableSize", C.c_int)]
+
+
 class BhtViewLite(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
                 ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_size_t),
@@ -156,6 +162,23 @@ def _declare_containers(L):
         getattr(L, "zs_rocm_assign__" + s).argtypes = [vp, vp, vp, sz]
         getattr(L, "zs_rocm_reorder__" + s).argtypes = [vp, vp, vp, i32]
         getattr(L, "zs_rocm_canonicalize__" + s).argtypes = [vp, vp]
+    L.zs_rocm_hashtable_create.argtypes = [i32, sz, i32, i32]
+    L.zs_rocm_hashtable_create.restype = vp
+    L.zs_rocm_hashtable_destroy.argtypes = [vp]
+    L.zs_rocm_hashtable_dim.argtypes = [vp]
+    L.zs_rocm_hashtable_table_size.argtypes = [vp]
+    L.zs_rocm_hashtable_table_size.restype = sz
+    L.zs_rocm_hashtable_size.argtypes = [vp]
+    L.zs_rocm_hashtable_get_view.argtypes = [vp, C.POINTER(HashTableView)]
+    L.zs_rocm_hashtable_reset.argtypes = [vp, vp, i32]
+    L.zs_rocm_hashtable_insert.argtypes = [vp, vp, vp, sz, vp]
+    L.zs_rocm_hashtable_insert_ids.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.zs_rocm_hashtable_query.argtypes = [vp, vp, vp, sz, vp]
+    L.zs_rocm_hashtable_entry.argtypes = [vp, vp, vp, sz, vp]
+    L.zs_rocm_hashtable_resize.argtypes = [vp, vp, sz]
+    L.zs_rocm_hashtable_preserve.argtypes = [vp, vp, sz]
+    L.zs_rocm_mpm_partition_for_particles.argtypes = [vp, vp, Port, sz, f32, i32]
+    L.zs_rocm_mpm_enlarge_sparsity__hashtable.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     PP = C.POINTER(MpmParams)
     L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32, i32]
     L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]

@@ -194,3 +194,57 @@ class Bht:
 
     def canonicalize(self, pol):
         getattr(lib(), "zs_rocm_canonicalize__" + self.s)(pol.handle, self._h)
+
+
+class HashTable:
+    """zs::HashTable<i32, dim, int> (container/HashTable.hpp:16-592): hash_combine hash, linear probing with stride 127 --
+    the table `partition_for_particles` returns and the Grids-based MPM path keys its blocks with."""
+
+    def __init__(self, dim, n, memsrc=1, devid=0):
+        self.dim = dim
+        self._h = lib().zs_rocm_hashtable_create(dim, n, memsrc, devid)
+        if not self._h:
+            raise ValueError("HashTable: dim must be 1..4")
+
+    def __del__(self):
+        try:
+            lib().zs_rocm_hashtable_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def size(self):
+        return lib().zs_rocm_hashtable_size(self._h)
+
+    def tableSize(self):
+        return lib().zs_rocm_hashtable_table_size(self._h)
+
+    def view(self):
+        from ._lib import HashTableView
+        v = HashTableView()
+        lib().zs_rocm_hashtable_get_view(self._h, C.byref(v))
+        return v
+
+    def reset(self, pol, clear_cnt=True):
+        lib().zs_rocm_hashtable_reset(pol.handle, self._h, int(clear_cnt))
+
+    def insert(self, pol, keys_ptr, n, ret_ptr=None):
+        lib().zs_rocm_hashtable_insert(pol.handle, self._h, keys_ptr, n, ret_ptr)
+
+    def insert_ids(self, pol, keys_ptr, ids_ptr, n, ok_ptr=None):
+        lib().zs_rocm_hashtable_insert_ids(pol.handle, self._h, keys_ptr, ids_ptr, n, ok_ptr)
+
+    def query(self, pol, keys_ptr, n, ret_ptr):
+        lib().zs_rocm_hashtable_query(pol.handle, self._h, keys_ptr, n, ret_ptr)
+
+    def entry(self, pol, keys_ptr, n, ret_ptr):
+        lib().zs_rocm_hashtable_entry(pol.handle, self._h, keys_ptr, n, ret_ptr)
+
+    def resize(self, pol, n):
+        lib().zs_rocm_hashtable_resize(pol.handle, self._h, n)
+
+    def preserve(self, pol, n):
+        lib().zs_rocm_hashtable_preserve(pol.handle, self._h, n)

@@ -1,0 +1,18 @@
+// hashtable.hpp -- host-side object of zs::HashTable<i32, dim, int> (container/HashTable.hpp:16-312); device protocol in
+// include/zensim_rocm/hashtable_device.hpp.
+#pragma once
+#include "common.hpp"
+#include "../../include/zensim_rocm/hashtable_device.hpp"
+
+struct zs_rocm_hashtable {
+  int dim = 3, memsrc = 1;
+  int8_t devid = 0;
+  size_t tableSize = 0;
+  int *keys = nullptr, *indices = nullptr, *status = nullptr, *activeKeys = nullptr, *cnt = nullptr;
+  zsr::HtDev dev() const {
+    zsr::HtDev d;
+    d.keys = keys; d.indices = indices; d.status = status; d.activeKeys = activeKeys; d.cnt = cnt;
+    d.tableSize = (int)tableSize;
+    return d;
+  }
+};

@@ -27,6 +27,7 @@
 //     registers for all its particles.
 // Algorithmic HBM bytes per particle: P2G 100 B read (+ 7 B grid), G2P 48 B read + 96 B write (+1.5 B grid).
 #include "bht.hpp"
+#include "hashtable.hpp"
 
 namespace zsr {
 
@@ -436,6 +437,31 @@ __global__ __launch_bounds__(256) void enlarge_sparsity_kernel(BhtDev t, int nbl
   const int dx = lo0 + o / (e1 * e2), dy = lo1 + (o / e2) % e1, dz = lo2 + o % e2;
   int k[3] = {t.activeKeys[3 * (size_t)i] + dx * kscale, t.activeKeys[3 * (size_t)i + 1] + dy * kscale, t.activeKeys[3 * (size_t)i + 2] + dz * kscale};
   bht_insert<3>(t, k);
+}
+// the same functors on a zs::HashTable<i32,3,int> (simulation/sparsity/SparsityOp.hpp:59-115 are written against HashTableView)
+__global__ __launch_bounds__(256) void compute_sparsity_ht_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, int side) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int b[3] = {0, 0, 0};
+  if (valid) {
+    float p[3];
+    load_attr<3>(pos, i, p);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side);
+  }
+  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
+  const bool pvalid = shfl_up((int)valid, 1) != 0;
+  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
+  if (valid && !dup) ht_insert<3>(t, b);
+}
+__global__ __launch_bounds__(256) void enlarge_sparsity_ht_kernel(HtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2) {
+  const int per = e0 * e1 * e2;
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nblocks * per) return;
+  const int i = (int)(g / per), o = (int)(g % per);
+  int k[3] = {t.activeKeys[3 * (size_t)i] + lo0 + o / (e1 * e2), t.activeKeys[3 * (size_t)i + 1] + lo1 + (o / e2) % e1,
+              t.activeKeys[3 * (size_t)i + 2] + lo2 + o % e2};
+  ht_insert<3>(t, k);
 }
 __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr, int kscale) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1370,6 +1396,26 @@ void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, zs_ro
   if (!n) return;
   hipLaunchKernelGGL(compute_sparsity_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->t.dev(), make_port<float>(pos), n,
                      1.0f / dx, side, keyIsOrigin ? side : 1);
+}
+void zs_rocm_mpm_partition_for_particles(zs_rocm_policy *pol, zs_rocm_hashtable *tab, zs_rocm_attr pos, size_t n, float dx,
+                                         int blocklen) {
+  if (tab->dim != 3) return;
+  zs_rocm_hashtable_reset(pol, tab, 1);  // CleanSparsity (SparsityCompute.tpp:19)
+  Launch L(pol, "partition_for_particles");
+  if (!n) return;
+  hipLaunchKernelGGL(compute_sparsity_ht_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->dev(), make_port<float>(pos), n,
+                     1.0f / dx, blocklen);
+}
+void zs_rocm_mpm_enlarge_sparsity__hashtable(zs_rocm_policy *pol, zs_rocm_hashtable *tab, const int lo[3], const int hi[3]) {
+  if (tab->dim != 3) return;
+  Launch L(pol, "enlarge_sparsity");
+  int nb = 0;
+  ZSR_CHECK(hipMemcpyAsync(&nb, tab->cnt, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+  if (nb <= 0 || e0 <= 0 || e1 <= 0 || e2 <= 0) return;
+  hipLaunchKernelGGL(enlarge_sparsity_ht_kernel, dim3(ceil_div((size_t)nb * e0 * e1 * e2, 256)), dim3(256), 0, L.stream, tab->dev(), nb,
+                     lo[0], lo[1], lo[2], e0, e1, e2);
 }
 void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, const int lo[3], const int hi[3], int keyStride) {
   Launch L(pol, "EnlargeSparsity");

@@ -106,6 +106,20 @@ class MpmTransfer:
         self.binned = False
         return self.nblocks
 
+    def adopt_partition(self, active_keys_ptr, nblocks):
+        """Use a partition numbered elsewhere -- the `_activeKeys` of a zs::HashTable<i32,3,int> built by
+        partition_for_particles (the reference's Grids path) -- block i of the grid = active_keys[i]."""
+        L = lib()
+        self.table = Bht(3, int(nblocks))
+        self.table.assign(self.pol, active_keys_ptr, int(nblocks))
+        self.nblocks = int(nblocks)
+        nc = self.side ** 3
+        self.grid = torch.zeros(self.nblocks * 7 * nc, dtype=torch.float32, device=self.device)
+        self.nbr = torch.empty(self.nblocks * 8, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr(), self.kstride)
+        self.binned = False
+        return self.nblocks
+
     def rebin(self):
         """particle -> block binning + physical reorder of the AoSoA buffer (count / scan / distribute)."""
         L = lib()
