@@ -17,6 +17,7 @@
 #include "zensim/math/Hash.hpp" /* must precede HashUtils.hpp, which calls hash_combine unqualified */
 #include "zensim/py_interop/HashUtils.hpp"
 #include "zensim/math/bit/Bits.h"
+#include "zensim/geometry/AnalyticLevelSet.h" /* AABBBox, overlaps, BoundingVolumeInterface */
 #include <random>
 
 using namespace zs;
@@ -95,6 +96,23 @@ unsigned ref_hash_combine32(unsigned seed, unsigned val) {
 /* HashTableView::do_hash (container/HashTable.hpp:496-500) is three lines over hash_combine with a size_t seed; HashTable.hpp
    itself pulls in the execution-policy headers (unbuildable here), so the fold is spelled out over the reference's own
    64-bit hash_combine (math/Hash.hpp:19-28), which is what this pins. */
+/* _build_init_mc_id of LBvh (container/Bvh.hpp:177-188; Bvh.hpp itself needs the policy headers): the box-centre /
+   unit-cube / morton-code chain over the reference's own AABBBox (geometry/AnalyticLevelSet.h), getBoxCenter /
+   getUniformCoord (geometry/BoundingVolumeInterface.hpp:12-31) and morton_code<3> (math/bit/Bits.h:122-140) */
+unsigned ref_lbvh_morton(const float *whole, const float *bv) {
+  using Box = AABBBox<3, float>;
+  using TV = vec<float, 3>;
+  Box w{TV{whole[0], whole[1], whole[2]}, TV{whole[3], whole[4], whole[5]}};
+  Box b{TV{bv[0], bv[1], bv[2]}, TV{bv[3], bv[4], bv[5]}};
+  auto c = b.getBoxCenter();
+  auto coord = w.getUniformCoord(c).template cast<f32>();
+  return morton_code<3>(coord);
+}
+int ref_aabb_overlaps(const float *a, const float *q) {
+  using Box = AABBBox<3, float>;
+  using TV = vec<float, 3>;
+  return overlaps(Box{TV{a[0], a[1], a[2]}, TV{a[3], a[4], a[5]}}, Box{TV{q[0], q[1], q[2]}, TV{q[3], q[4], q[5]}}) ? 1 : 0;
+}
 int ref_hashtable_do_hash(const int *key, int dim) {
   size_t ret = key[0];
   for (int d = 1; d < dim; ++d) hash_combine(ret, key[d]);

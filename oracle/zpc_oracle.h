@@ -128,6 +128,26 @@ const int32_t *orc_hashtable_active_keys(const orc_hashtable *);
 void orc_hashtable_resize(orc_hashtable *, size_t nExpected);      /* :281-292 */
 void orc_hashtable_preserve(orc_hashtable *, size_t nExpected);    /* :258-279 */
 
+/* ---------------------------------------------------------------- LBvh (lbvh.c) */
+/* zs::LBvh<3, int, f32>, container/Bvh.hpp:86-492 (structure), :810-1082 (build), :1219-1248 (refit), :644-680 (traversal).
+ * Boxes are [n][6] floats {min xyz, max xyz} = AABBBox<3, f32>. */
+typedef struct orc_lbvh orc_lbvh;
+uint32_t orc_morton_3d_32(float x, float y, float z);                       /* math/bit/Bits.h:122-125 */
+void orc_lbvh_whole_box(const float *bvs, size_t n, float box[6]);          /* compute_bounding_box, Bvh.hpp:39-84 */
+uint32_t orc_lbvh_morton(const float whole[6], const float bv[6]);          /* _build_init_mc_id, :177-188 */
+orc_lbvh *orc_lbvh_create(void);
+void orc_lbvh_destroy(orc_lbvh *);
+void orc_lbvh_build(orc_lbvh *, const float *primBvs, size_t n, int refit);
+void orc_lbvh_refit(orc_lbvh *, const float *primBvs);
+size_t orc_lbvh_num_leaves(const orc_lbvh *);
+size_t orc_lbvh_num_nodes(const orc_lbvh *);
+const float *orc_lbvh_bvs(const orc_lbvh *);
+const int32_t *orc_lbvh_parents(const orc_lbvh *);
+const int32_t *orc_lbvh_levels(const orc_lbvh *);
+const int32_t *orc_lbvh_leaf_inds(const orc_lbvh *);
+const int32_t *orc_lbvh_aux_indices(const orc_lbvh *);
+size_t orc_lbvh_iter_neighbors(const orc_lbvh *, const float bv[6], int32_t *out, size_t cap);
+
 /* ---------------------------------------------------------------- MPM (mpm.c) */
 /* McAdams 3x3 SVD, column-major 9-vectors: math/matrix/SVD.hpp:15-1030 */
 void orc_svd3(const float F[9], float U[9], float S[3], float V[9]);

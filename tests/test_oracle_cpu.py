@@ -311,6 +311,48 @@ def test_hashtable_oracle_semantics(oracle, dim):
     oracle.orc_hashtable_destroy(t)
 
 
+def test_lbvh_morton_matches_reference_golden(oracle):
+    """box centre -> unit cube -> 30-bit morton code (Bvh.hpp:177-188) vs the reference's own AABBBox / morton_code<3>
+    (tests/golden/lbvh.npz from oracle/_ref), incl. the coord == 1 case where (u32)(1 * 1024) spills past 10 bits."""
+    g = np.load(os.path.join(GOLD, "lbvh.npz"))
+    oracle.orc_lbvh_morton.restype = C.c_uint32
+    whole, bvs = g["whole"], g["bvs"]
+    for b, code in zip(bvs, g["codes"]):
+        assert oracle.orc_lbvh_morton(ptr(whole), ptr(b)) == code
+    wb = np.zeros(6, np.float32)
+    oracle.orc_lbvh_whole_box(ptr(np.ascontiguousarray(bvs[2:])), C.c_size_t(bvs.shape[0] - 2), ptr(wb))
+    assert np.array_equal(wb, whole)
+
+
+@pytest.mark.parametrize("n,dup", [(1, 0), (2, 0), (3, 0), (4, 0), (37, 0), (1000, 0), (3000, 1)])
+def test_lbvh_oracle_structure_and_traversal(oracle, n, dup):
+    """restated LBvh::build: pre-order layout invariants (Bvh.hpp:288-338) and iter_neighbors == brute force."""
+    from util import lbvh_boxes, oracle_lbvh
+    bv = lbvh_boxes(n, 60 + n, dup)
+    b, arrs = oracle_lbvh(oracle, bv)
+    nn = 2 * n - 1 if n > 2 else n
+    assert arrs["numNodes"] == nn
+    if n > 2:
+        par, lev, aux, leaf, bvs = arrs["parents"], arrs["levels"], arrs["auxIndices"], arrs["leafInds"], arrs["bvs"]
+        assert par[0] == -1 and sorted(aux[leaf].tolist()) == list(range(n))          # every primitive is exactly one leaf
+        assert (lev[leaf] == 0).all() and (lev > 0).sum() == n - 1
+        trunk = np.nonzero(lev > 0)[0]
+        assert (par[trunk + 1] == trunk).all() and (lev[trunk + 1] == lev[trunk] - 1).all()  # left child follows its parent
+        rc = np.where(lev[trunk + 1] > 0, aux[trunk + 1], trunk + 2)
+        assert (par[rc] == trunk).all()
+        # node boxes contain their children
+        assert (bvs[trunk, :3] <= np.minimum(bvs[trunk + 1, :3], bvs[rc, :3])).all()
+        assert (bvs[trunk, 3:] >= np.maximum(bvs[trunk + 1, 3:], bvs[rc, 3:])).all()
+        assert np.array_equal(bvs[leaf], bv[aux[leaf]])
+    out = np.zeros(n, np.int32)
+    oracle.orc_lbvh_iter_neighbors.restype = C.c_size_t
+    for q in range(min(n, 150)):
+        k = oracle.orc_lbvh_iter_neighbors(b, ptr(bv[q]), ptr(out), C.c_size_t(n))
+        ref = np.nonzero(((bv[:, :3] <= bv[q, 3:]) & (bv[:, 3:] >= bv[q, :3])).all(1))[0]
+        assert np.array_equal(np.sort(out[:k]), ref)
+    oracle.orc_lbvh_destroy(b)
+
+
 def test_mpm_oracle_conservation(oracle):
     """size-independent properties of the restated P2G/G2P: mass & momentum conservation, affine velocity field
     reproduced exactly by P2G -> grid update -> G2P (APIC/MLS-MPM property)."""

@@ -114,3 +114,32 @@ class OracleMpm:
                 self.o.orc_bht_destroy(self.table)
         except Exception:
             pass
+
+
+def lbvh_boxes(n, seed, dup=False):
+    """n AABBs [n][6] = {min xyz, max xyz}: jittered centres in the unit cube, extents 0.5-3 % (dup: centres snapped to a
+    coarse lattice so that many morton codes coincide)."""
+    g = rng(seed)
+    c = g.uniform(0, 1, (n, 3)).astype(np.float32)
+    if dup:
+        c = (np.round(c * 6) / 6).astype(np.float32)
+    e = g.uniform(0.005, 0.03, (n, 3)).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([c - e, c + e], axis=1).astype(np.float32))
+
+
+def oracle_lbvh(oracle, bv, refit=1):
+    import ctypes as C
+    n = bv.shape[0]
+    oracle.orc_lbvh_create.restype = C.c_void_p
+    oracle.orc_lbvh_num_nodes.restype = C.c_size_t
+    for f in ("parents", "levels", "leaf_inds", "aux_indices"):
+        getattr(oracle, "orc_lbvh_" + f).restype = C.POINTER(C.c_int32)
+    oracle.orc_lbvh_bvs.restype = C.POINTER(C.c_float)
+    b = C.c_void_p(oracle.orc_lbvh_create())
+    oracle.orc_lbvh_build(b, bv.ctypes.data_as(C.c_void_p), C.c_size_t(n), refit)
+    nn = oracle.orc_lbvh_num_nodes(b)
+    A = lambda p, shape: np.ctypeslib.as_array(p, shape=shape).copy()
+    arrs = {"numNodes": nn, "parents": A(oracle.orc_lbvh_parents(b), (nn,)), "levels": A(oracle.orc_lbvh_levels(b), (nn,)),
+            "auxIndices": A(oracle.orc_lbvh_aux_indices(b), (nn,)), "leafInds": A(oracle.orc_lbvh_leaf_inds(b), (n,)),
+            "bvs": A(oracle.orc_lbvh_bvs(b), (nn, 6))}
+    return b, arrs

@@ -85,6 +85,18 @@ def main():
     ref.ref_hashtable_do_hash.restype = C.c_int
     hh = np.array([[ref.ref_hashtable_do_hash(P(k), d) for d in (1, 2, 3, 4)] for k in hk], np.int32)
     np.savez_compressed(os.path.join(OUT, "hashtable.npz"), keys=hk, do_hash=hh)
+    # ---- LBvh morton chain (container/Bvh.hpp:177-188 over AABBBox::getBoxCenter / getUniformCoord / morton_code<3>) + overlaps
+    g3 = np.random.default_rng(20250929)
+    c = g3.uniform(-2, 3, (400, 3)).astype(np.float32)
+    e = g3.uniform(0.001, 0.2, (400, 3)).astype(np.float32)
+    bvs = np.concatenate([c - e, c + e], axis=1).astype(np.float32)
+    whole = np.concatenate([bvs[:, :3].min(0) - np.float32(10 * 1.1920929e-07), bvs[:, 3:].max(0) + np.float32(10 * 1.1920929e-07)]).astype(np.float32)
+    bvs[0, :3] = whole[:3]; bvs[0, 3:] = whole[:3]      # centre on the low corner -> coord 0
+    bvs[1, :3] = whole[3:]; bvs[1, 3:] = whole[3:]      # centre on the high corner -> coord 1 (the 1024 overflow case)
+    ref.ref_lbvh_morton.restype = C.c_uint
+    codes = np.array([ref.ref_lbvh_morton(P(whole), P(b)) for b in bvs], np.uint32)
+    ov = np.array([[ref.ref_aabb_overlaps(P(bvs[i]), P(bvs[j])) for j in range(40)] for i in range(40)], np.int32)
+    np.savez_compressed(os.path.join(OUT, "lbvh.npz"), whole=whole, bvs=bvs, codes=codes, overlaps40=ov)
     print("wrote", os.listdir(OUT))
 
 
