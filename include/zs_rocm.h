@@ -316,6 +316,34 @@ ZS_ROCM_EXPORT void zs_rocm_hashtable_entry(zs_rocm_policy *, const zs_rocm_hash
 ZS_ROCM_EXPORT void zs_rocm_hashtable_resize(zs_rocm_policy *, zs_rocm_hashtable *, size_t numExpectedEntries);
 ZS_ROCM_EXPORT void zs_rocm_hashtable_preserve(zs_rocm_policy *, zs_rocm_hashtable *, size_t numExpectedEntries);
 
+/* ======================================================================== (B) LBvh */
+/* zs::LBvh<3, int, f32> (container/Bvh.hpp:86-492): linear BVH over AABBs, Karras (2012) topology on sorted 30-bit morton
+ * codes, stored in depth-first pre-order with escape indices for stack-less traversal.  Boxes are AABBBox<3, f32> =
+ * [n][6] floats {min xyz, max xyz} in device memory.  The reference exposes it only as a C++ template
+ * (`bvh.build(pol, primBvs)`, `pol(range(n), [bvh = proxy<space>(bvh)](i){ bvh.iter_neighbors(bv, f); })`). */
+typedef struct zs_rocm_lbvh zs_rocm_lbvh;
+typedef struct {
+  float *orderedBvs; /* [numNodes][6] */
+  int *parents, *levels, *leafInds, *auxIndices;
+  int numNodes, numLeaves;
+} zs_rocm_lbvh_view; /* LBvhView members, Bvh.hpp:790-792 */
+ZS_ROCM_EXPORT zs_rocm_lbvh *zs_rocm_lbvh_create(void);
+ZS_ROCM_EXPORT void zs_rocm_lbvh_destroy(zs_rocm_lbvh *);
+ZS_ROCM_EXPORT size_t zs_rocm_lbvh_num_leaves(const zs_rocm_lbvh *); /* getNumLeaves, :125 */
+ZS_ROCM_EXPORT size_t zs_rocm_lbvh_num_nodes(const zs_rocm_lbvh *);  /* getNumNodes, :126-129: 2n-1, or n when n <= 2 */
+ZS_ROCM_EXPORT void zs_rocm_lbvh_get_view(const zs_rocm_lbvh *, zs_rocm_lbvh_view *out);
+/* LBvh::build(pol, primBvs, wrapv<Refit>) (:810-1082); n == 0 is a no-op, n <= 2 stores the boxes themselves */
+ZS_ROCM_EXPORT void zs_rocm_lbvh_build(zs_rocm_policy *, zs_rocm_lbvh *, const float *primBvs, size_t n, int refit);
+/* LBvh::refit (:1219-1248); returns -1 (the reference throws) when n differs from the built leaf count */
+ZS_ROCM_EXPORT int zs_rocm_lbvh_refit(zs_rocm_policy *, zs_rocm_lbvh *, const float *primBvs, size_t n);
+/* LBvh::getTotalBox (:152-171) -> box6 (device pointer, 6 floats) */
+ZS_ROCM_EXPORT void zs_rocm_lbvh_total_box(zs_rocm_policy *, const zs_rocm_lbvh *, float *box6);
+/* bulk LBvhView::iter_neighbors (:644-680): counts[q] = number of primitives whose box overlaps queryBvs[q]; then, with
+ * offsets = exclusive_scan(counts), out[offsets[q] ...] = their ids in traversal order */
+ZS_ROCM_EXPORT void zs_rocm_lbvh_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, int *counts);
+ZS_ROCM_EXPORT void zs_rocm_lbvh_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, const int *offsets,
+                                            int *out);
+
 /* ======================================================================== (B) MPM transfers */
 /* A particle attribute stored in an AoS zs::Vector<vec<T,N>> (geometry/Structurefree.hpp:21-237) or in
  * a TileVector channel group: component d of particle i lives at

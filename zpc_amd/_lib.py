@@ -19,6 +19,12 @@ class HashTableView(C.Structure):
                 ("cnt", C.c_void_p), ("tableSize", C.c_int)]
 
 
+class LBvhView(C.Structure):
+    """zs_rocm_lbvh_view (LBvhView members, container/Bvh.hpp:790-792)."""
+    _fields_ = [("orderedBvs", C.c_void_p), ("parents", C.c_void_p), ("levels", C.c_void_p), ("leafInds", C.c_void_p),
+                ("auxIndices", C.c_void_p), ("numNodes", C.c_int), ("numLeaves", C.c_int)]
+
+
 class BhtViewLite(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
                 ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_size_t),
@@ -179,6 +185,18 @@ def _declare_containers(L):
     L.zs_rocm_hashtable_preserve.argtypes = [vp, vp, sz]
     L.zs_rocm_mpm_partition_for_particles.argtypes = [vp, vp, Port, sz, f32, i32]
     L.zs_rocm_mpm_enlarge_sparsity__hashtable.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.zs_rocm_lbvh_create.restype = vp
+    L.zs_rocm_lbvh_destroy.argtypes = [vp]
+    L.zs_rocm_lbvh_num_leaves.argtypes = [vp]
+    L.zs_rocm_lbvh_num_leaves.restype = sz
+    L.zs_rocm_lbvh_num_nodes.argtypes = [vp]
+    L.zs_rocm_lbvh_num_nodes.restype = sz
+    L.zs_rocm_lbvh_get_view.argtypes = [vp, C.POINTER(LBvhView)]
+    L.zs_rocm_lbvh_build.argtypes = [vp, vp, vp, sz, i32]
+    L.zs_rocm_lbvh_refit.argtypes = [vp, vp, vp, sz]
+    L.zs_rocm_lbvh_total_box.argtypes = [vp, vp, vp]
+    L.zs_rocm_lbvh_query_count.argtypes = [vp, vp, vp, sz, vp]
+    L.zs_rocm_lbvh_query_fill.argtypes = [vp, vp, vp, sz, vp, vp]
     PP = C.POINTER(MpmParams)
     L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32, i32]
     L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]

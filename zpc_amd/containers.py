@@ -248,3 +248,56 @@ class HashTable:
 
     def preserve(self, pol, n):
         lib().zs_rocm_hashtable_preserve(pol.handle, self._h, n)
+
+
+class LBvh:
+    """zs::LBvh<3, int, f32> (container/Bvh.hpp:86-1248): build / refit over [n][6] float boxes {min xyz, max xyz} held in a
+    device tensor; bulk iter_neighbors as a count pass + exclusive scan + fill pass."""
+
+    def __init__(self):
+        self._h = lib().zs_rocm_lbvh_create()
+
+    def __del__(self):
+        try:
+            lib().zs_rocm_lbvh_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def build(self, pol, bvs, refit=True):
+        n = bvs.numel() // 6
+        lib().zs_rocm_lbvh_build(pol.handle, self._h, bvs.data_ptr(), n, int(refit))
+
+    def refit(self, pol, bvs):
+        if lib().zs_rocm_lbvh_refit(pol.handle, self._h, bvs.data_ptr(), bvs.numel() // 6) != 0:
+            raise RuntimeError("bvh topology changes, require rebuild!")  # Bvh.hpp:1230-1231
+
+    def numLeaves(self):
+        return lib().zs_rocm_lbvh_num_leaves(self._h)
+
+    def numNodes(self):
+        return lib().zs_rocm_lbvh_num_nodes(self._h)
+
+    def view(self):
+        from ._lib import LBvhView
+        v = LBvhView()
+        lib().zs_rocm_lbvh_get_view(self._h, C.byref(v))
+        return v
+
+    def query(self, pol, queries):
+        """(offsets[nq+1], ids): ids[offsets[q]:offsets[q+1]] = primitives overlapping queries[q], traversal order."""
+        import torch
+        from .primitives import exclusive_scan
+        nq = queries.numel() // 6
+        counts = torch.zeros(nq + 1, dtype=torch.int32, device=queries.device)
+        lib().zs_rocm_lbvh_query_count(pol.handle, self._h, queries.data_ptr(), nq, counts.data_ptr())
+        offsets = torch.empty_like(counts)
+        exclusive_scan(pol, counts, offsets)
+        pol.syncCtx()
+        total = int(offsets[nq].item())
+        out = torch.empty(max(total, 1), dtype=torch.int32, device=queries.device)
+        lib().zs_rocm_lbvh_query_fill(pol.handle, self._h, queries.data_ptr(), nq, offsets.data_ptr(), out.data_ptr())
+        return offsets, out[:total]

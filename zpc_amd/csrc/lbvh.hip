@@ -1,0 +1,364 @@
+// lbvh.hip -- zs::LBvh<3, int, f32>::build / refit (container/Bvh.hpp:810-1248) and bulk overlap queries for gfx950.
+//
+// Pipeline of build (reference functor in brackets):
+//   whole box      two-level min/max reduction of the boxes padded by 10 eps (the reference issues 6 float atomics per box,
+//                  compute_bounding_box Bvh.hpp:11-23,39-84)
+//   morton codes   box centre -> unit cube -> 30-bit code  [_build_init_mc_id :177-188]
+//   sort           radix_sort_pair<u32 code, i32 id> (onesweep, primitives.hip)
+//   topology       one lane per trunk node: Karras' range search + split over the sorted codes  [_build_build_topo :200-287]
+//   layout         exclusive_scan of leaf depths -> pre-order node numbers, levels, escape indices
+//                  [_build_supp_topo :288-303, _build_reorder_leaf :304-319, _build_reorder_trunk :320-338]
+//   refit          bottom-up with one arrival flag per trunk node  [_refit_bottom_up :469-492]
+// Every array of the result is a deterministic function of the input (stable sort, integer topology, min/max boxes), so the
+// tests compare bit for bit with the CPU oracle.  Built with -ffp-contract=off: the centre/unit-cube arithmetic must round
+// exactly like the reference's scalar code for the morton codes to agree.
+#include <cfloat>
+
+#include "common.hpp"
+#include "../../include/zensim_rocm/lbvh_device.hpp"
+
+namespace zsr {
+
+void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
+void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit, int ebit);
+
+}  // namespace zsr
+
+struct zs_rocm_lbvh {
+  size_t numLeaves = 0, numNodes = 0, capLeaves = 0;
+  zsr::AABB3 *orderedBvs = nullptr;
+  int *parents = nullptr, *levels = nullptr, *leafInds = nullptr, *auxIndices = nullptr;
+  zsr::LBvhDev dev() const {
+    zsr::LBvhDev d;
+    d.orderedBvs = orderedBvs; d.parents = parents; d.levels = levels; d.leafInds = leafInds; d.auxIndices = auxIndices;
+    d.numNodes = (int)numNodes;
+    return d;
+  }
+};
+
+namespace zsr {
+
+__device__ __forceinline__ unsigned expand_bits_32(unsigned v) {  // math/bit/Bits.h:84-90
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+__device__ __forceinline__ unsigned count_lz(unsigned x) { return x ? (unsigned)__clz((int)x) : 32u; }
+
+constexpr int BOX_BLOCK = 256;
+// per-block min/max of the padded boxes -> partial[block][6]; `final`: fold the partials into out[6]
+__global__ __launch_bounds__(BOX_BLOCK) void lbvh_box_reduce_kernel(const AABB3 *bvs, size_t n, float *partial, int pad) {
+  __shared__ float sm[BOX_BLOCK / 64][6];
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const float eps = pad ? 10 * FLT_EPSILON : 0.f;
+  for (size_t i = (size_t)blockIdx.x * BOX_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BOX_BLOCK) {
+    const AABB3 b = bvs[i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], b.lo[d] - eps);
+      hi[d] = fmaxf(hi[d], b.hi[d] + eps);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], shfl_down(lo[d], o));
+      hi[d] = fmaxf(hi[d], shfl_down(hi[d], o));
+    }
+  if (lane_id() == 0)
+    for (int d = 0; d < 3; ++d) { sm[wave_id()][d] = lo[d]; sm[wave_id()][3 + d] = hi[d]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float r = sm[0][threadIdx.x];
+    for (int w = 1; w < BOX_BLOCK / 64; ++w) r = threadIdx.x < 3 ? fminf(r, sm[w][threadIdx.x]) : fmaxf(r, sm[w][threadIdx.x]);
+    partial[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+  }
+}
+__global__ void lbvh_box_final_kernel(const float *partial, int nblocks, float *out) {
+  const int c = threadIdx.x;
+  if (c >= 6) return;
+  float r = partial[c];
+  for (int b = 1; b < nblocks; ++b) r = c < 3 ? fminf(r, partial[(size_t)b * 6 + c]) : fmaxf(r, partial[(size_t)b * 6 + c]);
+  out[c] = r;
+}
+// _build_init_mc_id + _build_init_depths
+__global__ __launch_bounds__(256) void lbvh_morton_kernel(const AABB3 *bvs, int n, const float *whole, unsigned *mcs, int *indices,
+                                                          unsigned *lDepths) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    lDepths[n] = 0;
+    return;
+  }
+  lDepths[i] = 1;
+  const AABB3 b = bvs[i];
+  unsigned code = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float c = (b.lo[d] + b.hi[d]) / 2;            // getBoxCenter
+    const float len = whole[3 + d] - whole[d];           // getUniformCoord (BoundingVolumeInterface.hpp:24-31)
+    float o = c - whole[d];
+    o = o < 0.f ? 0.f : (o > len ? len : o);
+    const float u = __fdiv_rn(o, len);
+    code |= expand_bits_32((unsigned)(u * 1024.f)) << (2 - d);  // morton_3d_32, Bits.h:122-125
+  }
+  mcs[i] = code;
+  indices[i] = i;
+}
+// _build_build_topo (Bvh.hpp:200-287), one lane per trunk node
+__global__ __launch_bounds__(256) void lbvh_topo_kernel(const unsigned *mcs, int numTrunk, int *tPars, int *tLs, int *tRs, int *lPars,
+                                                        unsigned *lDepths) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= numTrunk) return;
+  const int numLeaves = numTrunk + 1;
+  int i = 0, j = 0;
+  if (idx == 0) {
+    j = numLeaves - 1;
+  } else {
+    const int left = idx;
+    int right = idx;
+    const unsigned pre = mcs[idx - 1], cur = mcs[idx], nxt = mcs[idx + 1];
+    if (pre == cur && cur == nxt) {
+      for (++right; right < numLeaves - 1; ++right)
+        if (mcs[right] != mcs[right + 1]) break;
+      j = right;
+      i = left;
+    } else {
+      const unsigned lLZ = count_lz(pre ^ cur), rLZ = count_lz(nxt ^ cur);
+      const int dir = lLZ > rLZ ? -1 : 1;
+      const unsigned minLZ = lLZ > rLZ ? rLZ : lLZ;
+      int step;
+      for (step = 2;; step <<= 1) {
+        right = left + step * dir;
+        if (!(right < numLeaves && right >= 0 && count_lz(mcs[right] ^ cur) > minLZ)) break;
+      }
+      int len = 0;
+      for (step >>= 1; step >= 1; step >>= 1) {
+        right = left + (len + step) * dir;
+        if (right < numLeaves && right >= 0)
+          if (count_lz(mcs[right] ^ cur) > minLZ) len += step;
+      }
+      if (dir == 1) { i = left; j = left + len; } else { i = left - len; j = left; }
+    }
+  }
+  atomicAdd(&lDepths[i], 1u);
+  tLs[idx] = i;
+  tRs[idx] = j;
+  int gamma;
+  const unsigned lCode = mcs[i], rCode = mcs[j];
+  if (lCode == rCode)
+    gamma = i;
+  else {
+    const unsigned LZ = count_lz(lCode ^ rCode);
+    int len = 0;
+    for (int step = (j - i + 1) >> 1;; step = (step + 1) >> 1) {
+      if (i + len + step <= numTrunk)
+        if (count_lz(mcs[i + len + step] ^ lCode) > LZ) len += step;
+      if (step <= 1) break;
+    }
+    gamma = i + len;
+  }
+  // children: trunk children are named by their index, leaf children by index + numTrunk (only the parent links are kept:
+  // the pre-order layout makes the child arrays of the reference redundant)
+  if (i == gamma) lPars[gamma] = idx; else tPars[gamma] = idx;
+  if (j == gamma + 1) lPars[gamma + 1] = idx; else tPars[gamma + 1] = idx;
+  if (idx == 0) tPars[0] = -1;
+}
+// _build_supp_topo (Bvh.hpp:288-303)
+__global__ __launch_bounds__(256) void lbvh_supp_topo_kernel(int numLeaves, int *levels, const unsigned *lOffsets, const int *lPars,
+                                                             int *lLcas, const int *tPars, int *tDst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= numLeaves) return;
+  const int numTrunk = numLeaves - 1;
+  int depth = (int)(lOffsets[idx + 1] - lOffsets[idx]);
+  int dst = (int)lOffsets[idx + 1] - 2;
+  int node = lPars[idx], ch = idx + numTrunk, level = 0;
+  for (; --depth; node = tPars[node], --dst) {
+    tDst[node] = dst;
+    levels[dst] = ++level;
+    ch = node;
+  }
+  lLcas[idx] = ch;
+}
+// _build_reorder_leaf (Bvh.hpp:304-319)
+__global__ __launch_bounds__(256) void lbvh_reorder_leaf_kernel(int numLeaves, const unsigned *lOffsets, const int *lPars, int *auxIndices,
+                                                                int *parents, int *levels, const int *pInds, int *lInds, const int *tDst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= numLeaves) return;
+  const int dst = (int)lOffsets[idx + 1] - 1;
+  auxIndices[dst] = pInds[idx];
+  parents[dst] = tDst[lPars[idx]];
+  levels[dst] = 0;
+  lInds[idx] = dst;
+}
+// _build_reorder_trunk (Bvh.hpp:320-338)
+__global__ __launch_bounds__(256) void lbvh_reorder_trunk_kernel(int numTrunk, const int *lLcas, const unsigned *lOffsets, int *auxIndices,
+                                                                 int *parents, const int *tRs, const int *tPars, const int *tDst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= numTrunk) return;
+  const int dst = tDst[idx], r = tRs[idx];
+  if (r != numTrunk) {
+    const int lca = lLcas[r + 1];
+    auxIndices[dst] = lca < numTrunk ? tDst[lca] : (int)lOffsets[r + 1];
+  } else
+    auxIndices[dst] = -1;
+  parents[dst] = idx != 0 ? tDst[tPars[idx]] : -1;
+}
+// _refit_bottom_up (Bvh.hpp:469-492): the second lane to arrive at a trunk node merges its children and climbs
+__global__ __launch_bounds__(256) void lbvh_refit_kernel(int numLeaves, const AABB3 *primBvs, AABB3 *orderedBvs, const int *auxIndices,
+                                                         const int *leafInds, const int *parents, const int *levels, int *flags) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= numLeaves) return;
+  int node = leafInds[idx];
+  orderedBvs[node] = primBvs[auxIndices[node]];
+  node = parents[node];
+  while (node != -1) {
+    __threadfence();  // this lane's child box is visible device-wide before it signs in
+    if (atomicCAS(&flags[node], 0, 1) == 0) break;
+    __threadfence();  // the sibling signed in earlier: its box (written before its fence) is visible now
+    const int lc = node + 1;
+    const int rc = levels[lc] ? auxIndices[lc] : lc + 1;
+    const volatile AABB3 *L = orderedBvs + lc, *R = orderedBvs + rc;
+    AABB3 bv;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      bv.lo[d] = fminf(L->lo[d], R->lo[d]);
+      bv.hi[d] = fmaxf(L->hi[d], R->hi[d]);
+    }
+    orderedBvs[node] = bv;
+    node = parents[node];
+  }
+}
+__global__ __launch_bounds__(256) void lbvh_small_kernel(int n, const AABB3 *primBvs, AABB3 *orderedBvs, int *leafInds, int *auxIndices,
+                                                         int *parents, int *levels) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  orderedBvs[i] = primBvs[i];
+  if (leafInds) { leafInds[i] = i; auxIndices[i] = i; parents[i] = 0; levels[i] = 0; }
+}
+// bulk iter_neighbors: count pass / fill pass
+template <bool FILL>
+__global__ __launch_bounds__(256) void lbvh_query_kernel(LBvhDev bvh, const AABB3 *queries, size_t nq, int *counts, const int *offsets,
+                                                         int *out) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const AABB3 bv = queries[q];
+  int c = 0;
+  int *dst = FILL ? out + offsets[q] : nullptr;
+  bvh.iter_neighbors(bv, [&](int id) {
+    if constexpr (FILL) dst[c] = id;
+    ++c;
+  });
+  if (!FILL) counts[q] = c;
+}
+
+static void lbvh_reserve(zs_rocm_lbvh &b, size_t n) {
+  if (n <= b.capLeaves) return;
+  (void)hipFree(b.orderedBvs); (void)hipFree(b.parents); (void)hipFree(b.levels); (void)hipFree(b.leafInds); (void)hipFree(b.auxIndices);
+  const size_t nodes = n > 2 ? 2 * n - 1 : n;
+  ZSR_CHECK(hipMalloc((void **)&b.orderedBvs, nodes * sizeof(AABB3)));
+  ZSR_CHECK(hipMalloc((void **)&b.parents, nodes * sizeof(int)));
+  ZSR_CHECK(hipMalloc((void **)&b.levels, nodes * sizeof(int)));
+  ZSR_CHECK(hipMalloc((void **)&b.auxIndices, nodes * sizeof(int)));
+  ZSR_CHECK(hipMalloc((void **)&b.leafInds, n * sizeof(int)));
+  b.capLeaves = n;
+}
+static void lbvh_refit_impl(Launch &L, zs_rocm_lbvh &b, const AABB3 *primBvs) {
+  const int n = (int)b.numLeaves;
+  if (n == 0) return;
+  if (n <= 2) {
+    hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(64), 0, L.stream, n, primBvs, b.orderedBvs, (int *)nullptr, (int *)nullptr,
+                       (int *)nullptr, (int *)nullptr);
+    return;
+  }
+  int *flags = (int *)L.temp(sizeof(int) * b.numNodes);
+  ZSR_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * b.numNodes, L.stream));
+  hipLaunchKernelGGL(lbvh_refit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, primBvs, b.orderedBvs, b.auxIndices, b.leafInds,
+                     b.parents, b.levels, flags);
+}
+
+}  // namespace zsr
+
+using namespace zsr;
+
+extern "C" {
+
+zs_rocm_lbvh *zs_rocm_lbvh_create(void) { return new zs_rocm_lbvh; }
+void zs_rocm_lbvh_destroy(zs_rocm_lbvh *b) {
+  if (!b) return;
+  (void)hipFree(b->orderedBvs); (void)hipFree(b->parents); (void)hipFree(b->levels); (void)hipFree(b->leafInds); (void)hipFree(b->auxIndices);
+  delete b;
+}
+size_t zs_rocm_lbvh_num_leaves(const zs_rocm_lbvh *b) { return b->numLeaves; }
+size_t zs_rocm_lbvh_num_nodes(const zs_rocm_lbvh *b) { return b->numNodes; }
+void zs_rocm_lbvh_get_view(const zs_rocm_lbvh *b, zs_rocm_lbvh_view *v) {
+  v->orderedBvs = (float *)b->orderedBvs; v->parents = b->parents; v->levels = b->levels; v->leafInds = b->leafInds;
+  v->auxIndices = b->auxIndices; v->numNodes = (int)b->numNodes; v->numLeaves = (int)b->numLeaves;
+}
+
+void zs_rocm_lbvh_build(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primBvsF, size_t n, int refit) {
+  if (n == 0) return;  // Bvh.hpp:821
+  Launch L(pol, "lbvh_build");
+  const AABB3 *primBvs = (const AABB3 *)primBvsF;
+  lbvh_reserve(*b, n);
+  b->numLeaves = n;
+  b->numNodes = n > 2 ? 2 * n - 1 : n;
+  if (n <= 2) {  // :823-831
+    hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(64), 0, L.stream, (int)n, primBvs, b->orderedBvs, b->leafInds, b->auxIndices,
+                       b->parents, b->levels);
+    return;
+  }
+  const int numLeaves = (int)n, numTrunk = numLeaves - 1;
+  const int rb = (int)std::min<size_t>(ceil_div(n, BOX_BLOCK * 4), 1024);
+  float *partial = (float *)L.temp(sizeof(float) * 6 * rb), *whole = (float *)L.temp(sizeof(float) * 8);
+  unsigned *mcs = (unsigned *)L.temp(sizeof(unsigned) * n), *sortedMcs = (unsigned *)L.temp(sizeof(unsigned) * n);
+  int *indices = (int *)L.temp(sizeof(int) * n), *pInds = (int *)L.temp(sizeof(int) * n);
+  unsigned *lDepths = (unsigned *)L.temp(sizeof(unsigned) * (n + 1)), *lOffsets = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
+  int *tPars = (int *)L.temp(sizeof(int) * n), *tLs = (int *)L.temp(sizeof(int) * n), *tRs = (int *)L.temp(sizeof(int) * n);
+  int *tDst = (int *)L.temp(sizeof(int) * n), *lPars = (int *)L.temp(sizeof(int) * n), *lLcas = (int *)L.temp(sizeof(int) * n);
+  hipLaunchKernelGGL(lbvh_box_reduce_kernel, dim3(rb), dim3(BOX_BLOCK), 0, L.stream, primBvs, n, partial, 1);
+  hipLaunchKernelGGL(lbvh_box_final_kernel, dim3(1), dim3(64), 0, L.stream, partial, rb, whole);
+  hipLaunchKernelGGL(lbvh_morton_kernel, dim3(ceil_div(n + 1, 256)), dim3(256), 0, L.stream, primBvs, numLeaves, whole, mcs, indices, lDepths);
+  radix_sort_pair_u32(L, mcs, indices, sortedMcs, pInds, n, 0, 32);
+  hipLaunchKernelGGL(lbvh_topo_kernel, dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, sortedMcs, numTrunk, tPars, tLs, tRs, lPars, lDepths);
+  exclusive_scan_u32(L, lDepths, n + 1, lOffsets);
+  hipLaunchKernelGGL(lbvh_supp_topo_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, numLeaves, b->levels, lOffsets, lPars, lLcas, tPars, tDst);
+  hipLaunchKernelGGL(lbvh_reorder_leaf_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, numLeaves, lOffsets, lPars, b->auxIndices,
+                     b->parents, b->levels, pInds, b->leafInds, tDst);
+  hipLaunchKernelGGL(lbvh_reorder_trunk_kernel, dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, numTrunk, lLcas, lOffsets, b->auxIndices,
+                     b->parents, tRs, tPars, tDst);
+  if (refit) lbvh_refit_impl(L, *b, primBvs);
+}
+int zs_rocm_lbvh_refit(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primBvs, size_t n) {
+  if (n != b->numLeaves) return -1;  // "bvh topology changes, require rebuild!" (Bvh.hpp:1230-1231)
+  Launch L(pol, "lbvh_refit");
+  lbvh_refit_impl(L, *b, (const AABB3 *)primBvs);
+  return 0;
+}
+void zs_rocm_lbvh_total_box(zs_rocm_policy *pol, const zs_rocm_lbvh *b, float *box6Dev) {
+  Launch L(pol, "lbvh_total_box");
+  if (b->numLeaves == 0) return;
+  if (b->numLeaves > 2) {  // root box (getTotalBox, Bvh.hpp:152-171)
+    ZSR_CHECK(hipMemcpyAsync(box6Dev, b->orderedBvs, sizeof(AABB3), hipMemcpyDeviceToDevice, L.stream));
+    return;
+  }
+  float *partial = (float *)L.temp(sizeof(float) * 6);
+  hipLaunchKernelGGL(lbvh_box_reduce_kernel, dim3(1), dim3(BOX_BLOCK), 0, L.stream, b->orderedBvs, b->numLeaves, partial, 0);
+  hipLaunchKernelGGL(lbvh_box_final_kernel, dim3(1), dim3(64), 0, L.stream, partial, 1, box6Dev);
+}
+void zs_rocm_lbvh_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq, int *counts) {
+  Launch L(pol, "lbvh_query_count");
+  if (!nq) return;
+  hipLaunchKernelGGL((lbvh_query_kernel<false>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, b->dev(), (const AABB3 *)queryBvs, nq, counts,
+                     (const int *)nullptr, (int *)nullptr);
+}
+void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq, const int *offsets, int *out) {
+  Launch L(pol, "lbvh_query_fill");
+  if (!nq) return;
+  hipLaunchKernelGGL((lbvh_query_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, b->dev(), (const AABB3 *)queryBvs, nq,
+                     (int *)nullptr, offsets, out);
+}
+
+}  // extern "C"
