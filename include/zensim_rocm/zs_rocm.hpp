@@ -30,6 +30,7 @@
 #include "bht_device.hpp"
 #include "merge_sort.hpp"
 #include "hashtable_device.hpp"
+#include "lbvh_device.hpp"
 
 #define ZS_LAMBDA __device__
 #define ZS_FUNCTION __forceinline__ __host__ __device__
@@ -506,6 +507,33 @@ template <int Side = 8> struct SparseGrid {
   float _background = 0.f;
 };
 
+// zs::LBvh<3, int, f32> (container/Bvh.hpp:86-1248) over a zs::Vector<AABBBox<3, f32>> of primitive boxes
+using AABBBox3f = zsr::AABB3;  // {lo[3], hi[3]} == AABBBox<3, f32> {_min, _max}
+using LBvhView = zsr::LBvhDev; // iter_neighbors(bv, f) / self_iter_neighbors(leaf, f) / find_nearest(p, f, cap) inside kernels
+struct LBvh {
+  LBvh() : _h(zs_rocm_lbvh_create()) {}
+  ~LBvh() { zs_rocm_lbvh_destroy(_h); }
+  LBvh(const LBvh &) = delete;
+  template <class Pol> void build(const Pol &pol, const Vector<AABBBox3f> &primBvs, bool refit = true) {  // :810-1082
+    zs_rocm_lbvh_build(pol.handle(), _h, (const float *)primBvs.data(), primBvs.size(), refit);
+  }
+  template <class Pol> void refit(const Pol &pol, const Vector<AABBBox3f> &primBvs) {  // :1219-1248
+    if (zs_rocm_lbvh_refit(pol.handle(), _h, (const float *)primBvs.data(), primBvs.size()) != 0)
+      throw std::runtime_error("bvh topology changes, require rebuild!");
+  }
+  std::size_t getNumLeaves() const { return zs_rocm_lbvh_num_leaves(_h); }
+  std::size_t getNumNodes() const { return zs_rocm_lbvh_num_nodes(_h); }
+  LBvhView view() const {
+    zs_rocm_lbvh_view v;
+    zs_rocm_lbvh_get_view(_h, &v);
+    LBvhView r;
+    r.orderedBvs = (const zsr::AABB3 *)v.orderedBvs; r.parents = v.parents; r.levels = v.levels; r.leafInds = v.leafInds;
+    r.auxIndices = v.auxIndices; r.numNodes = v.numNodes;
+    return r;
+  }
+  zs_rocm_lbvh *_h;
+};
+
 // view<space>(container) / proxy<space>(container)  (container/Vector.hpp:455-615, TileVector.hpp:693-1540, Bht.hpp:403)
 template <execspace_e space, class T> VectorView<T> view(Vector<T> &v) {
   static_assert(space == execspace_e::rocm, "this header provides the rocm space only");
@@ -516,6 +544,7 @@ template <execspace_e space, class T, int L> TileVectorView<T, L> view(std::init
 template <execspace_e space, int dim, int B> BHTView<dim> view(bht<dim, B> &t) { return t.view(); }
 template <execspace_e space, int dim> HashTableView<dim> view(HashTable<dim> &t) { return t.view(); }
 template <execspace_e space, int Side> SparseGridView<Side> view(SparseGrid<Side> &g) { return g.view(); }
+template <execspace_e space> LBvhView view(const LBvh &b) { return b.view(); }
 template <execspace_e space, class C> auto proxy(C &c) { return view<space>(c); }
 template <execspace_e space, class T, int L> auto proxy(std::initializer_list<const char *> l, TileVector<T, L> &v) { return view<space>(l, v); }
 

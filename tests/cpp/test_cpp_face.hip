@@ -268,6 +268,44 @@ int main() {
     for (int i = 0; i < np; ++i) worst = std::max(worst, err.data()[i]);
     CHECK(worst < 2e-5f);  // trilinear interpolation reproduces linear fields
   }
+  // ---- LBvh: build, iter_neighbors / self_iter_neighbors inside lambdas (Bvh.hpp:644-728) vs brute force
+  {
+    const int n = 6000;
+    std::vector<AABBBox3f> hb(n);
+    unsigned s = 4242u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (float)(1u << 24); };
+    for (auto &b : hb) {
+      const float c[3] = {rnd(), rnd(), rnd()}, e = 0.004f + 0.02f * rnd();
+      for (int d = 0; d < 3; ++d) { b.lo[d] = c[d] - e; b.hi[d] = c[d] + e; }
+    }
+    Vector<AABBBox3f> bvs(n, memsrc_e::device);
+    hipMemcpy(bvs.data(), hb.data(), sizeof(AABBBox3f) * n, hipMemcpyHostToDevice);
+    LBvh bvh;
+    bvh.build(pol, bvs);
+    CHECK(bvh.getNumLeaves() == (std::size_t)n && bvh.getNumNodes() == (std::size_t)(2 * n - 1));
+    Vector<int> cnt(n, memsrc_e::um), selfcnt(1, memsrc_e::um);
+    selfcnt.reset(0);
+    pol(range(n), [bv = view<space>(bvh), q = view<space>(bvs), c = view<space>(cnt), sc = view<space>(selfcnt)] ZS_LAMBDA(long long i) {
+      int k = 0;
+      bv.iter_neighbors(q[i], [&](int) { ++k; });
+      c[i] = k;
+      int pairs = 0;
+      bv.self_iter_neighbors((int)i, [&](int) { ++pairs; });
+      atomic_add(exec_rocm, &sc[0], pairs);
+    });
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += cnt.data()[i];
+    long long brute = 0;
+    for (int i = 0; i < n; i += 40) {  // spot-check rows exactly
+      int k = 0;
+      for (int j = 0; j < n; ++j) k += zsr::aabb_overlaps(hb[j], hb[i]);
+      CHECK(k == cnt.data()[i]);
+    }
+    for (int i = 0; i < n; ++i)
+      for (int j = i; j < n; ++j) brute += zsr::aabb_overlaps(hb[j], hb[i]);
+    CHECK(2 * brute - n == total);                 // ordered pairs = 2 * unordered (incl. self) - self
+    CHECK(selfcnt.data()[0] == (int)brute);        // self iteration reports every unordered pair (and self) once
+  }
   CHECK(zs_rocm_last_error(-1) == 0);
   std::printf("cpp face ok\n");
   return 0;

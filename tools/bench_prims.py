@@ -83,6 +83,26 @@ def main():
         distinct = tab.size()
         add("bht<int,3,int,16> build, %s (%d distinct)" % (name, distinct), n, 12 + 32.0 * distinct / n, ms)
         del tab
+    del pos
+    # config 5: 10 M triangle AABBs of a jittered surface mesh in [0,1)^3 (extent ~ 2 cells of a 3163^2 sheet), LBvh<3,int,f32>
+    from zpc_amd.containers import LBvh
+    n = 10_000_000
+    side = 3163
+    uv = torch.rand(n, 2, device="cuda", generator=g)
+    ctr = torch.stack([uv[:, 0], uv[:, 1], 0.5 + 0.2 * torch.sin(6.28 * uv[:, 0]) * torch.cos(6.28 * uv[:, 1])], dim=1)
+    ext = (1.0 / side) * (0.5 + torch.rand(n, 3, device="cuda", generator=g))
+    bvs = torch.cat([ctr - ext, ctr + ext], dim=1).contiguous()
+    bvh = LBvh()
+    # traffic floor per primitive: boxes read by reduce + morton + leaf refit (72) + code/id written (8) + pair sort (64)
+    # + node arrays written: (2n-1)/n * (24 box + 12 ints) + 4 leafInds (~76) + trunk temporaries ~6 ints r/w (48)
+    add("LBvh build+refit, 10M AABBs", n, 268, timeit(lambda: bvh.build(pol, bvs), reps=3, warm=1))
+    add("LBvh refit, 10M AABBs", n, 24 + 2 * 24 + 3 * 4 * 2, timeit(lambda: bvh.refit(pol, bvs), reps=3, warm=1))
+    nq = 1_000_000
+    counts = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: zs.lib().zs_rocm_lbvh_query_count(pol.handle, bvh.handle, bvs.data_ptr(), nq, counts.data_ptr()), reps=3, warm=1)
+    hits = float(counts.double().mean().item())
+    add("LBvh iter_neighbors count, 1M queries (%.1f hits/query)" % hits, nq, 24 + 4, ms)
+    del bvh, bvs
     if "--json" in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 
