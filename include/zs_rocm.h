@@ -391,6 +391,27 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *, zs_rocm_bht_3
 /* keyStride: 1 for block-coordinate keys, side for block-origin keys */
 ZS_ROCM_EXPORT void zs_rocm_mpm_enlarge_sparsity(zs_rocm_policy *, zs_rocm_bht_3 *, const int lo[3], const int hi[3],
                                                  int keyStride);
+/* ======================================================================== (B) IndexBuckets */
+/* zs::IndexBuckets<3, i32, i32> (container/IndexBuckets.hpp:9-67) and `index_buckets_for_particles(pol, particles, dx,
+ * displacement)` (simulation/particle/Query.tpp:9-58): a HashTable<i32,3,int> of occupied cells (key = floor(x/dx +
+ * displacement), CleanSparsity + ComputeSparsity with blockLen 1, offset 0), counts[numBuckets+1] (SpatiallyCount,
+ * simulation/sparsity/SparsityOp.hpp:117-152), offsets = exclusive_scan(counts), indices[n] = particle ids grouped by
+ * bucket (SpatiallyDistribute, :154-196).  The reference fills a bucket in atomic race order; here ids are ascending
+ * inside a bucket (= the sequential policy's result), so the structure is reproducible. */
+typedef struct zs_rocm_index_buckets zs_rocm_index_buckets;
+typedef struct {
+  zs_rocm_hashtable *table; /* _table: bucket number = table.query(cell) */
+  int *indices;             /* [numEntries] */
+  int *offsets, *counts;    /* [numBuckets + 1] */
+  int numBuckets, numEntries;
+  float dx;
+} zs_rocm_index_buckets_view; /* IndexBucketsView members, IndexBuckets.hpp:112-114 */
+ZS_ROCM_EXPORT zs_rocm_index_buckets *zs_rocm_index_buckets_create(void);
+ZS_ROCM_EXPORT void zs_rocm_index_buckets_destroy(zs_rocm_index_buckets *);
+ZS_ROCM_EXPORT void zs_rocm_index_buckets_get_view(const zs_rocm_index_buckets *, zs_rocm_index_buckets_view *out);
+/* `expectedCells` sizes the hash table (0: the particle count, as the reference does: tableSize = next_2pow(n) * 16) */
+ZS_ROCM_EXPORT void zs_rocm_index_buckets_for_particles(zs_rocm_policy *, zs_rocm_index_buckets *, zs_rocm_attr pos, size_t n,
+                                                        float dx, float displacement, size_t expectedCells);
 /* The same two functors on a zs::HashTable<i32,3,int> partition (their in-tree form: `partition_for_particles`,
  * simulation/sparsity/SparsityCompute.tpp:5-24 = CleanSparsity + ComputeSparsity(dx, blocklen, table, x), offset -2,
  * displacement 0.5; EnlargeSparsity sparsity/SparsityOp.hpp:89-115).  `zs_rocm_assign__bht_int_3_int_16(pol, bht,

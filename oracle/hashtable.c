@@ -6,6 +6,7 @@
 #include "zpc_oracle.h"
 
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -171,3 +172,36 @@ void orc_hashtable_preserve(orc_hashtable *t, size_t nExpected) {
   int32_t keep = numEntries < (int32_t)nExpected ? numEntries : (int32_t)nExpected;
   for (int32_t i = 0; i < keep; ++i) orc_hashtable_insert_id(t, t->activeKeys + (size_t)i * (size_t)t->dim, i);
 }
+
+/* index_buckets_for_particles, simulation/particle/Query.tpp:9-58 under the sequential policy: cells = floor(x/dx +
+   displacement) (ComputeSparsity with blockLen 1, offset 0), counts (SpatiallyCount), offsets = exclusive scan, indices
+   filled in particle order (SpatiallyDistribute) => ascending ids inside a bucket.  Arrays are malloc'ed; caller frees
+   with orc_index_buckets_free. */
+orc_hashtable *orc_index_buckets_for_particles(const float *pos, size_t n, float dx, float displacement, size_t expectedCells,
+                                               int32_t **countsOut, int32_t **offsetsOut, int32_t **indicesOut) {
+  orc_hashtable *t = orc_hashtable_create(3, expectedCells ? expectedCells : n);
+  const float dxinv = 1.0f / dx;
+  int32_t *cellOf = (int32_t *)malloc((n + 1) * 4);
+  for (size_t i = 0; i < n; ++i) {
+    int32_t c[3];
+    for (int d = 0; d < 3; ++d) c[d] = (int32_t)floorf(pos[3 * i + d] * dxinv + displacement);
+    orc_hashtable_insert(t, c);
+    cellOf[i] = 0;
+  }
+  size_t numCells = (size_t)t->cnt + 1;
+  int32_t *counts = (int32_t *)calloc(numCells, 4), *offsets = (int32_t *)calloc(numCells, 4), *fill = (int32_t *)calloc(numCells, 4);
+  int32_t *indices = (int32_t *)malloc((n + 1) * 4);
+  for (size_t i = 0; i < n; ++i) {
+    int32_t c[3];
+    for (int d = 0; d < 3; ++d) c[d] = (int32_t)floorf(pos[3 * i + d] * dxinv + displacement);
+    cellOf[i] = orc_hashtable_query(t, c);
+    counts[cellOf[i]]++;
+  }
+  int32_t run = 0;
+  for (size_t k = 0; k < numCells; ++k) { offsets[k] = run; run += counts[k]; }
+  for (size_t i = 0; i < n; ++i) indices[offsets[cellOf[i]] + fill[cellOf[i]]++] = (int32_t)i;
+  free(cellOf); free(fill);
+  *countsOut = counts; *offsetsOut = offsets; *indicesOut = indices;
+  return t;
+}
+void orc_index_buckets_free(int32_t *counts, int32_t *offsets, int32_t *indices) { free(counts); free(offsets); free(indices); }

@@ -127,6 +127,10 @@ int32_t orc_hashtable_get_table_size(const orc_hashtable *);
 const int32_t *orc_hashtable_active_keys(const orc_hashtable *);
 void orc_hashtable_resize(orc_hashtable *, size_t nExpected);      /* :281-292 */
 void orc_hashtable_preserve(orc_hashtable *, size_t nExpected);    /* :258-279 */
+/* zs::IndexBuckets<3,i32,i32> via index_buckets_for_particles (simulation/particle/Query.tpp:9-58), sequential policy */
+orc_hashtable *orc_index_buckets_for_particles(const float *pos, size_t n, float dx, float displacement, size_t expectedCells,
+                                               int32_t **counts, int32_t **offsets, int32_t **indices);
+void orc_index_buckets_free(int32_t *counts, int32_t *offsets, int32_t *indices);
 
 /* ---------------------------------------------------------------- LBvh (lbvh.c) */
 /* zs::LBvh<3, int, f32>, container/Bvh.hpp:86-492 (structure), :810-1082 (build), :1219-1248 (refit), :644-680 (traversal).

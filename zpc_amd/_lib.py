@@ -25,6 +25,12 @@ class LBvhView(C.Structure):
                 ("auxIndices", C.c_void_p), ("numNodes", C.c_int), ("numLeaves", C.c_int)]
 
 
+class IndexBucketsView(C.Structure):
+    """zs_rocm_index_buckets_view (IndexBucketsView members, container/IndexBuckets.hpp:112-114)."""
+    _fields_ = [("table", C.c_void_p), ("indices", C.c_void_p), ("offsets", C.c_void_p), ("counts", C.c_void_p),
+                ("numBuckets", C.c_int), ("numEntries", C.c_int), ("dx", C.c_float)]
+
+
 class BhtViewLite(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
                 ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_size_t),
@@ -197,6 +203,10 @@ def _declare_containers(L):
     L.zs_rocm_lbvh_total_box.argtypes = [vp, vp, vp]
     L.zs_rocm_lbvh_query_count.argtypes = [vp, vp, vp, sz, vp]
     L.zs_rocm_lbvh_query_fill.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.zs_rocm_index_buckets_create.restype = vp
+    L.zs_rocm_index_buckets_destroy.argtypes = [vp]
+    L.zs_rocm_index_buckets_get_view.argtypes = [vp, C.POINTER(IndexBucketsView)]
+    L.zs_rocm_index_buckets_for_particles.argtypes = [vp, vp, Port, sz, f32, f32, sz]
     PP = C.POINTER(MpmParams)
     L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32, i32]
     L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]

@@ -301,3 +301,26 @@ class LBvh:
         out = torch.empty(max(total, 1), dtype=torch.int32, device=queries.device)
         lib().zs_rocm_lbvh_query_fill(pol.handle, self._h, queries.data_ptr(), nq, offsets.data_ptr(), out.data_ptr())
         return offsets, out[:total]
+
+
+class IndexBuckets:
+    """zs::IndexBuckets<3, i32, i32> (container/IndexBuckets.hpp) built by index_buckets_for_particles
+    (simulation/particle/Query.tpp:9-58)."""
+
+    def __init__(self):
+        self._h = lib().zs_rocm_index_buckets_create()
+
+    def __del__(self):
+        try:
+            lib().zs_rocm_index_buckets_destroy(self._h)
+        except Exception:
+            pass
+
+    def build(self, pol, pos_port, n, dx, displacement=0.5, expected_cells=0):
+        lib().zs_rocm_index_buckets_for_particles(pol.handle, self._h, pos_port, n, dx, displacement, expected_cells)
+
+    def view(self):
+        from ._lib import IndexBucketsView
+        v = IndexBucketsView()
+        lib().zs_rocm_index_buckets_get_view(self._h, C.byref(v))
+        return v

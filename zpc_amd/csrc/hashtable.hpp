@@ -16,3 +16,11 @@ struct zs_rocm_hashtable {
     return d;
   }
 };
+
+// zs::IndexBuckets<3, i32, i32> (container/IndexBuckets.hpp:9-67)
+struct zs_rocm_index_buckets {
+  zs_rocm_hashtable *table = nullptr;
+  int *indices = nullptr, *offsets = nullptr, *counts = nullptr;
+  int numBuckets = 0, numEntries = 0;
+  float dx = 1.f;
+};

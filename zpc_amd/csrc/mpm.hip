@@ -32,6 +32,7 @@
 namespace zsr {
 
 void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
+void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit, int ebit);
 
 // ======================================================================================= small math
 __device__ __forceinline__ float rsq(float x) { return __frsqrt_rn(x); }
@@ -462,6 +463,37 @@ __global__ __launch_bounds__(256) void enlarge_sparsity_ht_kernel(HtDev t, int n
   int k[3] = {t.activeKeys[3 * (size_t)i] + lo0 + o / (e1 * e2), t.activeKeys[3 * (size_t)i + 1] + lo1 + (o / e2) % e1,
               t.activeKeys[3 * (size_t)i + 2] + lo2 + o % e2};
   ht_insert<3>(t, k);
+}
+// index_buckets_for_particles (simulation/particle/Query.tpp:9-58): ComputeSparsity with blockLen 1 / offset 0, then
+// SpatiallyCount (sparsity/SparsityOp.hpp:117-152)
+__global__ __launch_bounds__(256) void ib_cells_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int b[3] = {0, 0, 0};
+  if (valid) {
+    float p[3];
+    load_attr<3>(pos, i, p);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b[d] = (int)floorf(p[d] * dxinv + displacement);
+  }
+  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
+  const bool pvalid = shfl_up((int)valid, 1) != 0;
+  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
+  if (valid && !dup) ht_insert<3>(t, b);
+}
+__global__ __launch_bounds__(256) void ib_count_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement, unsigned *counts,
+                                                       unsigned *cellOf, int *ids) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[3];
+  load_attr<3>(pos, i, p);
+  int b[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) b[d] = (int)floorf(p[d] * dxinv + displacement);
+  const int c = ht_query<3>(t, b);
+  cellOf[i] = (unsigned)c;
+  ids[i] = (int)i;
+  atomicAdd(&counts[c], 1u);
 }
 __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr, int kscale) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1405,6 +1437,50 @@ void zs_rocm_mpm_partition_for_particles(zs_rocm_policy *pol, zs_rocm_hashtable 
   if (!n) return;
   hipLaunchKernelGGL(compute_sparsity_ht_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->dev(), make_port<float>(pos), n,
                      1.0f / dx, blocklen);
+}
+zs_rocm_index_buckets *zs_rocm_index_buckets_create(void) { return new zs_rocm_index_buckets; }
+void zs_rocm_index_buckets_destroy(zs_rocm_index_buckets *ib) {
+  if (!ib) return;
+  if (ib->table) zs_rocm_hashtable_destroy(ib->table);
+  (void)hipFree(ib->indices); (void)hipFree(ib->offsets); (void)hipFree(ib->counts);
+  delete ib;
+}
+void zs_rocm_index_buckets_get_view(const zs_rocm_index_buckets *ib, zs_rocm_index_buckets_view *v) {
+  v->table = ib->table; v->indices = ib->indices; v->offsets = ib->offsets; v->counts = ib->counts;
+  v->numBuckets = ib->numBuckets; v->numEntries = ib->numEntries; v->dx = ib->dx;
+}
+void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buckets *ib, zs_rocm_attr pos, size_t n, float dx,
+                                         float displacement, size_t expectedCells) {
+  ib->dx = dx;
+  if (ib->table) zs_rocm_hashtable_destroy(ib->table);
+  ib->table = zs_rocm_hashtable_create(3, expectedCells ? expectedCells : n, 1, 0);  // Query.tpp:27 (created reset)
+  (void)hipFree(ib->indices); (void)hipFree(ib->offsets); (void)hipFree(ib->counts);
+  ib->indices = ib->offsets = ib->counts = nullptr;
+  ib->numEntries = (int)n;
+  ib->numBuckets = 0;
+  if (!n) return;
+  Launch L(pol, "index_buckets_for_particles");
+  const float dxinv = 1.0f / dx;
+  hipLaunchKernelGGL(ib_cells_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, ib->table->dev(), make_port<float>(pos), n, dxinv,
+                     displacement);
+  int nc = 0;
+  ZSR_CHECK(hipMemcpyAsync(&nc, ib->table->cnt, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  ib->numBuckets = nc;
+  const size_t numCells = (size_t)nc + 1;  // Query.tpp:36
+  ZSR_CHECK(hipMalloc((void **)&ib->counts, numCells * sizeof(int)));
+  ZSR_CHECK(hipMalloc((void **)&ib->offsets, numCells * sizeof(int)));
+  ZSR_CHECK(hipMalloc((void **)&ib->indices, n * sizeof(int)));
+  ZSR_CHECK(hipMemsetAsync(ib->counts, 0, numCells * sizeof(int), L.stream));
+  unsigned *cellOf = (unsigned *)L.temp(sizeof(unsigned) * n), *cellSorted = (unsigned *)L.temp(sizeof(unsigned) * n);
+  int *ids = (int *)L.temp(sizeof(int) * n);
+  hipLaunchKernelGGL(ib_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, ib->table->dev(), make_port<float>(pos), n, dxinv,
+                     displacement, (unsigned *)ib->counts, cellOf, ids);
+  exclusive_scan_u32(L, (const unsigned *)ib->counts, numCells, (unsigned *)ib->offsets);
+  // SpatiallyDistribute as a stable sort of (bucket, particle id): ids ascend inside a bucket
+  int bits = 1;
+  while (bits < 32 && ((size_t)1 << bits) < numCells) ++bits;
+  radix_sort_pair_u32(L, cellOf, ids, cellSorted, ib->indices, n, 0, bits);
 }
 void zs_rocm_mpm_enlarge_sparsity__hashtable(zs_rocm_policy *pol, zs_rocm_hashtable *tab, const int lo[3], const int hi[3]) {
   if (tab->dim != 3) return;
