@@ -21,6 +21,7 @@
  */
 #ifndef ZS_ROCM_H
 #define ZS_ROCM_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -71,6 +72,18 @@ ZS_ROCM_EXPORT void zs_rocm_release_temporaries(void);
 /* py_interop/cuda/ExecutionPolicy.cpp:11-39: launch a module function (hipFunction_t) over `dim`
  * threads, block 128, grid ceil(dim/128), on the policy's stream, sync if shouldSync() */
 ZS_ROCM_EXPORT void launch__device(zs_rocm_policy *, void *kernel, size_t dim, void **args);
+
+/* ======================================================================== (A) runtime compilation */
+/* py_interop/cuda/Nvrtc.cpp:29-271 with hiprtc: cuda_compile_program / cuda_load_module / cuda_unload_module /
+ * cuda_get_kernel / cuda_launch_kernel -> rocm_*.  `arch` is the gfx number (950); 0 takes it from the current device.
+ * The output file is a code object; rocm_get_kernel returns the hipFunction_t that launch__device accepts.
+ * rocm_compile_program returns 0 on success (hiprtcResult otherwise, (size_t)-1 if hiprtc cannot be loaded). */
+ZS_ROCM_EXPORT size_t rocm_compile_program(const char *src, int arch, const char *include_dir, bool debug, bool verbose,
+                                           bool verify_fp, bool fast_math, const char *output_path);
+ZS_ROCM_EXPORT void *rocm_load_module(void *pol, const char *path);
+ZS_ROCM_EXPORT void rocm_unload_module(void *pol, void *module);
+ZS_ROCM_EXPORT void *rocm_get_kernel(void *pol, void *module, const char *name);
+ZS_ROCM_EXPORT size_t rocm_launch_kernel(void *context, void *kernel, size_t dim, void **args, void *stream);
 
 /* ======================================================================== (A) iterator ABI */
 /* py_interop/GenericIterator.hpp:11-16: element address =

@@ -106,3 +106,17 @@ def test_halo_exchange_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_hiprtc_compile_without_gpu(tmp_path):
+    """rocm_compile_program (py_interop/cuda/Nvrtc.cpp:29-146 over hiprtc) cross-compiles gfx950 with no device present;
+    a broken source reports a non-zero hiprtc result instead of writing a file."""
+    from zpc_amd import jit
+    out = str(tmp_path / "k.hsaco")
+    src = 'extern "C" __global__ void twice(float *x, unsigned long n) { unsigned long i = blockIdx.x * (unsigned long)blockDim.x + threadIdx.x; if (i < n) x[i] *= 2.f; }'
+    assert jit.compile_program(src, out, arch=950) == out
+    assert os.path.getsize(out) > 1000 and open(out, "rb").read(4) == b"\x7fELF"
+    bad = str(tmp_path / "bad.hsaco")
+    with pytest.raises(RuntimeError):
+        jit.compile_program("this is not HIP", bad, arch=950)
+    assert not os.path.exists(bad)

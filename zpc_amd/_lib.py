@@ -88,6 +88,15 @@ def _declare(L):
     L.zs_rocm_last_error.argtypes = [i32]
     L.zs_rocm_clear_error.argtypes = [i32]
     L.launch__device.argtypes = [vp, vp, sz, vp]
+    L.rocm_compile_program.argtypes = [C.c_char_p, i32, C.c_char_p, C.c_bool, C.c_bool, C.c_bool, C.c_bool, C.c_char_p]
+    L.rocm_compile_program.restype = sz
+    L.rocm_load_module.argtypes = [vp, C.c_char_p]
+    L.rocm_load_module.restype = vp
+    L.rocm_unload_module.argtypes = [vp, vp]
+    L.rocm_get_kernel.argtypes = [vp, vp, C.c_char_p]
+    L.rocm_get_kernel.restype = vp
+    L.rocm_launch_kernel.argtypes = [vp, vp, sz, vp, vp]
+    L.rocm_launch_kernel.restype = sz
     for T in ("int", "float", "double"):
         for op in ("reduce_sum", "reduce_prod", "reduce_min", "reduce_max", "exclusive_scan_sum",
                    "exclusive_scan_prod", "inclusive_scan_sum", "inclusive_scan_prod"):
