@@ -100,6 +100,14 @@ ZS_ROCM_DECL_PORT(float, aosoa_iterator_float_1)
 ZS_ROCM_DECL_PORT(const float, aosoa_iterator_const_float_1)
 ZS_ROCM_DECL_PORT(double, aosoa_iterator_double_1)
 ZS_ROCM_DECL_PORT(const double, aosoa_iterator_const_double_1)
+/* aosoa_iterator_port<T, 3>: same POD, dereferences to 3 components `tileMask + 1` elements apart (GenericIterator.hpp:96-104);
+ * the AoS form has numChns = 3 (element i at base + 3 i) */
+ZS_ROCM_DECL_PORT(int, aosoa_iterator_int_3)
+ZS_ROCM_DECL_PORT(const int, aosoa_iterator_const_int_3)
+ZS_ROCM_DECL_PORT(float, aosoa_iterator_float_3)
+ZS_ROCM_DECL_PORT(const float, aosoa_iterator_const_float_3)
+ZS_ROCM_DECL_PORT(double, aosoa_iterator_double_3)
+ZS_ROCM_DECL_PORT(const double, aosoa_iterator_const_double_3)
 
 /* ======================================================================== (A) parallel primitives */
 /* py_interop/cuda/ExecutionPolicy.cpp:41-131 (ZS_DEFINE_PARALLEL_PRIMITIVES for int, float, double).
@@ -163,74 +171,128 @@ ZS_ROCM_EXPORT void zs_rocm_merge_sort_f32(zs_rocm_policy *, float *keys, int32_
 ZS_ROCM_EXPORT void zs_rocm_merge_sort_f64(zs_rocm_policy *, double *keys, int32_t *vals, size_t n, int descending);
 
 /* ======================================================================== (A) allocators & Vector */
-/* py_interop/Allocator.cpp:5-21; memsrc_e: 0 = host, 1 = device, 2 = um (types/Property.h:7) */
+/* py_interop/Allocator.cpp:5-21; memsrc_e: 0 = host, 1 = device, 2 = um (types/Property.h:7).
+ * allocator_virtual = ZSPmrAllocator<true> over get_virtual_memory_source(mre, devid, reservedSpace, "STACK"): containers
+ * created with it reserve `reservedSpace` bytes of address space (hipMemAddressReserve) and map physical memory as they
+ * grow (hipMemCreate / hipMemMap), so their data pointer survives resize.  Every container entry point below also
+ * exists with the reference's `_virtual` suffix; both spellings accept the same handle types. */
 typedef struct zs_rocm_allocator zs_rocm_allocator;
 ZS_ROCM_EXPORT zs_rocm_allocator *allocator(int memsrc, int8_t devid);
+ZS_ROCM_EXPORT zs_rocm_allocator *allocator_virtual(int memsrc, int8_t devid, size_t reservedSpace);
 ZS_ROCM_EXPORT void del_allocator(zs_rocm_allocator *);
+ZS_ROCM_EXPORT void del_allocator_virtual(zs_rocm_allocator *);
 ZS_ROCM_EXPORT int mem_enum__host(void);
 ZS_ROCM_EXPORT int mem_enum__device(void);
 ZS_ROCM_EXPORT int mem_enum__um(void);
 
-/* py_interop/VectorInstantiations.cpp:8-80: zs::Vector<T> (container/Vector.hpp:11-421) */
-#define ZS_ROCM_DECL_VECTOR(T)                                                                    \
-  typedef struct zs_rocm_vector_##T zs_rocm_vector_##T;                                           \
-  ZS_ROCM_EXPORT zs_rocm_vector_##T *container__v_##T(zs_rocm_allocator *, size_t n);             \
-  ZS_ROCM_EXPORT void del_container__v_##T(zs_rocm_vector_##T *);                                 \
-  ZS_ROCM_EXPORT void relocate_container__v_##T(zs_rocm_vector_##T *, int memsrc, int8_t devid);  \
-  ZS_ROCM_EXPORT void resize_container__v_##T(zs_rocm_vector_##T *, size_t n);                    \
-  ZS_ROCM_EXPORT void reset_container__v_##T(zs_rocm_vector_##T *, int byteVal);                  \
-  ZS_ROCM_EXPORT size_t container_size__v_##T(const zs_rocm_vector_##T *);                        \
-  ZS_ROCM_EXPORT size_t container_capacity__v_##T(const zs_rocm_vector_##T *);                    \
-  ZS_ROCM_EXPORT T get_val_container__v_##T(zs_rocm_vector_##T *, size_t i);                      \
-  ZS_ROCM_EXPORT void set_val_container__v_##T(zs_rocm_vector_##T *, size_t i, T v);              \
+/* py_interop/VectorInstantiations.cpp:8-170: zs::Vector<T> (container/Vector.hpp:11-421) */
+typedef struct { void *_vector; } zs_rocm_vector_view_lite; /* VectorViewLite<T>, py_interop/VectorView.hpp:6-30 */
+#define ZS_ROCM_DECL_VECTOR(T, SFX)                                                                       \
+  ZS_ROCM_EXPORT zs_rocm_vector_##T *container__v_##T##SFX(zs_rocm_allocator *, size_t n);                \
+  ZS_ROCM_EXPORT void del_container__v_##T##SFX(zs_rocm_vector_##T *);                                    \
+  ZS_ROCM_EXPORT void relocate_container__v_##T##SFX(zs_rocm_vector_##T *, int memsrc, int8_t devid);     \
+  ZS_ROCM_EXPORT void resize_container__v_##T##SFX(zs_rocm_vector_##T *, size_t n);                       \
+  ZS_ROCM_EXPORT void reset_container__v_##T##SFX(zs_rocm_vector_##T *, int byteVal);                     \
+  ZS_ROCM_EXPORT size_t container_size__v_##T##SFX(const zs_rocm_vector_##T *);                           \
+  ZS_ROCM_EXPORT size_t container_capacity__v_##T##SFX(const zs_rocm_vector_##T *);                       \
+  ZS_ROCM_EXPORT T get_val_container__v_##T##SFX(zs_rocm_vector_##T *);            /* getVal()      */   \
+  ZS_ROCM_EXPORT void set_val_container__v_##T##SFX(zs_rocm_vector_##T *, T v);    /* setVal(v)     */   \
+  ZS_ROCM_EXPORT T get_val_i_container__v_##T##SFX(zs_rocm_vector_##T *, size_t i);                       \
+  ZS_ROCM_EXPORT void set_val_i_container__v_##T##SFX(zs_rocm_vector_##T *, size_t i, T v);              \
+  ZS_ROCM_EXPORT void copy_to_container__v_##T##SFX(zs_rocm_vector_##T *, void *hostSrc);   /* assignVals   */ \
+  ZS_ROCM_EXPORT void copy_from_container__v_##T##SFX(zs_rocm_vector_##T *, void *hostDst); /* retrieveVals */ \
+  ZS_ROCM_EXPORT T *get_handle_container__v_##T##SFX(zs_rocm_vector_##T *);                               \
+  ZS_ROCM_EXPORT zs_rocm_vector_view_lite *pyview__v_##T##SFX(zs_rocm_vector_##T *);                      \
+  ZS_ROCM_EXPORT zs_rocm_vector_view_lite *pyview__v_const_##T##SFX(const zs_rocm_vector_##T *);          \
+  ZS_ROCM_EXPORT aosoa_iterator_##T##_1 get_iterator_1__v_##T##SFX(zs_rocm_vector_##T *, uint32_t id);    \
+  ZS_ROCM_EXPORT aosoa_iterator_const_##T##_1 get_iterator_1__v_const_##T##SFX(const zs_rocm_vector_##T *, uint32_t id); \
+  ZS_ROCM_EXPORT aosoa_iterator_##T##_3 get_iterator_3__v_##T##SFX(zs_rocm_vector_##T *, uint32_t id);    \
+  ZS_ROCM_EXPORT aosoa_iterator_const_##T##_3 get_iterator_3__v_const_##T##SFX(const zs_rocm_vector_##T *, uint32_t id);
+#define ZS_ROCM_DECL_VECTOR_BOTH(T)                                                    \
+  typedef struct zs_rocm_vector_##T zs_rocm_vector_##T;                                \
+  ZS_ROCM_DECL_VECTOR(T, )                                                             \
+  ZS_ROCM_DECL_VECTOR(T, _virtual)                                                     \
+  ZS_ROCM_EXPORT void del_pyview__v_##T(zs_rocm_vector_view_lite *);                   \
+  ZS_ROCM_EXPORT void del_pyview__v_const_##T(zs_rocm_vector_view_lite *);             \
   ZS_ROCM_EXPORT T *container_data__v_##T(zs_rocm_vector_##T *);
-ZS_ROCM_DECL_VECTOR(int)
-ZS_ROCM_DECL_VECTOR(float)
-ZS_ROCM_DECL_VECTOR(double)
+ZS_ROCM_DECL_VECTOR_BOTH(int)
+ZS_ROCM_DECL_VECTOR_BOTH(float)
+ZS_ROCM_DECL_VECTOR_BOTH(double)
 
 /* ======================================================================== (A) TileVector */
-/* py_interop/TileVectorInstantiations.cpp:8-110: property tags + zs::TileVector<T, L>
+/* py_interop/TileVectorInstantiations.cpp:8-215: property tags + zs::TileVector<T, L>
  * (container/TileVector.hpp:14-561).  Storage: element (chn, i) at (i/L*C + chn)*L + i%L. */
 typedef struct zs_rocm_property_tags zs_rocm_property_tags;
 ZS_ROCM_EXPORT zs_rocm_property_tags *property_tags(const char *const *names, const int *sizes, size_t n);
 ZS_ROCM_EXPORT void del_property_tags(zs_rocm_property_tags *);
-#define ZS_ROCM_DECL_TILEVECTOR(T, L)                                                                      \
+ZS_ROCM_EXPORT void property_tags_get_item(zs_rocm_property_tags *, size_t index, const char **name, size_t *size);
+ZS_ROCM_EXPORT size_t property_tags_get_size(zs_rocm_property_tags *);
+typedef struct {
+  void *_vector;
+  int _numChannels;
+} zs_rocm_tv_view_lite; /* TileVectorViewLite<T, L>, py_interop/TileVectorView.hpp:9-131 */
+typedef struct {
+  void *_vector;
+  int _numChannels;
+  const char *_tagNames; /* [N] SmallString = char[32], in the container's memory space (TileVector.hpp:503-509) */
+  const int *_tagOffsets;
+  const int *_tagSizes;
+  int _N;
+} zs_rocm_tv_named_view_lite; /* TileVectorNamedViewLite<T, L>, py_interop/TileVectorView.hpp:133-287 */
+#define ZS_ROCM_DECL_TILEVECTOR(T, L, SFX)                                                                      \
+  ZS_ROCM_EXPORT zs_rocm_tv_##T##_##L *container__tv_##T##_##L##SFX(zs_rocm_allocator *,                        \
+                                                                   const zs_rocm_property_tags *, size_t n);   \
+  ZS_ROCM_EXPORT void del_container__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *);                                 \
+  ZS_ROCM_EXPORT void relocate_container__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *, int memsrc, int8_t devid);  \
+  ZS_ROCM_EXPORT void resize_container__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *, size_t n);                    \
+  ZS_ROCM_EXPORT void reset_container__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *, int byteVal);                  \
+  ZS_ROCM_EXPORT size_t container_size__tv_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *);                        \
+  ZS_ROCM_EXPORT size_t container_capacity__tv_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *);                    \
+  ZS_ROCM_EXPORT int property_offset__tv_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *, const char *name);        \
+  ZS_ROCM_EXPORT int property_size__tv_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *, const char *name);          \
+  ZS_ROCM_EXPORT aosoa_iterator_##T##_1 get_iterator_1__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *, uint32_t id,  \
+                                                                          uint32_t chnOffset);                 \
+  ZS_ROCM_EXPORT aosoa_iterator_const_##T##_1 get_iterator_1__tv_const_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *, \
+                                                                                      uint32_t id, uint32_t chnOffset); \
+  ZS_ROCM_EXPORT aosoa_iterator_##T##_3 get_iterator_3__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *, uint32_t id,  \
+                                                                          uint32_t chnOffset);                 \
+  ZS_ROCM_EXPORT aosoa_iterator_const_##T##_3 get_iterator_3__tv_const_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *, \
+                                                                                      uint32_t id, uint32_t chnOffset); \
+  ZS_ROCM_EXPORT zs_rocm_tv_view_lite *pyview__tv_##T##_##L##SFX(zs_rocm_tv_##T##_##L *);                       \
+  ZS_ROCM_EXPORT zs_rocm_tv_view_lite *pyview__tv_const_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *);           \
+  ZS_ROCM_EXPORT zs_rocm_tv_named_view_lite *pyview__tvn_##T##_##L##SFX(zs_rocm_tv_##T##_##L *);                \
+  ZS_ROCM_EXPORT zs_rocm_tv_named_view_lite *pyview__tvn_const_##T##_##L##SFX(const zs_rocm_tv_##T##_##L *);    \
+  /* py_interop/cuda/TileVectorUtility.cpp:7-30 -> append_channels (TileVector.hpp:583-623) */                 \
+  ZS_ROCM_EXPORT void append_properties__rocm_tv_##T##_##L##SFX(zs_rocm_policy *, zs_rocm_tv_##T##_##L *,       \
+                                                               const zs_rocm_property_tags *);
+#define ZS_ROCM_DECL_TILEVECTOR_BOTH(T, L)                                                                 \
   typedef struct zs_rocm_tv_##T##_##L zs_rocm_tv_##T##_##L;                                                \
-  ZS_ROCM_EXPORT zs_rocm_tv_##T##_##L *container__tv_##T##_##L(zs_rocm_allocator *,                        \
-                                                              const zs_rocm_property_tags *, size_t n);   \
-  ZS_ROCM_EXPORT void del_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *);                                 \
-  ZS_ROCM_EXPORT void relocate_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, int memsrc, int8_t devid);  \
-  ZS_ROCM_EXPORT void resize_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, size_t n);                    \
-  ZS_ROCM_EXPORT void reset_container__tv_##T##_##L(zs_rocm_tv_##T##_##L *, int byteVal);                  \
-  ZS_ROCM_EXPORT size_t container_size__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                        \
-  ZS_ROCM_EXPORT size_t container_capacity__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                    \
+  ZS_ROCM_DECL_TILEVECTOR(T, L, )                                                                          \
+  ZS_ROCM_DECL_TILEVECTOR(T, L, _virtual)                                                                  \
+  ZS_ROCM_EXPORT void del_pyview__tv_##T##_##L(zs_rocm_tv_view_lite *);                                    \
+  ZS_ROCM_EXPORT void del_pyview__tv_const_##T##_##L(zs_rocm_tv_view_lite *);                              \
+  ZS_ROCM_EXPORT void del_pyview__tvn_##T##_##L(zs_rocm_tv_named_view_lite *);                             \
+  ZS_ROCM_EXPORT void del_pyview__tvn_const_##T##_##L(zs_rocm_tv_named_view_lite *);                       \
   ZS_ROCM_EXPORT size_t container_num_channels__tv_##T##_##L(const zs_rocm_tv_##T##_##L *);                \
-  ZS_ROCM_EXPORT int property_offset__tv_##T##_##L(const zs_rocm_tv_##T##_##L *, const char *name);        \
-  ZS_ROCM_EXPORT int property_size__tv_##T##_##L(const zs_rocm_tv_##T##_##L *, const char *name);          \
   ZS_ROCM_EXPORT T *container_data__tv_##T##_##L(zs_rocm_tv_##T##_##L *);                                  \
-  ZS_ROCM_EXPORT aosoa_iterator_##T##_1 get_iterator_1__tv_##T##_##L(zs_rocm_tv_##T##_##L *, uint32_t id,  \
-                                                                     uint32_t chnOffset);                 \
-  /* py_interop/cuda/TileVectorUtility.cpp:7-30 -> append_channels (TileVector.hpp:583-623) */            \
-  ZS_ROCM_EXPORT void append_properties__rocm_tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *,       \
-                                                          const zs_rocm_property_tags *);                 \
   /* (B) TileVector::reset(pol, val) TileVector.hpp:624-640 */                                            \
   ZS_ROCM_EXPORT void zs_rocm_fill__tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *, T val);         \
   /* (B) TileVector::reorderTiles-style element reorder (TileVector.hpp:641-691): dst(:, i) = src(:, map[i]) \
      when gather != 0, dst(:, map[i]) = src(:, i) otherwise; all channels */                              \
   ZS_ROCM_EXPORT void zs_rocm_reorder__tv_##T##_##L(zs_rocm_policy *, zs_rocm_tv_##T##_##L *,              \
                                                    const int *map, int gather);
-ZS_ROCM_DECL_TILEVECTOR(int, 8)
-ZS_ROCM_DECL_TILEVECTOR(int, 32)
-ZS_ROCM_DECL_TILEVECTOR(int, 64)
-ZS_ROCM_DECL_TILEVECTOR(int, 512)
-ZS_ROCM_DECL_TILEVECTOR(float, 8)
-ZS_ROCM_DECL_TILEVECTOR(float, 32)
-ZS_ROCM_DECL_TILEVECTOR(float, 64)
-ZS_ROCM_DECL_TILEVECTOR(float, 512)
-ZS_ROCM_DECL_TILEVECTOR(double, 8)
-ZS_ROCM_DECL_TILEVECTOR(double, 32)
-ZS_ROCM_DECL_TILEVECTOR(double, 64)
-ZS_ROCM_DECL_TILEVECTOR(double, 512)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(int, 8)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(int, 32)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(int, 64)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(int, 512)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(float, 8)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(float, 32)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(float, 64)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(float, 512)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(double, 8)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(double, 32)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(double, 64)
+ZS_ROCM_DECL_TILEVECTOR_BOTH(double, 512)
 
 /* (B) raw AoSoA kernels on plain device pointers (what `pol(range(n), [tv = view<space>(tv)](i){...})`
  * load/store lambdas do, test/cuda/basic.cu:118-144).  tv has C channels of tile width L (power of 2). */
@@ -256,17 +318,22 @@ typedef struct {
   size_t tableSize;
   uint32_t hf0x, hf0y, hf1x, hf1y, hf2x, hf2y;
 } zs_rocm_bht_view_lite; /* py_interop/BhtView.hpp:96-111 (BhtViewLite) */
+#define ZS_ROCM_DECL_BHT_A(D, B, SFX)                                                                         \
+  ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_##B##SFX(zs_rocm_allocator *, size_t n);        \
+  ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *);                            \
+  ZS_ROCM_EXPORT void relocate_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *, int memsrc, int8_t devid); \
+  ZS_ROCM_EXPORT size_t container_size__bht_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *);                   \
+  ZS_ROCM_EXPORT size_t container_capacity__bht_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *);               \
+  ZS_ROCM_EXPORT void reset_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *, int clearCnt);            \
+  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *);                 \
+  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_const_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *);     \
+  /* py_interop/cuda/BhtUtility.cpp:7-26 -> bht::resize (Bht.hpp:320-340) */                                  \
+  ZS_ROCM_EXPORT void resize_container__rocm_bht_int_##D##_int_##B##SFX(zs_rocm_policy *, zs_rocm_bht_##D *,   \
+                                                                       size_t newCapacity);
 #define ZS_ROCM_DECL_BHT(D, B)                                                                           \
-  ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_##B(zs_rocm_allocator *, size_t n);        \
-  ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *);                            \
-  ZS_ROCM_EXPORT size_t container_size__bht_int_##D##_int_##B(const zs_rocm_bht_##D *);                   \
-  ZS_ROCM_EXPORT size_t container_capacity__bht_int_##D##_int_##B(const zs_rocm_bht_##D *);               \
-  ZS_ROCM_EXPORT void reset_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *, int clearCnt);            \
-  ZS_ROCM_EXPORT zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B(zs_rocm_bht_##D *);                 \
+  ZS_ROCM_DECL_BHT_A(D, B, )                                                                             \
+  ZS_ROCM_DECL_BHT_A(D, B, _virtual)                                                                     \
   ZS_ROCM_EXPORT void del_pyview__bht_int_##D##_int_##B(zs_rocm_bht_view_lite *);                         \
-  /* py_interop/cuda/BhtUtility.cpp:7-26 -> bht::resize (Bht.hpp:320-340) */                            \
-  ZS_ROCM_EXPORT void resize_container__rocm_bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,   \
-                                                                 size_t newCapacity);                   \
   /* (B) pol(range(n), [tb](i){ ret[i] = tb.insert(keys[i]); })  BHTView::insert, Bht.hpp:490-542 */     \
   ZS_ROCM_EXPORT void zs_rocm_insert__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *,          \
                                                           const int *keys, size_t n, int *ret);         \

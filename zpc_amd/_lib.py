@@ -31,6 +31,17 @@ class IndexBucketsView(C.Structure):
                 ("numBuckets", C.c_int), ("numEntries", C.c_int), ("dx", C.c_float)]
 
 
+class TvViewLite(C.Structure):
+    """TileVectorViewLite<T, L> (py_interop/TileVectorView.hpp:9-131)."""
+    _fields_ = [("_vector", C.c_void_p), ("_numChannels", C.c_int)]
+
+
+class TvNamedViewLite(C.Structure):
+    """TileVectorNamedViewLite<T, L> (py_interop/TileVectorView.hpp:133-287)."""
+    _fields_ = [("_vector", C.c_void_p), ("_numChannels", C.c_int), ("_tagNames", C.c_void_p), ("_tagOffsets", C.c_void_p),
+                ("_tagSizes", C.c_void_p), ("_N", C.c_int)]
+
+
 class BhtViewLite(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
                 ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_size_t),
@@ -122,50 +133,97 @@ def _declare_containers(L):
     L.property_tags.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), sz]
     L.property_tags.restype = vp
     L.del_property_tags.argtypes = [vp]
+    L.allocator_virtual.argtypes = [i32, i8, sz]
+    L.allocator_virtual.restype = vp
+    L.del_allocator_virtual.argtypes = [vp]
+    L.property_tags_get_item.argtypes = [vp, sz, C.POINTER(C.c_char_p), C.POINTER(sz)]
+    L.property_tags_get_size.argtypes = [vp]
+    L.property_tags_get_size.restype = sz
     for T, ct in (("int", C.c_int), ("float", C.c_float), ("double", C.c_double)):
-        g = lambda n: getattr(L, n % T)
-        g("container__v_%s").argtypes = [vp, sz]
-        g("container__v_%s").restype = vp
-        g("del_container__v_%s").argtypes = [vp]
-        g("relocate_container__v_%s").argtypes = [vp, i32, i8]
-        g("resize_container__v_%s").argtypes = [vp, sz]
-        g("reset_container__v_%s").argtypes = [vp, i32]
-        g("container_size__v_%s").argtypes = [vp]
-        g("container_size__v_%s").restype = sz
-        g("container_capacity__v_%s").argtypes = [vp]
-        g("container_capacity__v_%s").restype = sz
-        g("get_val_container__v_%s").argtypes = [vp, sz]
-        g("get_val_container__v_%s").restype = ct
-        g("set_val_container__v_%s").argtypes = [vp, sz, ct]
-        g("container_data__v_%s").argtypes = [vp]
-        g("container_data__v_%s").restype = vp
+        for sfx in ("", "_virtual"):  # ZSPmrAllocator<false> / <true> spellings of the same entry points
+            g = lambda n: getattr(L, (n % T) + sfx)
+            g("container__v_%s").argtypes = [vp, sz]
+            g("container__v_%s").restype = vp
+            g("del_container__v_%s").argtypes = [vp]
+            g("relocate_container__v_%s").argtypes = [vp, i32, i8]
+            g("resize_container__v_%s").argtypes = [vp, sz]
+            g("reset_container__v_%s").argtypes = [vp, i32]
+            g("container_size__v_%s").argtypes = [vp]
+            g("container_size__v_%s").restype = sz
+            g("container_capacity__v_%s").argtypes = [vp]
+            g("container_capacity__v_%s").restype = sz
+            g("get_val_container__v_%s").argtypes = [vp]
+            g("get_val_container__v_%s").restype = ct
+            g("set_val_container__v_%s").argtypes = [vp, ct]
+            g("get_val_i_container__v_%s").argtypes = [vp, sz]
+            g("get_val_i_container__v_%s").restype = ct
+            g("set_val_i_container__v_%s").argtypes = [vp, sz, ct]
+            g("copy_to_container__v_%s").argtypes = [vp, vp]
+            g("copy_from_container__v_%s").argtypes = [vp, vp]
+            g("get_handle_container__v_%s").argtypes = [vp]
+            g("get_handle_container__v_%s").restype = vp
+            g("pyview__v_%s").argtypes = [vp]
+            g("pyview__v_%s").restype = C.POINTER(C.c_void_p)
+            g("pyview__v_const_%s").argtypes = [vp]
+            g("pyview__v_const_%s").restype = C.POINTER(C.c_void_p)
+            for it in ("get_iterator_1__v_%s", "get_iterator_1__v_const_%s", "get_iterator_3__v_%s", "get_iterator_3__v_const_%s"):
+                g(it).argtypes = [vp, C.c_uint32]
+                g(it).restype = Port
+        getattr(L, "del_pyview__v_%s" % T).argtypes = [vp]
+        getattr(L, "del_pyview__v_const_%s" % T).argtypes = [vp]
+        getattr(L, "container_data__v_%s" % T).argtypes = [vp]
+        getattr(L, "container_data__v_%s" % T).restype = vp
         for Lw in (8, 32, 64, 512):
             s = "%s_%d" % (T, Lw)
-            h = lambda n: getattr(L, n % s)
-            h("container__tv_%s").argtypes = [vp, vp, sz]
-            h("container__tv_%s").restype = vp
-            h("del_container__tv_%s").argtypes = [vp]
-            h("relocate_container__tv_%s").argtypes = [vp, i32, i8]
-            h("resize_container__tv_%s").argtypes = [vp, sz]
-            h("reset_container__tv_%s").argtypes = [vp, i32]
-            for q in ("container_size__tv_%s", "container_capacity__tv_%s", "container_num_channels__tv_%s"):
-                h(q).argtypes = [vp]
-                h(q).restype = sz
-            h("property_offset__tv_%s").argtypes = [vp, C.c_char_p]
-            h("property_size__tv_%s").argtypes = [vp, C.c_char_p]
-            h("container_data__tv_%s").argtypes = [vp]
-            h("container_data__tv_%s").restype = vp
-            h("get_iterator_1__tv_%s").argtypes = [vp, C.c_uint32, C.c_uint32]
-            h("get_iterator_1__tv_%s").restype = Port
-            h("append_properties__rocm_tv_%s").argtypes = [vp, vp, vp]
-            h("zs_rocm_fill__tv_%s").argtypes = [vp, vp, ct]
-            h("zs_rocm_reorder__tv_%s").argtypes = [vp, vp, vp, i32]
+            for sfx in ("", "_virtual"):
+                h = lambda n: getattr(L, (n % s) + sfx)
+                h("container__tv_%s").argtypes = [vp, vp, sz]
+                h("container__tv_%s").restype = vp
+                h("del_container__tv_%s").argtypes = [vp]
+                h("relocate_container__tv_%s").argtypes = [vp, i32, i8]
+                h("resize_container__tv_%s").argtypes = [vp, sz]
+                h("reset_container__tv_%s").argtypes = [vp, i32]
+                for q in ("container_size__tv_%s", "container_capacity__tv_%s"):
+                    h(q).argtypes = [vp]
+                    h(q).restype = sz
+                h("property_offset__tv_%s").argtypes = [vp, C.c_char_p]
+                h("property_size__tv_%s").argtypes = [vp, C.c_char_p]
+                for it in ("get_iterator_1__tv_%s", "get_iterator_3__tv_%s"):
+                    h(it).argtypes = [vp, C.c_uint32, C.c_uint32]
+                    h(it).restype = Port
+                for it in ("get_iterator_1__tv_const_%s", "get_iterator_3__tv_const_%s"):
+                    h(it).argtypes = [vp, C.c_uint32, C.c_uint32]
+                    h(it).restype = Port
+                for pv, rt in (("pyview__tv_%s", TvViewLite), ("pyview__tv_const_%s", TvViewLite), ("pyview__tvn_%s", TvNamedViewLite),
+                               ("pyview__tvn_const_%s", TvNamedViewLite)):
+                    h(pv).argtypes = [vp]
+                    h(pv).restype = C.POINTER(rt)
+                h("append_properties__rocm_tv_%s").argtypes = [vp, vp, vp]
+            k = lambda n: getattr(L, n % s)
+            for dv in ("del_pyview__tv_%s", "del_pyview__tv_const_%s", "del_pyview__tvn_%s", "del_pyview__tvn_const_%s"):
+                k(dv).argtypes = [vp]
+            k("container_num_channels__tv_%s").argtypes = [vp]
+            k("container_num_channels__tv_%s").restype = sz
+            k("container_data__tv_%s").argtypes = [vp]
+            k("container_data__tv_%s").restype = vp
+            k("zs_rocm_fill__tv_%s").argtypes = [vp, vp, ct]
+            k("zs_rocm_reorder__tv_%s").argtypes = [vp, vp, vp, i32]
     L.zs_rocm_tv_from_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_to_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_scale_f32.argtypes = [vp, vp, sz, i32, i32, f32]
     L.zs_rocm_tv_gather_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
     for D, B in ((d, b) for d in (1, 2, 3, 4) for b in (16, 32)):
         s = "bht_int_%d_int_%d" % (D, B)
+        for sfx in ("", "_virtual"):
+            getattr(L, "relocate_container__" + s + sfx).argtypes = [vp, i32, i8]
+            getattr(L, "pyview__bht_const_int_%d_int_%d" % (D, B) + sfx).argtypes = [vp]
+            getattr(L, "pyview__bht_const_int_%d_int_%d" % (D, B) + sfx).restype = C.POINTER(BhtViewLite)
+            if sfx:
+                getattr(L, "container__" + s + sfx).argtypes = [vp, sz]
+                getattr(L, "container__" + s + sfx).restype = vp
+                getattr(L, "del_container__" + s + sfx).argtypes = [vp]
+                getattr(L, "container_size__" + s + sfx).argtypes = [vp]
+                getattr(L, "container_size__" + s + sfx).restype = sz
         getattr(L, "container__" + s).argtypes = [vp, sz]
         getattr(L, "container__" + s).restype = vp
         getattr(L, "del_container__" + s).argtypes = [vp]

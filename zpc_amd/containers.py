@@ -12,9 +12,10 @@ _ES = {"int": 4, "float": 4, "double": 8}
 class Allocator:
     """allocator(memsrc_e, ProcID) -- py_interop/Allocator.cpp:5-21"""
 
-    def __init__(self, memsrc=memsrc_device, devid=0):
+    def __init__(self, memsrc=memsrc_device, devid=0, virtual_reserve=0):
+        """virtual_reserve > 0: allocator_virtual(mre, devid, reservedSpace) -- containers keep their data pointer on resize."""
         self.memsrc, self.devid = memsrc, devid
-        self._h = lib().allocator(memsrc, devid)
+        self._h = lib().allocator_virtual(memsrc, devid, virtual_reserve) if virtual_reserve else lib().allocator(memsrc, devid)
 
     def __del__(self):
         try:
@@ -56,10 +57,23 @@ class Vector:
         self._f("relocate_container__v_%s")(self._h, memsrc, devid)
 
     def getVal(self, i=0):
-        return self._f("get_val_container__v_%s")(self._h, i)
+        """getVal(i): get_val_container__v_T(v) / get_val_i_container__v_T(v, i) (VectorInstantiations.cpp:70-92)."""
+        if i == 0:
+            return self._f("get_val_container__v_%s")(self._h)
+        return self._f("get_val_i_container__v_%s")(self._h, i)
 
     def setVal(self, v, i=0):
-        self._f("set_val_container__v_%s")(self._h, i, v)
+        if i == 0:
+            self._f("set_val_container__v_%s")(self._h, v)
+        else:
+            self._f("set_val_i_container__v_%s")(self._h, i, v)
+
+    def assignVals(self, host_array):
+        """copy_to_container__v_T(v, src): size() elements from host memory (Vector::assignVals)."""
+        self._f("copy_to_container__v_%s")(self._h, host_array.ctypes.data)
+
+    def retrieveVals(self, host_array):
+        self._f("copy_from_container__v_%s")(self._h, host_array.ctypes.data)
 
     def data(self):
         return self._f("container_data__v_%s")(self._h)

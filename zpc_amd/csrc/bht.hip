@@ -216,43 +216,76 @@ template <int DIM> static void bht_canonicalize(zs_rocm_policy *pol, BhtHost &t)
   bht_reorder_impl<DIM>(L, t, perm[cur], /*scatter=*/false, n);  // new key i = old key perm[i]
 }
 
+static zs_rocm_bht_view_lite *bht_make_view(const BhtHost &t) {  // py_interop/BhtInstantiations.cpp:62-110
+  auto *v = new zs_rocm_bht_view_lite;
+  v->keys = t.keys; v->indices = t.indices; v->status = t.status; v->activeKeys = t.activeKeys;
+  v->cnt = t.cnt; v->success = t.success; v->tableSize = t.tableSize;
+  v->hf0x = t.hf[0]; v->hf0y = t.hf[1]; v->hf1x = t.hf[2]; v->hf1y = t.hf[3];
+  v->hf2x = t.hf[4]; v->hf2y = t.hf[5];
+  return v;
+}
+// clone(mloc) + swap between device and unified memory (a host-resident table cannot serve a device policy)
+static void bht_relocate(BhtHost &t, int memsrc, int8_t devid) {
+  const int target = memsrc == 0 ? 1 : memsrc;
+  t.devid = devid;
+  if (target == t.memsrc) return;
+  BhtHost n = t;
+  n.memsrc = target;
+  const int ks = t.dim == 1 ? 1 : (t.dim == 2 ? 2 : 4);
+  const size_t ts = t.tableSize;
+  n.keys = (int *)bht_alloc(n, ts * ks * sizeof(int));
+  n.indices = (int *)bht_alloc(n, ts * sizeof(int));
+  n.status = (int *)bht_alloc(n, ts * sizeof(int));
+  n.activeKeys = (int *)bht_alloc(n, ts * t.dim * sizeof(int));
+  n.cnt = (int *)bht_alloc(n, sizeof(int));
+  n.success = (int *)bht_alloc(n, sizeof(int));
+  ZSR_CHECK(hipMemcpy(n.keys, t.keys, ts * ks * sizeof(int), hipMemcpyDefault));
+  ZSR_CHECK(hipMemcpy(n.indices, t.indices, ts * sizeof(int), hipMemcpyDefault));
+  ZSR_CHECK(hipMemcpy(n.status, t.status, ts * sizeof(int), hipMemcpyDefault));
+  ZSR_CHECK(hipMemcpy(n.activeKeys, t.activeKeys, ts * t.dim * sizeof(int), hipMemcpyDefault));
+  ZSR_CHECK(hipMemcpy(n.cnt, t.cnt, sizeof(int), hipMemcpyDefault));
+  ZSR_CHECK(hipMemcpy(n.success, t.success, sizeof(int), hipMemcpyDefault));
+  bht_destroy(t);
+  t = n;
+}
+
 }  // namespace zsr
 
 using namespace zsr;
 
 extern "C" {
 
-#define ZSR_DEFINE_BHT(D, B)                                                                                  \
-  zs_rocm_bht_##D *container__bht_int_##D##_int_##B(zs_rocm_allocator *a, size_t n) {                        \
+#define ZSR_DEFINE_BHT_A(D, B, SFX)                                                                         \
+  zs_rocm_bht_##D *container__bht_int_##D##_int_##B##SFX(zs_rocm_allocator *a, size_t n) {                   \
     auto *b = new zs_rocm_bht_##D;                                                                          \
-    bht_create(b->t, D, B, a ? a->memsrc : 1, a ? a->devid : 0, n);                                            \
+    bht_create(b->t, D, B, a ? a->memsrc : 1, a ? a->devid : 0, n);                                         \
     return b;                                                                                               \
   }                                                                                                         \
-  void del_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *b) {                                            \
+  void del_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *b) {                                       \
     bht_destroy(b->t);                                                                                      \
     delete b;                                                                                               \
   }                                                                                                         \
-  size_t container_size__bht_int_##D##_int_##B(const zs_rocm_bht_##D *b) { return (size_t)bht_size(b->t, nullptr); } \
-  size_t container_capacity__bht_int_##D##_int_##B(const zs_rocm_bht_##D *b) { return b->t.tableSize; }      \
-  void reset_container__bht_int_##D##_int_##B(zs_rocm_bht_##D *b, int clearCnt) { /* Bht.hpp:306-318 */      \
+  void relocate_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *b, int memsrc, int8_t devid) {        \
+    bht_relocate(b->t, memsrc, devid);                                                                      \
+  }                                                                                                         \
+  size_t container_size__bht_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *b) { return (size_t)bht_size(b->t, nullptr); } \
+  size_t container_capacity__bht_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *b) { return b->t.tableSize; } \
+  void reset_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *b, int clearCnt) { /* Bht.hpp:306-318 */ \
     bht_reset_table(b->t, nullptr);                                                                         \
     if (clearCnt) ZSR_CHECK(hipMemsetAsync(b->t.cnt, 0, sizeof(int), nullptr));                             \
     int one = 1;                                                                                            \
     ZSR_CHECK(hipMemcpy(b->t.success, &one, sizeof(int), hipMemcpyHostToDevice));                           \
     ZSR_CHECK(hipDeviceSynchronize());                                                                      \
   }                                                                                                         \
-  zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B(zs_rocm_bht_##D *b) {                                 \
-    auto *v = new zs_rocm_bht_view_lite;                                                                    \
-    v->keys = b->t.keys; v->indices = b->t.indices; v->status = b->t.status; v->activeKeys = b->t.activeKeys; \
-    v->cnt = b->t.cnt; v->success = b->t.success; v->tableSize = b->t.tableSize;                            \
-    v->hf0x = b->t.hf[0]; v->hf0y = b->t.hf[1]; v->hf1x = b->t.hf[2]; v->hf1y = b->t.hf[3];                 \
-    v->hf2x = b->t.hf[4]; v->hf2y = b->t.hf[5];                                                             \
-    return v;                                                                                               \
-  }                                                                                                         \
-  void del_pyview__bht_int_##D##_int_##B(zs_rocm_bht_view_lite *v) { delete v; }                             \
-  void resize_container__rocm_bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, size_t cap) {   \
+  zs_rocm_bht_view_lite *pyview__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *b) { return bht_make_view(b->t); } \
+  zs_rocm_bht_view_lite *pyview__bht_const_int_##D##_int_##B##SFX(const zs_rocm_bht_##D *b) { return bht_make_view(b->t); } \
+  void resize_container__rocm_bht_int_##D##_int_##B##SFX(zs_rocm_policy *pol, zs_rocm_bht_##D *b, size_t cap) { \
     bht_resize<D>(pol, b->t, cap);                                                                          \
-  }                                                                                                         \
+  }
+#define ZSR_DEFINE_BHT(D, B)                                                                                \
+  ZSR_DEFINE_BHT_A(D, B, )                                                                                  \
+  ZSR_DEFINE_BHT_A(D, B, _virtual)                                                                          \
+  void del_pyview__bht_int_##D##_int_##B(zs_rocm_bht_view_lite *v) { delete v; }                            \
   void zs_rocm_insert__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *keys,       \
                                             size_t n, int *ret) {                                           \
     bht_insert_many<D>(pol, b->t, keys, n, ret);                                                            \

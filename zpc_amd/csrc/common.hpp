@@ -56,6 +56,9 @@ void report_error(hipError_t e, const char *what, const char *file, int line);
 struct zs_rocm_allocator {
   int memsrc;    // memsrc_e: 0 host, 1 device, 2 um (types/Property.h:7)
   int8_t devid;  // ProcID, -1 = host
+  // > 0: ZSPmrAllocator<true> -- a "STACK" virtual memory source (get_virtual_memory_source, resource/Resource.h): the
+  // container reserves this much address space and maps physical memory as it grows; its data pointer never moves
+  size_t virtualReserve = 0;
 };
 
 // ------------------------------------------------------------------------------------ policy

@@ -47,16 +47,108 @@ static void mem_set(const zs_rocm_allocator &a, void *p, int ch, size_t bytes) {
   }
 }
 
+// HIP virtual memory management behind ZSPmrAllocator<true> (cuda/memory/Allocator.cpp:120-420 uses cuMemAddressReserve /
+// cuMemCreate / cuMemMap): reserve address space once, map granule-sized physical chunks at the end as the container grows.
+struct VmmRange {
+  char *base = nullptr;
+  size_t reserved = 0, mapped = 0, gran = 0;
+  int dev = 0;
+  std::vector<hipMemGenericAllocationHandle_t> chunks;
+  std::vector<size_t> chunkBytes;
+  bool reserve(size_t bytes, int device) {
+    dev = device;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
+    reserved = (bytes + gran - 1) / gran * gran;
+    if (hipMemAddressReserve((void **)&base, reserved, 0, nullptr, 0) != hipSuccess) {
+      base = nullptr;
+      return false;
+    }
+    return true;
+  }
+  bool grow(size_t bytes) {  // make [0, bytes) backed by physical memory
+    if (bytes <= mapped) return true;
+    size_t want = (bytes + gran - 1) / gran * gran;
+    if (want > reserved) return false;
+    const size_t add = want - mapped;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) return false;
+    if (hipMemMap(base + mapped, add, 0, h, 0) != hipSuccess) {
+      (void)hipMemRelease(h);
+      return false;
+    }
+    hipMemAccessDesc acc{};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base + mapped, add, &acc, 1) != hipSuccess) {
+      (void)hipMemUnmap(base + mapped, add);
+      (void)hipMemRelease(h);
+      return false;
+    }
+    chunks.push_back(h);
+    chunkBytes.push_back(add);
+    mapped = want;
+    return true;
+  }
+  void release() {
+    if (!base) return;
+    (void)hipDeviceSynchronize();
+    size_t off = 0;
+    for (size_t i = 0; i < chunks.size(); ++i) {
+      (void)hipMemUnmap(base + off, chunkBytes[i]);
+      (void)hipMemRelease(chunks[i]);
+      off += chunkBytes[i];
+    }
+    (void)hipMemAddressFree(base, reserved);
+    base = nullptr;
+    chunks.clear();
+    chunkBytes.clear();
+    mapped = reserved = 0;
+  }
+};
+
 // untyped zs::Vector (container/Vector.hpp:11-421)
 struct VecBuf {
   zs_rocm_allocator alloc{1, 0};
   char *data = nullptr;
   size_t size = 0, cap = 0, esize = 4;
+  VmmRange *vmm = nullptr;  // non-null: storage is a mapped prefix of a reserved address range
   VecBuf() = default;
   VecBuf(const zs_rocm_allocator &a, size_t n, size_t es) : alloc(a), size(n), cap(n), esize(es) {
+    if (a.virtualReserve && a.memsrc == 1) {
+      vmm = new VmmRange;
+      const int dev = a.devid >= 0 ? a.devid : current_device();
+      const size_t need = n * es;
+      if (vmm->reserve(a.virtualReserve > need ? a.virtualReserve : need, dev) && vmm->grow(need)) {
+        data = vmm->base;
+        cap = vmm->mapped / es;
+        return;
+      }
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "[zs_rocm] virtual memory source unavailable on this device/runtime: using a plain allocation\n");
+      warned = true;
+      vmm->release();
+      delete vmm;
+      vmm = nullptr;
+      (void)hipGetLastError();
+    }
     data = (char *)mem_alloc(a, n * es);
   }
-  ~VecBuf() { mem_free(alloc, data); }
+  ~VecBuf() {
+    if (vmm) {
+      vmm->release();
+      delete vmm;
+    } else
+      mem_free(alloc, data);
+  }
   VecBuf(const VecBuf &) = delete;
   VecBuf &operator=(const VecBuf &) = delete;
   void swap(VecBuf &o) {
@@ -65,6 +157,7 @@ struct VecBuf {
     std::swap(size, o.size);
     std::swap(cap, o.cap);
     std::swap(esize, o.esize);
+    std::swap(vmm, o.vmm);
   }
   size_t growth(size_t newSize) const {  // geometric_size_growth, Vector.hpp:407-416
     size_t g = cap + cap / 2;
@@ -76,6 +169,11 @@ struct VecBuf {
       return;
     }
     if (newSize > cap) {
+      if (vmm && vmm->grow(newSize * esize)) {  // virtual: map more pages behind the same pointer, nothing moves
+        cap = vmm->mapped / esize;
+        size = newSize;
+        return;
+      }
       size_t ncap = growth(newSize);
       if (size_t r = ncap % alignment) ncap += alignment - r;
       VecBuf tmp(alloc, ncap, esize);
@@ -87,7 +185,7 @@ struct VecBuf {
     size = newSize;
   }
   void relocate(int memsrc, int8_t devid) {  // clone(mloc) + swap
-    zs_rocm_allocator na{memsrc, devid};
+    zs_rocm_allocator na{memsrc, devid, alloc.virtualReserve};
     VecBuf tmp(na, cap, esize);
     tmp.size = size;
     if (size) mem_copy(na, tmp.data, alloc, data, size * esize);
@@ -112,6 +210,27 @@ struct TileVec {
   int numChannels = 0;
   size_t L = 32, size = 0;
   VecBuf buf;
+  // property tables mirrored in the container's memory space for in-kernel name lookup (TileVector.hpp:76-88,503-509):
+  // tagNames[i] is a 32-byte SmallString, then offsets and sizes
+  char *tagNames = nullptr;
+  int *tagOffsets = nullptr, *tagSizes = nullptr;
+  void mirror_tags() {
+    const size_t n = names.size();
+    zs_rocm_allocator h{0, -1};
+    std::vector<char> nb(32 * (n ? n : 1), 0);
+    for (size_t i = 0; i < n; ++i) std::strncpy(nb.data() + 32 * i, names[i].c_str(), 31);
+    mem_free(buf.alloc, tagNames); mem_free(buf.alloc, tagOffsets); mem_free(buf.alloc, tagSizes);
+    zs_rocm_allocator plain{buf.alloc.memsrc, buf.alloc.devid};
+    tagNames = (char *)mem_alloc(plain, nb.size());
+    tagOffsets = (int *)mem_alloc(plain, sizeof(int) * (n ? n : 1));
+    tagSizes = (int *)mem_alloc(plain, sizeof(int) * (n ? n : 1));
+    mem_copy(plain, tagNames, h, nb.data(), nb.size());
+    if (n) {
+      mem_copy(plain, tagOffsets, h, offsets.data(), sizeof(int) * n);
+      mem_copy(plain, tagSizes, h, sizes.data(), sizeof(int) * n);
+    }
+  }
+  ~TileVec() { mem_free(buf.alloc, tagNames); mem_free(buf.alloc, tagOffsets); mem_free(buf.alloc, tagSizes); }
   TileVec(const zs_rocm_allocator &a, const zs_rocm_property_tags &t, size_t n, size_t L_, size_t es)
       : names(t.names), sizes(t.sizes), L(L_), size(n) {
     for (int s : sizes) {  // running sums in declaration order (TileVector.hpp:79-85)
@@ -120,6 +239,7 @@ struct TileVec {
     }
     VecBuf b(a, tiles(n) * L * (size_t)numChannels, es);
     buf.swap(b);
+    mirror_tags();
   }
   size_t tiles(size_t n) const { return (n + L - 1) / L; }
   int find(const char *name) const {
@@ -130,6 +250,13 @@ struct TileVec {
   void resize(size_t n) {  // TileVector.hpp:477-482
     size = n;
     buf.resize(tiles(n) * L * (size_t)numChannels, L * (size_t)numChannels);
+  }
+  void relocate(int m, int8_t d) {
+    mem_free(buf.alloc, tagNames); mem_free(buf.alloc, tagOffsets); mem_free(buf.alloc, tagSizes);
+    tagNames = nullptr;
+    tagOffsets = tagSizes = nullptr;
+    buf.relocate(m, d);
+    mirror_tags();
   }
 };
 
@@ -230,8 +357,13 @@ template <class W> static void tv_fill(Launch &L, void *buf, size_t total, W val
 // ======================================================================================= C ABI
 extern "C" {
 
-zs_rocm_allocator *allocator(int memsrc, int8_t devid) { return new zs_rocm_allocator{memsrc, devid}; }
+zs_rocm_allocator *allocator(int memsrc, int8_t devid) { return new zs_rocm_allocator{memsrc, devid, 0}; }
+// py_interop/Allocator.cpp:14-19: get_virtual_memory_source(mre, devid, reservedSpace, "STACK")
+zs_rocm_allocator *allocator_virtual(int memsrc, int8_t devid, size_t reservedSpace) {
+  return new zs_rocm_allocator{memsrc, devid, reservedSpace ? reservedSpace : (size_t)1 << 36};
+}
 void del_allocator(zs_rocm_allocator *a) { delete a; }
+void del_allocator_virtual(zs_rocm_allocator *a) { delete a; }
 int mem_enum__host(void) { return 0; }
 int mem_enum__device(void) { return 1; }
 int mem_enum__um(void) { return 2; }
@@ -245,66 +377,103 @@ zs_rocm_property_tags *property_tags(const char *const *names, const int *sizes,
   return t;
 }
 void del_property_tags(zs_rocm_property_tags *t) { delete t; }
+void property_tags_get_item(zs_rocm_property_tags *t, size_t index, const char **name, size_t *size) {
+  *name = t->names[index].c_str();
+  *size = (size_t)t->sizes[index];
+}
+size_t property_tags_get_size(zs_rocm_property_tags *t) { return t->names.size(); }
 
-// ---- Vector<T>
-#define ZSR_DEFINE_VECTOR(T)                                                                        \
-  struct zs_rocm_vector_##T { VecBuf b; };                                                          \
-  zs_rocm_vector_##T *container__v_##T(zs_rocm_allocator *a, size_t n) {                            \
-    auto *v = new zs_rocm_vector_##T;                                                               \
-    VecBuf tmp(*a, n, sizeof(T));                                                                   \
-    v->b.swap(tmp);                                                                                 \
-    return v;                                                                                       \
-  }                                                                                                 \
-  void del_container__v_##T(zs_rocm_vector_##T *v) { delete v; }                                    \
-  void relocate_container__v_##T(zs_rocm_vector_##T *v, int m, int8_t d) { v->b.relocate(m, d); }   \
-  void resize_container__v_##T(zs_rocm_vector_##T *v, size_t n) { v->b.resize(n); }                 \
-  void reset_container__v_##T(zs_rocm_vector_##T *v, int ch) { v->b.reset(ch); }                    \
-  size_t container_size__v_##T(const zs_rocm_vector_##T *v) { return v->b.size; }                   \
-  size_t container_capacity__v_##T(const zs_rocm_vector_##T *v) { return v->b.cap; }                \
-  T get_val_container__v_##T(zs_rocm_vector_##T *v, size_t i) { /* getVal: 1-element copy */       \
-    T r{};                                                                                          \
-    zs_rocm_allocator h{0, -1};                                                                     \
-    mem_copy(h, &r, v->b.alloc, v->b.data + i * sizeof(T), sizeof(T));                              \
-    return r;                                                                                       \
-  }                                                                                                 \
-  void set_val_container__v_##T(zs_rocm_vector_##T *v, size_t i, T x) {                             \
-    zs_rocm_allocator h{0, -1};                                                                     \
-    mem_copy(v->b.alloc, v->b.data + i * sizeof(T), h, &x, sizeof(T));                              \
-  }                                                                                                 \
+// ---- Vector<T>: py_interop/VectorInstantiations.cpp:8-170.  SFX is empty or _virtual: both name the same object type, the
+// allocator the container was created with decides how its storage grows.
+#define ZSR_DEFINE_VECTOR_TYPE(T) struct zs_rocm_vector_##T { VecBuf b; };
+#define ZSR_DEFINE_VECTOR(T, SFX)                                                                          \
+  zs_rocm_vector_##T *container__v_##T##SFX(zs_rocm_allocator *a, size_t n) {                              \
+    auto *v = new zs_rocm_vector_##T;                                                                      \
+    VecBuf tmp(*a, n, sizeof(T));                                                                          \
+    v->b.swap(tmp);                                                                                        \
+    return v;                                                                                              \
+  }                                                                                                        \
+  void del_container__v_##T##SFX(zs_rocm_vector_##T *v) { delete v; }                                      \
+  void relocate_container__v_##T##SFX(zs_rocm_vector_##T *v, int m, int8_t d) { v->b.relocate(m, d); }     \
+  void resize_container__v_##T##SFX(zs_rocm_vector_##T *v, size_t n) { v->b.resize(n); }                   \
+  void reset_container__v_##T##SFX(zs_rocm_vector_##T *v, int ch) { v->b.reset(ch); }                      \
+  size_t container_size__v_##T##SFX(const zs_rocm_vector_##T *v) { return v->b.size; }                     \
+  size_t container_capacity__v_##T##SFX(const zs_rocm_vector_##T *v) { return v->b.cap; }                  \
+  T get_val_i_container__v_##T##SFX(zs_rocm_vector_##T *v, size_t i) { /* getVal(i): 1-element copy */     \
+    T r{};                                                                                                 \
+    zs_rocm_allocator h{0, -1};                                                                            \
+    mem_copy(h, &r, v->b.alloc, v->b.data + i * sizeof(T), sizeof(T));                                     \
+    return r;                                                                                              \
+  }                                                                                                        \
+  void set_val_i_container__v_##T##SFX(zs_rocm_vector_##T *v, size_t i, T x) {                             \
+    zs_rocm_allocator h{0, -1};                                                                            \
+    mem_copy(v->b.alloc, v->b.data + i * sizeof(T), h, &x, sizeof(T));                                     \
+  }                                                                                                        \
+  T get_val_container__v_##T##SFX(zs_rocm_vector_##T *v) { return get_val_i_container__v_##T##SFX(v, 0); } \
+  void set_val_container__v_##T##SFX(zs_rocm_vector_##T *v, T x) { set_val_i_container__v_##T##SFX(v, 0, x); } \
+  void copy_to_container__v_##T##SFX(zs_rocm_vector_##T *v, void *src) { /* assignVals(host src) */        \
+    zs_rocm_allocator h{0, -1};                                                                            \
+    mem_copy(v->b.alloc, v->b.data, h, src, v->b.size * sizeof(T));                                        \
+  }                                                                                                        \
+  void copy_from_container__v_##T##SFX(zs_rocm_vector_##T *v, void *dst) { /* retrieveVals(host dst) */    \
+    zs_rocm_allocator h{0, -1};                                                                            \
+    mem_copy(h, dst, v->b.alloc, v->b.data, v->b.size * sizeof(T));                                        \
+  }                                                                                                        \
+  T *get_handle_container__v_##T##SFX(zs_rocm_vector_##T *v) { return (T *)v->b.data; }                    \
+  zs_rocm_vector_view_lite *pyview__v_##T##SFX(zs_rocm_vector_##T *v) { return new zs_rocm_vector_view_lite{v->b.data}; } \
+  zs_rocm_vector_view_lite *pyview__v_const_##T##SFX(const zs_rocm_vector_##T *v) {                        \
+    return new zs_rocm_vector_view_lite{v->b.data};                                                        \
+  }                                                                                                        \
+  aosoa_iterator_##T##_1 get_iterator_1__v_##T##SFX(zs_rocm_vector_##T *v, uint32_t id) {                  \
+    return aosoa_iterator_##T##_1{(T *)v->b.data, id, 0u, 0u, 1u}; /* aos ctor, GenericIterator.hpp:71-72 */ \
+  }                                                                                                        \
+  aosoa_iterator_const_##T##_1 get_iterator_1__v_const_##T##SFX(const zs_rocm_vector_##T *v, uint32_t id) { \
+    return aosoa_iterator_const_##T##_1{(const T *)v->b.data, id, 0u, 0u, 1u};                             \
+  }                                                                                                        \
+  aosoa_iterator_##T##_3 get_iterator_3__v_##T##SFX(zs_rocm_vector_##T *v, uint32_t id) {                  \
+    return aosoa_iterator_##T##_3{(T *)v->b.data, id, 0u, 0u, 3u};                                         \
+  }                                                                                                        \
+  aosoa_iterator_const_##T##_3 get_iterator_3__v_const_##T##SFX(const zs_rocm_vector_##T *v, uint32_t id) { \
+    return aosoa_iterator_const_##T##_3{(const T *)v->b.data, id, 0u, 0u, 3u};                             \
+  }
+#define ZSR_DEFINE_VECTOR_BOTH(T)                                                     \
+  ZSR_DEFINE_VECTOR_TYPE(T)                                                           \
+  ZSR_DEFINE_VECTOR(T, )                                                              \
+  ZSR_DEFINE_VECTOR(T, _virtual)                                                      \
+  void del_pyview__v_##T(zs_rocm_vector_view_lite *v) { delete v; }                   \
+  void del_pyview__v_const_##T(zs_rocm_vector_view_lite *v) { delete v; }             \
   T *container_data__v_##T(zs_rocm_vector_##T *v) { return (T *)v->b.data; }
-ZSR_DEFINE_VECTOR(int)
-ZSR_DEFINE_VECTOR(float)
-ZSR_DEFINE_VECTOR(double)
+ZSR_DEFINE_VECTOR_BOTH(int)
+ZSR_DEFINE_VECTOR_BOTH(float)
+ZSR_DEFINE_VECTOR_BOTH(double)
 
 // ---- TileVector<T, L>
-#define ZSR_DEFINE_TILEVECTOR(T, LW)                                                                          \
-  struct zs_rocm_tv_##T##_##LW { TileVec *tv; };                                                              \
-  zs_rocm_tv_##T##_##LW *container__tv_##T##_##LW(zs_rocm_allocator *a, const zs_rocm_property_tags *t,       \
+#define ZSR_DEFINE_TILEVECTOR_TYPE(T, LW) struct zs_rocm_tv_##T##_##LW { TileVec *tv; };
+#define ZSR_DEFINE_TILEVECTOR(T, LW, SFX)                                                                     \
+  zs_rocm_tv_##T##_##LW *container__tv_##T##_##LW##SFX(zs_rocm_allocator *a, const zs_rocm_property_tags *t,       \
                                                   size_t n) {                                                 \
     return new zs_rocm_tv_##T##_##LW{new TileVec(*a, *t, n, LW, sizeof(T))};                                  \
   }                                                                                                           \
-  void del_container__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v) {                                               \
+  void del_container__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v) {                                               \
     delete v->tv;                                                                                             \
     delete v;                                                                                                 \
   }                                                                                                           \
-  void relocate_container__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v, int m, int8_t d) { v->tv->buf.relocate(m, d); } \
-  void resize_container__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v, size_t n) { v->tv->resize(n); }              \
-  void reset_container__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v, int ch) { v->tv->buf.reset(ch); }             \
-  size_t container_size__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v) { return v->tv->size; }                \
-  size_t container_capacity__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v) {                                  \
+  void relocate_container__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v, int m, int8_t d) { v->tv->relocate(m, d); } \
+  void resize_container__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v, size_t n) { v->tv->resize(n); }              \
+  void reset_container__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v, int ch) { v->tv->buf.reset(ch); }             \
+  size_t container_size__tv_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v) { return v->tv->size; }                \
+  size_t container_capacity__tv_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v) {                                  \
     return v->tv->numChannels ? v->tv->buf.cap / (size_t)v->tv->numChannels : 0; /* TileVector.hpp:382 */     \
   }                                                                                                           \
-  size_t container_num_channels__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v) { return (size_t)v->tv->numChannels; } \
-  int property_offset__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v, const char *name) {                      \
+  int property_offset__tv_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v, const char *name) {                      \
     int i = v->tv->find(name);                                                                                \
     return i < 0 ? -1 : v->tv->offsets[i]; /* getPropertyOffset, TileVector.hpp:528-535 */                    \
   }                                                                                                           \
-  int property_size__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v, const char *name) {                        \
+  int property_size__tv_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v, const char *name) {                        \
     int i = v->tv->find(name);                                                                                \
     return i < 0 ? -1 : v->tv->sizes[i];                                                                      \
   }                                                                                                           \
-  T *container_data__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v) { return (T *)v->tv->buf.data; }                 \
-  aosoa_iterator_##T##_1 get_iterator_1__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v, uint32_t id,                 \
+  aosoa_iterator_##T##_1 get_iterator_1__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v, uint32_t id,                 \
                                                        uint32_t chnOffset) {                                  \
     /* aosoa_iterator(aosoa, ptr, id, tileSize, chnOffset, numChns), GenericIterator.hpp:76-82 */             \
     aosoa_iterator_##T##_1 it;                                                                                \
@@ -315,7 +484,35 @@ ZSR_DEFINE_VECTOR(double)
     it.numChns = (uint32_t)v->tv->numChannels;                                                                \
     return it;                                                                                                \
   }                                                                                                           \
-  void append_properties__rocm_tv_##T##_##LW(zs_rocm_policy *pol, zs_rocm_tv_##T##_##LW *v,                   \
+  aosoa_iterator_const_##T##_1 get_iterator_1__tv_const_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v, uint32_t id, \
+                                                                       uint32_t chnOffset) {                  \
+    return aosoa_iterator_const_##T##_1{(const T *)v->tv->buf.data + (size_t)chnOffset * LW, id, (uint32_t)log2i(LW), LW - 1, \
+                                       (uint32_t)v->tv->numChannels};                                         \
+  }                                                                                                           \
+  aosoa_iterator_##T##_3 get_iterator_3__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v, uint32_t id, uint32_t chnOffset) { \
+    return aosoa_iterator_##T##_3{(T *)v->tv->buf.data + (size_t)chnOffset * LW, id, (uint32_t)log2i(LW), LW - 1, \
+                                 (uint32_t)v->tv->numChannels};                                               \
+  }                                                                                                           \
+  aosoa_iterator_const_##T##_3 get_iterator_3__tv_const_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v, uint32_t id, \
+                                                                       uint32_t chnOffset) {                  \
+    return aosoa_iterator_const_##T##_3{(const T *)v->tv->buf.data + (size_t)chnOffset * LW, id, (uint32_t)log2i(LW), LW - 1, \
+                                       (uint32_t)v->tv->numChannels};                                         \
+  }                                                                                                           \
+  zs_rocm_tv_view_lite *pyview__tv_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v) {                                \
+    return new zs_rocm_tv_view_lite{v->tv->buf.data, v->tv->numChannels};                                     \
+  }                                                                                                           \
+  zs_rocm_tv_view_lite *pyview__tv_const_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v) {                    \
+    return new zs_rocm_tv_view_lite{v->tv->buf.data, v->tv->numChannels};                                     \
+  }                                                                                                           \
+  zs_rocm_tv_named_view_lite *pyview__tvn_##T##_##LW##SFX(zs_rocm_tv_##T##_##LW *v) {                         \
+    return new zs_rocm_tv_named_view_lite{v->tv->buf.data, v->tv->numChannels, v->tv->tagNames, v->tv->tagOffsets, \
+                                          v->tv->tagSizes, (int)v->tv->names.size()};                         \
+  }                                                                                                           \
+  zs_rocm_tv_named_view_lite *pyview__tvn_const_##T##_##LW##SFX(const zs_rocm_tv_##T##_##LW *v) {             \
+    return new zs_rocm_tv_named_view_lite{v->tv->buf.data, v->tv->numChannels, v->tv->tagNames, v->tv->tagOffsets, \
+                                          v->tv->tagSizes, (int)v->tv->names.size()};                         \
+  }                                                                                                           \
+  void append_properties__rocm_tv_##T##_##LW##SFX(zs_rocm_policy *pol, zs_rocm_tv_##T##_##LW *v,                   \
                                              const zs_rocm_property_tags *tags) {                             \
     TileVec &o = *v->tv;                                                                                      \
     zs_rocm_property_tags merged{o.names, o.sizes};                                                           \
@@ -350,7 +547,10 @@ ZSR_DEFINE_VECTOR(double)
     }                                                                                                         \
     delete v->tv;                                                                                             \
     v->tv = nt;                                                                                               \
-  }                                                                                                           \
+  }
+#define ZSR_DEFINE_TILEVECTOR_ONCE(T, LW)                                                                     \
+  size_t container_num_channels__tv_##T##_##LW(const zs_rocm_tv_##T##_##LW *v) { return (size_t)v->tv->numChannels; } \
+  T *container_data__tv_##T##_##LW(zs_rocm_tv_##T##_##LW *v) { return (T *)v->tv->buf.data; }                 \
   void zs_rocm_fill__tv_##T##_##LW(zs_rocm_policy *pol, zs_rocm_tv_##T##_##LW *v, T val) {                    \
     Launch L(pol, "tv_reset");                                                                                \
     using W = std::conditional_t<sizeof(T) == 4, uint32_t, uint64_t>;                                         \
@@ -381,19 +581,28 @@ ZSR_DEFINE_VECTOR(double)
     delete v->tv;                                                                                             \
     v->tv = nt;                                                                                               \
   }
+#define ZSR_DEFINE_TILEVECTOR_BOTH(T, LW)                                                   \
+  ZSR_DEFINE_TILEVECTOR_TYPE(T, LW)                                                         \
+  ZSR_DEFINE_TILEVECTOR(T, LW, )                                                            \
+  ZSR_DEFINE_TILEVECTOR(T, LW, _virtual)                                                    \
+  ZSR_DEFINE_TILEVECTOR_ONCE(T, LW)                                                         \
+  void del_pyview__tv_##T##_##LW(zs_rocm_tv_view_lite *v) { delete v; }                     \
+  void del_pyview__tv_const_##T##_##LW(zs_rocm_tv_view_lite *v) { delete v; }               \
+  void del_pyview__tvn_##T##_##LW(zs_rocm_tv_named_view_lite *v) { delete v; }              \
+  void del_pyview__tvn_const_##T##_##LW(zs_rocm_tv_named_view_lite *v) { delete v; }
 
-ZSR_DEFINE_TILEVECTOR(int, 8)
-ZSR_DEFINE_TILEVECTOR(int, 32)
-ZSR_DEFINE_TILEVECTOR(int, 64)
-ZSR_DEFINE_TILEVECTOR(int, 512)
-ZSR_DEFINE_TILEVECTOR(float, 8)
-ZSR_DEFINE_TILEVECTOR(float, 32)
-ZSR_DEFINE_TILEVECTOR(float, 64)
-ZSR_DEFINE_TILEVECTOR(float, 512)
-ZSR_DEFINE_TILEVECTOR(double, 8)
-ZSR_DEFINE_TILEVECTOR(double, 32)
-ZSR_DEFINE_TILEVECTOR(double, 64)
-ZSR_DEFINE_TILEVECTOR(double, 512)
+ZSR_DEFINE_TILEVECTOR_BOTH(int, 8)
+ZSR_DEFINE_TILEVECTOR_BOTH(int, 32)
+ZSR_DEFINE_TILEVECTOR_BOTH(int, 64)
+ZSR_DEFINE_TILEVECTOR_BOTH(int, 512)
+ZSR_DEFINE_TILEVECTOR_BOTH(float, 8)
+ZSR_DEFINE_TILEVECTOR_BOTH(float, 32)
+ZSR_DEFINE_TILEVECTOR_BOTH(float, 64)
+ZSR_DEFINE_TILEVECTOR_BOTH(float, 512)
+ZSR_DEFINE_TILEVECTOR_BOTH(double, 8)
+ZSR_DEFINE_TILEVECTOR_BOTH(double, 32)
+ZSR_DEFINE_TILEVECTOR_BOTH(double, 64)
+ZSR_DEFINE_TILEVECTOR_BOTH(double, 512)
 
 // ---- raw AoSoA kernels
 void zs_rocm_tv_from_aos_f32(zs_rocm_policy *pol, const float *aos, size_t n, int C, int Lw, float *tv) {
