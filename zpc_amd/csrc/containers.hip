@@ -61,9 +61,15 @@ struct VmmRange {
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) return false;
+    // uniform power-of-two chunks, the range aligned to the chunk size (mixed-size mappings at unaligned offsets made
+    // hipMemSetAccess fail intermittently on ROCm 7): reserved / 1024 clamped to [2 MiB, 1 GiB]
+    gran = (size_t)2 << 20;
+    while (gran < g) gran <<= 1;
+    while (gran < ((size_t)1 << 30) && gran * 1024 < bytes) gran <<= 1;
     reserved = (bytes + gran - 1) / gran * gran;
-    if (hipMemAddressReserve((void **)&base, reserved, 0, nullptr, 0) != hipSuccess) {
+    if (hipMemAddressReserve((void **)&base, reserved, gran, nullptr, 0) != hipSuccess) {
       base = nullptr;
       return false;
     }
@@ -71,31 +77,41 @@ struct VmmRange {
   }
   bool grow(size_t bytes) {  // make [0, bytes) backed by physical memory
     if (bytes <= mapped) return true;
-    size_t want = (bytes + gran - 1) / gran * gran;
-    if (want > reserved) return false;
-    const size_t add = want - mapped;
+    const size_t want = (bytes + gran - 1) / gran * gran;
+    if (want > reserved) {
+      fprintf(stderr, "[zs_rocm] virtual range exhausted: need %zu of %zu reserved bytes\n", want, reserved);
+      return false;
+    }
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) return false;
-    if (hipMemMap(base + mapped, add, 0, h, 0) != hipSuccess) {
-      (void)hipMemRelease(h);
-      return false;
-    }
     hipMemAccessDesc acc{};
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = dev;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(base + mapped, add, &acc, 1) != hipSuccess) {
-      (void)hipMemUnmap(base + mapped, add);
-      (void)hipMemRelease(h);
-      return false;
+    while (mapped < want) {
+      hipMemGenericAllocationHandle_t h;
+      hipError_t e = hipMemCreate(&h, gran, &prop, 0);
+      if (e != hipSuccess) {
+        fprintf(stderr, "[zs_rocm] hipMemCreate(%zu) failed: %s\n", gran, hipGetErrorString(e));
+        return false;
+      }
+      if ((e = hipMemMap(base + mapped, gran, 0, h, 0)) != hipSuccess) {
+        fprintf(stderr, "[zs_rocm] hipMemMap failed: %s\n", hipGetErrorString(e));
+        (void)hipMemRelease(h);
+        return false;
+      }
+      if ((e = hipMemSetAccess(base + mapped, gran, &acc, 1)) != hipSuccess) {
+        fprintf(stderr, "[zs_rocm] hipMemSetAccess failed: %s\n", hipGetErrorString(e));
+        (void)hipMemUnmap(base + mapped, gran);
+        (void)hipMemRelease(h);
+        return false;
+      }
+      chunks.push_back(h);
+      chunkBytes.push_back(gran);
+      mapped += gran;
     }
-    chunks.push_back(h);
-    chunkBytes.push_back(add);
-    mapped = want;
     return true;
   }
   void release() {
