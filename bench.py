@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--unbinned", action="store_true", help="particle-order path (reference algorithm) instead of the binned path")
     ap.add_argument("--no-cache-stress", action="store_true",
                     help="evaluate the constitutive model inside P2G (reference order) instead of in the tail of the previous G2P")
+    ap.add_argument("--fused", action="store_true",
+                    help="one fused G2P2G pass per step (G2P of step n + P2G of step n+1; v, C, stress stay on chip) instead of "
+                         "separate P2G and G2P kernels")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -257,6 +260,33 @@ def main():
             e3.record()
             g2p_ev.append((e2, e3))
 
+    fused_ev = []
+
+    def step_fused(timed, write_all=False):
+        # grid holds the velocities of the current step (after grid_update): G2P from it, P2G of the next step into the
+        # second (zeroed) grid, which then becomes the current one
+        if timed:
+            e0, e1 = ev(), ev()
+            e0.record()
+        mt.g2p2g(write_all=write_all)
+        if timed:
+            e1.record()
+            fused_ev.append((e0, e1))
+        if halo is not None:
+            halo.exchange(pack, unpack_add)
+        mt.grid_update((0.0, -9.8, 0.0))
+
+    if a.fused:
+        if a.unbinned or not mt.cache_stress:
+            raise SystemExit("--fused needs the binned path with cached stress")
+        mt.clear_grid()
+        mt.p2g()
+        if halo is not None:
+            halo.exchange(pack, unpack_add)
+        mt.grid_update((0.0, -9.8, 0.0))
+        unfused_step = step
+        step = lambda timed: step_fused(timed)
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -271,6 +301,9 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    if a.fused and a.checksum:
+        step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
+        torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
 
     n_total = n_local
@@ -292,15 +325,16 @@ def main():
         if dist is not None:
             dist.all_reduce(cs)
         checksum = [float(x) for x in cs.cpu()]
-    p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev]))
-    g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev]))
+    p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
+    g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
+    fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
 
     if rank == 0:
         value = n_total * a.steps / elapsed
         # cached stress: P2G reads m,x,v,C + P F^T (100 B) + 7 B grid; G2P additionally reads/writes logJp and writes P F^T
         p2g_bytes = 107.0 if mt.cache_stress else P2G_BYTES[model]
         g2p_bytes = G2P_BYTES + ((36.0 + (8.0 if model == 1 else 0.0)) if mt.cache_stress else 0.0)
-        ach = p2g_bytes * n_local / (p2g_ms * 1e-3) / 1e9
+        ach = p2g_bytes * n_local / (max(p2g_ms, 1e-9) * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_p2g.json")
         if os.path.exists(pmc):
@@ -327,10 +361,32 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
                          "constitutive_update": "tail of previous G2P (particles.stress)" if mt.cache_stress else "inside P2G",
-                         "g2p": {"achieved": g2p_bytes * n_local / (g2p_ms * 1e-3) / 1e9, "launch_ms": g2p_ms,
+                         "g2p": {"achieved": g2p_bytes * n_local / (max(g2p_ms, 1e-9) * 1e-3) / 1e9, "launch_ms": g2p_ms,
                                  "bytes_per_particle": g2p_bytes}},
             "hip_error": err,
         }
+        if a.fused:
+            # fused pass: reads m, x, F (, logJp) = 52 (56) B, writes x, F (, logJp) = 48 (52) B, grid A velocities 1.5 B and
+            # grid B clear + accumulate 7 B per particle at 8 particles per node
+            fb = (56.0 + 52.0 if model == 1 else 52.0 + 48.0) + 1.5 + 7.0
+            fach = fb * n_local / (fused_ms * 1e-3) / 1e9
+            ftraffic = None
+            pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json")
+            if os.path.exists(pmcf):
+                try:
+                    j = json.load(open(pmcf))
+                    if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model:
+                        ftraffic = j.get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+            out["config"]["workload"] = out["config"]["workload"].replace("step = grid reset + P2G + grid update + G2P",
+                                                                          "step = grid reset + fused G2P2G (G2P of step n, P2G of step n+1) + grid update")
+            out["roofline"] = {"bound": "hbm", "kernel": "g2p2g_binned_kernel", "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": fach / HBM_PEAK_GBS, "traffic": ftraffic, "bytes_per_particle": fb,
+                               "particles_per_launch": n_local, "launch_ms": fused_ms,
+                               "note": "VALU-limited (per-particle 3x3 SVD + 27-node stencils), not HBM-limited: the fused pass moves "
+                                       "116.5 B per particle instead of the 296.5 B of separate P2G + G2P kernels",
+                               "unfused_bytes_per_particle": 296.5 if model == 1 else 288.5}
         if checksum is not None:
             out["checksum"] = checksum
         if world == 1 and not a.no_cpu_baseline:

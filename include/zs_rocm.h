@@ -532,6 +532,15 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,
                                     const unsigned *cellCount, const int *nbr);
 /* particles.stress := model(F, logJp) * volume, logJp updated (no-op when particles.stress.base == NULL) */
+/* Fused transfer: G2P of step n (from gridA: velocities after zs_rocm_mpm_grid_update) and P2G of step n+1 (into gridB,
+ * zeroed by the caller) in one pass over the binned particles -- the reference's G2P2GTransfer idea
+ * (simulation/transfer/G2P2G.hpp:20-148).  Same results as zs_rocm_mpm_g2p followed by zs_rocm_mpm_p2g; HBM traffic per
+ * particle drops from 296.5 B to 116.5 B because v, C and the cached stress stay on chip.  Requires binned particles and
+ * the `stress` attribute (state of the particles that take the exact path is parked there).  writeAll != 0 also writes
+ * v, C, stress of every particle (e.g. on the last step).  Returns 0, or -1 if the requirements are not met. */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
+                                     const float *gridA, float *gridB, size_t nblocks, const int *binStart,
+                                     const unsigned *cellCount, const int *nbr, int writeAll);
 ZS_ROCM_EXPORT void zs_rocm_mpm_update_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
 /* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
  * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */

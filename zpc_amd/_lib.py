@@ -280,6 +280,7 @@ def _declare_containers(L):
     L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, i32, vp, vp, vp]
     L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp, i32]
     L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_mpm_g2p2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]

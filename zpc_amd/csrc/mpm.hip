@@ -918,6 +918,45 @@ template <int ROLE, int LW> struct SplitRec {
   }
 };
 
+// one particle's contribution of the channels of ROLE to the 27 stencil nodes of its cell (registers):
+//   momentum roles:  W m (b + g . (xi - xp))      stress roles:  W kscale (g . (xi - xp))        [+ W m for the mass channel]
+// evaluated as Ws * ((Px[a] + Py[b]) + Pz[c]) with the per-axis products hoisted
+template <int ROLE>
+__device__ __forceinline__ void split_accumulate(const MpmDev &mp, const Arena &ar, float m, float kscale,
+                                                 const float (&b)[SplitRole<ROLE>::NA], const float (&g)[SplitRole<ROLE>::NA][3],
+                                                 float (&accm)[27], float (&acc)[27][SplitRole<ROLE>::NA]) {
+  using R = SplitRole<ROLE>;
+  float Px[3][R::NA], Py[3][R::NA], Pz[3][R::NA], wzs[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
+#pragma unroll
+    for (int q = 0; q < R::NA; ++q) {
+      Px[k][q] = g[q][0] * x0;
+      Py[k][q] = g[q][1] * x1;
+      Pz[k][q] = fmaf(g[q][2], x2, b[q]);
+    }
+    wzs[k] = ar.w[2][k] * (R::USEM ? m : kscale);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float wxy = ar.w[0][a] * ar.w[1][bb];
+      float qv[R::NA];
+#pragma unroll
+      for (int q = 0; q < R::NA; ++q) qv[q] = Px[a][q] + Py[bb][q];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float Ws = wxy * wzs[c];
+        const int n = (a * 3 + bb) * 3 + c;
+        if constexpr (R::HASMASS) accm[n] += Ws;
+#pragma unroll
+        for (int q = 0; q < R::NA; ++q) acc[n][q] = fmaf(Ws, qv[q] + Pz[c][q], acc[n][q]);
+      }
+    }
+}
+
 template <int SIDE, int ROLE, int LW>
 __device__ __forceinline__ void p2g_split_sweep(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
                                                 int cx, int cy, int cz, float *a0, int *stale, int *staleCount) {
@@ -948,35 +987,7 @@ __device__ __forceinline__ void p2g_split_sweep(const MpmDev &mp, const Particle
       if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
         if constexpr (ROLE == 0) stale[atomicAdd(staleCount, 1)] = i0;  // exact path afterwards (queued once)
       } else {
-        float Px[3][R::NA], Py[3][R::NA], Pz[3][R::NA], wzs[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
-#pragma unroll
-          for (int q = 0; q < R::NA; ++q) {
-            Px[k][q] = cur.g[q][0] * x0;
-            Py[k][q] = cur.g[q][1] * x1;
-            Pz[k][q] = fmaf(cur.g[q][2], x2, cur.b[q]);
-          }
-          wzs[k] = ar.w[2][k] * (R::USEM ? cur.m : kscale);
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb) {
-            const float wxy = ar.w[0][a] * ar.w[1][bb];
-            float qv[R::NA];
-#pragma unroll
-            for (int q = 0; q < R::NA; ++q) qv[q] = Px[a][q] + Py[bb][q];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float Ws = wxy * wzs[c];
-              const int n = (a * 3 + bb) * 3 + c;
-              if constexpr (R::HASMASS) accm[n] += Ws;
-#pragma unroll
-              for (int q = 0; q < R::NA; ++q) acc[n][q] = fmaf(Ws, qv[q] + Pz[c][q], acc[n][q]);
-            }
-          }
+        split_accumulate<ROLE>(mp, ar, cur.m, kscale, cur.b, cur.g, accm, acc);
       }
     }
     cur = nxt;
@@ -1021,6 +1032,220 @@ __global__ __launch_bounds__(256) void p2g_binned_split_kernel(MpmDev mp, Partic
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
     const int bn = nbr[(size_t)geo.block * 8 + slot];
+    if (bn >= 0) {
+      const float *a = arena + AL::at(x, y, z);
+      float *g = grid + (size_t)bn * 7 * NC + cell;
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        const float v = a[ch * AL::CH];
+        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
+      }
+    }
+  }
+}
+
+// ---- "wide" cached-stress P2G: ONE wave per bin carries all 7 channels (27 x 7 = 189 register accumulators).
+// The four-wave split above repeats the arena / weight / address work in every wave (PMC: 1113 VALU instructions per
+// 64-particle round, SQ_INSTS_VALU x 4 cycles = 96 % of the SIMD cycles: that kernel is VALU-bound).  Here the per-particle
+// work is done once (~600 VALU per round).  The price is 2 waves per SIMD; the latency the occupancy no longer hides is
+// covered by asynchronous global -> LDS loads (global_load_lds_dword: no staging VGPRs) issued one round ahead into a
+// double-buffered record area of the LDS.
+constexpr int P2GW_NF = 25;  // m, x(3), v(3), C(9), P F^T vol(9)
+
+// `tileBase`: wave-uniform element offset of a tile at or before the bin's first particle.  The per-lane part of every address
+// is then a 32-bit byte offset from a scalar base (global_load_lds_dword v_off, s[base:base+1] offset:imm): ONE address VGPR
+// per round instead of a 64-bit pointer per attribute.
+template <int LW>
+__device__ __forceinline__ void p2gw_issue(const ParticlesDev &ps, size_t i, bool has, float *buf, size_t tileBase) {
+  // every lane of the wave executes the 25 instructions (LDS destination = wave-uniform row + lane * 4); lanes without a
+  // particle in this round are masked off by exec
+  if (has) {
+    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
+    const unsigned voff = LW != 0 ? (unsigned)((o.o - tileBase) * sizeof(float)) : 0u;
+    auto ptr = [&](const Port<float> &p, int comp) -> const float * {
+      if constexpr (LW != 0)
+        return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.base + tileBase) + (size_t)voff) + (size_t)comp * LW;
+      else
+        return p.base + p.off(o.o) + (size_t)comp * p.cstride();
+    };
+    __builtin_amdgcn_global_load_lds(ptr(ps.mass, 0), (__attribute__((address_space(3))) void *)(buf + 0 * 64), 4, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.pos, d), (__attribute__((address_space(3))) void *)(buf + (1 + d) * 64), 4, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.vel, d), (__attribute__((address_space(3))) void *)(buf + (4 + d) * 64), 4, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.C, d), (__attribute__((address_space(3))) void *)(buf + (7 + d) * 64), 4, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, 0);
+  }
+}
+template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const ParticlesDev &ps, int start) {
+  if constexpr (LW != 0) return ((size_t)start / LW) * (size_t)ps.pos.chns * LW;
+  else return 0;
+}
+
+// one particle record (LDS row layout of p2gw_issue) -> the lane's 27 x 7 register stencil
+__device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
+  const float m = rec[0];
+  float xo[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
+  {  // ---- mass + momentum: W m (v + C (xi - xp))
+    float Px[3][3], Py[3][3], Pz[3][3], wzm[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = rec[(4 + d) * 64], c0 = rec[(7 + d) * 64], c1 = rec[(10 + d) * 64], c2 = rec[(13 + d) * 64];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Px[k][d] = c0 * xo[0][k];
+        Py[k][d] = c1 * xo[1][k];
+        Pz[k][d] = fmaf(c2, xo[2][k], v);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wzm[k] = ar.w[2][k] * m;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        const float wxy = ar.w[0][a] * ar.w[1][bb];
+        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float Wm = wxy * wzm[c];
+          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
+          A[0] += Wm;
+          A[1] = fmaf(Wm, q0 + Pz[c][0], A[1]);
+          A[2] = fmaf(Wm, q1 + Pz[c][1], A[2]);
+          A[3] = fmaf(Wm, q2 + Pz[c][2], A[3]);
+        }
+      }
+  }
+  {  // ---- stress: W kscale (P F^T vol) (xi - xp)
+    float Px[3][3], Py[3][3], Pz[3][3], wzk[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float c0 = rec[(16 + d) * 64], c1 = rec[(19 + d) * 64], c2 = rec[(22 + d) * 64];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Px[k][d] = c0 * xo[0][k];
+        Py[k][d] = c1 * xo[1][k];
+        Pz[k][d] = c2 * xo[2][k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wzk[k] = ar.w[2][k] * kscale;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        const float wxy = ar.w[0][a] * ar.w[1][bb];
+        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float Wk = wxy * wzk[c];
+          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
+          A[4] = fmaf(Wk, q0 + Pz[c][0], A[4]);
+          A[5] = fmaf(Wk, q1 + Pz[c][1], A[5]);
+          A[6] = fmaf(Wk, q2 + Pz[c][2], A[6]);
+        }
+      }
+  }
+}
+
+// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of 6.4 KB)
+template <int SIDE, int LW, int DEPTH>
+__global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+                                                       const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  using AL = ArenaLds;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  constexpr int NB = DEPTH + 1;
+  // the record buffers and the flush arena are never live at the same time: one LDS region serves both, so that DEPTH = 2
+  // (19.2 KB) still leaves room for the 8 waves per CU the register file allows
+  constexpr int LDSF = NB * P2GW_NF * 64 > 7 * AL::CH ? NB * P2GW_NF * 64 : 7 * AL::CH;
+  __shared__ float lds[LDSF];
+  float *arena = lds;
+  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds);
+  const int bin = blockIdx.x;
+  const int start = binStart[bin], end = binStart[bin + 1];
+  if (start == end) return;
+  const int lane = threadIdx.x;
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
+  const float dxi = 1.0f / mp.dx;
+  const float kscale = -mp.dt * (4.f * dxi * dxi);  // contrib = -dt D_inv (P F^T vol)
+  float acc[27][7];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
+  // two walks over the same counts: `lead` runs DEPTH rounds ahead and issues the loads, `walk` consumes
+  const size_t tileBase = p2gw_tile_base<LW>(ps, start);
+  RoundWalk lead(cnt, start), walk(cnt, start);
+  int li;
+  bool lany = true;
+  int issued = 0;  // rounds issued and not yet consumed (wave-uniform)
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (lany) {
+      const bool lh = lead.next(li, lany);
+      if (lany) {
+        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[d % NB], tileBase);
+        ++issued;
+      }
+    }
+  }
+  int slot = 0, lslot = DEPTH % NB;
+  int i0;
+  bool any;
+  bool has0 = walk.next(i0, any);
+  while (any) {
+    if (lany) {
+      const bool lh = lead.next(li, lany);
+      if (lany) {
+        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[lslot], tileBase);
+        lslot = lslot + 1 == NB ? 0 : lslot + 1;
+        ++issued;
+      }
+    }
+    // wait until only the records issued AFTER the current one are still in flight
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (has0) {
+      const float *rec = pbuf[slot] + lane;
+      const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz)
+        stale[atomicAdd(staleCount, 1)] = i0;  // exact path afterwards
+      else
+        p2gw_accumulate(mp, ar, rec, kscale, acc);
+    }
+    --issued;
+    slot = slot + 1 == NB ? 0 : slot + 1;
+    has0 = walk.next(i0, any);
+  }
+  __syncthreads();  // every record has been consumed: the region becomes the arena
+  for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
+  __syncthreads();
+  float *a0 = arena + AL::at(cx, cy, cz);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases (one wave: its LDS operations execute in order)
+    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) g[ch * AL::CH] += acc[k][ch];
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (int node = lane; node < 216; node += 64) {
+    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
+    int slot2, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot2, cell);
+    const int bn = nbr[(size_t)geo.block * 8 + slot2];
     if (bn >= 0) {
       const float *a = arena + AL::at(x, y, z);
       float *g = grid + (size_t)bn * 7 * NC + cell;
@@ -1176,6 +1401,49 @@ __global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev
   g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
 }
 
+// v = sum W v_i and B = sum W v_i (xi - xp)^T over the 27 register-resident node velocities of the lane's cell, by sum
+// factorisation over z, then y, then x (W = wx wy wz): ~290 VALU ops instead of ~1000 for the node-by-node form of
+// G2P.hpp:54-66 (same sums, different association)
+__device__ __forceinline__ void g2p_gather_factorized(const MpmDev &mp, const Arena &ar, const float (&nv)[27][3], float D_inv,
+                                                      float (&vel)[3], float (&C)[9]) {
+  float xz[3], xy[3], xx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
+    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
+    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
+  }
+  float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // B[j][k]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) vel[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      float s0[3], s1[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v0 = nv[(a * 3 + bb) * 3 + 0][j], v1 = nv[(a * 3 + bb) * 3 + 1][j], v2 = nv[(a * 3 + bb) * 3 + 2][j];
+        s0[j] = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
+        s1[j] = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
+        t0[j] = fmaf(ar.w[1][bb], s0[j], t0[j]);
+        t1[j] = fmaf(xy[bb], s0[j], t1[j]);
+        t2[j] = fmaf(ar.w[1][bb], s1[j], t2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      vel[j] = fmaf(ar.w[0][a], t0[j], vel[j]);
+      B[j][0] = fmaf(xx[a], t0[j], B[j][0]);
+      B[j][1] = fmaf(ar.w[0][a], t1[j], B[j][1]);
+      B[j][2] = fmaf(ar.w[0][a], t2[j], B[j][2]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;  // C[d] += W v_i[d%3] xixp[d/3] D_inv (G2P.hpp:65)
+}
+
 template <int SIDE, int SMODEL, int LW>
 __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *binStart,
                                                         const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
@@ -1230,43 +1498,8 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
       if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
         stale[atomicAdd(staleCount, 1)] = i0;
       } else {
-        // v = sum W v_i and B = sum W v_i (xi - xp)^T by sum factorisation over z, then y, then x (W = wx wy wz): ~290 VALU
-        // ops instead of ~1000 for the node-by-node form of G2P.hpp:54-66 (same sums, different association)
-        float xz[3], xy[3], xx[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
-          xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
-          xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
-        }
-        float vel[3] = {0.f, 0.f, 0.f}, B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // B[j][k]
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb) {
-            float s0[3], s1[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const float v0 = nv[(a * 3 + bb) * 3 + 0][j], v1 = nv[(a * 3 + bb) * 3 + 1][j], v2 = nv[(a * 3 + bb) * 3 + 2][j];
-              s0[j] = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
-              s1[j] = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
-              t0[j] = fmaf(ar.w[1][bb], s0[j], t0[j]);
-              t1[j] = fmaf(xy[bb], s0[j], t1[j]);
-              t2[j] = fmaf(ar.w[1][bb], s1[j], t2[j]);
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            vel[j] = fmaf(ar.w[0][a], t0[j], vel[j]);
-            B[j][0] = fmaf(xx[a], t0[j], B[j][0]);
-            B[j][1] = fmaf(ar.w[0][a], t1[j], B[j][1]);
-            B[j][2] = fmaf(ar.w[0][a], t2[j], B[j][2]);
-          }
-        }
-        float C[9];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;  // C[d] += W v_i[d%3] xixp[d/3] D_inv (G2P.hpp:65)
+        float vel[3], C[9];
+        g2p_gather_factorized(mp, ar, nv, D_inv, vel, C);
         g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
       }
     }
@@ -1284,6 +1517,326 @@ __global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev 
   const float dxi = 1.0f / mp.dx;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
     g2p_gather_global<SIDE, SMODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
+}
+
+// ======================================================================================= G2P2G (fused)
+// G2P of step n and P2G of step n+1 in ONE pass over the particles (the reference has the same idea as G2P2GTransfer,
+// simulation/transfer/G2P2G.hpp): a particle is read once (m, x, F, logJp: 56 B), gathered from grid A, advected, its F and
+// constitutive model updated, and scattered straight into grid B; only x, F, logJp go back to HBM (52 B).  v, C and
+// P F^T vol never leave the chip (WRITE_ALL stores them for callers that want the full state).  Unfused, the same work
+// moves 296.5 B per particle and step.
+//
+// One workgroup of four waves owns a bin; lane = cell.  Per chunk of four rounds:
+//   phase 1   wave w runs round 4c + w through G2P (node velocities read from the LDS arena) + F update + constitutive model
+//             and stages {m, x', v', C', P F^T} of its 64 particles in LDS;
+//   phase 2   waves 0/1 accumulate mass + momentum (4 channels, 108 register accumulators) of staged rounds {0,1} / {2,3},
+//             waves 2/3 the three stress channels of the same rounds; two LDS arenas collect the two halves.
+// The kernel is VALU-bound (SQ_INSTS_VALU x 4 cycles ~ 85 % of the SIMD cycles), so the design minimises instructions: the
+// first version kept the 81 node velocities in registers and used the four channel roles of p2g_binned_split_kernel in
+// phase 2 (each staged round consumed by 4 waves: 4x the arena / weight work) and took 5.0 ms per 67.1 M-particle step.
+// Particles that are not in the cell they are stored under are exact as before: mis-binned at read -> queue G (global
+// gather + global scatter afterwards); moved out of the cell by this step's advection -> queue P (state stored, global
+// scatter afterwards).
+constexpr int G2P2G_NF = 25;  // staged floats per particle: m, x(3), v(3), C(9), P F^T vol(9)
+
+// gather of g2p_gather_factorized with the node velocities read from the LDS arena (81 ds_read per particle; the fused
+// kernel is VALU-bound and needs the 81 VGPRs a register-resident copy would cost for its P2G stencil)
+__device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar, const float *a0, float D_inv, float (&vel)[3],
+                                               float (&C)[9]) {
+  using AL = ArenaLds;
+  float xz[3], xy[3], xx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
+    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
+    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
+  }
+  float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) vel[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float *g = a0 + AL::at(a, bb, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v0 = g[j * AL::CH], v1 = g[j * AL::CH + 1], v2 = g[j * AL::CH + 2];
+        const float s0 = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
+        const float s1 = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
+        t0[j] = fmaf(ar.w[1][bb], s0, t0[j]);
+        t1[j] = fmaf(xy[bb], s0, t1[j]);
+        t2[j] = fmaf(ar.w[1][bb], s1, t2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      vel[j] = fmaf(ar.w[0][a], t0[j], vel[j]);
+      B[j][0] = fmaf(xx[a], t0[j], B[j][0]);
+      B[j][1] = fmaf(ar.w[0][a], t1[j], B[j][1]);
+      B[j][2] = fmaf(ar.w[0][a], t2[j], B[j][2]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;
+}
+
+// phase-2 consumer of one staged record.  STRESS = false: mass + momentum (4 channels), true: rhs (3 channels)
+template <bool STRESS>
+__device__ __forceinline__ void g2p2g_consume(const MpmDev &mp, const float *st, int lane, float kscale, float (&acc)[27][STRESS ? 3 : 4]) {
+  auto f = [&](int k) { return st[k * 64 + lane]; };
+  const float pos[3] = {f(1), f(2), f(3)};
+  Arena ar;
+  make_arena(mp.dx, pos, ar);
+  float xo[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
+  float Px[3][3], Py[3][3], Pz[3][3], wzs[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float c0 = STRESS ? f(16 + d) : f(7 + d), c1 = STRESS ? f(19 + d) : f(10 + d), c2 = STRESS ? f(22 + d) : f(13 + d);
+    const float v = STRESS ? 0.f : f(4 + d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Px[k][d] = c0 * xo[0][k];
+      Py[k][d] = c1 * xo[1][k];
+      Pz[k][d] = STRESS ? c2 * xo[2][k] : fmaf(c2, xo[2][k], v);
+    }
+  }
+  const float scale = STRESS ? kscale : f(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float wxy = ar.w[0][a] * ar.w[1][bb];
+      const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float Ws = wxy * wzs[c];
+        auto &A = acc[(a * 3 + bb) * 3 + c];
+        if constexpr (!STRESS) {
+          A[0] += Ws;
+          A[1] = fmaf(Ws, q0 + Pz[c][0], A[1]);
+          A[2] = fmaf(Ws, q1 + Pz[c][1], A[2]);
+          A[3] = fmaf(Ws, q2 + Pz[c][2], A[3]);
+        } else {
+          A[0] = fmaf(Ws, q0 + Pz[c][0], A[0]);
+          A[1] = fmaf(Ws, q1 + Pz[c][1], A[1]);
+          A[2] = fmaf(Ws, q2 + Pz[c][2], A[2]);
+        }
+      }
+    }
+}
+
+template <int LW, bool DP> struct RecG {  // fused-step inputs: m, x, F (, logJp)
+  float pos[3], F[9], m, logJp;
+  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
+    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
+    pload<LW, 3>(ps.pos, o, pos);
+    pload<LW, 9>(ps.F, o, F);
+    m = pload1<LW>(ps.mass, o);
+    if constexpr (DP) logJp = pload1<LW>(ps.logJp, o);
+  }
+};
+
+// W = wave index: phase 1 handles round 4c + W; phase 2 role: waves 0/1 take mass + momentum of staged rounds {0,1} / {2,3},
+// waves 2/3 the stress channels of rounds {0,1} / {2,3}; waves 0,2 accumulate into arena 0, waves 1,3 into arena 1
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W>
+__device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
+                                           int lane, const float *varena, float *parena, float *stage, unsigned long long *smask,
+                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount) {
+  using AL = ArenaLds;
+  constexpr bool DP = SMODEL == ZS_MPM_DRUCKER_PRAGER;
+  constexpr bool STRESS = W >= 2;
+  constexpr int NCH = STRESS ? 3 : 4;
+  constexpr int R0 = (W & 1) * 2;  // first of this wave's two staged rounds in phase 2
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const float dxi = 1.0f / mp.dx;
+  const float D_inv = 4.f * dxi * dxi;
+  const float kscale = -mp.dt * D_inv;
+  const float *v0 = varena + AL::at(cx, cy, cz);
+  float acc[27][NCH];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc[k][q] = 0.f;
+  RoundWalk walk(cnt, start);
+  auto next_chunk = [&](int &idx, bool &has, bool &any) {
+    any = false;
+    has = false;
+    idx = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int i;
+      bool a;
+      const bool h = walk.next(i, a);
+      if (r == 0) any = a;
+      if (r == W) {
+        idx = i;
+        has = h;
+      }
+    }
+  };
+  int i0, i1;
+  bool has0, has1, any, any1;
+  next_chunk(i0, has0, any);
+  RecG<LW, DP> cur, nxt;
+  if (has0) cur.load(ps, (size_t)i0);
+  float *myStage = stage + (size_t)W * (G2P2G_NF * 64);
+  while (any) {
+    next_chunk(i1, has1, any1);
+    if (has1) nxt.load(ps, (size_t)i1);  // in flight during this chunk
+    // ---------------- phase 1: G2P + update of this wave's round
+    bool valid = false;
+    if (has0) {
+      Arena ar;
+      make_arena(mp.dx, cur.pos, ar);
+      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
+        staleG[atomicAdd(staleGCount, 1)] = i0;  // mis-binned: exact gather + scatter afterwards
+      } else {
+        float vel[3], C[9];
+        g2p_gather_lds(mp, ar, v0, D_inv, vel, C);
+        const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
+        float pos[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
+        float tmp[9], F[9], PF[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * cur.F[3 * c] + tmp[r + 3] * cur.F[3 * c + 1] + tmp[r + 6] * cur.F[3 * c + 2];
+        pstore<LW, 9>(ps.F, o, F);
+        pstore<LW, 3>(ps.pos, o, pos);
+        if constexpr (SMODEL == ZS_MPM_FIXED_COROTATED) {
+          stress_fixedcorotated(mp.mat, F, PF);
+        } else {
+          float lj = cur.logJp;
+          stress_sand<false>(mp.mat, lj, F, PF);
+          pstore1<LW>(ps.logJp, o, lj);
+        }
+        bool moved = false;  // does the particle still belong to this lane's cell?
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int corner = (int)floorf(pos[d] * dxi - 0.5f);
+          moved = moved || (corner - geo.org[d] != (d == 0 ? cx : (d == 1 ? cy : cz)));
+        }
+        if (WRITE_ALL || moved) {
+          pstore<LW, 3>(ps.vel, o, vel);
+          pstore<LW, 9>(ps.C, o, C);
+          pstore<LW, 9>(ps.stress, o, PF);
+        }
+        if (moved) {
+          staleP[atomicAdd(stalePCount, 1)] = i0;  // left the cell during this step: exact scatter afterwards
+        } else {
+          valid = true;
+          myStage[0 * 64 + lane] = cur.m;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = pos[d];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
+#pragma unroll
+          for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
+#pragma unroll
+          for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
+        }
+      }
+    }
+    {
+      const unsigned long long vm = __ballot(valid);
+      if (lane == 0) smask[W] = vm;
+    }
+    __syncthreads();
+    // ---------------- phase 2: two staged rounds per wave, 4 (mass + momentum) or 3 (stress) channels
+#pragma unroll 1
+    for (int rr = R0; rr < R0 + 2; ++rr) {
+      const unsigned long long vm = smask[rr];
+      if (vm == 0ull) continue;
+      if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)rr * (G2P2G_NF * 64), lane, kscale, acc);
+    }
+    __syncthreads();  // the stage is free again
+    cur = nxt;
+    has0 = has1;
+    i0 = i1;
+    any = any1;
+  }
+  float *a0 = parena + (size_t)(W & 1) * (7 * AL::CH) + AL::at(cx, cy, cz);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) g[((STRESS ? 4 : 0) + q) * AL::CH] += acc[k][q];
+    __syncthreads();
+  }
+}
+
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL>
+__global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
+                                                           const int *binStart, const unsigned *cellCount, const int *nbr, int *staleG,
+                                                           int *staleGCount, int *staleP, int *stalePCount) {
+  using AL = ArenaLds;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  __shared__ float varena[3 * AL::CH];
+  __shared__ float parena[2 * 7 * AL::CH];
+  __shared__ float stage[4 * G2P2G_NF * 64];
+  __shared__ unsigned long long smask[4];
+  const int bin = blockIdx.x;
+  const int start = binStart[bin], end = binStart[bin + 1];
+  if (start == end) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  if (tid < 216) {  // node decoded once for the 3 velocity channels
+    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
+    int slot, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+    const int bn = nbr[(size_t)geo.block * 8 + slot];
+    float *a = varena + AL::at(x, y, z);
+    const float *g = gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
+  }
+  for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
+  __syncthreads();
+  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
+  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
+  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
+  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
+  if (tid < 216) {
+    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
+    int slot, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+    const int bn = nbr[(size_t)geo.block * 8 + slot];
+    if (bn >= 0) {
+      const float *a = parena + AL::at(x, y, z);
+      float *g = gridB + (size_t)bn * 7 * NC + cell;
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        const float v = a[ch * AL::CH] + a[(7 + ch) * AL::CH];
+        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
+      }
+    }
+  }
+}
+// queue G: gather from grid A with hash queries (stores the full state), then scatter to grid B; queue P: scatter only
+template <int SIDE, int SMODEL>
+__global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
+                                                          const int *staleG, const int *staleGCount, const int *staleP,
+                                                          const int *stalePCount) {
+  const int ng = *staleGCount, np = *stalePCount;
+  const float dxi = 1.0f / mp.dx;
+  const float D_inv = 4.f * dxi * dxi;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ng + np; j += gridDim.x * blockDim.x) {
+    const size_t i = (size_t)(j < ng ? staleG[j] : staleP[j - ng]);
+    if (j < ng) g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, gridA, D_inv);
+    p2g_scatter_global<SIDE, MPM_CACHED_STRESS>(mp, ps, i, t, gridB, D_inv);
+  }
 }
 
 // stand-alone constitutive update (first step, or after the host changed F / logJp)
@@ -1557,6 +2110,18 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
     const int lw = uniform_lane_width(ps, p->model == ZS_MPM_DRUCKER_PRAGER && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
+    // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
+    static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
+    if (kmodel == MPM_CACHED_STRESS && !split4) {
+#define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
+  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, \
+                     staleCount);                                                                                                      \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+                     (const int *)staleCount)
+      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
+      else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
+      return;
+    }
     if (kmodel == MPM_CACHED_STRESS) {
 #define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
   hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
@@ -1624,6 +2189,43 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
   hipLaunchKernelGGL((g2p_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
     ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_GLOBAL);
   }
+}
+
+// G2P (from gridA) + P2G (into gridB, zeroed by the caller) in one pass; `particles.stress` must be present (it carries the
+// state of the particles that take the exact path).  writeAll != 0 also stores v, C and P F^T vol of every particle.
+int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                      float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll) {
+  if (!ps.n || !nblocks) return 0;
+  if (!ps.stress.base || !binStart || !cellCount || !nbr) {
+    fprintf(stderr, "[zs_rocm] g2p2g needs binned particles and the `stress` attribute\n");
+    return -1;
+  }
+  Launch L(pol, "G2P2GTransfer");
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+  int *staleG = (int *)L.temp(sizeof(int) * (ps.n + 64));
+  int *staleP = (int *)L.temp(sizeof(int) * (ps.n + 64));
+  int *counts = (int *)L.temp(sizeof(int) * 64);
+  ZSR_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 64, L.stream));
+  const int lw = uniform_lane_width(ps, p->model == ZS_MPM_DRUCKER_PRAGER, true);
+#define CALL_G2P2G4(S, M, LWv, WA)                                                                                                    \
+  hipLaunchKernelGGL((g2p2g_binned_kernel<S, M, LWv, WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, binStart,     \
+                     cellCount, nbr, staleG, counts, staleP, counts + 32);                                                            \
+  hipLaunchKernelGGL((g2p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, (const int *)staleG,      \
+                     (const int *)counts, (const int *)staleP, (const int *)(counts + 32))
+#define CALL_G2P2G3(S, M, LWv)          \
+  do {                                  \
+    if (writeAll) { CALL_G2P2G4(S, M, LWv, true); } \
+    else { CALL_G2P2G4(S, M, LWv, false); }         \
+  } while (0)
+#define CALL_G2P2G(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P2G3, S, M)
+  if (p->side == 4 && p->model == ZS_MPM_FIXED_COROTATED) { CALL_G2P2G(4, ZS_MPM_FIXED_COROTATED); }
+  else if (p->side == 4) { CALL_G2P2G(4, ZS_MPM_DRUCKER_PRAGER); }
+  else if (p->model == ZS_MPM_FIXED_COROTATED) { CALL_G2P2G(8, ZS_MPM_FIXED_COROTATED); }
+  else { CALL_G2P2G(8, ZS_MPM_DRUCKER_PRAGER); }
+  return 0;
 }
 
 void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {

@@ -163,6 +163,22 @@ class MpmTransfer:
         lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
                               self.nblocks, bs, cc, nb)
 
+    def g2p2g(self, write_all=False):
+        """Fused G2P (from self.grid) + P2G (into a zeroed second grid, which then becomes self.grid): zs_rocm_mpm_g2p2g.
+        Needs cache_stress=True and binned particles."""
+        if not (self.cache_stress and self.binned):
+            raise RuntimeError("g2p2g needs cache_stress=True and rebin()")
+        if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
+            self.grid2 = torch.zeros_like(self.grid)
+        else:
+            self.grid2.zero_()
+        rc = lib().zs_rocm_mpm_g2p2g(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
+                                     self.grid2.data_ptr(), self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
+                                     self.nbr.data_ptr(), int(write_all))
+        if rc != 0:
+            raise RuntimeError("zs_rocm_mpm_g2p2g refused the call")
+        self.grid, self.grid2 = self.grid2, self.grid
+
     def grid_by_key(self):
         """{(bx,by,bz): ndarray[7, side^3]} -- for comparisons that must not depend on block numbering."""
         v = self.table.view()
