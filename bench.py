@@ -49,9 +49,9 @@ def parse():
     ap.add_argument("--unbinned", action="store_true", help="particle-order path (reference algorithm) instead of the binned path")
     ap.add_argument("--no-cache-stress", action="store_true",
                     help="evaluate the constitutive model inside P2G (reference order) instead of in the tail of the previous G2P")
-    ap.add_argument("--fused", action="store_true",
-                    help="one fused G2P2G pass per step (G2P of step n + P2G of step n+1; v, C, stress stay on chip) instead of "
-                         "separate P2G and G2P kernels")
+    ap.add_argument("--unfused", action="store_true",
+                    help="separate P2G and G2P kernels per step instead of the fused G2P2G pass (G2P of step n + P2G of step n+1 in "
+                         "one kernel; v, C, stress stay on chip)")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -147,6 +147,7 @@ def cpu_baseline(sample, dx, dt, model, side, vol):
 
 def main():
     a = parse()
+    a.fused = not (a.unfused or a.unbinned or a.no_cache_stress)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -357,7 +358,7 @@ def main():
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
                        "rebin_ms_once": rebin_ms},
-            "roofline": {"bound": "hbm", "kernel": "p2g_binned_kernel" if not a.unbinned else "p2g_global_kernel",
+            "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
                          "constitutive_update": "tail of previous G2P (particles.stress)" if mt.cache_stress else "inside P2G",
@@ -366,9 +367,11 @@ def main():
             "hip_error": err,
         }
         if a.fused:
-            # fused pass: reads m, x, F (, logJp) = 52 (56) B, writes x, F (, logJp) = 48 (52) B, grid A velocities 1.5 B and
-            # grid B clear + accumulate 7 B per particle at 8 particles per node
-            fb = (56.0 + 52.0 if model == 1 else 52.0 + 48.0) + 1.5 + 7.0
+            # algorithmic bytes of the work one launch does = one G2P + one P2G per particle: SURVEY.md 8(d), 145.5 + 107 (115
+            # with logJp) B.  What the fused pass actually has to move is less: m, x, F (, logJp) in (52 / 56 B), x, F (, logJp)
+            # out (48 / 52 B), grid A velocities 1.5 B, grid B clear + accumulate 7 B
+            fb = 260.5 if model == 1 else 252.5
+            fmin = (56.0 + 52.0 if model == 1 else 52.0 + 48.0) + 1.5 + 7.0
             fach = fb * n_local / (fused_ms * 1e-3) / 1e9
             ftraffic = None
             pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json")
@@ -384,9 +387,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "g2p2g_binned_kernel", "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": fach / HBM_PEAK_GBS, "traffic": ftraffic, "bytes_per_particle": fb,
                                "particles_per_launch": n_local, "launch_ms": fused_ms,
-                               "note": "VALU-limited (per-particle 3x3 SVD + 27-node stencils), not HBM-limited: the fused pass moves "
-                                       "116.5 B per particle instead of the 296.5 B of separate P2G + G2P kernels",
-                               "unfused_bytes_per_particle": 296.5 if model == 1 else 288.5}
+                               "fused_min_bytes_per_particle": fmin,
+                               "note": "bytes_per_particle = SURVEY 8(d) P2G + G2P; the fused pass keeps v, C and the stress on chip "
+                                       "(traffic < algorithmic bytes) and is VALU-limited: SQ_INSTS_VALU x 4 cycles = 81 % of the SIMD "
+                                       "cycles (profiles/r01_pmc_g2p2g.md)"}
         if checksum is not None:
             out["checksum"] = checksum
         if world == 1 and not a.no_cpu_baseline:

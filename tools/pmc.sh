@@ -9,7 +9,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$R/gpurun_out/pmc_$tag/$name
   mkdir -p $out
-  rocprofv3 --kernel-trace --kernel-include-regex "binned_kernel|binned_split|tv_scale" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py $args > $out/bench.json 2> $out/stderr.txt
+  rocprofv3 --kernel-trace --kernel-include-regex "binned_kernel|binned_split|wide_kernel|tv_scale" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py $args > $out/bench.json 2> $out/stderr.txt
   f=$(find $out -name '*counter_collection.csv' | head -1)
   echo "== $grp -> $f"
   python3 - "$f" <<'PY'
@@ -19,14 +19,17 @@ if not f: sys.exit(0)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r.get("Kernel_Name", "")
-    if "p2g_binned" in k or "g2p_binned" in k or "tv_scale" in k:
-        k = k.split("(")[0]
-        short = "p2g_binned" if "p2g_binned" in k else ("g2p_binned" if "g2p_binned" in k else "tv_scale")
+    short = None
+    for tag in ("g2p2g_binned", "p2g_wide", "p2g_binned_split", "p2g_binned", "g2p_binned", "tv_scale"):
+        if tag in k:
+            short = tag
+            break
+    if short:
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     for c in acc[k]:
         v = acc[k][c]
-        print("%-12s %-24s n=%d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+        print("%-18s %-24s n=%d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
 PY
   find $out -name '*.csv' -size +8M -delete
 done

@@ -1687,8 +1687,9 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
   next_chunk(i0, has0, any);
   RecG<LW, DP> cur, nxt;
   if (has0) cur.load(ps, (size_t)i0);
-  float *myStage = stage + (size_t)W * (G2P2G_NF * 64);
+  int par = 0;  // stage / mask buffer of this chunk (double buffered: ONE barrier per chunk)
   while (any) {
+    float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
     next_chunk(i1, has1, any1);
     if (has1) nxt.load(ps, (size_t)i1);  // in flight during this chunk
     // ---------------- phase 1: G2P + update of this wave's round
@@ -1750,17 +1751,17 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     }
     {
       const unsigned long long vm = __ballot(valid);
-      if (lane == 0) smask[W] = vm;
+      if (lane == 0) smask[par * 4 + W] = vm;
     }
-    __syncthreads();
+    __syncthreads();  // this chunk is staged; everybody has finished consuming the chunk before the previous one
     // ---------------- phase 2: two staged rounds per wave, 4 (mass + momentum) or 3 (stress) channels
 #pragma unroll 1
     for (int rr = R0; rr < R0 + 2; ++rr) {
-      const unsigned long long vm = smask[rr];
+      const unsigned long long vm = smask[par * 4 + rr];
       if (vm == 0ull) continue;
-      if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)rr * (G2P2G_NF * 64), lane, kscale, acc);
+      if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
     }
-    __syncthreads();  // the stage is free again
+    par ^= 1;
     cur = nxt;
     has0 = has1;
     i0 = i1;
@@ -1784,8 +1785,8 @@ __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesD
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float varena[3 * AL::CH];
   __shared__ float parena[2 * 7 * AL::CH];
-  __shared__ float stage[4 * G2P2G_NF * 64];
-  __shared__ unsigned long long smask[4];
+  __shared__ float stage[2 * 4 * G2P2G_NF * 64];
+  __shared__ unsigned long long smask[2 * 4];
   const int bin = blockIdx.x;
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
