@@ -481,17 +481,32 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
     tileStart[t] = s - myCount;
     // look back over the predecessors' descriptors of digit t
     if (tile != 0) {
+      // look back over the predecessors' descriptors of digit t, LB tiles per round trip: the loads of one batch are
+      // independent, so a walk over many aggregate-only tiles (the tiles that started together with this one) costs one L2
+      // latency per batch instead of one per tile
+      constexpr int LB = 8;
       long long p = (long long)tile - 1;
-      while (true) {
-        const unsigned v = __hip_atomic_load(desc + (size_t)p * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned f = v & ~OS_VAL_MASK;
-        if (f == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          continue;
+      bool done = false;
+      while (!done) {
+        unsigned v[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+          v[j] = p - j >= 0 ? __hip_atomic_load(desc + (size_t)(p - j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : OS_FLAG_PREFIX;  // before tile 0: an empty inclusive prefix
+        int used = 0;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          if (!done && used == j) {
+            const unsigned f = v[j] & ~OS_VAL_MASK;
+            if (f != 0) {
+              excl += v[j] & OS_VAL_MASK;
+              ++used;
+              done = f == OS_FLAG_PREFIX;
+            }
+          }
         }
-        excl += v & OS_VAL_MASK;
-        if (f == OS_FLAG_PREFIX) break;
-        --p;
+        p -= used;
+        if (!done && used < LB) __builtin_amdgcn_s_sleep(1);  // ran into a tile that has not published yet
       }
       __hip_atomic_store(myDesc, OS_FLAG_PREFIX | (excl + myCount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
