@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="separate P2G and G2P kernels per step instead of the fused G2P2G pass (G2P of step n + P2G of step n+1 in "
                          "one kernel; v, C, stress stay on chip)")
+    ap.add_argument("--migrate-every", type=int, default=0,
+                    help="every K steps: move particles to the rank that owns their cell, rebuild partition / halo lists / bins "
+                         "(0 = never; the default bench window moves particles < 0.1 cell)")
+    ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -182,6 +186,10 @@ def main():
 
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
+    drift = [float(x) for x in a.drift.split(",")]
+    for k in range(3):
+        if drift[k] != 0.0:
+            aos[:, 4 + k] += drift[k]
     n_local = aos.shape[0]
     mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device,
                      cache_stress=not a.no_cache_stress)
@@ -198,15 +206,39 @@ def main():
     rebin_ms = (time.perf_counter() - t0) * 1e3
     mt.update_stress()  # constitutive state for the first P2G (later ones get it from the preceding G2P)
 
-    # ---- halo exchange setup
-    halo = None
+    # ---- halo exchange setup (re-run after every re-partition)
     nc = a.side ** 3
-    if world > 1:
-        hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL("libamdhip64.so")
+    stage = {}
+
+    def dev_buf(buf):
+        if buf.device.type != "cpu":
+            return buf
+        if buf.data_ptr() not in stage:
+            stage[buf.data_ptr()] = torch.empty(buf.numel(), dtype=torch.float32, device=device)
+        return stage[buf.data_ptr()]
+
+    def pack(blocks, nb, buf):
+        d = dev_buf(buf)
+        lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
+        if d is not buf:
+            buf.copy_(d)  # gloo validation path: stage through host memory
+
+    def unpack_add(blocks, nb, buf):
+        d = dev_buf(buf)
+        if d is not buf:
+            d.copy_(buf)
+        lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
+
+    def make_halo():
+        if world == 1:
+            return None
+        nb_ = mt.nblocks
         v = mt.table.view()
-        keys = torch.empty(nblocks * 3, dtype=torch.int32, device=device)
-        hip.hipMemcpy(C.c_void_p(keys.data_ptr()), C.c_void_p(v.activeKeys), C.c_size_t(nblocks * 12), 3)
-        my_keys = keys.cpu().numpy().reshape(nblocks, 3)
+        keys = torch.empty(max(nb_, 1) * 3, dtype=torch.int32, device=device)
+        if nb_:
+            hip.hipMemcpy(C.c_void_p(keys.data_ptr()), C.c_void_p(v.activeKeys), C.c_size_t(nb_ * 12), 3)
+        my_keys = keys.cpu().numpy()[: nb_ * 3].reshape(nb_, 3)
 
         def lookup(sk):
             d = torch.from_numpy(np.ascontiguousarray(sk)).to(device)
@@ -215,28 +247,10 @@ def main():
             torch.cuda.synchronize()
             return r.cpu().numpy()
 
-        halo = HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
+        return HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
                             lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), 7 * nc)
-        stage = {}
 
-        def dev_buf(buf):
-            if buf.device.type != "cpu":
-                return buf
-            if buf.data_ptr() not in stage:
-                stage[buf.data_ptr()] = torch.empty(buf.numel(), dtype=torch.float32, device=device)
-            return stage[buf.data_ptr()]
-
-        def pack(blocks, nb, buf):
-            d = dev_buf(buf)
-            lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
-            if d is not buf:
-                buf.copy_(d)  # gloo validation path: stage through host memory
-
-        def unpack_add(blocks, nb, buf):
-            d = dev_buf(buf)
-            if d is not buf:
-                d.copy_(buf)
-            lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
+    halo = make_halo()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     p2g_ev, g2p_ev = [], []
@@ -277,16 +291,39 @@ def main():
             halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
 
-    if a.fused:
-        if a.unbinned or not mt.cache_stress:
-            raise SystemExit("--fused needs the binned path with cached stress")
+    migrated = 0
+
+    def prime_grid():
         mt.clear_grid()
         mt.p2g()
         if halo is not None:
             halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
+
+    def remap():
+        """particles -> owning ranks, new partition / halo lists / bins (full particle state must be in memory)"""
+        nonlocal halo, nblocks, migrated
+        from zpc_amd.dist import migrate_particles
+        moved = (0, 0)
+        if world > 1:
+            to_c = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
+            moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device))
+        nblocks = mt.build_partition(max(4096, mt.n // 128))
+        if not a.unbinned:
+            mt.rebin()
+        stage.clear()
+        halo = make_halo()
+        if a.fused:
+            prime_grid()
+        migrated += moved[0]
+        return moved
+
+    if a.fused:
+        if a.unbinned or not mt.cache_stress:
+            raise SystemExit("--fused needs the binned path with cached stress")
+        prime_grid()
         unfused_step = step
-        step = lambda timed: step_fused(timed)
+        step = lambda timed, write_all=False: step_fused(timed, write_all)
 
     def barrier():
         torch.cuda.synchronize()
@@ -294,12 +331,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step(False)
+    K = a.migrate_every
+    done = 0
+
+    def run_steps(count, timed):
+        nonlocal done
+        for _ in range(count):
+            remap_now = K > 0 and (done + 1) % K == 0
+            if a.fused:
+                step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
+            else:
+                step(timed)
+            done += 1
+            if remap_now:
+                remap()
+
+    run_steps(a.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
+    run_steps(a.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     if a.fused and a.checksum:
@@ -307,6 +357,7 @@ def main():
         torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
 
+    n_local = mt.n
     n_total = n_local
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -357,7 +408,7 @@ def main():
                           "" if not a.unbinned else " [particle-order path]"),
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
-                       "rebin_ms_once": rebin_ms},
+                       "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,

@@ -300,6 +300,10 @@ ZS_ROCM_EXPORT void zs_rocm_tv_from_aos_f32(zs_rocm_policy *, const float *aos, 
 ZS_ROCM_EXPORT void zs_rocm_tv_to_aos_f32(zs_rocm_policy *, const float *tv, size_t n, int C, int L, float *aos);
 /* load every channel, scale by `alpha`, store back (BASELINE config 2 "AoSoA load/store": 8*C bytes/element) */
 ZS_ROCM_EXPORT void zs_rocm_tv_scale_f32(zs_rocm_policy *, float *tv, size_t n, int C, int L, float alpha);
+/* rows map[j] of an AoSoA buffer -> AoS rows j, and AoS rows j -> elements dstOffset + j of an AoSoA buffer: the pack / unpack
+ * of the inter-rank particle migration ("ncclSend/Recv of AoSoA tiles after a per-destination radix partition") */
+ZS_ROCM_EXPORT void zs_rocm_tv_gather_rows_f32(zs_rocm_policy *, const float *tv, const int *map, size_t m, int C, int L, float *aos);
+ZS_ROCM_EXPORT void zs_rocm_tv_scatter_rows_f32(zs_rocm_policy *, const float *aos, size_t m, int C, int L, float *tv, size_t dstOffset);
 ZS_ROCM_EXPORT void zs_rocm_tv_gather_f32(zs_rocm_policy *, const float *src, float *dst, size_t n, int C, int L, const int *map);
 
 /* ======================================================================== (A) bht */
@@ -551,6 +555,11 @@ ZS_ROCM_EXPORT void zs_rocm_svd3(zs_rocm_policy *, const float *F, size_t n, flo
  * zpc has no collective layer).  pack: buf[i][c][k] = grid[blocks[i]][chn0+c][k];
  * unpack: add = 0 set, 1 add (every block listed once), 2 atomic add (a block may be listed several times: concatenated
  * messages of several peers). */
+/* owner rank of every particle for the block-aligned spatial split of the multi-GPU driver: cell = floor(x / dx) clamped to
+ * [lo, hi); axis d is cut into dims[d] slabs at lo + (len k / dims[d]) rounded down to a multiple of `align` cells;
+ * rank = (r0 * dims[1] + r1) * dims[2] + r2 */
+ZS_ROCM_EXPORT void zs_rocm_mpm_owner_rank(zs_rocm_policy *, zs_rocm_attr pos, size_t n, float dx, const int lo[3], const int hi[3],
+                                           const int dims[3], int align, int *owner);
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_pack(zs_rocm_policy *, const float *grid, const int *blocks, size_t nb, int side,
                                           int chn0, int nchn, float *buf);
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_unpack(zs_rocm_policy *, float *grid, const int *blocks, size_t nb, int side,

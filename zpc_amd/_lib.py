@@ -212,6 +212,8 @@ def _declare_containers(L):
     L.zs_rocm_tv_to_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_scale_f32.argtypes = [vp, vp, sz, i32, i32, f32]
     L.zs_rocm_tv_gather_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_tv_gather_rows_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_tv_scatter_rows_f32.argtypes = [vp, vp, sz, i32, i32, vp, sz]
     for D, B in ((d, b) for d in (1, 2, 3, 4) for b in (16, 32)):
         s = "bht_int_%d_int_%d" % (D, B)
         for sfx in ("", "_virtual"):
@@ -280,6 +282,7 @@ def _declare_containers(L):
     L.zs_rocm_mpm_bin_particles.argtypes = [vp, vp, Port, sz, f32, i32, i32, vp, vp, vp]
     L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp, i32]
     L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_mpm_owner_rank.argtypes = [vp, Port, sz, f32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]
     L.zs_rocm_mpm_g2p2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

@@ -345,6 +345,40 @@ __global__ void tv_to_aos_kernel(const float *tv, size_t n, int C, int lbits, fl
   for (int k = threadIdx.x; k < cnt * C; k += blockDim.x) aos[i0 * (size_t)C + k] = sm[k];
 }
 
+// rows map[j] of an AoSoA buffer -> AoS rows j (send buffers of the particle migration); 64 rows per block through LDS so that
+// both sides are coalesced
+__global__ void tv_gather_rows_kernel(const float *tv, const int *map, size_t m, int C, int lbits, float *aos) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int cnt = (int)(m - j0 < 64 ? m - j0 : 64);
+  const size_t L = (size_t)1 << lbits;
+  for (int k = threadIdx.x; k < 64 * C; k += blockDim.x) {
+    const int c = k >> 6, l = k & 63;
+    if (l < cnt) {
+      const size_t i = (size_t)map[j0 + l];
+      sm[l * C + c] = tv[(((i >> lbits) * (size_t)C + c) << lbits) | (i & (L - 1))];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cnt * C; k += blockDim.x) aos[j0 * (size_t)C + k] = sm[k];
+}
+// AoS rows j -> elements dstOffset + j of an AoSoA buffer (received particles appended behind the kept ones)
+__global__ void tv_scatter_rows_kernel(const float *aos, size_t m, int C, int lbits, float *tv, size_t dstOffset) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int cnt = (int)(m - j0 < 64 ? m - j0 : 64);
+  const size_t L = (size_t)1 << lbits;
+  for (int k = threadIdx.x; k < cnt * C; k += blockDim.x) sm[k] = aos[j0 * (size_t)C + k];
+  __syncthreads();
+  for (int k = threadIdx.x; k < 64 * C; k += blockDim.x) {
+    const int c = k >> 6, l = k & 63;
+    if (l < cnt) {
+      const size_t i = dstOffset + j0 + l;
+      tv[(((i >> lbits) * (size_t)C + c) << lbits) | (i & (L - 1))] = sm[l * C + c];
+    }
+  }
+}
+
 // BASELINE config 2 "TileVector AoSoA load/store": read every channel of every element, scale, write back.
 // The buffer of whole tiles is contiguous, so the AoSoA sweep is a flat 16-byte-per-lane stream.
 __global__ __launch_bounds__(256) void tv_scale_kernel(float4 *buf, size_t nvec, float alpha) {
@@ -640,6 +674,18 @@ void zs_rocm_tv_scale_f32(zs_rocm_policy *pol, float *tv, size_t n, int C, int L
   if (!nvec) return;
   unsigned grid = (unsigned)std::min<size_t>(ceil_div(nvec, 256), 256 * 16);
   hipLaunchKernelGGL(tv_scale_kernel, dim3(grid), dim3(256), 0, L.stream, (float4 *)tv, nvec, alpha);
+}
+void zs_rocm_tv_gather_rows_f32(zs_rocm_policy *pol, const float *tv, const int *map, size_t m, int C, int Lw, float *aos) {
+  Launch L(pol, "tv_gather_rows");
+  if (!m) return;
+  hipLaunchKernelGGL(tv_gather_rows_kernel, dim3(ceil_div(m, 64)), dim3(256), 64 * C * sizeof(float), L.stream, tv, map, m, C,
+                     log2i((size_t)Lw), aos);
+}
+void zs_rocm_tv_scatter_rows_f32(zs_rocm_policy *pol, const float *aos, size_t m, int C, int Lw, float *tv, size_t dstOffset) {
+  Launch L(pol, "tv_scatter_rows");
+  if (!m) return;
+  hipLaunchKernelGGL(tv_scatter_rows_kernel, dim3(ceil_div(m, 64)), dim3(256), 64 * C * sizeof(float), L.stream, aos, m, C,
+                     log2i((size_t)Lw), tv, dstOffset);
 }
 void zs_rocm_tv_gather_f32(zs_rocm_policy *pol, const float *src, float *dst, size_t n, int C, int Lw, const int *map) {
   Launch L(pol, "tv_gather");

@@ -1882,6 +1882,32 @@ __global__ void svd_kernel(const float *F, size_t n, float *U, float *S, float *
 #pragma unroll
   for (int d = 0; d < 3; ++d) S[3 * i + d] = s[d];
 }
+// owner rank of every particle under the block-aligned box split of zpc_amd/dist.py (cell_box): cell = floor(x / dx) clamped to
+// the global box; along axis d the box [lo, hi) is cut at lo + (n k / dims) rounded down to a multiple of `align`
+struct OwnerSplit {
+  int lo[3], hi[3], dims[3], align;
+};
+__global__ __launch_bounds__(256) void owner_rank_kernel(Port<float> pos, size_t n, float dxinv, OwnerSplit sp, int *owner) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[3];
+  load_attr<3>(pos, i, p);
+  int rc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int c = (int)floorf(p[d] * dxinv);
+    c = c < sp.lo[d] ? sp.lo[d] : (c >= sp.hi[d] ? sp.hi[d] - 1 : c);
+    const int len = sp.hi[d] - sp.lo[d];
+    int r = 0;
+    for (int k = 1; k < sp.dims[d]; ++k) {
+      int cut = sp.lo[d] + (int)(((long long)len * k) / sp.dims[d]);
+      cut = floordiv(cut, sp.align) * sp.align;
+      r += c >= cut;
+    }
+    rc[d] = r;
+  }
+  owner[i] = (rc[0] * sp.dims[1] + rc[1]) * sp.dims[2] + rc[2];
+}
 __global__ void halo_pack_kernel(const float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, float *buf) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)nchn * nc;
@@ -2255,6 +2281,15 @@ void zs_rocm_svd3(zs_rocm_policy *pol, const float *F, size_t n, float *U, float
   hipLaunchKernelGGL(svd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, F, n, U, S, V);
 }
 
+void zs_rocm_mpm_owner_rank(zs_rocm_policy *pol, zs_rocm_attr pos, size_t n, float dx, const int lo[3], const int hi[3], const int dims[3],
+                            int align, int *owner) {
+  Launch L(pol, "owner_rank");
+  if (!n) return;
+  OwnerSplit sp;
+  for (int d = 0; d < 3; ++d) { sp.lo[d] = lo[d]; sp.hi[d] = hi[d]; sp.dims[d] = dims[d]; }
+  sp.align = align < 1 ? 1 : align;
+  hipLaunchKernelGGL(owner_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, make_port<float>(pos), n, 1.0f / dx, sp, owner);
+}
 void zs_rocm_mpm_halo_pack(zs_rocm_policy *pol, const float *grid, const int *blocks, size_t nb, int side, int chn0, int nchn, float *buf) {
   Launch L(pol, "halo_pack");
   const int nc = side * side * side;

@@ -122,3 +122,65 @@ class HaloExchange:
         for w in d.batch_isend_irecv(ops):
             w.wait()
         unpack_add(self.blocks_all, self.total_blocks, self.recvbuf)
+
+
+def migrate_particles(mt, pol, dist, rank, world_size, glo, ghi, align, to_comm=None, from_comm=None):
+    """Move every particle to the rank that owns the cell it is in now.  `mt` is a MpmTransfer whose full
+    particle state is in memory (after g2p / g2p2g(write_all=True)).  Device work is done by libzsrocm kernels:
+    owner classification, a stable radix partition of the particle ids by destination, AoSoA -> AoS row gather into the send
+    buffer, AoSoA compaction of the kept rows and AoS -> AoSoA scatter of the received rows; torch.distributed moves the
+    bytes (all_to_all_single with uneven splits = ncclSend/ncclRecv groups over the xGMI links).
+    Returns (n_sent, n_received).  After it the caller rebuilds partition, halo lists and bins."""
+    import ctypes as C
+    import torch
+    from ._lib import lib
+    from .primitives import radix_sort_pair
+    L = lib()
+    n, nchn, lw, dev = mt.n, mt.nchn, mt.L, mt.device
+    if world_size == 1:
+        return 0, 0
+    dims = split_dims(world_size)
+    owner = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    lo3, hi3, d3 = (C.c_int * 3)(*glo), (C.c_int * 3)(*ghi), (C.c_int * 3)(*dims)
+    L.zs_rocm_mpm_owner_rank(pol.handle, mt._port("x"), n, mt.params.dx, lo3, hi3, d3, int(align), owner.data_ptr())
+    ids = torch.arange(max(n, 1), dtype=torch.int32, device=dev)
+    so, order = torch.empty_like(owner), torch.empty_like(ids)
+    bits = max(1, (world_size - 1).bit_length())
+    if n:
+        radix_sort_pair(pol, owner, ids, so, order, n=n, sbit=0, ebit=bits)  # stable: ids ascend inside a destination
+    pol.syncCtx()
+    counts = torch.bincount(so[:n].long(), minlength=world_size).cpu().tolist() if n else [0] * world_size
+    starts = [0]
+    for c in counts:
+        starts.append(starts[-1] + c)
+    keep = order[starts[rank]:starts[rank + 1]]
+    leave = torch.cat([order[starts[p]:starts[p + 1]] for p in range(world_size) if p != rank]) if n else order[:0]
+    n_keep, n_leave = int(keep.numel()), int(leave.numel())
+    send_rows = [counts[p] if p != rank else 0 for p in range(world_size)]
+    sendbuf = torch.empty(max(n_leave, 1) * nchn, dtype=torch.float32, device=dev)
+    if n_leave:
+        leave = leave.contiguous()
+        L.zs_rocm_tv_gather_rows_f32(pol.handle, mt.buf.data_ptr(), leave.data_ptr(), n_leave, nchn, lw, sendbuf.data_ptr())
+    pol.syncCtx()
+    to_comm = to_comm or (lambda t: t)
+    from_comm = from_comm or (lambda t: t)
+    sc = to_comm(torch.tensor(send_rows, dtype=torch.int64, device=dev))
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc)
+    recv_rows = [int(x) for x in rc.cpu().tolist()]
+    n_recv = sum(recv_rows)
+    recvbuf = to_comm(torch.empty(max(n_recv, 1) * nchn, dtype=torch.float32, device=dev))
+    dist.all_to_all_single(recvbuf[: n_recv * nchn], to_comm(sendbuf)[: n_leave * nchn], [r * nchn for r in recv_rows],
+                           [r * nchn for r in send_rows])
+    recvbuf = from_comm(recvbuf)
+    n_new = n_keep + n_recv
+    tiles = (n_new + lw - 1) // lw
+    newbuf = torch.zeros(max(tiles, 1) * lw * nchn, dtype=torch.float32, device=dev)
+    if n_keep:
+        keep = keep.contiguous()
+        L.zs_rocm_tv_gather_f32(pol.handle, mt.buf.data_ptr(), newbuf.data_ptr(), n_keep, nchn, lw, keep.data_ptr())
+    if n_recv:
+        L.zs_rocm_tv_scatter_rows_f32(pol.handle, recvbuf.data_ptr(), n_recv, nchn, lw, newbuf.data_ptr(), n_keep)
+    pol.syncCtx()
+    mt.set_particles(newbuf[: tiles * lw * nchn] if tiles else newbuf[:0], n_new)
+    return n_leave, n_recv

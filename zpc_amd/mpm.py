@@ -60,6 +60,15 @@ class MpmTransfer:
                          self._port("logJp") if self.model == DRUCKER_PRAGER else null,
                          self._port("PF") if self.cache_stress else null, self.n)
 
+    def set_particles(self, buf, n):
+        """Adopt a new AoSoA particle buffer (after an inter-rank migration): the partition and the bins are void."""
+        self.n = int(n)
+        self.tiles = (self.n + self.L - 1) // self.L
+        assert buf.numel() == self.tiles * self.L * self.nchn
+        self.buf, self.buf2 = buf, None
+        self.order = self.bin_start = self.cell_count = None
+        self.binned = False
+
     def update_stress(self):
         """particles.PF := model(F, logJp) * vol (first step / after host edits of F); no-op without cache_stress."""
         lib().zs_rocm_mpm_update_stress(self.pol.handle, C.byref(self.params), self.particles())
