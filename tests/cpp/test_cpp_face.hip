@@ -305,6 +305,35 @@ int main() {
       for (int j = i; j < n; ++j) brute += zsr::aabb_overlaps(hb[j], hb[i]);
     CHECK(2 * brute - n == total);                 // ordered pairs = 2 * unordered (incl. self) - self
     CHECK(selfcnt.data()[0] == (int)brute);        // self iteration reports every unordered pair (and self) once
+    // ray_intersect (Bvh.hpp:521-545) and find_nearest_point (:622-661) vs brute force over the leaves
+    const int nq = 512;
+    Vector<int> hits(nq, memsrc_e::um), nearest(nq, memsrc_e::um);
+    pol(range(nq), [bv = view<space>(bvh), h = view<space>(hits), nn = view<space>(nearest)] ZS_LAMBDA(long long i) {
+      const float t = (float)i / 512.f;
+      const float ro[3] = {-0.1f, t, 0.5f * t + 0.1f}, rd[3] = {1.f, 0.3f - 0.6f * t, 0.2f};
+      int k = 0;
+      bv.ray_intersect(ro, rd, [&](int) { ++k; });
+      h[i] = k;
+      const float p[3] = {t, 1.f - t, 0.5f};
+      int best = -1;
+      bv.find_nearest_point(p, 3.402823466e+38f, &best);
+      nn[i] = best;
+    });
+    for (int i = 0; i < nq; i += 7) {
+      const float t = (float)i / 512.f;
+      const float ro[3] = {-0.1f, t, 0.5f * t + 0.1f}, rd[3] = {1.f, 0.3f - 0.6f * t, 0.2f}, p[3] = {t, 1.f - t, 0.5f};
+      int k = 0, best = -1;
+      float bd = 3.4e38f;
+      for (int j = 0; j < n; ++j) {
+        k += LBvhView::ray_box_intersect(ro, rd, hb[j]);
+        const float x = p[0] - hb[j].lo[0], y = p[1] - hb[j].lo[1], z = p[2] - hb[j].lo[2], d2 = x * x + y * y + z * z;
+        if (d2 < bd) { bd = d2; best = j; }
+      }
+      CHECK(k == hits.data()[i]);
+      const int g = nearest.data()[i];
+      const float gx = p[0] - hb[g].lo[0], gy = p[1] - hb[g].lo[1], gz = p[2] - hb[g].lo[2];
+      CHECK(g >= 0 && gx * gx + gy * gy + gz * gz <= bd * (1.f + 1e-6f));
+    }
   }
   CHECK(zs_rocm_last_error(-1) == 0);
   std::printf("cpp face ok\n");
