@@ -62,6 +62,7 @@ ZS_ROCM_EXPORT float zs_rocm_policy_last_elapsed_ms(const zs_rocm_policy *); /* 
 ZS_ROCM_EXPORT int zs_rocm_last_error(int device);
 ZS_ROCM_EXPORT void zs_rocm_clear_error(int device);
 ZS_ROCM_EXPORT int zs_rocm_device_count(void);
+ZS_ROCM_EXPORT int zs_rocm_current_device(void); /* the calling thread's HIP device (0 without a GPU) */
 /* frees the grow-only per-stream temporary arenas (stand-in for streamMemFree, cuda/Cuda.cu:169-176) */
 /* scratch memory for a caller-side kernel sequence on the policy's stream: the stream-ordered temporary of
  * get_temporary_memory_source(pol) (resource/cuda/ExecutionPolicy.cu:5-16, cuda/memory/Allocator.h:33-50).  One block of
@@ -427,6 +428,11 @@ ZS_ROCM_EXPORT void zs_rocm_lbvh_total_box(zs_rocm_policy *, const zs_rocm_lbvh 
 ZS_ROCM_EXPORT void zs_rocm_lbvh_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, int *counts);
 ZS_ROCM_EXPORT void zs_rocm_lbvh_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, const int *offsets,
                                             int *out);
+/* self-collision broadphase (LBvhView::self_iter_neighbors, container/Bvh.hpp:695-728, driven over every leaf): thread k walks
+ * from the k-th leaf in node order; counts[k] = overlapping leaves AFTER it (the leaf itself is skipped), so every unordered
+ * pair of overlapping primitives appears exactly once.  fill: pairs[2*(offsets[k]+c)] = {primitive of leaf k, other primitive}. */
+ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, int *counts /* [numLeaves] */);
+ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const int *offsets, int *pairs);
 
 /* ======================================================================== (B) MPM transfers */
 /* A particle attribute stored in an AoS zs::Vector<vec<T,N>> (geometry/Structurefree.hpp:21-237) or in

@@ -260,3 +260,29 @@ size_t orc_lbvh_iter_neighbors(const orc_lbvh *b, const float bv[6], int32_t *ou
   }
   return cnt;
 }
+
+/* LBvhView::self_iter_neighbors (container/Bvh.hpp:695-728): the walk starts AT the leaf with sorted index `leafId`; reports the
+   leaf itself and every overlapping leaf after it in node order (ids = primitive indices) */
+size_t orc_lbvh_self_iter_neighbors(const orc_lbvh *b, int32_t leafId, int32_t *out, size_t cap) {
+  size_t cnt = 0;
+  const int32_t numNodes = (int32_t)b->numNodes;
+  if (numNodes <= 2) {
+    const float *bv = b->orderedBvs + 6 * (size_t)leafId;
+    for (int32_t i = leafId + 1; i != numNodes; ++i)
+      if (bv_overlaps(b->orderedBvs + 6 * (size_t)i, bv)) { if (out && cnt < cap) out[cnt] = i; ++cnt; }
+    return cnt;
+  }
+  int32_t node = b->leafInds[leafId];
+  const float *bv = b->orderedBvs + 6 * (size_t)node;
+  while (node != -1 && node != numNodes) {
+    int32_t level = b->levels[node];
+    for (; level; --level, ++node)
+      if (!bv_overlaps(b->orderedBvs + 6 * (size_t)node, bv)) break;
+    if (level == 0) {
+      if (bv_overlaps(b->orderedBvs + 6 * (size_t)node, bv)) { if (out && cnt < cap) out[cnt] = b->auxIndices[node]; ++cnt; }
+      node++;
+    } else
+      node = b->auxIndices[node];
+  }
+  return cnt;
+}

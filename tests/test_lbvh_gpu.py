@@ -97,3 +97,32 @@ def test_iter_neighbors_matches_oracle_order_and_brute_force(pol, oracle, n, dup
             brute = np.nonzero(((bv[:, :3] <= q[k, 3:]) & (bv[:, 3:] >= q[k, :3])).all(1))[0]
             assert np.array_equal(np.sort(mine), brute)
     oracle.orc_lbvh_destroy(b)
+
+
+@pytest.mark.parametrize("n,dup", [(1, 0), (2, 0), (3000, 0), (40_000, 1)])
+def test_self_collision_broadphase_matches_oracle_walk_and_brute_force(pol, oracle, n, dup):
+    """zs_rocm_lbvh_self_query_{count,fill}: self_iter_neighbors over every leaf; per leaf the same ids in the same order as the
+    oracle's walk of the same tree, and the pair set = brute-force overlapping pairs, each once."""
+    from zpc_amd.containers import LBvh
+    bv = lbvh_boxes(n, 977, dup)
+    b, ref = oracle_lbvh(oracle, bv)
+    bvh = LBvh()
+    bvh.build(pol, torch.from_numpy(bv).cuda())
+    offsets, pairs = bvh.self_query(pol)
+    pol.syncCtx()
+    off, pr = offsets.cpu().numpy(), pairs.cpu().numpy()
+    leaf_prim = ref["auxIndices"][ref["leafInds"]] if n > 2 else np.arange(n)
+    out = np.zeros(n, np.int32)
+    oracle.orc_lbvh_self_iter_neighbors.restype = C.c_size_t
+    for k in range(0, n, max(1, n // 1500)):
+        c = oracle.orc_lbvh_self_iter_neighbors(b, C.c_int32(k), out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        want = out[:c][out[:c] != leaf_prim[k]]
+        mine = pr[off[k]:off[k + 1]]
+        assert (mine[:, 0] == leaf_prim[k]).all() and np.array_equal(mine[:, 1], want)
+    if n <= 3000:
+        ov = ((bv[:, None, :3] <= bv[None, :, 3:]) & (bv[:, None, 3:] >= bv[None, :, :3])).all(2)
+        ii, jj = np.nonzero(np.triu(ov, 1))
+        got = np.sort(pr, axis=1)
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert np.array_equal(got, np.stack([ii, jj], 1).astype(np.int32))
+    oracle.orc_lbvh_destroy(b)

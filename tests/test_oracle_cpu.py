@@ -350,6 +350,21 @@ def test_lbvh_oracle_structure_and_traversal(oracle, n, dup):
         k = oracle.orc_lbvh_iter_neighbors(b, ptr(bv[q]), ptr(out), C.c_size_t(n))
         ref = np.nonzero(((bv[:, :3] <= bv[q, 3:]) & (bv[:, 3:] >= bv[q, :3])).all(1))[0]
         assert np.array_equal(np.sort(out[:k]), ref)
+    # self iteration over every leaf: each unordered overlapping pair once (plus the leaf itself when n > 2)
+    oracle.orc_lbvh_self_iter_neighbors.restype = C.c_size_t
+    if n <= 3000:
+        leaf_prim = arrs["auxIndices"][arrs["leafInds"]] if n > 2 else np.arange(n)
+        pairs = set()
+        for k in range(n):
+            c = oracle.orc_lbvh_self_iter_neighbors(b, C.c_int32(k), ptr(out), C.c_size_t(n))
+            for j in out[:c]:
+                if j != leaf_prim[k]:
+                    key = (min(int(j), int(leaf_prim[k])), max(int(j), int(leaf_prim[k])))
+                    assert key not in pairs
+                    pairs.add(key)
+        ov = ((bv[:, None, :3] <= bv[None, :, 3:]) & (bv[:, None, 3:] >= bv[None, :, :3])).all(2)
+        ii, jj = np.nonzero(np.triu(ov, 1))
+        assert pairs == set(zip(ii.tolist(), jj.tolist()))
     oracle.orc_lbvh_destroy(b)
 
 

@@ -102,6 +102,11 @@ def main():
     ms = timeit(lambda: zs.lib().zs_rocm_lbvh_query_count(pol.handle, bvh.handle, bvs.data_ptr(), nq, counts.data_ptr()), reps=3, warm=1)
     hits = float(counts.double().mean().item())
     add("LBvh iter_neighbors count, 1M queries (%.1f hits/query)" % hits, nq, 24 + 4, ms)
+    # config 5 proper: self-collision broadphase over all 10M leaves (count pass; the fill pass repeats the walk)
+    sc = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: zs.lib().zs_rocm_lbvh_self_query_count(pol.handle, bvh.handle, sc.data_ptr()), reps=3, warm=1)
+    npairs = float(sc.double().sum().item())
+    add("LBvh self-collision broadphase count, 10M leaves (%.2f pairs/leaf)" % (npairs / n), n, 24 + 4, ms)
     del bvh, bvs
     if "--json" in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

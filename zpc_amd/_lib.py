@@ -272,6 +272,8 @@ def _declare_containers(L):
     L.zs_rocm_lbvh_total_box.argtypes = [vp, vp, vp]
     L.zs_rocm_lbvh_query_count.argtypes = [vp, vp, vp, sz, vp]
     L.zs_rocm_lbvh_query_fill.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.zs_rocm_lbvh_self_query_count.argtypes = [vp, vp, vp]
+    L.zs_rocm_lbvh_self_query_fill.argtypes = [vp, vp, vp, vp]
     L.zs_rocm_index_buckets_create.restype = vp
     L.zs_rocm_index_buckets_destroy.argtypes = [vp]
     L.zs_rocm_index_buckets_get_view.argtypes = [vp, C.POINTER(IndexBucketsView)]

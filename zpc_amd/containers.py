@@ -12,8 +12,11 @@ _ES = {"int": 4, "float": 4, "double": 8}
 class Allocator:
     """allocator(memsrc_e, ProcID) -- py_interop/Allocator.cpp:5-21"""
 
-    def __init__(self, memsrc=memsrc_device, devid=0, virtual_reserve=0):
-        """virtual_reserve > 0: allocator_virtual(mre, devid, reservedSpace) -- containers keep their data pointer on resize."""
+    def __init__(self, memsrc=memsrc_device, devid=None, virtual_reserve=0):
+        """virtual_reserve > 0: allocator_virtual(mre, devid, reservedSpace) -- containers keep their data pointer on resize.
+        devid None = the calling thread's current device (one process per GPU: rank k must not allocate on device 0)."""
+        if devid is None:
+            devid = lib().zs_rocm_current_device() if memsrc != memsrc_host else -1
         self.memsrc, self.devid = memsrc, devid
         self._h = lib().allocator_virtual(memsrc, devid, virtual_reserve) if virtual_reserve else lib().allocator(memsrc, devid)
 
@@ -315,6 +318,22 @@ class LBvh:
         out = torch.empty(max(total, 1), dtype=torch.int32, device=queries.device)
         lib().zs_rocm_lbvh_query_fill(pol.handle, self._h, queries.data_ptr(), nq, offsets.data_ptr(), out.data_ptr())
         return offsets, out[:total]
+
+    def self_query(self, pol, device="cuda"):
+        """Self-collision broadphase: (offsets[numLeaves+1], pairs[total, 2]) -- every unordered pair of overlapping primitive
+        boxes once; offsets is indexed by the leaf's position in node order (self_iter_neighbors over every leaf)."""
+        import torch
+        from .primitives import exclusive_scan
+        n = int(self.numLeaves())
+        counts = torch.zeros(n + 1, dtype=torch.int32, device=device)
+        lib().zs_rocm_lbvh_self_query_count(pol.handle, self._h, counts.data_ptr())
+        offsets = torch.empty_like(counts)
+        exclusive_scan(pol, counts, offsets)
+        pol.syncCtx()
+        total = int(offsets[n].item())
+        pairs = torch.empty(max(total, 1) * 2, dtype=torch.int32, device=device)
+        lib().zs_rocm_lbvh_self_query_fill(pol.handle, self._h, offsets.data_ptr(), pairs.data_ptr())
+        return offsets, pairs[: 2 * total].view(total, 2)
 
 
 class IndexBuckets:

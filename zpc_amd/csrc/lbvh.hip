@@ -270,6 +270,26 @@ __global__ __launch_bounds__(256) void lbvh_query_kernel(LBvhDev bvh, const AABB
   if (!FILL) counts[q] = c;
 }
 
+// self-collision broadphase: thread k takes the k-th leaf in node (Morton) order, so neighbouring lanes walk neighbouring
+// subtrees; LBvhView::self_iter_neighbors reports every overlapping unordered pair once (and the leaf itself, skipped here)
+template <bool FILL>
+__global__ __launch_bounds__(256) void lbvh_self_query_kernel(LBvhDev bvh, int *counts, const int *offsets, int *pairs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= bvh.numLeaves()) return;
+  const int self = bvh.numNodes <= 2 ? k : bvh.auxIndices[bvh.leafInds[k]];
+  int c = 0;
+  int *dst = FILL ? pairs + 2 * (size_t)offsets[k] : nullptr;
+  bvh.self_iter_neighbors(k, [&](int id) {
+    if (id == self) return;
+    if constexpr (FILL) {
+      dst[2 * c] = self;
+      dst[2 * c + 1] = id;
+    }
+    ++c;
+  });
+  if (!FILL) counts[k] = c;
+}
+
 static void lbvh_reserve(zs_rocm_lbvh &b, size_t n) {
   if (n <= b.capLeaves) return;
   (void)hipFree(b.orderedBvs); (void)hipFree(b.parents); (void)hipFree(b.levels); (void)hipFree(b.leafInds); (void)hipFree(b.auxIndices);
@@ -375,6 +395,18 @@ void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const f
   if (!nq) return;
   hipLaunchKernelGGL((lbvh_query_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, b->dev(), (const AABB3 *)queryBvs, nq,
                      (int *)nullptr, offsets, out);
+}
+void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, int *counts) {
+  Launch L(pol, "lbvh_self_query_count");
+  if (!b->numLeaves) return;
+  hipLaunchKernelGGL((lbvh_self_query_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, b->dev(), counts,
+                     (const int *)nullptr, (int *)nullptr);
+}
+void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const int *offsets, int *pairs) {
+  Launch L(pol, "lbvh_self_query_fill");
+  if (!b->numLeaves) return;
+  hipLaunchKernelGGL((lbvh_self_query_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, b->dev(), (int *)nullptr,
+                     offsets, pairs);
 }
 
 }  // extern "C"

@@ -157,6 +157,7 @@ void zs_rocm_clear_error(int device) {
   c.errorStatus = 0;
   c.errorPrinted = false;
 }
+int zs_rocm_current_device(void) { return current_device(); }
 int zs_rocm_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
