@@ -33,6 +33,8 @@ def timeit(fn, reps=20, warm=3):
 def main():
     pol = zs.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     rows = []
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None  # prims,tv,bht,lbvh
+    want = lambda k: only is None or k in only
 
     def add(name, n, unit_bytes, ms):
         gbs = unit_bytes * n / (ms * 1e-3) / 1e9
@@ -41,7 +43,7 @@ def main():
         print("%-44s n=%-10d %9.4f ms  %9.2f G/s  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, n, ms, n / ms / 1e6, gbs, 100 * gbs / PEAK), flush=True)
 
     g = torch.Generator(device="cuda").manual_seed(1)
-    for n in (1_000_000, 16_000_000, 64_000_000):
+    for n in (1_000_000, 16_000_000, 64_000_000) if want("prims") else ():
         a = torch.randint(-2**30, 2**30, (n,), dtype=torch.int32, device="cuda", generator=g)
         out1 = torch.zeros(1, dtype=torch.int32, device="cuda")
         out = torch.empty_like(a)
@@ -63,7 +65,7 @@ def main():
             add("merge_sort_pair<i32,i32> (%d passes)" % passes, n, 16 * passes, t_all - t_copy)
         del a, out, v, vo
     # config 2: TileVector<f32,32>{m:1,x:3,v:3,F:9,C:9} load-all/store-all at 16M
-    for n, L, Cn in ((16_000_000, 32, 25), (64_000_000, 64, 26)):
+    for n, L, Cn in ((16_000_000, 32, 25), (64_000_000, 64, 26)) if want("tv") else ():
         tiles = (n + L - 1) // L
         tv = torch.rand(tiles * L * Cn, dtype=torch.float32, device="cuda", generator=g)
         add("TileVector<f32,%d> %d ch load+store" % (L, Cn), n, 8 * Cn, timeit(lambda: zs.lib().zs_rocm_tv_scale_f32(pol.handle, tv.data_ptr(), n, Cn, L, C.c_float(1.0001))))
@@ -71,7 +73,7 @@ def main():
     # config 2: bht build, 16M random particles in [0,1)^3, dx = 1/256: cell keys (~10.6M distinct) and 8^3-block keys
     n = 16_000_000
     pos = torch.rand(n, 3, device="cuda", generator=g)
-    for name, keys in (("cell keys", torch.floor(pos * 256).to(torch.int32)), ("8^3-block keys", torch.floor(pos * 32).to(torch.int32))):
+    for name, keys in (("cell keys", torch.floor(pos * 256).to(torch.int32)), ("8^3-block keys", torch.floor(pos * 32).to(torch.int32))) if want("bht") else ():
         keys = keys.contiguous()
         tab = Bht(3, n)
 
@@ -86,6 +88,8 @@ def main():
     del pos
     # config 5: 10 M triangle AABBs of a jittered surface mesh in [0,1)^3 (extent ~ 2 cells of a 3163^2 sheet), LBvh<3,int,f32>
     from zpc_amd.containers import LBvh
+    if not want("lbvh"):
+        return rows
     n = 10_000_000
     side = 3163
     uv = torch.rand(n, 2, device="cuda", generator=g)
@@ -108,9 +112,10 @@ def main():
     npairs = float(sc.double().sum().item())
     add("LBvh self-collision broadphase count, 10M leaves (%.2f pairs/leaf)" % (npairs / n), n, 24 + 4, ms)
     del bvh, bvs
-    if "--json" in sys.argv:
-        json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+    return rows
 
 
 if __name__ == "__main__":
-    main()
+    rows = main()
+    if "--json" in sys.argv:
+        json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -427,34 +427,58 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
   int val[ITEMS];
   unsigned rank[ITEMS];
   const size_t base = tileBase + (size_t)w * (64 * ITEMS) + lane;
+  // full tile of plain arrays (the common case): raw pointers with immediate offsets, no bounds checks.  The generic path
+  // keeps the TileVector channel addressing (Port::off) and the ragged last tile.
+  const bool fast = tileCount == TILE && kin.contiguous() && kout.contiguous() && (!PAIR || (vin.contiguous() && vout.contiguous()));
+  if (fast) {
+    const K *kp = kin.base + kin.idx + base;
+    const int *vp = PAIR ? vin.base + vin.idx + base : nullptr;
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const size_t i = base + (size_t)k * 64;
-    if (i < n) {
-      key[k] = kin[i];
-      if constexpr (PAIR) val[k] = vin[i];
+    for (int k = 0; k < ITEMS; ++k) {
+      key[k] = kp[k * 64];
+      if constexpr (PAIR) val[k] = vp[k * 64];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const size_t i = base + (size_t)k * 64;
+      if (i < n) {
+        key[k] = kin[i];
+        if constexpr (PAIR) val[k] = vin[i];
+      }
     }
   }
   volatile unsigned *wc = cnt[w];
   const unsigned long long lt = lanemask_lt();
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const bool valid = base + (size_t)k * 64 < n;
+  const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
+  // ballot multisplit, 4 VALU per bit: t = -(bit) (v_bfe_i32), its ballot m (v_cmp), peers &= ~(m ^ t) on both halves
+  // (one v_bitop3_b32 each: truth table of a & ~(b ^ c) with a = 0xF0, b = 0xCC, c = 0xAA -> 0x90)
+  auto rank_item = [&](int k, bool valid) {
     const unsigned d = valid ? KeyBits<K>::digit(key[k], st, mask) : 0u;
-    unsigned long long peers = __ballot(valid);
+    const unsigned long long vb = __ballot(valid);
+    unsigned plo = (unsigned)vb, phi = (unsigned)(vb >> 32);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
+      const unsigned tb = (unsigned)__builtin_amdgcn_sbfe((int)d, b, 1);
+      const unsigned long long m = __ballot(tb != 0u);
+      plo = __builtin_amdgcn_bitop3_b32(plo, (unsigned)m, tb, 0x90);
+      phi = __builtin_amdgcn_bitop3_b32(phi, (unsigned)(m >> 32), tb, 0x90);
     }
     // every lane reads its digit's running count (same-address broadcast), then the lowest peer lane bumps it: LDS
     // operations of one wave execute in order, so no cross-lane shuffle of the old value is needed
-    const unsigned below = (unsigned)__popcll(peers & lt);
+    const unsigned below = (unsigned)__popc(plo & ltlo) + (unsigned)__popc(phi & lthi);
     const unsigned old = wc[d];
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) wc[d] = old + (unsigned)__popcll(peers);
+    if (valid && below == 0) wc[d] = old + (unsigned)__popc(plo) + (unsigned)__popc(phi);
     rank[k] = old + below;
     __builtin_amdgcn_wave_barrier();
+  };
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) rank_item(k, true);
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) rank_item(k, base + (size_t)k * 64 < n);
   }
   __syncthreads();
   // thread t < 256 owns digit t: wave offsets, tile count, chained scan
@@ -526,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
   // tile-local digit order in LDS
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    if (base + (size_t)k * 64 < n) {
+    if (fast || base + (size_t)k * 64 < n) {
       const unsigned d = KeyBits<K>::digit(key[k], st, mask);
       const unsigned lp = cnt[w][d] + rank[k];
       keyS[lp] = key[k];
@@ -535,15 +559,29 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
   }
   __syncthreads();
   // coalesced runs out
+  if (fast) {
+    K *ko = kout.base + kout.idx;
+    int *vo = PAIR ? vout.base + vout.idx : nullptr;
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
-    if (lp < tileCount) {
+    for (int k = 0; k < ITEMS; ++k) {
+      const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
       const K kk = keyS[lp];
       const unsigned d = KeyBits<K>::digit(kk, st, mask);
-      const size_t dst = (size_t)(globalStart[d] + lp);
-      kout[dst] = kk;
-      if constexpr (PAIR) vout[dst] = valS[lp];
+      const unsigned dst = globalStart[d] + lp;
+      ko[dst] = kk;
+      if constexpr (PAIR) vo[dst] = valS[lp];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
+      if (lp < tileCount) {
+        const K kk = keyS[lp];
+        const unsigned d = KeyBits<K>::digit(kk, st, mask);
+        const size_t dst = (size_t)(globalStart[d] + lp);
+        kout[dst] = kk;
+        if constexpr (PAIR) vout[dst] = valS[lp];
+      }
     }
   }
 }
