@@ -56,6 +56,9 @@ def parse():
                     help="every K steps: move particles to the rank that owns their cell, rebuild partition / halo lists / bins "
                          "(0 = never; the default bench window moves particles < 0.1 cell)")
     ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1, fused step: exchange the ghost blocks after the whole transfer kernel instead of overlapping "
+                         "it with the interior blocks")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -198,18 +201,14 @@ def main():
     lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n_local, mt.nchn, mt.L, mt.buf.data_ptr())
     torch.cuda.synchronize()
     del aos
-    nblocks = mt.build_partition(max(4096, n_local // 128))
-    t0 = time.perf_counter()
-    if not a.unbinned:
-        mt.rebin()
-    torch.cuda.synchronize()
-    rebin_ms = (time.perf_counter() - t0) * 1e3
-    mt.update_stress()  # constitutive state for the first P2G (later ones get it from the preceding G2P)
-
-    # ---- halo exchange setup (re-run after every re-partition)
+    # ---- partition, block numbering, bins, halo lists (re-run after every re-partition)
     nc = a.side ** 3
-    hip = C.CDLL("libamdhip64.so")
     stage = {}
+    overlap = world > 1 and a.fused and not a.no_overlap
+    comm_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
+    pol_comm = zpc_amd.rocm_exec().sync(False).external_stream(comm_stream.cuda_stream) if overlap else pol
+    ev_boundary, ev_comm = torch.cuda.Event(), torch.cuda.Event()
+    n_boundary = 0
 
     def dev_buf(buf):
         if buf.device.type != "cpu":
@@ -218,39 +217,59 @@ def main():
             stage[buf.data_ptr()] = torch.empty(buf.numel(), dtype=torch.float32, device=device)
         return stage[buf.data_ptr()]
 
-    def pack(blocks, nb, buf):
-        d = dev_buf(buf)
-        lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
-        if d is not buf:
-            buf.copy_(d)  # gloo validation path: stage through host memory
+    def make_pack(p):
+        def pack(blocks, nb, buf):
+            d = dev_buf(buf)
+            lib().zs_rocm_mpm_halo_pack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
+            if d is not buf:
+                buf.copy_(d)  # gloo validation path: stage through host memory
+        return pack
 
-    def unpack_add(blocks, nb, buf):
-        d = dev_buf(buf)
-        if d is not buf:
-            d.copy_(buf)
-        lib().zs_rocm_mpm_halo_unpack(pol.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
+    def make_unpack(p):
+        def unpack_add(blocks, nb, buf):
+            d = dev_buf(buf)
+            if d is not buf:
+                d.copy_(buf)
+            lib().zs_rocm_mpm_halo_unpack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
+        return unpack_add
 
-    def make_halo():
-        if world == 1:
-            return None
-        nb_ = mt.nblocks
-        v = mt.table.view()
-        keys = torch.empty(max(nb_, 1) * 3, dtype=torch.int32, device=device)
-        if nb_:
-            hip.hipMemcpy(C.c_void_p(keys.data_ptr()), C.c_void_p(v.activeKeys), C.c_size_t(nb_ * 12), 3)
-        my_keys = keys.cpu().numpy()[: nb_ * 3].reshape(nb_, 3)
+    pack, unpack_add = make_pack(pol), make_unpack(pol)
+    pack_c, unpack_add_c = make_pack(pol_comm), make_unpack(pol_comm)
 
-        def lookup(sk):
-            d = torch.from_numpy(np.ascontiguousarray(sk)).to(device)
-            r = torch.empty(sk.shape[0], dtype=torch.int32, device=device)
-            mt.table.query(pol, d.data_ptr(), sk.shape[0], r.data_ptr())
-            torch.cuda.synchronize()
-            return r.cpu().numpy()
+    def partition_and_halo():
+        """sparse-grid partition of the local particles; with the overlapped exchange the blocks near a rank boundary are
+        numbered first; bins; ghost-block lists"""
+        nonlocal n_boundary
+        from zpc_amd.dist import gather_block_keys, near_shared_mask
+        nb_ = mt.build_partition(max(4096, mt.n // 128))
+        all_keys = None
+        if world > 1:
+            all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
+            if overlap:
+                n_boundary = mt.reorder_partition(near_shared_mask(all_keys[rank], all_keys, rank, mt.kstride))
+        if not a.unbinned:
+            mt.rebin()
+        stage.clear()
+        h = None
+        if world > 1:
+            my_keys = mt.active_keys()
 
-        return HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
-                            lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), 7 * nc)
+            def lookup(sk):
+                d = torch.from_numpy(np.ascontiguousarray(sk)).to(device)
+                r = torch.empty(sk.shape[0], dtype=torch.int32, device=device)
+                mt.table.query(pol, d.data_ptr(), sk.shape[0], r.data_ptr())
+                torch.cuda.synchronize()
+                return r.cpu().numpy()
 
-    halo = make_halo()
+            h = HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
+                             lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), 7 * nc, all_keys=all_keys)
+        return nb_, h
+
+    t0 = time.perf_counter()
+    nblocks, halo = partition_and_halo()
+    torch.cuda.synchronize()
+    rebin_ms = (time.perf_counter() - t0) * 1e3
+    mt.update_stress()  # constitutive state for the first P2G (later ones get it from the preceding G2P)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     p2g_ev, g2p_ev = [], []
@@ -283,12 +302,24 @@ def main():
         if timed:
             e0, e1 = ev(), ev()
             e0.record()
-        mt.g2p2g(write_all=write_all)
-        if timed:
-            e1.record()
-            fused_ev.append((e0, e1))
-        if halo is not None:
-            halo.exchange(pack, unpack_add)
+        if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
+            # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
+            mt.g2p2g(write_all=write_all, split=n_boundary, between=lambda: ev_boundary.record())
+            if timed:
+                e1.record()
+                fused_ev.append((e0, e1))
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev_boundary)
+                halo.exchange(pack_c, unpack_add_c)
+                ev_comm.record()
+            torch.cuda.current_stream().wait_event(ev_comm)
+        else:
+            mt.g2p2g(write_all=write_all)
+            if timed:
+                e1.record()
+                fused_ev.append((e0, e1))
+            if halo is not None:
+                halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
 
     migrated = 0
@@ -308,11 +339,7 @@ def main():
         if world > 1:
             to_c = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
             moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device))
-        nblocks = mt.build_partition(max(4096, mt.n // 128))
-        if not a.unbinned:
-            mt.rebin()
-        stage.clear()
-        halo = make_halo()
+        nblocks, halo = partition_and_halo()
         if a.fused:
             prime_grid()
         migrated += moved[0]
@@ -356,6 +383,11 @@ def main():
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
+    drift = int(mt.drift_flag.item()) if mt.drift_flag is not None else 0
+    if overlap and drift:
+        # an exact-path particle of an interior block may have reached a shared block after its ghost sums were sent
+        raise SystemExit("rank %d: particles drifted more than one bin from their bins -- re-bin more often (--migrate-every) "
+                         "or run with --no-overlap" % rank)
 
     n_local = mt.n
     n_total = n_local
@@ -408,6 +440,7 @@ def main():
                           "" if not a.unbinned else " [particle-order path]"),
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
+                       "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

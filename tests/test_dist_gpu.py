@@ -17,6 +17,8 @@ ARGS = ["--cells", "24,48,24", "--steps", "4", "--warmup", "0", "--no-cpu-baseli
 
 
 def _run(n, ARGS=ARGS):
+    if "--cells" in ARGS[2:]:  # a later --cells overrides the default one
+        ARGS = ARGS[2:]
     env = dict(os.environ)
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS
@@ -33,12 +35,19 @@ def _run(n, ARGS=ARGS):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("n", [2, 4, 8])
-def test_n_ranks_reproduce_single_rank(n):
-    ref = _run(1)
-    out = _run(n)
+@pytest.mark.parametrize("n,extra", [(2, []), (4, []), (8, []), (2, ["--no-overlap"]), (4, ["--side", "4"]),
+                                     (2, ["--cells", "16,192,16", "--side", "4"]), (2, ["--cells", "16,192,16"])])
+def test_n_ranks_reproduce_single_rank(n, extra):
+    """default N > 1 step: boundary blocks first, ghost exchange on a second stream overlapped with the interior blocks"""
+    ref = _run(1, ARGS + extra)
+    out = _run(n, ARGS + extra)
     assert out["n_gpus"] == n and out["config"]["particles"] == ref["config"]["particles"]
     assert out["config"]["halo_bytes_per_step_rank0"] > 0
+    assert out["config"]["halo_overlap"] == ("--no-overlap" not in extra)
+    if out["config"]["halo_overlap"]:
+        assert 0 < out["config"]["boundary_blocks_rank0"] <= out["config"]["grid_blocks_rank0"]
+    if "--cells" in extra:  # tall column: most blocks are interior, so the split launch + second stream really run
+        assert out["config"]["boundary_blocks_rank0"] < out["config"]["grid_blocks_rank0"] // 2
     a, b = np.array(ref["checksum"]), np.array(out["checksum"])
     # sums and sums of squares of every particle channel (m, x, v, C, F, logJp) after 4 steps; particles are generated
     # from their global id, so every decomposition starts from the same state and must reach the same state up to float
@@ -71,3 +80,18 @@ def test_particle_migration_between_ranks(n, extra):
     assert (np.abs(a[:nch] - b[:nch]) <= 2e-5 * scale + 1e-12).all(), np.abs(a[:nch] - b[:nch]) / scale
     assert (np.abs(a[nch:] - b[nch:]) <= 1e-4 * np.abs(a[nch:]) + 1e-12).all()
     assert out["hip_error"] == 0 and ref["hip_error"] == 0
+
+
+def test_overlap_drift_guard_refuses_stale_bins():
+    """Without re-binning, particles flying 3 cells per step leave the margin that keeps interior blocks away from the shared
+    blocks: the overlapped step must refuse the run (device drift flag of zs_rocm_mpm_g2p2g_range) instead of silently
+    dropping ghost contributions.  (A run like this needs --migrate-every anyway: the particles also leave the partition.)"""
+    args = ["--cells", "16,192,16", "--side", "4", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--drift", "0,60,0"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device"] + args
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and b"drifted more than one bin" in r.stderr

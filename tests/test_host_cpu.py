@@ -57,6 +57,21 @@ def test_domain_decomposition_boxes():
     assert np.array_equal(s, shared_keys(b, a))                   # same order on both sides
 
 
+def test_boundary_first_block_mask():
+    """near_shared_mask: the blocks within two blocks of a block another rank also holds (they are numbered and launched
+    first so that their ghost sums can travel while the interior computes); key units = block side (stride)."""
+    from zpc_amd.dist import near_shared_mask
+    k0 = np.array([[x, y, z] for x in range(0, 9) for y in range(3) for z in (0, 1)], np.int32)   # rank 0: x < 9, ghost layer 8
+    k1 = np.array([[x, y, z] for x in range(7, 16) for y in range(3) for z in (0, 1)], np.int32)  # rank 1: x >= 7, ghost layer 7
+    for stride in (1, 4, 8):
+        m0 = near_shared_mask(k0 * stride, [k0 * stride, k1 * stride], 0, stride)
+        m1 = near_shared_mask(k1 * stride, [k0 * stride, k1 * stride], 1, stride)
+        assert sorted(set(k0[m0][:, 0].tolist())) == [5, 6, 7, 8] and sorted(set(k0[~m0][:, 0].tolist())) == [0, 1, 2, 3, 4]
+        assert sorted(set(k1[m1][:, 0].tolist())) == [7, 8, 9, 10]
+    assert not near_shared_mask(k0, [k0, k1 + 100], 0, 1).any()      # nothing shared -> nothing is boundary
+    assert near_shared_mask(k0[:0], [k0[:0], k1], 0, 1).shape == (0,)
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist

@@ -1699,6 +1699,10 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
       make_arena(mp.dx, cur.pos, ar);
       if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
         staleG[atomicAdd(staleGCount, 1)] = i0;  // mis-binned: exact gather + scatter afterwards
+        // drift guard of the split launch: the exact path of an interior block may only reach blocks within two of its own
+        if ((unsigned)(ar.corner[0] - geo.org[0] + 4) >= 12u || (unsigned)(ar.corner[1] - geo.org[1] + 4) >= 12u ||
+            (unsigned)(ar.corner[2] - geo.org[2] + 4) >= 12u)
+          staleGCount[8] = 1;
       } else {
         float vel[3], C[9];
         g2p_gather_lds(mp, ar, v0, D_inv, vel, C);
@@ -1735,6 +1739,9 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         }
         if (moved) {
           staleP[atomicAdd(stalePCount, 1)] = i0;  // left the cell during this step: exact scatter afterwards
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            if ((unsigned)((int)floorf(pos[d] * dxi - 0.5f) - geo.org[d] + 4) >= 12u) staleGCount[8] = 1;
         } else {
           valid = true;
           myStage[0 * 64 + lane] = cur.m;
@@ -1780,14 +1787,14 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
 template <int SIDE, int SMODEL, int LW, bool WRITE_ALL>
 __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
                                                            const int *binStart, const unsigned *cellCount, const int *nbr, int *staleG,
-                                                           int *staleGCount, int *staleP, int *stalePCount) {
+                                                           int *staleGCount, int *staleP, int *stalePCount, int binBase) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float varena[3 * AL::CH];
   __shared__ float parena[2 * 7 * AL::CH];
   __shared__ float stage[2 * 4 * G2P2G_NF * 64];
   __shared__ unsigned long long smask[2 * 4];
-  const int bin = blockIdx.x;
+  const int bin = blockIdx.x + binBase;  // a launch covers a range of blocks (boundary blocks first, see zs_rocm_mpm_g2p2g_range)
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1829,8 +1836,9 @@ __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesD
 template <int SIDE, int SMODEL>
 __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
                                                           const int *staleG, const int *staleGCount, const int *staleP,
-                                                          const int *stalePCount) {
+                                                          const int *stalePCount, int *driftFlag) {
   const int ng = *staleGCount, np = *stalePCount;
+  if (driftFlag && blockIdx.x == 0 && threadIdx.x == 0 && staleGCount[8]) *driftFlag = 1;
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ng + np; j += gridDim.x * blockDim.x) {
@@ -2220,18 +2228,27 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
 
 // G2P (from gridA) + P2G (into gridB, zeroed by the caller) in one pass; `particles.stress` must be present (it carries the
 // state of the particles that take the exact path).  writeAll != 0 also stores v, C and P F^T vol of every particle.
-int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
-                      float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll) {
+// blocks [blockBegin, blockEnd) only.  Multi-GPU step (bench.py): the partition is numbered with the blocks near a rank boundary
+// first; their range is launched first, its ghost-block sums travel on a second stream while the interior range computes.
+// An interior block's exact-path particles must not reach a shared block: *driftFlag is set to 1 when a particle handled
+// by the exact path sits more than one bin away from the bin it is stored in (re-bin more often then).
+int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                            float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll,
+                            size_t blockBegin, size_t blockEnd, int *driftFlag) {
   if (!ps.n || !nblocks) return 0;
   if (!ps.stress.base || !binStart || !cellCount || !nbr) {
     fprintf(stderr, "[zs_rocm] g2p2g needs binned particles and the `stress` attribute\n");
     return -1;
   }
+  if (blockEnd > nblocks) blockEnd = nblocks;
+  if (blockBegin >= blockEnd) return 0;
   Launch L(pol, "G2P2GTransfer");
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
-  const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+  const unsigned bpb = p->side == 4 ? 1u : 8u;
+  const unsigned nbins = (unsigned)((blockEnd - blockBegin) * bpb);
+  const int binBase = (int)(blockBegin * bpb);
   int *staleG = (int *)L.temp(sizeof(int) * (ps.n + 64));
   int *staleP = (int *)L.temp(sizeof(int) * (ps.n + 64));
   int *counts = (int *)L.temp(sizeof(int) * 64);
@@ -2239,9 +2256,9 @@ int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   const int lw = uniform_lane_width(ps, p->model == ZS_MPM_DRUCKER_PRAGER, true);
 #define CALL_G2P2G4(S, M, LWv, WA)                                                                                                    \
   hipLaunchKernelGGL((g2p2g_binned_kernel<S, M, LWv, WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, binStart,     \
-                     cellCount, nbr, staleG, counts, staleP, counts + 32);                                                            \
+                     cellCount, nbr, staleG, counts, staleP, counts + 32, binBase);                                                   \
   hipLaunchKernelGGL((g2p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, (const int *)staleG,      \
-                     (const int *)counts, (const int *)staleP, (const int *)(counts + 32))
+                     (const int *)counts, (const int *)staleP, (const int *)(counts + 32), driftFlag)
 #define CALL_G2P2G3(S, M, LWv)          \
   do {                                  \
     if (writeAll) { CALL_G2P2G4(S, M, LWv, true); } \
@@ -2253,6 +2270,10 @@ int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   else if (p->model == ZS_MPM_FIXED_COROTATED) { CALL_G2P2G(8, ZS_MPM_FIXED_COROTATED); }
   else { CALL_G2P2G(8, ZS_MPM_DRUCKER_PRAGER); }
   return 0;
+}
+int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                      float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll) {
+  return zs_rocm_mpm_g2p2g_range(pol, p, ps, tab, gridA, gridB, nblocks, binStart, cellCount, nbr, writeAll, 0, nblocks, nullptr);
 }
 
 void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {

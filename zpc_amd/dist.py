@@ -56,36 +56,64 @@ def shared_keys(my_keys, peer_keys):
     return s.view(np.int32).reshape(-1, 3)
 
 
+def gather_block_keys(dist, world_size, my_keys, backend_dev):
+    """all_gather of the ranks' [n,3] int32 block-key lists (variable length -> padded to the longest); list of numpy arrays."""
+    import torch
+    n = np.array([my_keys.shape[0]], np.int64)
+    cnt_t = torch.from_numpy(n).to(backend_dev)
+    counts = [torch.zeros_like(cnt_t) for _ in range(world_size)]
+    dist.all_gather(counts, cnt_t)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    mine = torch.zeros(mx, 3, dtype=torch.int32, device=backend_dev)
+    if my_keys.shape[0]:
+        mine[: my_keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(my_keys.astype(np.int32))).to(backend_dev)
+    allk = [torch.zeros_like(mine) for _ in range(world_size)]
+    dist.all_gather(allk, mine)
+    return [allk[p][: counts[p]].cpu().numpy() for p in range(world_size)]
+
+
+def near_shared_mask(my_keys, all_keys, rank, stride, margin=2):
+    """mask[i] = 1 when block my_keys[i] is within `margin` blocks (Chebyshev, key units of `stride`) of a block that also
+    exists on another rank.  These blocks are numbered and launched first; the others may run while the ghost sums travel:
+    a block's bins write to the blocks at offsets {0,1}^3, their exact-path particles (<= one bin away, enforced by the
+    drift flag of zs_rocm_mpm_g2p2g_range) to offsets {-1..2}^3."""
+    if my_keys.shape[0] == 0:
+        return np.zeros(0, bool)
+    sh = [shared_keys(my_keys, all_keys[p]) for p in range(len(all_keys)) if p != rank]
+    sh = [x for x in sh if x.shape[0]]
+    if not sh:
+        return np.zeros(my_keys.shape[0], bool)
+    sh = np.unique(np.concatenate(sh), axis=0).astype(np.int64) // stride
+    r = np.arange(-margin, margin + 1)
+    off = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1).reshape(-1, 3)
+    near = (sh[:, None, :] + off[None, :, :]).reshape(-1, 3)
+    B = 1 << 20  # block coordinates of a 512^3 .. 4096^3 grid fit comfortably
+
+    def code(k):
+        k = k + B // 2
+        return (k[:, 0] * B + k[:, 1]) * B + k[:, 2]
+
+    return np.isin(code(my_keys.astype(np.int64) // stride), np.unique(code(near)))
+
+
 class HaloExchange:
     """Ghost-block partial-sum exchange.  `lookup(keys[n,3]) -> local block numbers` , `pack(blocks_t, nb, buf)`,
     `unpack_add(blocks_t, nb, buf)` are supplied by the caller (HIP kernels in production: zs_rocm_query__bht /
     zs_rocm_mpm_halo_pack / zs_rocm_mpm_halo_unpack)."""
 
-    def __init__(self, dist, rank, world_size, my_keys, lookup, make_index_tensor, make_buffer, block_floats):
+    def __init__(self, dist, rank, world_size, my_keys, lookup, make_index_tensor, make_buffer, block_floats, all_keys=None):
         self.dist, self.rank, self.world = dist, rank, world_size
-        self.peers = []  # (peer, blocks_tensor, nb, sendbuf, recvbuf)
+        self.peers = []  # (peer, offset, nb) into the concatenated block list / buffers
         if world_size == 1:
             return
-        # every rank learns every rank's key list (variable length -> pad to the max)
-        import torch
-        n = np.array([my_keys.shape[0]], np.int64)
-        backend_dev = make_buffer(1).device
-        cnt_t = torch.from_numpy(n).to(backend_dev)
-        counts = [torch.zeros_like(cnt_t) for _ in range(world_size)]
-        dist.all_gather(counts, cnt_t)
-        counts = [int(c.item()) for c in counts]
-        mx = max(max(counts), 1)
-        mine = torch.zeros(mx, 3, dtype=torch.int32, device=backend_dev)
-        if my_keys.shape[0]:
-            mine[: my_keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(my_keys.astype(np.int32))).to(backend_dev)
-        allk = [torch.zeros_like(mine) for _ in range(world_size)]
-        dist.all_gather(allk, mine)
+        if all_keys is None:  # every rank learns every rank's key list
+            all_keys = gather_block_keys(dist, world_size, my_keys, make_buffer(1).device)
         found = []
         for p in range(world_size):
             if p == rank:
                 continue
-            pk = allk[p][: counts[p]].cpu().numpy()
-            sk = shared_keys(my_keys, pk)
+            sk = shared_keys(my_keys, all_keys[p])
             if sk.shape[0] == 0:
                 continue
             local = lookup(sk)

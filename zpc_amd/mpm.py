@@ -38,6 +38,7 @@ class MpmTransfer:
         self.tiles = (self.n + self.L - 1) // self.L
         self.buf = torch.zeros(self.tiles * self.L * self.nchn, dtype=torch.float32, device=self.device)
         self.buf2 = None  # second buffer for re-binning (ping-pong)
+        self.drift_flag = None  # device int set by zs_rocm_mpm_g2p2g_range when the split-launch margin is violated
         self.key_is_origin = bool(key_is_origin)  # SparseGrid convention: partition keys are block origins (multiples of side)
         self.kstride = side if key_is_origin else 1
         self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side,
@@ -146,6 +147,8 @@ class MpmTransfer:
         self.pol.syncCtx()
         self.buf, self.buf2 = self.buf2, self.buf
         self.binned = True
+        if self.drift_flag is not None:
+            self.drift_flag.zero_()
 
     # ------------------------------------------------------------------ one sub-step
     def clear_grid(self):
@@ -172,21 +175,53 @@ class MpmTransfer:
         lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
                               self.nblocks, bs, cc, nb)
 
-    def g2p2g(self, write_all=False):
+    def g2p2g(self, write_all=False, split=None, between=None):
         """Fused G2P (from self.grid) + P2G (into a zeroed second grid, which then becomes self.grid): zs_rocm_mpm_g2p2g.
-        Needs cache_stress=True and binned particles."""
+        Needs cache_stress=True and binned particles.  split=k: blocks [0, k) are launched first, `between()` is called (the
+        caller records an event there and starts the ghost exchange of the NEW self.grid on another stream), then blocks
+        [k, nblocks) are launched (zs_rocm_mpm_g2p2g_range)."""
         if not (self.cache_stress and self.binned):
             raise RuntimeError("g2p2g needs cache_stress=True and rebin()")
         if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
             self.grid2 = torch.zeros_like(self.grid)
         else:
             self.grid2.zero_()
-        rc = lib().zs_rocm_mpm_g2p2g(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
-                                     self.grid2.data_ptr(), self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
-                                     self.nbr.data_ptr(), int(write_all))
-        if rc != 0:
-            raise RuntimeError("zs_rocm_mpm_g2p2g refused the call")
-        self.grid, self.grid2 = self.grid2, self.grid
+        if self.drift_flag is None:
+            self.drift_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
+        src, dst = self.grid, self.grid2
+        self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
+        for k, (b0, b1) in enumerate(ranges):
+            rc = lib().zs_rocm_mpm_g2p2g_range(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
+                                               dst.data_ptr(), self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
+                                               self.nbr.data_ptr(), int(write_all), b0, b1, self.drift_flag.data_ptr())
+            if rc != 0:
+                raise RuntimeError("zs_rocm_mpm_g2p2g refused the call")
+            if k == 0 and between is not None:
+                between()
+
+    def reorder_partition(self, first_mask):
+        """Renumber the blocks so that those with first_mask[i] != 0 come first (stable); returns their count.  Call between
+        build_partition() and rebin()."""
+        import numpy as np
+        keys = self.active_keys()
+        m = np.asarray(first_mask).astype(bool)
+        order = np.concatenate([np.nonzero(m)[0], np.nonzero(~m)[0]])
+        pk = torch.from_numpy(np.ascontiguousarray(keys[order])).to(self.device)
+        self.adopt_partition(pk.data_ptr(), keys.shape[0])
+        self.pol.syncCtx()
+        return int(m.sum())
+
+    def active_keys(self):
+        """[nblocks, 3] int32 block keys in block-number order (host copy of the table's activeKeys)."""
+        import ctypes
+        v = self.table.view()
+        nb = self.nblocks
+        keys = torch.empty(max(nb, 1) * 3, dtype=torch.int32, device=self.device)
+        self.pol.syncCtx()
+        if nb:
+            ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(v.activeKeys), ctypes.c_size_t(nb * 12), 3)
+        return keys.cpu().numpy()[: nb * 3].reshape(nb, 3)
 
     def grid_by_key(self):
         """{(bx,by,bz): ndarray[7, side^3]} -- for comparisons that must not depend on block numbering."""
