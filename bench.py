@@ -56,6 +56,9 @@ def parse():
                     help="every K steps: move particles to the rank that owns their cell, rebuild partition / halo lists / bins "
                          "(0 = never; the default bench window moves particles < 0.1 cell)")
     ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
+    ap.add_argument("--floor", action="store_true",
+                    help="apply a Separate plane collider 1.5 cells above y = 0 after every grid update "
+                         "(ApplyBoundaryConditionOnGridBlocks; off in the headline configuration)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, fused step: exchange the ghost blocks after the whole transfer kernel instead of overlapping "
                          "it with the interior blocks")
@@ -271,6 +274,11 @@ def main():
     rebin_ms = (time.perf_counter() - t0) * 1e3
     mt.update_stress()  # constitutive state for the first P2G (later ones get it from the preceding G2P)
 
+    floor = None
+    if a.floor:
+        from zpc_amd.mpm import make_collider, PLANE, SEPARATE
+        floor = make_collider(PLANE, SEPARATE, [0.0, 1.5 * dx, 0.0, 0.0, 1.0, 0.0])
+
     ev = lambda: torch.cuda.Event(enable_timing=True)
     p2g_ev, g2p_ev = [], []
 
@@ -286,6 +294,8 @@ def main():
         if halo is not None:
             halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
+        if floor is not None:
+            mt.apply_boundary(floor)
         if timed:
             e2, e3 = ev(), ev()
             e2.record()
@@ -321,6 +331,8 @@ def main():
             if halo is not None:
                 halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
+        if floor is not None:
+            mt.apply_boundary(floor)
 
     migrated = 0
 
@@ -330,6 +342,8 @@ def main():
         if halo is not None:
             halo.exchange(pack, unpack_add)
         mt.grid_update((0.0, -9.8, 0.0))
+        if floor is not None:
+            mt.apply_boundary(floor)
 
     def remap():
         """particles -> owning ranks, new partition / halo lists / bins (full particle state must be in memory)"""
@@ -440,7 +454,7 @@ def main():
                           "" if not a.unbinned else " [particle-order path]"),
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
-                       "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
+                       "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -537,6 +537,29 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_p2g(zs_rocm_policy *, const zs_rocm_mpm_params *
  * (simulation/grid/GridOp.hpp:71-108).  maxVelSqr may be NULL. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_grid_update(zs_rocm_policy *, const zs_rocm_mpm_params *, float *grid, size_t nblocks,
                                             const float extf[3], float *maxVelSqr);
+/* Collider<AnalyticLevelSet<Plane|Cuboid|Sphere|Cylinder, f32, 3>> (geometry/Collider.h:10-206; the analytic members of
+ * GeneralBoundary, :246-252).  param: plane {origin xyz, normal xyz}; cuboid {min xyz, max xyz}; sphere {centre xyz, radius};
+ * cylinder {bottom centre xyz, radius, length, axis 0|1|2}.  x = R s X + b maps material to world space (R row-major). */
+enum { ZS_ROCM_GEOM_PLANE = 0, ZS_ROCM_GEOM_CUBOID = 1, ZS_ROCM_GEOM_SPHERE = 2, ZS_ROCM_GEOM_CYLINDER = 3 };
+enum { ZS_ROCM_COLLIDER_STICKY = 0, ZS_ROCM_COLLIDER_SLIP = 1, ZS_ROCM_COLLIDER_SEPARATE = 2 }; /* collider_e */
+typedef struct zs_rocm_collider {
+  int geometry, type;
+  float param[8];
+  float s, dsdt;
+  float R[9];
+  float omega[3];
+  float b[3], dbdt[3];
+} zs_rocm_collider;
+/* identity transform, sticky */
+ZS_ROCM_EXPORT void zs_rocm_collider_init(zs_rocm_collider *c, int geometry, int type, const float *param, int nparam);
+/* pol(Collapse{nblocks, side^3}, ApplyBoundaryConditionOnGridBlocks{collider, partition, grids}) (simulation/grid/GridOp.hpp:111-164):
+ * every node with mass > 0 at world position (block key * side + cell) * dx gets collider.resolveCollision(pos, vel).
+ * Runs after zs_rocm_mpm_grid_update (the grid holds velocities). */
+ZS_ROCM_EXPORT void zs_rocm_mpm_apply_boundary(zs_rocm_policy *, const zs_rocm_mpm_params *, const zs_rocm_bht_3 *, float *grid,
+                                               size_t nblocks, const zs_rocm_collider *collider);
+/* bulk Collider::resolveCollision on n points (x, v: [n][3] device arrays, v updated; inside[n] may be NULL): test entry */
+ZS_ROCM_EXPORT void zs_rocm_collider_resolve(zs_rocm_policy *, const zs_rocm_collider *collider, const float *x, float *v, size_t n,
+                                             int *inside);
 /* pol(range(n), G2PTransfer{apic, dt, model, grids, table, particles}) (simulation/transfer/G2P.hpp:24-90) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,

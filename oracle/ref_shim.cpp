@@ -18,9 +18,46 @@
 #include "zensim/py_interop/HashUtils.hpp"
 #include "zensim/math/bit/Bits.h"
 #include "zensim/geometry/AnalyticLevelSet.h" /* AABBBox, overlaps, BoundingVolumeInterface */
+#include "zensim/math/Rotation.hpp"            /* Rotation, AngularVelocity (members of Collider) */
 #include <random>
 
 using namespace zs;
+
+/* Collider<LS>::resolveCollision (geometry/Collider.h:82-112).  Collider.h itself includes GenericLevelSet.h, which pulls in
+   the execution-policy headers (un-vendored magic_enum: unbuildable here), so the member function is spelled out over the
+   reference's own AnalyticLevelSet (getSignedDistance / getNormal / getMaterialVelocity through LevelSetInterface), Rotation,
+   AngularVelocity and vec types -- those are what this pins. */
+template <class LS>
+static int ref_resolve_with(const LS &levelset, int type, float s, float dsdt, const float *Rm, const float *om, const float *b_,
+                            const float *dbdt_, const float *x_, float *v_) {
+  using T = float;
+  using TV = vec<float, 3>;
+  Rotation<float, 3> R{};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R(i, j) = Rm[3 * i + j];
+  AngularVelocity<float, 3> omega{TV{om[0], om[1], om[2]}};
+  TV b{b_[0], b_[1], b_[2]}, dbdt{dbdt_[0], dbdt_[1], dbdt_[2]}, x{x_[0], x_[1], x_[2]}, v{v_[0], v_[1], v_[2]};
+  T erosion = 0;
+  int hit = 0;
+  TV x_minus_b = x - b;
+  T one_over_s = 1 / s;
+  TV X = R.transpose() * x_minus_b * one_over_s;
+  if (levelset.getSignedDistance(X) < -erosion) {
+    TV v_object = omega.cross(x_minus_b) + (dsdt * one_over_s) * x_minus_b + R * s * levelset.getMaterialVelocity(X) + dbdt;
+    if (type == 0)
+      v = v_object;
+    else {
+      v -= v_object;
+      TV n = R * levelset.getNormal(X);
+      T proj = n.dot(v);
+      if ((type == 2 && proj < 0) || type == 1) v -= proj * n;
+      v += v_object;
+    }
+    hit = 1;
+  }
+  for (int d = 0; d < 3; ++d) v_[d] = v[d];
+  return hit;
+}
 
 extern "C" {
 
@@ -112,6 +149,21 @@ int ref_aabb_overlaps(const float *a, const float *q) {
   using Box = AABBBox<3, float>;
   using TV = vec<float, 3>;
   return overlaps(Box{TV{a[0], a[1], a[2]}, TV{a[3], a[4], a[5]}}, Box{TV{q[0], q[1], q[2]}, TV{q[3], q[4], q[5]}}) ? 1 : 0;
+}
+int ref_collider_resolve(int geometry, int type, const float *p, float s, float dsdt, const float *R, const float *omega, const float *b,
+                         const float *dbdt, const float *x, float *v) {
+  using TV = vec<float, 3>;
+  if (geometry == 0)
+    return ref_resolve_with(AnalyticLevelSet<analytic_geometry_e::Plane, float, 3>{TV{p[0], p[1], p[2]}, TV{p[3], p[4], p[5]}}, type, s, dsdt,
+                            R, omega, b, dbdt, x, v);
+  if (geometry == 1)
+    return ref_resolve_with(AnalyticLevelSet<analytic_geometry_e::Cuboid, float, 3>{TV{p[0], p[1], p[2]}, TV{p[3], p[4], p[5]}}, type, s,
+                            dsdt, R, omega, b, dbdt, x, v);
+  if (geometry == 2)
+    return ref_resolve_with(AnalyticLevelSet<analytic_geometry_e::Sphere, float, 3>{TV{p[0], p[1], p[2]}, p[3]}, type, s, dsdt, R, omega, b,
+                            dbdt, x, v);
+  return ref_resolve_with(AnalyticLevelSet<analytic_geometry_e::Cylinder, float, 3>{TV{p[0], p[1], p[2]}, p[3], p[4], (int)p[5]}, type, s,
+                          dsdt, R, omega, b, dbdt, x, v);
 }
 int ref_hashtable_do_hash(const int *key, int dim) {
   size_t ret = key[0];

@@ -143,3 +143,15 @@ def oracle_lbvh(oracle, bv, refit=1):
             "auxIndices": A(oracle.orc_lbvh_aux_indices(b), (nn,)), "leafInds": A(oracle.orc_lbvh_leaf_inds(b), (n,)),
             "bvs": A(oracle.orc_lbvh_bvs(b), (nn, 6))}
     return b, arrs
+
+
+def collider_struct(cs):
+    """row of tests/golden/collider.npz `cases` ([geometry, type, param x8, s, dsdt, R x9, omega x3, b x3, dbdt x3]) ->
+    ctypes struct with the layout shared by zs_rocm_collider and orc_collider"""
+    import ctypes as C
+
+    class Col(C.Structure):
+        _fields_ = [("geometry", C.c_int), ("type", C.c_int), ("param", C.c_float * 8), ("s", C.c_float), ("dsdt", C.c_float),
+                    ("R", C.c_float * 9), ("omega", C.c_float * 3), ("b", C.c_float * 3), ("dbdt", C.c_float * 3)]
+    return Col(int(cs[0]), int(cs[1]), (C.c_float * 8)(*cs[2:10]), float(cs[10]), float(cs[11]), (C.c_float * 9)(*cs[12:21]),
+               (C.c_float * 3)(*cs[21:24]), (C.c_float * 3)(*cs[24:27]), (C.c_float * 3)(*cs[27:30]))

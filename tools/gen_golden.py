@@ -97,6 +97,47 @@ def main():
     codes = np.array([ref.ref_lbvh_morton(P(whole), P(b)) for b in bvs], np.uint32)
     ov = np.array([[ref.ref_aabb_overlaps(P(bvs[i]), P(bvs[j])) for j in range(40)] for i in range(40)], np.int32)
     np.savez_compressed(os.path.join(OUT, "lbvh.npz"), whole=whole, bvs=bvs, codes=codes, overlaps40=ov)
+    # ---- colliders: Collider<AnalyticLevelSet<Plane|Cuboid|Sphere|Cylinder>>::resolveCollision (geometry/Collider.h:82-112)
+    g4 = np.random.default_rng(20250930)
+    cases = []
+    for geom in range(4):
+        for ctype in range(3):
+            for rep in range(2):
+                moving = rep == 1
+                if geom == 0:
+                    nrm = g4.standard_normal(3); nrm /= np.linalg.norm(nrm)
+                    par = np.concatenate([g4.uniform(-0.2, 0.2, 3), nrm, [0, 0]])
+                elif geom == 1:
+                    lo = g4.uniform(-0.5, -0.1, 3); par = np.concatenate([lo, lo + g4.uniform(0.3, 0.9, 3), [0, 0]])
+                elif geom == 2:
+                    par = np.concatenate([g4.uniform(-0.2, 0.2, 3), [g4.uniform(0.3, 0.6)], [0, 0, 0, 0]])
+                else:
+                    par = np.concatenate([g4.uniform(-0.2, 0.2, 3), [g4.uniform(0.2, 0.5), g4.uniform(0.3, 0.8), float(g4.integers(0, 3))], [0, 0]])
+                if moving:
+                    q = g4.standard_normal(4); q /= np.linalg.norm(q)
+                    w, x, y, z = q
+                    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+                    sc, dsdt = g4.uniform(0.7, 1.5), g4.uniform(-0.3, 0.3)
+                    om, b, dbdt = g4.uniform(-1, 1, 3), g4.uniform(-0.1, 0.1, 3), g4.uniform(-0.5, 0.5, 3)
+                else:
+                    R, sc, dsdt, om, b, dbdt = np.eye(3), 1.0, 0.0, np.zeros(3), np.zeros(3), np.zeros(3)
+                cases.append(np.concatenate([[geom, ctype], par, [sc, dsdt], R.reshape(-1), om, b, dbdt]).astype(np.float32))
+    cases = np.stack(cases)                       # [24, 2 + 8 + 2 + 9 + 9]
+    npts = 96
+    cx = g4.uniform(-0.9, 0.9, (cases.shape[0], npts, 3)).astype(np.float32)
+    cv = g4.uniform(-1, 1, (cases.shape[0], npts, 3)).astype(np.float32)
+    cout, cin = cv.copy(), np.zeros((cases.shape[0], npts), np.int32)
+    for k, cs in enumerate(cases):
+        par, sc, dsdt = np.ascontiguousarray(cs[2:10]), float(cs[10]), float(cs[11])
+        R, om, b, dbdt = (np.ascontiguousarray(cs[12:21]), np.ascontiguousarray(cs[21:24]), np.ascontiguousarray(cs[24:27]),
+                          np.ascontiguousarray(cs[27:30]))
+        for i in range(npts):
+            cin[k, i] = ref.ref_collider_resolve(int(cs[0]), int(cs[1]), P(par), C.c_float(sc), C.c_float(dsdt), P(R), P(om), P(b), P(dbdt),
+                                                 P(cx[k, i]), P(cout[k, i]))
+    np.savez_compressed(os.path.join(OUT, "collider.npz"), cases=cases, x=cx, v=cv, v_out=cout, inside=cin)
+    print("collider: %d of %d points inside" % (cin.sum(), cin.size))
     print("wrote", os.listdir(OUT))
 
 

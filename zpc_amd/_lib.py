@@ -81,6 +81,12 @@ def lib():
     return _lib
 
 
+class Collider(C.Structure):
+    """zs_rocm_collider (include/zs_rocm.h): Collider<AnalyticLevelSet<...>, f32, 3> of geometry/Collider.h"""
+    _fields_ = [("geometry", C.c_int), ("type", C.c_int), ("param", C.c_float * 8), ("s", C.c_float), ("dsdt", C.c_float),
+                ("R", C.c_float * 9), ("omega", C.c_float * 3), ("b", C.c_float * 3), ("dbdt", C.c_float * 3)]
+
+
 def _declare(L):
     vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
     L.policy__device.restype = vp
@@ -292,6 +298,9 @@ def _declare_containers(L):
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
     L.zs_rocm_mpm_update_stress.argtypes = [vp, PP, Particles]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_collider_init.argtypes = [C.POINTER(Collider), i32, i32, C.POINTER(C.c_float), i32]
+    L.zs_rocm_mpm_apply_boundary.argtypes = [vp, PP, vp, vp, sz, C.POINTER(Collider)]
+    L.zs_rocm_collider_resolve.argtypes = [vp, C.POINTER(Collider), vp, vp, sz, vp]
     L.zs_rocm_mpm_halo_pack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp]
     L.zs_rocm_mpm_halo_unpack.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp, i32]
 

@@ -167,6 +167,12 @@ class MpmTransfer:
         lib().zs_rocm_mpm_grid_update(self.pol.handle, C.byref(self.params), self.grid.data_ptr(), self.nblocks, e,
                                       max_vel.data_ptr() if max_vel is not None else None)
 
+    def apply_boundary(self, collider):
+        """ApplyBoundaryConditionOnGridBlocks (simulation/grid/GridOp.hpp:111-164): collider.resolveCollision on every grid node
+        with mass; call after grid_update.  `collider`: make_collider(...)."""
+        lib().zs_rocm_mpm_apply_boundary(self.pol.handle, C.byref(self.params), self.table.handle, self.grid.data_ptr(), self.nblocks,
+                                         C.byref(collider))
+
     def g2p(self, binned=None):
         binned = self.binned if binned is None else binned
         bs = self.bin_start.data_ptr() if binned else None
@@ -235,3 +241,24 @@ class MpmTransfer:
         k = keys.cpu().numpy().reshape(nb, 3)
         g = self.grid.cpu().numpy().reshape(nb, 7, self.side ** 3)
         return {tuple(int(x) for x in k[i]): g[i] for i in range(nb)}
+
+
+PLANE, CUBOID, SPHERE, CYLINDER = 0, 1, 2, 3   # analytic_geometry_e members GeneralBoundary holds (geometry/Collider.h:246-252)
+STICKY, SLIP, SEPARATE = 0, 1, 2               # collider_e (geometry/Collider.h:8)
+
+
+def make_collider(geometry, ctype, param, s=1.0, dsdt=0.0, R=None, omega=(0, 0, 0), b=(0, 0, 0), dbdt=(0, 0, 0)):
+    """zs::Collider<AnalyticLevelSet<geometry, f32, 3>>{levelset(param), ctype} with setTranslation / setRotation / scale.
+    param: plane (origin xyz, normal xyz), cuboid (min xyz, max xyz), sphere (centre xyz, radius), cylinder (bottom xyz, radius,
+    length, axis)."""
+    from ._lib import Collider
+    c = Collider()
+    p = [float(v) for v in param]
+    lib().zs_rocm_collider_init(C.byref(c), int(geometry), int(ctype), (C.c_float * len(p))(*p), len(p))
+    c.s, c.dsdt = float(s), float(dsdt)
+    if R is not None:
+        c.R = (C.c_float * 9)(*[float(v) for v in (R.reshape(-1) if hasattr(R, "reshape") else R)])
+    c.omega = (C.c_float * 3)(*[float(v) for v in omega])
+    c.b = (C.c_float * 3)(*[float(v) for v in b])
+    c.dbdt = (C.c_float * 3)(*[float(v) for v in dbdt])
+    return c
