@@ -457,7 +457,7 @@ typedef struct {
   size_t n;
 } zs_rocm_particles;
 
-enum { ZS_MPM_FIXED_COROTATED = 0, ZS_MPM_DRUCKER_PRAGER = 1 };
+enum { ZS_MPM_FIXED_COROTATED = 0, ZS_MPM_DRUCKER_PRAGER = 1, ZS_MPM_VONMISES_FIXED_COROTATED = 2, ZS_MPM_NACC = 3 };
 typedef struct {
   int model;          /* FixedCorotatedConfig | DruckerPragerConfig (physics/ConstitutiveModel.hpp:739-757) */
   float dx, dt;
@@ -467,7 +467,12 @@ typedef struct {
   int side;           /* grid block side: 4 = Grids<f32,3,4> (geometry/Structure.hpp), 8 = SparseGrid<3,f32,8> */
   int keyIsOrigin;    /* 0: partition keys are block coordinates cell/side (Grids + HashTable/bht, simulation/Utils.hpp:24-31);
                          1: keys are block origins in cells, multiples of side (SparseGrid, geometry/SparseGrid.hpp:305-309) */
+  float yieldStress;  /* VonMisesFixedCorotatedConfig::yieldStress (physics/ConstitutiveModel.hpp:745-749) */
+  float xi, Msqr;     /* NACCConfig::xi, NACCConfig::Msqr() (:759-785; zs_rocm_nacc_msqr); NACC also uses E, nu, beta, logJp */
+  int hardeningOn;    /* NACCConfig::hardeningOn */
 } zs_rocm_mpm_params;
+/* NACCConfig::Msqr() for friction angle `fa` and dimension 3, evaluated as the reference does (physics/ConstitutiveModel.hpp:771-785) */
+ZS_ROCM_EXPORT float zs_rocm_nacc_msqr(float fa);
 
 /* grid: TileVector<f32, side^3> with 7 channels {m:1, v:3, rhs:3} (simulation/mpm/Simulator.cpp:116-122),
  * block b channel c cell k at grid[(b*7 + c)*side^3 + k], cell id = (x*side + y)*side + z

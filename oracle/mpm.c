@@ -171,6 +171,126 @@ void orc_stress_fixedcorotated(float volume, float mu, float lam, const float F[
   pft_vol(P, F, volume, PF);
 }
 
+/* math::sqrtNewtonRaphson<float> (math/MathUtils.h:239-252): what the HOST header uses where the CUDA one calls sqrtf */
+static float sqrt_newton(float n) {
+  const float relTol = 1e-6f, eps = 128.f * 1.1920929e-07f;
+  if (n < -eps) return NAN;
+  if (n < eps) return 0.f;
+  float xn = 1.f, xnp1 = 0.5f * (xn + n / xn);
+  const float tol = (n * relTol > eps) ? n * relTol : eps;
+  for (; fabsf(xnp1 - xn) > tol; xnp1 = 0.5f * (xn + n / xn)) xn = xnp1;
+  return xnp1;
+}
+
+/* compute_stress_vonmisesfixedcorotated.  hostVariant = 1: physics/ConstitutiveModel_Vol_dP.hpp:48-111 (Newton square roots,
+   negative discriminant clamped) -- the form oracle/_ref pins; hostVariant = 0: cuda/physics/ConstitutiveModel.hpp:47-116
+   (sqrtf) -- the form the GPU path is compared with.  F is projected in place. */
+void orc_stress_vonmises(float volume, float mu, float lam, float yieldStress, int hostVariant, float F[9], float PF[9]) {
+  float U[9], S[3], V[9], Sc[3];
+  orc_svd3(F, U, S, V);
+  for (int d = 0; d < 3; ++d) Sc[d] = 1e-4f > S[d] ? 1e-4f : S[d];
+  float J = Sc[0] * Sc[1] * Sc[2]; /* prod(): ((1 * s0) * s1) * s2 */
+  float tau[3], st[3];
+  for (int d = 0; d < 3; ++d) tau[d] = 2 * mu * (Sc[d] - 1) * Sc[d] + lam * (J - 1) * J;
+  float tr = tau[0] + tau[1] + tau[2];
+  for (int d = 0; d < 3; ++d) st[d] = tau[d] - (tr / 3.f);
+  float l2 = st[0] * st[0] + st[1] * st[1] + st[2] * st[2];
+  float s_norm = hostVariant ? sqrt_newton(l2) : sqrtf(l2);
+  float scaled_tauy = (hostVariant ? sqrt_newton(2.f / (6.f - 3.f)) : sqrtf(2.f / (6.f - 3.f))) * yieldStress;
+  if (s_norm - scaled_tauy > 0) {
+    float alpha = scaled_tauy / s_norm;
+    J = 1.f;
+    for (int d = 0; d < 3; ++d) {
+      float tau_new = alpha * st[d] + (tr / 3.f);
+      float b2m4ac = mu * mu - 2 * mu * (lam * (J - 1) * J - tau_new);
+      float sq = hostVariant ? (b2m4ac < 0 ? 0.f : sqrt_newton(b2m4ac)) : sqrtf(b2m4ac);
+      S[d] = (mu + sq) / (2 * mu);
+    }
+    mat_diag_matT(F, U, S, V);
+  }
+  J = S[0] * S[1] * S[2];
+  float smu = 2.f * mu, slam = lam * (J - 1.f), Ph[3], P[9];
+  Ph[0] = smu * (S[0] - 1.f) + slam * (S[1] * S[2]);
+  Ph[1] = smu * (S[1] - 1.f) + slam * (S[0] * S[2]);
+  Ph[2] = smu * (S[2] - 1.f) + slam * (S[0] * S[1]);
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) P[r + 3 * c] = Ph[0] * U[r] * V[c] + Ph[1] * U[r + 3] * V[c + 3] + Ph[2] * U[r + 6] * V[c + 6];
+  pft_vol(P, F, volume, PF);
+}
+
+/* compute_stress_nacc.  hostVariant = 1: physics/ConstitutiveModel_Vol_dP.hpp:113-243, whose yield pressure reads
+   p0 = bm * 0.00001 + sin((double)(xi * max(-logJp, 0))); hostVariant = 0: cuda/physics/ConstitutiveModel.hpp:118-243 with
+   p0 = bm * (0.00001 + sinh(xi * max(-logJp, 0))) -- the CudaExecutionPolicy behaviour the GPU path follows.  Everything
+   after that line is the same code in both headers.  F is projected in place, logJp hardened. */
+void orc_stress_nacc(float volume, float mu, float lam, float bm, float xi, float beta, float Msqr, int hardeningOn, int hostVariant,
+                     float *logJp, float F[9], float PF[9]) {
+  float U[9], S[3], V[9];
+  orc_svd3(F, U, S, V);
+  float a = -*logJp > 0 ? -*logJp : 0;
+  float p0 = hostVariant ? (float)(bm * 0.00001f + sin((double)(xi * a))) : bm * (0.00001f + sinhf(xi * a));
+  float p_min = -beta * p0;
+  float Je_trial = S[0] * S[1] * S[2];
+  float Bh[3] = {S[0] * S[0], S[1] * S[1], S[2] * S[2]};
+  float trB = (Bh[0] + Bh[1] + Bh[2]) / 3.f;
+  float Jm = mu * powf(Je_trial, -2.f / 3.f);
+  float sh[3] = {Jm * (Bh[0] - trB), Jm * (Bh[1] - trB), Jm * (Bh[2] - trB)};
+  float psi = bm * 0.5f * (Je_trial - 1.f / Je_trial);
+  float p_trial = -psi * Je_trial;
+  float ys = 3.f / 2.f * (1 + 2.f * beta);
+  float yp = (Msqr * (p_trial - p_min) * (p_trial - p0));
+  float sn = sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2];
+  float y = (ys * sn) + yp;
+  if (p_trial > p0) {
+    float Je_new = sqrtf(-2.f * p0 / bm + 1.f);
+    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+    mat_diag_matT(F, U, S, V);
+    if (hardeningOn) *logJp += logf(Je_trial / Je_new);
+  } else if (p_trial < p_min) {
+    float Je_new = sqrtf(-2.f * p_min / bm + 1.f);
+    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+    mat_diag_matT(F, U, S, V);
+    if (hardeningOn) *logJp += logf(Je_trial / Je_new);
+  } else if (y >= 1e-4) {
+    float Bs = powf(Je_trial, 2.f / 3.f) / mu * sqrtf(-yp / ys) / sqrtf(sn);
+    for (int i = 0; i < 3; ++i) S[i] = sqrtf(sh[i] * Bs + trB);
+    mat_diag_matT(F, U, S, V);
+    if (hardeningOn && p0 > 1e-4 && p_trial < p0 - 1e-4 && p_trial > 1e-4 + p_min) {
+      float pc = (1.f - beta) * p0 / 2;
+      float q_trial = sqrtf(3.f / 2.f * sn);
+      float dir[2] = {pc - p_trial, -q_trial};
+      float dn = sqrtf(dir[0] * dir[0] + dir[1] * dir[1]);
+      dir[0] /= dn;
+      dir[1] /= dn;
+      float Cq = Msqr * (pc - p_min) * (pc - p0);
+      float Bq = Msqr * dir[0] * (2 * pc - p0 - p_min);
+      float Aq = Msqr * dir[0] * dir[0] + (1 + 2 * beta) * dir[1] * dir[1];
+      float l1 = (-Bq + sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
+      float l2 = (-Bq - sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
+      float p1 = pc + l1 * dir[0], p2 = pc + l2 * dir[0];
+      float pf = (p_trial - pc) * (p1 - pc) > 0 ? p1 : p2;
+      float tJ = (-2 * pf / bm + 1);
+      float Jf = sqrtf(tJ > 0 ? tJ : -tJ);
+      if (Jf > 1e-4) *logJp += logf(Je_trial / Jf);
+    }
+  }
+  float J = S[0] * S[1] * S[2];
+  float b[9];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) b[r + 3 * c] = F[r] * F[c] + F[r + 3] * F[c + 3] + F[r + 6] * F[c + 6]; /* MatrixUtils.h:244-256 */
+  float trb = (b[0] + b[4] + b[8]) / 3.f;
+  b[0] -= trb; b[4] -= trb; b[8] -= trb;
+  float dc = mu * powf(J, -2.f / 3.f), ic = bm * .5f * (J * J - 1.f);
+  for (int d = 0; d < 9; ++d) PF[d] = (dc * b[d] + ((d & 3) ? 0.f : ic)) * volume;
+}
+/* NACCConfig::bulk(), Msqr() (physics/ConstitutiveModel.hpp:767-785), dim = 3 */
+float orc_nacc_bulk(float E, float nu) { return 2.f / 3.f * (E / (2 * (1 + nu))) + (E * nu / ((1 + nu) * (1 - 2 * nu))); }
+float orc_nacc_msqr(float fa) {
+  float sin_phi = sinf(fa);
+  float mcf = sqrtf(2.f / 3.f) * 2.f * sin_phi / (3.f - sin_phi);
+  float M = mcf * 3 / sqrtf(2.f / (6.f - 3));
+  return M * M;
+}
+
 void orc_stress_sand(float volume, float mu, float lam, float cohesion, float beta, float yieldSurface,
                      int volCorrection, float *logJp, float F[9], float PF[9]) {
   float U[9], S[3], V[9];
@@ -303,6 +423,12 @@ void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const 
     memcpy(F, Fm + 9 * i, 36);
     if (p->model == 0) {
       orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
+    } else if (p->model == 2) { /* P2G.hpp:86-88 */
+      orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, 0, F, contrib);
+    } else if (p->model == 3) { /* P2G.hpp:96-101 */
+      float lj = logJp[i];
+      orc_stress_nacc(p->volume, mu, lam, orc_nacc_bulk(p->E, p->nu), p->xi, p->beta, p->Msqr, p->hardeningOn, 0, &lj, F, contrib);
+      logJp[i] = lj;
     } else {
       float lj = logJp[i];
       orc_stress_sand(p->volume, mu, lam, p->cohesion, p->beta, p->yieldSurface, p->volCorrection, &lj, F, contrib);

@@ -89,6 +89,34 @@ void ref_stress_sand(float volume, float mu, float lam, float cohesion, float be
     F[i] = f[i];
   }
 }
+void ref_stress_vonmises(float volume, float mu, float lam, float yieldStress, float *F, float *PF) {
+  vec<float, 9> f{}, pf{};
+  for (int i = 0; i < 9; ++i) f[i] = F[i];
+  compute_stress_vonmisesfixedcorotated(volume, mu, lam, yieldStress, f, pf);
+  for (int i = 0; i < 9; ++i) {
+    PF[i] = pf[i];
+    F[i] = f[i];
+  }
+}
+void ref_stress_nacc(float volume, float mu, float lam, float bm, float xi, float beta, float Msqr, int hardeningOn, float *logJp,
+                     float *F, float *PF) {
+  vec<float, 9> f{}, pf{};
+  for (int i = 0; i < 9; ++i) f[i] = F[i];
+  compute_stress_nacc(volume, mu, lam, bm, xi, beta, Msqr, (bool)hardeningOn, *logJp, f, pf);
+  for (int i = 0; i < 9; ++i) {
+    PF[i] = pf[i];
+    F[i] = f[i];
+  }
+}
+/* NACCConfig (physics/ConstitutiveModel.hpp:759-785) */
+void ref_nacc_config(float E, float nu, float fa, float *bulk, float *Msqr) {
+  NACCConfig c{};
+  c.E = E;
+  c.nu = nu;
+  c.fa = fa;
+  *bulk = c.bulk();
+  *Msqr = c.Msqr();
+}
 /* base_node<1> and quadratic_bspline_weights<0>: InterpolationKernel.hpp:47-55,93-130 */
 int ref_base_node_quadratic(float x) { return base_node<1>(x); }
 void ref_quadratic_weights(const float *x, float *w /*[3][3]*/) {

@@ -165,14 +165,22 @@ void orc_stress_sand(float volume, float mu, float lam, float cohesion, float be
 void orc_arena(float dx, const float pos[3], int32_t corner[3], float localPos[3], float w[9]);
 
 typedef struct {
-  int model;          /* 0 = FixedCorotated, 1 = DruckerPrager(sand) */
+  int model;          /* 0 = FixedCorotated, 1 = DruckerPrager(sand), 2 = VonMisesFixedCorotated, 3 = NACC */
   float dx, dt;
   float volume, E, nu;
   float cohesion, beta, yieldSurface;
   int volCorrection;
   int side;           /* block side length in cells: 4 (Grids<f32,3,4>) or 8 (SparseGrid<3,f32,8>) */
   int nthreads;       /* 1 = SequentialExecutionPolicy order, >1 = OmpExecutionPolicy with float CAS atomics */
+  float yieldStress;  /* model 2 = VonMisesFixedCorotated */
+  float xi, Msqr;     /* model 3 = NACC (also E, nu, beta) */
+  int hardeningOn;
 } orc_mpm_params;
+void orc_stress_vonmises(float volume, float mu, float lam, float yieldStress, int hostVariant, float F[9], float PF[9]);
+void orc_stress_nacc(float volume, float mu, float lam, float bm, float xi, float beta, float Msqr, int hardeningOn, int hostVariant,
+                     float *logJp, float F[9], float PF[9]);
+float orc_nacc_bulk(float E, float nu);
+float orc_nacc_msqr(float fa);
 
 /* sparsity/SparsityOp.hpp:59-115: ComputeSparsity + EnlargeSparsity on a bht keyed by block coord */
 void orc_mpm_build_partition(orc_bht *table, const float *pos, size_t n, float dx, int side);

@@ -35,8 +35,13 @@ def test_svd_and_stress_blocks(pol, oracle):
     assert (np.linalg.det(Um) > 0).all() and (np.linalg.det(Vm) > 0).all()     # rotations (math::svd convention)
     # stress: fixed corotated + sand
     mu, lam = 0.5 * 5e4 / 1.4, 5e4 * 0.4 / (1.4 * 0.2)
-    for model in (0, 1):
-        p = MpmParams(model, 1 / 64, 1e-4, 2.5e-7, 5e4, 0.4, 0.0, 1.0, YIELD_SURFACE, 1, 4, 0)
+    oracle.orc_nacc_bulk.restype = C.c_float
+    oracle.orc_nacc_msqr.restype = C.c_float
+    bm, msqr = oracle.orc_nacc_bulk(C.c_float(5e4), C.c_float(0.4)), oracle.orc_nacc_msqr(C.c_float(45.0))
+    assert zs.lib().zs_rocm_nacc_msqr(45.0) == msqr
+    for model in (0, 1, 2, 3):
+        # von Mises: yield stress 500 (part of the cloud yields); NACC: beta 0.5, xi 0.8, hardening on
+        p = MpmParams(model, 1 / 64, 1e-4, 2.5e-7, 5e4, 0.4, 0.0, 0.5 if model == 3 else 1.0, YIELD_SURFACE, 1, 4, 0, 500.0, 0.8, msqr, 1)
         Fd = dF.clone()
         lj = torch.from_numpy((0.01 * g.standard_normal(n)).astype(np.float32)).cuda()
         lj0 = lj.cpu().numpy().copy()
@@ -46,19 +51,32 @@ def test_svd_and_stress_blocks(pol, oracle):
         ref = np.zeros((n, 9), np.float32)
         Fo = F.copy()
         ljo = lj0.copy()
+        cf = C.c_float
         for i in range(n):
             if model == 0:
-                oracle.orc_stress_fixedcorotated(C.c_float(2.5e-7), C.c_float(mu), C.c_float(lam), ptr(Fo[i]), ptr(ref[i]))
+                oracle.orc_stress_fixedcorotated(cf(2.5e-7), cf(mu), cf(lam), ptr(Fo[i]), ptr(ref[i]))
+            elif model == 2:  # hostVariant 0 = the CUDA header's arithmetic (sqrtf), which the GPU path follows
+                oracle.orc_stress_vonmises(cf(2.5e-7), cf(mu), cf(lam), cf(500.0), 0, ptr(Fo[i]), ptr(ref[i]))
             else:
-                l = C.c_float(ljo[i])
-                oracle.orc_stress_sand(C.c_float(2.5e-7), C.c_float(mu), C.c_float(lam), C.c_float(0.0), C.c_float(1.0),
-                                       C.c_float(YIELD_SURFACE), 1, C.byref(l), ptr(Fo[i]), ptr(ref[i]))
+                l = cf(ljo[i])
+                if model == 1:
+                    oracle.orc_stress_sand(cf(2.5e-7), cf(mu), cf(lam), cf(0.0), cf(1.0), cf(YIELD_SURFACE), 1, C.byref(l), ptr(Fo[i]), ptr(ref[i]))
+                else:
+                    oracle.orc_stress_nacc(cf(2.5e-7), cf(mu), cf(lam), cf(bm), cf(0.8), cf(0.5), cf(msqr), 1, 0, C.byref(l), ptr(Fo[i]), ptr(ref[i]))
                 ljo[i] = l.value
         scale = (2 * mu + lam) * 2.5e-7
-        assert np.abs(PFh - ref).max() < 5e-5 * scale * max(1.0, np.abs(F - np.eye(3).reshape(1, 9)).max()), model
-        if model == 1:
-            assert np.abs(lj.cpu().numpy() - ljo).max() < 2e-5
-            assert np.abs(Fd.cpu().numpy() - Fo).max() < 2e-5
+        rowmag = np.maximum(np.abs(ref).max(1, keepdims=True), scale * max(1.0, np.abs(F - np.eye(3).reshape(1, 9)).max()))
+        ok = np.isfinite(ref).all(1)  # von Mises: a negative discriminant gives NaN in the CUDA header (sqrtf), on both sides
+        assert ok.mean() > 0.5 and np.array_equal(np.isfinite(PFh).all(1), ok), model
+        assert (np.abs(PFh - ref)[ok] <= 1e-4 * rowmag[ok]).all(), (model, (np.abs(PFh - ref)[ok] / rowmag[ok]).max())
+        if model != 0:
+            assert np.abs(Fd.cpu().numpy() - Fo)[ok].max() < 5e-5, model          # projected F returned by the test entry
+        if model in (1, 3):
+            ljg = lj.cpu().numpy()
+            fin = np.isfinite(ljo)  # NACC, inverted F: log of a negative volume ratio -> NaN, on both sides
+            assert np.array_equal(np.isfinite(ljg), fin) and np.abs(ljg - ljo)[ok & fin].max() < 2e-5, model
+        if model == 2:
+            assert 0.05 < (np.abs(Fo - F).max(1) > 1e-6).mean() < 1.0             # some particles yield, in both implementations
 
 
 def _compare_grids(ga, gb, rtol):
@@ -71,7 +89,7 @@ def _compare_grids(ga, gb, rtol):
 
 
 @pytest.mark.parametrize("side", [4, 8])
-@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
 @pytest.mark.parametrize("binned", [False, True])
 def test_p2g_g2p_vs_oracle(pol, oracle, side, model, binned):
     from zpc_amd.mpm import MpmTransfer
@@ -80,12 +98,13 @@ def test_p2g_g2p_vs_oracle(pol, oracle, side, model, binned):
     n = pos.shape[0]
     vol = dx ** 3 / 8
     lj0 = (0.01 * rng(33).standard_normal(n)).astype(np.float32)
-    om = OracleMpm(oracle, model, dx, dt, side, vol)
+    om = OracleMpm(oracle, model, dx, dt, side, vol, yield_stress=200.0, beta=0.5 if model == 3 else 1.0)
     nb_o = om.build_partition(pos, n)
     lj_o = om.p2g(mass, pos, vel, Cm, F, lj0.copy())
 
-    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, lane_width=64)
-    mt.upload(mass, pos, vel, Cm, F, lj0 if model == 1 else None)
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, lane_width=64, yield_stress=200.0,
+                     beta=0.5 if model == 3 else 1.0)
+    mt.upload(mass, pos, vel, Cm, F, lj0 if model in (1, 3) else None)
     nb = mt.build_partition(n)
     assert nb == nb_o
     if binned:
@@ -98,22 +117,24 @@ def test_p2g_g2p_vs_oracle(pol, oracle, side, model, binned):
     mt.clear_grid()
     mt.p2g()
     pol.syncCtx()
-    _compare_grids(mt.grid_by_key(), om.grid_by_key(), 2e-4)
+    # NACC: the hardening update takes the root of a nearly cancelling discriminant, its stress is the least well conditioned
+    grtol = 5e-4 if model == 3 else 2e-4
+    _compare_grids(mt.grid_by_key(), om.grid_by_key(), grtol)
     # conservation (size-independent property): total mass and momentum on the grid == particles
     g = np.stack(list(mt.grid_by_key().values()))
     assert abs(g[:, 0].sum() - mass.sum()) < 1e-4 * mass.sum()
     mom_p = (mass[:, None] * vel).sum(0)
     assert np.abs(g[:, 1:4].sum(axis=(0, 2)) - mom_p).max() < 2e-3 * np.abs(mass[:, None] * vel).sum()
-    if model == 1:
+    if model in (1, 3):
         d = mt.download()
         inv = mt.order.cpu().numpy() if binned else np.arange(n)
-        assert np.abs(d["logJp"] - lj_o[inv]).max() < 2e-5
+        assert np.abs(d["logJp"] - lj_o[inv]).max() < (2e-3 if model == 3 else 2e-5)
     # grid update + G2P
     mx = torch.zeros(1, dtype=torch.float32, device="cuda")
     mt.grid_update((0.0, -9.8, 0.0), mx)
     mxo = om.grid_update((0.0, -9.8, 0.0))
     assert abs(float(mx.item()) - mxo) <= 1e-4 * mxo
-    _compare_grids(mt.grid_by_key(), om.grid_by_key(), 2e-4)
+    _compare_grids(mt.grid_by_key(), om.grid_by_key(), grtol)
     po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
     om.g2p(po, vo, Co, Fo)
     mt.g2p()
@@ -231,7 +252,7 @@ def test_aos_particles(pol, oracle, binned):
     assert np.abs(out[:, 25] - lj_o[inv]).max() < 2e-5
 
 
-@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
 @pytest.mark.parametrize("side", [4, 8])
 def test_cached_stress_matches_recompute_over_steps(pol, oracle, model, side):
     """Fusing the constitutive update into the tail of G2P (particles.stress) gives the same multi-step trajectory as the
@@ -242,13 +263,14 @@ def test_cached_stress_matches_recompute_over_steps(pol, oracle, model, side):
     n = pos.shape[0]
     vol = dx ** 3 / 8
     lj0 = (0.01 * rng(83).standard_normal(n)).astype(np.float32)
-    om = OracleMpm(oracle, model, dx, dt, side, vol)
+    om = OracleMpm(oracle, model, dx, dt, side, vol, yield_stress=200.0, beta=0.5 if model == 3 else 1.0)
     om.build_partition(pos, n)
     po, vo, Co, Fo, ljo = pos.copy(), vel.copy(), Cm.copy(), F.copy(), lj0.copy()
     runs = {}
     for cached in (False, True):
-        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=cached)
-        mt.upload(mass, pos, vel, Cm, F, lj0 if model == 1 else None)
+        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=cached, yield_stress=200.0,
+                         beta=0.5 if model == 3 else 1.0)
+        mt.upload(mass, pos, vel, Cm, F, lj0 if model in (1, 3) else None)
         assert mt.build_partition(n) == om.nblocks
         mt.rebin()
         mt.update_stress()
@@ -284,12 +306,12 @@ def test_cached_stress_matches_recompute_over_steps(pol, oracle, model, side):
         assert np.abs(da[k] - db[k]).max() <= tol, k          # cached == recompute
         ref = {"x": po, "v": vo, "F": Fo, "C": Co}[k]
         assert np.abs(db[k] - ref).max() <= tol * 2, k         # both follow the oracle
-    if model == 1:
+    if model in (1, 3):
         assert np.abs(da["logJp"] - db["logJp"]).max() < 5e-5
-        assert np.abs(db["logJp"] - ljo).max() < 1e-4
+        assert np.abs(db["logJp"] - ljo).max() < (2e-3 if model == 3 else 1e-4)   # NACC hardening: see test_p2g_g2p_vs_oracle
 
 
-@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
 @pytest.mark.parametrize("side", [4, 8])
 def test_fused_g2p2g_matches_unfused_steps(pol, oracle, model, side):
     """zs_rocm_mpm_g2p2g (G2P of step n + P2G of step n+1 in one pass, v / C / stress kept on chip) reproduces the unfused
@@ -297,14 +319,17 @@ def test_fused_g2p2g_matches_unfused_steps(pol, oracle, model, side):
     pushes particles across cell boundaries so that both exact-path queues are exercised."""
     from zpc_amd.mpm import MpmTransfer
     dx, dt = 1.0 / 64, 1e-3
-    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=91 + model, vel_scale=3.0)
+    # von Mises: the CUDA header takes sqrtf of a discriminant that turns negative under strong compression (NaN, "Wrong
+    # projection"); keep that model's cloud gentle -- the cell-crossing particles are exercised by the other three models
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=91 + model, vel_scale=3.0 if model != 2 else 0.3)
     n = pos.shape[0]
     vol = dx ** 3 / 8
     lj0 = (0.01 * rng(93).standard_normal(n)).astype(np.float32)
     runs = []
     for fused in (False, True):
-        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
-        mt.upload(mass, pos, vel, Cm, F, lj0 if model == 1 else None)
+        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True, yield_stress=200.0,
+                         beta=0.5 if model == 3 else 1.0)
+        mt.upload(mass, pos, vel, Cm, F, lj0 if model in (1, 3) else None)
         mt.build_partition(n)
         mt.rebin()
         mt.update_stress()
@@ -339,8 +364,8 @@ def test_fused_g2p2g_matches_unfused_steps(pol, oracle, model, side):
         return out
     da, db = original_order(a), original_order(b)
     moved = np.abs(da["x"] - pos).max() / dx
-    assert moved > 0.05  # the cloud really moved (cells were crossed)
+    assert moved > (0.05 if model != 2 else 0.005)  # the cloud really moved (cells were crossed)
     for k, tol in (("x", 3e-6), ("v", 5e-4 * np.abs(da["v"]).max()), ("F", 1e-4), ("C", 1e-3 * np.abs(da["C"]).max())):
         assert np.abs(da[k] - db[k]).max() <= tol, k
-    if model == 1:
+    if model in (1, 3):
         assert np.abs(da["logJp"] - db["logJp"]).max() < 1e-4

@@ -411,3 +411,48 @@ def test_collider_matches_reference_golden(oracle):
         assert np.array_equal(ins, g["inside"][k])
         assert np.array_equal(v, g["v_out"][k]), (k, cs[:2])
         assert np.array_equal(v[ins == 0], g["v"][k][ins == 0])          # outside: untouched
+
+
+def test_vonmises_and_nacc_match_reference_golden(oracle):
+    """compute_stress_vonmisesfixedcorotated / compute_stress_nacc of the HOST header (physics/ConstitutiveModel_Vol_dP.hpp:48-243)
+    compiled in place -> tests/golden/stress_models.npz; the oracle's hostVariant = 1 form reproduces them.  The CUDA-header
+    form (hostVariant = 0, what the GPU path follows) differs only in sqrtf-vs-Newton square roots (von Mises) and in the yield
+    pressure line p0 (NACC): identical wherever -logJp <= 0."""
+    g, sv = np.load(os.path.join(GOLD, "stress_models.npz")), np.load(os.path.join(GOLD, "svd_stress.npz"))
+    F, mu, lam, vol = sv["F"], float(sv["mu"]), float(sv["lam"]), float(sv["vol"])
+    n, cf = F.shape[0], C.c_float
+    scale = (2 * mu + lam) * vol
+    oracle.orc_nacc_bulk.restype = C.c_float
+    oracle.orc_nacc_msqr.restype = C.c_float
+    assert oracle.orc_nacc_bulk(cf(5e4), cf(0.4)) == float(g["nacc_bulk"]) and oracle.orc_nacc_msqr(cf(45.0)) == float(g["nacc_msqr"])
+
+    def rel(a, b):
+        return (np.abs(a - b) / np.maximum(np.abs(b).max(1, keepdims=True), scale)).max()
+    for variant in (1, 0):
+        Fv, pf = F.copy(), np.zeros((n, 9), np.float32)
+        for i in range(n):
+            oracle.orc_stress_vonmises(cf(vol), cf(mu), cf(lam), cf(float(g["vm_yield"])), variant, ptr(Fv[i]), ptr(pf[i]))
+        ok = np.isfinite(pf).all(1)          # CUDA form: sqrtf of a negative discriminant (the host form clamps it)
+        assert ok.all() if variant else ok.mean() > 0.75
+        if variant:
+            assert rel(pf[ok], g["PF_vm"][ok]) < 1e-4 and np.abs(Fv - g["F_vm_out"])[ok].max() < 5e-5
+        else:
+            # the host header's sqrtNewtonRaphson stops at an ABSOLUTE step of n * 1e-6 (MathUtils.h:246): percent-level errors
+            # for the discriminant ~ mu^2 of a yielding particle, which the CUDA header's sqrtf does not have.  So the CUDA form
+            # agrees tightly with the host golden where nothing was projected and only loosely elsewhere.
+            still = ok & (np.abs(g["F_vm_out"] - F).max(1) == 0)
+            assert still.sum() > 0 and rel(pf[still], g["PF_vm"][still]) < 1e-4
+            assert rel(pf[ok], g["PF_vm"][ok]) < 0.25 and np.abs(Fv - g["F_vm_out"])[ok].max() < 0.25
+        Fn, pfn, lj = F.copy(), np.zeros((n, 9), np.float32), g["logJp_in"].copy()
+        for i in range(n):
+            x = cf(lj[i])
+            oracle.orc_stress_nacc(cf(vol), cf(mu), cf(lam), cf(float(g["nacc_bulk"])), cf(0.8), cf(0.5), cf(float(g["nacc_msqr"])), 1,
+                                   variant, C.byref(x), ptr(Fn[i]), ptr(pfn[i]))
+            lj[i] = x.value
+        sel = slice(0, n) if variant else slice(0, n // 2)   # first half: logJp >= 0, where both headers agree
+        assert rel(pfn[sel], g["PF_nacc"][sel]) < 2e-5 and np.abs(Fn - g["F_nacc_out"])[sel].max() < 2e-5
+        fin = np.isfinite(g["logJp_out"])  # inverted F (Je_trial < 0): log of a negative ratio, NaN on both sides
+        assert np.array_equal(np.isfinite(lj)[sel], fin[sel]) and np.abs(lj - g["logJp_out"])[sel][fin[sel]].max() < 2e-5
+        if not variant:  # and the second half really takes the other yield pressure
+            assert np.abs(pfn[n // 2:] - g["PF_nacc"][n // 2:]).max() > 1e-3 * scale
+    assert (np.abs(g["F_vm_out"] - F).max(1) > 1e-6).mean() > 0.3 and (g["logJp_out"] != g["logJp_in"]).mean() > 0.3

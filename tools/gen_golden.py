@@ -97,6 +97,28 @@ def main():
     codes = np.array([ref.ref_lbvh_morton(P(whole), P(b)) for b in bvs], np.uint32)
     ov = np.array([[ref.ref_aabb_overlaps(P(bvs[i]), P(bvs[j])) for j in range(40)] for i in range(40)], np.int32)
     np.savez_compressed(os.path.join(OUT, "lbvh.npz"), whole=whole, bvs=bvs, codes=codes, overlaps40=ov)
+    # ---- von Mises and NACC (physics/ConstitutiveModel_Vol_dP.hpp:48-243) on the F set of svd_stress.npz
+    Fm = np.load(os.path.join(OUT, "svd_stress.npz"))["F"]
+    nm = Fm.shape[0]
+    g5 = np.random.default_rng(20251001)
+    vm_yield = np.float32(500.0)
+    F_vm, PF_vm = Fm.copy(), np.zeros((nm, 9), np.float32)
+    for i in range(nm):
+        ref.ref_stress_vonmises(C.c_float(vol), mu, lam, C.c_float(float(vm_yield)), P(F_vm[i]), P(PF_vm[i]))
+    bulk, msqr = C.c_float(), C.c_float()
+    ref.ref_nacc_config(C.c_float(5e4), C.c_float(0.4), C.c_float(45.0), C.byref(bulk), C.byref(msqr))
+    lj_in = (0.02 * np.abs(g5.standard_normal(nm))).astype(np.float32)
+    lj_in[nm // 2:] *= -1            # second half: -logJp > 0, where the host header's p0 differs from the CUDA header's
+    lj_out, F_nacc, PF_nacc = lj_in.copy(), Fm.copy(), np.zeros((nm, 9), np.float32)
+    for i in range(nm):
+        l = C.c_float(lj_out[i])
+        ref.ref_stress_nacc(C.c_float(vol), mu, lam, bulk, C.c_float(0.8), C.c_float(0.5), msqr, 1, C.byref(l), P(F_nacc[i]), P(PF_nacc[i]))
+        lj_out[i] = l.value
+    np.savez_compressed(os.path.join(OUT, "stress_models.npz"), vm_yield=vm_yield, F_vm_out=F_vm, PF_vm=PF_vm, nacc_bulk=np.float32(bulk.value),
+                        nacc_msqr=np.float32(msqr.value), nacc_xi=np.float32(0.8), nacc_beta=np.float32(0.5), logJp_in=lj_in,
+                        logJp_out=lj_out, F_nacc_out=F_nacc, PF_nacc=PF_nacc)
+    print("von Mises: %d of %d projected; NACC: %d F changed, %d logJp changed" %
+          ((np.abs(F_vm - Fm).max(1) > 1e-7).sum(), nm, (np.abs(F_nacc - Fm).max(1) > 1e-7).sum(), (lj_out != lj_in).sum()))
     # ---- colliders: Collider<AnalyticLevelSet<Plane|Cuboid|Sphere|Cylinder>>::resolveCollision (geometry/Collider.h:82-112)
     g4 = np.random.default_rng(20250930)
     cases = []

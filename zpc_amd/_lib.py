@@ -57,7 +57,8 @@ class Particles(C.Structure):
 class MpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
-                ("volCorrection", C.c_int), ("side", C.c_int), ("keyIsOrigin", C.c_int)]
+                ("volCorrection", C.c_int), ("side", C.c_int), ("keyIsOrigin", C.c_int), ("yieldStress", C.c_float),
+                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int)]
 
 
 _lib = None
@@ -298,6 +299,8 @@ def _declare_containers(L):
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
     L.zs_rocm_mpm_update_stress.argtypes = [vp, PP, Particles]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_nacc_msqr.argtypes = [f32]
+    L.zs_rocm_nacc_msqr.restype = f32
     L.zs_rocm_collider_init.argtypes = [C.POINTER(Collider), i32, i32, C.POINTER(C.c_float), i32]
     L.zs_rocm_mpm_apply_boundary.argtypes = [vp, PP, vp, vp, sz, C.POINTER(Collider)]
     L.zs_rocm_collider_resolve.argtypes = [vp, C.POINTER(Collider), vp, vp, sz, vp]

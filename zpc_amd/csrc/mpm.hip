@@ -190,6 +190,9 @@ __device__ __forceinline__ void pft_vol(const float (&P)[9], const float (&F)[9]
 struct Material {
   float volume, mu, lam, cohesion, beta, yieldSurface;
   int volCorrection;
+  float yieldStress;           // von Mises
+  float bm, xi, Msqr;          // NACC: bulk modulus NACCConfig::bulk(), hardening factor, M^2
+  int hardeningOn;
 };
 
 // compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47).  The reference forms P = U diag(Phat) V^T and
@@ -294,6 +297,127 @@ __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, flo
   }
 }
 
+// compute_stress_vonmisesfixedcorotated (cuda/physics/ConstitutiveModel.hpp:47-116): von Mises return mapping of the
+// Kirchhoff stress in principal space, F projected in place (the caller decides whether it is stored), then the
+// fixed-corotated P F^T vol of the projected state.
+__device__ __forceinline__ void stress_vonmises(const Material &m, float (&F)[9], float (&PF)[9]) {
+  float U[9], S[3], V[9];
+  svd3(F, U, S, V);
+  float Sc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) Sc[d] = 1e-4f > S[d] ? 1e-4f : S[d];
+  float J = Sc[0] * Sc[1] * Sc[2];
+  float tau[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) tau[d] = 2 * m.mu * (Sc[d] - 1) * Sc[d] + m.lam * (J - 1) * J;
+  const float tr = tau[0] + tau[1] + tau[2];
+  float st[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) st[d] = tau[d] - (tr / 3.f);
+  const float s_norm = sqrtf(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]);
+  const float scaled_tauy = sqrtf(2.f / (6.f - 3.f)) * m.yieldStress;
+  if (s_norm - scaled_tauy > 0) {
+    const float alpha = scaled_tauy / s_norm;
+    J = 1.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float tau_new = alpha * st[d] + (tr / 3.f);
+      const float b2m4ac = m.mu * m.mu - 2 * m.mu * (m.lam * (J - 1) * J - tau_new);
+      S[d] = (m.mu + sqrtf(b2m4ac)) / (2 * m.mu);
+    }
+    mat_diag_matT(F, U, S, V);
+  }
+  J = S[0] * S[1] * S[2];
+  const float smu = 2.f * m.mu, slam = m.lam * (J - 1.f);
+  float Ph[3], P[9];
+  Ph[0] = smu * (S[0] - 1.f) + slam * (S[1] * S[2]);
+  Ph[1] = smu * (S[1] - 1.f) + slam * (S[0] * S[2]);
+  Ph[2] = smu * (S[2] - 1.f) + slam * (S[0] * S[1]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) P[r + 3 * c] = Ph[0] * U[r] * V[c] + Ph[1] * U[r + 3] * V[c + 3] + Ph[2] * U[r + 6] * V[c + 6];
+  pft_vol(P, F, m.volume, PF);
+}
+
+// compute_stress_nacc (cuda/physics/ConstitutiveModel.hpp:118-243): non-associated Cam-Clay, three projection cases +
+// hardening through logJp; F projected in place; neo-Hookean-type P F^T vol of the projected state.
+__device__ __forceinline__ void stress_nacc(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
+  float U[9], S[3], V[9];
+  svd3(F, U, S, V);
+  const float bm = m.bm, beta = m.beta, Msqr = m.Msqr, mu = m.mu;
+  const float p0 = bm * (0.00001f + sinhf(m.xi * (-logJp > 0 ? -logJp : 0)));
+  const float p_min = -beta * p0;
+  const float Je_trial = S[0] * S[1] * S[2];
+  const float Bh[3] = {S[0] * S[0], S[1] * S[1], S[2] * S[2]};
+  const float trB = (Bh[0] + Bh[1] + Bh[2]) / 3.f;
+  const float Jm = mu * powf(Je_trial, -2.f / 3.f);
+  const float sh[3] = {Jm * (Bh[0] - trB), Jm * (Bh[1] - trB), Jm * (Bh[2] - trB)};
+  const float psi = bm * 0.5f * (Je_trial - 1.f / Je_trial);
+  const float p_trial = -psi * Je_trial;
+  const float ys = 3.f / 2.f * (1 + 2.f * beta);
+  const float yp = (Msqr * (p_trial - p_min) * (p_trial - p0));
+  const float sn = sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2];
+  const float y = (ys * sn) + yp;
+  if (p_trial > p0) {  // case 1: max tip
+    const float Je_new = sqrtf(-2.f * p0 / bm + 1.f);
+    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+    mat_diag_matT(F, U, S, V);
+    if (m.hardeningOn) logJp += logf(Je_trial / Je_new);
+  } else if (p_trial < p_min) {  // case 2: min tip
+    const float Je_new = sqrtf(-2.f * p_min / bm + 1.f);
+    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+    mat_diag_matT(F, U, S, V);
+    if (m.hardeningOn) logJp += logf(Je_trial / Je_new);
+  } else if (y >= 1e-4) {  // case 3: onto the yield surface + hardening
+    const float Bs = powf(Je_trial, 2.f / 3.f) / mu * sqrtf(-yp / ys) / sqrtf(sn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S[i] = sqrtf(sh[i] * Bs + trB);
+    mat_diag_matT(F, U, S, V);
+    if (m.hardeningOn && p0 > 1e-4 && p_trial < p0 - 1e-4 && p_trial > 1e-4 + p_min) {
+      const float pc = (1.f - beta) * p0 / 2;
+      const float q_trial = sqrtf(3.f / 2.f * sn);
+      float dir[2] = {pc - p_trial, -q_trial};
+      const float dn = sqrtf(dir[0] * dir[0] + dir[1] * dir[1]);
+      dir[0] /= dn;
+      dir[1] /= dn;
+      const float Cq = Msqr * (pc - p_min) * (pc - p0);
+      const float Bq = Msqr * dir[0] * (2 * pc - p0 - p_min);
+      const float Aq = Msqr * dir[0] * dir[0] + (1 + 2 * beta) * dir[1] * dir[1];
+      const float l1 = (-Bq + sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
+      const float l2 = (-Bq - sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
+      const float p1 = pc + l1 * dir[0], p2 = pc + l2 * dir[0];
+      const float pf = (p_trial - pc) * (p1 - pc) > 0 ? p1 : p2;
+      const float tJ = (-2 * pf / bm + 1);
+      const float Jf = sqrtf(tJ > 0 ? tJ : -tJ);
+      if (Jf > 1e-4) logJp += logf(Je_trial / Jf);
+    }
+  }
+  const float J = S[0] * S[1] * S[2];
+  float b[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b[r + 3 * c] = F[r] * F[c] + F[r + 3] * F[c + 3] + F[r + 6] * F[c + 6];  // F F^T
+  const float trb = (b[0] + b[4] + b[8]) / 3.f;
+  b[0] -= trb; b[4] -= trb; b[8] -= trb;
+  const float dc = mu * powf(J, -2.f / 3.f), ic = bm * .5f * (J * J - 1.f);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) PF[d] = (dc * b[d] + ((d & 3) ? 0.f : ic)) * m.volume;
+}
+
+// which models carry the scalar plastic state logJp (P2G.hpp:88-101)
+__host__ __device__ constexpr bool model_uses_logjp(int model) { return model == ZS_MPM_DRUCKER_PRAGER || model == ZS_MPM_NACC; }
+// one entry point for the four constitutive models of P2G.hpp:82-101.  F is the local copy: the plastic models project it
+// in place, P2G / G2P never store it back (only logJp), the test entry zs_rocm_mpm_stress does (WRITE_F).
+template <int MODEL, bool WRITE_F = false>
+__device__ __forceinline__ void model_stress(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
+  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(m, F, PF);
+  else if constexpr (MODEL == ZS_MPM_DRUCKER_PRAGER) stress_sand<WRITE_F>(m, logJp, F, PF);
+  else if constexpr (MODEL == ZS_MPM_VONMISES_FIXED_COROTATED) stress_vonmises(m, F, PF);
+  else stress_nacc(m, logJp, F, PF);
+}
+
 // ======================================================================================= arena
 // LocalArena<collocated, quadratic> (simulation/Utils.hpp:47-75, InterpolationKernel.hpp:47-55,93-130)
 struct Arena {
@@ -380,7 +504,7 @@ struct ParticlesDev {
 };
 // third "model" of the P2G kernels: P F^T * vol is read from the particles' `stress` attribute (written by the G2P of
 // the previous step, or by zs_rocm_mpm_update_stress) instead of being recomputed
-constexpr int MPM_CACHED_STRESS = 2;
+constexpr int MPM_CACHED_STRESS = 100;
 
 template <int N> __device__ __forceinline__ void load_attr(const Port<float> &p, size_t i, float (&out)[N]);
 template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p, size_t i, const float (&v)[N]);
@@ -398,14 +522,12 @@ __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const Particl
   float F[9];
   if constexpr (MODEL == MPM_CACHED_STRESS) {
     load_attr<9>(ps.stress, i, contrib);
-  } else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
-    load_attr<9>(ps.F, i, F);
-    stress_fixedcorotated(mp.mat, F, contrib);
   } else {
     load_attr<9>(ps.F, i, F);
-    float lj = ps.logJp.base[ps.logJp.off(i)];
-    stress_sand<false>(mp.mat, lj, F, contrib);
-    ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back (as in the reference)
+    float lj = 0.f;
+    if constexpr (model_uses_logjp(MODEL)) lj = ps.logJp.base[ps.logJp.off(i)];
+    model_stress<MODEL>(mp.mat, lj, F, contrib);
+    if constexpr (model_uses_logjp(MODEL)) ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back
   }
 #pragma unroll
   for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
@@ -693,7 +815,7 @@ template <int MODEL, int LW> struct RecB {  // sweep B inputs: x, F (, logJp) --
     pload<LW, 3>(ps.pos, o, pos);
     if constexpr (MODEL == MPM_CACHED_STRESS) pload<LW, 9>(ps.stress, o, F);
     else pload<LW, 9>(ps.F, o, F);
-    if constexpr (MODEL == ZS_MPM_DRUCKER_PRAGER) logJp = pload1<LW>(ps.logJp, o);
+    if constexpr (model_uses_logjp(MODEL)) logJp = pload1<LW>(ps.logJp, o);
   }
 };
 
@@ -810,12 +932,11 @@ __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesD
           if constexpr (MODEL == MPM_CACHED_STRESS) {
 #pragma unroll
             for (int d = 0; d < 9; ++d) contrib[d] = cur.F[d];
-          } else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) {
-            stress_fixedcorotated(mp.mat, cur.F, contrib);
           } else {
-            float lj = cur.logJp;
-            stress_sand<false>(mp.mat, lj, cur.F, contrib);
-            pstore1<LW>(ps.logJp, particle_offset<LW>(ps.pos.chns, (size_t)i0), lj);  // P2G.hpp:101 (projected F not written back)
+            float lj = model_uses_logjp(MODEL) ? cur.logJp : 0.f;
+            model_stress<MODEL>(mp.mat, lj, cur.F, contrib);
+            if constexpr (model_uses_logjp(MODEL))
+              pstore1<LW>(ps.logJp, particle_offset<LW>(ps.pos.chns, (size_t)i0), lj);  // P2G.hpp:101 (projected F not written back)
           }
 #pragma unroll
           for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
@@ -1302,14 +1423,13 @@ __global__ __launch_bounds__(256) void grid_update_kernel(float *grid, size_t nb
 template <int SMODEL, int LW = 0>
 __device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesDev &ps, POff<LW> o, float (&F)[9]) {
   if constexpr (SMODEL >= 0) {
-    float PF[9];
-    if constexpr (SMODEL == ZS_MPM_FIXED_COROTATED) {
-      stress_fixedcorotated(mp.mat, F, PF);
-    } else {
-      float lj = pload1<LW>(ps.logJp, o);
-      stress_sand<false>(mp.mat, lj, F, PF);
-      pstore1<LW>(ps.logJp, o, lj);
-    }
+    float PF[9], Fl[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) Fl[d] = F[d];  // the plastic models project their local copy only
+    float lj = 0.f;
+    if constexpr (model_uses_logjp(SMODEL)) lj = pload1<LW>(ps.logJp, o);
+    model_stress<SMODEL>(mp.mat, lj, Fl, PF);
+    if constexpr (model_uses_logjp(SMODEL)) pstore1<LW>(ps.logJp, o, lj);
     pstore<LW, 9>(ps.stress, o, PF);
   }
 }
@@ -1651,7 +1771,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
                                            int lane, const float *varena, float *parena, float *stage, unsigned long long *smask,
                                            int *staleG, int *staleGCount, int *staleP, int *stalePCount) {
   using AL = ArenaLds;
-  constexpr bool DP = SMODEL == ZS_MPM_DRUCKER_PRAGER;
+  constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool STRESS = W >= 2;
   constexpr int NCH = STRESS ? 3 : 4;
   constexpr int R0 = (W & 1) * 2;  // first of this wave's two staged rounds in phase 2
@@ -1719,12 +1839,11 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
           for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * cur.F[3 * c] + tmp[r + 3] * cur.F[3 * c + 1] + tmp[r + 6] * cur.F[3 * c + 2];
         pstore<LW, 9>(ps.F, o, F);
         pstore<LW, 3>(ps.pos, o, pos);
-        if constexpr (SMODEL == ZS_MPM_FIXED_COROTATED) {
-          stress_fixedcorotated(mp.mat, F, PF);
-        } else {
-          float lj = cur.logJp;
-          stress_sand<false>(mp.mat, lj, F, PF);
-          pstore1<LW>(ps.logJp, o, lj);
+        {  // F has been stored above: the plastic models may project this local copy
+          float lj = 0.f;
+          if constexpr (DP) lj = cur.logJp;
+          model_stress<SMODEL>(mp.mat, lj, F, PF);
+          if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
         }
         bool moved = false;  // does the particle still belong to this lane's cell?
 #pragma unroll
@@ -1864,11 +1983,11 @@ template <int MODEL> __global__ void stress_kernel(MpmDev mp, float *F, float *l
   float f[9], pf[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
-  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(mp.mat, f, pf);
-  else {
-    float lj = logJp[i];
-    stress_sand<true>(mp.mat, lj, f, pf);
-    logJp[i] = lj;
+  float lj = 0.f;
+  if constexpr (model_uses_logjp(MODEL)) lj = logJp[i];
+  model_stress<MODEL, true>(mp.mat, lj, f, pf);
+  if constexpr (model_uses_logjp(MODEL)) logJp[i] = lj;
+  if constexpr (MODEL != ZS_MPM_FIXED_COROTATED) {  // the plastic models return the projected F
 #pragma unroll
     for (int d = 0; d < 9; ++d) F[9 * i + d] = f[d];
   }
@@ -1949,6 +2068,12 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.beta = p->beta;
   d.mat.yieldSurface = p->yieldSurface;
   d.mat.volCorrection = p->volCorrection;
+  d.mat.yieldStress = p->yieldStress;
+  // NACCConfig::bulk() (physics/ConstitutiveModel.hpp:767-769), float arithmetic as written there
+  d.mat.bm = 2.f / 3.f * (p->E / (2 * (1 + p->nu))) + (p->E * p->nu / ((1 + p->nu) * (1 - 2 * p->nu)));
+  d.mat.xi = p->xi;
+  d.mat.Msqr = p->Msqr;
+  d.mat.hardeningOn = p->hardeningOn;
   d.kscale = p->keyIsOrigin ? p->side : 1;
   return d;
 }
@@ -1984,24 +2109,26 @@ static int uniform_lane_width(const zs_rocm_particles &p, bool useLogJp, bool us
     else { CALL(S, M, 0); }                      \
   } while (0)
 
-#define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                                        \
-  do {                                                                                    \
-    if ((side) == 4 && (model) == ZS_MPM_FIXED_COROTATED) { CALL(4, ZS_MPM_FIXED_COROTATED); } \
-    else if ((side) == 4 && (model) == ZS_MPM_DRUCKER_PRAGER) { CALL(4, ZS_MPM_DRUCKER_PRAGER); } \
-    else if ((side) == 4) { CALL(4, MPM_CACHED_STRESS); }                                 \
-    else if ((model) == ZS_MPM_FIXED_COROTATED) { CALL(8, ZS_MPM_FIXED_COROTATED); }      \
-    else if ((model) == ZS_MPM_DRUCKER_PRAGER) { CALL(8, ZS_MPM_DRUCKER_PRAGER); }        \
-    else { CALL(8, MPM_CACHED_STRESS); }                                                  \
+// CALL(SIDE, MODEL) for the runtime (side, model); `other` = the template value for anything that is not one of the four
+// constitutive models (MPM_CACHED_STRESS for P2G, -1 = "no constitutive update" for G2P)
+#define ZSR_DISPATCH_MODEL_(S, model, other, CALL)                                                        \
+  switch (model) {                                                                                        \
+    case ZS_MPM_FIXED_COROTATED: { CALL(S, ZS_MPM_FIXED_COROTATED); } break;                              \
+    case ZS_MPM_DRUCKER_PRAGER: { CALL(S, ZS_MPM_DRUCKER_PRAGER); } break;                                \
+    case ZS_MPM_VONMISES_FIXED_COROTATED: { CALL(S, ZS_MPM_VONMISES_FIXED_COROTATED); } break;            \
+    case ZS_MPM_NACC: { CALL(S, ZS_MPM_NACC); } break;                                                    \
+    default: { CALL(S, other); } break;                                                                   \
+  }
+#define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                          \
+  do {                                                                      \
+    if ((side) == 4) { ZSR_DISPATCH_MODEL_(4, model, MPM_CACHED_STRESS, CALL) } \
+    else { ZSR_DISPATCH_MODEL_(8, model, MPM_CACHED_STRESS, CALL) }         \
   } while (0)
 // G2P: third argument = stress model to evaluate at the end (-1: none)
-#define ZSR_DISPATCH_SIDE_SMODEL(side, smodel, CALL)                                      \
-  do {                                                                                    \
-    if ((side) == 4 && (smodel) < 0) { CALL(4, -1); }                                     \
-    else if ((side) == 4 && (smodel) == ZS_MPM_FIXED_COROTATED) { CALL(4, ZS_MPM_FIXED_COROTATED); } \
-    else if ((side) == 4) { CALL(4, ZS_MPM_DRUCKER_PRAGER); }                             \
-    else if ((smodel) < 0) { CALL(8, -1); }                                               \
-    else if ((smodel) == ZS_MPM_FIXED_COROTATED) { CALL(8, ZS_MPM_FIXED_COROTATED); }     \
-    else { CALL(8, ZS_MPM_DRUCKER_PRAGER); }                                              \
+#define ZSR_DISPATCH_SIDE_SMODEL(side, smodel, CALL)                        \
+  do {                                                                      \
+    if ((side) == 4) { ZSR_DISPATCH_MODEL_(4, smodel, -1, CALL) }           \
+    else { ZSR_DISPATCH_MODEL_(8, smodel, -1, CALL) }                       \
   } while (0)
 
 }  // namespace zsr
@@ -2144,7 +2271,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    const int lw = uniform_lane_width(ps, p->model == ZS_MPM_DRUCKER_PRAGER && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
+    const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
     // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
     static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
     if (kmodel == MPM_CACHED_STRESS && !split4) {
@@ -2173,10 +2300,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
   hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
                      (const int *)staleCount)
 #define CALL_P2G_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_P2G_BINNED3, S, M)
-    if (p->side == 4 && kmodel == ZS_MPM_FIXED_COROTATED) { CALL_P2G_BINNED(4, ZS_MPM_FIXED_COROTATED); }
-    else if (p->side == 4) { CALL_P2G_BINNED(4, ZS_MPM_DRUCKER_PRAGER); }
-    else if (kmodel == ZS_MPM_FIXED_COROTATED) { CALL_P2G_BINNED(8, ZS_MPM_FIXED_COROTATED); }
-    else { CALL_P2G_BINNED(8, ZS_MPM_DRUCKER_PRAGER); }
+    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_BINNED);  // kmodel is one of the four models here
   } else {
 #define CALL_P2G_GLOBAL(S, M) \
   hipLaunchKernelGGL((p2g_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
@@ -2211,7 +2335,7 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    const int lw = uniform_lane_width(ps, smodel == ZS_MPM_DRUCKER_PRAGER, smodel >= 0);
+    const int lw = uniform_lane_width(ps, model_uses_logjp(smodel), smodel >= 0);
 #define CALL_G2P_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((g2p_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \
@@ -2253,7 +2377,7 @@ int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
   int *staleP = (int *)L.temp(sizeof(int) * (ps.n + 64));
   int *counts = (int *)L.temp(sizeof(int) * 64);
   ZSR_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 64, L.stream));
-  const int lw = uniform_lane_width(ps, p->model == ZS_MPM_DRUCKER_PRAGER, true);
+  const int lw = uniform_lane_width(ps, model_uses_logjp(p->model), true);
 #define CALL_G2P2G4(S, M, LWv, WA)                                                                                                    \
   hipLaunchKernelGGL((g2p2g_binned_kernel<S, M, LWv, WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, binStart,     \
                      cellCount, nbr, staleG, counts, staleP, counts + 32, binBase);                                                   \
@@ -2265,10 +2389,8 @@ int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
     else { CALL_G2P2G4(S, M, LWv, false); }         \
   } while (0)
 #define CALL_G2P2G(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P2G3, S, M)
-  if (p->side == 4 && p->model == ZS_MPM_FIXED_COROTATED) { CALL_G2P2G(4, ZS_MPM_FIXED_COROTATED); }
-  else if (p->side == 4) { CALL_G2P2G(4, ZS_MPM_DRUCKER_PRAGER); }
-  else if (p->model == ZS_MPM_FIXED_COROTATED) { CALL_G2P2G(8, ZS_MPM_FIXED_COROTATED); }
-  else { CALL_G2P2G(8, ZS_MPM_DRUCKER_PRAGER); }
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return -1;
+  ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_G2P2G);
   return 0;
 }
 int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
@@ -2281,20 +2403,25 @@ void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p,
   if (!ps.n || !ps.stress.base) return;
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
-  if (p->model == ZS_MPM_FIXED_COROTATED)
-    hipLaunchKernelGGL((update_stress_kernel<ZS_MPM_FIXED_COROTATED>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
-  else
-    hipLaunchKernelGGL((update_stress_kernel<ZS_MPM_DRUCKER_PRAGER>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
+#define CALL_UPDATE_STRESS(S, M) hipLaunchKernelGGL((update_stress_kernel<M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd)
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return;
+  ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_UPDATE_STRESS)
 }
 
 void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *F, float *logJp, size_t n, float *PF) {
   Launch L(pol, "compute_stress");
   if (!n) return;
   MpmDev mp = make_dev(p);
-  if (p->model == ZS_MPM_FIXED_COROTATED)
-    hipLaunchKernelGGL((stress_kernel<ZS_MPM_FIXED_COROTATED>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF);
-  else
-    hipLaunchKernelGGL((stress_kernel<ZS_MPM_DRUCKER_PRAGER>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF);
+#define CALL_STRESS(S, M) hipLaunchKernelGGL((stress_kernel<M>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF)
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return;
+  ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_STRESS)
+}
+float zs_rocm_nacc_msqr(float fa) {  // NACCConfig::mohrColumbFriction / M / Msqr, dim = 3 (physics/ConstitutiveModel.hpp:771-785)
+  const int dim = 3;
+  const float sin_phi = std::sin(fa);  // the reference passes `fa` to sin() as it is
+  const float mcf = std::sqrt(2.f / 3.f) * 2.f * sin_phi / (3.f - sin_phi);
+  const float M = mcf * dim / std::sqrt(2.f / (6.f - dim));
+  return M * M;
 }
 void zs_rocm_svd3(zs_rocm_policy *pol, const float *F, size_t n, float *U, float *S, float *V) {
   Launch L(pol, "svd3");

@@ -15,17 +15,19 @@ import torch
 from ._lib import lib, Port, Particles, MpmParams
 from .containers import Bht
 
-FIXED_COROTATED, DRUCKER_PRAGER = 0, 1
+FIXED_COROTATED, DRUCKER_PRAGER, VONMISES_FIXED_COROTATED, NACC = 0, 1, 2, 3  # ConstitutiveModelConfig members with F
+HAS_LOGJP = (DRUCKER_PRAGER, NACC)
 
 
 class MpmTransfer:
     def __init__(self, pol, n, dx, dt, model=FIXED_COROTATED, side=4, lane_width=64, E=5e4, nu=0.4, volume=1.0,
                  cohesion=0.0, beta=1.0, yield_surface=0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), vol_correction=True,
-                 device="cuda", key_is_origin=False, aos=False, cache_stress=False):
+                 device="cuda", key_is_origin=False, aos=False, cache_stress=False, yield_stress=240e6, xi=0.8, friction_angle=45.0,
+                 hardening=True):
         self.pol, self.n, self.L, self.side = pol, int(n), int(lane_width), int(side)
         self.device = torch.device(device)
         self.model = model
-        self.nchn = 25 + (1 if model == DRUCKER_PRAGER else 0)
+        self.nchn = 25 + (1 if model in HAS_LOGJP else 0)
         self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
         # cache_stress: 9 extra channels "PF" hold P F^T vol, written by G2P (and update_stress), read by P2G
         self.cache_stress = bool(cache_stress)
@@ -41,8 +43,9 @@ class MpmTransfer:
         self.drift_flag = None  # device int set by zs_rocm_mpm_g2p2g_range when the split-launch margin is violated
         self.key_is_origin = bool(key_is_origin)  # SparseGrid convention: partition keys are block origins (multiples of side)
         self.kstride = side if key_is_origin else 1
+        # VonMisesFixedCorotatedConfig::yieldStress; NACCConfig::xi, Msqr() from the friction angle, hardeningOn (beta shared)
         self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side,
-                                int(self.key_is_origin))
+                                int(self.key_is_origin), yield_stress, xi, lib().zs_rocm_nacc_msqr(friction_angle), int(hardening))
         self.table = None
         self.grid = None
         self.nblocks = 0
@@ -58,7 +61,7 @@ class MpmTransfer:
     def particles(self):
         null = Port(None, 0, 0, 0, 1)
         return Particles(self._port("m"), self._port("x"), self._port("v"), self._port("C"), self._port("F"),
-                         self._port("logJp") if self.model == DRUCKER_PRAGER else null,
+                         self._port("logJp") if self.model in HAS_LOGJP else null,
                          self._port("PF") if self.cache_stress else null, self.n)
 
     def set_particles(self, buf, n):
@@ -79,7 +82,7 @@ class MpmTransfer:
         cols = [torch.as_tensor(mass, dtype=torch.float32).reshape(self.n, 1), torch.as_tensor(pos, dtype=torch.float32).reshape(self.n, 3),
                 torch.as_tensor(vel, dtype=torch.float32).reshape(self.n, 3), torch.as_tensor(Cm, dtype=torch.float32).reshape(self.n, 9),
                 torch.as_tensor(F, dtype=torch.float32).reshape(self.n, 9)]
-        if self.model == DRUCKER_PRAGER:
+        if self.model in HAS_LOGJP:
             lj = torch.zeros(self.n) if logJp is None else torch.as_tensor(logJp, dtype=torch.float32)
             cols.append(lj.reshape(self.n, 1))
         if self.cache_stress:
@@ -95,7 +98,7 @@ class MpmTransfer:
         self.pol.syncCtx()
         a = aos.cpu().numpy()
         out = {"m": a[:, 0].copy(), "x": a[:, 1:4].copy(), "v": a[:, 4:7].copy(), "C": a[:, 7:16].copy(), "F": a[:, 16:25].copy()}
-        if self.model == DRUCKER_PRAGER:
+        if self.model in HAS_LOGJP:
             out["logJp"] = a[:, 25].copy()
         return out
 
