@@ -95,3 +95,16 @@ def test_overlap_drift_guard_refuses_stale_bins():
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device"] + args
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode != 0 and b"drifted more than one bin" in r.stderr
+
+
+def test_rccl_calls_of_the_multi_gpu_path_on_one_gpu():
+    """tools/nccl_selftest.py: the torch.distributed calls of the halo exchange / migration / bench bookkeeping on the nccl (= RCCL)
+    backend with world_size 1 and self as the only peer, the exchange issued on the side stream exactly as bench.py does."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_selftest.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"nccl selftest ok" in r.stdout, r.stderr.decode()[-2000:]
