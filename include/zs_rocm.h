@@ -457,7 +457,13 @@ typedef struct {
   size_t n;
 } zs_rocm_particles;
 
-enum { ZS_MPM_FIXED_COROTATED = 0, ZS_MPM_DRUCKER_PRAGER = 1, ZS_MPM_VONMISES_FIXED_COROTATED = 2, ZS_MPM_NACC = 3 };
+enum {
+  ZS_MPM_FIXED_COROTATED = 0, ZS_MPM_DRUCKER_PRAGER = 1, ZS_MPM_VONMISES_FIXED_COROTATED = 2, ZS_MPM_NACC = 3,
+  /* EquationOfStateConfig (weakly compressible fluid): the particles carry the volume ratio J instead of F -- pass the
+   * 1-channel `J` attribute as zs_rocm_particles::F (only component 0 is read / written: G2P does J <- (1 + tr(C) dt) J,
+   * simulation/transfer/G2P.hpp:70-74; P2G.hpp:60-81 forms the stress from J and C) */
+  ZS_MPM_EQUATION_OF_STATE = 4
+};
 typedef struct {
   int model;          /* FixedCorotatedConfig | DruckerPragerConfig (physics/ConstitutiveModel.hpp:739-757) */
   float dx, dt;
@@ -470,6 +476,7 @@ typedef struct {
   float yieldStress;  /* VonMisesFixedCorotatedConfig::yieldStress (physics/ConstitutiveModel.hpp:745-749) */
   float xi, Msqr;     /* NACCConfig::xi, NACCConfig::Msqr() (:759-785; zs_rocm_nacc_msqr); NACC also uses E, nu, beta, logJp */
   int hardeningOn;    /* NACCConfig::hardeningOn */
+  float bulk, viscosity; /* EquationOfStateConfig::bulk, ::viscosity (gamma is fixed to 7 by the formula, P2G.hpp:64-69) */
 } zs_rocm_mpm_params;
 /* NACCConfig::Msqr() for friction angle `fa` and dimension 3, evaluated as the reference does (physics/ConstitutiveModel.hpp:771-785) */
 ZS_ROCM_EXPORT float zs_rocm_nacc_msqr(float fa);

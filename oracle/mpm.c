@@ -421,7 +421,25 @@ void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const 
     float contrib[9], F[9];
     const float *C = Cm + 9 * i;
     memcpy(F, Fm + 9 * i, 36);
-    if (p->model == 0) {
+    if (p->model == 4) { /* EquationOfStateConfig, P2G.hpp:60-81: J is kept in component 0 of the F slot */
+      float J = F[0];
+      float vol = p->volume * J;
+      float pressure = p->bulk;
+      {
+        float J2 = J * J;
+        float J4 = J2 * J2;
+        pressure = pressure * (1 / (J * J2 * J4) - 1);
+      }
+      contrib[0] = ((C[0] + C[0]) * p->viscosity - pressure) * vol;
+      contrib[1] = (C[1] + C[3]) * p->viscosity * vol;
+      contrib[2] = (C[2] + C[6]) * p->viscosity * vol;
+      contrib[3] = (C[3] + C[1]) * p->viscosity * vol;
+      contrib[4] = ((C[4] + C[4]) * p->viscosity - pressure) * vol;
+      contrib[5] = (C[5] + C[7]) * p->viscosity * vol;
+      contrib[6] = (C[6] + C[2]) * p->viscosity * vol;
+      contrib[7] = (C[7] + C[5]) * p->viscosity * vol;
+      contrib[8] = ((C[8] + C[8]) * p->viscosity - pressure) * vol;
+    } else if (p->model == 0) {
       orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
     } else if (p->model == 2) { /* P2G.hpp:86-88 */
       orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, 0, F, contrib);
@@ -513,10 +531,15 @@ void orc_mpm_g2p(const orc_mpm_params *p, const orc_bht *table, size_t n, float 
     /* F <- (I + dt C) F   (G2P.hpp:74-78, MatrixUtils.h:136-146) */
     float tmp[9], oldF[9], F[9];
     memcpy(oldF, Fm + 9 * i, 36);
-    for (int d = 0; d < 9; ++d) tmp[d] = C[d] * p->dt + ((d & 0x3) ? 0.f : 1.f);
-    for (int c = 0; c < 3; ++c)
-      for (int r = 0; r < 3; ++r)
-        F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+    if (p->model == 4) { /* G2P.hpp:70-74: J <- (1 + tr(C) dt) J */
+      memcpy(F, oldF, 36);
+      F[0] = (1 + (C[0] + C[4] + C[8]) * p->dt) * oldF[0];
+    } else {
+      for (int d = 0; d < 9; ++d) tmp[d] = C[d] * p->dt + ((d & 0x3) ? 0.f : 1.f);
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+          F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+    }
     memcpy(Fm + 9 * i, F, 36);
     memcpy(vel + 3 * i, v, 12);
     memcpy(Cm + 9 * i, C, 36);

@@ -165,7 +165,7 @@ void orc_stress_sand(float volume, float mu, float lam, float cohesion, float be
 void orc_arena(float dx, const float pos[3], int32_t corner[3], float localPos[3], float w[9]);
 
 typedef struct {
-  int model;          /* 0 = FixedCorotated, 1 = DruckerPrager(sand), 2 = VonMisesFixedCorotated, 3 = NACC */
+  int model;          /* 0 = FixedCorotated, 1 = DruckerPrager(sand), 2 = VonMisesFixedCorotated, 3 = NACC, 4 = EquationOfState */
   float dx, dt;
   float volume, E, nu;
   float cohesion, beta, yieldSurface;
@@ -175,6 +175,7 @@ typedef struct {
   float yieldStress;  /* model 2 = VonMisesFixedCorotated */
   float xi, Msqr;     /* model 3 = NACC (also E, nu, beta) */
   int hardeningOn;
+  float bulk, viscosity; /* model 4 = EquationOfState: J lives in component 0 of the F slot */
 } orc_mpm_params;
 void orc_stress_vonmises(float volume, float mu, float lam, float yieldStress, int hostVariant, float F[9], float PF[9]);
 void orc_stress_nacc(float volume, float mu, float lam, float bm, float xi, float beta, float Msqr, int hardeningOn, int hostVariant,

@@ -369,3 +369,59 @@ def test_fused_g2p2g_matches_unfused_steps(pol, oracle, model, side):
         assert np.abs(da[k] - db[k]).max() <= tol, k
     if model in (1, 3):
         assert np.abs(da["logJp"] - db["logJp"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("side", [4, 8])
+@pytest.mark.parametrize("binned,cached", [(False, False), (True, False), (True, True)])
+def test_equation_of_state_fluid_vs_oracle(pol, oracle, side, binned, cached):
+    """EquationOfStateConfig (P2G.hpp:60-81, G2P.hpp:70-74): particles carry J instead of F; two sub-steps (P2G, grid update,
+    G2P) against the oracle, through the particle-order path, the reference-order binned kernels and the cached-stress path;
+    then the fused pass must agree with the unfused sequence."""
+    from zpc_amd.mpm import MpmTransfer, EQUATION_OF_STATE
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=57 + side)
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    J = (1.0 + 0.02 * rng(58).standard_normal(n)).astype(np.float32)
+    om = OracleMpm(oracle, 4, dx, dt, side, vol, bulk=4e4, viscosity=0.05)
+    om.build_partition(pos, n)
+    Fo = np.zeros((n, 9), np.float32)
+    Fo[:, 0] = J
+    po, vo, Co = pos.copy(), vel.copy(), Cm.copy()
+    mt = MpmTransfer(pol, n, dx, dt, model=EQUATION_OF_STATE, side=side, volume=vol, cache_stress=cached, bulk=4e4, viscosity=0.05)
+    mt.upload(mass, pos, vel, Cm, J)
+    mt.build_partition(n)
+    if binned:
+        mt.rebin()
+    if cached:
+        mt.update_stress()
+    for step in range(2):
+        om.grid[:] = 0
+        om.p2g(mass, po, vo, Co, Fo)
+        mt.clear_grid()
+        mt.p2g()
+        pol.syncCtx()
+        _compare_grids(mt.grid_by_key(), om.grid_by_key(), 2e-4)
+        om.grid_update((0.0, -9.8, 0.0))
+        mt.grid_update((0.0, -9.8, 0.0))
+        om.g2p(po, vo, Co, Fo)
+        mt.g2p()
+        pol.syncCtx()
+        d = mt.download()
+        inv = mt.order.cpu().numpy() if binned else np.arange(n)
+        assert np.abs(d["x"] - po[inv]).max() < 2e-6
+        assert np.abs(d["v"] - vo[inv]).max() < 3e-4 * np.abs(vo).max()
+        assert np.abs(d["C"] - Co[inv]).max() < 5e-4 * np.abs(Co).max()
+        assert np.abs(d["J"][:, 0] - Fo[inv, 0]).max() < 2e-6
+    assert np.abs(Fo[:, 0] - J).max() > 1e-4        # J really evolved
+    if cached:  # fused pass == p2g of the state above + grid update + g2p
+        mt.clear_grid(); mt.p2g(); mt.grid_update((0.0, -9.8, 0.0))
+        om.grid[:] = 0; om.p2g(mass, po, vo, Co, Fo); om.grid_update((0.0, -9.8, 0.0)); om.g2p(po, vo, Co, Fo)
+        mt.g2p2g(write_all=True)
+        pol.syncCtx()
+        d = mt.download()
+        inv = mt.order.cpu().numpy()
+        assert np.abs(d["x"] - po[inv]).max() < 2e-6 and np.abs(d["J"][:, 0] - Fo[inv, 0]).max() < 2e-6
+        assert np.abs(d["v"] - vo[inv]).max() < 3e-4 * np.abs(vo).max()
+        om.grid[:] = 0; om.p2g(mass, po, vo, Co, Fo)
+        _compare_grids(mt.grid_by_key(), om.grid_by_key(), 3e-4)

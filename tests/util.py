@@ -47,7 +47,7 @@ class OrcMpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
                 ("volCorrection", C.c_int), ("side", C.c_int), ("nthreads", C.c_int), ("yieldStress", C.c_float),
-                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int)]
+                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int), ("bulk", C.c_float), ("viscosity", C.c_float)]
 
 
 YIELD_SURFACE = 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5)  # DruckerPragerConfig default
@@ -72,11 +72,11 @@ class OracleMpm:
     """Drives oracle/mpm.c + oracle/bht.c: the CPU restatement of partition build, P2G, grid update, G2P."""
 
     def __init__(self, oracle, model, dx, dt, side, volume, E=5e4, nu=0.4, nthreads=1, cohesion=0.0, beta=1.0, yield_stress=240e6,
-                 xi=0.8, friction_angle=45.0, hardening=True):
+                 xi=0.8, friction_angle=45.0, hardening=True, bulk=4e4, viscosity=0.0):
         self.o = oracle
         oracle.orc_nacc_msqr.restype = C.c_float
         self.p = OrcMpmParams(model, dx, dt, volume, E, nu, cohesion, beta, YIELD_SURFACE, 1, side, nthreads, yield_stress, xi,
-                              oracle.orc_nacc_msqr(C.c_float(friction_angle)), int(hardening))
+                              oracle.orc_nacc_msqr(C.c_float(friction_angle)), int(hardening), bulk, viscosity)
         self.side = side
         self.o.orc_bht_create.restype = C.c_void_p
         self.o.orc_bht_active_keys.restype = C.POINTER(C.c_int32)

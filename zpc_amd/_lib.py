@@ -58,7 +58,7 @@ class MpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
                 ("volCorrection", C.c_int), ("side", C.c_int), ("keyIsOrigin", C.c_int), ("yieldStress", C.c_float),
-                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int)]
+                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int), ("bulk", C.c_float), ("viscosity", C.c_float)]
 
 
 _lib = None

@@ -193,6 +193,7 @@ struct Material {
   float yieldStress;           // von Mises
   float bm, xi, Msqr;          // NACC: bulk modulus NACCConfig::bulk(), hardening factor, M^2
   int hardeningOn;
+  float bulk, viscosity;       // EquationOfState
 };
 
 // compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47).  The reference forms P = U diag(Phat) V^T and
@@ -406,13 +407,36 @@ __device__ __forceinline__ void stress_nacc(const Material &m, float &logJp, flo
   for (int d = 0; d < 9; ++d) PF[d] = (dc * b[d] + ((d & 3) ? 0.f : ic)) * m.volume;
 }
 
+// EquationOfState branch of P2GTransfer (simulation/transfer/P2G.hpp:60-81): J = particles.J, C = particles.C
+__device__ __forceinline__ void stress_eos(const Material &m, float J, const float (&C)[9], float (&PF)[9]) {
+  const float vol = m.volume * J;
+  float pressure = m.bulk;
+  {
+    const float J2 = J * J, J4 = J2 * J2;
+    pressure = pressure * (1 / (J * J2 * J4) - 1);
+  }
+  PF[0] = ((C[0] + C[0]) * m.viscosity - pressure) * vol;
+  PF[1] = (C[1] + C[3]) * m.viscosity * vol;
+  PF[2] = (C[2] + C[6]) * m.viscosity * vol;
+  PF[3] = (C[3] + C[1]) * m.viscosity * vol;
+  PF[4] = ((C[4] + C[4]) * m.viscosity - pressure) * vol;
+  PF[5] = (C[5] + C[7]) * m.viscosity * vol;
+  PF[6] = (C[6] + C[2]) * m.viscosity * vol;
+  PF[7] = (C[7] + C[5]) * m.viscosity * vol;
+  PF[8] = ((C[8] + C[8]) * m.viscosity - pressure) * vol;
+}
+// the fluid model keeps J where the solids keep F (component 0 of the `F` attribute); -2 = fluid without a constitutive
+// update in G2P (the G2P kernels' "no model" value for solids is -1)
+constexpr int MPM_FLUID_NO_STRESS = -2;
+__host__ __device__ constexpr bool model_is_fluid(int model) { return model == ZS_MPM_EQUATION_OF_STATE || model == MPM_FLUID_NO_STRESS; }
 // which models carry the scalar plastic state logJp (P2G.hpp:88-101)
 __host__ __device__ constexpr bool model_uses_logjp(int model) { return model == ZS_MPM_DRUCKER_PRAGER || model == ZS_MPM_NACC; }
 // one entry point for the four constitutive models of P2G.hpp:82-101.  F is the local copy: the plastic models project it
 // in place, P2G / G2P never store it back (only logJp), the test entry zs_rocm_mpm_stress does (WRITE_F).
 template <int MODEL, bool WRITE_F = false>
-__device__ __forceinline__ void model_stress(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
-  if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(m, F, PF);
+__device__ __forceinline__ void model_stress(const Material &m, float &logJp, float (&F)[9], float (&PF)[9], const float (&C)[9]) {
+  if constexpr (MODEL == ZS_MPM_EQUATION_OF_STATE) stress_eos(m, F[0], C, PF);
+  else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(m, F, PF);
   else if constexpr (MODEL == ZS_MPM_DRUCKER_PRAGER) stress_sand<WRITE_F>(m, logJp, F, PF);
   else if constexpr (MODEL == ZS_MPM_VONMISES_FIXED_COROTATED) stress_vonmises(m, F, PF);
   else stress_nacc(m, logJp, F, PF);
@@ -497,6 +521,44 @@ template <int LW> __device__ __forceinline__ void pstore1(const Port<float> &p, 
   if constexpr (LW != 0) p.base[o.o] = v;
   else p.base[p.off(o.o)] = v;
 }
+// deformation state of a particle: F (9 components) for the solids, the volume ratio J = component 0 of the same attribute
+// for the EquationOfState fluid (Structurefree.hpp: particles.F / particles.J)
+template <int LW, bool FLUID> __device__ __forceinline__ void pload_state(const Port<float> &p, POff<LW> o, float (&F)[9]) {
+  if constexpr (FLUID) {
+#pragma unroll
+    for (int d = 1; d < 9; ++d) F[d] = 0.f;
+    F[0] = pload1<LW>(p, o);
+  } else
+    pload<LW, 9>(p, o, F);
+}
+template <int LW, bool FLUID> __device__ __forceinline__ void pstore_state(const Port<float> &p, POff<LW> o, const float (&F)[9]) {
+  if constexpr (FLUID) pstore1<LW>(p, o, F[0]);
+  else pstore<LW, 9>(p, o, F);
+}
+template <bool FLUID> __device__ __forceinline__ void load_state(const Port<float> &p, size_t i, float (&F)[9]) {
+  if constexpr (FLUID) {
+#pragma unroll
+    for (int d = 1; d < 9; ++d) F[d] = 0.f;
+    F[0] = p.base[p.off(i)];
+  } else
+    load_attr<9>(p, i, F);
+}
+// G2P: F <- (I + dt C) F (G2P.hpp:75-78, MatrixUtils.h:136-146) or J <- (1 + tr(C) dt) J (:70-74)
+template <bool FLUID> __device__ __forceinline__ void advance_state(const float (&oldF)[9], const float (&C)[9], float dt, float (&F)[9]) {
+  if constexpr (FLUID) {
+#pragma unroll
+    for (int d = 1; d < 9; ++d) F[d] = 0.f;
+    F[0] = (1 + (C[0] + C[4] + C[8]) * dt) * oldF[0];
+  } else {
+    float tmp[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) tmp[d] = C[d] * dt + ((d & 0x3) ? 0.f : 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+  }
+}
 
 struct ParticlesDev {
   Port<float> mass, pos, vel, C, F, logJp, stress;
@@ -523,10 +585,12 @@ __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const Particl
   if constexpr (MODEL == MPM_CACHED_STRESS) {
     load_attr<9>(ps.stress, i, contrib);
   } else {
-    load_attr<9>(ps.F, i, F);
+    load_state<model_is_fluid(MODEL)>(ps.F, i, F);
+    float Cp[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (model_is_fluid(MODEL)) load_attr<9>(ps.C, i, Cp);
     float lj = 0.f;
     if constexpr (model_uses_logjp(MODEL)) lj = ps.logJp.base[ps.logJp.off(i)];
-    model_stress<MODEL>(mp.mat, lj, F, contrib);
+    model_stress<MODEL>(mp.mat, lj, F, contrib, Cp);
     if constexpr (model_uses_logjp(MODEL)) ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back
   }
 #pragma unroll
@@ -808,14 +872,16 @@ template <int LW> struct RecA {  // sweep A inputs: x, v, C, m (16 floats)
     mass = pload1<LW>(ps.mass, o);
   }
 };
-template <int MODEL, int LW> struct RecB {  // sweep B inputs: x, F (, logJp) -- or x, cached P F^T vol
+template <int MODEL, int LW> struct RecB {  // sweep B inputs: x, F (, logJp) -- or x, cached P F^T vol; fluid: x, J, C
   float pos[3], F[9], logJp;
+  float C[model_is_fluid(MODEL) ? 9 : 1];
   __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
     pload<LW, 3>(ps.pos, o, pos);
     if constexpr (MODEL == MPM_CACHED_STRESS) pload<LW, 9>(ps.stress, o, F);
-    else pload<LW, 9>(ps.F, o, F);
+    else pload_state<LW, model_is_fluid(MODEL)>(ps.F, o, F);
     if constexpr (model_uses_logjp(MODEL)) logJp = pload1<LW>(ps.logJp, o);
+    if constexpr (MODEL == ZS_MPM_EQUATION_OF_STATE) pload<LW, 9>(ps.C, o, C);  // P2G sweep only (G2P recomputes C)
   }
 };
 
@@ -934,7 +1000,12 @@ __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesD
             for (int d = 0; d < 9; ++d) contrib[d] = cur.F[d];
           } else {
             float lj = model_uses_logjp(MODEL) ? cur.logJp : 0.f;
-            model_stress<MODEL>(mp.mat, lj, cur.F, contrib);
+            float Cp[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (model_is_fluid(MODEL)) {
+#pragma unroll
+              for (int d = 0; d < 9; ++d) Cp[d] = cur.C[d];
+            }
+            model_stress<MODEL>(mp.mat, lj, cur.F, contrib, Cp);
             if constexpr (model_uses_logjp(MODEL))
               pstore1<LW>(ps.logJp, particle_offset<LW>(ps.pos.chns, (size_t)i0), lj);  // P2G.hpp:101 (projected F not written back)
           }
@@ -1421,14 +1492,14 @@ __global__ __launch_bounds__(256) void grid_update_kernel(float *grid, size_t nb
 // is VALU-bound by the SVD): stress(F_new, logJp) -> particles.stress (P F^T vol, unscaled), logJp updated.  Exactly what the
 // next P2G would compute from the same F (P2G.hpp:60-101); SMODEL < 0: disabled.
 template <int SMODEL, int LW = 0>
-__device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesDev &ps, POff<LW> o, float (&F)[9]) {
+__device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesDev &ps, POff<LW> o, float (&F)[9], const float (&C)[9]) {
   if constexpr (SMODEL >= 0) {
     float PF[9], Fl[9];
 #pragma unroll
     for (int d = 0; d < 9; ++d) Fl[d] = F[d];  // the plastic models project their local copy only
     float lj = 0.f;
     if constexpr (model_uses_logjp(SMODEL)) lj = pload1<LW>(ps.logJp, o);
-    model_stress<SMODEL>(mp.mat, lj, Fl, PF);
+    model_stress<SMODEL>(mp.mat, lj, Fl, PF, C);
     if constexpr (model_uses_logjp(SMODEL)) pstore1<LW>(ps.logJp, o, lj);
     pstore<LW, 9>(ps.stress, o, PF);
   }
@@ -1440,24 +1511,19 @@ __device__ __forceinline__ void g2p_finish_loaded(const MpmDev &mp, const Partic
   const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
 #pragma unroll
   for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
-  float tmp[9], F[9];
-#pragma unroll
-  for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
-  pstore<LW, 9>(ps.F, o, F);
+  float F[9];
+  advance_state<model_is_fluid(SMODEL)>(oldF, C, mp.dt, F);
+  pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
   pstore<LW, 3>(ps.pos, o, pos);
   pstore<LW, 3>(ps.vel, o, vel);
   pstore<LW, 9>(ps.C, o, C);
-  update_stress<SMODEL, LW>(mp, ps, o, F);
+  update_stress<SMODEL, LW>(mp, ps, o, F, C);
 }
 template <int SIDE, int SMODEL>
 __device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&vel)[3],
                                            const float (&C)[9]) {
   float oldF[9];
-  load_attr<9>(ps.F, i, oldF);
+  load_state<model_is_fluid(SMODEL)>(ps.F, i, oldF);
   g2p_finish_loaded<SIDE, SMODEL>(mp, ps, i, pos, oldF, vel, C);
 }
 
@@ -1607,7 +1673,8 @@ __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev 
   int i0, i1;
   bool any, any1;
   bool has0 = walk.next(i0, any);
-  RecB<ZS_MPM_FIXED_COROTATED, LW> cur, nxt;  // x, F
+  // x and the deformation state (F, or J for the fluid; the fluid's C is recomputed here, not read)
+  RecB<model_is_fluid(SMODEL) ? MPM_FLUID_NO_STRESS : ZS_MPM_FIXED_COROTATED, LW> cur, nxt;
   if (has0) cur.load(ps, (size_t)i0);
   while (any) {
     const bool has1 = walk.next(i1, any1);
@@ -1753,12 +1820,12 @@ __device__ __forceinline__ void g2p2g_consume(const MpmDev &mp, const float *st,
     }
 }
 
-template <int LW, bool DP> struct RecG {  // fused-step inputs: m, x, F (, logJp)
+template <int LW, bool DP, bool FLUID = false> struct RecG {  // fused-step inputs: m, x, F or J (, logJp)
   float pos[3], F[9], m, logJp;
   __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
     pload<LW, 3>(ps.pos, o, pos);
-    pload<LW, 9>(ps.F, o, F);
+    pload_state<LW, FLUID>(ps.F, o, F);
     m = pload1<LW>(ps.mass, o);
     if constexpr (DP) logJp = pload1<LW>(ps.logJp, o);
   }
@@ -1805,7 +1872,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
   int i0, i1;
   bool has0, has1, any, any1;
   next_chunk(i0, has0, any);
-  RecG<LW, DP> cur, nxt;
+  RecG<LW, DP, model_is_fluid(SMODEL)> cur, nxt;
   if (has0) cur.load(ps, (size_t)i0);
   int par = 0;  // stage / mask buffer of this chunk (double buffered: ONE barrier per chunk)
   while (any) {
@@ -1830,19 +1897,14 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         float pos[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
-        float tmp[9], F[9], PF[9];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) tmp[d] = C[d] * mp.dt + ((d & 0x3) ? 0.f : 1.f);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * cur.F[3 * c] + tmp[r + 3] * cur.F[3 * c + 1] + tmp[r + 6] * cur.F[3 * c + 2];
-        pstore<LW, 9>(ps.F, o, F);
+        float F[9], PF[9];
+        advance_state<model_is_fluid(SMODEL)>(cur.F, C, mp.dt, F);
+        pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
         pstore<LW, 3>(ps.pos, o, pos);
         {  // F has been stored above: the plastic models may project this local copy
           float lj = 0.f;
           if constexpr (DP) lj = cur.logJp;
-          model_stress<SMODEL>(mp.mat, lj, F, PF);
+          model_stress<SMODEL>(mp.mat, lj, F, PF, C);
           if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
         }
         bool moved = false;  // does the particle still belong to this lane's cell?
@@ -1971,9 +2033,10 @@ __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDe
 template <int SMODEL> __global__ __launch_bounds__(256) void update_stress_kernel(MpmDev mp, ParticlesDev ps) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
-  float F[9];
-  load_attr<9>(ps.F, i, F);
-  update_stress<SMODEL, 0>(mp, ps, particle_offset<0>(0u, i), F);
+  float F[9], C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  load_state<model_is_fluid(SMODEL)>(ps.F, i, F);
+  if constexpr (model_is_fluid(SMODEL)) load_attr<9>(ps.C, i, C);
+  update_stress<SMODEL, 0>(mp, ps, particle_offset<0>(0u, i), F, C);
 }
 
 // ======================================================================================= misc kernels
@@ -1985,7 +2048,8 @@ template <int MODEL> __global__ void stress_kernel(MpmDev mp, float *F, float *l
   for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
   float lj = 0.f;
   if constexpr (model_uses_logjp(MODEL)) lj = logJp[i];
-  model_stress<MODEL, true>(mp.mat, lj, f, pf);
+  const float C0[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the fluid's viscous part needs C: zero through this entry
+  model_stress<MODEL, true>(mp.mat, lj, f, pf, C0);
   if constexpr (model_uses_logjp(MODEL)) logJp[i] = lj;
   if constexpr (MODEL != ZS_MPM_FIXED_COROTATED) {  // the plastic models return the projected F
 #pragma unroll
@@ -2074,6 +2138,8 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.xi = p->xi;
   d.mat.Msqr = p->Msqr;
   d.mat.hardeningOn = p->hardeningOn;
+  d.mat.bulk = p->bulk;
+  d.mat.viscosity = p->viscosity;
   d.kscale = p->keyIsOrigin ? p->side : 1;
   return d;
 }
@@ -2117,6 +2183,8 @@ static int uniform_lane_width(const zs_rocm_particles &p, bool useLogJp, bool us
     case ZS_MPM_DRUCKER_PRAGER: { CALL(S, ZS_MPM_DRUCKER_PRAGER); } break;                                \
     case ZS_MPM_VONMISES_FIXED_COROTATED: { CALL(S, ZS_MPM_VONMISES_FIXED_COROTATED); } break;            \
     case ZS_MPM_NACC: { CALL(S, ZS_MPM_NACC); } break;                                                    \
+    case ZS_MPM_EQUATION_OF_STATE: { CALL(S, ZS_MPM_EQUATION_OF_STATE); } break;                          \
+    case MPM_FLUID_NO_STRESS: { CALL(S, MPM_FLUID_NO_STRESS); } break;                                    \
     default: { CALL(S, other); } break;                                                                   \
   }
 #define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                          \
@@ -2328,14 +2396,16 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
-  const int smodel = ps.stress.base ? p->model : -1;  // also evaluate the constitutive model for the next P2G
+  // also evaluate the constitutive model for the next P2G when the particles carry `stress`; otherwise only tell the
+  // kernels whether the deformation state is F or J
+  const int smodel = ps.stress.base ? p->model : (p->model == ZS_MPM_EQUATION_OF_STATE ? MPM_FLUID_NO_STRESS : -1);
   if (binStart && cellCount && nbr) {
     if (!nblocks) return;
     const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
     int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    const int lw = uniform_lane_width(ps, model_uses_logjp(smodel), smodel >= 0);
+    const int lw = uniform_lane_width(ps, model_uses_logjp(smodel), smodel >= 0);  // (-2 / -1: no stress attribute needed)
 #define CALL_G2P_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((g2p_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \
@@ -2389,7 +2459,7 @@ int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
     else { CALL_G2P2G4(S, M, LWv, false); }         \
   } while (0)
 #define CALL_G2P2G(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P2G3, S, M)
-  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return -1;
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
   ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_G2P2G);
   return 0;
 }
@@ -2404,7 +2474,7 @@ void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p,
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
 #define CALL_UPDATE_STRESS(S, M) hipLaunchKernelGGL((update_stress_kernel<M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd)
-  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return;
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return;
   ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_UPDATE_STRESS)
 }
 
@@ -2413,7 +2483,7 @@ void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float 
   if (!n) return;
   MpmDev mp = make_dev(p);
 #define CALL_STRESS(S, M) hipLaunchKernelGGL((stress_kernel<M>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF)
-  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_NACC) return;
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return;
   ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_STRESS)
 }
 float zs_rocm_nacc_msqr(float fa) {  // NACCConfig::mohrColumbFriction / M / Msqr, dim = 3 (physics/ConstitutiveModel.hpp:771-785)

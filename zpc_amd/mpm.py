@@ -16,6 +16,7 @@ from ._lib import lib, Port, Particles, MpmParams
 from .containers import Bht
 
 FIXED_COROTATED, DRUCKER_PRAGER, VONMISES_FIXED_COROTATED, NACC = 0, 1, 2, 3  # ConstitutiveModelConfig members with F
+EQUATION_OF_STATE = 4  # the fluid member: particles carry J (1 channel) where the solids carry F (9 channels)
 HAS_LOGJP = (DRUCKER_PRAGER, NACC)
 
 
@@ -23,11 +24,13 @@ class MpmTransfer:
     def __init__(self, pol, n, dx, dt, model=FIXED_COROTATED, side=4, lane_width=64, E=5e4, nu=0.4, volume=1.0,
                  cohesion=0.0, beta=1.0, yield_surface=0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), vol_correction=True,
                  device="cuda", key_is_origin=False, aos=False, cache_stress=False, yield_stress=240e6, xi=0.8, friction_angle=45.0,
-                 hardening=True):
+                 hardening=True, bulk=4e4, viscosity=0.0):
         self.pol, self.n, self.L, self.side = pol, int(n), int(lane_width), int(side)
         self.device = torch.device(device)
         self.model = model
-        self.nchn = 25 + (1 if model in HAS_LOGJP else 0)
+        self.fluid = model == EQUATION_OF_STATE
+        self.nF = 1 if self.fluid else 9        # channels of the deformation state: J or F
+        self.nchn = 16 + self.nF + (1 if model in HAS_LOGJP else 0)
         self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
         # cache_stress: 9 extra channels "PF" hold P F^T vol, written by G2P (and update_stress), read by P2G
         self.cache_stress = bool(cache_stress)
@@ -45,7 +48,8 @@ class MpmTransfer:
         self.kstride = side if key_is_origin else 1
         # VonMisesFixedCorotatedConfig::yieldStress; NACCConfig::xi, Msqr() from the friction angle, hardeningOn (beta shared)
         self.params = MpmParams(model, dx, dt, volume, E, nu, cohesion, beta, yield_surface, int(vol_correction), side,
-                                int(self.key_is_origin), yield_stress, xi, lib().zs_rocm_nacc_msqr(friction_angle), int(hardening))
+                                int(self.key_is_origin), yield_stress, xi, lib().zs_rocm_nacc_msqr(friction_angle), int(hardening),
+                                bulk, viscosity)
         self.table = None
         self.grid = None
         self.nblocks = 0
@@ -81,7 +85,7 @@ class MpmTransfer:
         """AoS host/device arrays -> AoSoA particle buffer (zs_rocm_tv_from_aos_f32)."""
         cols = [torch.as_tensor(mass, dtype=torch.float32).reshape(self.n, 1), torch.as_tensor(pos, dtype=torch.float32).reshape(self.n, 3),
                 torch.as_tensor(vel, dtype=torch.float32).reshape(self.n, 3), torch.as_tensor(Cm, dtype=torch.float32).reshape(self.n, 9),
-                torch.as_tensor(F, dtype=torch.float32).reshape(self.n, 9)]
+                torch.as_tensor(F, dtype=torch.float32).reshape(self.n, self.nF)]   # F, or J for the fluid
         if self.model in HAS_LOGJP:
             lj = torch.zeros(self.n) if logJp is None else torch.as_tensor(logJp, dtype=torch.float32)
             cols.append(lj.reshape(self.n, 1))
@@ -97,7 +101,8 @@ class MpmTransfer:
         lib().zs_rocm_tv_to_aos_f32(self.pol.handle, self.buf.data_ptr(), self.n, self.nchn, self.L, aos.data_ptr())
         self.pol.syncCtx()
         a = aos.cpu().numpy()
-        out = {"m": a[:, 0].copy(), "x": a[:, 1:4].copy(), "v": a[:, 4:7].copy(), "C": a[:, 7:16].copy(), "F": a[:, 16:25].copy()}
+        out = {"m": a[:, 0].copy(), "x": a[:, 1:4].copy(), "v": a[:, 4:7].copy(), "C": a[:, 7:16].copy(),
+               "J" if self.fluid else "F": a[:, 16:16 + self.nF].copy()}
         if self.model in HAS_LOGJP:
             out["logJp"] = a[:, 25].copy()
         return out
