@@ -56,6 +56,11 @@ def parse():
                     help="every K steps: move particles to the rank that owns their cell, rebuild partition / halo lists / bins "
                          "(0 = never; the default bench window moves particles < 0.1 cell)")
     ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
+    ap.add_argument("--rebin-check", type=int, default=4,
+                    help="fused step: every K steps read the number of particles that took the exact path (they left their cell "
+                         "since the last re-bin); above --rebin-threshold of the particles per step the next step materialises the "
+                         "full particle state and the particles are re-binned (local, no communication).  0 = never")
+    ap.add_argument("--rebin-threshold", type=float, default=0.003)
     ap.add_argument("--floor", action="store_true",
                     help="apply a Separate plane collider 1.5 cells above y = 0 after every grid update "
                          "(ApplyBoundaryConditionOnGridBlocks; off in the headline configuration)")
@@ -375,17 +380,29 @@ def main():
     K = a.migrate_every
     done = 0
 
+    rebins = 0
+    rebin_next = False
+
     def run_steps(count, timed):
-        nonlocal done
+        nonlocal done, rebins, rebin_next
         for _ in range(count):
             remap_now = K > 0 and (done + 1) % K == 0
             if a.fused:
-                step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
+                # the step before a re-map / re-bin materialises v, C, stress of every particle
+                step(timed, remap_now or rebin_next)
             else:
                 step(timed)
             done += 1
             if remap_now:
                 remap()
+                rebin_next = False
+            elif rebin_next:
+                mt.rebin()  # particles only: partition, block numbers and halo lists stay
+                rebins += 1
+                rebin_next = False
+                mt.exact_path_particles()
+            elif a.fused and a.rebin_check > 0 and done % a.rebin_check == 0:
+                rebin_next = mt.exact_path_particles() > a.rebin_threshold * mt.n * a.rebin_check
 
     run_steps(a.warmup, False)
     barrier()
@@ -397,7 +414,7 @@ def main():
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
-    drift = int(mt.drift_flag.item()) if mt.drift_flag is not None else 0
+    drift = int(mt.drift_flag[0].item()) if mt.drift_flag is not None else 0
     if overlap and drift:
         # an exact-path particle of an interior block may have reached a shared block after its ghost sums were sent
         raise SystemExit("rank %d: particles drifted more than one bin from their bins -- re-bin more often (--migrate-every) "
@@ -426,6 +443,8 @@ def main():
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
+    if os.environ.get("ZS_BENCH_PER_STEP") and rank == 0:
+        print("per-step fused ms:", " ".join("%.3f" % x.elapsed_time(y) for x, y in fused_ev), file=sys.stderr)
 
     if rank == 0:
         value = n_total * a.steps / elapsed
@@ -454,7 +473,7 @@ def main():
                           "" if not a.unbinned else " [particle-order path]"),
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
-                       "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
+                       "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

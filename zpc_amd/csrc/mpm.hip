@@ -2019,7 +2019,10 @@ __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDe
                                                           const int *staleG, const int *staleGCount, const int *staleP,
                                                           const int *stalePCount, int *driftFlag) {
   const int ng = *staleGCount, np = *stalePCount;
-  if (driftFlag && blockIdx.x == 0 && threadIdx.x == 0 && staleGCount[8]) *driftFlag = 1;
+  if (driftFlag && blockIdx.x == 0 && threadIdx.x == 0) {  // status words for the host: [0] drift flag, [1] exact-path particles
+    if (staleGCount[8]) driftFlag[0] = 1;
+    atomicAdd(&driftFlag[1], ng + np);
+  }
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ng + np; j += gridDim.x * blockDim.x) {
@@ -2120,6 +2123,10 @@ template <int MODE> __global__ void halo_unpack_kernel(float *grid, const int *b
 }
 
 // ======================================================================================= host helpers
+// exact-path kernels: grid-stride over a device-side count.  The walk of one particle is a chain of 27 dependent hash
+// queries, so the kernel is latency-bound and wants every wave slot of the chip: 8 blocks of 256 per CU (with 256 blocks a
+// queue of 640 k particles took 0.37 ms, i.e. half of an 8 M-particle step)
+constexpr unsigned STALE_BLOCKS = 2048;
 static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   MpmDev d;
   d.model = p->model;
@@ -2346,7 +2353,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
 #define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
   hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, \
                      staleCount);                                                                                                      \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
                      (const int *)staleCount)
       if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
       else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
@@ -2356,7 +2363,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
 #define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
   hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
                      stale, staleCount);                                                                                               \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
                      (const int *)staleCount)
       if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 4, 0);
       else ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 8, 0);
@@ -2365,7 +2372,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
 #define CALL_P2G_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((p2g_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
                      (const int *)staleCount)
 #define CALL_P2G_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_P2G_BINNED3, S, M)
     ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_BINNED);  // kmodel is one of the four models here
@@ -2409,7 +2416,7 @@ void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
 #define CALL_G2P_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((g2p_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \
-  hipLaunchKernelGGL((g2p_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
+  hipLaunchKernelGGL((g2p_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
                      (const int *)staleCount)
 #define CALL_G2P_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P_BINNED3, S, M)
     ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_BINNED);
@@ -2451,7 +2458,7 @@ int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
 #define CALL_G2P2G4(S, M, LWv, WA)                                                                                                    \
   hipLaunchKernelGGL((g2p2g_binned_kernel<S, M, LWv, WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, binStart,     \
                      cellCount, nbr, staleG, counts, staleP, counts + 32, binBase);                                                   \
-  hipLaunchKernelGGL((g2p2g_stale_kernel<S, M>), dim3(256), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, (const int *)staleG,      \
+  hipLaunchKernelGGL((g2p2g_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, (const int *)staleG,      \
                      (const int *)counts, (const int *)staleP, (const int *)(counts + 32), driftFlag)
 #define CALL_G2P2G3(S, M, LWv)          \
   do {                                  \

@@ -201,7 +201,7 @@ class MpmTransfer:
         else:
             self.grid2.zero_()
         if self.drift_flag is None:
-            self.drift_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.drift_flag = torch.zeros(2, dtype=torch.int32, device=self.device)
         ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
         src, dst = self.grid, self.grid2
         self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
@@ -213,6 +213,16 @@ class MpmTransfer:
                 raise RuntimeError("zs_rocm_mpm_g2p2g refused the call")
             if k == 0 and between is not None:
                 between()
+
+    def exact_path_particles(self, reset=True):
+        """Particles the fused steps since the last call handled on the exact path (they left their cell after the last
+        re-bin); synchronises the stream.  The re-bin trigger: the exact path costs ~50x the binned one per particle."""
+        if self.drift_flag is None:
+            return 0
+        c = int(self.drift_flag[1].item())
+        if reset:
+            self.drift_flag[1:].zero_()
+        return c
 
     def reorder_partition(self, first_mask):
         """Renumber the blocks so that those with first_mask[i] != 0 come first (stable); returns their count.  Call between
