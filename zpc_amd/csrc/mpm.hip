@@ -1724,7 +1724,8 @@ __global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev 
 // Particles that are not in the cell they are stored under are exact as before: mis-binned at read -> queue G (global
 // gather + global scatter afterwards); moved out of the cell by this step's advection -> queue P (state stored, global
 // scatter afterwards).
-constexpr int G2P2G_NF = 25;  // staged floats per particle: m, x(3), v(3), C(9), P F^T vol(9)
+constexpr int G2P2G_NF = 25;
+constexpr int G2P2G_MQ_CAP = 512;  // in-bin movers a workgroup can take through its LDS queue (a bin holds ~512 particles)  // staged floats per particle: m, x(3), v(3), C(9), P F^T vol(9)
 
 // gather of g2p_gather_factorized with the node velocities read from the LDS arena (81 ds_read per particle; the fused
 // kernel is VALU-bound and needs the 81 VGPRs a register-resident copy would cost for its P2G stencil)
@@ -1836,7 +1837,7 @@ template <int LW, bool DP, bool FLUID = false> struct RecG {  // fused-step inpu
 template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W>
 __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
                                            int lane, const float *varena, float *parena, float *stage, unsigned long long *smask,
-                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount) {
+                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount, int *mq, int *mqCount) {
   using AL = ArenaLds;
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool STRESS = W >= 2;
@@ -1884,15 +1885,17 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     if (has0) {
       Arena ar;
       make_arena(mp.dx, cur.pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-        staleG[atomicAdd(staleGCount, 1)] = i0;  // mis-binned: exact gather + scatter afterwards
+      // the particle's cell relative to the bin.  Anywhere inside the bin the node velocities are in the LDS arena, so a
+      // particle that has wandered into a neighbouring cell of the same bin is still gathered here; only one that is outside
+      // the bin altogether takes the exact path (hash queries into grid A)
+      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+      if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
+        staleG[atomicAdd(staleGCount, 1)] = i0;  // outside the bin: exact gather + scatter afterwards
         // drift guard of the split launch: the exact path of an interior block may only reach blocks within two of its own
-        if ((unsigned)(ar.corner[0] - geo.org[0] + 4) >= 12u || (unsigned)(ar.corner[1] - geo.org[1] + 4) >= 12u ||
-            (unsigned)(ar.corner[2] - geo.org[2] + 4) >= 12u)
-          staleGCount[8] = 1;
+        if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
       } else {
         float vel[3], C[9];
-        g2p_gather_lds(mp, ar, v0, D_inv, vel, C);
+        g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
         const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
         float pos[3];
 #pragma unroll
@@ -1907,22 +1910,29 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
           model_stress<SMODEL>(mp.mat, lj, F, PF, C);
           if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
         }
-        bool moved = false;  // does the particle still belong to this lane's cell?
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int corner = (int)floorf(pos[d] * dxi - 0.5f);
-          moved = moved || (corner - geo.org[d] != (d == 0 ? cx : (d == 1 ? cy : cz)));
-        }
+        // where is it now?  same cell as this lane: register accumulation (phase 2).  Another cell of the same bin: queued in
+        // LDS and scattered into the bin's arena by the dense post-pass of the kernel.  Outside the bin: exact path.
+        const int ncx = (int)floorf(pos[0] * dxi - 0.5f) - geo.org[0], ncy = (int)floorf(pos[1] * dxi - 0.5f) - geo.org[1],
+                  ncz = (int)floorf(pos[2] * dxi - 0.5f) - geo.org[2];
+        const bool moved = ncx != cx || ncy != cy || ncz != cz;
         if (WRITE_ALL || moved) {
           pstore<LW, 3>(ps.vel, o, vel);
           pstore<LW, 9>(ps.C, o, C);
           pstore<LW, 9>(ps.stress, o, PF);
         }
         if (moved) {
-          staleP[atomicAdd(stalePCount, 1)] = i0;  // left the cell during this step: exact scatter afterwards
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            if ((unsigned)((int)floorf(pos[d] * dxi - 0.5f) - geo.org[d] + 4) >= 12u) staleGCount[8] = 1;
+          bool queued = false;
+          if ((unsigned)ncx < 4u && (unsigned)ncy < 4u && (unsigned)ncz < 4u) {
+            const int slot = atomicAdd(mqCount, 1);
+            if (slot < G2P2G_MQ_CAP) {
+              mq[slot] = i0;
+              queued = true;
+            }
+          }
+          if (!queued) {
+            staleP[atomicAdd(stalePCount, 1)] = i0;  // left the bin during this step: exact scatter afterwards
+            if ((unsigned)(ncx + 4) >= 12u || (unsigned)(ncy + 4) >= 12u || (unsigned)(ncz + 4) >= 12u) staleGCount[8] = 1;
+          }
         } else {
           valid = true;
           myStage[0 * 64 + lane] = cur.m;
@@ -1975,6 +1985,9 @@ __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesD
   __shared__ float parena[2 * 7 * AL::CH];
   __shared__ float stage[2 * 4 * G2P2G_NF * 64];
   __shared__ unsigned long long smask[2 * 4];
+  __shared__ int mq[G2P2G_MQ_CAP];
+  __shared__ int mqCount;
+  if (threadIdx.x == 0) mqCount = 0;
   const int bin = blockIdx.x + binBase;  // a launch covers a range of blocks (boundary blocks first, see zs_rocm_mpm_g2p2g_range)
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
@@ -1993,10 +2006,56 @@ __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesD
   for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   __syncthreads();
-  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
-  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
-  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
-  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount);
+  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
+  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
+  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
+  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
+  // dense post-pass over the particles that changed cell inside this bin: one thread per particle, contributions added to the
+  // bin's arena with LDS atomics (the register stencils of the lanes are keyed to cells).  Their state was stored by other
+  // lanes of this workgroup a moment ago: read it at agent scope so that a stale L1 line (x was loaded in phase 1) cannot serve it.
+  {
+    const int nm = mqCount < G2P2G_MQ_CAP ? mqCount : G2P2G_MQ_CAP;  // the body ended with a barrier
+    const float dxi = 1.0f / mp.dx;
+    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    for (int q = tid; q < nm; q += 256) {
+      const size_t i = (size_t)mq[q];
+      auto cload = [&](const Port<float> &p, int comp) {
+        return __hip_atomic_load(p.base + p.off(i) + (size_t)comp * p.cstride(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      const float m = ps.mass.base[ps.mass.off(i)];
+      float pos[3], vel[3], C[9], PF[9];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { pos[d] = cload(ps.pos, d); vel[d] = cload(ps.vel, d); }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { C[d] = cload(ps.C, d); PF[d] = cload(ps.stress, d) * kscale; }
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
+      if ((unsigned)kx >= 4u || (unsigned)ky >= 4u || (unsigned)kz >= 4u) {
+        // the queueing test rounds pos * (1/dx) - 0.5 in one step, make_arena in two: on an exact cell face they can disagree
+        staleP[atomicAdd(stalePCount, 1)] = (int)i;
+        continue;
+      }
+      float *a0 = parena + AL::at(kx, ky, kz);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
+            const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
+            float *g = a0 + AL::at(a, b, c);
+            atomicAdd(g, W * m);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              atomicAdd(g + (1 + d) * AL::CH, W * m * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
+              atomicAdd(g + (4 + d) * AL::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
+            }
+          }
+    }
+    __syncthreads();
+  }
   if (tid < 216) {
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
