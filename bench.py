@@ -381,28 +381,25 @@ def main():
     done = 0
 
     rebins = 0
-    rebin_next = False
 
     def run_steps(count, timed):
-        nonlocal done, rebins, rebin_next
+        nonlocal done, rebins
         for _ in range(count):
             remap_now = K > 0 and (done + 1) % K == 0
             if a.fused:
-                # the step before a re-map / re-bin materialises v, C, stress of every particle
-                step(timed, remap_now or rebin_next)
+                step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
             else:
                 step(timed)
             done += 1
             if remap_now:
                 remap()
-                rebin_next = False
-            elif rebin_next:
-                mt.rebin()  # particles only: partition, block numbers and halo lists stay
-                rebins += 1
-                rebin_next = False
-                mt.exact_path_particles()
             elif a.fused and a.rebin_check > 0 and done % a.rebin_check == 0:
-                rebin_next = mt.exact_path_particles() > a.rebin_threshold * mt.n * a.rebin_check
+                if mt.exact_path_particles() > a.rebin_threshold * mt.n * a.rebin_check:
+                    # particles only (partition, block numbers and halo lists stay), and only the channels the next fused step
+                    # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid
+                    mt.rebin(inputs_only=True)
+                    rebins += 1
+                    mt.exact_path_particles()
 
     run_steps(a.warmup, False)
     barrier()

@@ -306,6 +306,9 @@ ZS_ROCM_EXPORT void zs_rocm_tv_scale_f32(zs_rocm_policy *, float *tv, size_t n, 
 ZS_ROCM_EXPORT void zs_rocm_tv_gather_rows_f32(zs_rocm_policy *, const float *tv, const int *map, size_t m, int C, int L, float *aos);
 ZS_ROCM_EXPORT void zs_rocm_tv_scatter_rows_f32(zs_rocm_policy *, const float *aos, size_t m, int C, int L, float *tv, size_t dstOffset);
 ZS_ROCM_EXPORT void zs_rocm_tv_gather_f32(zs_rocm_policy *, const float *src, float *dst, size_t n, int C, int L, const int *map);
+/* the same for the channels whose bit is set in channelMask only (C <= 64); the other channels of dst are left untouched */
+ZS_ROCM_EXPORT void zs_rocm_tv_gather_channels_f32(zs_rocm_policy *, const float *src, float *dst, size_t n, int C, int L, const int *map,
+                                                   unsigned long long channelMask);
 
 /* ======================================================================== (A) bht */
 /* py_interop/BhtInstantiations.cpp:6-128: zs::bht<int, dim, int, B>, dim 1-4, B = 16 | 32 (container/Bht.hpp:16-272).

@@ -219,6 +219,7 @@ def _declare_containers(L):
     L.zs_rocm_tv_to_aos_f32.argtypes = [vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_scale_f32.argtypes = [vp, vp, sz, i32, i32, f32]
     L.zs_rocm_tv_gather_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_tv_gather_channels_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp, C.c_uint64]
     L.zs_rocm_tv_gather_rows_f32.argtypes = [vp, vp, vp, sz, i32, i32, vp]
     L.zs_rocm_tv_scatter_rows_f32.argtypes = [vp, vp, sz, i32, i32, vp, sz]
     for D, B in ((d, b) for d in (1, 2, 3, 4) for b in (16, 32)):

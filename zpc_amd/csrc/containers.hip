@@ -312,6 +312,19 @@ __global__ void tv_reorder_kernel(const W *src, W *dst, size_t n, int C, int lbi
   for (int c = 0; c < C; ++c) d[(size_t)c << lbits] = s[(size_t)c << lbits];
 }
 
+// gather of a subset of the channels (bit c of `mask`): re-binning between fused MPM steps only has to carry the step's inputs
+__global__ void tv_gather_channels_kernel(const uint32_t *src, uint32_t *dst, size_t n, int C, int lbits, const int *map,
+                                          unsigned long long mask) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t L = (size_t)1 << lbits;
+  const size_t j = (size_t)map[i];
+  const uint32_t *s = src + (((j >> lbits) * (size_t)C) << lbits) + (j & (L - 1));
+  uint32_t *d = dst + (((i >> lbits) * (size_t)C) << lbits) + (i & (L - 1));
+  for (int c = 0; c < C; ++c)
+    if ((mask >> c) & 1ull) d[(size_t)c << lbits] = s[(size_t)c << lbits];  // mask is uniform: no divergence
+}
+
 __global__ void tv_from_aos_kernel(const float *aos, size_t n, int C, int lbits, float *tv) {
   // thread per (i, c) with c fastest on the AoS side would uncoalesce the AoSoA side; stage through LDS:
   // block handles 64 particles x C channels
@@ -686,6 +699,13 @@ void zs_rocm_tv_scatter_rows_f32(zs_rocm_policy *pol, const float *aos, size_t m
   if (!m) return;
   hipLaunchKernelGGL(tv_scatter_rows_kernel, dim3(ceil_div(m, 64)), dim3(256), 64 * C * sizeof(float), L.stream, aos, m, C,
                      log2i((size_t)Lw), tv, dstOffset);
+}
+void zs_rocm_tv_gather_channels_f32(zs_rocm_policy *pol, const float *src, float *dst, size_t n, int C, int Lw, const int *map,
+                                    unsigned long long channelMask) {
+  Launch L(pol, "tv_gather_channels");
+  if (!n || C > 64) return;
+  hipLaunchKernelGGL(tv_gather_channels_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, (const uint32_t *)src, (uint32_t *)dst, n,
+                     C, log2i((size_t)Lw), map, channelMask);
 }
 void zs_rocm_tv_gather_f32(zs_rocm_policy *pol, const float *src, float *dst, size_t n, int C, int Lw, const int *map) {
   Launch L(pol, "tv_gather");

@@ -138,8 +138,11 @@ class MpmTransfer:
         self.binned = False
         return self.nblocks
 
-    def rebin(self):
-        """particle -> block binning + physical reorder of the AoSoA buffer (count / scan / distribute)."""
+    def rebin(self, inputs_only=False):
+        """particle -> block binning + physical reorder of the AoSoA buffer (count / scan / distribute).
+        inputs_only: carry only m, x, F (or J) and logJp -- everything a fused G2P2G step reads; v, C and the cached stress are
+        outputs of that step (recomputed from the grid), so between fused steps they need not be moved (14 instead of 35
+        channels for the sand column).  Do not use it before p2g() / g2p() or before reading v, C, stress."""
         L = lib()
         if self.order is None or self.order.numel() != self.n:
             self.order = torch.empty(self.n, dtype=torch.int32, device=self.device)
@@ -150,8 +153,13 @@ class MpmTransfer:
                                     int(self.key_is_origin), self.order.data_ptr(), self.bin_start.data_ptr(), self.cell_count.data_ptr())
         if self.buf2 is None:
             self.buf2 = torch.empty_like(self.buf)
-        L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
-                                self.order.data_ptr())
+        if inputs_only:
+            mask = 0xF | (((1 << self.nF) - 1) << self.off["F"]) | ((1 << self.off["logJp"]) if self.model in HAS_LOGJP else 0)
+            L.zs_rocm_tv_gather_channels_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
+                                             self.order.data_ptr(), mask)
+        else:
+            L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), self.buf2.data_ptr(), self.n, self.nchn, self.L,
+                                    self.order.data_ptr())
         self.pol.syncCtx()
         self.buf, self.buf2 = self.buf2, self.buf
         self.binned = True
