@@ -411,7 +411,7 @@ def main():
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
-    drift = int(mt.drift_flag[0].item()) if mt.drift_flag is not None else 0
+    drift = int(mt.margin_violated())
     if overlap and drift:
         # an exact-path particle of an interior block may have reached a shared block after its ghost sums were sent
         raise SystemExit("rank %d: particles drifted more than one bin from their bins -- re-bin more often (--migrate-every) "

@@ -43,7 +43,8 @@ class MpmTransfer:
         self.tiles = (self.n + self.L - 1) // self.L
         self.buf = torch.zeros(self.tiles * self.L * self.nchn, dtype=torch.float32, device=self.device)
         self.buf2 = None  # second buffer for re-binning (ping-pong)
-        self.drift_flag = None  # device int set by zs_rocm_mpm_g2p2g_range when the split-launch margin is violated
+        self.drift_flag = None  # device status words of zs_rocm_mpm_g2p2g_range: [0] split-launch margin violated, [1] exact-path count
+        self.drift_tripped = False
         self.key_is_origin = bool(key_is_origin)  # SparseGrid convention: partition keys are block origins (multiples of side)
         self.kstride = side if key_is_origin else 1
         # VonMisesFixedCorotatedConfig::yieldStress; NACCConfig::xi, Msqr() from the friction angle, hardeningOn (beta shared)
@@ -164,6 +165,7 @@ class MpmTransfer:
         self.buf, self.buf2 = self.buf2, self.buf
         self.binned = True
         if self.drift_flag is not None:
+            self.drift_tripped = self.drift_tripped or bool(self.drift_flag[0].item())  # latched: a re-bin must not erase it
             self.drift_flag.zero_()
 
     # ------------------------------------------------------------------ one sub-step
@@ -222,6 +224,11 @@ class MpmTransfer:
             if k == 0 and between is not None:
                 between()
 
+    def margin_violated(self):
+        """True if, since construction, an exact-path particle was ever farther than one bin from its bin during a fused step
+        (the overlapped multi-GPU exchange is then not valid: see zs_rocm_mpm_g2p2g_range)."""
+        return self.drift_tripped or (self.drift_flag is not None and bool(self.drift_flag[0].item()))
+
     def exact_path_particles(self, reset=True):
         """Particles the fused steps since the last call handled on the exact path (they left their cell after the last
         re-bin); synchronises the stream.  The re-bin trigger: the exact path costs ~50x the binned one per particle."""
@@ -229,7 +236,7 @@ class MpmTransfer:
             return 0
         c = int(self.drift_flag[1].item())
         if reset:
-            self.drift_flag[1:].zero_()
+            self.drift_flag[1:].zero_()  # the margin flag [0] stays
         return c
 
     def reorder_partition(self, first_mask):
