@@ -1,2275 +1,10 @@
-// mpm.hip -- MLS-MPM particle<->grid transfers for gfx950.
-//
-// Replaces, behind include/zs_rocm.h:
-//   ComputeSparsity / EnlargeSparsity        simulation/sparsity/SparsityOp.hpp:59-115
-//   P2GTransfer::operator()                  simulation/transfer/P2G.hpp:51-125 (+ cuda/simulation/transfer/P2G.hpp:38-116)
-//   compute_stress_fixedcorotated / _sand    cuda/physics/ConstitutiveModel.hpp:10-326, math::svd cuda/math/matrix/svd.cuh
-//   ComputeGridBlockVelocity                 simulation/grid/GridOp.hpp:71-108
-//   G2PTransfer::operator()                  simulation/transfer/G2P.hpp:44-83
-//
-// The reference's CUDA P2G issues 27 hash queries + 189 global float atomics per particle.  Here:
-//   * particles are binned by the 4x4x4 cell group ("bin") of their base node (count -> scan -> distribute,
-//     the IndexBuckets idea of simulation/particle/Query.tpp:9-58) and stored round-robin over the 64 cells
-//     of a bin: round r holds the r-th particle of every cell that has one;
-//   * one wavefront owns one bin, lane c owns cell c.  All particles of a cell share the same 27 stencil
-//     nodes, so the lane accumulates its 27 x 7 node contributions IN REGISTERS across its particles, then
-//     adds them into a per-wave LDS arena of 6^3 nodes x 7 channels in 27 conflict-free phases (plain
-//     ds_read/ds_write: for a fixed stencil offset the 64 cells map to 64 distinct nodes on 32 distinct
-//     banks per half-wave), and the arena is flushed ONCE to the grid with global_atomic_add_f32.
-//     LDS float atomics are deliberately NOT used: ds_add_f32 measures 193 cycles per wave-instruction on
-//     gfx950 (3 cycles per lane, serialised) against 4.2 for ds_add_u32 and 11 for a read-add-write pair
-//     (tools/lds_bench.hip, profiles/); the first version of this kernel spent 94 % of its time in them;
-//   * particles that left their cell since the last re-binning are queued and handled by the exact
-//     particle-order kernel afterwards, so results never depend on how fresh the bins are;
-//   * the 3x3 SVD is per-lane scalar VALU (quaternion Jacobi, v_rsq_f32): it is not a dense
-//     contraction, so no MFMA;
-//   * G2P: the lane loads the 27 x 3 node velocities of its cell from the LDS arena once and keeps them in
-//     registers for all its particles.
-// Algorithmic HBM bytes per particle: P2G 100 B read (+ 7 B grid), G2P 48 B read + 96 B write (+1.5 B grid).
-#include "bht.hpp"
-#include "hashtable.hpp"
-
-namespace zsr {
-
-void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
-void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit, int ebit);
-
-// ======================================================================================= small math
-__device__ __forceinline__ float rsq(float x) { return __frsqrt_rn(x); }
-
-#define SVD_GAMMA 5.8284273147583007813f
-#define SVD_CSTAR 0.9238795325112867f
-#define SVD_SSTAR 0.3826834323650898f
-
-// one Jacobi conjugation in the (X,Y) plane of the symmetric matrix S, accumulated into quaternion q=(w,v)
-template <int X, int Y, int Z> __device__ __forceinline__ void jacobi_conj(float (&S)[3][3], float (&q)[4]) {
-  float sh = S[X][Y] * 0.5f;
-  float ch = S[X][X] - S[Y][Y];
-  const bool ok = sh * sh >= 1.e-20f;
-  sh = ok ? sh : 0.f;
-  ch = ok ? ch : 1.f;
-  float sh2 = sh * sh, ch2 = ch * ch;
-  const float w = rsq(sh2 + ch2);
-  sh *= w;
-  ch *= w;
-  const bool fix = ch2 <= SVD_GAMMA * sh2;  // angle too large for the approximation: use pi/8
-  sh = fix ? SVD_SSTAR : sh;
-  ch = fix ? SVD_CSTAR : ch;
-  sh2 = sh * sh;
-  ch2 = ch * ch;
-  const float c = ch2 - sh2, s = 2.f * sh * ch;
-  const float sxx = S[X][X], sxy = S[X][Y], syy = S[Y][Y], sxz = S[X][Z], syz = S[Y][Z];
-  const float t1 = c * sxx + s * sxy, t2 = c * sxy + s * syy;
-  const float t3 = -s * sxx + c * sxy, t4 = -s * sxy + c * syy;
-  S[X][X] = c * t1 + s * t2;
-  S[X][Y] = S[Y][X] = c * t3 + s * t4;
-  S[Y][Y] = -s * t3 + c * t4;
-  S[X][Z] = S[Z][X] = c * sxz + s * syz;
-  S[Y][Z] = S[Z][Y] = -s * sxz + c * syz;
-  const float qw = q[0], qx = q[1 + X], qy = q[1 + Y], qz = q[1 + Z];
-  q[0] = qw * ch - qz * sh;
-  q[1 + X] = qx * ch + qy * sh;
-  q[1 + Y] = qy * ch - qx * sh;
-  q[1 + Z] = qz * ch + qw * sh;
-}
-
-template <int A, int B, bool SWAPV> __device__ __forceinline__ void cond_swap_cols(float (&rho)[3], float (&Bm)[3][3], float (&Vm)[3][3]) {
-  const bool sw = rho[A] < rho[B];
-  const float ra = rho[A], rb = rho[B];
-  rho[A] = sw ? rb : ra;
-  rho[B] = sw ? ra : rb;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const float ba = Bm[r][A], bb = Bm[r][B];
-    Bm[r][A] = sw ? bb : ba;
-    Bm[r][B] = sw ? -ba : bb;
-    if constexpr (SWAPV) {
-      const float va = Vm[r][A], vb = Vm[r][B];
-      Vm[r][A] = sw ? vb : va;
-      Vm[r][B] = sw ? -va : vb;
-    }
-  }
-}
-
-template <int P, int R> __device__ __forceinline__ void qr_step(float (&Bm)[3][3], float (&Um)[3][3]) {
-  const float a1 = Bm[P][P], a2 = Bm[R][P];
-  const float rho2 = a1 * a1 + a2 * a2;
-  const bool ok = rho2 > 1.e-24f;
-  const float ir = rsq(ok ? rho2 : 1.f);
-  const float c = ok ? a1 * ir : 1.f, s = ok ? a2 * ir : 0.f;
-#pragma unroll
-  for (int col = 0; col < 3; ++col) {
-    const float bp = Bm[P][col], br = Bm[R][col];
-    Bm[P][col] = c * bp + s * br;
-    Bm[R][col] = -s * bp + c * br;
-  }
-#pragma unroll
-  for (int row = 0; row < 3; ++row) {
-    const float up = Um[row][P], ur = Um[row][R];
-    Um[row][P] = c * up + s * ur;
-    Um[row][R] = -s * up + c * ur;
-  }
-}
-
-// A = U diag(S) V^T; U, V rotations, |S0| >= |S1| >= |S2| (math::svd convention).  Outputs as [row][col] arrays:
-// Um, Sg, and -- only when asked for -- Vm (sorted) and Bs = A V (sorted, before the QR), which lets the caller form
-// P F^T = U diag(Phat) (F V)^T without ever building P or re-multiplying by F.
-template <bool NEED_V, bool NEED_B>
-__device__ __forceinline__ void svd3_core(const float (&A)[9], float (&Um)[3][3], float (&Sg)[3], float (&Vm)[3][3], float (&Bs)[3][3]) {
-  float S[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) S[i][j] = A[3 * i] * A[3 * j] + A[1 + 3 * i] * A[1 + 3 * j] + A[2 + 3 * i] * A[2 + 3 * j];
-  float q[4] = {1.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int sweep = 0; sweep < 4; ++sweep) {
-    jacobi_conj<0, 1, 2>(S, q);
-    jacobi_conj<1, 2, 0>(S, q);
-    jacobi_conj<2, 0, 1>(S, q);
-  }
-  const float n = rsq(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
-  Vm[0][0] = 1 - 2 * (y * y + z * z); Vm[0][1] = 2 * (x * y - w * z);     Vm[0][2] = 2 * (x * z + w * y);
-  Vm[1][0] = 2 * (x * y + w * z);     Vm[1][1] = 1 - 2 * (x * x + z * z); Vm[1][2] = 2 * (y * z - w * x);
-  Vm[2][0] = 2 * (x * z - w * y);     Vm[2][1] = 2 * (y * z + w * x);     Vm[2][2] = 1 - 2 * (x * x + y * y);
-  float Bm[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Bm[r][c] = A[r] * Vm[0][c] + A[r + 3] * Vm[1][c] + A[r + 6] * Vm[2][c];
-  float rho[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) rho[c] = Bm[0][c] * Bm[0][c] + Bm[1][c] * Bm[1][c] + Bm[2][c] * Bm[2][c];
-  cond_swap_cols<0, 1, NEED_V>(rho, Bm, Vm);
-  cond_swap_cols<0, 2, NEED_V>(rho, Bm, Vm);
-  cond_swap_cols<1, 2, NEED_V>(rho, Bm, Vm);
-  if constexpr (NEED_B) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Bs[r][c] = Bm[r][c];
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Um[r][c] = r == c ? 1.f : 0.f;
-  qr_step<0, 1>(Bm, Um);
-  qr_step<0, 2>(Bm, Um);
-  qr_step<1, 2>(Bm, Um);
-  Sg[0] = Bm[0][0]; Sg[1] = Bm[1][1]; Sg[2] = Bm[2][2];
-}
-
-// column-major 9-vector interface (diagnostic entry point zs_rocm_svd3)
-__device__ __forceinline__ void svd3(const float (&A)[9], float (&U)[9], float (&Sg)[3], float (&V)[9]) {
-  float Um[3][3], Vm[3][3], Bs[3][3];
-  svd3_core<true, false>(A, Um, Sg, Vm, Bs);
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      U[r + 3 * c] = Um[r][c];
-      V[r + 3 * c] = Vm[r][c];
-    }
-}
-
-// out = M1 diag(d) M2^T (math/matrix/MatrixUtils.h:26-47)
-__device__ __forceinline__ void mat_diag_matT(float (&out)[9], const float (&m1)[9], const float (&d)[3], const float (&m2)[9]) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) out[r + 3 * c] = m1[r] * d[0] * m2[c] + m1[r + 3] * d[1] * m2[c + 3] + m1[r + 6] * d[2] * m2[c + 6];
-}
-__device__ __forceinline__ void pft_vol(const float (&P)[9], const float (&F)[9], float volume, float (&PF)[9]) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) PF[r + 3 * c] = (P[r] * F[c] + P[r + 3] * F[c + 3] + P[r + 6] * F[c + 6]) * volume;
-}
-
-struct Material {
-  float volume, mu, lam, cohesion, beta, yieldSurface;
-  int volCorrection;
-  float yieldStress;           // von Mises
-  float bm, xi, Msqr;          // NACC: bulk modulus NACCConfig::bulk(), hardening factor, M^2
-  int hardeningOn;
-  float bulk, viscosity;       // EquationOfState
-};
-
-// compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47).  The reference forms P = U diag(Phat) V^T and
-// then P F^T; since (F V) is already available from the SVD, P F^T = U diag(Phat) (F V)^T is formed directly.
-__device__ __forceinline__ void stress_fixedcorotated(const Material &m, const float (&F)[9], float (&PF)[9]) {
-  float U[3][3], S[3], V[3][3], B[3][3];
-  svd3_core<false, true>(F, U, S, V, B);
-  const float J = S[0] * S[1] * S[2];
-  const float smu = 2.f * m.mu, slam = m.lam * (J - 1.f);
-  float Ph[3];
-  Ph[0] = (smu * (S[0] - 1.f) + slam * (S[1] * S[2])) * m.volume;
-  Ph[1] = (smu * (S[1] - 1.f) + slam * (S[0] * S[2])) * m.volume;
-  Ph[2] = (smu * (S[2] - 1.f) + slam * (S[0] * S[1])) * m.volume;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const float u0 = U[r][0] * Ph[0], u1 = U[r][1] * Ph[1], u2 = U[r][2] * Ph[2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) PF[r + 3 * c] = u0 * B[c][0] + u1 * B[c][1] + u2 * B[c][2];
-  }
-}
-
-// compute_stress_sand (cuda/physics/ConstitutiveModel.hpp:246-326): Drucker-Prager return mapping in log-strain.
-// logJp is updated.  The reference overwrites F with the projected F_e = U diag(New_S) V^T and then forms
-// P F_e^T * vol with P = U diag(Phat) V^T; with V^T V = I that product is U diag(Phat_i New_S_i) U^T * vol -- the
-// Kirchhoff stress -- so neither P nor V is needed for the force.  WRITE_F: also return the projected F (test entry).
-template <bool WRITE_F>
-__device__ __forceinline__ void stress_sand(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
-  float U[3][3], S[3], V[3][3], B[3][3];
-  svd3_core<WRITE_F, false>(F, U, S, V, B);
-  const float smu = 2.f * m.mu;
-  float eps[3], NS[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float a = fabsf(S[i]);
-    a = a > 1e-4f ? a : 1e-4f;
-    eps[i] = logf(a) - m.cohesion;
-  }
-  const float sum_eps = eps[0] + eps[1] + eps[2];
-  const float tr = sum_eps + logJp;
-  float eh[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) eh[i] = eps[i] - (tr * (1.f / 3.f));
-  const float ehn = sqrtf(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
-  bool newF = false;
-  float Hs[3] = {0.f, 0.f, 0.f};  // log of the projected singular values
-  if (tr >= 0.f) {  // case II: cone tip
-    NS[0] = NS[1] = NS[2] = expf(m.cohesion);
-    Hs[0] = Hs[1] = Hs[2] = m.cohesion;
-    newF = true;
-    if (m.volCorrection) logJp = m.beta * sum_eps + logJp;
-  } else if (m.mu != 0.f) {
-    logJp = 0.f;
-    const float dg = ehn + (3.f * m.lam + smu) / smu * tr * m.yieldSurface;
-    float H[3];
-    if (dg <= 0.f) {  // case I: inside the cone
-#pragma unroll
-      for (int i = 0; i < 3; ++i) H[i] = eps[i] + m.cohesion;
-    } else {  // case III: onto the cone surface
-      const float sc = dg * __frcp_rn(ehn);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) H[i] = eps[i] - sc * eh[i] + m.cohesion;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if constexpr (WRITE_F) NS[i] = expf(H[i]);
-      else NS[i] = 1.f;  // only its positivity matters below
-      Hs[i] = H[i];
-    }
-    newF = true;
-  }
-  // New_S_log = log(New_S) (ConstitutiveModel.hpp:309): New_S = exp(H), so log(New_S) == H up to one rounding; the
-  // mu == 0 && trace < 0 corner keeps the reference's log(0) = -inf
-  float tau[3];
-  {
-    float lg[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) lg[i] = NS[i] > 0.f ? Hs[i] : -INFINITY;
-    const float trl = lg[0] + lg[1] + lg[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) tau[i] = (smu * lg[i] + m.lam * trl) * m.volume;  // Phat_i * New_S_i * vol
-  }
-  if (newF) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float u0 = U[r][0] * tau[0], u1 = U[r][1] * tau[1], u2 = U[r][2] * tau[2];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) PF[r + 3 * c] = u0 * U[c][0] + u1 * U[c][1] + u2 * U[c][2];
-    }
-    if constexpr (WRITE_F) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float u0 = U[r][0] * NS[0], u1 = U[r][1] * NS[1], u2 = U[r][2] * NS[2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) F[r + 3 * c] = u0 * V[c][0] + u1 * V[c][1] + u2 * V[c][2];
-      }
-    }
-  } else {
-    // mu == 0 && trace < 0: F is not projected and New_S = 0 (reference corner case): P = U diag(-inf/0) V^T -> NaN/inf;
-    // reproduce "non-finite" without caring about the exact pattern
-#pragma unroll
-    for (int d = 0; d < 9; ++d) PF[d] = tau[0];
-  }
-}
-
-// compute_stress_vonmisesfixedcorotated (cuda/physics/ConstitutiveModel.hpp:47-116): von Mises return mapping of the
-// Kirchhoff stress in principal space, F projected in place (the caller decides whether it is stored), then the
-// fixed-corotated P F^T vol of the projected state.
-__device__ __forceinline__ void stress_vonmises(const Material &m, float (&F)[9], float (&PF)[9]) {
-  float U[9], S[3], V[9];
-  svd3(F, U, S, V);
-  float Sc[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) Sc[d] = 1e-4f > S[d] ? 1e-4f : S[d];
-  float J = Sc[0] * Sc[1] * Sc[2];
-  float tau[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) tau[d] = 2 * m.mu * (Sc[d] - 1) * Sc[d] + m.lam * (J - 1) * J;
-  const float tr = tau[0] + tau[1] + tau[2];
-  float st[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) st[d] = tau[d] - (tr / 3.f);
-  const float s_norm = sqrtf(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]);
-  const float scaled_tauy = sqrtf(2.f / (6.f - 3.f)) * m.yieldStress;
-  if (s_norm - scaled_tauy > 0) {
-    const float alpha = scaled_tauy / s_norm;
-    J = 1.f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float tau_new = alpha * st[d] + (tr / 3.f);
-      const float b2m4ac = m.mu * m.mu - 2 * m.mu * (m.lam * (J - 1) * J - tau_new);
-      S[d] = (m.mu + sqrtf(b2m4ac)) / (2 * m.mu);
-    }
-    mat_diag_matT(F, U, S, V);
-  }
-  J = S[0] * S[1] * S[2];
-  const float smu = 2.f * m.mu, slam = m.lam * (J - 1.f);
-  float Ph[3], P[9];
-  Ph[0] = smu * (S[0] - 1.f) + slam * (S[1] * S[2]);
-  Ph[1] = smu * (S[1] - 1.f) + slam * (S[0] * S[2]);
-  Ph[2] = smu * (S[2] - 1.f) + slam * (S[0] * S[1]);
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) P[r + 3 * c] = Ph[0] * U[r] * V[c] + Ph[1] * U[r + 3] * V[c + 3] + Ph[2] * U[r + 6] * V[c + 6];
-  pft_vol(P, F, m.volume, PF);
-}
-
-// compute_stress_nacc (cuda/physics/ConstitutiveModel.hpp:118-243): non-associated Cam-Clay, three projection cases +
-// hardening through logJp; F projected in place; neo-Hookean-type P F^T vol of the projected state.
-__device__ __forceinline__ void stress_nacc(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
-  float U[9], S[3], V[9];
-  svd3(F, U, S, V);
-  const float bm = m.bm, beta = m.beta, Msqr = m.Msqr, mu = m.mu;
-  const float p0 = bm * (0.00001f + sinhf(m.xi * (-logJp > 0 ? -logJp : 0)));
-  const float p_min = -beta * p0;
-  const float Je_trial = S[0] * S[1] * S[2];
-  const float Bh[3] = {S[0] * S[0], S[1] * S[1], S[2] * S[2]};
-  const float trB = (Bh[0] + Bh[1] + Bh[2]) / 3.f;
-  const float Jm = mu * powf(Je_trial, -2.f / 3.f);
-  const float sh[3] = {Jm * (Bh[0] - trB), Jm * (Bh[1] - trB), Jm * (Bh[2] - trB)};
-  const float psi = bm * 0.5f * (Je_trial - 1.f / Je_trial);
-  const float p_trial = -psi * Je_trial;
-  const float ys = 3.f / 2.f * (1 + 2.f * beta);
-  const float yp = (Msqr * (p_trial - p_min) * (p_trial - p0));
-  const float sn = sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2];
-  const float y = (ys * sn) + yp;
-  if (p_trial > p0) {  // case 1: max tip
-    const float Je_new = sqrtf(-2.f * p0 / bm + 1.f);
-    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
-    mat_diag_matT(F, U, S, V);
-    if (m.hardeningOn) logJp += logf(Je_trial / Je_new);
-  } else if (p_trial < p_min) {  // case 2: min tip
-    const float Je_new = sqrtf(-2.f * p_min / bm + 1.f);
-    S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
-    mat_diag_matT(F, U, S, V);
-    if (m.hardeningOn) logJp += logf(Je_trial / Je_new);
-  } else if (y >= 1e-4) {  // case 3: onto the yield surface + hardening
-    const float Bs = powf(Je_trial, 2.f / 3.f) / mu * sqrtf(-yp / ys) / sqrtf(sn);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) S[i] = sqrtf(sh[i] * Bs + trB);
-    mat_diag_matT(F, U, S, V);
-    if (m.hardeningOn && p0 > 1e-4 && p_trial < p0 - 1e-4 && p_trial > 1e-4 + p_min) {
-      const float pc = (1.f - beta) * p0 / 2;
-      const float q_trial = sqrtf(3.f / 2.f * sn);
-      float dir[2] = {pc - p_trial, -q_trial};
-      const float dn = sqrtf(dir[0] * dir[0] + dir[1] * dir[1]);
-      dir[0] /= dn;
-      dir[1] /= dn;
-      const float Cq = Msqr * (pc - p_min) * (pc - p0);
-      const float Bq = Msqr * dir[0] * (2 * pc - p0 - p_min);
-      const float Aq = Msqr * dir[0] * dir[0] + (1 + 2 * beta) * dir[1] * dir[1];
-      const float l1 = (-Bq + sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
-      const float l2 = (-Bq - sqrtf(Bq * Bq - 4 * Aq * Cq)) / (2 * Aq);
-      const float p1 = pc + l1 * dir[0], p2 = pc + l2 * dir[0];
-      const float pf = (p_trial - pc) * (p1 - pc) > 0 ? p1 : p2;
-      const float tJ = (-2 * pf / bm + 1);
-      const float Jf = sqrtf(tJ > 0 ? tJ : -tJ);
-      if (Jf > 1e-4) logJp += logf(Je_trial / Jf);
-    }
-  }
-  const float J = S[0] * S[1] * S[2];
-  float b[9];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) b[r + 3 * c] = F[r] * F[c] + F[r + 3] * F[c + 3] + F[r + 6] * F[c + 6];  // F F^T
-  const float trb = (b[0] + b[4] + b[8]) / 3.f;
-  b[0] -= trb; b[4] -= trb; b[8] -= trb;
-  const float dc = mu * powf(J, -2.f / 3.f), ic = bm * .5f * (J * J - 1.f);
-#pragma unroll
-  for (int d = 0; d < 9; ++d) PF[d] = (dc * b[d] + ((d & 3) ? 0.f : ic)) * m.volume;
-}
-
-// EquationOfState branch of P2GTransfer (simulation/transfer/P2G.hpp:60-81): J = particles.J, C = particles.C
-__device__ __forceinline__ void stress_eos(const Material &m, float J, const float (&C)[9], float (&PF)[9]) {
-  const float vol = m.volume * J;
-  float pressure = m.bulk;
-  {
-    const float J2 = J * J, J4 = J2 * J2;
-    pressure = pressure * (1 / (J * J2 * J4) - 1);
-  }
-  PF[0] = ((C[0] + C[0]) * m.viscosity - pressure) * vol;
-  PF[1] = (C[1] + C[3]) * m.viscosity * vol;
-  PF[2] = (C[2] + C[6]) * m.viscosity * vol;
-  PF[3] = (C[3] + C[1]) * m.viscosity * vol;
-  PF[4] = ((C[4] + C[4]) * m.viscosity - pressure) * vol;
-  PF[5] = (C[5] + C[7]) * m.viscosity * vol;
-  PF[6] = (C[6] + C[2]) * m.viscosity * vol;
-  PF[7] = (C[7] + C[5]) * m.viscosity * vol;
-  PF[8] = ((C[8] + C[8]) * m.viscosity - pressure) * vol;
-}
-// the fluid model keeps J where the solids keep F (component 0 of the `F` attribute); -2 = fluid without a constitutive
-// update in G2P (the G2P kernels' "no model" value for solids is -1)
-constexpr int MPM_FLUID_NO_STRESS = -2;
-__host__ __device__ constexpr bool model_is_fluid(int model) { return model == ZS_MPM_EQUATION_OF_STATE || model == MPM_FLUID_NO_STRESS; }
-// which models carry the scalar plastic state logJp (P2G.hpp:88-101)
-__host__ __device__ constexpr bool model_uses_logjp(int model) { return model == ZS_MPM_DRUCKER_PRAGER || model == ZS_MPM_NACC; }
-// one entry point for the four constitutive models of P2G.hpp:82-101.  F is the local copy: the plastic models project it
-// in place, P2G / G2P never store it back (only logJp), the test entry zs_rocm_mpm_stress does (WRITE_F).
-template <int MODEL, bool WRITE_F = false>
-__device__ __forceinline__ void model_stress(const Material &m, float &logJp, float (&F)[9], float (&PF)[9], const float (&C)[9]) {
-  if constexpr (MODEL == ZS_MPM_EQUATION_OF_STATE) stress_eos(m, F[0], C, PF);
-  else if constexpr (MODEL == ZS_MPM_FIXED_COROTATED) stress_fixedcorotated(m, F, PF);
-  else if constexpr (MODEL == ZS_MPM_DRUCKER_PRAGER) stress_sand<WRITE_F>(m, logJp, F, PF);
-  else if constexpr (MODEL == ZS_MPM_VONMISES_FIXED_COROTATED) stress_vonmises(m, F, PF);
-  else stress_nacc(m, logJp, F, PF);
-}
-
-// ======================================================================================= arena
-// LocalArena<collocated, quadratic> (simulation/Utils.hpp:47-75, InterpolationKernel.hpp:47-55,93-130)
-struct Arena {
-  int corner[3];
-  float lp[3];    // local position * dx
-  float w[3][3];  // w[axis][k]
-};
-// X = pos * (1/dx): the reference divides (simulation/Utils.hpp:52-55); the product differs by <= 1 ulp, which moves
-// a weight by O(1e-7) and never changes which bin a particle is stored in because the binning kernel uses this
-// same expression.
-__device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Arena &a) {
-  const float dxinv = 1.0f / dx;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float X = pos[d] * dxinv;
-    const float fl = floorf(X - 0.5f);
-    a.corner[d] = (int)fl;
-    const float lpn = X - fl;
-    const float d0 = lpn - floorf(lpn - 0.5f);
-    a.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
-    const float d1 = d0 - 1.0f;
-    a.w[d][1] = 0.75f - d1 * d1;
-    const float zz = 0.5f + d1;
-    a.w[d][2] = 0.5f * zz * zz;
-    a.lp[d] = lpn * dx;
-  }
-}
-
-__device__ __forceinline__ int floordiv(int a, int b) { return (a + (a < 0 ? -b + 1 : 0)) / b; }
-
-template <int N> __device__ __forceinline__ void load_attr(const Port<float> &p, size_t i, float (&out)[N]) {
-  const float *b = p.base + p.off(i);
-  const size_t cs = p.cstride();
-#pragma unroll
-  for (int d = 0; d < N; ++d) out[d] = b[d * cs];
-}
-template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p, size_t i, const float (&v)[N]) {
-  float *b = p.base + p.off(i);
-  const size_t cs = p.cstride();
-#pragma unroll
-  for (int d = 0; d < N; ++d) b[d * cs] = v[d];
-}
-
-// Fast particle addressing for the binned kernels.  When every attribute lives in ONE TileVector<f32, LW> (same tile
-// width / channel count, iterator index 0 -- the host checks this) the element offset of particle i,
-// ((i / LW) * chns) * LW + i % LW, is computed once per particle and every component load/store becomes
-// base(SGPR) + offset(VGPR) + d * LW * 4 (immediate): ~1 VALU per attribute instead of ~3 per component.
-// LW == 0: generic iterator ports (AoS vectors, mixed layouts).
-template <int LW> struct POff { size_t o; };
-template <int LW> __device__ __forceinline__ POff<LW> particle_offset(unsigned chns, size_t i) {
-  POff<LW> r;
-  if constexpr (LW != 0) r.o = ((i / LW) * (size_t)chns) * LW + (i % LW);
-  else r.o = i;
-  return r;
-}
-template <int LW, int N> __device__ __forceinline__ void pload(const Port<float> &p, POff<LW> o, float (&out)[N]) {
-  if constexpr (LW != 0) {
-    const float *b = p.base + o.o;
-#pragma unroll
-    for (int d = 0; d < N; ++d) out[d] = b[d * LW];
-  } else
-    load_attr<N>(p, o.o, out);
-}
-template <int LW> __device__ __forceinline__ float pload1(const Port<float> &p, POff<LW> o, int comp = 0) {
-  if constexpr (LW != 0) return p.base[o.o + comp * LW];
-  else return p.base[p.off(o.o) + comp * p.cstride()];
-}
-template <int LW, int N> __device__ __forceinline__ void pstore(const Port<float> &p, POff<LW> o, const float (&v)[N]) {
-  if constexpr (LW != 0) {
-    float *b = p.base + o.o;
-#pragma unroll
-    for (int d = 0; d < N; ++d) b[d * LW] = v[d];
-  } else
-    store_attr<N>(p, o.o, v);
-}
-template <int LW> __device__ __forceinline__ void pstore1(const Port<float> &p, POff<LW> o, float v) {
-  if constexpr (LW != 0) p.base[o.o] = v;
-  else p.base[p.off(o.o)] = v;
-}
-// deformation state of a particle: F (9 components) for the solids, the volume ratio J = component 0 of the same attribute
-// for the EquationOfState fluid (Structurefree.hpp: particles.F / particles.J)
-template <int LW, bool FLUID> __device__ __forceinline__ void pload_state(const Port<float> &p, POff<LW> o, float (&F)[9]) {
-  if constexpr (FLUID) {
-#pragma unroll
-    for (int d = 1; d < 9; ++d) F[d] = 0.f;
-    F[0] = pload1<LW>(p, o);
-  } else
-    pload<LW, 9>(p, o, F);
-}
-template <int LW, bool FLUID> __device__ __forceinline__ void pstore_state(const Port<float> &p, POff<LW> o, const float (&F)[9]) {
-  if constexpr (FLUID) pstore1<LW>(p, o, F[0]);
-  else pstore<LW, 9>(p, o, F);
-}
-template <bool FLUID> __device__ __forceinline__ void load_state(const Port<float> &p, size_t i, float (&F)[9]) {
-  if constexpr (FLUID) {
-#pragma unroll
-    for (int d = 1; d < 9; ++d) F[d] = 0.f;
-    F[0] = p.base[p.off(i)];
-  } else
-    load_attr<9>(p, i, F);
-}
-// G2P: F <- (I + dt C) F (G2P.hpp:75-78, MatrixUtils.h:136-146) or J <- (1 + tr(C) dt) J (:70-74)
-template <bool FLUID> __device__ __forceinline__ void advance_state(const float (&oldF)[9], const float (&C)[9], float dt, float (&F)[9]) {
-  if constexpr (FLUID) {
-#pragma unroll
-    for (int d = 1; d < 9; ++d) F[d] = 0.f;
-    F[0] = (1 + (C[0] + C[4] + C[8]) * dt) * oldF[0];
-  } else {
-    float tmp[9];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) tmp[d] = C[d] * dt + ((d & 0x3) ? 0.f : 1.f);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = 0; r < 3; ++r) F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
-  }
-}
-
-struct ParticlesDev {
-  Port<float> mass, pos, vel, C, F, logJp, stress;
-  size_t n;
-};
-// third "model" of the P2G kernels: P F^T * vol is read from the particles' `stress` attribute (written by the G2P of
-// the previous step, or by zs_rocm_mpm_update_stress) instead of being recomputed
-constexpr int MPM_CACHED_STRESS = 100;
-
-template <int N> __device__ __forceinline__ void load_attr(const Port<float> &p, size_t i, float (&out)[N]);
-template <int N> __device__ __forceinline__ void store_attr(const Port<float> &p, size_t i, const float (&v)[N]);
-struct MpmDev {
-  Material mat;
-  int model;
-  float dx, dt;
-  int kscale;  // partition keys are block coordinates (1: Grids + HashTable/bht convention) or block ORIGINS in cells
-               // (SIDE: SparseGrid convention, geometry/SparseGrid.hpp:305-309)
-};
-
-// per-particle constitutive update -> contrib = -dt * D_inv * (P F^T vol)   (P2G.hpp:60-105)
-template <int MODEL>
-__device__ __forceinline__ void particle_contrib(const MpmDev &mp, const ParticlesDev &ps, size_t i, float D_inv, float (&contrib)[9]) {
-  float F[9];
-  if constexpr (MODEL == MPM_CACHED_STRESS) {
-    load_attr<9>(ps.stress, i, contrib);
-  } else {
-    load_state<model_is_fluid(MODEL)>(ps.F, i, F);
-    float Cp[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (model_is_fluid(MODEL)) load_attr<9>(ps.C, i, Cp);
-    float lj = 0.f;
-    if constexpr (model_uses_logjp(MODEL)) lj = ps.logJp.base[ps.logJp.off(i)];
-    model_stress<MODEL>(mp.mat, lj, F, contrib, Cp);
-    if constexpr (model_uses_logjp(MODEL)) ps.logJp.base[ps.logJp.off(i)] = lj;  // P2G.hpp:101; the projected F is not written back
-  }
-#pragma unroll
-  for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
-}
-
-// ======================================================================================= sparsity
-__global__ __launch_bounds__(256) void compute_sparsity_kernel(BhtDev t, Port<float> pos, size_t n, float dxinv, int side, int kscale) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;
-  int b[3] = {0, 0, 0};
-  if (valid) {
-    float p[3];
-    load_attr<3>(pos, i, p);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side) * kscale;
-  }
-  // neighbouring lanes usually carry the same block: let only the first lane of a run insert (the others
-  // would get sentinel_v back from insert anyway)
-  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
-  const bool pvalid = shfl_up((int)valid, 1) != 0;
-  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
-  if (valid && !dup) bht_insert<3>(t, b);
-}
-__global__ __launch_bounds__(256) void enlarge_sparsity_kernel(BhtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2, int kscale) {
-  // thread per (block, offset)
-  const int per = e0 * e1 * e2;
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nblocks * per) return;
-  const int i = (int)(g / per), o = (int)(g % per);
-  const int dx = lo0 + o / (e1 * e2), dy = lo1 + (o / e2) % e1, dz = lo2 + o % e2;
-  int k[3] = {t.activeKeys[3 * (size_t)i] + dx * kscale, t.activeKeys[3 * (size_t)i + 1] + dy * kscale, t.activeKeys[3 * (size_t)i + 2] + dz * kscale};
-  bht_insert<3>(t, k);
-}
-// the same functors on a zs::HashTable<i32,3,int> (simulation/sparsity/SparsityOp.hpp:59-115 are written against HashTableView)
-__global__ __launch_bounds__(256) void compute_sparsity_ht_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, int side) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;
-  int b[3] = {0, 0, 0};
-  if (valid) {
-    float p[3];
-    load_attr<3>(pos, i, p);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[d] = floordiv((int)floorf(p[d] * dxinv + 0.5f) + (-2), side);
-  }
-  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
-  const bool pvalid = shfl_up((int)valid, 1) != 0;
-  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
-  if (valid && !dup) ht_insert<3>(t, b);
-}
-__global__ __launch_bounds__(256) void enlarge_sparsity_ht_kernel(HtDev t, int nblocks, int lo0, int lo1, int lo2, int e0, int e1, int e2) {
-  const int per = e0 * e1 * e2;
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nblocks * per) return;
-  const int i = (int)(g / per), o = (int)(g % per);
-  int k[3] = {t.activeKeys[3 * (size_t)i] + lo0 + o / (e1 * e2), t.activeKeys[3 * (size_t)i + 1] + lo1 + (o / e2) % e1,
-              t.activeKeys[3 * (size_t)i + 2] + lo2 + o % e2};
-  ht_insert<3>(t, k);
-}
-// index_buckets_for_particles (simulation/particle/Query.tpp:9-58): ComputeSparsity with blockLen 1 / offset 0, then
-// SpatiallyCount (sparsity/SparsityOp.hpp:117-152)
-__global__ __launch_bounds__(256) void ib_cells_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;
-  int b[3] = {0, 0, 0};
-  if (valid) {
-    float p[3];
-    load_attr<3>(pos, i, p);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b[d] = (int)floorf(p[d] * dxinv + displacement);
-  }
-  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
-  const bool pvalid = shfl_up((int)valid, 1) != 0;
-  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
-  if (valid && !dup) ht_insert<3>(t, b);
-}
-__global__ __launch_bounds__(256) void ib_count_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement, unsigned *counts,
-                                                       unsigned *cellOf, int *ids) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float p[3];
-  load_attr<3>(pos, i, p);
-  int b[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) b[d] = (int)floorf(p[d] * dxinv + displacement);
-  const int c = ht_query<3>(t, b);
-  cellOf[i] = (unsigned)c;
-  ids[i] = (int)i;
-  atomicAdd(&counts[c], 1u);
-}
-__global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr, int kscale) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nblocks * 8) return;
-  const int i = (int)(g >> 3), o = (int)(g & 7);
-  int k[3] = {t.activeKeys[3 * (size_t)i] + (o >> 2) * kscale, t.activeKeys[3 * (size_t)i + 1] + ((o >> 1) & 1) * kscale,
-              t.activeKeys[3 * (size_t)i + 2] + (o & 1) * kscale};
-  nbr[g] = bht_query<3>(t, k);
-}
-
-// ======================================================================================= binning
-// A "bin" is a 4x4x4 group of cells = 64 cells = one wavefront.  SIDE 4: bin == grid block.  SIDE 8: a grid
-// block holds 2x2x2 bins, bin = block * 8 + sub, sub = ((lx>>2)*2 + (ly>>2))*2 + (lz>>2).
-template <int SIDE> constexpr int bins_per_block() { return (SIDE / 4) * (SIDE / 4) * (SIDE / 4); }
-
-template <int SIDE>
-__global__ __launch_bounds__(256) void bin_count_kernel(BhtDev t, Port<float> pos, size_t n, float dx, unsigned *cellCount,
-                                                        unsigned *cellOf, unsigned *rankOf, int *err, int kscale) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float p[3];
-  load_attr<3>(pos, i, p);
-  int key[3], loc[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int c = (int)floorf(p[d] * (1.0f / dx) - 0.5f);
-    loc[d] = c & (SIDE - 1);
-    key[d] = (c - loc[d]) / SIDE * kscale;
-  }
-  const int b = bht_query<3>(t, key);
-  if (b < 0) {
-    *err = 1;
-    cellOf[i] = 0xffffffffu;
-    return;
-  }
-  const int sub = SIDE == 4 ? 0 : (((loc[0] >> 2) * 2 + (loc[1] >> 2)) * 2 + (loc[2] >> 2));
-  const unsigned cell = ((unsigned)b * bins_per_block<SIDE>() + sub) * 64u +
-                        (unsigned)(((loc[0] & 3) * 4 + (loc[1] & 3)) * 4 + (loc[2] & 3));
-  cellOf[i] = cell;
-  rankOf[i] = atomicAdd(&cellCount[cell], 1u);
-}
-__global__ __launch_bounds__(256) void bin_place_kernel(size_t n, const unsigned *cellStart, const unsigned *cellOf,
-                                                        const unsigned *rankOf, int *byCell) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned c = cellOf[i];
-  if (c != 0xffffffffu) byCell[cellStart[c] + rankOf[i]] = (int)i;
-}
-// one wave per bin, lane = cell: (cell, rank) order -> (rank, cell) order
-__global__ __launch_bounds__(64) void bin_roundrobin_kernel(int nbins, const unsigned *cellStart, const unsigned *cellCount,
-                                                            const int *byCell, int *order, int *binStart, unsigned total) {
-  const int bin = blockIdx.x, c = threadIdx.x;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + c], st = cellStart[(size_t)bin * 64 + c];
-  unsigned base = shfl(st, 0);
-  if (c == 0) {
-    binStart[bin] = (int)base;
-    if (bin == nbins - 1) binStart[nbins] = (int)total;
-  }
-  const unsigned long long lt = lanemask_lt();
-  for (unsigned r = 0;; ++r) {
-    const bool has = cnt > r;
-    const unsigned long long m = __ballot(has);
-    if (!m) break;
-    if (has) order[base + (unsigned)__popcll(m & lt)] = byCell[st + r];
-    base += (unsigned)__popcll(m);
-  }
-}
-
-// ======================================================================================= P2G
-// ---- particle-order path: the reference's algorithm (hash query + global float atomics per node), with the
-//      27 queries folded into the <= 8 distinct blocks a stencil can touch.
-template <int SIDE, int MODEL>
-__device__ __forceinline__ void p2g_scatter_global(const MpmDev &mp, const ParticlesDev &ps, size_t i, const BhtDev &t, float *grid,
-                                                   float D_inv) {
-  constexpr int NC = SIDE * SIDE * SIDE;
-  float pos[3], vel[3], C[9], contrib[9];
-  load_attr<3>(ps.pos, i, pos);
-  load_attr<3>(ps.vel, i, vel);
-  load_attr<9>(ps.C, i, C);
-  const float mass = ps.mass.base[ps.mass.off(i)];
-  particle_contrib<MODEL>(mp, ps, i, D_inv, contrib);
-  Arena ar;
-  make_arena(mp.dx, pos, ar);
-  int loc[3], key[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    loc[d] = ar.corner[d] & (SIDE - 1);
-    key[d] = (ar.corner[d] - loc[d]) / SIDE * mp.kscale;
-  }
-  int blk[8];
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
-    int k[3] = {key[0] + (o >> 2) * mp.kscale, key[1] + ((o >> 1) & 1) * mp.kscale, key[2] + (o & 1) * mp.kscale};
-    blk[o] = need ? bht_query<3>(t, k) : -1;
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int x = loc[0] + a, y = loc[1] + b, z = loc[2] + c;
-        const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
-        int bn = blk[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) bn = (o == q) ? blk[q] : bn;
-        if (bn < 0) continue;  // the reference does not check (P2G.hpp:109-110); a valid partition never gets here
-        const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
-        float *g = grid + (size_t)bn * 7 * NC + cell;
-        const float xi0 = (float)a * mp.dx - ar.lp[0], xi1 = (float)b * mp.dx - ar.lp[1], xi2 = (float)c * mp.dx - ar.lp[2];
-        float W = ar.w[0][a];
-        W *= ar.w[1][b];
-        W *= ar.w[2][c];
-        unsafeAtomicAdd(g, mass * W);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          unsafeAtomicAdd(g + (1 + d) * NC, W * mass * (vel[d] + (C[d] * xi0 + C[3 + d] * xi1 + C[6 + d] * xi2)));
-          unsafeAtomicAdd(g + (4 + d) * NC, (contrib[d] * xi0 + contrib[3 + d] * xi1 + contrib[6 + d] * xi2) * W);
-        }
-      }
-}
-
-template <int SIDE, int MODEL>
-__global__ __launch_bounds__(256) void p2g_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ps.n) return;
-  const float dxi = 1.0f / mp.dx;
-  p2g_scatter_global<SIDE, MODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
-}
-
-// ---- binned path
-// LDS arena of one bin: 6^3 nodes, strides (floats) z + 8 y + 52 x: for a fixed stencil offset the 64 cells of
-// a bin land on 32 distinct banks per 32-lane half.
-struct ArenaLds {
-  static constexpr int W = 6;
-  static constexpr int SY = 8, SX = 52, CH = W * SX;
-  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
-};
-
-// geometry of bin `bin`: grid block, origin of the bin inside the block (cells), origin in world cells
-template <int SIDE> struct BinGeom {
-  int block, o[3], org[3];
-  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin, int kscale) {
-    constexpr int BPB = bins_per_block<SIDE>();
-    block = bin / BPB;
-    const int sub = bin % BPB;
-    o[0] = SIDE == 4 ? 0 : ((sub >> 2) & 1) * 4;
-    o[1] = SIDE == 4 ? 0 : ((sub >> 1) & 1) * 4;
-    o[2] = SIDE == 4 ? 0 : (sub & 1) * 4;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) org[d] = t.activeKeys[3 * (size_t)block + d] * (SIDE / kscale) + o[d];
-  }
-};
-
-// arena node (x,y,z) of a bin -> (neighbour slot 0..7, cell id) in the grid block layout
-template <int SIDE> __device__ __forceinline__ void arena_to_grid(const int (&o)[3], int x, int y, int z, int &slot, int &cell) {
-  const int gx = o[0] + x, gy = o[1] + y, gz = o[2] + z;
-  slot = ((gx >= SIDE) << 2) | ((gy >= SIDE) << 1) | (gz >= SIDE);
-  cell = ((gx & (SIDE - 1)) * SIDE + (gy & (SIDE - 1))) * SIDE + (gz & (SIDE - 1));
-}
-
-// round-robin walk of one bin: round r visits the r-th particle of every cell (lane) that has one; the lanes
-// that take part in a round read consecutive particles (coalesced), the index needs only ballots on the counts,
-// so the loads of round r+1 can be issued before round r is computed (software pipelining: with ~220 VGPRs only
-// two waves share a SIMD and memory latency must be hidden inside the wave).
-struct RoundWalk {
-  unsigned cnt, r = 0;
-  int base;
-  unsigned long long lt;
-  __device__ __forceinline__ RoundWalk(unsigned cnt_, int start) : cnt(cnt_), base(start), lt(lanemask_lt()) {}
-  // returns whether this lane has a particle in the next round; any = some lane has
-  __device__ __forceinline__ bool next(int &i, bool &any) {
-    const bool has = cnt > r;
-    const unsigned long long m = __ballot(has);
-    any = m != 0ull;
-    i = base + __popcll(m & lt);
-    base += __popcll(m);
-    ++r;
-    return has;
-  }
-};
-template <int LW> struct RecA {  // sweep A inputs: x, v, C, m (16 floats)
-  float pos[3], vel[3], C[9], mass;
-  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
-    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    pload<LW, 3>(ps.pos, o, pos);
-    pload<LW, 3>(ps.vel, o, vel);
-    pload<LW, 9>(ps.C, o, C);
-    mass = pload1<LW>(ps.mass, o);
-  }
-};
-template <int MODEL, int LW> struct RecB {  // sweep B inputs: x, F (, logJp) -- or x, cached P F^T vol; fluid: x, J, C
-  float pos[3], F[9], logJp;
-  float C[model_is_fluid(MODEL) ? 9 : 1];
-  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
-    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    pload<LW, 3>(ps.pos, o, pos);
-    if constexpr (MODEL == MPM_CACHED_STRESS) pload<LW, 9>(ps.stress, o, F);
-    else pload_state<LW, model_is_fluid(MODEL)>(ps.F, o, F);
-    if constexpr (model_uses_logjp(MODEL)) logJp = pload1<LW>(ps.logJp, o);
-    if constexpr (MODEL == ZS_MPM_EQUATION_OF_STATE) pload<LW, 9>(ps.C, o, C);  // P2G sweep only (G2P recomputes C)
-  }
-};
-
-template <int SIDE, int MODEL, int LW>
-__global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
-                                                        const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  __shared__ float arena[7 * AL::CH];
-  const int bin = blockIdx.x;
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;  // empty bin (ghost block): uniform exit
-  const int lane = threadIdx.x;
-  for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
-
-  float *a0 = arena + AL::at(cx, cy, cz);
-  __syncthreads();
-  // Two sweeps over the bin's particles keep the register-resident stencil at 27 x 4 (mass, momentum) and
-  // 27 x 3 (stress) accumulators instead of 27 x 7 = 189, which would cap occupancy at one wave per SIMD;
-  // the price is reading x twice (+12 B/particle).
-  {  // ---- sweep A: m, m v + m C (xi - xp)
-    float acc[27][4];
-#pragma unroll
-    for (int k = 0; k < 27; ++k)
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) acc[k][ch] = 0.f;
-    RoundWalk walk(cnt, start);
-    int i0, i1;
-    bool any, any1;
-    bool has0 = walk.next(i0, any);
-    RecA<LW> cur, nxt;
-    if (has0) cur.load(ps, (size_t)i0);
-    while (any) {
-      const bool has1 = walk.next(i1, any1);
-      if (has1) nxt.load(ps, (size_t)i1);  // in flight while the current round is computed
-      if (has0) {
-        Arena ar;
-        make_arena(mp.dx, cur.pos, ar);
-        if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-          stale[atomicAdd(staleCount, 1)] = i0;  // left its cell since the last re-binning: exact path afterwards
-        } else {
-          // W m (v + C (xi - xp)) is affine in the node offset: evaluate it as (Px[a] + Py[b]) + Pz[c] with the
-          // per-axis products hoisted -> 8 VALU ops per node instead of ~20 (rounding differs from the
-          // reference's association by O(1 ulp), inside the stated tolerance)
-          float Px[3][3], Py[3][3], Pz[3][3], wzm[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              Px[k][d] = cur.C[d] * x0;
-              Py[k][d] = cur.C[3 + d] * x1;
-              Pz[k][d] = fmaf(cur.C[6 + d], x2, cur.vel[d]);
-            }
-            wzm[k] = ar.w[2][k] * cur.mass;
-          }
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-              const float wxy = ar.w[0][a] * ar.w[1][bb];
-              const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const float Wm = wxy * wzm[c];
-                float(&A)[4] = acc[(a * 3 + bb) * 3 + c];
-                A[0] += Wm;
-                A[1] = fmaf(Wm, q0 + Pz[c][0], A[1]);
-                A[2] = fmaf(Wm, q1 + Pz[c][1], A[2]);
-                A[3] = fmaf(Wm, q2 + Pz[c][2], A[3]);
-              }
-            }
-        }
-      }
-      cur = nxt;
-      has0 = has1;
-      i0 = i1;
-      any = any1;
-    }
-    // 27 phases: in phase (a,b,c) lane (cx,cy,cz) owns node (cx+a, cy+b, cz+c) -- all 64 nodes distinct
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) g[ch * AL::CH] += acc[k][ch];
-      __syncthreads();
-    }
-  }
-  {  // ---- sweep B: rhs = -dt D_inv (P F^T vol) (xi - xp) W
-    float acc[27][3];
-#pragma unroll
-    for (int k = 0; k < 27; ++k)
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) acc[k][ch] = 0.f;
-    RoundWalk walk(cnt, start);
-    int i0, i1;
-    bool any, any1;
-    bool has0 = walk.next(i0, any);
-    RecB<MODEL, LW> cur, nxt;
-    if (has0) cur.load(ps, (size_t)i0);
-    while (any) {
-      const bool has1 = walk.next(i1, any1);
-      if (has1) nxt.load(ps, (size_t)i1);
-      if (has0) {
-        Arena ar;
-        make_arena(mp.dx, cur.pos, ar);
-        if (ar.corner[0] - geo.org[0] == cx && ar.corner[1] - geo.org[1] == cy && ar.corner[2] - geo.org[2] == cz) {
-          float contrib[9];
-          if constexpr (MODEL == MPM_CACHED_STRESS) {
-#pragma unroll
-            for (int d = 0; d < 9; ++d) contrib[d] = cur.F[d];
-          } else {
-            float lj = model_uses_logjp(MODEL) ? cur.logJp : 0.f;
-            float Cp[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if constexpr (model_is_fluid(MODEL)) {
-#pragma unroll
-              for (int d = 0; d < 9; ++d) Cp[d] = cur.C[d];
-            }
-            model_stress<MODEL>(mp.mat, lj, cur.F, contrib, Cp);
-            if constexpr (model_uses_logjp(MODEL))
-              pstore1<LW>(ps.logJp, particle_offset<LW>(ps.pos.chns, (size_t)i0), lj);  // P2G.hpp:101 (projected F not written back)
-          }
-#pragma unroll
-          for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -mp.dt * D_inv;
-          float Qx[3][3], Qy[3][3], Qz[3][3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              Qx[k][d] = contrib[d] * x0;
-              Qy[k][d] = contrib[3 + d] * x1;
-              Qz[k][d] = contrib[6 + d] * x2;
-            }
-          }
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-              const float wxy = ar.w[0][a] * ar.w[1][bb];
-              const float q0 = Qx[a][0] + Qy[bb][0], q1 = Qx[a][1] + Qy[bb][1], q2 = Qx[a][2] + Qy[bb][2];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const float Wt = wxy * ar.w[2][c];
-                float(&A)[3] = acc[(a * 3 + bb) * 3 + c];
-                A[0] = fmaf(Wt, q0 + Qz[c][0], A[0]);
-                A[1] = fmaf(Wt, q1 + Qz[c][1], A[1]);
-                A[2] = fmaf(Wt, q2 + Qz[c][2], A[2]);
-              }
-            }
-        }
-      }
-      cur = nxt;
-      has0 = has1;
-      i0 = i1;
-      any = any1;
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3) + 4 * AL::CH;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) g[ch * AL::CH] += acc[k][ch];
-      __syncthreads();
-    }
-  }
-  // flush: consecutive lanes -> consecutive z of one (channel, x, y) row
-  int nb[8];
-#pragma unroll
-  for (int o = 0; o < 8; ++o) nb[o] = nbr[(size_t)geo.block * 8 + o];
-  for (int k = lane; k < 7 * 216; k += 64) {
-    const int ch = k / 216, node = k % 216;
-    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
-    const float v = arena[ch * AL::CH + AL::at(x, y, z)];
-    if (v == 0.f) continue;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    int bn = nb[0];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) bn = (slot == q) ? nb[q] : bn;
-    if (bn < 0) continue;
-    unsafeAtomicAdd(grid + ((size_t)bn * 7 + ch) * NC + cell, v);
-  }
-}
-
-// ---- binned path, cached stress: channel-split workgroup.
-// With the constitutive update moved to the tail of G2P, P2G has ~15 VALU ops per byte-lane left and becomes latency bound
-// at two waves per SIMD (the 27 x 4 register stencil of sweep A costs 175 VGPRs).  Here one workgroup of FOUR waves owns a
-// bin and each wave accumulates a subset of the 7 grid channels (all waves walk the same particles; the repeated reads of
-// x / m hit L1/L2):   wave 0: m, mv_x    wave 1: mv_y, mv_z    wave 2: rhs_x, rhs_y    wave 3: rhs_z
-// -> <= 54 accumulators per lane, ~4x the loads in flight per bin, and the per-bin zero/flush work spread over 256 lanes.
-template <int ROLE> struct SplitRole {
-  static constexpr int NA = (ROLE == 0 || ROLE == 3) ? 1 : 2;  // affine channels handled by this wave
-  static constexpr bool HASMASS = ROLE == 0;                   // plus the mass channel
-  static constexpr bool USEM = ROLE < 2;                       // momentum channels are weighted by W * m, stress ones by W
-  static constexpr int CH0 = ROLE == 0 ? 1 : (ROLE == 1 ? 2 : (ROLE == 2 ? 4 : 6));  // first arena channel
-};
-template <int ROLE, int LW> struct SplitRec {
-  using R = SplitRole<ROLE>;
-  float pos[3], m, b[R::NA], g[R::NA][3];
-  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
-    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    pload<LW, 3>(ps.pos, o, pos);
-    if constexpr (R::USEM) {
-      m = pload1<LW>(ps.mass, o);
-      constexpr int d0 = ROLE == 0 ? 0 : 1;
-#pragma unroll
-      for (int k = 0; k < R::NA; ++k) {
-        b[k] = pload1<LW>(ps.vel, o, d0 + k);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) g[k][j] = pload1<LW>(ps.C, o, d0 + k + 3 * j);  // row d of the column-major C
-      }
-    } else {
-      constexpr int d0 = ROLE == 2 ? 0 : 2;
-#pragma unroll
-      for (int k = 0; k < R::NA; ++k) {
-        b[k] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) g[k][j] = pload1<LW>(ps.stress, o, d0 + k + 3 * j);
-      }
-    }
-  }
-};
-
-// one particle's contribution of the channels of ROLE to the 27 stencil nodes of its cell (registers):
-//   momentum roles:  W m (b + g . (xi - xp))      stress roles:  W kscale (g . (xi - xp))        [+ W m for the mass channel]
-// evaluated as Ws * ((Px[a] + Py[b]) + Pz[c]) with the per-axis products hoisted
-template <int ROLE>
-__device__ __forceinline__ void split_accumulate(const MpmDev &mp, const Arena &ar, float m, float kscale,
-                                                 const float (&b)[SplitRole<ROLE>::NA], const float (&g)[SplitRole<ROLE>::NA][3],
-                                                 float (&accm)[27], float (&acc)[27][SplitRole<ROLE>::NA]) {
-  using R = SplitRole<ROLE>;
-  float Px[3][R::NA], Py[3][R::NA], Pz[3][R::NA], wzs[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float x0 = (float)k * mp.dx - ar.lp[0], x1 = (float)k * mp.dx - ar.lp[1], x2 = (float)k * mp.dx - ar.lp[2];
-#pragma unroll
-    for (int q = 0; q < R::NA; ++q) {
-      Px[k][q] = g[q][0] * x0;
-      Py[k][q] = g[q][1] * x1;
-      Pz[k][q] = fmaf(g[q][2], x2, b[q]);
-    }
-    wzs[k] = ar.w[2][k] * (R::USEM ? m : kscale);
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      const float wxy = ar.w[0][a] * ar.w[1][bb];
-      float qv[R::NA];
-#pragma unroll
-      for (int q = 0; q < R::NA; ++q) qv[q] = Px[a][q] + Py[bb][q];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float Ws = wxy * wzs[c];
-        const int n = (a * 3 + bb) * 3 + c;
-        if constexpr (R::HASMASS) accm[n] += Ws;
-#pragma unroll
-        for (int q = 0; q < R::NA; ++q) acc[n][q] = fmaf(Ws, qv[q] + Pz[c][q], acc[n][q]);
-      }
-    }
-}
-
-template <int SIDE, int ROLE, int LW>
-__device__ __forceinline__ void p2g_split_sweep(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
-                                                int cx, int cy, int cz, float *a0, int *stale, int *staleCount) {
-  using AL = ArenaLds;
-  using R = SplitRole<ROLE>;
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = R::USEM ? 1.f : -mp.dt * (4.f * dxi * dxi);  // contrib = -dt D_inv (P F^T vol)
-  float accm[27];
-  float acc[27][R::NA];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    accm[k] = 0.f;
-#pragma unroll
-    for (int q = 0; q < R::NA; ++q) acc[k][q] = 0.f;
-  }
-  RoundWalk walk(cnt, start);
-  int i0, i1;
-  bool any, any1;
-  bool has0 = walk.next(i0, any);
-  SplitRec<ROLE, LW> cur, nxt;
-  if (has0) cur.load(ps, (size_t)i0);
-  while (any) {
-    const bool has1 = walk.next(i1, any1);
-    if (has1) nxt.load(ps, (size_t)i1);
-    if (has0) {
-      Arena ar;
-      make_arena(mp.dx, cur.pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-        if constexpr (ROLE == 0) stale[atomicAdd(staleCount, 1)] = i0;  // exact path afterwards (queued once)
-      } else {
-        split_accumulate<ROLE>(mp, ar, cur.m, kscale, cur.b, cur.g, accm, acc);
-      }
-    }
-    cur = nxt;
-    has0 = has1;
-    i0 = i1;
-    any = any1;
-  }
-  // 27 conflict-free phases; every wave of the workgroup executes the same 27 barriers
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-    if constexpr (R::HASMASS) g[0] += accm[k];
-#pragma unroll
-    for (int q = 0; q < R::NA; ++q) g[(R::CH0 + q) * AL::CH] += acc[k][q];
-    __syncthreads();
-  }
-}
-
-template <int SIDE, int LW>
-__global__ __launch_bounds__(256) void p2g_binned_split_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
-                                                               const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  __shared__ float arena[7 * AL::CH];
-  const int bin = blockIdx.x;
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int k = tid; k < 7 * AL::CH; k += 256) arena[k] = 0.f;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  float *a0 = arena + AL::at(cx, cy, cz);
-  __syncthreads();
-  if (w == 0) p2g_split_sweep<SIDE, 0, LW>(mp, ps, geo, start, cnt, cx, cy, cz, a0, stale, staleCount);
-  else if (w == 1) p2g_split_sweep<SIDE, 1, LW>(mp, ps, geo, start, cnt, cx, cy, cz, a0, stale, staleCount);
-  else if (w == 2) p2g_split_sweep<SIDE, 2, LW>(mp, ps, geo, start, cnt, cx, cy, cz, a0, stale, staleCount);
-  else p2g_split_sweep<SIDE, 3, LW>(mp, ps, geo, start, cnt, cx, cy, cz, a0, stale, staleCount);
-  // flush (the last phase barrier has made every channel visible): thread = arena node, decoded once for all 7 channels
-  if (tid < 216) {
-    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    const int bn = nbr[(size_t)geo.block * 8 + slot];
-    if (bn >= 0) {
-      const float *a = arena + AL::at(x, y, z);
-      float *g = grid + (size_t)bn * 7 * NC + cell;
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        const float v = a[ch * AL::CH];
-        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
-      }
-    }
-  }
-}
-
-// ---- "wide" cached-stress P2G: ONE wave per bin carries all 7 channels (27 x 7 = 189 register accumulators).
-// The four-wave split above repeats the arena / weight / address work in every wave (PMC: 1113 VALU instructions per
-// 64-particle round, SQ_INSTS_VALU x 4 cycles = 96 % of the SIMD cycles: that kernel is VALU-bound).  Here the per-particle
-// work is done once (~600 VALU per round).  The price is 2 waves per SIMD; the latency the occupancy no longer hides is
-// covered by asynchronous global -> LDS loads (global_load_lds_dword: no staging VGPRs) issued one round ahead into a
-// double-buffered record area of the LDS.
-constexpr int P2GW_NF = 25;  // m, x(3), v(3), C(9), P F^T vol(9)
-
-// `tileBase`: wave-uniform element offset of a tile at or before the bin's first particle.  The per-lane part of every address
-// is then a 32-bit byte offset from a scalar base (global_load_lds_dword v_off, s[base:base+1] offset:imm): ONE address VGPR
-// per round instead of a 64-bit pointer per attribute.
-template <int LW>
-__device__ __forceinline__ void p2gw_issue(const ParticlesDev &ps, size_t i, bool has, float *buf, size_t tileBase) {
-  // every lane of the wave executes the 25 instructions (LDS destination = wave-uniform row + lane * 4); lanes without a
-  // particle in this round are masked off by exec
-  if (has) {
-    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    const unsigned voff = LW != 0 ? (unsigned)((o.o - tileBase) * sizeof(float)) : 0u;
-    auto ptr = [&](const Port<float> &p, int comp) -> const float * {
-      if constexpr (LW != 0)
-        return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.base + tileBase) + (size_t)voff) + (size_t)comp * LW;
-      else
-        return p.base + p.off(o.o) + (size_t)comp * p.cstride();
-    };
-    __builtin_amdgcn_global_load_lds(ptr(ps.mass, 0), (__attribute__((address_space(3))) void *)(buf + 0 * 64), 4, 0, 0);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.pos, d), (__attribute__((address_space(3))) void *)(buf + (1 + d) * 64), 4, 0, 0);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.vel, d), (__attribute__((address_space(3))) void *)(buf + (4 + d) * 64), 4, 0, 0);
-#pragma unroll
-    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.C, d), (__attribute__((address_space(3))) void *)(buf + (7 + d) * 64), 4, 0, 0);
-#pragma unroll
-    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, 0);
-  }
-}
-template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const ParticlesDev &ps, int start) {
-  if constexpr (LW != 0) return ((size_t)start / LW) * (size_t)ps.pos.chns * LW;
-  else return 0;
-}
-
-// one particle record (LDS row layout of p2gw_issue) -> the lane's 27 x 7 register stencil
-__device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
-  const float m = rec[0];
-  float xo[3][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
-  {  // ---- mass + momentum: W m (v + C (xi - xp))
-    float Px[3][3], Py[3][3], Pz[3][3], wzm[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float v = rec[(4 + d) * 64], c0 = rec[(7 + d) * 64], c1 = rec[(10 + d) * 64], c2 = rec[(13 + d) * 64];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Px[k][d] = c0 * xo[0][k];
-        Py[k][d] = c1 * xo[1][k];
-        Pz[k][d] = fmaf(c2, xo[2][k], v);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wzm[k] = ar.w[2][k] * m;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float wxy = ar.w[0][a] * ar.w[1][bb];
-        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float Wm = wxy * wzm[c];
-          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
-          A[0] += Wm;
-          A[1] = fmaf(Wm, q0 + Pz[c][0], A[1]);
-          A[2] = fmaf(Wm, q1 + Pz[c][1], A[2]);
-          A[3] = fmaf(Wm, q2 + Pz[c][2], A[3]);
-        }
-      }
-  }
-  {  // ---- stress: W kscale (P F^T vol) (xi - xp)
-    float Px[3][3], Py[3][3], Pz[3][3], wzk[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float c0 = rec[(16 + d) * 64], c1 = rec[(19 + d) * 64], c2 = rec[(22 + d) * 64];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Px[k][d] = c0 * xo[0][k];
-        Py[k][d] = c1 * xo[1][k];
-        Pz[k][d] = c2 * xo[2][k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wzk[k] = ar.w[2][k] * kscale;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float wxy = ar.w[0][a] * ar.w[1][bb];
-        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float Wk = wxy * wzk[c];
-          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
-          A[4] = fmaf(Wk, q0 + Pz[c][0], A[4]);
-          A[5] = fmaf(Wk, q1 + Pz[c][1], A[5]);
-          A[6] = fmaf(Wk, q2 + Pz[c][2], A[6]);
-        }
-      }
-  }
-}
-
-// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of 6.4 KB)
-template <int SIDE, int LW, int DEPTH>
-__global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
-                                                       const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  constexpr int NB = DEPTH + 1;
-  // the record buffers and the flush arena are never live at the same time: one LDS region serves both, so that DEPTH = 2
-  // (19.2 KB) still leaves room for the 8 waves per CU the register file allows
-  constexpr int LDSF = NB * P2GW_NF * 64 > 7 * AL::CH ? NB * P2GW_NF * 64 : 7 * AL::CH;
-  __shared__ float lds[LDSF];
-  float *arena = lds;
-  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds);
-  const int bin = blockIdx.x;
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;
-  const int lane = threadIdx.x;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);  // contrib = -dt D_inv (P F^T vol)
-  float acc[27][7];
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
-  // two walks over the same counts: `lead` runs DEPTH rounds ahead and issues the loads, `walk` consumes
-  const size_t tileBase = p2gw_tile_base<LW>(ps, start);
-  RoundWalk lead(cnt, start), walk(cnt, start);
-  int li;
-  bool lany = true;
-  int issued = 0;  // rounds issued and not yet consumed (wave-uniform)
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (lany) {
-      const bool lh = lead.next(li, lany);
-      if (lany) {
-        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[d % NB], tileBase);
-        ++issued;
-      }
-    }
-  }
-  int slot = 0, lslot = DEPTH % NB;
-  int i0;
-  bool any;
-  bool has0 = walk.next(i0, any);
-  while (any) {
-    if (lany) {
-      const bool lh = lead.next(li, lany);
-      if (lany) {
-        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[lslot], tileBase);
-        lslot = lslot + 1 == NB ? 0 : lslot + 1;
-        ++issued;
-      }
-    }
-    // wait until only the records issued AFTER the current one are still in flight
-    if (issued >= 3) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has0) {
-      const float *rec = pbuf[slot] + lane;
-      const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
-      Arena ar;
-      make_arena(mp.dx, pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz)
-        stale[atomicAdd(staleCount, 1)] = i0;  // exact path afterwards
-      else
-        p2gw_accumulate(mp, ar, rec, kscale, acc);
-    }
-    --issued;
-    slot = slot + 1 == NB ? 0 : slot + 1;
-    has0 = walk.next(i0, any);
-  }
-  __syncthreads();  // every record has been consumed: the region becomes the arena
-  for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
-  __syncthreads();
-  float *a0 = arena + AL::at(cx, cy, cz);
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases (one wave: its LDS operations execute in order)
-    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) g[ch * AL::CH] += acc[k][ch];
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  for (int node = lane; node < 216; node += 64) {
-    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
-    int slot2, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot2, cell);
-    const int bn = nbr[(size_t)geo.block * 8 + slot2];
-    if (bn >= 0) {
-      const float *a = arena + AL::at(x, y, z);
-      float *g = grid + (size_t)bn * 7 * NC + cell;
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        const float v = a[ch * AL::CH];
-        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
-      }
-    }
-  }
-}
-
-// exact path for the queued particles (persistent grid-stride over a device-side count)
-template <int SIDE, int MODEL>
-__global__ __launch_bounds__(256) void p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *stale,
-                                                        const int *staleCount) {
-  const int n = *staleCount;
-  const float dxi = 1.0f / mp.dx;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    p2g_scatter_global<SIDE, MODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
-}
-
-// ======================================================================================= grid update
-template <int SIDE>
-__global__ __launch_bounds__(256) void grid_update_kernel(float *grid, size_t nblocks, float dt, float e0, float e1, float e2,
-                                                          float *maxVelSqr) {
-  constexpr int NC = SIDE * SIDE * SIDE;
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float vsq = 0.f;
-  if (g < nblocks * NC) {
-    const size_t b = g / NC, c = g % NC;
-    float *blk = grid + b * 7 * NC + c;
-    float mass = blk[0];
-    if (mass != 0.f) {
-      mass = 1.f / mass;
-      const float v0 = blk[1 * NC] * mass + e0 * dt, v1 = blk[2 * NC] * mass + e1 * dt, v2 = blk[3 * NC] * mass + e2 * dt;
-      blk[1 * NC] = v0;
-      blk[2 * NC] = v1;
-      blk[3 * NC] = v2;
-      vsq = v0 * v0 + v1 * v1 + v2 * v2;
-    }
-  }
-  if (maxVelSqr) {  // atomic_max(maxVel, |v|^2) (GridOp.hpp:103-104): wave max, then one int-ordered atomic
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) vsq = fmaxf(vsq, shfl_down(vsq, d));
-    if (lane_id() == 0 && vsq > 0.f) atomicMax((int *)maxVelSqr, __float_as_int(vsq));
-  }
-}
-
-// ======================================================================================= G2P
-// constitutive update for the NEXT P2G, fused into the tail of G2P where the VALU is otherwise idle (G2P is HBM-bound, P2G
-// is VALU-bound by the SVD): stress(F_new, logJp) -> particles.stress (P F^T vol, unscaled), logJp updated.  Exactly what the
-// next P2G would compute from the same F (P2G.hpp:60-101); SMODEL < 0: disabled.
-template <int SMODEL, int LW = 0>
-__device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesDev &ps, POff<LW> o, float (&F)[9], const float (&C)[9]) {
-  if constexpr (SMODEL >= 0) {
-    float PF[9], Fl[9];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) Fl[d] = F[d];  // the plastic models project their local copy only
-    float lj = 0.f;
-    if constexpr (model_uses_logjp(SMODEL)) lj = pload1<LW>(ps.logJp, o);
-    model_stress<SMODEL>(mp.mat, lj, Fl, PF, C);
-    if constexpr (model_uses_logjp(SMODEL)) pstore1<LW>(ps.logJp, o, lj);
-    pstore<LW, 9>(ps.stress, o, PF);
-  }
-}
-
-template <int SIDE, int SMODEL, int LW = 0>
-__device__ __forceinline__ void g2p_finish_loaded(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&oldF)[9],
-                                                  const float (&vel)[3], const float (&C)[9]) {
-  const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
-  float F[9];
-  advance_state<model_is_fluid(SMODEL)>(oldF, C, mp.dt, F);
-  pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
-  pstore<LW, 3>(ps.pos, o, pos);
-  pstore<LW, 3>(ps.vel, o, vel);
-  pstore<LW, 9>(ps.C, o, C);
-  update_stress<SMODEL, LW>(mp, ps, o, F, C);
-}
-template <int SIDE, int SMODEL>
-__device__ __forceinline__ void g2p_finish(const MpmDev &mp, const ParticlesDev &ps, size_t i, float (&pos)[3], const float (&vel)[3],
-                                           const float (&C)[9]) {
-  float oldF[9];
-  load_state<model_is_fluid(SMODEL)>(ps.F, i, oldF);
-  g2p_finish_loaded<SIDE, SMODEL>(mp, ps, i, pos, oldF, vel, C);
-}
-
-template <int SIDE, int SMODEL>
-__device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const ParticlesDev &ps, size_t i, const BhtDev &t, const float *grid,
-                                                  float D_inv) {
-  constexpr int NC = SIDE * SIDE * SIDE;
-  float pos[3];
-  load_attr<3>(ps.pos, i, pos);
-  Arena ar;
-  make_arena(mp.dx, pos, ar);
-  int loc[3], key[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    loc[d] = ar.corner[d] & (SIDE - 1);
-    key[d] = (ar.corner[d] - loc[d]) / SIDE * mp.kscale;
-  }
-  int blk[8];
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    const bool need = (!(o & 4) || loc[0] + 2 >= SIDE) && (!(o & 2) || loc[1] + 2 >= SIDE) && (!(o & 1) || loc[2] + 2 >= SIDE);
-    int k[3] = {key[0] + (o >> 2) * mp.kscale, key[1] + ((o >> 1) & 1) * mp.kscale, key[2] + (o & 1) * mp.kscale};
-    blk[o] = need ? bht_query<3>(t, k) : -1;
-  }
-  float vel[3] = {0.f, 0.f, 0.f}, C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int x = loc[0] + a, y = loc[1] + b, z = loc[2] + c;
-        const int o = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
-        int bn = blk[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) bn = (o == q) ? blk[q] : bn;
-        float vi[3] = {0.f, 0.f, 0.f};
-        if (bn >= 0) {
-          const float *g = grid + (size_t)bn * 7 * NC + ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
-          vi[0] = g[1 * NC];
-          vi[1] = g[2 * NC];
-          vi[2] = g[3 * NC];
-        }
-        const float xi[3] = {(float)a * mp.dx - ar.lp[0], (float)b * mp.dx - ar.lp[1], (float)c * mp.dx - ar.lp[2]};
-        float W = ar.w[0][a];
-        W *= ar.w[1][b];
-        W *= ar.w[2][c];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) vel[d] += vi[d] * W;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) C[d] += W * vi[d % 3] * xi[d / 3] * D_inv;
-      }
-  g2p_finish<SIDE, SMODEL>(mp, ps, i, pos, vel, C);
-}
-
-template <int SIDE, int SMODEL>
-__global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ps.n) return;
-  const float dxi = 1.0f / mp.dx;
-  g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
-}
-
-// v = sum W v_i and B = sum W v_i (xi - xp)^T over the 27 register-resident node velocities of the lane's cell, by sum
-// factorisation over z, then y, then x (W = wx wy wz): ~290 VALU ops instead of ~1000 for the node-by-node form of
-// G2P.hpp:54-66 (same sums, different association)
-__device__ __forceinline__ void g2p_gather_factorized(const MpmDev &mp, const Arena &ar, const float (&nv)[27][3], float D_inv,
-                                                      float (&vel)[3], float (&C)[9]) {
-  float xz[3], xy[3], xx[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
-    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
-    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
-  }
-  float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // B[j][k]
-#pragma unroll
-  for (int j = 0; j < 3; ++j) vel[j] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      float s0[3], s1[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float v0 = nv[(a * 3 + bb) * 3 + 0][j], v1 = nv[(a * 3 + bb) * 3 + 1][j], v2 = nv[(a * 3 + bb) * 3 + 2][j];
-        s0[j] = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
-        s1[j] = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
-        t0[j] = fmaf(ar.w[1][bb], s0[j], t0[j]);
-        t1[j] = fmaf(xy[bb], s0[j], t1[j]);
-        t2[j] = fmaf(ar.w[1][bb], s1[j], t2[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      vel[j] = fmaf(ar.w[0][a], t0[j], vel[j]);
-      B[j][0] = fmaf(xx[a], t0[j], B[j][0]);
-      B[j][1] = fmaf(ar.w[0][a], t1[j], B[j][1]);
-      B[j][2] = fmaf(ar.w[0][a], t2[j], B[j][2]);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;  // C[d] += W v_i[d%3] xixp[d/3] D_inv (G2P.hpp:65)
-}
-
-template <int SIDE, int SMODEL, int LW>
-__global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *binStart,
-                                                        const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  __shared__ float arena[3 * AL::CH];
-  const int bin = blockIdx.x;
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;
-  const int lane = threadIdx.x;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  for (int node = lane; node < 216; node += 64) {  // node decoded once for the 3 velocity channels
-    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    const int bn = nbr[(size_t)geo.block * 8 + slot];
-    float *a = arena + AL::at(x, y, z);
-    const float *g = grid + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
-  }
-  __syncthreads();
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  // the 27 x 3 node velocities of this lane's cell, register resident for all its particles (re-reading them from LDS per
-  // particle frees 50 VGPRs but measured 8 % slower)
-  float nv[27][3];
-  {
-    const float *a0 = arena + AL::at(cx, cy, cz);
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-      nv[k][0] = g[0];
-      nv[k][1] = g[AL::CH];
-      nv[k][2] = g[2 * AL::CH];
-    }
-  }
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
-  RoundWalk walk(cnt, start);
-  int i0, i1;
-  bool any, any1;
-  bool has0 = walk.next(i0, any);
-  // x and the deformation state (F, or J for the fluid; the fluid's C is recomputed here, not read)
-  RecB<model_is_fluid(SMODEL) ? MPM_FLUID_NO_STRESS : ZS_MPM_FIXED_COROTATED, LW> cur, nxt;
-  if (has0) cur.load(ps, (size_t)i0);
-  while (any) {
-    const bool has1 = walk.next(i1, any1);
-    if (has1) nxt.load(ps, (size_t)i1);
-    if (has0) {
-      Arena ar;
-      make_arena(mp.dx, cur.pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-        stale[atomicAdd(staleCount, 1)] = i0;
-      } else {
-        float vel[3], C[9];
-        g2p_gather_factorized(mp, ar, nv, D_inv, vel, C);
-        g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
-      }
-    }
-    cur = nxt;
-    has0 = has1;
-    i0 = i1;
-    any = any1;
-  }
-}
-
-template <int SIDE, int SMODEL>
-__global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *stale,
-                                                        const int *staleCount) {
-  const int n = *staleCount;
-  const float dxi = 1.0f / mp.dx;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    g2p_gather_global<SIDE, SMODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
-}
-
-// ======================================================================================= G2P2G (fused)
-// G2P of step n and P2G of step n+1 in ONE pass over the particles (the reference has the same idea as G2P2GTransfer,
-// simulation/transfer/G2P2G.hpp): a particle is read once (m, x, F, logJp: 56 B), gathered from grid A, advected, its F and
-// constitutive model updated, and scattered straight into grid B; only x, F, logJp go back to HBM (52 B).  v, C and
-// P F^T vol never leave the chip (WRITE_ALL stores them for callers that want the full state).  Unfused, the same work
-// moves 296.5 B per particle and step.
-//
-// One workgroup of four waves owns a bin; lane = cell.  Per chunk of four rounds:
-//   phase 1   wave w runs round 4c + w through G2P (node velocities read from the LDS arena) + F update + constitutive model
-//             and stages {m, x', v', C', P F^T} of its 64 particles in LDS;
-//   phase 2   waves 0/1 accumulate mass + momentum (4 channels, 108 register accumulators) of staged rounds {0,1} / {2,3},
-//             waves 2/3 the three stress channels of the same rounds; two LDS arenas collect the two halves.
-// The kernel is VALU-bound (SQ_INSTS_VALU x 4 cycles ~ 85 % of the SIMD cycles), so the design minimises instructions: the
-// first version kept the 81 node velocities in registers and used the four channel roles of p2g_binned_split_kernel in
-// phase 2 (each staged round consumed by 4 waves: 4x the arena / weight work) and took 5.0 ms per 67.1 M-particle step.
-// Particles that are not in the cell they are stored under are exact as before: mis-binned at read -> queue G (global
-// gather + global scatter afterwards); moved out of the cell by this step's advection -> queue P (state stored, global
-// scatter afterwards).
-constexpr int G2P2G_NF = 25;
-constexpr int G2P2G_MQ_CAP = 512;  // in-bin movers a workgroup can take through its LDS queue (a bin holds ~512 particles)  // staged floats per particle: m, x(3), v(3), C(9), P F^T vol(9)
-
-// gather of g2p_gather_factorized with the node velocities read from the LDS arena (81 ds_read per particle; the fused
-// kernel is VALU-bound and needs the 81 VGPRs a register-resident copy would cost for its P2G stencil)
-__device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar, const float *a0, float D_inv, float (&vel)[3],
-                                               float (&C)[9]) {
-  using AL = ArenaLds;
-  float xz[3], xy[3], xx[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
-    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
-    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
-  }
-  float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-#pragma unroll
-  for (int j = 0; j < 3; ++j) vel[j] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      const float *g = a0 + AL::at(a, bb, 0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float v0 = g[j * AL::CH], v1 = g[j * AL::CH + 1], v2 = g[j * AL::CH + 2];
-        const float s0 = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
-        const float s1 = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
-        t0[j] = fmaf(ar.w[1][bb], s0, t0[j]);
-        t1[j] = fmaf(xy[bb], s0, t1[j]);
-        t2[j] = fmaf(ar.w[1][bb], s1, t2[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      vel[j] = fmaf(ar.w[0][a], t0[j], vel[j]);
-      B[j][0] = fmaf(xx[a], t0[j], B[j][0]);
-      B[j][1] = fmaf(ar.w[0][a], t1[j], B[j][1]);
-      B[j][2] = fmaf(ar.w[0][a], t2[j], B[j][2]);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;
-}
-
-// phase-2 consumer of one staged record.  STRESS = false: mass + momentum (4 channels), true: rhs (3 channels)
-template <bool STRESS>
-__device__ __forceinline__ void g2p2g_consume(const MpmDev &mp, const float *st, int lane, float kscale, float (&acc)[27][STRESS ? 3 : 4]) {
-  auto f = [&](int k) { return st[k * 64 + lane]; };
-  const float pos[3] = {f(1), f(2), f(3)};
-  Arena ar;
-  make_arena(mp.dx, pos, ar);
-  float xo[3][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
-  float Px[3][3], Py[3][3], Pz[3][3], wzs[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float c0 = STRESS ? f(16 + d) : f(7 + d), c1 = STRESS ? f(19 + d) : f(10 + d), c2 = STRESS ? f(22 + d) : f(13 + d);
-    const float v = STRESS ? 0.f : f(4 + d);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      Px[k][d] = c0 * xo[0][k];
-      Py[k][d] = c1 * xo[1][k];
-      Pz[k][d] = STRESS ? c2 * xo[2][k] : fmaf(c2, xo[2][k], v);
-    }
-  }
-  const float scale = STRESS ? kscale : f(0);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      const float wxy = ar.w[0][a] * ar.w[1][bb];
-      const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float Ws = wxy * wzs[c];
-        auto &A = acc[(a * 3 + bb) * 3 + c];
-        if constexpr (!STRESS) {
-          A[0] += Ws;
-          A[1] = fmaf(Ws, q0 + Pz[c][0], A[1]);
-          A[2] = fmaf(Ws, q1 + Pz[c][1], A[2]);
-          A[3] = fmaf(Ws, q2 + Pz[c][2], A[3]);
-        } else {
-          A[0] = fmaf(Ws, q0 + Pz[c][0], A[0]);
-          A[1] = fmaf(Ws, q1 + Pz[c][1], A[1]);
-          A[2] = fmaf(Ws, q2 + Pz[c][2], A[2]);
-        }
-      }
-    }
-}
-
-template <int LW, bool DP, bool FLUID = false> struct RecG {  // fused-step inputs: m, x, F or J (, logJp)
-  float pos[3], F[9], m, logJp;
-  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
-    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    pload<LW, 3>(ps.pos, o, pos);
-    pload_state<LW, FLUID>(ps.F, o, F);
-    m = pload1<LW>(ps.mass, o);
-    if constexpr (DP) logJp = pload1<LW>(ps.logJp, o);
-  }
-};
-
-// W = wave index: phase 1 handles round 4c + W; phase 2 role: waves 0/1 take mass + momentum of staged rounds {0,1} / {2,3},
-// waves 2/3 the stress channels of rounds {0,1} / {2,3}; waves 0,2 accumulate into arena 0, waves 1,3 into arena 1
-template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W>
-__device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
-                                           int lane, const float *varena, float *parena, float *stage, unsigned long long *smask,
-                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount, int *mq, int *mqCount) {
-  using AL = ArenaLds;
-  constexpr bool DP = model_uses_logjp(SMODEL);
-  constexpr bool STRESS = W >= 2;
-  constexpr int NCH = STRESS ? 3 : 4;
-  constexpr int R0 = (W & 1) * 2;  // first of this wave's two staged rounds in phase 2
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
-  const float kscale = -mp.dt * D_inv;
-  const float *v0 = varena + AL::at(cx, cy, cz);
-  float acc[27][NCH];
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) acc[k][q] = 0.f;
-  RoundWalk walk(cnt, start);
-  auto next_chunk = [&](int &idx, bool &has, bool &any) {
-    any = false;
-    has = false;
-    idx = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int i;
-      bool a;
-      const bool h = walk.next(i, a);
-      if (r == 0) any = a;
-      if (r == W) {
-        idx = i;
-        has = h;
-      }
-    }
-  };
-  int i0, i1;
-  bool has0, has1, any, any1;
-  next_chunk(i0, has0, any);
-  RecG<LW, DP, model_is_fluid(SMODEL)> cur, nxt;
-  if (has0) cur.load(ps, (size_t)i0);
-  int par = 0;  // stage / mask buffer of this chunk (double buffered: ONE barrier per chunk)
-  while (any) {
-    float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
-    next_chunk(i1, has1, any1);
-    if (has1) nxt.load(ps, (size_t)i1);  // in flight during this chunk
-    // ---------------- phase 1: G2P + update of this wave's round
-    bool valid = false;
-    if (has0) {
-      Arena ar;
-      make_arena(mp.dx, cur.pos, ar);
-      // the particle's cell relative to the bin.  Anywhere inside the bin the node velocities are in the LDS arena, so a
-      // particle that has wandered into a neighbouring cell of the same bin is still gathered here; only one that is outside
-      // the bin altogether takes the exact path (hash queries into grid A)
-      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
-      if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
-        staleG[atomicAdd(staleGCount, 1)] = i0;  // outside the bin: exact gather + scatter afterwards
-        // drift guard of the split launch: the exact path of an interior block may only reach blocks within two of its own
-        if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
-      } else {
-        float vel[3], C[9];
-        g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
-        const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
-        float pos[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
-        float F[9], PF[9];
-        advance_state<model_is_fluid(SMODEL)>(cur.F, C, mp.dt, F);
-        pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
-        pstore<LW, 3>(ps.pos, o, pos);
-        {  // F has been stored above: the plastic models may project this local copy
-          float lj = 0.f;
-          if constexpr (DP) lj = cur.logJp;
-          model_stress<SMODEL>(mp.mat, lj, F, PF, C);
-          if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
-        }
-        // where is it now?  same cell as this lane: register accumulation (phase 2).  Another cell of the same bin: queued in
-        // LDS and scattered into the bin's arena by the dense post-pass of the kernel.  Outside the bin: exact path.
-        const int ncx = (int)floorf(pos[0] * dxi - 0.5f) - geo.org[0], ncy = (int)floorf(pos[1] * dxi - 0.5f) - geo.org[1],
-                  ncz = (int)floorf(pos[2] * dxi - 0.5f) - geo.org[2];
-        const bool moved = ncx != cx || ncy != cy || ncz != cz;
-        if (WRITE_ALL || moved) {
-          pstore<LW, 3>(ps.vel, o, vel);
-          pstore<LW, 9>(ps.C, o, C);
-          pstore<LW, 9>(ps.stress, o, PF);
-        }
-        if (moved) {
-          bool queued = false;
-          if ((unsigned)ncx < 4u && (unsigned)ncy < 4u && (unsigned)ncz < 4u) {
-            const int slot = atomicAdd(mqCount, 1);
-            if (slot < G2P2G_MQ_CAP) {
-              mq[slot] = i0;
-              queued = true;
-            }
-          }
-          if (!queued) {
-            staleP[atomicAdd(stalePCount, 1)] = i0;  // left the bin during this step: exact scatter afterwards
-            if ((unsigned)(ncx + 4) >= 12u || (unsigned)(ncy + 4) >= 12u || (unsigned)(ncz + 4) >= 12u) staleGCount[8] = 1;
-          }
-        } else {
-          valid = true;
-          myStage[0 * 64 + lane] = cur.m;
-#pragma unroll
-          for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = pos[d];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
-#pragma unroll
-          for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
-#pragma unroll
-          for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
-        }
-      }
-    }
-    {
-      const unsigned long long vm = __ballot(valid);
-      if (lane == 0) smask[par * 4 + W] = vm;
-    }
-    __syncthreads();  // this chunk is staged; everybody has finished consuming the chunk before the previous one
-    // ---------------- phase 2: two staged rounds per wave, 4 (mass + momentum) or 3 (stress) channels
-#pragma unroll 1
-    for (int rr = R0; rr < R0 + 2; ++rr) {
-      const unsigned long long vm = smask[par * 4 + rr];
-      if (vm == 0ull) continue;
-      if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
-    }
-    par ^= 1;
-    cur = nxt;
-    has0 = has1;
-    i0 = i1;
-    any = any1;
-  }
-  float *a0 = parena + (size_t)(W & 1) * (7 * AL::CH) + AL::at(cx, cy, cz);
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) g[((STRESS ? 4 : 0) + q) * AL::CH] += acc[k][q];
-    __syncthreads();
-  }
-}
-
-template <int SIDE, int SMODEL, int LW, bool WRITE_ALL>
-__global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
-                                                           const int *binStart, const unsigned *cellCount, const int *nbr, int *staleG,
-                                                           int *staleGCount, int *staleP, int *stalePCount, int binBase) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  __shared__ float varena[3 * AL::CH];
-  __shared__ float parena[2 * 7 * AL::CH];
-  __shared__ float stage[2 * 4 * G2P2G_NF * 64];
-  __shared__ unsigned long long smask[2 * 4];
-  __shared__ int mq[G2P2G_MQ_CAP];
-  __shared__ int mqCount;
-  if (threadIdx.x == 0) mqCount = 0;
-  const int bin = blockIdx.x + binBase;  // a launch covers a range of blocks (boundary blocks first, see zs_rocm_mpm_g2p2g_range)
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  if (tid < 216) {  // node decoded once for the 3 velocity channels
-    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    const int bn = nbr[(size_t)geo.block * 8 + slot];
-    float *a = varena + AL::at(x, y, z);
-    const float *g = gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
-  }
-  for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  __syncthreads();
-  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  // dense post-pass over the particles that changed cell inside this bin: one thread per particle, contributions added to the
-  // bin's arena with LDS atomics (the register stencils of the lanes are keyed to cells).  Their state was stored by other
-  // lanes of this workgroup a moment ago: read it at agent scope so that a stale L1 line (x was loaded in phase 1) cannot serve it.
-  {
-    const int nm = mqCount < G2P2G_MQ_CAP ? mqCount : G2P2G_MQ_CAP;  // the body ended with a barrier
-    const float dxi = 1.0f / mp.dx;
-    const float kscale = -mp.dt * (4.f * dxi * dxi);
-    for (int q = tid; q < nm; q += 256) {
-      const size_t i = (size_t)mq[q];
-      auto cload = [&](const Port<float> &p, int comp) {
-        return __hip_atomic_load(p.base + p.off(i) + (size_t)comp * p.cstride(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      };
-      const float m = ps.mass.base[ps.mass.off(i)];
-      float pos[3], vel[3], C[9], PF[9];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { pos[d] = cload(ps.pos, d); vel[d] = cload(ps.vel, d); }
-#pragma unroll
-      for (int d = 0; d < 9; ++d) { C[d] = cload(ps.C, d); PF[d] = cload(ps.stress, d) * kscale; }
-      Arena ar;
-      make_arena(mp.dx, pos, ar);
-      const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
-      if ((unsigned)kx >= 4u || (unsigned)ky >= 4u || (unsigned)kz >= 4u) {
-        // the queueing test rounds pos * (1/dx) - 0.5 in one step, make_arena in two: on an exact cell face they can disagree
-        staleP[atomicAdd(stalePCount, 1)] = (int)i;
-        continue;
-      }
-      float *a0 = parena + AL::at(kx, ky, kz);
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
-            const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
-            float *g = a0 + AL::at(a, b, c);
-            atomicAdd(g, W * m);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              atomicAdd(g + (1 + d) * AL::CH, W * m * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
-              atomicAdd(g + (4 + d) * AL::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
-            }
-          }
-    }
-    __syncthreads();
-  }
-  if (tid < 216) {
-    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    const int bn = nbr[(size_t)geo.block * 8 + slot];
-    if (bn >= 0) {
-      const float *a = parena + AL::at(x, y, z);
-      float *g = gridB + (size_t)bn * 7 * NC + cell;
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        const float v = a[ch * AL::CH] + a[(7 + ch) * AL::CH];
-        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
-      }
-    }
-  }
-}
-// queue G: gather from grid A with hash queries (stores the full state), then scatter to grid B; queue P: scatter only
-template <int SIDE, int SMODEL>
-__global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
-                                                          const int *staleG, const int *staleGCount, const int *staleP,
-                                                          const int *stalePCount, int *driftFlag) {
-  const int ng = *staleGCount, np = *stalePCount;
-  if (driftFlag && blockIdx.x == 0 && threadIdx.x == 0) {  // status words for the host: [0] drift flag, [1] exact-path particles
-    if (staleGCount[8]) driftFlag[0] = 1;
-    atomicAdd(&driftFlag[1], ng + np);
-  }
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ng + np; j += gridDim.x * blockDim.x) {
-    const size_t i = (size_t)(j < ng ? staleG[j] : staleP[j - ng]);
-    if (j < ng) g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, gridA, D_inv);
-    p2g_scatter_global<SIDE, MPM_CACHED_STRESS>(mp, ps, i, t, gridB, D_inv);
-  }
-}
-
-// stand-alone constitutive update (first step, or after the host changed F / logJp)
-template <int SMODEL> __global__ __launch_bounds__(256) void update_stress_kernel(MpmDev mp, ParticlesDev ps) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ps.n) return;
-  float F[9], C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  load_state<model_is_fluid(SMODEL)>(ps.F, i, F);
-  if constexpr (model_is_fluid(SMODEL)) load_attr<9>(ps.C, i, C);
-  update_stress<SMODEL, 0>(mp, ps, particle_offset<0>(0u, i), F, C);
-}
-
-// ======================================================================================= misc kernels
-template <int MODEL> __global__ void stress_kernel(MpmDev mp, float *F, float *logJp, size_t n, float *PF) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float f[9], pf[9];
-#pragma unroll
-  for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
-  float lj = 0.f;
-  if constexpr (model_uses_logjp(MODEL)) lj = logJp[i];
-  const float C0[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the fluid's viscous part needs C: zero through this entry
-  model_stress<MODEL, true>(mp.mat, lj, f, pf, C0);
-  if constexpr (model_uses_logjp(MODEL)) logJp[i] = lj;
-  if constexpr (MODEL != ZS_MPM_FIXED_COROTATED) {  // the plastic models return the projected F
-#pragma unroll
-    for (int d = 0; d < 9; ++d) F[9 * i + d] = f[d];
-  }
-#pragma unroll
-  for (int d = 0; d < 9; ++d) PF[9 * i + d] = pf[d];
-}
-__global__ void svd_kernel(const float *F, size_t n, float *U, float *S, float *V) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float f[9], u[9], s[3], v[9];
-#pragma unroll
-  for (int d = 0; d < 9; ++d) f[d] = F[9 * i + d];
-  svd3(f, u, s, v);
-#pragma unroll
-  for (int d = 0; d < 9; ++d) {
-    U[9 * i + d] = u[d];
-    V[9 * i + d] = v[d];
-  }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) S[3 * i + d] = s[d];
-}
-// owner rank of every particle under the block-aligned box split of zpc_amd/dist.py (cell_box): cell = floor(x / dx) clamped to
-// the global box; along axis d the box [lo, hi) is cut at lo + (n k / dims) rounded down to a multiple of `align`
-struct OwnerSplit {
-  int lo[3], hi[3], dims[3], align;
-};
-__global__ __launch_bounds__(256) void owner_rank_kernel(Port<float> pos, size_t n, float dxinv, OwnerSplit sp, int *owner) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float p[3];
-  load_attr<3>(pos, i, p);
-  int rc[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    int c = (int)floorf(p[d] * dxinv);
-    c = c < sp.lo[d] ? sp.lo[d] : (c >= sp.hi[d] ? sp.hi[d] - 1 : c);
-    const int len = sp.hi[d] - sp.lo[d];
-    int r = 0;
-    for (int k = 1; k < sp.dims[d]; ++k) {
-      int cut = sp.lo[d] + (int)(((long long)len * k) / sp.dims[d]);
-      cut = floordiv(cut, sp.align) * sp.align;
-      r += c >= cut;
-    }
-    rc[d] = r;
-  }
-  owner[i] = (rc[0] * sp.dims[1] + rc[1]) * sp.dims[2] + rc[2];
-}
-__global__ void halo_pack_kernel(const float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, float *buf) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per = (size_t)nchn * nc;
-  if (g >= nb * per) return;
-  const size_t i = g / per, r = g % per;
-  buf[g] = grid[((size_t)blocks[i] * 7 + chn0) * nc + r];
-}
-// MODE 0: set, 1: add (each block appears once in `blocks`), 2: atomic add (the list may name a block several times, e.g. the
-// concatenated messages of several peers that all share a corner block)
-template <int MODE> __global__ void halo_unpack_kernel(float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, const float *buf) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per = (size_t)nchn * nc;
-  if (g >= nb * per) return;
-  const size_t i = g / per, r = g % per;
-  float *dst = grid + ((size_t)blocks[i] * 7 + chn0) * nc + r;
-  if constexpr (MODE == 2) unsafeAtomicAdd(dst, buf[g]);
-  else if constexpr (MODE == 1) *dst += buf[g];
-  else *dst = buf[g];
-}
-
-// ======================================================================================= host helpers
-// exact-path kernels: grid-stride over a device-side count.  The walk of one particle is a chain of 27 dependent hash
-// queries, so the kernel is latency-bound and wants every wave slot of the chip: 8 blocks of 256 per CU (with 256 blocks a
-// queue of 640 k particles took 0.37 ms, i.e. half of an 8 M-particle step)
-constexpr unsigned STALE_BLOCKS = 2048;
-static MpmDev make_dev(const zs_rocm_mpm_params *p) {
-  MpmDev d;
-  d.model = p->model;
-  d.dx = p->dx;
-  d.dt = p->dt;
-  d.mat.volume = p->volume;
-  d.mat.mu = (float)(0.5 * p->E / (1 + p->nu));  // lame_parameters (physics/ConstitutiveModel.hpp:34-38)
-  d.mat.lam = (float)(p->E * p->nu / ((1 + p->nu) * (1 - 2 * p->nu)));
-  d.mat.cohesion = p->cohesion;
-  d.mat.beta = p->beta;
-  d.mat.yieldSurface = p->yieldSurface;
-  d.mat.volCorrection = p->volCorrection;
-  d.mat.yieldStress = p->yieldStress;
-  // NACCConfig::bulk() (physics/ConstitutiveModel.hpp:767-769), float arithmetic as written there
-  d.mat.bm = 2.f / 3.f * (p->E / (2 * (1 + p->nu))) + (p->E * p->nu / ((1 + p->nu) * (1 - 2 * p->nu)));
-  d.mat.xi = p->xi;
-  d.mat.Msqr = p->Msqr;
-  d.mat.hardeningOn = p->hardeningOn;
-  d.mat.bulk = p->bulk;
-  d.mat.viscosity = p->viscosity;
-  d.kscale = p->keyIsOrigin ? p->side : 1;
-  return d;
-}
-static ParticlesDev make_particles(const zs_rocm_particles &p) {
-  ParticlesDev d;
-  d.mass = make_port<float>(p.mass);
-  d.pos = make_port<float>(p.pos);
-  d.vel = make_port<float>(p.vel);
-  d.C = make_port<float>(p.C);
-  d.F = make_port<float>(p.F);
-  d.logJp = make_port<float>(p.logJp);
-  d.stress = make_port<float>(p.stress);
-  d.n = p.n;
-  return d;
-}
-
-// lane width LW of the fast addressing path (64 or 32) when all used attributes share one TileVector layout, else 0
-static int uniform_lane_width(const zs_rocm_particles &p, bool useLogJp, bool useStress) {
-  const zs_rocm_attr *a[7] = {&p.mass, &p.pos, &p.vel, &p.C, &p.F, useLogJp ? &p.logJp : nullptr, useStress ? &p.stress : nullptr};
-  const zs_rocm_attr &r = p.pos;
-  if (r.tileMask != 63u && r.tileMask != 31u) return 0;
-  for (auto *q : a) {
-    if (!q) continue;
-    if (!q->base || q->idx != 0 || q->numTileBits != r.numTileBits || q->tileMask != r.tileMask || q->numChns != r.numChns) return 0;
-  }
-  if ((1u << r.numTileBits) != r.tileMask + 1u) return 0;
-  return (int)r.tileMask + 1;
-}
-#define ZSR_DISPATCH_LW(lw, CALL, S, M)          \
-  do {                                           \
-    if ((lw) == 64) { CALL(S, M, 64); }          \
-    else if ((lw) == 32) { CALL(S, M, 32); }     \
-    else { CALL(S, M, 0); }                      \
-  } while (0)
-
-// CALL(SIDE, MODEL) for the runtime (side, model); `other` = the template value for anything that is not one of the four
-// constitutive models (MPM_CACHED_STRESS for P2G, -1 = "no constitutive update" for G2P)
-#define ZSR_DISPATCH_MODEL_(S, model, other, CALL)                                                        \
-  switch (model) {                                                                                        \
-    case ZS_MPM_FIXED_COROTATED: { CALL(S, ZS_MPM_FIXED_COROTATED); } break;                              \
-    case ZS_MPM_DRUCKER_PRAGER: { CALL(S, ZS_MPM_DRUCKER_PRAGER); } break;                                \
-    case ZS_MPM_VONMISES_FIXED_COROTATED: { CALL(S, ZS_MPM_VONMISES_FIXED_COROTATED); } break;            \
-    case ZS_MPM_NACC: { CALL(S, ZS_MPM_NACC); } break;                                                    \
-    case ZS_MPM_EQUATION_OF_STATE: { CALL(S, ZS_MPM_EQUATION_OF_STATE); } break;                          \
-    case MPM_FLUID_NO_STRESS: { CALL(S, MPM_FLUID_NO_STRESS); } break;                                    \
-    default: { CALL(S, other); } break;                                                                   \
-  }
-#define ZSR_DISPATCH_SIDE_MODEL(side, model, CALL)                          \
-  do {                                                                      \
-    if ((side) == 4) { ZSR_DISPATCH_MODEL_(4, model, MPM_CACHED_STRESS, CALL) } \
-    else { ZSR_DISPATCH_MODEL_(8, model, MPM_CACHED_STRESS, CALL) }         \
-  } while (0)
-// G2P: third argument = stress model to evaluate at the end (-1: none)
-#define ZSR_DISPATCH_SIDE_SMODEL(side, smodel, CALL)                        \
-  do {                                                                      \
-    if ((side) == 4) { ZSR_DISPATCH_MODEL_(4, smodel, -1, CALL) }           \
-    else { ZSR_DISPATCH_MODEL_(8, smodel, -1, CALL) }                       \
-  } while (0)
-
-}  // namespace zsr
+// mpm.hip -- partition, index buckets, binning, grid update, constitutive test entries, owner classification, halo pack/unpack (see mpm_device.hpp for the kernels)
+#include "mpm_device.hpp"
 
 using namespace zsr;
 
 extern "C" {
+
 
 void zs_rocm_mpm_compute_sparsity(zs_rocm_policy *pol, zs_rocm_bht_3 *tab, zs_rocm_attr pos, size_t n, float dx, int side,
                                   int keyIsOrigin) {
@@ -2391,56 +126,6 @@ void zs_rocm_mpm_bin_particles(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, zs
   if (herr) fprintf(stderr, "[zs_rocm] bin_particles: particles outside the partition were dropped from the bins\n");
 }
 
-void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, float *grid,
-                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
-  Launch L(pol, "P2GTransfer");
-  if (!ps.n) return;
-  MpmDev mp = make_dev(p);
-  ParticlesDev pd = make_particles(ps);
-  BhtDev t = tab->t.dev();
-  const int kmodel = ps.stress.base ? MPM_CACHED_STRESS : p->model;  // cached P F^T vol (see zs_rocm_mpm_g2p) or recompute
-  if (binStart && cellCount && nbr) {
-    if (!nblocks) return;
-    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
-    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
-    int *staleCount = stale + ps.n + 32;
-    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
-    // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
-    static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
-    if (kmodel == MPM_CACHED_STRESS && !split4) {
-#define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
-  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, \
-                     staleCount);                                                                                                      \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
-      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
-      else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
-      return;
-    }
-    if (kmodel == MPM_CACHED_STRESS) {
-#define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
-  hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
-                     stale, staleCount);                                                                                               \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
-      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 4, 0);
-      else ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 8, 0);
-      return;
-    }
-#define CALL_P2G_BINNED3(S, M, LWv)                                                                                                  \
-  hipLaunchKernelGGL((p2g_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
-                     stale, staleCount);                                                                                             \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
-                     (const int *)staleCount)
-#define CALL_P2G_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_P2G_BINNED3, S, M)
-    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_BINNED);  // kmodel is one of the four models here
-  } else {
-#define CALL_P2G_GLOBAL(S, M) \
-  hipLaunchKernelGGL((p2g_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
-    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_GLOBAL);
-  }
-}
 
 void zs_rocm_mpm_grid_update(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *grid, size_t nblocks, const float extf[3],
                              float *maxVelSqr) {
@@ -2455,84 +140,7 @@ void zs_rocm_mpm_grid_update(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, f
                        extf[1], extf[2], maxVelSqr);
 }
 
-void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *grid,
-                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
-  Launch L(pol, "G2PTransfer");
-  if (!ps.n) return;
-  MpmDev mp = make_dev(p);
-  ParticlesDev pd = make_particles(ps);
-  BhtDev t = tab->t.dev();
-  // also evaluate the constitutive model for the next P2G when the particles carry `stress`; otherwise only tell the
-  // kernels whether the deformation state is F or J
-  const int smodel = ps.stress.base ? p->model : (p->model == ZS_MPM_EQUATION_OF_STATE ? MPM_FLUID_NO_STRESS : -1);
-  if (binStart && cellCount && nbr) {
-    if (!nblocks) return;
-    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
-    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
-    int *staleCount = stale + ps.n + 32;
-    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
-    const int lw = uniform_lane_width(ps, model_uses_logjp(smodel), smodel >= 0);  // (-2 / -1: no stress attribute needed)
-#define CALL_G2P_BINNED3(S, M, LWv)                                                                                                  \
-  hipLaunchKernelGGL((g2p_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
-                     stale, staleCount);                                                                                             \
-  hipLaunchKernelGGL((g2p_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
-                     (const int *)staleCount)
-#define CALL_G2P_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P_BINNED3, S, M)
-    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_BINNED);
-  } else {
-#define CALL_G2P_GLOBAL(S, M) \
-  hipLaunchKernelGGL((g2p_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
-    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_GLOBAL);
-  }
-}
 
-// G2P (from gridA) + P2G (into gridB, zeroed by the caller) in one pass; `particles.stress` must be present (it carries the
-// state of the particles that take the exact path).  writeAll != 0 also stores v, C and P F^T vol of every particle.
-// blocks [blockBegin, blockEnd) only.  Multi-GPU step (bench.py): the partition is numbered with the blocks near a rank boundary
-// first; their range is launched first, its ghost-block sums travel on a second stream while the interior range computes.
-// An interior block's exact-path particles must not reach a shared block: *driftFlag is set to 1 when a particle handled
-// by the exact path sits more than one bin away from the bin it is stored in (re-bin more often then).
-int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
-                            float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll,
-                            size_t blockBegin, size_t blockEnd, int *driftFlag) {
-  if (!ps.n || !nblocks) return 0;
-  if (!ps.stress.base || !binStart || !cellCount || !nbr) {
-    fprintf(stderr, "[zs_rocm] g2p2g needs binned particles and the `stress` attribute\n");
-    return -1;
-  }
-  if (blockEnd > nblocks) blockEnd = nblocks;
-  if (blockBegin >= blockEnd) return 0;
-  Launch L(pol, "G2P2GTransfer");
-  MpmDev mp = make_dev(p);
-  ParticlesDev pd = make_particles(ps);
-  BhtDev t = tab->t.dev();
-  const unsigned bpb = p->side == 4 ? 1u : 8u;
-  const unsigned nbins = (unsigned)((blockEnd - blockBegin) * bpb);
-  const int binBase = (int)(blockBegin * bpb);
-  int *staleG = (int *)L.temp(sizeof(int) * (ps.n + 64));
-  int *staleP = (int *)L.temp(sizeof(int) * (ps.n + 64));
-  int *counts = (int *)L.temp(sizeof(int) * 64);
-  ZSR_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 64, L.stream));
-  const int lw = uniform_lane_width(ps, model_uses_logjp(p->model), true);
-#define CALL_G2P2G4(S, M, LWv, WA)                                                                                                    \
-  hipLaunchKernelGGL((g2p2g_binned_kernel<S, M, LWv, WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, binStart,     \
-                     cellCount, nbr, staleG, counts, staleP, counts + 32, binBase);                                                   \
-  hipLaunchKernelGGL((g2p2g_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, gridA, gridB, (const int *)staleG,      \
-                     (const int *)counts, (const int *)staleP, (const int *)(counts + 32), driftFlag)
-#define CALL_G2P2G3(S, M, LWv)          \
-  do {                                  \
-    if (writeAll) { CALL_G2P2G4(S, M, LWv, true); } \
-    else { CALL_G2P2G4(S, M, LWv, false); }         \
-  } while (0)
-#define CALL_G2P2G(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P2G3, S, M)
-  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
-  ZSR_DISPATCH_SIDE_MODEL(p->side, p->model, CALL_G2P2G);
-  return 0;
-}
-int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
-                      float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll) {
-  return zs_rocm_mpm_g2p2g_range(pol, p, ps, tab, gridA, gridB, nblocks, binStart, cellCount, nbr, writeAll, 0, nblocks, nullptr);
-}
 
 void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {
   Launch L(pol, "update_stress");
@@ -2541,7 +149,7 @@ void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p,
   ParticlesDev pd = make_particles(ps);
 #define CALL_UPDATE_STRESS(S, M) hipLaunchKernelGGL((update_stress_kernel<M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd)
   if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return;
-  ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_UPDATE_STRESS)
+  ZSR_DISPATCH_PURE_(0, p->model, CALL_UPDATE_STRESS)
 }
 
 void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float *F, float *logJp, size_t n, float *PF) {
@@ -2550,7 +158,7 @@ void zs_rocm_mpm_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, float 
   MpmDev mp = make_dev(p);
 #define CALL_STRESS(S, M) hipLaunchKernelGGL((stress_kernel<M>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, mp, F, logJp, n, PF)
   if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return;
-  ZSR_DISPATCH_MODEL_(0, p->model, ZS_MPM_FIXED_COROTATED, CALL_STRESS)
+  ZSR_DISPATCH_PURE_(0, p->model, CALL_STRESS)
 }
 float zs_rocm_nacc_msqr(float fa) {  // NACCConfig::mohrColumbFriction / M / Msqr, dim = 3 (physics/ConstitutiveModel.hpp:771-785)
   const int dim = 3;
@@ -2595,5 +203,6 @@ void zs_rocm_mpm_halo_unpack(zs_rocm_policy *pol, float *grid, const int *blocks
     hipLaunchKernelGGL((halo_unpack_kernel<0>), dim3(ceil_div(nb * nchn * nc, 256)), dim3(256), 0, L.stream, grid, blocks, nb, nc, chn0,
                        nchn, buf);
 }
+
 
 }  // extern "C"

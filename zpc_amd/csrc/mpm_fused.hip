@@ -1,0 +1,47 @@
+// mpm_fused.hip -- fused G2P2G entry points: zs_rocm_mpm_g2p2g_range / zs_rocm_mpm_g2p2g (see mpm_device.hpp for the kernels)
+#include "mpm_device.hpp"
+
+using namespace zsr;
+
+extern "C" {
+// G2P (from gridA) + P2G (into gridB, zeroed by the caller) in one pass; `particles.stress` must be present (it carries the
+// state of the particles that take the exact path).  writeAll != 0 also stores v, C and P F^T vol of every particle.
+// blocks [blockBegin, blockEnd) only.  Multi-GPU step (bench.py): the partition is numbered with the blocks near a rank boundary
+// first; their range is launched first, its ghost-block sums travel on a second stream while the interior range computes.
+// An interior block's exact-path particles must not reach a shared block: *driftFlag is set to 1 when a particle handled
+// by the exact path sits more than one bin away from the bin it is stored in (re-bin more often then).
+int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                            float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll,
+                            size_t blockBegin, size_t blockEnd, int *driftFlag) {
+  if (!ps.n || !nblocks) return 0;
+  if (!ps.stress.base || !binStart || !cellCount || !nbr) {
+    fprintf(stderr, "[zs_rocm] g2p2g needs binned particles and the `stress` attribute\n");
+    return -1;
+  }
+  if (blockEnd > nblocks) blockEnd = nblocks;
+  if (blockBegin >= blockEnd) return 0;
+  Launch L(pol, "G2P2GTransfer");
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const unsigned bpb = p->side == 4 ? 1u : 8u;
+  const unsigned nbins = (unsigned)((blockEnd - blockBegin) * bpb);
+  const int binBase = (int)(blockBegin * bpb);
+  int *staleG = (int *)L.temp(sizeof(int) * (ps.n + 64));
+  int *staleP = (int *)L.temp(sizeof(int) * (ps.n + 64));
+  int *counts = (int *)L.temp(sizeof(int) * 64);
+  ZSR_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 64, L.stream));
+  const int lw = uniform_lane_width(ps, model_uses_logjp(p->model), true);
+  if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
+  const FusedArgs a{gridA, gridB, binStart, cellCount, nbr, staleG, staleP, counts, driftFlag, nbins, binBase, writeAll, lw, p->model};
+  if (p->side == 4) g2p2g_launch_side<4>(L, mp, pd, t, a);
+  else g2p2g_launch_side<8>(L, mp, pd, t, a);
+  return 0;
+}
+
+int zs_rocm_mpm_g2p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                      float *gridB, size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr, int writeAll) {
+  return zs_rocm_mpm_g2p2g_range(pol, p, ps, tab, gridA, gridB, nblocks, binStart, cellCount, nbr, writeAll, 0, nblocks, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,6 @@
+// mpm_fused8.hip -- the fused G2P2G kernels for 8^3-cell grid blocks (explicit instantiation of g2p2g_launch_side<8>)
+#include "mpm_fused_impl.hpp"
+
+namespace zsr {
+template void g2p2g_launch_side<8>(Launch &, const MpmDev &, const ParticlesDev &, const BhtDev &, const FusedArgs &);
+}

@@ -1,0 +1,22 @@
+// mpm_fused_impl.hpp -- body of g2p2g_launch_side<S> (included by mpm_fused4.hip and mpm_fused8.hip only)
+#pragma once
+#include "mpm_device.hpp"
+
+namespace zsr {
+
+template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const ParticlesDev &pd, const BhtDev &t, const FusedArgs &a) {
+#define CALL_G2P2G4(SS, M, LWv, WA)                                                                                                   \
+  hipLaunchKernelGGL((g2p2g_binned_kernel<SS, M, LWv, WA>), dim3(a.nbins), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,        \
+                     a.binStart, a.cellCount, a.nbr, a.staleG, a.counts, a.staleP, a.counts + 32, a.binBase);                         \
+  hipLaunchKernelGGL((g2p2g_stale_kernel<SS, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,             \
+                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag)
+#define CALL_G2P2G3(SS, M, LWv)                       \
+  do {                                                \
+    if (a.writeAll) { CALL_G2P2G4(SS, M, LWv, true); } \
+    else { CALL_G2P2G4(SS, M, LWv, false); }          \
+  } while (0)
+#define CALL_G2P2G(SS, M) ZSR_DISPATCH_LW(a.lw, CALL_G2P2G3, SS, M)
+  ZSR_DISPATCH_PURE_(S, a.model, CALL_G2P2G)
+}
+
+}  // namespace zsr

@@ -1,0 +1,38 @@
+// mpm_g2p.hip -- G2PTransfer entry point: zs_rocm_mpm_g2p (see mpm_device.hpp for the kernels)
+#include "mpm_device.hpp"
+
+using namespace zsr;
+
+extern "C" {
+void zs_rocm_mpm_g2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *grid,
+                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
+  Launch L(pol, "G2PTransfer");
+  if (!ps.n) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  // also evaluate the constitutive model for the next P2G when the particles carry `stress`; otherwise only tell the
+  // kernels whether the deformation state is F or J
+  const int smodel = ps.stress.base ? p->model : (p->model == ZS_MPM_EQUATION_OF_STATE ? MPM_FLUID_NO_STRESS : -1);
+  if (binStart && cellCount && nbr) {
+    if (!nblocks) return;
+    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
+    int *staleCount = stale + ps.n + 32;
+    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
+    const int lw = uniform_lane_width(ps, model_uses_logjp(smodel), smodel >= 0);  // (-2 / -1: no stress attribute needed)
+#define CALL_G2P_BINNED3(S, M, LWv)                                                                                                  \
+  hipLaunchKernelGGL((g2p_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
+                     stale, staleCount);                                                                                             \
+  hipLaunchKernelGGL((g2p_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
+                     (const int *)staleCount)
+#define CALL_G2P_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_G2P_BINNED3, S, M)
+    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_BINNED);
+  } else {
+#define CALL_G2P_GLOBAL(S, M) \
+  hipLaunchKernelGGL((g2p_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
+    ZSR_DISPATCH_SIDE_SMODEL(p->side, smodel, CALL_G2P_GLOBAL);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// mpm_p2g.hip -- P2GTransfer entry point: zs_rocm_mpm_p2g (see mpm_device.hpp for the kernels)
+#include "mpm_device.hpp"
+
+using namespace zsr;
+
+extern "C" {
+void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, float *grid,
+                     size_t nblocks, const int *binStart, const unsigned *cellCount, const int *nbr) {
+  Launch L(pol, "P2GTransfer");
+  if (!ps.n) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const int kmodel = ps.stress.base ? MPM_CACHED_STRESS : p->model;  // cached P F^T vol (see zs_rocm_mpm_g2p) or recompute
+  if (binStart && cellCount && nbr) {
+    if (!nblocks) return;
+    const unsigned nbins = (unsigned)(nblocks * (p->side == 4 ? 1 : 8));
+    int *stale = (int *)L.temp(sizeof(int) * (ps.n + 64));
+    int *staleCount = stale + ps.n + 32;
+    ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
+    const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
+    // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
+    static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
+    if (kmodel == MPM_CACHED_STRESS && !split4) {
+#define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
+  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, \
+                     staleCount);                                                                                                      \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+                     (const int *)staleCount)
+      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
+      else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
+      return;
+    }
+    if (kmodel == MPM_CACHED_STRESS) {
+#define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
+  hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
+                     stale, staleCount);                                                                                               \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+                     (const int *)staleCount)
+      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 4, 0);
+      else ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 8, 0);
+      return;
+    }
+#define CALL_P2G_BINNED3(S, M, LWv)                                                                                                  \
+  hipLaunchKernelGGL((p2g_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
+                     stale, staleCount);                                                                                             \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,                 \
+                     (const int *)staleCount)
+#define CALL_P2G_BINNED(S, M) ZSR_DISPATCH_LW(lw, CALL_P2G_BINNED3, S, M)
+    ZSR_DISPATCH_SIDE_PURE(p->side, kmodel, CALL_P2G_BINNED);  // kmodel is one of the five models here
+  } else {
+#define CALL_P2G_GLOBAL(S, M) \
+  hipLaunchKernelGGL((p2g_global_kernel<S, M>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, grid)
+    ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_GLOBAL);
+  }
+}
+
+}  // extern "C"
