@@ -1634,6 +1634,9 @@ __device__ __forceinline__ void g2p_gather_factorized(const MpmDev &mp, const Ar
   for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;  // C[d] += W v_i[d%3] xixp[d/3] D_inv (G2P.hpp:65)
 }
 
+__device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar, const float *a0, float D_inv, float (&vel)[3],
+                                               float (&C)[9]);
+
 template <int SIDE, int SMODEL, int LW>
 static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *binStart,
                                                         const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
@@ -1686,12 +1689,18 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
     if (has0) {
       Arena ar;
       make_arena(mp.dx, cur.pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
-        stale[atomicAdd(staleCount, 1)] = i0;
-      } else {
+      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+      if (ocx == cx && ocy == cy && ocz == cz) {
         float vel[3], C[9];
         g2p_gather_factorized(mp, ar, nv, D_inv, vel, C);
         g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
+      } else if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
+        // another cell of the same bin (the particle moved since the last re-bin): its nodes are in the LDS arena
+        float vel[3], C[9];
+        g2p_gather_lds(mp, ar, arena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+        g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
+      } else {
+        stale[atomicAdd(staleCount, 1)] = i0;  // outside the bin: exact path (hash queries)
       }
     }
     cur = nxt;
