@@ -9,7 +9,9 @@ template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const Parti
   hipLaunchKernelGGL((g2p2g_binned_kernel<SS, M, LWv, WA>), dim3(a.nbins), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,        \
                      a.binStart, a.cellCount, a.nbr, a.staleG, a.counts, a.staleP, a.counts + 32, a.binBase);                         \
   hipLaunchKernelGGL((g2p2g_stale_kernel<SS, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,             \
-                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag)
+                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag);  \
+  hipLaunchKernelGGL((stale_scatter_coop_kernel<SS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridB,                  \
+                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32))
 #define CALL_G2P2G3(SS, M, LWv)                       \
   do {                                                \
     if (a.writeAll) { CALL_G2P2G4(SS, M, LWv, true); } \
