@@ -381,9 +381,11 @@ def main():
     done = 0
 
     rebins = 0
+    check_iv = max(a.rebin_check, 1)
+    next_check, last_check = check_iv, 0
 
     def run_steps(count, timed):
-        nonlocal done, rebins
+        nonlocal done, rebins, check_iv, next_check, last_check
         for _ in range(count):
             remap_now = K > 0 and (done + 1) % K == 0
             if a.fused:
@@ -393,13 +395,22 @@ def main():
             done += 1
             if remap_now:
                 remap()
-            elif a.fused and a.rebin_check > 0 and done % a.rebin_check == 0:
-                if mt.exact_path_particles() > a.rebin_threshold * mt.n * a.rebin_check:
+            elif a.fused and a.rebin_check > 0 and done >= next_check:
+                # reading the count synchronises the stream: look less often while hardly anything takes the exact path
+                rate = mt.exact_path_particles() / (max(mt.n, 1) * max(done - last_check, 1))
+                last_check = done
+                if rate > a.rebin_threshold:
                     # particles only (partition, block numbers and halo lists stay), and only the channels the next fused step
                     # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid
                     mt.rebin(inputs_only=True)
                     rebins += 1
                     mt.exact_path_particles()
+                    check_iv = a.rebin_check
+                elif rate < a.rebin_threshold / 8:
+                    check_iv = min(check_iv * 2, 32)
+                else:
+                    check_iv = a.rebin_check
+                next_check = done + check_iv
 
     run_steps(a.warmup, False)
     barrier()
