@@ -1246,7 +1246,8 @@ static __global__ __launch_bounds__(256) void p2g_binned_split_kernel(MpmDev mp,
 // work is done once (~600 VALU per round).  The price is 2 waves per SIMD; the latency the occupancy no longer hides is
 // covered by asynchronous global -> LDS loads (global_load_lds_dword: no staging VGPRs) issued one round ahead into a
 // double-buffered record area of the LDS.
-constexpr int P2GW_NF = 25;  // m, x(3), v(3), C(9), P F^T vol(9)
+constexpr int P2GW_NF = 25;
+constexpr int P2GW_MQ_CAP = 256;  // in-bin movers the wide P2G takes through its LDS queue  // m, x(3), v(3), C(9), P F^T vol(9)
 
 // `tileBase`: wave-uniform element offset of a tile at or before the bin's first particle.  The per-lane part of every address
 // is then a 32-bit byte offset from a scalar base (global_load_lds_dword v_off, s[base:base+1] offset:imm): ONE address VGPR
@@ -1364,10 +1365,14 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
   __shared__ float lds[LDSF];
   float *arena = lds;
   float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds);
+  __shared__ int mq[P2GW_MQ_CAP];  // particles that sit in another cell of this bin (moved since the last re-bin)
+  __shared__ int mqCount;
   const int bin = blockIdx.x;
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int lane = threadIdx.x;
+  if (lane == 0) mqCount = 0;
+  __syncthreads();
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
@@ -1416,10 +1421,21 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
       const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
       Arena ar;
       make_arena(mp.dx, pos, ar);
-      if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz)
-        stale[atomicAdd(staleCount, 1)] = i0;  // exact path afterwards
-      else
+      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+      if (ocx == cx && ocy == cy && ocz == cz) {
         p2gw_accumulate(mp, ar, rec, kscale, acc);
+      } else {
+        // another cell of the same bin: queued for the post-pass into this bin's arena; outside the bin: exact path afterwards
+        bool queued = false;
+        if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
+          const int q = atomicAdd(&mqCount, 1);
+          if (q < P2GW_MQ_CAP) {
+            mq[q] = i0;
+            queued = true;
+          }
+        }
+        if (!queued) stale[atomicAdd(staleCount, 1)] = i0;
+      }
     }
     --issued;
     slot = slot + 1 == NB ? 0 : slot + 1;
@@ -1437,6 +1453,40 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  {  // post-pass: the queued in-bin particles, one lane each, added to the arena with LDS atomics (same values as the exact path)
+    const int nm = mqCount < P2GW_MQ_CAP ? mqCount : P2GW_MQ_CAP;
+    for (int q = lane; q < nm; q += 64) {
+      const size_t i = (size_t)mq[q];
+      float pos[3], vel[3], C[9], PF[9];
+      load_attr<3>(ps.pos, i, pos);
+      load_attr<3>(ps.vel, i, vel);
+      load_attr<9>(ps.C, i, C);
+      load_attr<9>(ps.stress, i, PF);
+      const float m = ps.mass.base[ps.mass.off(i)];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) PF[d] *= kscale;
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      float *b0 = arena + AL::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1], ar.corner[2] - geo.org[2]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
+            const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
+            float *g = b0 + AL::at(a, b, c);
+            atomicAdd(g, W * m);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              atomicAdd(g + (1 + d) * AL::CH, W * m * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
+              atomicAdd(g + (4 + d) * AL::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
+            }
+          }
+    }
+    __syncthreads();
+  }
   for (int node = lane; node < 216; node += 64) {
     const int x = node / 36, y = (node / 6) % 6, z = node % 6;
     int slot2, cell;
