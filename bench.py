@@ -311,7 +311,7 @@ def main():
 
     fused_ev = []
 
-    def step_fused(timed, write_all=False):
+    def step_fused(timed, write_all=False, reorder=False):
         # grid holds the velocities of the current step (after grid_update): G2P from it, P2G of the next step into the
         # second (zeroed) grid, which then becomes the current one
         if timed:
@@ -319,7 +319,7 @@ def main():
             e0.record()
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
-            mt.g2p2g(write_all=write_all, split=n_boundary, between=lambda: ev_boundary.record())
+            mt.g2p2g(write_all=write_all, split=n_boundary, between=lambda: ev_boundary.record(), reorder=reorder)
             if timed:
                 e1.record()
                 fused_ev.append((e0, e1))
@@ -329,7 +329,7 @@ def main():
                 ev_comm.record()
             torch.cuda.current_stream().wait_event(ev_comm)
         else:
-            mt.g2p2g(write_all=write_all)
+            mt.g2p2g(write_all=write_all, reorder=reorder)
             if timed:
                 e1.record()
                 fused_ev.append((e0, e1))
@@ -369,7 +369,7 @@ def main():
             raise SystemExit("--fused needs the binned path with cached stress")
         prime_grid()
         unfused_step = step
-        step = lambda timed, write_all=False: step_fused(timed, write_all)
+        step = lambda timed, write_all=False, reorder=False: step_fused(timed, write_all, reorder)
 
     def barrier():
         torch.cuda.synchronize()
@@ -401,7 +401,8 @@ def main():
                 last_check = done
                 if rate > a.rebin_threshold:
                     # particles only (partition, block numbers and halo lists stay), and only the channels the next fused step
-                    # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid
+                    # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid.  (MpmTransfer.g2p2g(reorder=True)
+                    # folds the re-bin into the step instead; with today's binning order its scattered reads cost as much.)
                     mt.rebin(inputs_only=True)
                     rebins += 1
                     mt.exact_path_particles()

@@ -598,6 +598,16 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *, const zs_rocm_mpm_p
                                            const float *gridA, float *gridB, size_t nblocks, const int *binStart,
                                            const unsigned *cellCount, const int *nbr, int writeAll, size_t blockBegin,
                                            size_t blockEnd, int *driftFlag);
+/* Fused step that re-bins on the fly.  binStart / cellCount describe the NEW binned order (zs_rocm_mpm_bin_particles on the
+ * current positions, `order` = its permutation: slot i holds the particle stored at order[i]); the step's inputs m, x, F, logJp
+ * are read from slot order[i] of particlesIn, everything the step stores (incl. m) goes to slot i of particlesOut.  Both
+ * particle sets must be two buffers of one layout.  The physical re-bin thus costs no pass of its own, and every particle
+ * starts the step in the cell it is binned in. */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_reorder_range(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles particlesOut,
+                                                   zs_rocm_particles particlesIn, const int *order, const zs_rocm_bht_3 *,
+                                                   const float *gridA, float *gridB, size_t nblocks, const int *binStart,
+                                                   const unsigned *cellCount, const int *nbr, int writeAll, size_t blockBegin,
+                                                   size_t blockEnd, int *driftFlag);
 ZS_ROCM_EXPORT void zs_rocm_mpm_update_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
 /* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
  * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */

@@ -463,3 +463,42 @@ def test_inputs_only_rebin_between_fused_steps(pol, oracle, model):
         assert (np.abs(a.sum(0) - b.sum(0)) <= 2e-5 * scale).all(), k
         assert (np.abs((a ** 2).sum(0) - (b ** 2).sum(0)) <= 1e-4 * (a ** 2).sum(0) + 1e-30).all(), k
     _compare_grids(ga, gb, 3e-4)
+
+
+@pytest.mark.parametrize("model,side", [(0, 4), (1, 8), (4, 4)])
+def test_reordering_fused_step_matches_in_place_steps(pol, oracle, model, side):
+    """g2p2g(reorder=True): every step bins the particles anew and carries them into that order (inputs through the
+    permutation from the other buffer).  Six such steps of a fast cloud end in the same particle state (order-independent
+    channel sums) and grid as six in-place fused steps, and put nothing on the exact path that started the step mis-binned."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=151 + model, vel_scale=3.0)
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    lj0 = (0.01 * rng(152).standard_normal(n)).astype(np.float32)
+    state = (1.0 + 0.02 * rng(153).standard_normal(n)).astype(np.float32) if model == 4 else F
+    res = []
+    for reorder in (False, True):
+        mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True, viscosity=0.05)
+        mt.upload(mass, pos, vel, Cm, state, lj0 if model == 1 else None)
+        mt.build_partition(n)
+        mt.rebin()
+        mt.update_stress()
+        mt.clear_grid(); mt.p2g(); mt.grid_update((0.0, -9.8, 0.0))
+        if reorder:
+            mt.buf2 = torch.full_like(mt.buf, float("nan"))  # the step must fill everything it later reads
+        for step in range(6):
+            # the last step materialises v, C, stress for the comparison (a re-ordering step never does)
+            mt.g2p2g(write_all=(step == 5), reorder=reorder and step < 5)
+            mt.grid_update((0.0, -9.8, 0.0))
+        pol.syncCtx()
+        res.append((mt.download(), mt.grid_by_key(), mt.exact_path_particles()))
+    (da, ga, ea), (db, gb, eb) = res
+    assert eb < ea  # in place, the particles that left their bin keep taking the exact path; re-binned every step only the new ones do
+    for k in da:
+        a, b = da[k].reshape(n, -1).astype(np.float64), db[k].reshape(n, -1).astype(np.float64)
+        assert np.isfinite(b).all(), k
+        scale = np.sqrt(n * (a ** 2).sum(0)) + 1e-30
+        assert (np.abs(a.sum(0) - b.sum(0)) <= 2e-5 * scale).all(), k
+        assert (np.abs((a ** 2).sum(0) - (b ** 2).sum(0)) <= 1e-4 * (a ** 2).sum(0) + 1e-30).all(), k
+    _compare_grids(ga, gb, 3e-4)

@@ -295,6 +295,7 @@ def _declare_containers(L):
     L.zs_rocm_mpm_owner_rank.argtypes = [vp, Port, sz, f32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]
     L.zs_rocm_mpm_g2p2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32]
     L.zs_rocm_mpm_g2p2g_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
+    L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]

@@ -732,7 +732,33 @@ static __global__ __launch_bounds__(256) void bin_place_kernel(size_t n, const u
   const unsigned c = cellOf[i];
   if (c != 0xffffffffu) byCell[cellStart[c] + rankOf[i]] = (int)i;
 }
-// one wave per bin, lane = cell: (cell, rank) order -> (rank, cell) order
+// one wave per bin, lane = cell: (cell, rank) order -> (rank, cell) order.  The ranks handed out by the counting pass are in
+// arrival order of its atomics; the lane first sorts its cell's particle ids (odd-even transposition network in registers,
+// K = 8 / 16 / 32 chosen per bin), so that within a cell the particles keep their previous relative order: a particle that
+// did not change cell stays in "its" round, and the permutation of a re-ordering fused step is the identity except around the
+// movers (coalesced reads through `order`).
+template <int K>
+__device__ __forceinline__ void bin_rr_emit(unsigned cnt, unsigned st, const int *byCell, int *order, unsigned &base, unsigned long long lt) {
+  int ids[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) ids[k] = (unsigned)k < cnt ? byCell[st + k] : 0x7fffffff;
+#pragma unroll
+  for (int pass = 0; pass < K; ++pass)
+#pragma unroll
+    for (int k = pass & 1; k + 1 < K; k += 2) {
+      const int a = ids[k], b = ids[k + 1];
+      ids[k] = a < b ? a : b;
+      ids[k + 1] = a < b ? b : a;
+    }
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const bool has = cnt > (unsigned)r;
+    const unsigned long long m = __ballot(has);
+    if (!m) return;
+    if (has) order[base + (unsigned)__popcll(m & lt)] = ids[r];
+    base += (unsigned)__popcll(m);
+  }
+}
 static __global__ __launch_bounds__(64) void bin_roundrobin_kernel(int nbins, const unsigned *cellStart, const unsigned *cellCount,
                                                             const int *byCell, int *order, int *binStart, unsigned total) {
   const int bin = blockIdx.x, c = threadIdx.x;
@@ -743,7 +769,17 @@ static __global__ __launch_bounds__(64) void bin_roundrobin_kernel(int nbins, co
     if (bin == nbins - 1) binStart[nbins] = (int)total;
   }
   const unsigned long long lt = lanemask_lt();
-  for (unsigned r = 0;; ++r) {
+  unsigned mx = cnt;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned o = shfl_down(mx, d);
+    mx = o > mx ? o : mx;
+  }
+  mx = shfl(mx, 0);
+  if (mx <= 8u) bin_rr_emit<8>(cnt, st, byCell, order, base, lt);
+  else if (mx <= 16u) bin_rr_emit<16>(cnt, st, byCell, order, base, lt);
+  else bin_rr_emit<32>(cnt, st, byCell, order, base, lt);
+  for (unsigned r = 32;; ++r) {  // cells with more than 32 particles: the rest in arrival order
     const bool has = cnt > r;
     const unsigned long long m = __ballot(has);
     if (!m) break;
@@ -1886,21 +1922,29 @@ __device__ __forceinline__ void g2p2g_consume(const MpmDev &mp, const float *st,
 
 template <int LW, bool DP, bool FLUID = false> struct RecG {  // fused-step inputs: m, x, F or J (, logJp)
   float pos[3], F[9], m, logJp;
-  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
+  // `delta`: element offset from the (output) attribute arrays of `ps` to the input arrays -- 0 in place; in the re-ordering
+  // step the inputs are read from the other buffer of the same layout at the particle's OLD index
+  __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i, long long delta = 0) {
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-    pload<LW, 3>(ps.pos, o, pos);
-    pload_state<LW, FLUID>(ps.F, o, F);
-    m = pload1<LW>(ps.mass, o);
-    if constexpr (DP) logJp = pload1<LW>(ps.logJp, o);
+    Port<float> pp = ps.pos, pf = ps.F, pm = ps.mass, pl = ps.logJp;
+    pp.base += delta; pf.base += delta; pm.base += delta;
+    pload<LW, 3>(pp, o, pos);
+    pload_state<LW, FLUID>(pf, o, F);
+    m = pload1<LW>(pm, o);
+    if constexpr (DP) {
+      pl.base += delta;
+      logJp = pload1<LW>(pl, o);
+    }
   }
 };
 
 // W = wave index: phase 1 handles round 4c + W; phase 2 role: waves 0/1 take mass + momentum of staged rounds {0,1} / {2,3},
 // waves 2/3 the stress channels of rounds {0,1} / {2,3}; waves 0,2 accumulate into arena 0, waves 1,3 into arena 1
-template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W>
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W, bool REORDER>
 __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
                                            int lane, const float *varena, float *parena, float *stage, unsigned long long *smask,
-                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount, int *mq, int *mqCount) {
+                                           int *staleG, int *staleGCount, int *staleP, int *stalePCount, int *mq, int *mqCount,
+                                           const int *order, long long inDelta) {
   using AL = ArenaLds;
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool STRESS = W >= 2;
@@ -1937,12 +1981,14 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
   bool has0, has1, any, any1;
   next_chunk(i0, has0, any);
   RecG<LW, DP, model_is_fluid(SMODEL)> cur, nxt;
-  if (has0) cur.load(ps, (size_t)i0);
+  // re-ordering step (order != nullptr): slot i of the (new) binned order holds the particle stored at order[i] of the input
+  // buffer; everything this kernel stores goes to slot i of the output buffer, so the physical re-bin costs no pass of its own
+  if (has0) cur.load(ps, REORDER ? (size_t)order[i0] : (size_t)i0, REORDER ? inDelta : 0ll);
   int par = 0;  // stage / mask buffer of this chunk (double buffered: ONE barrier per chunk)
   while (any) {
     float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
     next_chunk(i1, has1, any1);
-    if (has1) nxt.load(ps, (size_t)i1);  // in flight during this chunk
+    if (has1) nxt.load(ps, REORDER ? (size_t)order[i1] : (size_t)i1, REORDER ? inDelta : 0ll);  // in flight during this chunk
     // ---------------- phase 1: G2P + update of this wave's round
     bool valid = false;
     if (has0) {
@@ -1953,6 +1999,13 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
       // the bin altogether takes the exact path (hash queries into grid A)
       const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
       if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
+        if constexpr (REORDER) {  // the exact path works on slot i0 of the output buffer: give it the inputs
+          const POff<LW> oo = particle_offset<LW>(ps.pos.chns, (size_t)i0);
+          pstore<LW, 3>(ps.pos, oo, cur.pos);
+          pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, oo, cur.F);
+          pstore1<LW>(ps.mass, oo, cur.m);
+          if constexpr (DP) pstore1<LW>(ps.logJp, oo, cur.logJp);
+        }
         staleG[atomicAdd(staleGCount, 1)] = i0;  // outside the bin: exact gather + scatter afterwards
         // drift guard of the split launch: the exact path of an interior block may only reach blocks within two of its own
         if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
@@ -1967,6 +2020,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         advance_state<model_is_fluid(SMODEL)>(cur.F, C, mp.dt, F);
         pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
         pstore<LW, 3>(ps.pos, o, pos);
+        if constexpr (REORDER) pstore1<LW>(ps.mass, o, cur.m);  // the mass moves with the particle
         {  // F has been stored above: the plastic models may project this local copy
           float lj = 0.f;
           if constexpr (DP) lj = cur.logJp;
@@ -2038,10 +2092,11 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
   }
 }
 
-template <int SIDE, int SMODEL, int LW, bool WRITE_ALL>
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, bool REORDER = false>
 static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
                                                            const int *binStart, const unsigned *cellCount, const int *nbr, int *staleG,
-                                                           int *staleGCount, int *staleP, int *stalePCount, int binBase) {
+                                                           int *staleGCount, int *staleP, int *stalePCount, int binBase,
+                                                           const int *order, long long inDelta) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float varena[3 * AL::CH];
@@ -2069,10 +2124,10 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
   for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
   __syncthreads();
-  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
-  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount);
+  if (w == 0) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 0, REORDER>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, order, inDelta);
+  else if (w == 1) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 1, REORDER>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, order, inDelta);
+  else if (w == 2) g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 2, REORDER>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, order, inDelta);
+  else g2p2g_body<SIDE, SMODEL, LW, WRITE_ALL, 3, REORDER>(mp, ps, geo, start, cnt, lane, varena, parena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, order, inDelta);
   // dense post-pass over the particles that changed cell inside this bin: one thread per particle, contributions added to the
   // bin's arena with LDS atomics (the register stencils of the lanes are keyed to cells).  Their state was stored by other
   // lanes of this workgroup a moment ago: read it at agent scope so that a stale L1 line (x was loaded in phase 1) cannot serve it.
@@ -2411,6 +2466,8 @@ struct FusedArgs {
   int *staleG, *staleP, *counts, *driftFlag;
   unsigned nbins;
   int binBase, writeAll, lw, model;
+  const int *order;   // re-ordering step: input slot of output slot i (nullptr: in place)
+  long long inDelta;  // element offset from the output attribute arrays to the input ones
 };
 template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const ParticlesDev &pd, const BhtDev &t, const FusedArgs &a);
 

@@ -63,11 +63,11 @@ class MpmTransfer:
         bits = self.L.bit_length() - 1  # AoS: L == 1 -> numTileBits = tileMask = 0, component stride 1 (GenericIterator.hpp:71-72)
         return Port(buf.data_ptr() + self.off[name] * self.L * 4, 0, bits, self.L - 1, self.nchn)
 
-    def particles(self):
+    def particles(self, buf=None):
         null = Port(None, 0, 0, 0, 1)
-        return Particles(self._port("m"), self._port("x"), self._port("v"), self._port("C"), self._port("F"),
-                         self._port("logJp") if self.model in HAS_LOGJP else null,
-                         self._port("PF") if self.cache_stress else null, self.n)
+        return Particles(self._port("m", buf), self._port("x", buf), self._port("v", buf), self._port("C", buf), self._port("F", buf),
+                         self._port("logJp", buf) if self.model in HAS_LOGJP else null,
+                         self._port("PF", buf) if self.cache_stress else null, self.n)
 
     def set_particles(self, buf, n):
         """Adopt a new AoSoA particle buffer (after an inter-rank migration): the partition and the bins are void."""
@@ -199,13 +199,29 @@ class MpmTransfer:
         lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
                               self.nblocks, bs, cc, nb)
 
-    def g2p2g(self, write_all=False, split=None, between=None):
+    def g2p2g(self, write_all=False, split=None, between=None, reorder=False):
         """Fused G2P (from self.grid) + P2G (into a zeroed second grid, which then becomes self.grid): zs_rocm_mpm_g2p2g.
         Needs cache_stress=True and binned particles.  split=k: blocks [0, k) are launched first, `between()` is called (the
         caller records an event there and starts the ghost exchange of the NEW self.grid on another stream), then blocks
-        [k, nblocks) are launched (zs_rocm_mpm_g2p2g_range)."""
+        [k, nblocks) are launched (zs_rocm_mpm_g2p2g_range).
+        reorder=True: the particles are binned anew by their current positions (count / scan / distribute only) and the step
+        itself carries them into that order -- inputs read from the old buffer through the permutation, results stored to the
+        other buffer (zs_rocm_mpm_g2p2g_reorder_range): a re-bin without the separate reorder pass."""
         if not (self.cache_stress and self.binned):
             raise RuntimeError("g2p2g needs cache_stress=True and rebin()")
+        src_buf = None
+        if reorder and write_all:
+            raise ValueError("a re-ordering step cannot also materialise v, C, stress (write_all)")
+        if reorder:
+            L = lib()
+            if self.order is None or self.order.numel() != self.n:
+                self.order = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            L.zs_rocm_mpm_bin_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
+                                        int(self.key_is_origin), self.order.data_ptr(), self.bin_start.data_ptr(),
+                                        self.cell_count.data_ptr())
+            if self.buf2 is None:
+                self.buf2 = torch.empty_like(self.buf)
+            src_buf, self.buf, self.buf2 = self.buf, self.buf2, self.buf  # results go to the other buffer
         if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
             self.grid2 = torch.zeros_like(self.grid)
         else:
@@ -216,9 +232,15 @@ class MpmTransfer:
         src, dst = self.grid, self.grid2
         self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
         for k, (b0, b1) in enumerate(ranges):
-            rc = lib().zs_rocm_mpm_g2p2g_range(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
-                                               dst.data_ptr(), self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
-                                               self.nbr.data_ptr(), int(write_all), b0, b1, self.drift_flag.data_ptr())
+            if src_buf is None:
+                rc = lib().zs_rocm_mpm_g2p2g_range(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
+                                                   dst.data_ptr(), self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
+                                                   self.nbr.data_ptr(), int(write_all), b0, b1, self.drift_flag.data_ptr())
+            else:
+                rc = lib().zs_rocm_mpm_g2p2g_reorder_range(self.pol.handle, C.byref(self.params), self.particles(), self.particles(src_buf),
+                                                           self.order.data_ptr(), self.table.handle, src.data_ptr(), dst.data_ptr(),
+                                                           self.nblocks, self.bin_start.data_ptr(), self.cell_count.data_ptr(),
+                                                           self.nbr.data_ptr(), int(write_all), b0, b1, self.drift_flag.data_ptr())
             if rc != 0:
                 raise RuntimeError("zs_rocm_mpm_g2p2g refused the call")
             if k == 0 and between is not None:
