@@ -24,10 +24,18 @@ void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigne
 
 }  // namespace zsr
 
+// 32-byte node for the bulk query kernels: box, level and leaf id / escape index in one aligned fetch instead of three arrays
+struct alignas(32) LbvhPackedNode {
+  float lo[3], hi[3];
+  int level, aux;
+};
 struct zs_rocm_lbvh {
   size_t numLeaves = 0, numNodes = 0, capLeaves = 0;
   zsr::AABB3 *orderedBvs = nullptr;
   int *parents = nullptr, *levels = nullptr, *leafInds = nullptr, *auxIndices = nullptr;
+  mutable LbvhPackedNode *packed = nullptr;  // refreshed lazily by the query entry points after a build / refit
+  mutable size_t packedCap = 0;
+  mutable bool packedValid = false;
   zsr::LBvhDev dev() const {
     zsr::LBvhDev d;
     d.orderedBvs = orderedBvs; d.parents = parents; d.levels = levels; d.leafInds = leafInds; d.auxIndices = auxIndices;
@@ -290,6 +298,95 @@ __global__ __launch_bounds__(256) void lbvh_self_query_kernel(LBvhDev bvh, int *
   if (!FILL) counts[k] = c;
 }
 
+__global__ __launch_bounds__(256) void lbvh_pack_kernel(LBvhDev bvh, LbvhPackedNode *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bvh.numNodes) return;
+  const AABB3 b = bvh.orderedBvs[i];
+  LbvhPackedNode n;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { n.lo[d] = b.lo[d]; n.hi[d] = b.hi[d]; }
+  n.level = bvh.numNodes > 2 ? bvh.levels[i] : 0;
+  n.aux = bvh.numNodes > 2 ? bvh.auxIndices[i] : i;
+  out[i] = n;
+}
+// the reference's stack-less walk over packed nodes: at a trunk node an overlap descends to the left child (node + 1), a miss
+// follows the escape index; this is the `for (; level; --level, ++node)` spine loop of Bvh.hpp:661-678 unrolled per node
+template <class F>
+__device__ __forceinline__ void lbvh_walk_packed(const LbvhPackedNode *nodes, int numNodes, int node, const AABB3 &bv, F &&f) {
+  if (numNodes <= 2) {
+    for (int i = node; i != numNodes; ++i) {
+      const LbvhPackedNode n = nodes[i];
+      bool ov = true;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ov = ov && !(bv.lo[d] > n.hi[d] || bv.hi[d] < n.lo[d]);
+      if (ov) f(i);
+    }
+    return;
+  }
+  while (node != -1 && node != numNodes) {
+    const LbvhPackedNode n = nodes[node];
+    bool ov = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ov = ov && !(bv.lo[d] > n.hi[d] || bv.hi[d] < n.lo[d]);
+    if (n.level == 0) {
+      if (ov) f(n.aux);
+      node++;
+    } else
+      node = ov ? node + 1 : n.aux;
+  }
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void lbvh_query_packed_kernel(const LbvhPackedNode *nodes, int numNodes, const AABB3 *queries, size_t nq,
+                                                                int *counts, const int *offsets, int *out) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const AABB3 bv = queries[q];
+  int c = 0;
+  int *dst = FILL ? out + offsets[q] : nullptr;
+  lbvh_walk_packed(nodes, numNodes, 0, bv, [&](int id) {
+    if constexpr (FILL) dst[c] = id;
+    ++c;
+  });
+  if (!FILL) counts[q] = c;
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void lbvh_self_query_packed_kernel(const LbvhPackedNode *nodes, int numNodes, int numLeaves,
+                                                                     const int *leafInds, int *counts, const int *offsets, int *pairs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= numLeaves) return;
+  const int start = numNodes <= 2 ? k : leafInds[k];
+  const LbvhPackedNode me = nodes[start];
+  AABB3 bv;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { bv.lo[d] = me.lo[d]; bv.hi[d] = me.hi[d]; }
+  const int self = me.aux;
+  int c = 0;
+  int *dst = FILL ? pairs + 2 * (size_t)offsets[k] : nullptr;
+  // numNodes <= 2: the reference starts at leafId + 1 (Bvh.hpp:697-707); otherwise AT the leaf, which reports itself first
+  lbvh_walk_packed(nodes, numNodes, numNodes <= 2 ? start + 1 : start, bv, [&](int id) {
+    if (id == self) return;
+    if constexpr (FILL) {
+      dst[2 * c] = self;
+      dst[2 * c + 1] = id;
+    }
+    ++c;
+  });
+  if (!FILL) counts[k] = c;
+}
+static const LbvhPackedNode *lbvh_packed(Launch &L, const zs_rocm_lbvh &b) {
+  if (b.packedCap < b.numNodes) {
+    (void)hipFree(b.packed);
+    ZSR_CHECK(hipMalloc((void **)&b.packed, b.numNodes * sizeof(LbvhPackedNode)));
+    b.packedCap = b.numNodes;
+    b.packedValid = false;
+  }
+  if (!b.packedValid) {
+    hipLaunchKernelGGL(lbvh_pack_kernel, dim3(ceil_div(b.numNodes, 256)), dim3(256), 0, L.stream, b.dev(), b.packed);
+    b.packedValid = true;
+  }
+  return b.packed;
+}
+
 static void lbvh_reserve(zs_rocm_lbvh &b, size_t n) {
   if (n <= b.capLeaves) return;
   (void)hipFree(b.orderedBvs); (void)hipFree(b.parents); (void)hipFree(b.levels); (void)hipFree(b.leafInds); (void)hipFree(b.auxIndices);
@@ -325,6 +422,7 @@ zs_rocm_lbvh *zs_rocm_lbvh_create(void) { return new zs_rocm_lbvh; }
 void zs_rocm_lbvh_destroy(zs_rocm_lbvh *b) {
   if (!b) return;
   (void)hipFree(b->orderedBvs); (void)hipFree(b->parents); (void)hipFree(b->levels); (void)hipFree(b->leafInds); (void)hipFree(b->auxIndices);
+  (void)hipFree(b->packed);
   delete b;
 }
 size_t zs_rocm_lbvh_num_leaves(const zs_rocm_lbvh *b) { return b->numLeaves; }
@@ -341,6 +439,7 @@ void zs_rocm_lbvh_build(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primB
   lbvh_reserve(*b, n);
   b->numLeaves = n;
   b->numNodes = n > 2 ? 2 * n - 1 : n;
+  b->packedValid = false;
   if (n <= 2) {  // :823-831
     hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(64), 0, L.stream, (int)n, primBvs, b->orderedBvs, b->leafInds, b->auxIndices,
                        b->parents, b->levels);
@@ -370,6 +469,7 @@ void zs_rocm_lbvh_build(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primB
 int zs_rocm_lbvh_refit(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primBvs, size_t n) {
   if (n != b->numLeaves) return -1;  // "bvh topology changes, require rebuild!" (Bvh.hpp:1230-1231)
   Launch L(pol, "lbvh_refit");
+  b->packedValid = false;
   lbvh_refit_impl(L, *b, (const AABB3 *)primBvs);
   return 0;
 }
@@ -387,26 +487,28 @@ void zs_rocm_lbvh_total_box(zs_rocm_policy *pol, const zs_rocm_lbvh *b, float *b
 void zs_rocm_lbvh_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq, int *counts) {
   Launch L(pol, "lbvh_query_count");
   if (!nq) return;
-  hipLaunchKernelGGL((lbvh_query_kernel<false>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, b->dev(), (const AABB3 *)queryBvs, nq, counts,
-                     (const int *)nullptr, (int *)nullptr);
+  if (!b->numLeaves) { ZSR_CHECK(hipMemsetAsync(counts, 0, nq * sizeof(int), L.stream)); return; }
+  hipLaunchKernelGGL((lbvh_query_packed_kernel<false>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
+                     (const AABB3 *)queryBvs, nq, counts, (const int *)nullptr, (int *)nullptr);
 }
 void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq, const int *offsets, int *out) {
   Launch L(pol, "lbvh_query_fill");
   if (!nq) return;
-  hipLaunchKernelGGL((lbvh_query_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, b->dev(), (const AABB3 *)queryBvs, nq,
-                     (int *)nullptr, offsets, out);
+  if (!b->numLeaves) return;
+  hipLaunchKernelGGL((lbvh_query_packed_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
+                     (const AABB3 *)queryBvs, nq, (int *)nullptr, offsets, out);
 }
 void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, int *counts) {
   Launch L(pol, "lbvh_self_query_count");
   if (!b->numLeaves) return;
-  hipLaunchKernelGGL((lbvh_self_query_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, b->dev(), counts,
-                     (const int *)nullptr, (int *)nullptr);
+  hipLaunchKernelGGL((lbvh_self_query_packed_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr);
 }
 void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const int *offsets, int *pairs) {
   Launch L(pol, "lbvh_self_query_fill");
   if (!b->numLeaves) return;
-  hipLaunchKernelGGL((lbvh_self_query_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, b->dev(), (int *)nullptr,
-                     offsets, pairs);
+  hipLaunchKernelGGL((lbvh_self_query_packed_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs);
 }
 
 }  // extern "C"
