@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=512, help="cells per unit length: dx = 1/grid (512: config 4; 256: config 3)")
     ap.add_argument("--cells", type=str, default="128,512,128",
                     help="sand column extent in cells, 8 particles each (default 128x512x128 = 64 Mi particles; splits evenly on block planes for 2/4/8 ranks)")
     ap.add_argument("--model", type=str, default="sand", choices=["sand", "jello"])
@@ -188,9 +189,9 @@ def main():
     from zpc_amd.dist import cell_box, HaloExchange
 
     model = 1 if a.model == "sand" else 0
-    dx, dt = 1.0 / 512, 1e-4
+    dx, dt = 1.0 / a.grid, 1e-4
     ext = [int(x) for x in a.cells.split(",")]
-    glo = [(512 - ext[0]) // 2 // a.side * a.side, 0, (512 - ext[2]) // 2 // a.side * a.side]
+    glo = [(a.grid - ext[0]) // 2 // a.side * a.side, 0, (a.grid - ext[2]) // 2 // a.side * a.side]
     ghi = [glo[d] + ext[d] for d in range(3)]
     lo, hi = cell_box(rank, world, glo, ghi, align=a.side)
     vol = dx ** 3 / 8
@@ -471,15 +472,17 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
+        workload = ("%s %dx%dx%d cells, 8 particles/cell = %d particles, dx=1/%d (%d^3 sparse grid), %s, %d^3-cell grid blocks "
+                    "(bht<int,3,int,16> + TileVector<f32,%d^3> {m,v,rhs}), TileVector<f32,%d> particles; step = grid reset + P2G + grid "
+                    "update + G2P%s"
+                    % ("MPM sand column" if model else "MPM elastic jello block", ext[0], ext[1], ext[2], n_total, a.grid, a.grid,
+                       "DruckerPrager" if model else "FixedCorotated", a.side, a.side, a.lane_width,
+                       "" if not a.unbinned else " [particle-order path]"))
         out = {
             "metric": "particle*steps/s (P2G+G2P)", "value": value, "unit": "particle*steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MPM sand column %dx%dx%d cells, 8 particles/cell = %d particles, dx=1/512 (512^3 sparse grid), "
-                                   "%s, %d^3-cell grid blocks (bht<int,3,int,16> + TileVector<f32,%d^3> {m,v,rhs}), TileVector<f32,%d> particles; "
-                                   "step = grid reset + P2G + grid update + G2P%s"
-                       % (ext[0], ext[1], ext[2], n_total, "DruckerPrager" if model else "FixedCorotated", a.side, a.side, a.lane_width,
-                          "" if not a.unbinned else " [particle-order path]"),
+            "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
