@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "zensim_rocm/zs_rocm.hpp"
+#include "zensim_rocm/collider_device.hpp"
 
 #define CHECK(c)                                                        \
   do {                                                                  \
@@ -334,6 +335,41 @@ int main() {
       const float gx = p[0] - hb[g].lo[0], gy = p[1] - hb[g].lo[1], gz = p[2] - hb[g].lo[2];
       CHECK(g >= 0 && gx * gx + gy * gy + gz * gz <= bd * (1.f + 1e-6f));
     }
+  }
+  {  // Collider<AnalyticLevelSet<Sphere>> (slip, moving) inside a user lambda == the same struct evaluated on the host
+    zs_rocm_collider c;
+    const float par[4] = {0.1f, -0.05f, 0.02f, 0.45f};
+    zs_rocm_collider_init(&c, ZS_ROCM_GEOM_SPHERE, ZS_ROCM_COLLIDER_SLIP, par, 4);
+    c.dbdt[0] = 0.3f; c.omega[2] = 0.7f; c.b[1] = 0.05f;
+    const zsr::ColliderDev col(c);
+    const int nq = 4096;
+    Vector<float> xs(3 * nq, memsrc_e::um), vs(3 * nq, memsrc_e::um);
+    Vector<int> ins(nq, memsrc_e::um);
+    for (int i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) {
+        xs.data()[3 * i + d] = -0.8f + 1.6f * (float)((i * 37 + d * 101 + (i / 7) * 13) % 997) / 997.f;
+        vs.data()[3 * i + d] = -1.f + 2.f * (float)((i * 53 + d * 211) % 499) / 499.f;
+      }
+    std::vector<float> v0(vs.data(), vs.data() + 3 * nq);
+    pol(range(nq), [col, x = view<space>(xs), v = view<space>(vs), in = view<space>(ins)] ZS_LAMBDA(long long i) {
+      const float p[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+      float u[3] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+      in[i] = col.resolveCollision(p, u) ? 1 : 0;
+      v[3 * i] = u[0]; v[3 * i + 1] = u[1]; v[3 * i + 2] = u[2];
+    });
+    int inside = 0;
+    for (int i = 0; i < nq; ++i) {
+      const float p[3] = {xs.data()[3 * i], xs.data()[3 * i + 1], xs.data()[3 * i + 2]};
+      float u[3] = {v0[3 * i], v0[3 * i + 1], v0[3 * i + 2]};
+      float xmb[3], X[3];
+      col.to_material(p, xmb, X);
+      if (fabsf(col.signed_distance(X)) < 1e-4f) continue;  // on the surface the two roundings may disagree
+      const bool h = col.resolveCollision(p, u);
+      CHECK((int)h == ins.data()[i]);
+      inside += h;
+      for (int d = 0; d < 3; ++d) CHECK(fabsf(u[d] - vs.data()[3 * i + d]) < 1e-5f);
+    }
+    CHECK(inside > 200 && inside < nq - 200);
   }
   CHECK(zs_rocm_last_error(-1) == 0);
   std::printf("cpp face ok\n");
