@@ -58,10 +58,9 @@ def parse():
                          "(0 = never; the default bench window moves particles < 0.1 cell)")
     ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
     ap.add_argument("--rebin-check", type=int, default=4,
-                    help="fused step: every K steps read the number of particles that took the exact path (they left their cell "
-                         "since the last re-bin); above --rebin-threshold of the particles per step the next step materialises the "
-                         "full particle state and the particles are re-binned (local, no communication).  0 = never")
-    ap.add_argument("--rebin-threshold", type=float, default=0.003)
+                    help="fused step: every K..8K steps look at the step times since the last re-bin; once the time lost to "
+                         "particles that left their cell (sum of step time - best step time) exceeds the cost of a re-bin, the "
+                         "particles are re-binned (local, no communication; only the step's input channels move).  0 = never")
     ap.add_argument("--floor", action="store_true",
                     help="apply a Separate plane collider 1.5 cells above y = 0 after every grid update "
                          "(ApplyBoundaryConditionOnGridBlocks; off in the headline configuration)")
@@ -312,17 +311,22 @@ def main():
 
     fused_ev = []
 
+    ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
+
     def step_fused(timed, write_all=False, reorder=False):
         # grid holds the velocities of the current step (after grid_update): G2P from it, P2G of the next step into the
         # second (zeroed) grid, which then becomes the current one
-        if timed:
+        track = timed or a.rebin_check > 0
+        if track:
             e0, e1 = ev(), ev()
             e0.record()
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
             mt.g2p2g(write_all=write_all, split=n_boundary, between=lambda: ev_boundary.record(), reorder=reorder)
-            if timed:
+            if track:
                 e1.record()
+                ctrl_ev.append((e0, e1))
+            if timed:
                 fused_ev.append((e0, e1))
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev_boundary)
@@ -331,8 +335,10 @@ def main():
             torch.cuda.current_stream().wait_event(ev_comm)
         else:
             mt.g2p2g(write_all=write_all, reorder=reorder)
-            if timed:
+            if track:
                 e1.record()
+                ctrl_ev.append((e0, e1))
+            if timed:
                 fused_ev.append((e0, e1))
             if halo is not None:
                 halo.exchange(pack, unpack_add)
@@ -381,12 +387,16 @@ def main():
     K = a.migrate_every
     done = 0
 
+    # re-bin controller: particles that leave their cell make the fused launch slower step by step (LDS queue, exact path); a
+    # re-bin resets that at a fixed cost.  Re-bin when the time lost since the last re-bin (sum of launch time - best launch time)
+    # reaches the cost of a re-bin: for a linearly growing loss that is the period that minimises the average step time.
     rebins = 0
     check_iv = max(a.rebin_check, 1)
-    next_check, last_check = check_iv, 0
+    next_check = check_iv
+    best_ms, lost_ms, rebin_cost_ms = None, 0.0, None
 
     def run_steps(count, timed):
-        nonlocal done, rebins, check_iv, next_check, last_check
+        nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms
         for _ in range(count):
             remap_now = K > 0 and (done + 1) % K == 0
             if a.fused:
@@ -396,20 +406,32 @@ def main():
             done += 1
             if remap_now:
                 remap()
+                ctrl_ev.clear()
+                best_ms, lost_ms = None, 0.0
             elif a.fused and a.rebin_check > 0 and done >= next_check:
-                # reading the count synchronises the stream: look less often while hardly anything takes the exact path
-                rate = mt.exact_path_particles() / (max(mt.n, 1) * max(done - last_check, 1))
-                last_check = done
-                if rate > a.rebin_threshold:
+                ctrl_ev[-1][1].synchronize()  # the look stalls the stream: done less often while nothing is being lost
+                for e0, e1 in ctrl_ev:
+                    t = e0.elapsed_time(e1)
+                    best_ms = t if best_ms is None else min(best_ms, t)
+                    lost_ms += max(0.0, t - 1.01 * best_ms)
+                ctrl_ev.clear()
+                if rebin_cost_ms is None:
+                    rebin_cost_ms = 0.6 * best_ms  # first guess: 14 of 35 channels read + written, plus the ordering passes
+                if lost_ms >= rebin_cost_ms:
                     # particles only (partition, block numbers and halo lists stay), and only the channels the next fused step
                     # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid.  (MpmTransfer.g2p2g(reorder=True)
                     # folds the re-bin into the step instead; with today's binning order its scattered reads cost as much.)
+                    r0, r1 = ev(), ev()
+                    r0.record()
                     mt.rebin(inputs_only=True)
+                    r1.record()
+                    r1.synchronize()
+                    rebin_cost_ms = r0.elapsed_time(r1)
                     rebins += 1
-                    mt.exact_path_particles()
+                    best_ms, lost_ms = None, 0.0
                     check_iv = a.rebin_check
-                elif rate < a.rebin_threshold / 8:
-                    check_iv = min(check_iv * 2, 32)
+                elif lost_ms < 0.1 * rebin_cost_ms:
+                    check_iv = min(check_iv * 2, 8 * a.rebin_check)
                 else:
                     check_iv = a.rebin_check
                 next_check = done + check_iv
