@@ -108,3 +108,19 @@ def test_rccl_calls_of_the_multi_gpu_path_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_selftest.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"nccl selftest ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_long_run_with_rebins_is_rank_independent():
+    """40 steps of a drifting tall column (0.05 cell per step, 2 cells in total -- inside the partition's margin, so no
+    re-partition is needed: particles keep changing cells, the re-bin controller of bench.py fires at rank-dependent moments) on 1
+    and on 2 ranks with the overlapped exchange: same final particle state."""
+    args = ["--cells", "16,192,16", "--side", "4", "--steps", "40", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--drift", "0,1,0",
+            "--rebin-check", "2"]
+    ref = _run(1, args)
+    out = _run(2, args)
+    assert out["config"]["particles"] == ref["config"]["particles"] and out["hip_error"] == 0 and ref["hip_error"] == 0
+    a, b = np.array(ref["checksum"]), np.array(out["checksum"])
+    nch = len(a) // 2
+    scale = np.sqrt(ref["config"]["particles"] * np.maximum(a[nch:], 1e-30))
+    assert (np.abs(a[:nch] - b[:nch]) <= 5e-5 * scale + 1e-12).all(), np.abs(a[:nch] - b[:nch]) / scale
+    assert (np.abs(a[nch:] - b[nch:]) <= 2e-4 * np.abs(a[nch:]) + 1e-12).all()
