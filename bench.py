@@ -452,6 +452,10 @@ def main():
         raise SystemExit("rank %d: particles drifted more than one bin from their bins -- re-bin more often (--migrate-every) "
                          "or run with --no-overlap" % rank)
 
+    if a.fused and mt.left_partition():
+        # the reference does not check this either (P2G.hpp:109-110), but a benchmark that loses mass is not a benchmark
+        raise SystemExit("rank %d: particles left the sparse-grid partition (contributions dropped) -- use --migrate-every K to "
+                         "rebuild the partition" % rank)
     n_local = mt.n
     n_total = n_local
     if dist is not None:

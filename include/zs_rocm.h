@@ -590,10 +590,12 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g(zs_rocm_policy *, const zs_rocm_mpm_params 
                                      const float *gridA, float *gridB, size_t nblocks, const int *binStart,
                                      const unsigned *cellCount, const int *nbr, int writeAll);
 /* The same over blocks [blockBegin, blockEnd) only (multi-GPU step: the blocks near a rank boundary are numbered first and
- * launched first, their ghost sums travel while the interior range computes).  driftFlag (device int[2], may be NULL):
+ * launched first, their ghost sums travel while the interior range computes).  driftFlag (device int[3], may be NULL):
  * [0] is set to 1 when an exact-path particle sits more than one 4^3 bin away from the bin it is stored in (the margin that
  * keeps interior blocks from touching shared blocks no longer holds: re-bin); [1] accumulates the number of particles the
- * call handled on the exact path (moved out of their cell since the last re-bin) -- the caller's re-bin trigger. */
+ * call handled on the exact path (moved out of their cell since the last re-bin) -- the caller's re-bin trigger; [2] is set
+ * to 1 when a particle's stencil reached a node whose block is not in the partition (the reference does not check,
+ * P2G.hpp:109-110; here the contribution is dropped and the caller is told to rebuild the partition). */
 ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_range(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
                                            const float *gridA, float *gridB, size_t nblocks, const int *binStart,
                                            const unsigned *cellCount, const int *nbr, int writeAll, size_t blockBegin,

@@ -2181,14 +2181,16 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
     const int bn = nbr[(size_t)geo.block * 8 + slot];
+    const float *a = parena + AL::at(x, y, z);
     if (bn >= 0) {
-      const float *a = parena + AL::at(x, y, z);
       float *g = gridB + (size_t)bn * 7 * NC + cell;
 #pragma unroll
       for (int ch = 0; ch < 7; ++ch) {
         const float v = a[ch * AL::CH] + a[(7 + ch) * AL::CH];
         if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
       }
+    } else if (a[0] + a[7 * AL::CH] != 0.f) {
+      staleGCount[9] = 1;  // mass for a node whose block is not in the partition: the partition no longer covers the particles
     }
   }
 }
@@ -2201,6 +2203,7 @@ static __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, Part
   if (driftFlag && blockIdx.x == 0 && threadIdx.x == 0) {  // status words for the host: [0] drift flag, [1] exact-path particles
     if (staleGCount[8]) driftFlag[0] = 1;
     atomicAdd(&driftFlag[1], ng + np);
+    if (staleGCount[9]) driftFlag[2] = 1;
   }
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
@@ -2215,7 +2218,7 @@ static __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, Part
 // order of additions per node are those of p2g_scatter_global.
 template <int SIDE>
 static __global__ __launch_bounds__(256) void stale_scatter_coop_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *qa,
-                                                                 const int *na, const int *qb, const int *nb) {
+                                                                 const int *na, const int *qb, const int *nb, int *status) {
   constexpr int NC = SIDE * SIDE * SIDE;
   const int n0 = *na, n = n0 + *nb;
   const int sub = threadIdx.x & 31;
@@ -2250,6 +2253,7 @@ static __global__ __launch_bounds__(256) void stale_scatter_coop_kernel(MpmDev m
     const int x = loc[0] + a, y = loc[1] + b, z = loc[2] + c;
     const int o = sub < 27 ? (((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE)) : 0;
     const int bn = __shfl(myblk, o, 32);
+    if (sub < 27 && bn < 0 && status) status[2] = 1;  // a stencil node outside the partition: its contribution is lost
     if (sub < 27 && bn >= 0) {
       const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
       float *g = grid + (size_t)bn * 7 * NC + cell;

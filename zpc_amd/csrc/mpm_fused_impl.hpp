@@ -11,7 +11,7 @@ template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const Parti
   hipLaunchKernelGGL((g2p2g_stale_kernel<SS, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,             \
                      (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag);  \
   hipLaunchKernelGGL((stale_scatter_coop_kernel<SS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridB,                  \
-                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32))
+                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag)
 // the re-ordering variant exists without writeAll only (a re-ordering step never has to materialise v, C, stress)
 #define CALL_G2P2G3(SS, M, LWv)                                   \
   do {                                                            \

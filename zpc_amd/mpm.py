@@ -45,6 +45,7 @@ class MpmTransfer:
         self.buf2 = None  # second buffer for re-binning (ping-pong)
         self.drift_flag = None  # device status words of zs_rocm_mpm_g2p2g_range: [0] split-launch margin violated, [1] exact-path count
         self.drift_tripped = False
+        self.outside_tripped = False
         self.key_is_origin = bool(key_is_origin)  # SparseGrid convention: partition keys are block origins (multiples of side)
         self.kstride = side if key_is_origin else 1
         # VonMisesFixedCorotatedConfig::yieldStress; NACCConfig::xi, Msqr() from the friction angle, hardeningOn (beta shared)
@@ -165,7 +166,9 @@ class MpmTransfer:
         self.buf, self.buf2 = self.buf2, self.buf
         self.binned = True
         if self.drift_flag is not None:
-            self.drift_tripped = self.drift_tripped or bool(self.drift_flag[0].item())  # latched: a re-bin must not erase it
+            flags = self.drift_flag.cpu()
+            self.drift_tripped = self.drift_tripped or bool(flags[0])  # latched: a re-bin must not erase them
+            self.outside_tripped = self.outside_tripped or bool(flags[2])
             self.drift_flag.zero_()
 
     # ------------------------------------------------------------------ one sub-step
@@ -227,7 +230,7 @@ class MpmTransfer:
         else:
             self.grid2.zero_()
         if self.drift_flag is None:
-            self.drift_flag = torch.zeros(2, dtype=torch.int32, device=self.device)
+            self.drift_flag = torch.zeros(3, dtype=torch.int32, device=self.device)
         ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
         src, dst = self.grid, self.grid2
         self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
@@ -251,6 +254,11 @@ class MpmTransfer:
         (the overlapped multi-GPU exchange is then not valid: see zs_rocm_mpm_g2p2g_range)."""
         return self.drift_tripped or (self.drift_flag is not None and bool(self.drift_flag[0].item()))
 
+    def left_partition(self):
+        """True if a fused step ever dropped a contribution because a particle's stencil reached a block that is not in the
+        partition: rebuild the partition (build_partition / re-map) more often."""
+        return self.outside_tripped or (self.drift_flag is not None and bool(self.drift_flag[2].item()))
+
     def exact_path_particles(self, reset=True):
         """Particles the fused steps since the last call handled on the exact path (they left their cell after the last
         re-bin); synchronises the stream.  The re-bin trigger: the exact path costs ~50x the binned one per particle."""
@@ -258,7 +266,7 @@ class MpmTransfer:
             return 0
         c = int(self.drift_flag[1].item())
         if reset:
-            self.drift_flag[1:].zero_()  # the margin flag [0] stays
+            self.drift_flag[1:2].zero_()  # the flags [0], [2] stay
         return c
 
     def reorder_partition(self, first_mask):
