@@ -111,6 +111,12 @@ def main():
     ms = timeit(lambda: zs.lib().zs_rocm_lbvh_self_query_count(pol.handle, bvh.handle, sc.data_ptr()), reps=3, warm=1)
     npairs = float(sc.double().sum().item())
     add("LBvh self-collision broadphase count, 10M leaves (%.2f pairs/leaf)" % (npairs / n), n, 24 + 4, ms)
+    # config 5 end to end: build + refit, count pass, exclusive scan, fill pass -> the (i, j) pair list
+    def config5():
+        bvh.build(pol, bvs)
+        return bvh.self_query(pol)
+    ms = timeit(config5, reps=3, warm=1)
+    add("config 5: LBvh build + self-collision pair list, 10M boxes (%.0f M pairs)" % (npairs / 1e6), n, 268 + 2 * 28 + 8 * npairs / n, ms)
     del bvh, bvs
     return rows
 
