@@ -267,3 +267,24 @@ def test_tilevector_channel_iterators(pol, oracle):
         assert np.array_equal(o.cpu().numpy(), (np.cumsum(vals, dtype=np.int64) - vals).astype(np.int32))
         zs.radix_sort(pol, it, o, n=n)
         assert np.array_equal(o.cpu().numpy(), np.sort(vals))
+
+
+def test_empty_ranges(pol):
+    """n = 0 through the C ABI: reduce returns init (SequentialExecutionPolicy: the fold over an empty range,
+    execution/ExecutionPolicy.hpp:267-274), scans and sorts leave their outputs untouched, nothing is launched out of bounds."""
+    import zpc_amd as zs
+    a = torch.zeros(4, dtype=torch.int32, device="cuda")[:0]
+    out1 = torch.full((1,), 123, dtype=torch.int32, device="cuda")
+    for op, init in ((zs.plus, 0), (zs.multiplies, 1), (zs.getmin, 2**31 - 1), (zs.getmax, -2**31)):
+        zs.reduce(pol, a, 0, out1, op=op)
+        assert int(out1.item()) == init
+    zs.reduce(pol, a, 0, out1, init=77, op=zs.plus)
+    assert int(out1.item()) == 77
+    guard = torch.full((8,), -5, dtype=torch.int32, device="cuda")
+    zs.exclusive_scan(pol, a, guard[:0])
+    zs.inclusive_scan(pol, a, guard[:0])
+    zs.radix_sort(pol, a, guard[:0])
+    zs.radix_sort_pair(pol, a, a, guard[:0], guard[:0])
+    zs.merge_sort(pol, guard[:0])
+    pol.syncCtx()
+    assert (guard.cpu().numpy() == -5).all() and zs.lib().zs_rocm_last_error(-1) == 0
