@@ -433,7 +433,9 @@ ZS_ROCM_EXPORT void zs_rocm_lbvh_query_fill(zs_rocm_policy *, const zs_rocm_lbvh
                                             int *out);
 /* self-collision broadphase (LBvhView::self_iter_neighbors, container/Bvh.hpp:695-728, driven over every leaf): thread k walks
  * from the k-th leaf in node order; counts[k] = overlapping leaves AFTER it (the leaf itself is skipped), so every unordered
- * pair of overlapping primitives appears exactly once.  fill: pairs[2*(offsets[k]+c)] = {primitive of leaf k, other primitive}. */
+ * pair of overlapping primitives appears exactly once.  fill: pairs[2*(offsets[k]+c)] = {primitive of leaf k, other primitive}.
+ * The count pass remembers the first 16 hits of every leaf inside the LBvh object; a fill pass on the unchanged tree copies
+ * them instead of walking again (the memory is released with the object, invalidated by build / refit). */
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, int *counts /* [numLeaves] */);
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const int *offsets, int *pairs);
 

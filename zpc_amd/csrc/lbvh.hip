@@ -36,6 +36,11 @@ struct zs_rocm_lbvh {
   mutable LbvhPackedNode *packed = nullptr;  // refreshed lazily by the query entry points after a build / refit
   mutable size_t packedCap = 0;
   mutable bool packedValid = false;
+  // hits of the last self-query count pass (up to LBVH_HIT_CACHE per leaf, hit-major): the fill pass copies them instead of
+  // walking the tree a second time
+  mutable int *hitCache = nullptr, *hitCounts = nullptr;
+  mutable size_t hitCacheLeaves = 0;
+  mutable bool hitCacheValid = false;
   zsr::LBvhDev dev() const {
     zsr::LBvhDev d;
     d.orderedBvs = orderedBvs; d.parents = parents; d.levels = levels; d.leafInds = leafInds; d.auxIndices = auxIndices;
@@ -349,29 +354,50 @@ __global__ __launch_bounds__(256) void lbvh_query_packed_kernel(const LbvhPacked
   });
   if (!FILL) counts[q] = c;
 }
+constexpr int LBVH_HIT_CACHE = 16;
+// FILL = false: count pass; also remembers the first LBVH_HIT_CACHE hits of every leaf (cache[j * numLeaves + k]) and its count.
+// FILL = true: leaves whose hits all fit into the cache are copied from it, the others walk again.
 template <bool FILL>
 __global__ __launch_bounds__(256) void lbvh_self_query_packed_kernel(const LbvhPackedNode *nodes, int numNodes, int numLeaves,
-                                                                     const int *leafInds, int *counts, const int *offsets, int *pairs) {
+                                                                     const int *leafInds, int *counts, const int *offsets, int *pairs,
+                                                                     int *cache, int *cacheCounts, int useCache) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= numLeaves) return;
   const int start = numNodes <= 2 ? k : leafInds[k];
   const LbvhPackedNode me = nodes[start];
+  const int self = me.aux;
+  int *dst = FILL ? pairs + 2 * (size_t)offsets[k] : nullptr;
+  if constexpr (FILL) {
+    if (useCache) {
+      const int cc = cacheCounts[k];
+      if (cc <= LBVH_HIT_CACHE) {
+        for (int j = 0; j < cc; ++j) {
+          dst[2 * j] = self;
+          dst[2 * j + 1] = cache[(size_t)j * numLeaves + k];
+        }
+        return;
+      }
+    }
+  }
   AABB3 bv;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { bv.lo[d] = me.lo[d]; bv.hi[d] = me.hi[d]; }
-  const int self = me.aux;
   int c = 0;
-  int *dst = FILL ? pairs + 2 * (size_t)offsets[k] : nullptr;
   // numNodes <= 2: the reference starts at leafId + 1 (Bvh.hpp:697-707); otherwise AT the leaf, which reports itself first
   lbvh_walk_packed(nodes, numNodes, numNodes <= 2 ? start + 1 : start, bv, [&](int id) {
     if (id == self) return;
     if constexpr (FILL) {
       dst[2 * c] = self;
       dst[2 * c + 1] = id;
+    } else {
+      if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = id;
     }
     ++c;
   });
-  if (!FILL) counts[k] = c;
+  if (!FILL) {
+    counts[k] = c;
+    cacheCounts[k] = c;
+  }
 }
 static const LbvhPackedNode *lbvh_packed(Launch &L, const zs_rocm_lbvh &b) {
   if (b.packedCap < b.numNodes) {
@@ -423,6 +449,7 @@ void zs_rocm_lbvh_destroy(zs_rocm_lbvh *b) {
   if (!b) return;
   (void)hipFree(b->orderedBvs); (void)hipFree(b->parents); (void)hipFree(b->levels); (void)hipFree(b->leafInds); (void)hipFree(b->auxIndices);
   (void)hipFree(b->packed);
+  (void)hipFree(b->hitCache); (void)hipFree(b->hitCounts);
   delete b;
 }
 size_t zs_rocm_lbvh_num_leaves(const zs_rocm_lbvh *b) { return b->numLeaves; }
@@ -440,6 +467,7 @@ void zs_rocm_lbvh_build(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primB
   b->numLeaves = n;
   b->numNodes = n > 2 ? 2 * n - 1 : n;
   b->packedValid = false;
+  b->hitCacheValid = false;
   if (n <= 2) {  // :823-831
     hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(64), 0, L.stream, (int)n, primBvs, b->orderedBvs, b->leafInds, b->auxIndices,
                        b->parents, b->levels);
@@ -470,6 +498,7 @@ int zs_rocm_lbvh_refit(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primBv
   if (n != b->numLeaves) return -1;  // "bvh topology changes, require rebuild!" (Bvh.hpp:1230-1231)
   Launch L(pol, "lbvh_refit");
   b->packedValid = false;
+  b->hitCacheValid = false;
   lbvh_refit_impl(L, *b, (const AABB3 *)primBvs);
   return 0;
 }
@@ -501,14 +530,23 @@ void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const f
 void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, int *counts) {
   Launch L(pol, "lbvh_self_query_count");
   if (!b->numLeaves) return;
+  if (b->hitCacheLeaves < b->numLeaves) {
+    (void)hipFree(b->hitCache); (void)hipFree(b->hitCounts);
+    ZSR_CHECK(hipMalloc((void **)&b->hitCache, b->numLeaves * LBVH_HIT_CACHE * sizeof(int)));
+    ZSR_CHECK(hipMalloc((void **)&b->hitCounts, b->numLeaves * sizeof(int)));
+    b->hitCacheLeaves = b->numLeaves;
+  }
   hipLaunchKernelGGL((lbvh_self_query_packed_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr);
+                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
+                     b->hitCache, b->hitCounts, 0);
+  b->hitCacheValid = true;  // until the next build / refit
 }
 void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const int *offsets, int *pairs) {
   Launch L(pol, "lbvh_self_query_fill");
   if (!b->numLeaves) return;
   hipLaunchKernelGGL((lbvh_self_query_packed_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs);
+                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
+                     b->hitCacheValid ? 1 : 0);
 }
 
 }  // extern "C"
