@@ -254,7 +254,10 @@ def main():
         if world > 1:
             all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
             if overlap:
-                n_boundary = mt.reorder_partition(near_shared_mask(all_keys[rank], all_keys, rank, mt.kstride))
+                # blocks whose launch must precede the exchange: 8^3 blocks hold their 4^3 bins and those bins' exact-path particles
+                # (at most one bin away, drift flag) within one block of themselves; 4^3 blocks (block = bin) within two
+                n_boundary = mt.reorder_partition(near_shared_mask(all_keys[rank], all_keys, rank, mt.kstride,
+                                                                   margin=1 if a.side == 8 else 2))
         if not a.unbinned:
             mt.rebin()
         stage.clear()

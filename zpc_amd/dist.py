@@ -76,8 +76,9 @@ def gather_block_keys(dist, world_size, my_keys, backend_dev):
 def near_shared_mask(my_keys, all_keys, rank, stride, margin=2):
     """mask[i] = 1 when block my_keys[i] is within `margin` blocks (Chebyshev, key units of `stride`) of a block that also
     exists on another rank.  These blocks are numbered and launched first; the others may run while the ghost sums travel:
-    a block's bins write to the blocks at offsets {0,1}^3, their exact-path particles (<= one bin away, enforced by the
-    drift flag of zs_rocm_mpm_g2p2g_range) to offsets {-1..2}^3."""
+    a block's bins write to the blocks at offsets {0,1}^3, their exact-path particles (<= one 4^3 bin away, enforced by the
+    drift flag of zs_rocm_mpm_g2p2g_range) to offsets {-1..2}^3 when a block is one bin (side 4: margin 2) and to
+    {-1..1}^3 when a block holds 2^3 bins (side 8: base nodes -4..+11 of the block, stencils up to +13 < 16: margin 1)."""
     if my_keys.shape[0] == 0:
         return np.zeros(0, bool)
     sh = [shared_keys(my_keys, all_keys[p]) for p in range(len(all_keys)) if p != rank]
