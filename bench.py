@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--floor", action="store_true",
                     help="apply a Separate plane collider 1.5 cells above y = 0 after every grid update "
                          "(ApplyBoundaryConditionOnGridBlocks; off in the headline configuration)")
+    ap.add_argument("--decomp", type=str, default="",
+                    help="rank grid AxBxC (default: slabs along y, 1xNx1); e.g. 2x2x2")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, fused step: exchange the ghost blocks after the whole transfer kernel instead of overlapping "
                          "it with the interior blocks")
@@ -186,6 +188,8 @@ def main():
     from zpc_amd import lib
     from zpc_amd.mpm import MpmTransfer
     from zpc_amd.dist import cell_box, HaloExchange
+    if a.decomp and world > 1:
+        zpc_amd.dist.set_split_dims(world, [int(v) for v in a.decomp.split("x")])
 
     model = 1 if a.model == "sand" else 0
     dx, dt = 1.0 / a.grid, 1e-4

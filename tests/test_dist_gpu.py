@@ -35,7 +35,8 @@ def _run(n, ARGS=ARGS):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("n,extra", [(2, []), (4, []), (8, []), (2, ["--no-overlap"]), (4, ["--side", "4"]),
+@pytest.mark.parametrize("n,extra", [(2, []), (4, ["--decomp", "2x2x1"]), (8, ["--decomp", "2x2x2"]), (8, ["--cells", "24,128,24"]),
+                                     (2, ["--no-overlap"]), (4, ["--side", "4", "--cells", "24,64,24"]),
                                      (2, ["--cells", "16,192,16", "--side", "4"]), (2, ["--cells", "16,192,16"])])
 def test_n_ranks_reproduce_single_rank(n, extra):
     """default N > 1 step: boundary blocks first, ghost exchange on a second stream overlapped with the interior blocks"""
@@ -46,7 +47,7 @@ def test_n_ranks_reproduce_single_rank(n, extra):
     assert out["config"]["halo_overlap"] == ("--no-overlap" not in extra)
     if out["config"]["halo_overlap"]:
         assert 0 < out["config"]["boundary_blocks_rank0"] <= out["config"]["grid_blocks_rank0"]
-    if "--cells" in extra:  # tall column: most blocks are interior, so the split launch + second stream really run
+    if "16,192,16" in extra:  # tall column: most blocks are interior, so the split launch + second stream really run
         assert out["config"]["boundary_blocks_rank0"] < out["config"]["grid_blocks_rank0"] // 2
     a, b = np.array(ref["checksum"]), np.array(out["checksum"])
     # sums and sums of squares of every particle channel (m, x, v, C, F, logJp) after 4 steps; particles are generated
