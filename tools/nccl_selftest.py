@@ -45,14 +45,15 @@ h.peers = [(0, 0, 2), (0, 2, 1)]  # two messages, like two peers
 before = grid.clone()
 comm = torch.cuda.Stream(device=dev, priority=-1)
 ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
-ev0.record()
-with torch.cuda.stream(comm):
-    comm.wait_event(ev0)
-    h.exchange(lambda b, nb, buf: buf.copy_(grid.reshape(-1)), lambda b, nb, buf: grid.add_(buf.reshape(3, bf)))
-    ev1.record()
-torch.cuda.current_stream().wait_event(ev1)
+for rep in range(3):  # the message list (P2POp objects) is built once and re-used every step
+    ev0.record()
+    with torch.cuda.stream(comm):
+        comm.wait_event(ev0)
+        h.exchange(lambda b, nb, buf: buf.copy_(grid.reshape(-1)), lambda b, nb, buf: grid.add_(buf.reshape(3, bf)))
+        ev1.record()
+    torch.cuda.current_stream().wait_event(ev1)
 torch.cuda.synchronize()
-assert torch.allclose(grid, 2 * before)
+assert torch.allclose(grid, 8 * before)
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()

@@ -157,11 +157,12 @@ class HaloExchange:
         d = self.dist
         bf = self.block_floats
         pack(self.blocks_all, self.total_blocks, self.sendbuf)
-        ops = []
-        for p, off, nb in self.peers:
-            ops.append(d.P2POp(d.isend, self.sendbuf[off * bf:(off + nb) * bf], p))
-            ops.append(d.P2POp(d.irecv, self.recvbuf[off * bf:(off + nb) * bf], p))
-        for w in d.batch_isend_irecv(ops):
+        if getattr(self, "_ops", None) is None:  # the message list is fixed for the life of the partition
+            self._ops = []
+            for p, off, nb in self.peers:
+                self._ops.append(d.P2POp(d.isend, self.sendbuf[off * bf:(off + nb) * bf], p))
+                self._ops.append(d.P2POp(d.irecv, self.recvbuf[off * bf:(off + nb) * bf], p))
+        for w in d.batch_isend_irecv(self._ops):
             w.wait()
         unpack_add(self.blocks_all, self.total_blocks, self.recvbuf)
 
