@@ -222,19 +222,39 @@ __global__ __launch_bounds__(256) void lbvh_reorder_trunk_kernel(int numTrunk, c
 // agent-scope box accesses (sc1: served at the device coherence point, never from a CU- or XCD-local cache line), so the
 // bottom-up walk needs no __threadfence (on gfx950 a device fence writes back / invalidates L2: measured 94 ms per refit
 // of 10 M leaves with fences vs the figure in DESIGN.md without)
+// 16 + 8 bytes per box (two memory transactions instead of three 8-byte ones; the refit is bound by the number of L2
+// transactions).  sc1 = agent scope: served by / written through to L2.  The accesses need not be single-copy atomic: a box is
+// read only after its writer has drained its stores and signed in at the parent's flag.
+typedef float lbvh_f4 __attribute__((ext_vector_type(4)));
+typedef float lbvh_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_box_agent(AABB3 *p, const AABB3 &b) {
-  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-  const unsigned long long *v = reinterpret_cast<const unsigned long long *>(&b);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) __hip_atomic_store(q + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const lbvh_f4 a = {b.lo[0], b.lo[1], b.lo[2], b.hi[0]};
+  const lbvh_f2 c = {b.hi[1], b.hi[2]};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1" ::"v"(p), "v"(a), "v"(c) : "memory");
 }
 __device__ __forceinline__ AABB3 load_box_agent(const AABB3 *p) {
-  const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+  lbvh_f4 a;
+  lbvh_f2 c;
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(c)
+               : "v"(p)
+               : "memory");
   AABB3 b;
-  unsigned long long *v = reinterpret_cast<unsigned long long *>(&b);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) v[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  b.lo[0] = a.x; b.lo[1] = a.y; b.lo[2] = a.z; b.hi[0] = a.w; b.hi[1] = c.x; b.hi[2] = c.y;
   return b;
+}
+// both children in flight together: four loads, one wait
+__device__ __forceinline__ void load_box2_agent(const AABB3 *pl, const AABB3 *pr, AABB3 &L, AABB3 &R) {
+  lbvh_f4 a, d;
+  lbvh_f2 c, e;
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %4, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx2 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(c), "=&v"(d), "=&v"(e)
+      : "v"(pl), "v"(pr)
+      : "memory");
+  L.lo[0] = a.x; L.lo[1] = a.y; L.lo[2] = a.z; L.hi[0] = a.w; L.hi[1] = c.x; L.hi[2] = c.y;
+  R.lo[0] = d.x; R.lo[1] = d.y; R.lo[2] = d.z; R.hi[0] = d.w; R.hi[1] = e.x; R.hi[2] = e.y;
 }
 // _refit_bottom_up (Bvh.hpp:469-492): the second lane to arrive at a trunk node merges its children and climbs
 __global__ __launch_bounds__(256) void lbvh_refit_kernel(int numLeaves, const AABB3 *primBvs, AABB3 *orderedBvs, const int *auxIndices,
@@ -249,7 +269,8 @@ __global__ __launch_bounds__(256) void lbvh_refit_kernel(int numLeaves, const AA
     if (atomicCAS(&flags[node], 0, 1) == 0) break;     // first to arrive: the sibling will do the merge
     const int lc = node + 1;
     const int rc = levels[lc] ? auxIndices[lc] : lc + 1;
-    const AABB3 L = load_box_agent(orderedBvs + lc), R = load_box_agent(orderedBvs + rc);
+    AABB3 L, R;
+    load_box2_agent(orderedBvs + lc, orderedBvs + rc, L, R);
     AABB3 bv;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
