@@ -577,6 +577,25 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_apply_boundary(zs_rocm_policy *, const zs_rocm_m
 /* bulk Collider::resolveCollision on n points (x, v: [n][3] device arrays, v updated; inside[n] may be NULL): test entry */
 ZS_ROCM_EXPORT void zs_rocm_collider_resolve(zs_rocm_policy *, const zs_rocm_collider *collider, const float *x, float *v, size_t n,
                                              int *inside);
+/* Gather-style transfers: linear particle <-> cell-centre weights, 1/8 cell <-> node weights.
+ * pol(Collapse{nblocks, side^3}, P2C2GTransfer{scheme, dt, model, buckets, particles, table, grids}): kind 0 = P2C2GTransfer
+ * (simulation/transfer/P2C2G.hpp:29-305: mass, momentum with the affine term, and -dt * stress), 1 = P2C2GTransferMomentum (:321-506: mass and
+ * momentum only), 2 = P2C2GTransferForce (:522-790: -dt * stress only).  ADDS into grid channels 0..3 (m, mv) like the reference's atomics.
+ * `buckets` = zs_rocm_index_buckets_for_particles(pos, n, dx, displacement 0); particles.C is the reference's `B` (Structurefree.hpp:268-271:
+ * one storage).  Built from gathers only (per particle -> per cell -> per node): no float atomics, reproducible bit for bit; each particle's
+ * constitutive update runs once (the reference functor repeats it, and its logJp store, for every cell that sees the particle).
+ * Returns 0, -1 on bad arguments. */
+ZS_ROCM_EXPORT int zs_rocm_mpm_p2c2g(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_index_buckets *buckets,
+                                     const zs_rocm_bht_3 *, float *grid, size_t nblocks, int kind);
+/* pol(range(n), PreG2C2PTransfer{particles}) (simulation/transfer/G2C2P.hpp:208-221): v = 0, C = 0 */
+ZS_ROCM_EXPORT void zs_rocm_mpm_pre_g2c2p(zs_rocm_policy *, zs_rocm_particles);
+/* pol(Collapse{nblocks, side^3}, G2C2PTransfer{scheme, dt, model, buckets, grids, table, particles}) (G2C2P.hpp:38-204): v_p += sum W v_c,
+ * B_p += sum W (v_c (x) x_i - v_c (x) x_p); `buckets` may be NULL (the particle side is a gather here). */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2c2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_index_buckets *buckets,
+                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks);
+/* pol(range(n), PostG2C2PTransfer{scheme, dt, dx, model, particles}) (G2C2P.hpp:224-275): C = B Dinv; F <- (I + dt C) F (J for the fluid);
+ * x += v dt */
+ZS_ROCM_EXPORT void zs_rocm_mpm_post_g2c2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
 /* pol(range(n), G2PTransfer{apic, dt, model, grids, table, particles}) (simulation/transfer/G2P.hpp:24-90) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,

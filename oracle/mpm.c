@@ -407,6 +407,42 @@ static inline int locate(const orc_bht *table, const int32_t coord[3], int side,
   return orc_bht_query(table, blk);
 }
 
+/* the constitutive switch shared by P2GTransfer (P2G.hpp:60-103) and the P2C2G functors (P2C2G.hpp:98-142): stress of one particle,
+ * contrib = P F^T vol (or the fluid's viscous stress); logJp is updated for the plastic models, F is only a scratch copy */
+static void model_contrib(const orc_mpm_params *p, float mu, float lam, const float *C, float *F, float *logJp, float contrib[9]) {
+  if (p->model == 4) { /* EquationOfStateConfig, P2G.hpp:60-81: J is kept in component 0 of the F slot */
+    float J = F[0];
+    float vol = p->volume * J;
+    float pressure = p->bulk;
+    {
+      float J2 = J * J;
+      float J4 = J2 * J2;
+      pressure = pressure * (1 / (J * J2 * J4) - 1);
+    }
+    contrib[0] = ((C[0] + C[0]) * p->viscosity - pressure) * vol;
+    contrib[1] = (C[1] + C[3]) * p->viscosity * vol;
+    contrib[2] = (C[2] + C[6]) * p->viscosity * vol;
+    contrib[3] = (C[3] + C[1]) * p->viscosity * vol;
+    contrib[4] = ((C[4] + C[4]) * p->viscosity - pressure) * vol;
+    contrib[5] = (C[5] + C[7]) * p->viscosity * vol;
+    contrib[6] = (C[6] + C[2]) * p->viscosity * vol;
+    contrib[7] = (C[7] + C[5]) * p->viscosity * vol;
+    contrib[8] = ((C[8] + C[8]) * p->viscosity - pressure) * vol;
+  } else if (p->model == 0) {
+    orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
+  } else if (p->model == 2) { /* P2G.hpp:86-88 */
+    orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, 0, F, contrib);
+  } else if (p->model == 3) { /* P2G.hpp:96-101 */
+    float lj = *logJp;
+    orc_stress_nacc(p->volume, mu, lam, orc_nacc_bulk(p->E, p->nu), p->xi, p->beta, p->Msqr, p->hardeningOn, 0, &lj, F, contrib);
+    *logJp = lj;
+  } else {
+    float lj = *logJp;
+    orc_stress_sand(p->volume, mu, lam, p->cohesion, p->beta, p->yieldSurface, p->volCorrection, &lj, F, contrib);
+    *logJp = lj; /* P2G.hpp:101 -- note: the projected F is NOT written back */
+  }
+}
+
 void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const float *mass,
                  const float *pos, const float *vel, const float *Cm, const float *Fm, float *logJp,
                  float *grid) {
@@ -421,37 +457,7 @@ void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const 
     float contrib[9], F[9];
     const float *C = Cm + 9 * i;
     memcpy(F, Fm + 9 * i, 36);
-    if (p->model == 4) { /* EquationOfStateConfig, P2G.hpp:60-81: J is kept in component 0 of the F slot */
-      float J = F[0];
-      float vol = p->volume * J;
-      float pressure = p->bulk;
-      {
-        float J2 = J * J;
-        float J4 = J2 * J2;
-        pressure = pressure * (1 / (J * J2 * J4) - 1);
-      }
-      contrib[0] = ((C[0] + C[0]) * p->viscosity - pressure) * vol;
-      contrib[1] = (C[1] + C[3]) * p->viscosity * vol;
-      contrib[2] = (C[2] + C[6]) * p->viscosity * vol;
-      contrib[3] = (C[3] + C[1]) * p->viscosity * vol;
-      contrib[4] = ((C[4] + C[4]) * p->viscosity - pressure) * vol;
-      contrib[5] = (C[5] + C[7]) * p->viscosity * vol;
-      contrib[6] = (C[6] + C[2]) * p->viscosity * vol;
-      contrib[7] = (C[7] + C[5]) * p->viscosity * vol;
-      contrib[8] = ((C[8] + C[8]) * p->viscosity - pressure) * vol;
-    } else if (p->model == 0) {
-      orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
-    } else if (p->model == 2) { /* P2G.hpp:86-88 */
-      orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, 0, F, contrib);
-    } else if (p->model == 3) { /* P2G.hpp:96-101 */
-      float lj = logJp[i];
-      orc_stress_nacc(p->volume, mu, lam, orc_nacc_bulk(p->E, p->nu), p->xi, p->beta, p->Msqr, p->hardeningOn, 0, &lj, F, contrib);
-      logJp[i] = lj;
-    } else {
-      float lj = logJp[i];
-      orc_stress_sand(p->volume, mu, lam, p->cohesion, p->beta, p->yieldSurface, p->volCorrection, &lj, F, contrib);
-      logJp[i] = lj; /* P2G.hpp:101 -- note: the projected F is NOT written back */
-    }
+    model_contrib(p, mu, lam, C, F, logJp ? logJp + i : NULL, contrib);
     for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * -p->dt * D_inv; /* P2G.hpp:105 */
     int32_t corner[3];
     float lp[3], w[9];
@@ -543,5 +549,163 @@ void orc_mpm_g2p(const orc_mpm_params *p, const orc_bht *table, size_t n, float 
     memcpy(Fm + 9 * i, F, 36);
     memcpy(vel + 3 * i, v, 12);
     memcpy(Cm + 9 * i, C, 36);
+  }
+}
+
+/* ------------------------------------------------------------------------------------ gather-style transfers
+ * P2C2GTransfer / P2C2GTransferMomentum / P2C2GTransferForce (simulation/transfer/P2C2G.hpp:53-189, :346-439, :547-679) and
+ * G2C2PTransfer / PostG2C2PTransfer (simulation/transfer/G2C2P.hpp:59-135, :224-275): linear particle <-> cell-centre weights,
+ * 1/8 cell <-> node weights; the launch range is Collapse{nblocks, side^3} over the partition's cells, visited here in
+ * (block, cell) order, the 27 buckets in ndrange<3>(3) order, a bucket's particles in ascending id.
+ *
+ * One deliberate difference, documented in DESIGN.md: the reference functor re-runs the constitutive update for every
+ * (cell, particle) pair -- up to 8 times per particle -- and stores logJp each time, so for the plastic models its result
+ * depends on the order in which cells are visited.  The restatement evaluates every particle ONCE, from the logJp of the
+ * previous step (what a race-free run of the reference computes for every pair that reads before the first write). */
+static inline float dinv_axis(float x, float dx, float dx_inv) {
+  float r = x - (float)(int32_t)floorf(x * dx_inv + 0.5f) * dx; /* P2C2G.hpp:88 */
+  return 2.f / (dx * dx - 2 * r * r);                            /* :89 */
+}
+static inline int in_kernel_range(const float *posp, const float posc[3], float dx) { /* P2C2G.hpp:72-76 */
+  for (int d = 0; d < 3; ++d)
+    if (fabsf(posp[d] - posc[d]) > dx) return 0;
+  return 1;
+}
+
+void orc_mpm_p2c2g(const orc_mpm_params *p, int kind, const orc_bht *table, const orc_hashtable *buckets, const int32_t *offsets,
+                   const int32_t *indices, size_t n, const float *mass, const float *pos, const float *vel, const float *Bm,
+                   const float *Fm, float *logJp, float *grid) {
+  const float dx = p->dx, dx_inv = 1.0f / dx, dt = p->dt;
+  const int side = p->side, ncell = side * side * side;
+  float mu, lam;
+  orc_lame(p->E, p->nu, &mu, &lam);
+  /* per particle: contrib of P2C2G.hpp:94-146 (kind 0), :391 (kind 1: C Dinv mass), :589-644 (kind 2: stress only) */
+  float *Q = (float *)malloc(sizeof(float) * 9 * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) {
+    float Dinv[3], C[9], F[9], contrib[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < 3; ++d) Dinv[d] = dinv_axis(pos[3 * i + d], dx, dx_inv);
+    for (int d = 0; d < 9; ++d) C[d] = Bm[9 * i + d] * Dinv[d / 3];
+    if (kind != 1) {
+      memcpy(F, Fm + 9 * i, 36);
+      model_contrib(p, mu, lam, C, F, logJp ? logJp + i : NULL, contrib);
+      for (int d = 0; d < 9; ++d) contrib[d] *= Dinv[d / 3] * -dt;
+    }
+    if (kind != 2)
+      for (int d = 0; d < 9; ++d) contrib[d] += C[d] * mass[i];
+    memcpy(Q + 9 * i, contrib, 36);
+  }
+  const int32_t *keys = orc_bht_active_keys(table);
+  const int nblocks = orc_bht_size(table);
+  for (int b = 0; b < nblocks; ++b)
+    for (int cell = 0; cell < ncell; ++cell) {
+      int32_t coord[3] = {keys[3 * b] * side + cell / (side * side), keys[3 * b + 1] * side + (cell / side) % side,
+                          keys[3 * b + 2] * side + cell % side};
+      float posc[3], m_c = 0.f, mv_c[3] = {0, 0, 0}, Q_c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, QXp_c[3] = {0, 0, 0};
+      for (int d = 0; d < 3; ++d) posc[d] = ((float)coord[d] + 0.5f) * dx;
+      for (int o = 0; o < 27; ++o) {
+        int32_t bc[3] = {coord[0] - 1 + o / 9, coord[1] - 1 + (o / 3) % 3, coord[2] - 1 + o % 3};
+        const int32_t bno = orc_hashtable_query(buckets, bc);
+        if (bno < 0) continue;
+        for (int st = offsets[bno], ed = offsets[bno + 1]; st != ed; ++st) {
+          const int32_t id = indices[st];
+          const float *posp = pos + 3 * (size_t)id;
+          if (!in_kernel_range(posp, posc, dx)) continue;
+          const float *contrib = Q + 9 * (size_t)id;
+          float Wpc = 1.f;
+          for (int d = 0; d < 3; ++d) {
+            const float xabs = fabsf((posc[d] - posp[d]) * dx_inv);
+            Wpc *= (kind == 0 || xabs <= 1) ? 1.f - xabs : 0.f; /* P2C2G.hpp:151 (kind 0: no clamp), :396-402, :649-655 */
+          }
+          if (kind != 2) {
+            m_c += mass[id] * Wpc;
+            for (int d = 0; d < 3; ++d) mv_c[d] += mass[id] * vel[3 * (size_t)id + d] * Wpc;
+          }
+          for (int d = 0; d < 3; ++d)
+            QXp_c[d] += (contrib[d] * posp[0] + contrib[3 + d] * posp[1] + contrib[6 + d] * posp[2]) * Wpc;
+          for (int d = 0; d < 9; ++d) Q_c[d] += contrib[d] * Wpc;
+        }
+      }
+      /* stage 2 (c -> i), P2C2G.hpp:166-187 */
+      for (int o = 0; o < 8; ++o) {
+        int32_t ci[3] = {coord[0] + (o >> 2), coord[1] + ((o >> 1) & 1), coord[2] + (o & 1)};
+        const float posi[3] = {(float)ci[0] * dx, (float)ci[1] * dx, (float)ci[2] * dx};
+        int32_t cid;
+        const int bno = locate(table, ci, side, &cid);
+        if (bno < 0) continue;
+        float *blk = grid + (size_t)bno * 7 * (size_t)ncell;
+        const float Wci = 1.f / 8;
+        if (kind != 2) blk[cid] += m_c * Wci;
+        for (int d = 0; d < 3; ++d)
+          blk[(1 + d) * ncell + cid]
+              += (mv_c[d] + ((Q_c[d] * posi[0] + Q_c[3 + d] * posi[1] + Q_c[6 + d] * posi[2]) - QXp_c[d])) * Wci;
+      }
+    }
+  free(Q);
+}
+
+/* G2C2PTransfer (G2C2P.hpp:59-135): v_p and B_p are ACCUMULATED (PreG2C2PTransfer, :215-218, zeroes them first) */
+void orc_mpm_g2c2p(const orc_mpm_params *p, const orc_bht *table, const orc_hashtable *buckets, const int32_t *offsets,
+                   const int32_t *indices, const float *pos, float *vel, float *Bm, const float *grid) {
+  const float dx = p->dx, dx_inv = 1.0f / dx;
+  const int side = p->side, ncell = side * side * side;
+  const int32_t *keys = orc_bht_active_keys(table);
+  const int nblocks = orc_bht_size(table);
+  for (int b = 0; b < nblocks; ++b)
+    for (int cell = 0; cell < ncell; ++cell) {
+      int32_t coord[3] = {keys[3 * b] * side + cell / (side * side), keys[3 * b + 1] * side + (cell / side) % side,
+                          keys[3 * b + 2] * side + cell % side};
+      float v_c[3] = {0, 0, 0}, vx_c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, posc[3];
+      for (int o = 0; o < 8; ++o) {
+        int32_t ci[3] = {coord[0] + (o >> 2), coord[1] + ((o >> 1) & 1), coord[2] + (o & 1)};
+        const float posi[3] = {(float)ci[0] * dx, (float)ci[1] * dx, (float)ci[2] * dx};
+        int32_t cid;
+        const int bno = locate(table, ci, side, &cid);
+        if (bno < 0) continue;
+        const float *blk = grid + (size_t)bno * 7 * (size_t)ncell;
+        const float W = 1.f / 8;
+        const float v_i[3] = {blk[1 * ncell + cid], blk[2 * ncell + cid], blk[3 * ncell + cid]};
+        for (int d = 0; d < 3; ++d) v_c[d] += v_i[d] * W;
+        for (int d = 0; d < 9; ++d) vx_c[d] += W * v_i[d % 3] * posi[d / 3];
+      }
+      for (int d = 0; d < 3; ++d) posc[d] = ((float)coord[d] + 0.5f) * dx;
+      for (int o = 0; o < 27; ++o) {
+        int32_t bc[3] = {coord[0] - 1 + o / 9, coord[1] - 1 + (o / 3) % 3, coord[2] - 1 + o % 3};
+        const int32_t bno = orc_hashtable_query(buckets, bc);
+        if (bno < 0) continue;
+        for (int st = offsets[bno], ed = offsets[bno + 1]; st != ed; ++st) {
+          const int32_t id = indices[st];
+          const float *posp = pos + 3 * (size_t)id;
+          if (!in_kernel_range(posp, posc, dx)) continue;
+          float W = 1.f;
+          for (int d = 0; d < 3; ++d) {
+            const float xabs = fabsf((posc[d] - posp[d]) * dx_inv);
+            W *= xabs <= 1 ? 1.f - xabs : 0.f;
+          }
+          for (int d = 0; d < 3; ++d) vel[3 * (size_t)id + d] += v_c[d] * W;
+          for (int d = 0; d < 9; ++d) Bm[9 * (size_t)id + d] += W * (vx_c[d] - v_c[d % 3] * posp[d / 3]);
+        }
+      }
+    }
+}
+
+/* PostG2C2PTransfer (G2C2P.hpp:235-270) */
+void orc_mpm_post_g2c2p(const orc_mpm_params *p, size_t n, float *pos, const float *vel, const float *Bm, float *Fm) {
+  const float dx = p->dx, dx_inv = 1.0f / dx, dt = p->dt;
+  for (size_t i = 0; i < n; ++i) {
+    float C[9], Dinv[3];
+    for (int d = 0; d < 3; ++d) Dinv[d] = dinv_axis(pos[3 * i + d], dx, dx_inv);
+    for (int d = 0; d < 9; ++d) C[d] = Bm[9 * i + d] * Dinv[d / 3];
+    if (p->model == 4) {
+      Fm[9 * i] = (1 + (C[0] + C[4] + C[8]) * dt) * Fm[9 * i];
+    } else {
+      float tmp[9], oldF[9], F[9];
+      memcpy(oldF, Fm + 9 * i, 36);
+      for (int d = 0; d < 9; ++d) tmp[d] = C[d] * dt + ((d & 0x3) ? 0.f : 1.f);
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+          F[r + 3 * c] = tmp[r] * oldF[3 * c] + tmp[r + 3] * oldF[3 * c + 1] + tmp[r + 6] * oldF[3 * c + 2];
+      memcpy(Fm + 9 * i, F, 36);
+    }
+    for (int d = 0; d < 3; ++d) pos[3 * i + d] += vel[3 * i + d] * dt;
   }
 }

@@ -192,6 +192,15 @@ void orc_mpm_p2g(const orc_mpm_params *p, const orc_bht *table, size_t n, const 
 /* simulation/grid/GridOp.hpp:71-108 (v = mv/m + extf*dt; max |v|^2) */
 void orc_mpm_grid_update(const orc_mpm_params *p, size_t nblocks, float *grid, const float extf[3],
                          float *maxVelSqr);
+/* simulation/transfer/P2C2G.hpp:53-189 (kind 0 P2C2GTransfer), :346-439 (1 ...Momentum), :547-679 (2 ...Force); buckets = IndexBuckets of
+ * cell size dx, displacement 0; each particle's constitutive update is evaluated once (see mpm.c) */
+void orc_mpm_p2c2g(const orc_mpm_params *p, int kind, const orc_bht *table, const orc_hashtable *buckets, const int32_t *offsets,
+                   const int32_t *indices, size_t n, const float *mass, const float *pos, const float *vel, const float *B,
+                   const float *F, float *logJp, float *grid);
+/* simulation/transfer/G2C2P.hpp:59-135 (accumulates into vel / B), :235-270 */
+void orc_mpm_g2c2p(const orc_mpm_params *p, const orc_bht *table, const orc_hashtable *buckets, const int32_t *offsets,
+                   const int32_t *indices, const float *pos, float *vel, float *B, const float *grid);
+void orc_mpm_post_g2c2p(const orc_mpm_params *p, size_t n, float *pos, const float *vel, const float *B, float *F);
 /* simulation/transfer/G2P.hpp:44-83 */
 void orc_mpm_g2p(const orc_mpm_params *p, const orc_bht *table, size_t n, float *pos, float *vel,
                  float *C, float *F, const float *grid);

@@ -1,0 +1,154 @@
+"""GPU parity for the gather-style transfers P2C2G / G2C2P (simulation/transfer/P2C2G.hpp, G2C2P.hpp) vs the CPU oracle.
+
+Tolerances: the HIP path sums a node's 8 cells (and a particle's 8 cells) in a fixed order that differs from the oracle's
+cell-major order, and contracts a*b+c: grid channels to rel 2e-4 of the channel magnitude (5e-4 NACC, as for P2G), particle
+velocities / B to rel 2e-4, F to 2e-5.  The HIP path itself issues no float atomics: two runs agree bit for bit."""
+import numpy as np
+import pytest
+
+from util import rng, make_cloud, OracleMpm
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(ga, gb, rtol, chans):
+    assert set(ga.keys()) == set(gb.keys())
+    A = np.stack([ga[k] for k in sorted(ga)])
+    B = np.stack([gb[k] for k in sorted(ga)])
+    for ch in chans:
+        s = np.abs(B[:, ch]).max() + 1e-30
+        assert np.abs(A[:, ch] - B[:, ch]).max() <= rtol * s, (ch, np.abs(A[:, ch] - B[:, ch]).max() / s)
+
+
+def _setup(pol, oracle, side, model, seed, aos=False, key_is_origin=False, lane_width=64):
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Bm, F = make_cloud(7, dx, 2, seed=seed, vel_scale=0.3)
+    Bm = (Bm * dx * dx * 0.25).astype(np.float32)   # B = C / Dinv ~ C dx^2 / 4 .. dx^2 / 2
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    kw = dict(yield_stress=200.0, beta=0.5 if model == 3 else 1.0, bulk=4e4, viscosity=0.01)
+    if model == 4:
+        F = (1.0 + 0.01 * rng(seed + 1).standard_normal((n, 9))).astype(np.float32)   # J in component 0
+    om = OracleMpm(oracle, model, dx, dt, side, vol, **kw)
+    om.build_partition(pos, n)
+    om.build_buckets(pos)
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, lane_width=lane_width, aos=aos, key_is_origin=key_is_origin, **kw)
+    lj0 = (0.01 * rng(seed + 2).standard_normal(n)).astype(np.float32)
+    mt.upload(mass, pos, vel, Bm, F[:, :1] if model == 4 else F, lj0 if model in (1, 3) else None)
+    assert mt.build_partition(n) == om.nblocks
+    mt.build_buckets()
+    return om, mt, (mass, pos, vel, Bm, F, lj0)
+
+
+@pytest.mark.parametrize("side", [4, 8])
+@pytest.mark.parametrize("model,kind", [(0, 0), (0, 1), (0, 2), (1, 0), (2, 2), (3, 0), (4, 0)])
+def test_p2c2g_vs_oracle(pol, oracle, side, model, kind):
+    om, mt, (mass, pos, vel, Bm, F, lj0) = _setup(pol, oracle, side, model, seed=70 + side + model)
+    lj_o = om.p2c2g(kind, mass, pos, vel, Bm, F, lj0.copy())
+    mt.clear_grid()
+    mt.p2c2g(kind)
+    pol.syncCtx()
+    g1 = mt.grid.clone()
+    _cmp(mt.grid_by_key(), om.grid_by_key(), 5e-4 if model == 3 else 2e-4, range(4))
+    g = mt.grid.cpu().numpy().reshape(mt.nblocks, 7, side ** 3)
+    assert not g[:, 4:].any()                                     # channels 4..6 are not touched (P2C2G.hpp:176-186)
+    if kind != 2:   # conservation: the linear and the 1/8 weights are partitions of unity
+        assert abs(g[:, 0].sum() - mass.sum()) < 1e-4 * mass.sum()
+    else:
+        assert not g[:, 0].any()
+    if kind == 1:   # the affine term carries no net momentum
+        mom_p = (mass[:, None] * vel).sum(0)
+        assert np.abs(g[:, 1:4].sum(axis=(0, 2)) - mom_p).max() < 2e-3 * np.abs(mass[:, None] * vel).sum()
+    if model in (1, 3) and kind != 1:
+        assert np.abs(mt.download()["logJp"] - lj_o).max() < (2e-3 if model == 3 else 2e-5)
+    # no atomics anywhere: a second run (fresh logJp) reproduces the grid bit for bit
+    mt.upload(mass, pos, vel, Bm, F[:, :1] if model == 4 else F, lj0 if model in (1, 3) else None)
+    mt.clear_grid()
+    mt.p2c2g(kind)
+    pol.syncCtx()
+    assert torch.equal(g1, mt.grid)
+
+
+def test_p2c2g_adds_and_splits(pol, oracle):
+    """The transfer ADDS into the grid (atomic_add in the reference), and Transfer == Momentum + Force up to rounding."""
+    om, mt, (mass, pos, vel, Bm, F, lj0) = _setup(pol, oracle, 4, 0, seed=90)
+    mt.clear_grid()
+    mt.p2c2g(0)
+    pol.syncCtx()
+    full = mt.grid.clone()
+    mt.clear_grid()
+    mt.p2c2g(1)
+    mt.p2c2g(2)
+    pol.syncCtx()
+    s = full.abs().max().item()
+    assert (mt.grid - full).abs().max().item() < 1e-5 * s
+
+
+@pytest.mark.parametrize("variant", ["aos", "origin_keys", "lane32"])
+def test_p2c2g_layout_variants(pol, oracle, variant):
+    """AoS particle storage, SparseGrid-style block-origin keys and a 32-wide AoSoA give the same bits as the default layout."""
+    om, mt, data = _setup(pol, oracle, 8, 0, seed=95)
+    _, mt2, _ = _setup(pol, oracle, 8, 0, seed=95, aos=variant == "aos", key_is_origin=variant == "origin_keys",
+                       lane_width=32 if variant == "lane32" else 64)
+    for m in (mt, mt2):
+        m.clear_grid()
+        m.p2c2g(0)
+    pol.syncCtx()
+    ga, gb = mt.grid_by_key(), mt2.grid_by_key()
+    if variant == "origin_keys":
+        gb = {tuple(k // 8 for k in key): v for key, v in gb.items()}
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k])
+
+
+@pytest.mark.parametrize("side", [4, 8])
+@pytest.mark.parametrize("model", [0, 4])
+def test_g2c2p_vs_oracle(pol, oracle, side, model):
+    om, mt, (mass, pos, vel, Bm, F, lj0) = _setup(pol, oracle, side, model, seed=80 + side + model)
+    om.p2c2g(0, mass, pos, vel, Bm, F, lj0.copy())
+    mt.clear_grid()
+    mt.p2c2g(0)
+    om.grid_update((0.0, -9.8, 0.0))
+    mt.grid_update((0.0, -9.8, 0.0))
+    po, vo, Bo, Fo = pos.copy(), vel.copy(), Bm.copy(), F.copy()
+    om.g2c2p(po, vo, Bo, Fo)
+    mt.g2c2p()
+    pol.syncCtx()
+    d = mt.download()
+    assert np.abs(d["x"] - po).max() < 1e-6
+    assert np.abs(d["v"] - vo).max() < 2e-4 * np.abs(vo).max()
+    assert np.abs(d["C"] - Bo).max() < 2e-4 * np.abs(Bo).max() + 1e-9
+    if model == 4:
+        assert np.abs(d["J"][:, 0] - Fo[:, 0]).max() < 2e-5
+    else:
+        assert np.abs(d["F"] - Fo).max() < 2e-5
+
+
+def test_g2c2p_reproduces_affine_field(pol, oracle):
+    """Size-independent property: for grid velocities v_i = A x_i + b the transfer returns v_p = A x_p + b and, with
+    C = B Dinv, the velocity gradient A itself (the point of the Dinv factor of P2C2G.hpp:88-89)."""
+    om, mt, (mass, pos, vel, Bm, F, lj0) = _setup(pol, oracle, 4, 0, seed=99)
+    dx, nc = mt.params.dx, 64
+    A = np.array([[0.3, -0.2, 0.1], [0.05, 0.4, -0.3], [-0.1, 0.2, 0.25]], np.float32)
+    b = np.array([0.5, -0.25, 0.125], np.float32)
+    keys = mt.active_keys()
+    loc = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    xi = ((keys[:, None, :] * 4 + loc[None]) * dx).astype(np.float32)             # [nb, 64, 3]
+    v = xi @ A.T + b
+    g = np.zeros((mt.nblocks, 7, nc), np.float32)
+    g[:, 1:4] = v.transpose(0, 2, 1)
+    mt.grid.copy_(torch.from_numpy(g.reshape(-1)).cuda())
+    mt.params.dt = 0.0   # keep x and F: look at v and B only
+    mt.g2c2p()
+    pol.syncCtx()
+    d = mt.download()
+    want = pos @ A.T + b
+    assert np.abs(d["v"] - want).max() < 2e-5
+    r = pos - np.floor(pos / dx + 0.5) * dx
+    Dinv = 2.0 / (dx * dx - 2 * r * r)                                              # per axis
+    Cm = d["C"].reshape(-1, 3, 3) * Dinv[:, :, None]                                # C[d] *= Dinv[d / 3], column-major: C[r + 3 c]
+    grad = Cm.transpose(0, 2, 1)                                                     # [n][r][c]
+    assert np.abs(grad - A[None]).max() < 2e-3

@@ -109,6 +109,32 @@ class OracleMpm:
         n = pos.shape[0]
         self.o.orc_mpm_g2p(C.byref(self.p), self.table, C.c_size_t(n), ptr(pos), ptr(vel), ptr(Cm), ptr(F), ptr(self.grid))
 
+    # ---- gather-style transfers (oracle/mpm.c: orc_mpm_p2c2g / orc_mpm_g2c2p / orc_mpm_post_g2c2p)
+    def build_buckets(self, pos):
+        """IndexBuckets of cell size dx, displacement 0 (sequential policy: ascending ids per bucket)."""
+        n = pos.shape[0]
+        I32P = C.POINTER(C.c_int32)
+        self.o.orc_index_buckets_for_particles.restype = C.c_void_p
+        self._ib = (I32P(), I32P(), I32P())
+        self.buckets = C.c_void_p(self.o.orc_index_buckets_for_particles(ptr(pos), C.c_size_t(n), C.c_float(self.p.dx), C.c_float(0.0),
+                                                                         C.c_size_t(0), C.byref(self._ib[0]), C.byref(self._ib[1]),
+                                                                         C.byref(self._ib[2])))
+
+    def p2c2g(self, kind, mass, pos, vel, Bm, F, logJp=None):
+        n = pos.shape[0]
+        lj = np.zeros(n, np.float32) if logJp is None else logJp
+        self.o.orc_mpm_p2c2g(C.byref(self.p), int(kind), self.table, self.buckets, self._ib[1], self._ib[2], C.c_size_t(n), ptr(mass),
+                             ptr(pos), ptr(vel), ptr(Bm), ptr(F), ptr(lj), ptr(self.grid))
+        return lj
+
+    def g2c2p(self, pos, vel, Bm, F):
+        """Pre + G2C2P + Post on AoS arrays, in place."""
+        n = pos.shape[0]
+        vel[:] = 0
+        Bm[:] = 0
+        self.o.orc_mpm_g2c2p(C.byref(self.p), self.table, self.buckets, self._ib[1], self._ib[2], ptr(pos), ptr(vel), ptr(Bm), ptr(self.grid))
+        self.o.orc_mpm_post_g2c2p(C.byref(self.p), C.c_size_t(n), ptr(pos), ptr(vel), ptr(Bm), ptr(F))
+
     def grid_by_key(self):
         return {tuple(int(x) for x in self.keys[i]): self.grid[i] for i in range(self.nblocks)}
 

@@ -298,6 +298,12 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
+    L.zs_rocm_mpm_p2c2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, i32]
+    L.zs_rocm_mpm_p2c2g.restype = i32
+    L.zs_rocm_mpm_pre_g2c2p.argtypes = [vp, Particles]
+    L.zs_rocm_mpm_g2c2p.argtypes = [vp, PP, Particles, vp, vp, vp, sz]
+    L.zs_rocm_mpm_g2c2p.restype = i32
+    L.zs_rocm_mpm_post_g2c2p.argtypes = [vp, PP, Particles]
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
     L.zs_rocm_mpm_update_stress.argtypes = [vp, PP, Particles]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]

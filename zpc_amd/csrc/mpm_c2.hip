@@ -1,0 +1,361 @@
+// mpm_c2.hip -- the gather-style transfers: P2C2GTransfer / P2C2GTransferMomentum / P2C2GTransferForce
+// (simulation/transfer/P2C2G.hpp:53-189, :346-439, :547-679) and PreG2C2P / G2C2P / PostG2C2P (simulation/transfer/G2C2P.hpp:59-135,
+// :208-275).  Linear particle <-> cell-centre weights, 1/8 cell <-> node weights.
+//
+// The reference runs one functor over Collapse{nblocks, side^3}: per cell it walks the 27 IndexBuckets around the cell, evaluates the
+// constitutive model of every particle in range (again for each of the up to 8 cells that see the particle) and then does float
+// atomics into the 8 nodes (P2C2G) or into the particles (G2C2P).  Here every stage is a gather, so no float atomic is issued and a run
+// is reproducible bit for bit:
+//   P2C2G  1. per particle: constitutive update ONCE, 64-byte record {pos, mass, mass*vel, Q}          (c2_particle_kernel)
+//          2. per cell: walk the 27 buckets, sum the 16 cell moments                                   (p2c2g_cell_kernel)
+//          3. per node: sum the 8 cells around the node, add to the grid                               (p2c2g_node_kernel)
+//   G2C2P  1. per cell: v_c and v_c (x) x_i from the 8 nodes                                            (g2c2p_cell_kernel)
+//          2. per particle: sum over the cells in range, add to v_p / B_p                              (g2c2p_particle_kernel)
+// Evaluating the plastic models once per particle also removes the reference's order dependence (its functor stores logJp up to 8
+// times per particle and later cells read the updated value).
+#include "mpm_device.hpp"
+#include "hashtable.hpp"
+
+using namespace zsr;
+
+namespace {
+
+constexpr int C2_TRANSFER = 0, C2_MOMENTUM = 1, C2_FORCE = 2;
+
+__device__ __forceinline__ float c2_dinv(float x, float dx, float dxi) {
+  const float r = x - (float)(int)floorf(x * dxi + 0.5f) * dx;  // P2C2G.hpp:88
+  return 2.f / (dx * dx - 2 * r * r);                            // :89
+}
+
+// ---- P2C2G stage 1: per particle
+template <int MODEL, int KIND>
+__global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDev ps, float4 *rec) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float dx = mp.dx, dxi = 1.0f / dx;
+  float pos[3], vel[3] = {0.f, 0.f, 0.f}, C[9], Q[9], Dinv[3];
+  load_attr<3>(ps.pos, i, pos);
+  load_attr<9>(ps.C, i, C);
+  const float mass = ps.mass.base[ps.mass.off(i)];
+  if constexpr (KIND != C2_FORCE) load_attr<3>(ps.vel, i, vel);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) Dinv[d] = c2_dinv(pos[d], dx, dxi);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) C[d] *= Dinv[d / 3];
+  if constexpr (KIND == C2_MOMENTUM) {
+#pragma unroll
+    for (int d = 0; d < 9; ++d) Q[d] = C[d] * mass;  // P2C2G.hpp:391
+  } else {
+    float F[9];
+    load_state<model_is_fluid(MODEL)>(ps.F, i, F);
+    float lj = 0.f;
+    if constexpr (model_uses_logjp(MODEL)) lj = ps.logJp.base[ps.logJp.off(i)];
+    model_stress<MODEL>(mp.mat, lj, F, Q, C);
+    if constexpr (model_uses_logjp(MODEL)) ps.logJp.base[ps.logJp.off(i)] = lj;  // P2C2G.hpp:140
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      Q[d] *= Dinv[d / 3] * -mp.dt;                            // :144
+      if constexpr (KIND == C2_TRANSFER) Q[d] += C[d] * mass;  // :146
+    }
+  }
+  float4 *r = rec + 4 * i;
+  r[0] = make_float4(pos[0], pos[1], pos[2], mass);
+  r[1] = make_float4(mass * vel[0], mass * vel[1], mass * vel[2], Q[0]);
+  r[2] = make_float4(Q[1], Q[2], Q[3], Q[4]);
+  r[3] = make_float4(Q[5], Q[6], Q[7], Q[8]);
+}
+
+// block key (in the table's convention) and cell coordinate of cell `cell` of block b
+template <int SIDE> __device__ __forceinline__ void c2_cell_coord(const BhtDev &t, int b, int cell, int kscale, int (&coord)[3]) {
+  const int cs = SIDE / kscale;  // keys are block coordinates (kscale 1) or block origins in cells (kscale SIDE)
+  coord[0] = t.activeKeys[3 * (size_t)b] * cs + cell / (SIDE * SIDE);
+  coord[1] = t.activeKeys[3 * (size_t)b + 1] * cs + (cell / SIDE) % SIDE;
+  coord[2] = t.activeKeys[3 * (size_t)b + 2] * cs + cell % SIDE;
+}
+
+// ---- P2C2G stage 2: per cell, the 16 moments m_c, mv_c, Q_c, (Q x_p)_c  (P2C2G.hpp:66-163); sums[b][16][NC]
+template <int SIDE, int KIND>
+__global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets, const int *indices,
+                                                         const float4 *rec, float *sums, int nblocks) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nblocks * NC) return;
+  const int b = (int)(g / NC), cell = (int)(g % NC);
+  const float dx = mp.dx, dxi = 1.0f / dx;
+  int coord[3];
+  c2_cell_coord<SIDE>(t, b, cell, mp.kscale, coord);
+  const float pc0 = ((float)coord[0] + 0.5f) * dx, pc1 = ((float)coord[1] + 0.5f) * dx, pc2 = ((float)coord[2] + 0.5f) * dx;
+  float m_c = 0.f, mv[3] = {0.f, 0.f, 0.f}, Qc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, QX[3] = {0.f, 0.f, 0.f};
+  for (int o = 0; o < 27; ++o) {
+    const int bc[3] = {coord[0] - 1 + o / 9, coord[1] - 1 + (o / 3) % 3, coord[2] - 1 + o % 3};
+    const int bno = ht_query<3>(buckets, bc);
+    if (bno < 0) continue;
+    for (int st = offsets[bno], ed = offsets[bno + 1]; st != ed; ++st) {
+      const float4 *r = rec + 4 * (size_t)indices[st];
+      const float4 r0 = r[0];
+      const float d0 = pc0 - r0.x, d1 = pc1 - r0.y, d2 = pc2 - r0.z;
+      if (fabsf(d0) > dx || fabsf(d1) > dx || fabsf(d2) > dx) continue;  // checkInKernelRange, :72-76
+      const float4 r1 = r[1], r2 = r[2], r3 = r[3];
+      const float a0 = fabsf(d0 * dxi), a1 = fabsf(d1 * dxi), a2 = fabsf(d2 * dxi);
+      float W = 1.f;
+      if constexpr (KIND == C2_TRANSFER) {  // :149-151
+        W *= 1.f - a0; W *= 1.f - a1; W *= 1.f - a2;
+      } else {  // :396-402, :649-655
+        W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;
+      }
+      const float Q[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+      if constexpr (KIND != C2_FORCE) {
+        m_c += r0.w * W;
+        mv[0] += r1.x * W; mv[1] += r1.y * W; mv[2] += r1.z * W;
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) QX[d] += (Q[d] * r0.x + Q[3 + d] * r0.y + Q[6 + d] * r0.z) * W;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) Qc[d] += Q[d] * W;
+    }
+  }
+  float *s = sums + (size_t)b * 16 * NC + cell;
+  s[0] = m_c;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) s[(1 + d) * NC] = mv[d];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) s[(4 + d) * NC] = Qc[d];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) s[(13 + d) * NC] = QX[d];
+}
+
+// ---- P2C2G stage 3: per node, the 8 cells node - {0,1}^3  (the gather form of :166-187).  One workgroup per block.
+template <int SIDE, int KIND>
+__global__ __launch_bounds__(256) void p2c2g_node_kernel(MpmDev mp, BhtDev t, const float *sums, float *grid) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  __shared__ int nb[8];  // block number of key - {0,1}^3, x-major
+  const int b = blockIdx.x;
+  if (threadIdx.x < 8) {
+    const int o = threadIdx.x;
+    int k[3] = {t.activeKeys[3 * (size_t)b] - (o >> 2) * mp.kscale, t.activeKeys[3 * (size_t)b + 1] - ((o >> 1) & 1) * mp.kscale,
+                t.activeKeys[3 * (size_t)b + 2] - (o & 1) * mp.kscale};
+    nb[o] = o ? bht_query<3>(t, k) : b;
+  }
+  __syncthreads();
+  const float dx = mp.dx;
+  for (int cell = threadIdx.x; cell < NC; cell += blockDim.x) {
+    int ci[3];
+    c2_cell_coord<SIDE>(t, b, cell, mp.kscale, ci);
+    const float p0 = (float)ci[0] * dx, p1 = (float)ci[1] * dx, p2 = (float)ci[2] * dx;  // posi, :171
+    const int lx = cell / (SIDE * SIDE), ly = (cell / SIDE) % SIDE, lz = cell % SIDE;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 7; o >= 0; --o) {  // cell = node - (o bits): ascending cell coordinate
+      const int x = lx - (o >> 2), y = ly - ((o >> 1) & 1), z = lz - (o & 1);
+      const int w = ((x < 0) << 2) | ((y < 0) << 1) | (z < 0);
+      const int bn = nb[w];
+      if (bn < 0) continue;  // that cell's block is not in the partition: the reference's launch range has no such cell
+      const float *s = sums + (size_t)bn * 16 * NC + (((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1)));
+      constexpr float Wci = 1.f / 8;
+      if constexpr (KIND != C2_FORCE) acc[0] += s[0] * Wci;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float mvd = KIND != C2_FORCE ? s[(1 + d) * NC] : 0.f;
+        const float lin = (s[(4 + d) * NC] * p0 + s[(7 + d) * NC] * p1 + s[(10 + d) * NC] * p2) - s[(13 + d) * NC];
+        acc[1 + d] += (KIND != C2_FORCE ? mvd + lin : lin) * Wci;
+      }
+    }
+    float *gp = grid + (size_t)b * 7 * NC + cell;
+    if constexpr (KIND != C2_FORCE) gp[0] += acc[0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gp[(1 + d) * NC] += acc[1 + d];
+  }
+}
+
+// ---- G2C2P stage 1: per cell v_c, v_c (x) x_i from the nodes cell + {0,1}^3  (G2C2P.hpp:69-90); cv[b][12][NC]
+template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_cell_kernel(MpmDev mp, BhtDev t, const float *grid, float *cv) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  __shared__ int nb[8];  // block number of key + {0,1}^3
+  const int b = blockIdx.x;
+  if (threadIdx.x < 8) {
+    const int o = threadIdx.x;
+    int k[3] = {t.activeKeys[3 * (size_t)b] + (o >> 2) * mp.kscale, t.activeKeys[3 * (size_t)b + 1] + ((o >> 1) & 1) * mp.kscale,
+                t.activeKeys[3 * (size_t)b + 2] + (o & 1) * mp.kscale};
+    nb[o] = o ? bht_query<3>(t, k) : b;
+  }
+  __syncthreads();
+  const float dx = mp.dx;
+  for (int cell = threadIdx.x; cell < NC; cell += blockDim.x) {
+    int coord[3];
+    c2_cell_coord<SIDE>(t, b, cell, mp.kscale, coord);
+    const int lx = cell / (SIDE * SIDE), ly = (cell / SIDE) % SIDE, lz = cell % SIDE;
+    float v[3] = {0.f, 0.f, 0.f}, vx[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int x = lx + (o >> 2), y = ly + ((o >> 1) & 1), z = lz + (o & 1);
+      const int w = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+      const int bn = nb[w];
+      if (bn < 0) continue;  // :82
+      const float *gp = grid + (size_t)bn * 7 * NC + (((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1)));
+      const float posi[3] = {(float)(coord[0] + (o >> 2)) * dx, (float)(coord[1] + ((o >> 1) & 1)) * dx, (float)(coord[2] + (o & 1)) * dx};
+      const float vi[3] = {gp[1 * NC], gp[2 * NC], gp[3 * NC]};
+      constexpr float W = 1.f / 8;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[d] += vi[d] * W;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) vx[d] += W * vi[d % 3] * posi[d / 3];
+    }
+    float *c = cv + (size_t)b * 12 * NC + cell;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d * NC] = v[d];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) c[(3 + d) * NC] = vx[d];
+  }
+}
+
+// ---- G2C2P stage 2: per particle, the cells whose centre is within dx  (the gather form of :92-131).  Adds to v_p and B_p like the
+// reference's atomics (PreG2C2PTransfer zeroes them).  Cells floor(x/dx - 0.5) + {0,1}^3: a third cell per axis can only pass the range
+// check with a weight that rounds to 0.
+template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_particle_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *cv) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float dx = mp.dx, dxi = 1.0f / dx;
+  float pos[3], v[3], B[9];
+  load_attr<3>(ps.pos, i, pos);
+  load_attr<3>(ps.vel, i, v);
+  load_attr<9>(ps.C, i, B);
+  int c0[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) c0[d] = (int)floorf(pos[d] * dxi - 0.5f);
+  int lastKey[3] = {0, 0, 0}, lastBlk = -2;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const int c[3] = {c0[0] + (o >> 2), c0[1] + ((o >> 1) & 1), c0[2] + (o & 1)};
+    const float d0 = ((float)c[0] + 0.5f) * dx - pos[0], d1 = ((float)c[1] + 0.5f) * dx - pos[1], d2 = ((float)c[2] + 0.5f) * dx - pos[2];
+    if (fabsf(d0) > dx || fabsf(d1) > dx || fabsf(d2) > dx) continue;
+    int key[3], loc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      loc[d] = c[d] & (SIDE - 1);
+      key[d] = (c[d] - loc[d]) / SIDE * mp.kscale;
+    }
+    if (lastBlk == -2 || key[0] != lastKey[0] || key[1] != lastKey[1] || key[2] != lastKey[2]) {
+      lastBlk = bht_query<3>(t, key);
+      lastKey[0] = key[0]; lastKey[1] = key[1]; lastKey[2] = key[2];
+    }
+    if (lastBlk < 0) continue;
+    const float a0 = fabsf(d0 * dxi), a1 = fabsf(d1 * dxi), a2 = fabsf(d2 * dxi);
+    float W = 1.f;
+    W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;  // :109-115
+    const float *cp = cv + (size_t)lastBlk * 12 * NC + ((loc[0] * SIDE + loc[1]) * SIDE + loc[2]);
+    const float vc[3] = {cp[0], cp[NC], cp[2 * NC]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v[d] += vc[d] * W;  // :120
+#pragma unroll
+    for (int d = 0; d < 9; ++d) B[d] += W * (cp[(3 + d) * NC] - vc[d % 3] * pos[d / 3]);  // :122-124
+  }
+  store_attr<3>(ps.vel, i, v);
+  store_attr<9>(ps.C, i, B);
+}
+
+__global__ __launch_bounds__(256) void pre_g2c2p_kernel(ParticlesDev ps) {  // G2C2P.hpp:215-218
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float z3[3] = {0.f, 0.f, 0.f}, z9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  store_attr<3>(ps.vel, i, z3);
+  store_attr<9>(ps.C, i, z9);
+}
+
+template <bool FLUID> __global__ __launch_bounds__(256) void post_g2c2p_kernel(MpmDev mp, ParticlesDev ps) {  // G2C2P.hpp:235-270
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  const float dx = mp.dx, dxi = 1.0f / dx;
+  float pos[3], vel[3], C[9], oldF[9], F[9];
+  load_attr<3>(ps.pos, i, pos);
+  load_attr<3>(ps.vel, i, vel);
+  load_attr<9>(ps.C, i, C);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) C[d] *= c2_dinv(pos[d / 3], dx, dxi);
+  load_state<FLUID>(ps.F, i, oldF);
+  advance_state<FLUID>(oldF, C, mp.dt, F);
+  if constexpr (FLUID) ps.F.base[ps.F.off(i)] = F[0];
+  else store_attr<9>(ps.F, i, F);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) pos[d] += vel[d] * mp.dt;
+  store_attr<3>(ps.pos, i, pos);
+}
+
+}  // namespace
+
+extern "C" {
+
+int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_index_buckets *buckets,
+                      const zs_rocm_bht_3 *tab, float *grid, size_t nblocks, int kind) {
+  if (kind < C2_TRANSFER || kind > C2_FORCE || (p->side != 4 && p->side != 8)) return -1;
+  if (kind != C2_MOMENTUM && (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE)) return -1;
+  if (!ps.n || !nblocks) return 0;
+  if (!buckets || !buckets->table || !buckets->offsets || !buckets->indices || (size_t)buckets->numEntries != ps.n) {
+    fprintf(stderr, "[zs_rocm] p2c2g needs the IndexBuckets of these particles (index_buckets_for_particles, cell size dx, displacement 0)\n");
+    return -1;
+  }
+  Launch L(pol, "P2C2GTransfer");
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const size_t nc = (size_t)p->side * p->side * p->side;
+  float4 *rec = (float4 *)L.temp(sizeof(float4) * 4 * ps.n);
+  float *sums = (float *)L.temp(sizeof(float) * 16 * nc * nblocks);
+  const dim3 pg(ceil_div(ps.n, 256)), blk(256);
+#define CALL_C2_PARTICLE(S, M) \
+  if (kind == C2_TRANSFER) hipLaunchKernelGGL((c2_particle_kernel<M, C2_TRANSFER>), pg, blk, 0, L.stream, mp, pd, rec); \
+  else hipLaunchKernelGGL((c2_particle_kernel<M, C2_FORCE>), pg, blk, 0, L.stream, mp, pd, rec)
+  if (kind == C2_MOMENTUM) hipLaunchKernelGGL((c2_particle_kernel<ZS_MPM_FIXED_COROTATED, C2_MOMENTUM>), pg, blk, 0, L.stream, mp, pd, rec);
+  else { ZSR_DISPATCH_PURE_(0, p->model, CALL_C2_PARTICLE) }
+  const HtDev bk = buckets->table->dev();
+  const dim3 cg(ceil_div(nc * nblocks, 256));
+#define CALL_C2_CELLS(S, K)                                                                                                             \
+  hipLaunchKernelGGL((p2c2g_cell_kernel<S, K>), cg, blk, 0, L.stream, mp, t, bk, (const int *)buckets->offsets,                           \
+                     (const int *)buckets->indices, (const float4 *)rec, sums, (int)nblocks);                                            \
+  hipLaunchKernelGGL((p2c2g_node_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, (const float *)sums, grid)
+#define CALL_C2_KIND(S)                                    \
+  if (kind == C2_TRANSFER) { CALL_C2_CELLS(S, C2_TRANSFER); } \
+  else if (kind == C2_MOMENTUM) { CALL_C2_CELLS(S, C2_MOMENTUM); } \
+  else { CALL_C2_CELLS(S, C2_FORCE); }
+  if (p->side == 4) { CALL_C2_KIND(4) } else { CALL_C2_KIND(8) }
+  return 0;
+}
+
+void zs_rocm_mpm_pre_g2c2p(zs_rocm_policy *pol, zs_rocm_particles ps) {
+  Launch L(pol, "PreG2C2PTransfer");
+  if (!ps.n) return;
+  hipLaunchKernelGGL(pre_g2c2p_kernel, dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, make_particles(ps));
+}
+
+int zs_rocm_mpm_g2c2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_index_buckets *buckets,
+                      const zs_rocm_bht_3 *tab, const float *grid, size_t nblocks) {
+  (void)buckets;  // the particle side is a gather too: the buckets of the reference functor are not needed
+  if (p->side != 4 && p->side != 8) return -1;
+  if (!ps.n || !nblocks) return 0;
+  Launch L(pol, "G2C2PTransfer");
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const size_t nc = (size_t)p->side * p->side * p->side;
+  float *cv = (float *)L.temp(sizeof(float) * 12 * nc * nblocks);
+  if (p->side == 4) {
+    hipLaunchKernelGGL((g2c2p_cell_kernel<4>), dim3((unsigned)nblocks), dim3(64), 0, L.stream, mp, t, grid, cv);
+    hipLaunchKernelGGL((g2c2p_particle_kernel<4>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, (const float *)cv);
+  } else {
+    hipLaunchKernelGGL((g2c2p_cell_kernel<8>), dim3((unsigned)nblocks), dim3(256), 0, L.stream, mp, t, grid, cv);
+    hipLaunchKernelGGL((g2c2p_particle_kernel<8>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, (const float *)cv);
+  }
+  return 0;
+}
+
+void zs_rocm_mpm_post_g2c2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {
+  Launch L(pol, "PostG2C2PTransfer");
+  if (!ps.n) return;
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  if (p->model == ZS_MPM_EQUATION_OF_STATE)
+    hipLaunchKernelGGL((post_g2c2p_kernel<true>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
+  else hipLaunchKernelGGL((post_g2c2p_kernel<false>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd);
+}
+
+}  // extern "C"

@@ -202,6 +202,31 @@ class MpmTransfer:
         lib().zs_rocm_mpm_g2p(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
                               self.nblocks, bs, cc, nb)
 
+    # ------------------------------------------------------------------ gather-style transfers (P2C2G.hpp / G2C2P.hpp)
+    def build_buckets(self):
+        """IndexBuckets of cell size dx over the current positions (index_buckets_for_particles, displacement 0): bucket = the cell
+        that contains the particle, which is what P2C2GTransfer's 27-bucket walk expects."""
+        from .containers import IndexBuckets
+        self.buckets = IndexBuckets()
+        self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=0.0)
+        return self.buckets
+
+    def p2c2g(self, kind=0):
+        """kind 0 P2C2GTransfer, 1 P2C2GTransferMomentum, 2 P2C2GTransferForce; ADDS into grid channels m, mv."""
+        if lib().zs_rocm_mpm_p2c2g(self.pol.handle, C.byref(self.params), self.particles(), self.buckets._h, self.table.handle,
+                                   self.grid.data_ptr(), self.nblocks, int(kind)) != 0:
+            raise RuntimeError("zs_rocm_mpm_p2c2g refused its arguments")
+
+    def g2c2p(self):
+        """PreG2C2PTransfer + G2C2PTransfer + PostG2C2PTransfer: v, B (= C) from the grid, then F (or J) and x advance."""
+        L = lib()
+        L.zs_rocm_mpm_pre_g2c2p(self.pol.handle, self.particles())
+        if L.zs_rocm_mpm_g2c2p(self.pol.handle, C.byref(self.params), self.particles(), None, self.table.handle, self.grid.data_ptr(),
+                               self.nblocks) != 0:
+            raise RuntimeError("zs_rocm_mpm_g2c2p refused its arguments")
+        L.zs_rocm_mpm_post_g2c2p(self.pol.handle, C.byref(self.params), self.particles())
+        self.binned = False
+
     def g2p2g(self, write_all=False, split=None, between=None, reorder=False):
         """Fused G2P (from self.grid) + P2G (into a zeroed second grid, which then becomes self.grid): zs_rocm_mpm_g2p2g.
         Needs cache_stress=True and binned particles.  split=k: blocks [0, k) are launched first, `between()` is called (the
