@@ -23,4 +23,5 @@ struct zs_rocm_index_buckets {
   int *indices = nullptr, *offsets = nullptr, *counts = nullptr;
   int numBuckets = 0, numEntries = 0;
   float dx = 1.f;
+  float displacement = 0.5f;  // coord_offset the buckets were built with (Query.tpp:11)
 };

@@ -36,6 +36,7 @@ void zs_rocm_index_buckets_get_view(const zs_rocm_index_buckets *ib, zs_rocm_ind
 void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buckets *ib, zs_rocm_attr pos, size_t n, float dx,
                                          float displacement, size_t expectedCells) {
   ib->dx = dx;
+  ib->displacement = displacement;
   if (ib->table) zs_rocm_hashtable_destroy(ib->table);
   ib->table = zs_rocm_hashtable_create(3, expectedCells ? expectedCells : n, 1, 0);  // Query.tpp:27 (created reset)
   (void)hipFree(ib->indices); (void)hipFree(ib->offsets); (void)hipFree(ib->counts);

@@ -6,7 +6,8 @@
 // constitutive model of every particle in range (again for each of the up to 8 cells that see the particle) and then does float
 // atomics into the 8 nodes (P2C2G) or into the particles (G2C2P).  Here every stage is a gather, so no float atomic is issued and a run
 // is reproducible bit for bit:
-//   P2C2G  1. per particle: constitutive update ONCE, 64-byte record {pos, mass, mass*vel, Q}          (c2_particle_kernel)
+//   P2C2G  0. per bucket: order the bucket's particles by octant                                     (c2_octant_kernel)
+//          1. per particle: constitutive update ONCE, 64-byte record {pos, mass, mass*vel, Q} in bucket order (c2_particle_kernel)
 //          2. per cell: walk the 27 buckets, sum the 16 cell moments                                   (p2c2g_cell_kernel)
 //          3. per node: sum the 8 cells around the node, add to the grid                               (p2c2g_node_kernel)
 //   G2C2P  1. per cell: v_c and v_c (x) x_i from the 8 nodes                                            (g2c2p_cell_kernel)
@@ -27,11 +28,50 @@ __device__ __forceinline__ float c2_dinv(float x, float dx, float dxi) {
   return 2.f / (dx * dx - 2 * r * r);                            // :89
 }
 
-// ---- P2C2G stage 1: per particle
+// ---- P2C2G stage 0: per bucket, order the bucket's particles by the octant of the cell they sit in (stable: ascending id inside an
+// octant).  A cell at offset -1 / +1 from a bucket along an axis can only be reached by the particles in the upper / lower half of the
+// bucket along that axis (|x_p - x_c| <= dx), so the cell kernel walks 64 instead of 216 candidates per cell.  sub[b]: byte k = number of
+// particles of the bucket in octants < k (code = 4 hx + 2 hy + hz); ~0 = not ordered (more than 255 particles in the bucket, or buckets that are
+// not the cells of this grid: then every bucket is walked whole and only the range check decides).
+__device__ __forceinline__ int c2_octant(const Port<float> &pos, size_t i, float dxi) {
+  float p[3];
+  load_attr<3>(pos, i, p);
+  int code = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float X = p[d] * dxi;
+    code = code * 2 + (X - floorf(X) >= 0.5f ? 1 : 0);
+  }
+  return code;
+}
+__global__ __launch_bounds__(256) void c2_octant_kernel(Port<float> pos, float dxi, const int *offsets, const int *indices, int nbuckets,
+                                                        int canOrder, int *sorted, unsigned long long *sub) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const int st = offsets[b], ed = offsets[b + 1];
+  if (!canOrder || ed - st > 255) {
+    for (int k = st; k < ed; ++k) sorted[k] = indices[k];
+    sub[b] = ~0ull;
+    return;
+  }
+  unsigned long long counts = 0;
+  for (int k = st; k < ed; ++k) counts += 1ull << (8 * c2_octant(pos, (size_t)indices[k], dxi));
+  const unsigned long long excl = (counts * 0x0101010101010101ull) << 8;  // bytewise exclusive prefix sum (total <= 255: no carry)
+  unsigned long long cur = excl;
+  for (int k = st; k < ed; ++k) {
+    const int id = indices[k], sh = 8 * c2_octant(pos, (size_t)id, dxi);
+    sorted[st + (int)((cur >> sh) & 255)] = id;
+    cur += 1ull << sh;
+  }
+  sub[b] = excl;
+}
+
+// ---- P2C2G stage 1: per particle, in bucket order (slot s of IndexBuckets::indices)
 template <int MODEL, int KIND>
-__global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDev ps, float4 *rec) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ps.n) return;
+__global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDev ps, const int *indices, float4 *rec) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= ps.n) return;
+  const size_t i = (size_t)indices[slot];  // records are laid out in bucket order: a bucket's particles are one contiguous run
   const float dx = mp.dx, dxi = 1.0f / dx;
   float pos[3], vel[3] = {0.f, 0.f, 0.f}, C[9], Q[9], Dinv[3];
   load_attr<3>(ps.pos, i, pos);
@@ -58,7 +98,7 @@ __global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDe
       if constexpr (KIND == C2_TRANSFER) Q[d] += C[d] * mass;  // :146
     }
   }
-  float4 *r = rec + 4 * i;
+  float4 *r = rec + 4 * slot;
   r[0] = make_float4(pos[0], pos[1], pos[2], mass);
   r[1] = make_float4(mass * vel[0], mass * vel[1], mass * vel[2], Q[0]);
   r[2] = make_float4(Q[1], Q[2], Q[3], Q[4]);
@@ -73,55 +113,83 @@ template <int SIDE> __device__ __forceinline__ void c2_cell_coord(const BhtDev &
   coord[2] = t.activeKeys[3 * (size_t)b + 2] * cs + cell % SIDE;
 }
 
-// ---- P2C2G stage 2: per cell, the 16 moments m_c, mv_c, Q_c, (Q x_p)_c  (P2C2G.hpp:66-163); sums[b][16][NC]
+// ---- P2C2G stage 2: per cell, the 16 moments m_c, mv_c, Q_c, (Q x_p)_c  (P2C2G.hpp:66-163); sums[b][16][NC].  One workgroup per
+// block: the bucket ranges of the (SIDE+2)^3 cells around the block are looked up once (one hash probe per halo cell instead of 27 per
+// cell) and kept in LDS together with the octant offsets of stage 0.
 template <int SIDE, int KIND>
-__global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets, const int *indices,
-                                                         const float4 *rec, float *sums, int nblocks) {
-  constexpr int NC = SIDE * SIDE * SIDE;
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nblocks * NC) return;
-  const int b = (int)(g / NC), cell = (int)(g % NC);
+__global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets,
+                                                         const unsigned long long *sub, const float4 *rec, float *sums) {
+  constexpr int NC = SIDE * SIDE * SIDE, H = SIDE + 2, NH = H * H * H;
+  __shared__ int2 range[NH];
+  __shared__ unsigned long long octs[NH];
+  const int b = blockIdx.x;
   const float dx = mp.dx, dxi = 1.0f / dx;
-  int coord[3];
-  c2_cell_coord<SIDE>(t, b, cell, mp.kscale, coord);
-  const float pc0 = ((float)coord[0] + 0.5f) * dx, pc1 = ((float)coord[1] + 0.5f) * dx, pc2 = ((float)coord[2] + 0.5f) * dx;
-  float m_c = 0.f, mv[3] = {0.f, 0.f, 0.f}, Qc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, QX[3] = {0.f, 0.f, 0.f};
-  for (int o = 0; o < 27; ++o) {
-    const int bc[3] = {coord[0] - 1 + o / 9, coord[1] - 1 + (o / 3) % 3, coord[2] - 1 + o % 3};
+  int org[3];
+  c2_cell_coord<SIDE>(t, b, 0, mp.kscale, org);
+  for (int h = threadIdx.x; h < NH; h += blockDim.x) {
+    const int bc[3] = {org[0] - 1 + h / (H * H), org[1] - 1 + (h / H) % H, org[2] - 1 + h % H};
     const int bno = ht_query<3>(buckets, bc);
-    if (bno < 0) continue;
-    for (int st = offsets[bno], ed = offsets[bno + 1]; st != ed; ++st) {
-      const float4 *r = rec + 4 * (size_t)indices[st];
-      const float4 r0 = r[0];
-      const float d0 = pc0 - r0.x, d1 = pc1 - r0.y, d2 = pc2 - r0.z;
-      if (fabsf(d0) > dx || fabsf(d1) > dx || fabsf(d2) > dx) continue;  // checkInKernelRange, :72-76
-      const float4 r1 = r[1], r2 = r[2], r3 = r[3];
-      const float a0 = fabsf(d0 * dxi), a1 = fabsf(d1 * dxi), a2 = fabsf(d2 * dxi);
-      float W = 1.f;
-      if constexpr (KIND == C2_TRANSFER) {  // :149-151
-        W *= 1.f - a0; W *= 1.f - a1; W *= 1.f - a2;
-      } else {  // :396-402, :649-655
-        W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;
-      }
-      const float Q[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-      if constexpr (KIND != C2_FORCE) {
-        m_c += r0.w * W;
-        mv[0] += r1.x * W; mv[1] += r1.y * W; mv[2] += r1.z * W;
-      }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) QX[d] += (Q[d] * r0.x + Q[3 + d] * r0.y + Q[6 + d] * r0.z) * W;
-#pragma unroll
-      for (int d = 0; d < 9; ++d) Qc[d] += Q[d] * W;
-    }
+    range[h] = bno < 0 ? make_int2(0, 0) : make_int2(offsets[bno], offsets[bno + 1] - offsets[bno]);  // {start, count}
+    octs[h] = bno < 0 ? 0ull : sub[bno];
   }
-  float *s = sums + (size_t)b * 16 * NC + cell;
-  s[0] = m_c;
+  __syncthreads();
+  for (int cell = threadIdx.x; cell < NC; cell += blockDim.x) {
+    const int lx = cell / (SIDE * SIDE), ly = (cell / SIDE) % SIDE, lz = cell % SIDE;
+    const float pc0 = ((float)(org[0] + lx) + 0.5f) * dx, pc1 = ((float)(org[1] + ly) + 0.5f) * dx, pc2 = ((float)(org[2] + lz) + 0.5f) * dx;
+    float m_c = 0.f, mv[3] = {0.f, 0.f, 0.f}, Qc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, QX[3] = {0.f, 0.f, 0.f};
+    for (int o = 0; o < 27; ++o) {  // ndrange<3>(3) order
+      const int ox = o / 9, oy = (o / 3) % 3, oz = o % 3;
+      const int h = ((lx + ox) * H + ly + oy) * H + lz + oz;
+      const int2 sc = range[h];
+      if (!sc.y) continue;
+      const unsigned long long oc = octs[h];
+      const bool ordered = oc != ~0ull;
+      // half-cells of the bucket that can reach this cell: offset -1 -> upper half only, +1 -> lower half only
+      const int xlo = ox == 0, xhi = ox != 2, ylo = oy == 0, yhi = oy != 2, zlo = oz == 0, zhi = oz != 2;
+      for (int hx = xlo; hx <= xhi; ++hx)
+        for (int hy = ylo; hy <= yhi; ++hy) {
+          int a = 0, e = sc.y;
+          if (ordered) {
+            const int clo = hx * 4 + hy * 2 + zlo, chi = hx * 4 + hy * 2 + zhi;
+            a = (int)((oc >> (8 * clo)) & 255);
+            if (chi != 7) e = (int)((oc >> (8 * chi + 8)) & 255);
+          } else if (hx != xlo || hy != ylo) {
+            continue;  // an unordered bucket is walked once, whole
+          }
+          for (int st = sc.x + a, ed = sc.x + e; st < ed; ++st) {
+            const float4 *r = rec + 4 * (size_t)st;
+            const float4 r0 = r[0];
+            const float d0 = pc0 - r0.x, d1 = pc1 - r0.y, d2 = pc2 - r0.z;
+            if (fabsf(d0) > dx || fabsf(d1) > dx || fabsf(d2) > dx) continue;  // checkInKernelRange, :72-76
+            const float4 r1 = r[1], r2 = r[2], r3 = r[3];
+            const float a0 = fabsf(d0 * dxi), a1 = fabsf(d1 * dxi), a2 = fabsf(d2 * dxi);
+            float W = 1.f;
+            if constexpr (KIND == C2_TRANSFER) {  // :149-151
+              W *= 1.f - a0; W *= 1.f - a1; W *= 1.f - a2;
+            } else {  // :396-402, :649-655
+              W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;
+            }
+            const float Q[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+            if constexpr (KIND != C2_FORCE) {
+              m_c += r0.w * W;
+              mv[0] += r1.x * W; mv[1] += r1.y * W; mv[2] += r1.z * W;
+            }
 #pragma unroll
-  for (int d = 0; d < 3; ++d) s[(1 + d) * NC] = mv[d];
+            for (int d = 0; d < 3; ++d) QX[d] += (Q[d] * r0.x + Q[3 + d] * r0.y + Q[6 + d] * r0.z) * W;
 #pragma unroll
-  for (int d = 0; d < 9; ++d) s[(4 + d) * NC] = Qc[d];
+            for (int d = 0; d < 9; ++d) Qc[d] += Q[d] * W;
+          }
+        }
+    }
+    float *s = sums + (size_t)b * 16 * NC + cell;
+    s[0] = m_c;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) s[(13 + d) * NC] = QX[d];
+    for (int d = 0; d < 3; ++d) s[(1 + d) * NC] = mv[d];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) s[(4 + d) * NC] = Qc[d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s[(13 + d) * NC] = QX[d];
+  }
 }
 
 // ---- P2C2G stage 3: per node, the 8 cells node - {0,1}^3  (the gather form of :166-187).  One workgroup per block.
@@ -167,7 +235,7 @@ __global__ __launch_bounds__(256) void p2c2g_node_kernel(MpmDev mp, BhtDev t, co
   }
 }
 
-// ---- G2C2P stage 1: per cell v_c, v_c (x) x_i from the nodes cell + {0,1}^3  (G2C2P.hpp:69-90); cv[b][12][NC]
+// ---- G2C2P stage 1: per cell v_c, v_c (x) x_i from the nodes cell + {0,1}^3  (G2C2P.hpp:69-90); cv[b][NC][12]
 template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_cell_kernel(MpmDev mp, BhtDev t, const float *grid, float *cv) {
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ int nb[8];  // block number of key + {0,1}^3
@@ -200,11 +268,10 @@ template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_cell_kernel(Mpm
 #pragma unroll
       for (int d = 0; d < 9; ++d) vx[d] += W * vi[d % 3] * posi[d / 3];
     }
-    float *c = cv + (size_t)b * 12 * NC + cell;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) c[d * NC] = v[d];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) c[(3 + d) * NC] = vx[d];
+    float4 *c = (float4 *)cv + 3 * ((size_t)b * NC + cell);  // 48 contiguous bytes per cell: a particle reads 8 cells
+    c[0] = make_float4(v[0], v[1], v[2], vx[0]);
+    c[1] = make_float4(vx[1], vx[2], vx[3], vx[4]);
+    c[2] = make_float4(vx[5], vx[6], vx[7], vx[8]);
   }
 }
 
@@ -243,12 +310,13 @@ template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_particle_kernel
     const float a0 = fabsf(d0 * dxi), a1 = fabsf(d1 * dxi), a2 = fabsf(d2 * dxi);
     float W = 1.f;
     W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;  // :109-115
-    const float *cp = cv + (size_t)lastBlk * 12 * NC + ((loc[0] * SIDE + loc[1]) * SIDE + loc[2]);
-    const float vc[3] = {cp[0], cp[NC], cp[2 * NC]};
+    const float4 *cp = (const float4 *)cv + 3 * ((size_t)lastBlk * NC + ((loc[0] * SIDE + loc[1]) * SIDE + loc[2]));
+    const float4 q0 = cp[0], q1 = cp[1], q2 = cp[2];
+    const float vc[3] = {q0.x, q0.y, q0.z}, vx[9] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
     for (int d = 0; d < 3; ++d) v[d] += vc[d] * W;  // :120
 #pragma unroll
-    for (int d = 0; d < 9; ++d) B[d] += W * (cp[(3 + d) * NC] - vc[d % 3] * pos[d / 3]);  // :122-124
+    for (int d = 0; d < 9; ++d) B[d] += W * (vx[d] - vc[d % 3] * pos[d / 3]);  // :122-124
   }
   store_attr<3>(ps.vel, i, v);
   store_attr<9>(ps.C, i, B);
@@ -300,18 +368,23 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   BhtDev t = tab->t.dev();
   const size_t nc = (size_t)p->side * p->side * p->side;
   float4 *rec = (float4 *)L.temp(sizeof(float4) * 4 * ps.n);
+  int *sorted = (int *)L.temp(sizeof(int) * ps.n);
+  unsigned long long *sub = (unsigned long long *)L.temp(sizeof(unsigned long long) * (buckets->numBuckets + 1));
+  hipLaunchKernelGGL(c2_octant_kernel, dim3(ceil_div((size_t)buckets->numBuckets, 256)), dim3(256), 0, L.stream, pd.pos, 1.0f / p->dx,
+                     (const int *)buckets->offsets, (const int *)buckets->indices, buckets->numBuckets,
+                     (int)(buckets->dx == p->dx && buckets->displacement == 0.f), sorted, sub);  // other buckets: walked whole
   float *sums = (float *)L.temp(sizeof(float) * 16 * nc * nblocks);
   const dim3 pg(ceil_div(ps.n, 256)), blk(256);
 #define CALL_C2_PARTICLE(S, M) \
-  if (kind == C2_TRANSFER) hipLaunchKernelGGL((c2_particle_kernel<M, C2_TRANSFER>), pg, blk, 0, L.stream, mp, pd, rec); \
-  else hipLaunchKernelGGL((c2_particle_kernel<M, C2_FORCE>), pg, blk, 0, L.stream, mp, pd, rec)
-  if (kind == C2_MOMENTUM) hipLaunchKernelGGL((c2_particle_kernel<ZS_MPM_FIXED_COROTATED, C2_MOMENTUM>), pg, blk, 0, L.stream, mp, pd, rec);
+  if (kind == C2_TRANSFER) hipLaunchKernelGGL((c2_particle_kernel<M, C2_TRANSFER>), pg, blk, 0, L.stream, mp, pd, (const int *)sorted, rec); \
+  else hipLaunchKernelGGL((c2_particle_kernel<M, C2_FORCE>), pg, blk, 0, L.stream, mp, pd, (const int *)sorted, rec)
+  if (kind == C2_MOMENTUM) hipLaunchKernelGGL((c2_particle_kernel<ZS_MPM_FIXED_COROTATED, C2_MOMENTUM>), pg, blk, 0, L.stream, mp, pd,
+                                                (const int *)sorted, rec);
   else { ZSR_DISPATCH_PURE_(0, p->model, CALL_C2_PARTICLE) }
   const HtDev bk = buckets->table->dev();
-  const dim3 cg(ceil_div(nc * nblocks, 256));
-#define CALL_C2_CELLS(S, K)                                                                                                             \
-  hipLaunchKernelGGL((p2c2g_cell_kernel<S, K>), cg, blk, 0, L.stream, mp, t, bk, (const int *)buckets->offsets,                           \
-                     (const int *)buckets->indices, (const float4 *)rec, sums, (int)nblocks);                                            \
+#define CALL_C2_CELLS(S, K)                                                                                                               \
+  hipLaunchKernelGGL((p2c2g_cell_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, bk,                  \
+                     (const int *)buckets->offsets, (const unsigned long long *)sub, (const float4 *)rec, sums);                                                            \
   hipLaunchKernelGGL((p2c2g_node_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, (const float *)sums, grid)
 #define CALL_C2_KIND(S)                                    \
   if (kind == C2_TRANSFER) { CALL_C2_CELLS(S, C2_TRANSFER); } \
