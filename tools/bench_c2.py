@@ -1,8 +1,8 @@
 """P2C2G / G2C2P (gather-style transfers) at the config-3 size: 8 M particles (128^3 cells x 8) on a 256^3 grid, blocks of 8^3.
 Prints one JSON line per pass with HIP-event times (per-kernel with ZS_C2_PROFILE=1 through the policy's profile switch)."""
-import json, sys, time
+import json, os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import zpc_amd
 from zpc_amd import lib

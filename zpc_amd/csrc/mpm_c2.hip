@@ -7,7 +7,7 @@
 // atomics into the 8 nodes (P2C2G) or into the particles (G2C2P).  Here every stage is a gather, so no float atomic is issued and a run
 // is reproducible bit for bit:
 //   P2C2G  0. per bucket: order the bucket's particles by octant                                     (c2_octant_kernel)
-//          1. per particle: constitutive update ONCE, 64-byte record {pos, mass, mass*vel, Q} in bucket order (c2_particle_kernel)
+//          1. per particle: constitutive update ONCE, 64-byte record {pos, mass, Q, mass*vel} in bucket order (c2_particle_kernel)
 //          2. per cell: walk the 27 buckets, sum the 16 cell moments                                   (p2c2g_cell_kernel)
 //          3. per node: sum the 8 cells around the node, add to the grid                               (p2c2g_node_kernel)
 //   G2C2P  1. per cell: v_c and v_c (x) x_i from the 8 nodes                                            (g2c2p_cell_kernel)
@@ -45,12 +45,12 @@ __device__ __forceinline__ int c2_octant(const Port<float> &pos, size_t i, float
   return code;
 }
 __global__ __launch_bounds__(256) void c2_octant_kernel(Port<float> pos, float dxi, const int *offsets, const int *indices, int nbuckets,
-                                                        int canOrder, int *sorted, unsigned long long *sub) {
+                                                        int canOrder, int *slotOf, unsigned long long *sub) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const int st = offsets[b], ed = offsets[b + 1];
   if (!canOrder || ed - st > 255) {
-    for (int k = st; k < ed; ++k) sorted[k] = indices[k];
+    for (int k = st; k < ed; ++k) slotOf[indices[k]] = k;
     sub[b] = ~0ull;
     return;
   }
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void c2_octant_kernel(Port<float> pos, float d
   unsigned long long cur = excl;
   for (int k = st; k < ed; ++k) {
     const int id = indices[k], sh = 8 * c2_octant(pos, (size_t)id, dxi);
-    sorted[st + (int)((cur >> sh) & 255)] = id;
+    slotOf[id] = st + (int)((cur >> sh) & 255);
     cur += 1ull << sh;
   }
   sub[b] = excl;
@@ -68,16 +68,18 @@ __global__ __launch_bounds__(256) void c2_octant_kernel(Port<float> pos, float d
 
 // ---- P2C2G stage 1: per particle, in bucket order (slot s of IndexBuckets::indices)
 template <int MODEL, int KIND>
-__global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDev ps, const int *indices, float4 *rec) {
-  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= ps.n) return;
-  const size_t i = (size_t)indices[slot];  // records are laid out in bucket order: a bucket's particles are one contiguous run
+__global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDev ps, const int *slotOf, float4 *rec) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ps.n) return;
+  // records are laid out in bucket order (a bucket's particles are one contiguous run); the particle attributes are read in storage
+  // order (coalesced AoSoA rows) and the 64-byte record is the scattered access
+  const size_t slot = (size_t)slotOf[i];
   const float dx = mp.dx, dxi = 1.0f / dx;
   float pos[3], vel[3] = {0.f, 0.f, 0.f}, C[9], Q[9], Dinv[3];
   load_attr<3>(ps.pos, i, pos);
   load_attr<9>(ps.C, i, C);
   const float mass = ps.mass.base[ps.mass.off(i)];
-  if constexpr (KIND != C2_FORCE) load_attr<3>(ps.vel, i, vel);
+  load_attr<3>(ps.vel, i, vel);
 #pragma unroll
   for (int d = 0; d < 3; ++d) Dinv[d] = c2_dinv(pos[d], dx, dxi);
 #pragma unroll
@@ -100,9 +102,9 @@ __global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDe
   }
   float4 *r = rec + 4 * slot;
   r[0] = make_float4(pos[0], pos[1], pos[2], mass);
-  r[1] = make_float4(mass * vel[0], mass * vel[1], mass * vel[2], Q[0]);
-  r[2] = make_float4(Q[1], Q[2], Q[3], Q[4]);
-  r[3] = make_float4(Q[5], Q[6], Q[7], Q[8]);
+  r[1] = make_float4(Q[0], Q[1], Q[2], Q[3]);
+  r[2] = make_float4(Q[4], Q[5], Q[6], Q[7]);
+  r[3] = make_float4(Q[8], mass * vel[0], mass * vel[1], mass * vel[2]);
 }
 
 // block key (in the table's convention) and cell coordinate of cell `cell` of block b
@@ -169,11 +171,12 @@ __global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, Ht
             } else {  // :396-402, :649-655
               W *= a0 <= 1 ? 1.f - a0 : 0.f; W *= a1 <= 1 ? 1.f - a1 : 0.f; W *= a2 <= 1 ? 1.f - a2 : 0.f;
             }
-            const float Q[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-            if constexpr (KIND != C2_FORCE) {
-              m_c += r0.w * W;
-              mv[0] += r1.x * W; mv[1] += r1.y * W; mv[2] += r1.z * W;
-            }
+            const float Q[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+            // all 16 moments for every kind (the Force variant's node stage ignores m_c, mv_c): when that variant read only part of
+            // the record the compiler re-sliced the four float4 loads into 16-byte loads at offsets 12 / 28 plus a late dependent
+            // dword, and the kernel ran 2x slower than the variants that use everything
+            m_c += r0.w * W;
+            mv[0] += r3.y * W; mv[1] += r3.z * W; mv[2] += r3.w * W;
 #pragma unroll
             for (int d = 0; d < 3; ++d) QX[d] += (Q[d] * r0.x + Q[3 + d] * r0.y + Q[6 + d] * r0.z) * W;
 #pragma unroll
@@ -368,18 +371,18 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   BhtDev t = tab->t.dev();
   const size_t nc = (size_t)p->side * p->side * p->side;
   float4 *rec = (float4 *)L.temp(sizeof(float4) * 4 * ps.n);
-  int *sorted = (int *)L.temp(sizeof(int) * ps.n);
+  int *slotOf = (int *)L.temp(sizeof(int) * ps.n);
   unsigned long long *sub = (unsigned long long *)L.temp(sizeof(unsigned long long) * (buckets->numBuckets + 1));
   hipLaunchKernelGGL(c2_octant_kernel, dim3(ceil_div((size_t)buckets->numBuckets, 256)), dim3(256), 0, L.stream, pd.pos, 1.0f / p->dx,
                      (const int *)buckets->offsets, (const int *)buckets->indices, buckets->numBuckets,
-                     (int)(buckets->dx == p->dx && buckets->displacement == 0.f), sorted, sub);  // other buckets: walked whole
+                     (int)(buckets->dx == p->dx && buckets->displacement == 0.f), slotOf, sub);  // other buckets: walked whole
   float *sums = (float *)L.temp(sizeof(float) * 16 * nc * nblocks);
   const dim3 pg(ceil_div(ps.n, 256)), blk(256);
 #define CALL_C2_PARTICLE(S, M) \
-  if (kind == C2_TRANSFER) hipLaunchKernelGGL((c2_particle_kernel<M, C2_TRANSFER>), pg, blk, 0, L.stream, mp, pd, (const int *)sorted, rec); \
-  else hipLaunchKernelGGL((c2_particle_kernel<M, C2_FORCE>), pg, blk, 0, L.stream, mp, pd, (const int *)sorted, rec)
+  if (kind == C2_TRANSFER) hipLaunchKernelGGL((c2_particle_kernel<M, C2_TRANSFER>), pg, blk, 0, L.stream, mp, pd, (const int *)slotOf, rec); \
+  else hipLaunchKernelGGL((c2_particle_kernel<M, C2_FORCE>), pg, blk, 0, L.stream, mp, pd, (const int *)slotOf, rec)
   if (kind == C2_MOMENTUM) hipLaunchKernelGGL((c2_particle_kernel<ZS_MPM_FIXED_COROTATED, C2_MOMENTUM>), pg, blk, 0, L.stream, mp, pd,
-                                                (const int *)sorted, rec);
+                                                (const int *)slotOf, rec);
   else { ZSR_DISPATCH_PURE_(0, p->model, CALL_C2_PARTICLE) }
   const HtDev bk = buckets->table->dev();
 #define CALL_C2_CELLS(S, K)                                                                                                               \
