@@ -37,10 +37,16 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
                                          float displacement, size_t expectedCells) {
   ib->dx = dx;
   ib->displacement = displacement;
-  if (ib->table) zs_rocm_hashtable_destroy(ib->table);
-  ib->table = zs_rocm_hashtable_create(3, expectedCells ? expectedCells : n, 1, 0);  // Query.tpp:27 (created reset)
-  (void)hipFree(ib->indices); (void)hipFree(ib->offsets); (void)hipFree(ib->counts);
-  ib->indices = ib->offsets = ib->counts = nullptr;
+  // a time loop rebuilds the buckets every step: table and arrays are kept while they are large enough (hipMalloc / hipFree
+  // synchronise the device and cost more than the kernels below)
+  const size_t want = expectedCells ? expectedCells : n;
+  if (ib->table && ib->tableFor == want) {
+    zs_rocm_hashtable_reset(pol, ib->table, 1);
+  } else {
+    if (ib->table) zs_rocm_hashtable_destroy(ib->table);
+    ib->table = zs_rocm_hashtable_create(3, want, 1, 0);  // Query.tpp:27 (created reset)
+    ib->tableFor = want;
+  }
   ib->numEntries = (int)n;
   ib->numBuckets = 0;
   if (!n) return;
@@ -53,9 +59,17 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
   ZSR_CHECK(hipStreamSynchronize(L.stream));
   ib->numBuckets = nc;
   const size_t numCells = (size_t)nc + 1;  // Query.tpp:36
-  ZSR_CHECK(hipMalloc((void **)&ib->counts, numCells * sizeof(int)));
-  ZSR_CHECK(hipMalloc((void **)&ib->offsets, numCells * sizeof(int)));
-  ZSR_CHECK(hipMalloc((void **)&ib->indices, n * sizeof(int)));
+  if (numCells > ib->capCells) {
+    (void)hipFree(ib->offsets); (void)hipFree(ib->counts);
+    ib->capCells = numCells + numCells / 2;
+    ZSR_CHECK(hipMalloc((void **)&ib->counts, ib->capCells * sizeof(int)));
+    ZSR_CHECK(hipMalloc((void **)&ib->offsets, ib->capCells * sizeof(int)));
+  }
+  if (n > ib->capEntries) {
+    (void)hipFree(ib->indices);
+    ib->capEntries = n;
+    ZSR_CHECK(hipMalloc((void **)&ib->indices, n * sizeof(int)));
+  }
   ZSR_CHECK(hipMemsetAsync(ib->counts, 0, numCells * sizeof(int), L.stream));
   unsigned *cellOf = (unsigned *)L.temp(sizeof(unsigned) * n), *cellSorted = (unsigned *)L.temp(sizeof(unsigned) * n);
   int *ids = (int *)L.temp(sizeof(int) * n);

@@ -207,7 +207,8 @@ class MpmTransfer:
         """IndexBuckets of cell size dx over the current positions (index_buckets_for_particles, displacement 0): bucket = the cell
         that contains the particle, which is what P2C2GTransfer's 27-bucket walk expects."""
         from .containers import IndexBuckets
-        self.buckets = IndexBuckets()
+        if getattr(self, "buckets", None) is None:
+            self.buckets = IndexBuckets()   # rebuilt in place every step: the table and the arrays are reused
         self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=0.0)
         return self.buckets
 
