@@ -152,3 +152,30 @@ def test_g2c2p_reproduces_affine_field(pol, oracle):
     Cm = d["C"].reshape(-1, 3, 3) * Dinv[:, :, None]                                # C[d] *= Dinv[d / 3], column-major: C[r + 3 c]
     grad = Cm.transpose(0, 2, 1)                                                     # [n][r][c]
     assert np.abs(grad - A[None]).max() < 2e-3
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_c2_time_loop_vs_oracle(pol, oracle, model):
+    """Three full sub-steps (buckets -> P2C2G -> grid update -> G2C2P) on the GPU and in the oracle: the states stay together
+    (the buckets are rebuilt in place every step; the partition is fixed, the cloud moves by a fraction of a cell)."""
+    om, mt, (mass, pos, vel, Bm, F, lj0) = _setup(pol, oracle, 4, model, seed=120 + model)
+    po, vo, Bo, Fo, ljo = pos.copy(), vel.copy(), Bm.copy(), F.copy(), lj0.copy()
+    for step in range(3):
+        om.build_buckets(po)
+        om.grid[:] = 0
+        ljo = om.p2c2g(0, mass, po, vo, Bo, Fo, ljo)
+        om.grid_update((0.0, -9.8, 0.0))
+        om.g2c2p(po, vo, Bo, Fo)
+        mt.build_buckets()
+        mt.clear_grid()
+        mt.p2c2g(0)
+        mt.grid_update((0.0, -9.8, 0.0))
+        mt.g2c2p()
+    pol.syncCtx()
+    d = mt.download()
+    assert np.abs(d["x"] - po).max() < 2e-6
+    assert np.abs(d["v"] - vo).max() < 5e-4 * np.abs(vo).max()
+    assert np.abs(d["C"] - Bo).max() < 5e-4 * np.abs(Bo).max()
+    assert np.abs(d["F"] - Fo).max() < 5e-5
+    if model == 1:
+        assert np.abs(d["logJp"] - ljo).max() < 5e-5
