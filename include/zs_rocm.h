@@ -596,6 +596,10 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2c2p(zs_rocm_policy *, const zs_rocm_mpm_params 
 /* pol(range(n), PostG2C2PTransfer{scheme, dt, dx, model, particles}) (G2C2P.hpp:224-275): C = B Dinv; F <- (I + dt C) F (J for the fluid);
  * x += v dt */
 ZS_ROCM_EXPORT void zs_rocm_mpm_post_g2c2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
+/* The three G2C2P functors above in one pass over the particles (v and B start from 0 instead of being zeroed, re-read and re-written):
+ * same bits as zs_rocm_mpm_pre_g2c2p + zs_rocm_mpm_g2c2p + zs_rocm_mpm_post_g2c2p. */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2c2p_step(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
+                                          const float *grid, size_t nblocks);
 /* pol(range(n), G2PTransfer{apic, dt, model, grids, table, particles}) (simulation/transfer/G2P.hpp:24-90) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,

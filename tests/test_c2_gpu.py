@@ -115,8 +115,14 @@ def test_g2c2p_vs_oracle(pol, oracle, side, model):
     mt.grid_update((0.0, -9.8, 0.0))
     po, vo, Bo, Fo = pos.copy(), vel.copy(), Bm.copy(), F.copy()
     om.g2c2p(po, vo, Bo, Fo)
-    mt.g2c2p()
+    buf0 = mt.buf.clone()
+    mt.g2c2p(fused=False)
     pol.syncCtx()
+    three = mt.buf.clone()
+    mt.buf.copy_(buf0)
+    mt.g2c2p()          # Pre + G2C2P + Post in one pass: same bits
+    pol.syncCtx()
+    assert torch.equal(three, mt.buf)
     d = mt.download()
     assert np.abs(d["x"] - po).max() < 1e-6
     assert np.abs(d["v"] - vo).max() < 2e-4 * np.abs(vo).max()

@@ -46,6 +46,7 @@ def main(cells=128, grid=256, side=8, model=0, iters=5, shuffle=False):
     mt.clear_grid(); mt.p2c2g(0); mt.grid_update((0.0, -9.8, 0.0))
     mt.params.dt = 0.0   # repeatable: positions and F stay put
     rows["g2c2p_ms"] = timed(mt.g2c2p)
+    rows["g2c2p_three_calls_ms"] = timed(lambda: mt.g2c2p(fused=False))
     mt.params.dt = dt
     # the scatter transfers on the same particles, particle order (the reference algorithm) for comparison
     def p2g():

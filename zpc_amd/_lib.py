@@ -304,6 +304,8 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2c2p.argtypes = [vp, PP, Particles, vp, vp, vp, sz]
     L.zs_rocm_mpm_g2c2p.restype = i32
     L.zs_rocm_mpm_post_g2c2p.argtypes = [vp, PP, Particles]
+    L.zs_rocm_mpm_g2c2p_step.argtypes = [vp, PP, Particles, vp, vp, sz]
+    L.zs_rocm_mpm_g2c2p_step.restype = i32
     L.zs_rocm_mpm_stress.argtypes = [vp, PP, vp, vp, sz, vp]
     L.zs_rocm_mpm_update_stress.argtypes = [vp, PP, Particles]
     L.zs_rocm_svd3.argtypes = [vp, vp, sz, vp, vp, vp]

@@ -281,15 +281,20 @@ template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_cell_kernel(Mpm
 // ---- G2C2P stage 2: per particle, the cells whose centre is within dx  (the gather form of :92-131).  Adds to v_p and B_p like the
 // reference's atomics (PreG2C2PTransfer zeroes them).  Cells floor(x/dx - 0.5) + {0,1}^3: a third cell per axis can only pass the range
 // check with a weight that rounds to 0.
-template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_particle_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *cv) {
+// STEP: PreG2C2P + G2C2P + PostG2C2P in one pass (v, B start from 0 instead of being zeroed, re-read and re-written; then C = B Dinv,
+// F <- (I + dt C) F or J <- (1 + tr C dt) J, x += v dt): same bits as the three calls.
+template <int SIDE, bool STEP = false, bool FLUID = false>
+__global__ __launch_bounds__(256) void g2c2p_particle_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *cv) {
   constexpr int NC = SIDE * SIDE * SIDE;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
   const float dx = mp.dx, dxi = 1.0f / dx;
-  float pos[3], v[3], B[9];
+  float pos[3], v[3] = {0.f, 0.f, 0.f}, B[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   load_attr<3>(ps.pos, i, pos);
-  load_attr<3>(ps.vel, i, v);
-  load_attr<9>(ps.C, i, B);
+  if constexpr (!STEP) {
+    load_attr<3>(ps.vel, i, v);
+    load_attr<9>(ps.C, i, B);
+  }
   int c0[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) c0[d] = (int)floorf(pos[d] * dxi - 0.5f);
@@ -323,6 +328,18 @@ template <int SIDE> __global__ __launch_bounds__(256) void g2c2p_particle_kernel
   }
   store_attr<3>(ps.vel, i, v);
   store_attr<9>(ps.C, i, B);
+  if constexpr (STEP) {  // PostG2C2PTransfer, G2C2P.hpp:235-270
+    float C[9], oldF[9], F[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) C[d] = B[d] * c2_dinv(pos[d / 3], dx, dxi);
+    load_state<FLUID>(ps.F, i, oldF);
+    advance_state<FLUID>(oldF, C, mp.dt, F);
+    if constexpr (FLUID) ps.F.base[ps.F.off(i)] = F[0];
+    else store_attr<9>(ps.F, i, F);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos[d] += v[d] * mp.dt;
+    store_attr<3>(ps.pos, i, pos);
+  }
 }
 
 __global__ __launch_bounds__(256) void pre_g2c2p_kernel(ParticlesDev ps) {  // G2C2P.hpp:215-218
@@ -420,6 +437,30 @@ int zs_rocm_mpm_g2c2p(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   } else {
     hipLaunchKernelGGL((g2c2p_cell_kernel<8>), dim3((unsigned)nblocks), dim3(256), 0, L.stream, mp, t, grid, cv);
     hipLaunchKernelGGL((g2c2p_particle_kernel<8>), dim3(ceil_div(ps.n, 256)), dim3(256), 0, L.stream, mp, pd, t, (const float *)cv);
+  }
+  return 0;
+}
+
+int zs_rocm_mpm_g2c2p_step(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
+                           const float *grid, size_t nblocks) {
+  if (p->side != 4 && p->side != 8) return -1;
+  if (!ps.n || !nblocks) return 0;
+  Launch L(pol, "G2C2PTransfer");
+  MpmDev mp = make_dev(p);
+  ParticlesDev pd = make_particles(ps);
+  BhtDev t = tab->t.dev();
+  const size_t nc = (size_t)p->side * p->side * p->side;
+  float *cv = (float *)L.temp(sizeof(float) * 12 * nc * nblocks);
+  const dim3 pg(ceil_div(ps.n, 256)), blk(256);
+  const bool fluid = p->model == ZS_MPM_EQUATION_OF_STATE;
+  if (p->side == 4) {
+    hipLaunchKernelGGL((g2c2p_cell_kernel<4>), dim3((unsigned)nblocks), dim3(64), 0, L.stream, mp, t, grid, cv);
+    if (fluid) hipLaunchKernelGGL((g2c2p_particle_kernel<4, true, true>), pg, blk, 0, L.stream, mp, pd, t, (const float *)cv);
+    else hipLaunchKernelGGL((g2c2p_particle_kernel<4, true, false>), pg, blk, 0, L.stream, mp, pd, t, (const float *)cv);
+  } else {
+    hipLaunchKernelGGL((g2c2p_cell_kernel<8>), dim3((unsigned)nblocks), dim3(256), 0, L.stream, mp, t, grid, cv);
+    if (fluid) hipLaunchKernelGGL((g2c2p_particle_kernel<8, true, true>), pg, blk, 0, L.stream, mp, pd, t, (const float *)cv);
+    else hipLaunchKernelGGL((g2c2p_particle_kernel<8, true, false>), pg, blk, 0, L.stream, mp, pd, t, (const float *)cv);
   }
   return 0;
 }

@@ -218,9 +218,16 @@ class MpmTransfer:
                                    self.grid.data_ptr(), self.nblocks, int(kind)) != 0:
             raise RuntimeError("zs_rocm_mpm_p2c2g refused its arguments")
 
-    def g2c2p(self):
-        """PreG2C2PTransfer + G2C2PTransfer + PostG2C2PTransfer: v, B (= C) from the grid, then F (or J) and x advance."""
+    def g2c2p(self, fused=True):
+        """PreG2C2PTransfer + G2C2PTransfer + PostG2C2PTransfer: v, B (= C) from the grid, then F (or J) and x advance.
+        fused: one pass over the particles (zs_rocm_mpm_g2c2p_step) instead of the three calls; same bits."""
         L = lib()
+        if fused:
+            if L.zs_rocm_mpm_g2c2p_step(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, self.grid.data_ptr(),
+                                        self.nblocks) != 0:
+                raise RuntimeError("zs_rocm_mpm_g2c2p_step refused its arguments")
+            self.binned = False
+            return
         L.zs_rocm_mpm_pre_g2c2p(self.pol.handle, self.particles())
         if L.zs_rocm_mpm_g2c2p(self.pol.handle, C.byref(self.params), self.particles(), None, self.table.handle, self.grid.data_ptr(),
                                self.nblocks) != 0:
