@@ -185,3 +185,60 @@ def test_c2_time_loop_vs_oracle(pol, oracle, model):
     assert np.abs(d["F"] - Fo).max() < 5e-5
     if model == 1:
         assert np.abs(d["logJp"] - ljo).max() < 5e-5
+
+
+def _run_both(pol, oracle, mass, pos, vel, Bm, F, side, displacement=0.0):
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    om = OracleMpm(oracle, 0, dx, dt, side, vol)
+    om.build_partition(pos, n)
+    om.build_buckets(pos, displacement)
+    om.p2c2g(0, mass, pos, vel, Bm, F)
+    mt = MpmTransfer(pol, n, dx, dt, model=0, side=side, volume=vol)
+    mt.upload(mass, pos, vel, Bm, F)
+    assert mt.build_partition(n) == om.nblocks
+    mt.build_buckets(displacement)
+    mt.clear_grid()
+    mt.p2c2g(0)
+    pol.syncCtx()
+    return om, mt
+
+
+@pytest.mark.parametrize("side", [4, 8])
+def test_p2c2g_crowded_buckets(pol, oracle, side):
+    """More than 255 particles in one cell: that bucket is not octant-ordered and is walked whole (only the range check decides)."""
+    dx = 1.0 / 64
+    mass, pos, vel, Bm, F = make_cloud(4, dx, 2, seed=130, vel_scale=0.3)
+    g = rng(131)
+    k = 700
+    extra = (np.array([0.33, 0.34, 0.32], np.float32) // dx + g.random((k, 3)).astype(np.float32)) * dx   # 700 particles in ONE cell
+    pos = np.concatenate([pos, extra.astype(np.float32)])
+    n = pos.shape[0]
+    mass = np.full(n, mass[0], np.float32)
+    vel = (0.3 * g.standard_normal((n, 3))).astype(np.float32)
+    Bm = (0.1 * dx * dx * 0.25 * g.standard_normal((n, 9))).astype(np.float32)
+    F = (np.eye(3).reshape(1, 9) + 0.01 * g.standard_normal((n, 9))).astype(np.float32)
+    om, mt = _run_both(pol, oracle, mass, pos, vel, Bm, F, side)
+    v = mt.buckets.view()
+    cnt = torch.zeros(v.numBuckets + 1, dtype=torch.int32, device="cuda")
+    import ctypes
+    ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(v.counts), ctypes.c_size_t(4 * v.numBuckets), 3)
+    assert int(cnt.max()) > 255
+    _cmp(mt.grid_by_key(), om.grid_by_key(), 2e-4, range(4))
+    gsum = mt.grid.cpu().numpy().reshape(mt.nblocks, 7, side ** 3)[:, 0].sum()
+    assert abs(gsum - mass.sum()) < 1e-4 * mass.sum()
+
+
+def test_p2c2g_foreign_buckets(pol, oracle):
+    """Buckets that are not the cells of this grid (built with displacement 0.5): no octant shortcut is taken, the 27-bucket walk and
+    the range check give what the reference functor gives on such buckets (every particle within dx of a cell centre still lies in
+    one of the 27 buckets around the cell, so mass is conserved)."""
+    dx = 1.0 / 64
+    mass, pos, vel, Bm, F = make_cloud(6, dx, 2, seed=140, vel_scale=0.3)
+    Bm = (Bm * dx * dx * 0.25).astype(np.float32)
+    om, mt = _run_both(pol, oracle, mass, pos, vel, Bm, F, 4, displacement=0.5)
+    _cmp(mt.grid_by_key(), om.grid_by_key(), 2e-4, range(4))
+    gsum = mt.grid.cpu().numpy().reshape(mt.nblocks, 7, 64)[:, 0].sum()
+    assert abs(gsum - mass.sum()) < 1e-4 * mass.sum()

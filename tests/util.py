@@ -110,13 +110,13 @@ class OracleMpm:
         self.o.orc_mpm_g2p(C.byref(self.p), self.table, C.c_size_t(n), ptr(pos), ptr(vel), ptr(Cm), ptr(F), ptr(self.grid))
 
     # ---- gather-style transfers (oracle/mpm.c: orc_mpm_p2c2g / orc_mpm_g2c2p / orc_mpm_post_g2c2p)
-    def build_buckets(self, pos):
+    def build_buckets(self, pos, displacement=0.0):
         """IndexBuckets of cell size dx, displacement 0 (sequential policy: ascending ids per bucket)."""
         n = pos.shape[0]
         I32P = C.POINTER(C.c_int32)
         self.o.orc_index_buckets_for_particles.restype = C.c_void_p
         self._ib = (I32P(), I32P(), I32P())
-        self.buckets = C.c_void_p(self.o.orc_index_buckets_for_particles(ptr(pos), C.c_size_t(n), C.c_float(self.p.dx), C.c_float(0.0),
+        self.buckets = C.c_void_p(self.o.orc_index_buckets_for_particles(ptr(pos), C.c_size_t(n), C.c_float(self.p.dx), C.c_float(displacement),
                                                                          C.c_size_t(0), C.byref(self._ib[0]), C.byref(self._ib[1]),
                                                                          C.byref(self._ib[2])))
 

@@ -203,13 +203,13 @@ class MpmTransfer:
                               self.nblocks, bs, cc, nb)
 
     # ------------------------------------------------------------------ gather-style transfers (P2C2G.hpp / G2C2P.hpp)
-    def build_buckets(self):
+    def build_buckets(self, displacement=0.0):
         """IndexBuckets of cell size dx over the current positions (index_buckets_for_particles, displacement 0): bucket = the cell
         that contains the particle, which is what P2C2GTransfer's 27-bucket walk expects."""
         from .containers import IndexBuckets
         if getattr(self, "buckets", None) is None:
             self.buckets = IndexBuckets()   # rebuilt in place every step: the table and the arrays are reused
-        self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=0.0)
+        self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=displacement)
         return self.buckets
 
     def p2c2g(self, kind=0):
