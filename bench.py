@@ -553,6 +553,24 @@ def main():
                                "note": "bytes_per_particle = SURVEY 8(d) P2G + G2P; the fused pass keeps v, C and the stress on chip "
                                        "(traffic < algorithmic bytes) and is VALU-limited: SQ_INSTS_VALU x 4 cycles = 81 % of the SIMD "
                                        "cycles (profiles/r01_pmc_g2p2g.md)"}
+        # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
+        # bytes over HIP-event time, after the timed region)
+        try:
+            ca = torch.empty(1 << 28, dtype=torch.float32, device=device)
+            cb = torch.empty_like(ca)
+            cb.copy_(ca)
+            ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ce[0].record()
+            for _ in range(5):
+                cb.copy_(ca)
+            ce[1].record()
+            torch.cuda.synchronize()
+            copy_gbs = 2.0 * ca.numel() * 4 * 5 / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+            del ca, cb
+            out["roofline"]["measured_copy"] = copy_gbs
+            out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / copy_gbs
+        except Exception:
+            pass
         if checksum is not None:
             out["checksum"] = checksum
         if world == 1 and not a.no_cpu_baseline:
