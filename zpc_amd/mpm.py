@@ -209,7 +209,9 @@ class MpmTransfer:
         from .containers import IndexBuckets
         if getattr(self, "buckets", None) is None:
             self.buckets = IndexBuckets()   # rebuilt in place every step: the table and the arrays are reused
-        self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=displacement)
+        # table sized for the occupied cells, which the partition bounds (the reference sizes it for one cell per particle)
+        cells = min(self.n, self.nblocks * self.side ** 3) if getattr(self, "nblocks", 0) else 0
+        self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=displacement, expected_cells=cells)
         return self.buckets
 
     def p2c2g(self, kind=0):
