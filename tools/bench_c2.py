@@ -56,4 +56,5 @@ def main(cells=128, grid=256, side=8, model=0, iters=5, shuffle=False):
 
 if __name__ == "__main__":
     main(shuffle=False)
-    main(shuffle=True)
+    if "--lattice-only" not in sys.argv:
+        main(shuffle=True)
