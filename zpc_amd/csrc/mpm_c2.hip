@@ -22,6 +22,9 @@ using namespace zsr;
 namespace {
 
 constexpr int C2_TRANSFER = 0, C2_MOMENTUM = 1, C2_FORCE = 2;
+#ifndef ZS_C2_CXN
+#  define ZS_C2_CXN 2  // 2 x 2 x 2 cells per lane (1: 1 x 2 x 2 -- measured 5 % slower)
+#endif
 
 __device__ __forceinline__ float c2_dinv(float x, float dx, float dxi) {
   const float r = x - (float)(int)floorf(x * dxi + 0.5f) * dx;  // P2C2G.hpp:88
@@ -54,12 +57,17 @@ __global__ __launch_bounds__(256) void c2_octant_kernel(Port<float> pos, float d
     sub[b] = ~0ull;
     return;
   }
-  unsigned long long counts = 0;
-  for (int k = st; k < ed; ++k) counts += 1ull << (8 * c2_octant(pos, (size_t)indices[k], dxi));
+  unsigned long long counts = 0, codes = 0;  // the octants of the first 21 particles stay in a register: one scattered read each
+  for (int k = st; k < ed; ++k) {
+    const int code = c2_octant(pos, (size_t)indices[k], dxi);
+    counts += 1ull << (8 * code);
+    if (k - st < 21) codes |= (unsigned long long)code << (3 * (k - st));
+  }
   const unsigned long long excl = (counts * 0x0101010101010101ull) << 8;  // bytewise exclusive prefix sum (total <= 255: no carry)
   unsigned long long cur = excl;
   for (int k = st; k < ed; ++k) {
-    const int id = indices[k], sh = 8 * c2_octant(pos, (size_t)id, dxi);
+    const int id = indices[k];
+    const int sh = 8 * (k - st < 21 ? (int)((codes >> (3 * (k - st))) & 7) : c2_octant(pos, (size_t)id, dxi));
     slotOf[id] = st + (int)((cur >> sh) & 255);
     cur += 1ull << sh;
   }
@@ -192,6 +200,116 @@ __global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, Ht
     for (int d = 0; d < 9; ++d) s[(4 + d) * NC] = Qc[d];
 #pragma unroll
     for (int d = 0; d < 3; ++d) s[(13 + d) * NC] = QX[d];
+  }
+}
+
+// ---- P2C2G stage 2, 2x2x2 cells per lane: the 8 cells of a lane need the particles of a 3x3x3-cell volume (27 x 8 records instead of
+// 8 x 64: the cell-per-lane kernel above leaves L2 with 8-16 GB per launch because the 8 cells that need a record run at different
+// times in different waves).  The record is loaded once and applied to whichever of the lane's 8 cells it is in range of.  One wave per
+// 8^3 block (8 blocks of 4^3 cells per wave).
+template <int SIDE, int KIND, int CXN>
+__global__ __launch_bounds__(128) void p2c2g_cell8_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets,
+                                                         const unsigned long long *sub, const float4 *rec, float *sums, int nblocks) {
+  constexpr int NC = SIDE * SIDE * SIDE, H = SIDE + 2, NH = H * H * H, GS = SIDE / 2, G = (SIDE / CXN) * GS * GS;
+  constexpr int TPB = SIDE == 8 ? G : 64, NB = TPB / G;  // CXN x 2 x 2 cells per lane; threads per workgroup, blocks per workgroup
+  __shared__ int2 range[NB * NH];
+  __shared__ unsigned long long octs[NB * NH];
+  const int b0 = blockIdx.x * NB;
+  const float dx = mp.dx, dxi = 1.0f / dx;
+  for (int h = threadIdx.x; h < NB * NH; h += TPB) {
+    const int b = b0 + h / NH, hh = h % NH;
+    int2 r = make_int2(0, 0);
+    unsigned long long oc = 0ull;
+    if (b < nblocks) {
+      int o3[3];
+      c2_cell_coord<SIDE>(t, b, 0, mp.kscale, o3);
+      const int bc[3] = {o3[0] - 1 + hh / (H * H), o3[1] - 1 + (hh / H) % H, o3[2] - 1 + hh % H};
+      const int bno = ht_query<3>(buckets, bc);
+      if (bno >= 0) {
+        r = make_int2(offsets[bno], offsets[bno + 1] - offsets[bno]);
+        oc = sub[bno];
+      }
+    }
+    range[h] = r;
+    octs[h] = oc;
+  }
+  __syncthreads();
+  const int bi = threadIdx.x / G, grp = threadIdx.x % G, b = b0 + bi;
+  if (b >= nblocks) return;
+  const int g3[3] = {CXN * (grp / (GS * GS)), 2 * ((grp / GS) % GS), 2 * (grp % GS)};  // local coordinate of the lane's first cell
+  int org[3];
+  c2_cell_coord<SIDE>(t, b, 0, mp.kscale, org);
+  float pc[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pc[d][j] = ((float)(org[d] + g3[d] + j) + 0.5f) * dx;
+  float acc[4 * CXN][16];
+#pragma unroll
+  for (int c = 0; c < 4 * CXN; ++c)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[c][k] = 0.f;
+  for (int bb = 0; bb < 16 * (CXN + 2); ++bb) {  // buckets (first cell - 1) + {0..CXN+1} x {0..3}^2
+    const int bx = bb >> 4, by = (bb >> 2) & 3, bz = bb & 3;
+    const int h = bi * NH + ((g3[0] + bx) * H + g3[1] + by) * H + g3[2] + bz;
+    const int2 sc = range[h];
+    if (!sc.y) continue;
+    const unsigned long long oc = octs[h];
+    const bool ordered = oc != ~0ull;
+    // the lane's cells reach the upper half of bucket 0 and the lower half of bucket 3 only
+    const int xlo = bx == 0, xhi = bx != CXN + 1, ylo = by == 0, yhi = by != 3, zlo = bz == 0, zhi = bz != 3;
+    for (int hx = xlo; hx <= xhi; ++hx)
+      for (int hy = ylo; hy <= yhi; ++hy) {
+        int a = 0, e = sc.y;
+        if (ordered) {
+          const int clo = hx * 4 + hy * 2 + zlo, chi = hx * 4 + hy * 2 + zhi;
+          a = (int)((oc >> (8 * clo)) & 255);
+          if (chi != 7) e = (int)((oc >> (8 * chi + 8)) & 255);
+        } else if (hx != xlo || hy != ylo) {
+          continue;
+        }
+        for (int st = sc.x + a, ed = sc.x + e; st < ed; ++st) {
+          const float4 *r = rec + 4 * (size_t)st;
+          const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+          const float x3[3] = {r0.x, r0.y, r0.z};
+          float w[3][2];
+          bool in[3][2];
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float dd = pc[d][j] - x3[d];
+              in[d][j] = !(fabsf(dd) > dx);  // checkInKernelRange, :72-76
+              const float aa = fabsf(dd * dxi);
+              w[d][j] = KIND == C2_TRANSFER ? 1.f - aa : (aa <= 1 ? 1.f - aa : 0.f);  // :149-151 / :396-402, :649-655
+            }
+          const float Q[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+          float qx[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) qx[d] = Q[d] * r0.x + Q[3 + d] * r0.y + Q[6 + d] * r0.z;
+#pragma unroll
+          for (int c = 0; c < 4 * CXN; ++c) {
+            const int i = c >> 2, j = (c >> 1) & 1, k = c & 1;
+            if (in[0][i] && in[1][j] && in[2][k]) {
+              float W = 1.f;
+              W *= w[0][i]; W *= w[1][j]; W *= w[2][k];
+              acc[c][0] += r0.w * W;
+              acc[c][1] += r3.y * W; acc[c][2] += r3.z * W; acc[c][3] += r3.w * W;
+#pragma unroll
+              for (int d = 0; d < 9; ++d) acc[c][4 + d] += Q[d] * W;
+#pragma unroll
+              for (int d = 0; d < 3; ++d) acc[c][13 + d] += qx[d] * W;
+            }
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4 * CXN; ++c) {
+    const int lx = g3[0] + (c >> 2), ly = g3[1] + ((c >> 1) & 1), lz = g3[2] + (c & 1);
+    float *sp = sums + (size_t)b * 16 * NC + ((lx * SIDE + ly) * SIDE + lz);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sp[k * NC] = acc[c][k];
   }
 }
 
@@ -402,9 +520,16 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
                                                 (const int *)slotOf, rec);
   else { ZSR_DISPATCH_PURE_(0, p->model, CALL_C2_PARTICLE) }
   const HtDev bk = buckets->table->dev();
+  static const bool cell1 = [] { const char *e = getenv("ZS_ROCM_C2_CELL1"); return e && e[0] == '1'; }();  // the cell-per-lane kernel
+  constexpr int CXN = ZS_C2_CXN;  // cells per lane = CXN x 2 x 2
 #define CALL_C2_CELLS(S, K)                                                                                                               \
-  hipLaunchKernelGGL((p2c2g_cell_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, bk,                  \
-                     (const int *)buckets->offsets, (const unsigned long long *)sub, (const float4 *)rec, sums);                                                            \
+  if (cell1)                                                                                                                              \
+    hipLaunchKernelGGL((p2c2g_cell_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, bk,                \
+                       (const int *)buckets->offsets, (const unsigned long long *)sub, (const float4 *)rec, sums);                        \
+  else                                                                                                                                    \
+    hipLaunchKernelGGL((p2c2g_cell8_kernel<S, K, CXN>), dim3((unsigned)ceil_div(nblocks, (size_t)(S == 4 ? 4 * CXN : 1))),                \
+                       dim3(S == 4 ? 64 : 128 / CXN), 0, L.stream, mp, t, bk, (const int *)buckets->offsets,                              \
+                       (const unsigned long long *)sub, (const float4 *)rec, sums, (int)nblocks);                                         \
   hipLaunchKernelGGL((p2c2g_node_kernel<S, K>), dim3((unsigned)nblocks), dim3(S == 4 ? 64 : 256), 0, L.stream, mp, t, (const float *)sums, grid)
 #define CALL_C2_KIND(S)                                    \
   if (kind == C2_TRANSFER) { CALL_C2_CELLS(S, C2_TRANSFER); } \
