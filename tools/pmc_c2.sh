@@ -11,7 +11,7 @@ done
 python3 - $O <<'PY'
 import csv, glob, os, sys, collections
 root = sys.argv[1]
-TAGS = ("p2c2g_cell_kernel<8, 0>", "p2c2g_node_kernel<8, 0>", "c2_particle_kernel<0, 0>", "c2_octant", "g2c2p_cell", "g2c2p_particle_kernel<8, true")
+TAGS = ("p2c2g_cell8_kernel<8, 0", "p2c2g_node_kernel<8, 0>", "c2_particle_kernel<0, 0>", "c2_octant", "g2c2p_cell", "g2c2p_particle_kernel<8, true")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):

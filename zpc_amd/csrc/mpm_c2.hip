@@ -8,7 +8,7 @@
 // is reproducible bit for bit:
 //   P2C2G  0. per bucket: order the bucket's particles by octant                                     (c2_octant_kernel)
 //          1. per particle: constitutive update ONCE, 64-byte record {pos, mass, Q, mass*vel} in bucket order (c2_particle_kernel)
-//          2. per cell: walk the 27 buckets, sum the 16 cell moments                                   (p2c2g_cell_kernel)
+//          2. per 2x2x2 cells: walk the 4x4x4 buckets around them, sum the 16 moments of each cell     (p2c2g_cell8_kernel)
 //          3. per node: sum the 8 cells around the node, add to the grid                               (p2c2g_node_kernel)
 //   G2C2P  1. per cell: v_c and v_c (x) x_i from the 8 nodes                                            (g2c2p_cell_kernel)
 //          2. per particle: sum over the cells in range, add to v_p / B_p                              (g2c2p_particle_kernel)
