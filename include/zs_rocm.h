@@ -519,6 +519,13 @@ ZS_ROCM_EXPORT void zs_rocm_index_buckets_get_view(const zs_rocm_index_buckets *
 /* `expectedCells` sizes the hash table (0: the particle count, as the reference does: tableSize = next_2pow(n) * 16) */
 ZS_ROCM_EXPORT void zs_rocm_index_buckets_for_particles(zs_rocm_policy *, zs_rocm_index_buckets *, zs_rocm_attr pos, size_t n,
                                                         float dx, float displacement, size_t expectedCells);
+/* Buckets over the cells of a block partition, for the gather-style transfers of a time loop: bucket number = block * side^3 + cell id
+ * (the cell that contains the particle, displacement 0), counts / offsets / indices as above, but NO hash table is built (view.table ==
+ * NULL, numBuckets = nblocks * side^3): zs_rocm_mpm_p2c2g finds a cell's bucket through the partition it is given anyway, which must be
+ * this `table`.  Particles whose cell is not in the partition are listed in one extra bucket at index numBuckets that no transfer visits.
+ * 4.4 -> 1.5 ms per rebuild at 16.7 M particles (no hash inserts). */
+ZS_ROCM_EXPORT void zs_rocm_index_buckets_for_partition(zs_rocm_policy *, zs_rocm_index_buckets *, zs_rocm_attr pos, size_t n, float dx,
+                                                        const zs_rocm_bht_3 *table, int side, int keyIsOrigin);
 /* The same two functors on a zs::HashTable<i32,3,int> partition (their in-tree form: `partition_for_particles`,
  * simulation/sparsity/SparsityCompute.tpp:5-24 = CleanSparsity + ComputeSparsity(dx, blocklen, table, x), offset -2,
  * displacement 0.5; EnlargeSparsity sparsity/SparsityOp.hpp:89-115).  `zs_rocm_assign__bht_int_3_int_16(pol, bht,

@@ -21,7 +21,7 @@ def _cmp(ga, gb, rtol, chans):
         assert np.abs(A[:, ch] - B[:, ch]).max() <= rtol * s, (ch, np.abs(A[:, ch] - B[:, ch]).max() / s)
 
 
-def _setup(pol, oracle, side, model, seed, aos=False, key_is_origin=False, lane_width=64):
+def _setup(pol, oracle, side, model, seed, aos=False, key_is_origin=False, lane_width=64, dense=False):
     from zpc_amd.mpm import MpmTransfer
     dx, dt = 1.0 / 64, 1e-4
     mass, pos, vel, Bm, F = make_cloud(7, dx, 2, seed=seed, vel_scale=0.3)
@@ -38,7 +38,7 @@ def _setup(pol, oracle, side, model, seed, aos=False, key_is_origin=False, lane_
     lj0 = (0.01 * rng(seed + 2).standard_normal(n)).astype(np.float32)
     mt.upload(mass, pos, vel, Bm, F[:, :1] if model == 4 else F, lj0 if model in (1, 3) else None)
     assert mt.build_partition(n) == om.nblocks
-    mt.build_buckets()
+    mt.build_buckets(dense=dense)
     return om, mt, (mass, pos, vel, Bm, F, lj0)
 
 
@@ -242,3 +242,29 @@ def test_p2c2g_foreign_buckets(pol, oracle):
     _cmp(mt.grid_by_key(), om.grid_by_key(), 2e-4, range(4))
     gsum = mt.grid.cpu().numpy().reshape(mt.nblocks, 7, 64)[:, 0].sum()
     assert abs(gsum - mass.sum()) < 1e-4 * mass.sum()
+
+
+@pytest.mark.parametrize("side", [4, 8])
+@pytest.mark.parametrize("origin_keys", [False, True])
+def test_partition_buckets_give_the_same_bits(pol, oracle, side, origin_keys):
+    """zs_rocm_index_buckets_for_partition (bucket = block * side^3 + cell, no hash table) vs the hashed IndexBuckets: the same particles
+    per cell in the same (ascending id) order, so P2C2G produces the same bits; also through a three-step loop with in-place rebuilds."""
+    _, ma, data = _setup(pol, oracle, side, 1, seed=150, key_is_origin=origin_keys)
+    _, mb, _ = _setup(pol, oracle, side, 1, seed=150, key_is_origin=origin_keys, dense=True)
+    v = mb.buckets.view()
+    assert not v.table and v.numBuckets == mb.nblocks * side ** 3 and v.numEntries == mb.n
+    for step in range(3):
+        for m, dense in ((ma, False), (mb, True)):
+            m.build_buckets(dense=dense)
+            m.clear_grid()
+            m.p2c2g(0)
+        pol.syncCtx()
+        ga, gb = ma.grid_by_key(), mb.grid_by_key()
+        assert set(ga) == set(gb)
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), (step, k)
+        for m in (ma, mb):
+            m.grid_update((0.0, -9.8, 0.0))
+            m.g2c2p()
+    pol.syncCtx()
+    assert torch.equal(ma.buf, mb.buf)

@@ -39,6 +39,13 @@ def main(cells=128, grid=256, side=8, model=0, iters=5, shuffle=False):
         mt.build_buckets()
     torch.cuda.synchronize()
     rows["buckets_rebuild_ms"] = (time.time() - t0) * 1e3 / iters   # wall clock: the build reads the bucket count back
+    if "--hashed" not in sys.argv:
+        mt.build_buckets(dense=True); torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(iters):
+            mt.build_buckets(dense=True)
+        torch.cuda.synchronize()
+        rows["partition_buckets_rebuild_ms"] = (time.time() - t0) * 1e3 / iters   # P2C2G below then runs on these
     def p2c2g(kind):
         mt.clear_grid(); mt.p2c2g(kind)
     for kind, name in ((0, "p2c2g_ms"), (1, "p2c2g_momentum_ms"), (2, "p2c2g_force_ms")):

@@ -286,6 +286,7 @@ def _declare_containers(L):
     L.zs_rocm_index_buckets_destroy.argtypes = [vp]
     L.zs_rocm_index_buckets_get_view.argtypes = [vp, C.POINTER(IndexBucketsView)]
     L.zs_rocm_index_buckets_for_particles.argtypes = [vp, vp, Port, sz, f32, f32, sz]
+    L.zs_rocm_index_buckets_for_partition.argtypes = [vp, vp, Port, sz, f32, vp, i32, i32]
     PP = C.POINTER(MpmParams)
     L.zs_rocm_mpm_compute_sparsity.argtypes = [vp, vp, Port, sz, f32, i32, i32]
     L.zs_rocm_mpm_enlarge_sparsity.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]

@@ -352,6 +352,10 @@ class IndexBuckets:
     def build(self, pol, pos_port, n, dx, displacement=0.5, expected_cells=0):
         lib().zs_rocm_index_buckets_for_particles(pol.handle, self._h, pos_port, n, dx, displacement, expected_cells)
 
+    def build_for_partition(self, pol, pos_port, n, dx, table_handle, side, key_is_origin=False):
+        """Buckets over the cells of a block partition (zs_rocm_index_buckets_for_partition): no hash table, bucket = block * side^3 + cell."""
+        lib().zs_rocm_index_buckets_for_partition(pol.handle, self._h, pos_port, n, dx, table_handle, int(side), int(key_is_origin))
+
     def view(self):
         from ._lib import IndexBucketsView
         v = IndexBucketsView()

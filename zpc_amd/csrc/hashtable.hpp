@@ -24,5 +24,6 @@ struct zs_rocm_index_buckets {
   int numBuckets = 0, numEntries = 0;
   float dx = 1.f;
   float displacement = 0.5f;  // coord_offset the buckets were built with (Query.tpp:11)
+  int dense = 0, denseSide = 0;  // zs_rocm_index_buckets_for_partition: bucket number = block * side^3 + cell id, no hash table
   size_t capEntries = 0, capCells = 0, tableFor = 0;  // allocation sizes kept across rebuilds (a time loop rebuilds every step)
 };

@@ -37,6 +37,7 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
                                          float displacement, size_t expectedCells) {
   ib->dx = dx;
   ib->displacement = displacement;
+  ib->dense = 0;
   // a time loop rebuilds the buckets every step: table and arrays are kept while they are large enough (hipMalloc / hipFree
   // synchronise the device and cost more than the kernels below)
   const size_t want = expectedCells ? expectedCells : n;
@@ -80,6 +81,41 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < numCells) ++bits;
   radix_sort_pair_u32(L, cellOf, ids, cellSorted, ib->indices, n, 0, bits);
+}
+void zs_rocm_index_buckets_for_partition(zs_rocm_policy *pol, zs_rocm_index_buckets *ib, zs_rocm_attr pos, size_t n, float dx,
+                                         const zs_rocm_bht_3 *tab, int side, int keyIsOrigin) {
+  ib->dx = dx;
+  ib->displacement = 0.f;
+  if (ib->table) { zs_rocm_hashtable_destroy(ib->table); ib->table = nullptr; ib->tableFor = 0; }
+  ib->dense = 1;
+  ib->denseSide = side;
+  ib->numEntries = (int)n;
+  ib->numBuckets = 0;
+  Launch L(pol, "index_buckets_for_partition");
+  const int nb = bht_size(tab->t, L.stream);
+  if (!n || !nb || (side != 4 && side != 8)) return;
+  const size_t nbuckets = (size_t)nb * side * side * side, numCells = nbuckets + 2;  // + the bucket of the unlisted particles + end
+  ib->numBuckets = (int)nbuckets;
+  if (numCells > ib->capCells) {
+    (void)hipFree(ib->offsets); (void)hipFree(ib->counts);
+    ib->capCells = numCells + numCells / 2;
+    ZSR_CHECK(hipMalloc((void **)&ib->counts, ib->capCells * sizeof(int)));
+    ZSR_CHECK(hipMalloc((void **)&ib->offsets, ib->capCells * sizeof(int)));
+  }
+  if (n > ib->capEntries) {
+    (void)hipFree(ib->indices);
+    ib->capEntries = n;
+    ZSR_CHECK(hipMalloc((void **)&ib->indices, n * sizeof(int)));
+  }
+  ZSR_CHECK(hipMemsetAsync(ib->counts, 0, numCells * sizeof(int), L.stream));
+  unsigned *cellOf = (unsigned *)L.temp(sizeof(unsigned) * n), *cellSorted = (unsigned *)L.temp(sizeof(unsigned) * n);
+  int *ids = (int *)L.temp(sizeof(int) * n);
+  hipLaunchKernelGGL(ib_dense_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, tab->t.dev(), make_port<float>(pos), n, 1.0f / dx,
+                     side, keyIsOrigin ? side : 1, (int)nbuckets, (unsigned *)ib->counts, cellOf, ids);
+  exclusive_scan_u32(L, (const unsigned *)ib->counts, numCells, (unsigned *)ib->offsets);
+  int bits = 1;
+  while (bits < 32 && ((size_t)1 << bits) < numCells) ++bits;
+  radix_sort_pair_u32(L, cellOf, ids, cellSorted, ib->indices, n, 0, bits);  // stable: ids ascend inside a bucket
 }
 void zs_rocm_mpm_enlarge_sparsity__hashtable(zs_rocm_policy *pol, zs_rocm_hashtable *tab, const int lo[3], const int hi[3]) {
   if (tab->dim != 3) return;

@@ -123,11 +123,29 @@ template <int SIDE> __device__ __forceinline__ void c2_cell_coord(const BhtDev &
   coord[2] = t.activeKeys[3 * (size_t)b + 2] * cs + cell % SIDE;
 }
 
+// bucket number of a cell: a probe of the IndexBuckets' hash table, or -- buckets built over the partition itself
+// (zs_rocm_index_buckets_for_partition) -- the cell's position in the grid: block * side^3 + cell id
+struct C2Buckets {
+  HtDev ht;
+  int dense;
+};
+template <int SIDE> __device__ __forceinline__ int c2_bucket_no(const C2Buckets &bk, const BhtDev &t, int kscale, const int (&bc)[3]) {
+  if (!bk.dense) return ht_query<3>(bk.ht, bc);
+  int loc[3], key[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    loc[d] = bc[d] & (SIDE - 1);
+    key[d] = (bc[d] - loc[d]) / SIDE * kscale;
+  }
+  const int b = bht_query<3>(t, key);
+  return b < 0 ? -1 : b * (SIDE * SIDE * SIDE) + (loc[0] * SIDE + loc[1]) * SIDE + loc[2];
+}
+
 // ---- P2C2G stage 2: per cell, the 16 moments m_c, mv_c, Q_c, (Q x_p)_c  (P2C2G.hpp:66-163); sums[b][16][NC].  One workgroup per
 // block: the bucket ranges of the (SIDE+2)^3 cells around the block are looked up once (one hash probe per halo cell instead of 27 per
 // cell) and kept in LDS together with the octant offsets of stage 0.
 template <int SIDE, int KIND>
-__global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets,
+__global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, C2Buckets buckets, const int *offsets,
                                                          const unsigned long long *sub, const float4 *rec, float *sums) {
   constexpr int NC = SIDE * SIDE * SIDE, H = SIDE + 2, NH = H * H * H;
   __shared__ int2 range[NH];
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, Ht
   c2_cell_coord<SIDE>(t, b, 0, mp.kscale, org);
   for (int h = threadIdx.x; h < NH; h += blockDim.x) {
     const int bc[3] = {org[0] - 1 + h / (H * H), org[1] - 1 + (h / H) % H, org[2] - 1 + h % H};
-    const int bno = ht_query<3>(buckets, bc);
+    const int bno = c2_bucket_no<SIDE>(buckets, t, mp.kscale, bc);
     range[h] = bno < 0 ? make_int2(0, 0) : make_int2(offsets[bno], offsets[bno + 1] - offsets[bno]);  // {start, count}
     octs[h] = bno < 0 ? 0ull : sub[bno];
   }
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, Ht
 // times in different waves).  The record is loaded once and applied to whichever of the lane's 8 cells it is in range of.  One wave per
 // 8^3 block (8 blocks of 4^3 cells per wave).
 template <int SIDE, int KIND, int CXN>
-__global__ __launch_bounds__(128) void p2c2g_cell8_kernel(MpmDev mp, BhtDev t, HtDev buckets, const int *offsets,
+__global__ __launch_bounds__(128) void p2c2g_cell8_kernel(MpmDev mp, BhtDev t, C2Buckets buckets, const int *offsets,
                                                          const unsigned long long *sub, const float4 *rec, float *sums, int nblocks) {
   constexpr int NC = SIDE * SIDE * SIDE, H = SIDE + 2, NH = H * H * H, GS = SIDE / 2, G = (SIDE / CXN) * GS * GS;
   constexpr int TPB = SIDE == 8 ? G : 64, NB = TPB / G;  // CXN x 2 x 2 cells per lane; threads per workgroup, blocks per workgroup
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(128) void p2c2g_cell8_kernel(MpmDev mp, BhtDev t, H
       int o3[3];
       c2_cell_coord<SIDE>(t, b, 0, mp.kscale, o3);
       const int bc[3] = {o3[0] - 1 + hh / (H * H), o3[1] - 1 + (hh / H) % H, o3[2] - 1 + hh % H};
-      const int bno = ht_query<3>(buckets, bc);
+      const int bno = c2_bucket_no<SIDE>(buckets, t, mp.kscale, bc);
       if (bno >= 0) {
         r = make_int2(offsets[bno], offsets[bno + 1] - offsets[bno]);
         oc = sub[bno];
@@ -496,7 +514,8 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   if (kind < C2_TRANSFER || kind > C2_FORCE || (p->side != 4 && p->side != 8)) return -1;
   if (kind != C2_MOMENTUM && (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE)) return -1;
   if (!ps.n || !nblocks) return 0;
-  if (!buckets || !buckets->table || !buckets->offsets || !buckets->indices || (size_t)buckets->numEntries != ps.n) {
+  if (!buckets || (!buckets->table && !buckets->dense) || (buckets->dense && buckets->denseSide != p->side) || !buckets->offsets ||
+      !buckets->indices || (size_t)buckets->numEntries != ps.n) {
     fprintf(stderr, "[zs_rocm] p2c2g needs the IndexBuckets of these particles (index_buckets_for_particles, cell size dx, displacement 0)\n");
     return -1;
   }
@@ -507,9 +526,11 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   const size_t nc = (size_t)p->side * p->side * p->side;
   float4 *rec = (float4 *)L.temp(sizeof(float4) * 4 * ps.n);
   int *slotOf = (int *)L.temp(sizeof(int) * ps.n);
-  unsigned long long *sub = (unsigned long long *)L.temp(sizeof(unsigned long long) * (buckets->numBuckets + 1));
-  hipLaunchKernelGGL(c2_octant_kernel, dim3(ceil_div((size_t)buckets->numBuckets, 256)), dim3(256), 0, L.stream, pd.pos, 1.0f / p->dx,
-                     (const int *)buckets->offsets, (const int *)buckets->indices, buckets->numBuckets,
+  // buckets over the partition: the extra bucket of the unlisted particles is ordered too (every particle needs a record slot)
+  const int nbk = buckets->numBuckets + (buckets->dense ? 1 : 0);
+  unsigned long long *sub = (unsigned long long *)L.temp(sizeof(unsigned long long) * (nbk + 1));
+  hipLaunchKernelGGL(c2_octant_kernel, dim3(ceil_div((size_t)nbk, 256)), dim3(256), 0, L.stream, pd.pos, 1.0f / p->dx,
+                     (const int *)buckets->offsets, (const int *)buckets->indices, nbk,
                      (int)(buckets->dx == p->dx && buckets->displacement == 0.f), slotOf, sub);  // other buckets: walked whole
   float *sums = (float *)L.temp(sizeof(float) * 16 * nc * nblocks);
   const dim3 pg(ceil_div(ps.n, 256)), blk(256);
@@ -519,7 +540,7 @@ int zs_rocm_mpm_p2c2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_
   if (kind == C2_MOMENTUM) hipLaunchKernelGGL((c2_particle_kernel<ZS_MPM_FIXED_COROTATED, C2_MOMENTUM>), pg, blk, 0, L.stream, mp, pd,
                                                 (const int *)slotOf, rec);
   else { ZSR_DISPATCH_PURE_(0, p->model, CALL_C2_PARTICLE) }
-  const HtDev bk = buckets->table->dev();
+  const C2Buckets bk{buckets->dense ? HtDev{} : buckets->table->dev(), buckets->dense};
   static const bool cell1 = [] { const char *e = getenv("ZS_ROCM_C2_CELL1"); return e && e[0] == '1'; }();  // the cell-per-lane kernel
   constexpr int CXN = ZS_C2_CXN;  // cells per lane = CXN x 2 x 2
 #define CALL_C2_CELLS(S, K)                                                                                                               \

@@ -685,6 +685,27 @@ static __global__ __launch_bounds__(256) void ib_count_kernel(HtDev t, Port<floa
   ids[i] = (int)i;
   atomicAdd(&counts[c], 1u);
 }
+// buckets over the cells of a block partition (zs_rocm_index_buckets_for_partition): bucket = block * side^3 + cell id of the cell
+// that contains the particle; particles whose cell is not in the partition go to the extra bucket `nbuckets`
+static __global__ __launch_bounds__(256) void ib_dense_count_kernel(BhtDev t, Port<float> pos, size_t n, float dxinv, int side, int kscale,
+                                                             int nbuckets, unsigned *counts, unsigned *cellOf, int *ids) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[3];
+  load_attr<3>(pos, i, p);
+  int key[3], loc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int c = (int)floorf(p[d] * dxinv);
+    loc[d] = c & (side - 1);
+    key[d] = (c - loc[d]) / side * kscale;
+  }
+  const int b = bht_query<3>(t, key);
+  const int bucket = b < 0 ? nbuckets : b * side * side * side + (loc[0] * side + loc[1]) * side + loc[2];
+  cellOf[i] = (unsigned)bucket;
+  ids[i] = (int)i;
+  atomicAdd(&counts[bucket], 1u);
+}
 static __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, int nblocks, int *nbr, int kscale) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nblocks * 8) return;

@@ -203,12 +203,17 @@ class MpmTransfer:
                               self.nblocks, bs, cc, nb)
 
     # ------------------------------------------------------------------ gather-style transfers (P2C2G.hpp / G2C2P.hpp)
-    def build_buckets(self, displacement=0.0):
+    def build_buckets(self, displacement=0.0, dense=False):
         """IndexBuckets of cell size dx over the current positions (index_buckets_for_particles, displacement 0): bucket = the cell
         that contains the particle, which is what P2C2GTransfer's 27-bucket walk expects."""
         from .containers import IndexBuckets
         if getattr(self, "buckets", None) is None:
             self.buckets = IndexBuckets()   # rebuilt in place every step: the table and the arrays are reused
+        if dense:   # buckets over the partition's own cells: no hash table to fill (a time loop rebuilds the buckets every step)
+            assert displacement == 0.0
+            self.buckets.build_for_partition(self.pol, self._port("x"), self.n, self.params.dx, self.table.handle, self.side,
+                                             self.key_is_origin)
+            return self.buckets
         # table sized for the occupied cells, which the partition bounds (the reference sizes it for one cell per particle)
         cells = min(self.n, self.nblocks * self.side ** 3) if getattr(self, "nblocks", 0) else 0
         self.buckets.build(self.pol, self._port("x"), self.n, self.params.dx, displacement=displacement, expected_cells=cells)
