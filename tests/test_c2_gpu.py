@@ -268,3 +268,47 @@ def test_partition_buckets_give_the_same_bits(pol, oracle, side, origin_keys):
             m.g2c2p()
     pol.syncCtx()
     assert torch.equal(ma.buf, mb.buf)
+
+
+def test_partition_buckets_with_unlisted_particles(pol, oracle):
+    """Particles whose cell is not in the partition sit in the extra bucket no transfer visits: the grid gets exactly what the listed
+    particles give, nothing is written out of bounds, and G2C2P leaves the unlisted particles' v, B at zero."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Bm, F = make_cloud(5, dx, 2, seed=160, vel_scale=0.3)
+    Bm = (Bm * dx * dx * 0.25).astype(np.float32)
+    n0 = pos.shape[0]
+    vol = dx ** 3 / 8
+    ref = MpmTransfer(pol, n0, dx, dt, model=0, side=4, volume=vol)
+    ref.upload(mass, pos, vel, Bm, F)
+    ref.build_partition(n0)
+    ref.build_buckets(dense=True)
+    ref.clear_grid()
+    ref.p2c2g(0)
+    # the same cloud + 300 particles far outside the partition (> 255 of them in one cell: the extra bucket is not octant-ordered)
+    g = rng(161)
+    far = (np.array([0.9, 0.9, 0.9], np.float32) + g.random((300, 3)).astype(np.float32) * dx * 0.9).astype(np.float32)
+    pos2 = np.concatenate([pos, far])
+    n = pos2.shape[0]
+    cat = lambda a, w: np.concatenate([a, np.tile(a[:1], (300,) + (1,) * (a.ndim - 1))]).astype(np.float32)
+    mt = MpmTransfer(pol, n, dx, dt, model=0, side=4, volume=vol)
+    mt.upload(cat(mass, 1), pos2, cat(vel, 3), cat(Bm, 9), cat(F, 9))
+    mt.table, mt.nblocks, mt.nbr = ref.table, ref.nblocks, ref.nbr            # the partition of the first cloud only
+    mt.grid = torch.zeros_like(ref.grid)
+    mt.build_buckets(dense=True)
+    v = mt.buckets.view()
+    assert v.numEntries == n and v.numBuckets == ref.nblocks * 64
+    mt.p2c2g(0)
+    pol.syncCtx()
+    assert torch.equal(mt.grid, ref.grid)
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.g2c2p()
+    pol.syncCtx()
+    d = mt.download()
+    assert not d["v"][n0:].any() and not d["C"][n0:].any() and np.abs(d["v"][:n0]).max() > 0
+    assert zs_no_error()
+
+
+def zs_no_error():
+    import zpc_amd
+    return zpc_amd.lib().zs_rocm_last_error(-1) == 0
