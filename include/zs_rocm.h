@@ -588,9 +588,9 @@ ZS_ROCM_EXPORT void zs_rocm_collider_resolve(zs_rocm_policy *, const zs_rocm_col
  * pol(Collapse{nblocks, side^3}, P2C2GTransfer{scheme, dt, model, buckets, particles, table, grids}): kind 0 = P2C2GTransfer
  * (simulation/transfer/P2C2G.hpp:29-305: mass, momentum with the affine term, and -dt * stress), 1 = P2C2GTransferMomentum (:321-506: mass and
  * momentum only), 2 = P2C2GTransferForce (:522-790: -dt * stress only).  ADDS into grid channels 0..3 (m, mv) like the reference's atomics.
- * `buckets` = zs_rocm_index_buckets_for_particles(pos, n, dx, displacement 0); particles.C is the reference's `B` (Structurefree.hpp:268-271:
- * one storage).  Built from gathers only (per particle -> per cell -> per node): no float atomics, reproducible bit for bit; each particle's
- * constitutive update runs once (the reference functor repeats it, and its logJp store, for every cell that sees the particle).
+ * `buckets` = zs_rocm_index_buckets_for_particles(pos, n, dx, displacement 0) or zs_rocm_index_buckets_for_partition(...) over this table;
+ * particles.C is the reference's `B` (Structurefree.hpp:268-271: one storage).  Built from gathers only (per bucket -> per particle -> per
+ * 2x2x2 cells -> per node): no float atomics, reproducible bit for bit; each particle's constitutive update runs once (the reference functor repeats it, and its logJp store, for every cell that sees the particle).
  * Returns 0, -1 on bad arguments. */
 ZS_ROCM_EXPORT int zs_rocm_mpm_p2c2g(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_index_buckets *buckets,
                                      const zs_rocm_bht_3 *, float *grid, size_t nblocks, int kind);
