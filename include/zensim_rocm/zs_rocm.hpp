@@ -196,6 +196,15 @@ template <class T> struct Vector {
     tmp._size = n;
     swap(tmp);
   }
+  // retrieveVals / assignVals (Vector.hpp: whole-range copies out of / into the container), push_back / append (host-side growth)
+  void retrieveVals(T *dst) const { if (_size) (void)hipMemcpy(dst, _data, _size * sizeof(T), hipMemcpyDefault); }
+  void assignVals(const T *src) { if (_size) (void)hipMemcpy(_data, src, _size * sizeof(T), hipMemcpyDefault); }
+  void push_back(const T &v) { resize(_size + 1); setVal(v, _size - 1); }
+  void append(const Vector &o) {
+    const std::size_t old = _size;
+    resize(old + o._size);
+    if (o._size) (void)hipMemcpy(_data + old, o._data, o._size * sizeof(T), hipMemcpyDefault);
+  }
   Vector clone(memsrc_e mre) const {
     Vector r(_size, mre);
     if (_size) (void)hipMemcpy(r._data, _data, _size * sizeof(T), hipMemcpyDefault);
@@ -270,7 +279,16 @@ template <class T, int L> struct TileVector {
     return -1;
   }
   T *data() { return _buf.data(); }
+  const T *data() const { return _buf.data(); }
   void reset(int ch) { _buf.reset(ch); }
+  // maintenance ops that take a policy (TileVector.hpp:583-640); defined after RocmExecutionPolicy below
+  template <class Pol> void append_channels(const Pol &pol, const std::vector<PropertyTag> &tags);
+  template <class Pol> void reset(const Pol &pol, T val);
+  TileVector clone(memsrc_e mre) const {
+    TileVector r(_tags, _size, mre);
+    if (_buf.size()) (void)hipMemcpy(r._buf.data(), _buf.data(), _buf.size() * sizeof(T), hipMemcpyDefault);
+    return r;
+  }
   aosoa_iterator_float_1 port(int chn, unsigned idx = 0) {  // py_interop/GenericIterator.hpp:76-82 (float instantiation)
     static_assert(sizeof(T) == 4, "");
     int bits = 0;
@@ -599,6 +617,7 @@ struct RocmExecutionPolicy {
   bool shouldSync() const { return _sync; }
   void *getStream() const { return zs_rocm_policy_get_stream(_h); }
   void syncCtx() const { zs_rocm_policy_sync_ctx(_h); }
+  ProcID getProcid() const { return _dev; }  // -1 = the current device (cuda/execution/ExecutionPolicy.cuh:905)
   zs_rocm_policy *handle() const { return _h; }
 
   // pol(range(n), f)
@@ -727,6 +746,52 @@ template <class KeyIter, class Comp = less<void>> void sort(const RocmExecutionP
 template <class KeyIter, class ValIter, class Comp = less<void>>
 void sort_pair(const RocmExecutionPolicy &pol, KeyIter keys, ValIter vals, std::size_t n, Comp comp = {}) {
   pol.merge_sort_pair(keys, vals, n, comp);
+}
+
+
+// zs::for_each (execution/ExecutionPolicy.hpp:684-690), zs::par_exec(tag) (:85-97)
+template <class Range, class F> void for_each(const RocmExecutionPolicy &pol, Range &&r, F &&f) { pol(std::forward<Range>(r), std::forward<F>(f)); }
+inline RocmExecutionPolicy par_exec(rocm_exec_tag) { return rocm_exec(); }
+// valid_memspace_for_execution (resource/Resource.h:163-166, rocm branch): device and unified memory
+inline bool valid_memspace_for_execution(const RocmExecutionPolicy &, memsrc_e mre) { return mre == memsrc_e::device || mre == memsrc_e::um; }
+
+// zs::make_monoid(op).identity() (ZpcFunctional.hpp): the identities the primitives use as `init`
+template <class Op> struct monoid;
+template <class T> struct monoid<plus<T>> : plus<T> { static constexpr T identity() { return T(0); } };
+template <class T> struct monoid<multiplies<T>> : multiplies<T> { static constexpr T identity() { return T(1); } };
+template <class T> struct monoid<getmin<T>> : getmin<T> { static constexpr T identity() { return std::numeric_limits<T>::max(); } };
+template <class T> struct monoid<getmax<T>> : getmax<T> { static constexpr T identity() { return std::numeric_limits<T>::lowest(); } };
+template <class Op> constexpr monoid<Op> make_monoid(Op) { return {}; }
+
+// TileVector::append_channels(pol, tags) (TileVector.hpp:583-623): new channels are zero-filled, an existing tag must keep its width
+template <class T, int L> template <class Pol> void TileVector<T, L>::append_channels(const Pol &pol, const std::vector<PropertyTag> &tags) {
+  std::vector<PropertyTag> all = _tags;
+  for (auto &t : tags) {
+    bool found = false;
+    for (auto &o : _tags)
+      if (o.name == t.name) {
+        if (o.numChannels != t.numChannels) throw std::runtime_error("append_channels: property \"" + t.name + "\" changes its width");
+        found = true;
+      }
+    if (!found) all.push_back(t);
+  }
+  if (all.size() == _tags.size()) return;
+  TileVector grown(all, _size, _mre);
+  grown._buf.reset(0);
+  const int Co = _C, Cn = grown._C;
+  const T *src = _buf.data();
+  T *dst = grown._buf.data();
+  const long long rows = (long long)tiles() * Co * L;  // one element of one channel row per thread, whole tiles
+  pol(range(rows), [=] ZS_LAMBDA(long long e) {
+    const long long tile = e / ((long long)Co * L), r = e % ((long long)Co * L);
+    dst[tile * Cn * L + r] = src[e];  // the old channels keep their offsets, so a tile's first Co rows copy straight over
+  });
+  *this = std::move(grown);
+}
+// TileVector::reset(pol, val) (TileVector.hpp:624-640)
+template <class T, int L> template <class Pol> void TileVector<T, L>::reset(const Pol &pol, T val) {
+  T *p = _buf.data();
+  pol(range((long long)_buf.size()), [=] ZS_LAMBDA(long long e) { p[e] = val; });
 }
 
 }  // namespace zs

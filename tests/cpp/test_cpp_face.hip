@@ -372,6 +372,44 @@ int main() {
     CHECK(inside > 200 && inside < nq - 200);
   }
   CHECK(zs_rocm_last_error(-1) == 0);
+  // ---- Appendix-B odds and ends: append_channels / reset(pol, val) / clone, Vector bulk copies, for_each, par_exec, make_monoid
+  {
+    const int n = 1000;
+    TileVector<float, 32> tv({{"m", 1}, {"x", 3}}, n, memsrc_e::um);
+    tv.reset(pol, 2.5f);
+    CHECK(tv.data()[0] == 2.5f && tv.data()[tv.tiles() * 32 * 4 - 1] == 2.5f);
+    pol(range(n), [t = view<space>(tv)] ZS_LAMBDA(long long i) { t(1, i) = (float)i; });
+    tv.append_channels(pol, {{"x", 3}, {"v", 3}, {"J", 1}});  // "x" exists with the same width; "v" and "J" are new, zero-filled
+    CHECK(tv.numChannels() == 8 && tv.getPropertyOffset("v") == 4 && tv.getPropertyOffset("J") == 7 && tv.size() == (size_t)n);
+    pol.syncCtx();
+    for (int i = 0; i < n; ++i) {
+      const float *b = tv.data() + ((size_t)(i / 32) * 8) * 32 + i % 32;
+      CHECK(b[0] == 2.5f && b[32] == (float)i && b[4 * 32] == 0.f && b[7 * 32] == 0.f);
+    }
+    bool threw = false;
+    try { tv.append_channels(pol, {{"x", 2}}); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    auto h = tv.clone(memsrc_e::host);
+    CHECK(h.data()[32 + 5] == 5.f && h.numChannels() == 8);
+    Vector<int> a(4), b(3);
+    const int av[4] = {1, 2, 3, 4}, bv[3] = {7, 8, 9};
+    a.assignVals(av);
+    b.assignVals(bv);
+    a.append(b);
+    a.push_back(11);
+    int out[8];
+    a.retrieveVals(out);
+    CHECK(a.size() == 8 && out[0] == 1 && out[3] == 4 && out[4] == 7 && out[6] == 9 && out[7] == 11);
+    Vector<int> cnt(1);
+    cnt.setVal(0);
+    for_each(par_exec(rocm_c), range(1000), [c = view<space>(cnt)] ZS_LAMBDA(long long i) { atomic_add(exec_rocm, &c[0], (int)(i & 1)); });
+    CHECK(cnt.getVal() == 500);
+    CHECK(make_monoid(plus<int>{}).identity() == 0 && make_monoid(multiplies<float>{}).identity() == 1.f);
+    CHECK(make_monoid(getmin<int>{}).identity() == 2147483647 && make_monoid(getmax<int>{}).identity() == (-2147483647 - 1));
+    CHECK(make_monoid(getmax<int>{})(3, 9) == 9);
+    CHECK(valid_memspace_for_execution(pol, memsrc_e::device) && !valid_memspace_for_execution(pol, memsrc_e::host));
+    CHECK(pol.getProcid() == -1);
+  }
   std::printf("cpp face ok\n");
   return 0;
 }
