@@ -337,6 +337,19 @@ template <int dim> struct BHTView {  // BHTView (Bht.hpp:403-1072): insert / que
   __device__ __forceinline__ int query(const small_vec<int, dim> &key) const { return zsr::bht_query<dim>(t, key.v); }
   __device__ __forceinline__ int entry(const small_vec<int, dim> &key) const { return zsr::bht_query<dim, true>(t, key.v); }  // slot (:700-731)
   __device__ __forceinline__ int size() const { return *t.cnt; }
+  // tile_insert / tile_query (Bht.hpp:562-605, :734-776): every lane of the tile carries the same key and gets the same answer.  The
+  // reference lets the tile's lanes probe one B-slot bucket together; here rank 0 runs the lock-free probe (one 16-byte load per
+  // slot, bht_device.hpp) and the tile shares its result.  Tile = any cooperative-groups tile (thread_rank(), shfl()).
+  template <class Tile> __device__ __forceinline__ int tile_insert(Tile &tile, const small_vec<int, dim> &key) const {
+    int r = 0;
+    if (tile.thread_rank() == 0) r = insert(key);
+    return tile.shfl(r, 0);
+  }
+  template <class Tile> __device__ __forceinline__ int tile_query(Tile &tile, const small_vec<int, dim> &key) const {
+    int r = 0;
+    if (tile.thread_rank() == 0) r = query(key);
+    return tile.shfl(r, 0);
+  }
   int *_activeKeys() const { return t.activeKeys; }
 };
 template <int dim, int B = 16> struct bht {
@@ -754,6 +767,15 @@ template <class Range, class F> void for_each(const RocmExecutionPolicy &pol, Ra
 inline RocmExecutionPolicy par_exec(rocm_exec_tag) { return rocm_exec(); }
 // valid_memspace_for_execution (resource/Resource.h:163-166, rocm branch): device and unified memory
 inline bool valid_memspace_for_execution(const RocmExecutionPolicy &, memsrc_e mre) { return mre == memsrc_e::device || mre == memsrc_e::um; }
+
+// get_temporary_memory_source(pol) (resource/Resource.h:52-58 -> temporary_memory_resource<device_mem_tag>): stream-ordered scratch of
+// the policy's stream; allocations stay valid until the next launch through the same policy and are recycled, never freed one by one
+struct TemporaryMemorySource {
+  zs_rocm_policy *_h;
+  void *allocate(std::size_t bytes, std::size_t = 256) const { return zs_rocm_policy_temporary(_h, bytes); }
+  void deallocate(void *, std::size_t, std::size_t = 256) const {}
+};
+inline TemporaryMemorySource get_temporary_memory_source(const RocmExecutionPolicy &pol) { return {pol.handle()}; }
 
 // zs::make_monoid(op).identity() (ZpcFunctional.hpp): the identities the primitives use as `init`
 template <class Op> struct monoid;

@@ -10,6 +10,8 @@
 #include <numeric>
 #include <vector>
 
+#include <hip/hip_cooperative_groups.h>
+
 #include "zensim_rocm/zs_rocm.hpp"
 #include "zensim_rocm/collider_device.hpp"
 
@@ -409,6 +411,31 @@ int main() {
     CHECK(make_monoid(getmax<int>{})(3, 9) == 9);
     CHECK(valid_memspace_for_execution(pol, memsrc_e::device) && !valid_memspace_for_execution(pol, memsrc_e::host));
     CHECK(pol.getProcid() == -1);
+    int *scratch = (int *)get_temporary_memory_source(pol).allocate(1000 * sizeof(int));
+    CHECK(scratch != nullptr);
+    pol(range(1000), [scratch] ZS_LAMBDA(long long i) { scratch[i] = (int)i; });
+    Vector<int> total(1);
+    reduce(pol, (const int *)scratch, (const int *)scratch + 1000, total.data(), 0, plus<int>{});
+    CHECK(total.getVal() == 499500);
+    // tile_insert / tile_query: 16-lane tiles, every lane of a tile carries the tile's key
+    bht<3> tb(4096);
+    Vector<int> bad(1);
+    bad.setVal(0);
+    pol(range(64 * 16), [t = view<space>(tb), b = view<space>(bad)] ZS_LAMBDA(long long i) {
+      auto tile = cooperative_groups::tiled_partition<16>(cooperative_groups::this_thread_block());
+      const int g = (int)(i / 16);
+      small_vec<int, 3> key{{g % 4, (g / 4) % 4, g / 16}};
+      const int no = t.tile_insert(tile, key);
+      if (no < 0 || no >= 64) atomic_add(exec_rocm, &b[0], 1);
+    });
+    CHECK(tb.size() == 64 && bad.getVal() == 0);
+    pol(range(64 * 16), [t = view<space>(tb), b = view<space>(bad)] ZS_LAMBDA(long long i) {
+      auto tile = cooperative_groups::tiled_partition<16>(cooperative_groups::this_thread_block());
+      const int g = (int)(i / 16);
+      small_vec<int, 3> key{{g % 4, (g / 4) % 4, g / 16}}, absent{{9, g, 9}};
+      if (t.tile_query(tile, key) < 0 || t.tile_query(tile, absent) != -1) atomic_add(exec_rocm, &b[0], 1);
+    });
+    CHECK(bad.getVal() == 0);
   }
   std::printf("cpp face ok\n");
   return 0;
