@@ -239,6 +239,30 @@ template <class T, int N> struct small_vec {
   ZS_FUNCTION const T &operator[](int i) const { return v[i]; }
   ZS_FUNCTION T &operator()(int i) { return v[i]; }
 };
+// zs::ndrange<d>(n) (ZpcIterator.hpp): the index tuples of {0..n-1}^d, first index slowest -- `for (auto loc : ndrange<3>(3))` walks a
+// stencil in the order the transfers use (simulation/transfer/P2G.hpp:106, P2C2G.hpp:79); get<I>(loc) or loc[I] reads a component
+template <int d> struct ndrange_t {
+  int n;
+  struct iterator {
+    int i, n;
+    ZS_FUNCTION small_vec<int, d> operator*() const {
+      small_vec<int, d> r{};
+      int k = i;
+      for (int a = d - 1; a >= 0; --a) { r.v[a] = k % n; k /= n; }
+      return r;
+    }
+    ZS_FUNCTION iterator &operator++() { ++i; return *this; }
+    ZS_FUNCTION bool operator!=(const iterator &o) const { return i != o.i; }
+  };
+  ZS_FUNCTION iterator begin() const { return {0, n}; }
+  ZS_FUNCTION iterator end() const {
+    int t = 1;
+    for (int a = 0; a < d; ++a) t *= n;
+    return {t, n};
+  }
+};
+template <int d> ZS_FUNCTION constexpr ndrange_t<d> ndrange(int n) { return {n}; }
+template <int I, class T, int N> ZS_FUNCTION constexpr const T &get(const small_vec<T, N> &v) { return v.v[I]; }
 template <int... Ns> struct dim_t {};
 template <int... Ns> constexpr dim_t<Ns...> dim_c{};
 

@@ -411,6 +411,19 @@ int main() {
     CHECK(make_monoid(getmax<int>{})(3, 9) == 9);
     CHECK(valid_memspace_for_execution(pol, memsrc_e::device) && !valid_memspace_for_execution(pol, memsrc_e::host));
     CHECK(pol.getProcid() == -1);
+    {  // ndrange<3>(3): 27 stencil offsets, first index slowest, on the host and inside a kernel
+      int k = 0, okh = 1;
+      for (auto loc : ndrange<3>(3)) { okh &= (get<0>(loc) == k / 9 && loc[1] == (k / 3) % 3 && get<2>(loc) == k % 3); ++k; }
+      CHECK(k == 27 && okh);
+      Vector<int> s3(1);
+      s3.setVal(0);
+      pol(range(64), [s = view<space>(s3)] ZS_LAMBDA(long long) {
+        int acc = 0;
+        for (auto loc : ndrange<3>(3)) acc += get<0>(loc) * 9 + get<1>(loc) * 3 + get<2>(loc);
+        atomic_add(exec_rocm, &s[0], acc);
+      });
+      CHECK(s3.getVal() == 64 * 351);
+    }
     int *scratch = (int *)get_temporary_memory_source(pol).allocate(1000 * sizeof(int));
     CHECK(scratch != nullptr);
     pol(range(1000), [scratch] ZS_LAMBDA(long long i) { scratch[i] = (int)i; });
