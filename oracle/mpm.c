@@ -431,10 +431,10 @@ static void model_contrib(const orc_mpm_params *p, float mu, float lam, const fl
   } else if (p->model == 0) {
     orc_stress_fixedcorotated(p->volume, mu, lam, F, contrib);
   } else if (p->model == 2) { /* P2G.hpp:86-88 */
-    orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, 0, F, contrib);
+    orc_stress_vonmises(p->volume, mu, lam, p->yieldStress, p->hostVariant, F, contrib);
   } else if (p->model == 3) { /* P2G.hpp:96-101 */
     float lj = *logJp;
-    orc_stress_nacc(p->volume, mu, lam, orc_nacc_bulk(p->E, p->nu), p->xi, p->beta, p->Msqr, p->hardeningOn, 0, &lj, F, contrib);
+    orc_stress_nacc(p->volume, mu, lam, orc_nacc_bulk(p->E, p->nu), p->xi, p->beta, p->Msqr, p->hardeningOn, p->hostVariant, &lj, F, contrib);
     *logJp = lj;
   } else {
     float lj = *logJp;

@@ -19,6 +19,10 @@
 #include "zensim/math/bit/Bits.h"
 #include "zensim/geometry/AnalyticLevelSet.h" /* AABBBox, overlaps, BoundingVolumeInterface */
 #include "zensim/math/Rotation.hpp"            /* Rotation, AngularVelocity (members of Collider) */
+#include "zensim/simulation/Utils.hpp"         /* LocalArena / make_local_arena, unpack_coord_in_grid(coord, side) */
+#include "zensim/math/matrix/MatrixUtils.h"    /* matrixMatrixMultiplication3d */
+#include <array>
+#include <map>
 #include <random>
 
 using namespace zs;
@@ -59,7 +63,188 @@ static int ref_resolve_with(const LS &levelset, int type, float s, float dsdt, c
   return hit;
 }
 
+/* ---- P2GTransfer / G2PTransfer as whole functions (simulation/transfer/P2G.hpp:51-125, G2P.hpp:44-83) ---------------------
+   The functor headers include ExecutionPolicy.hpp / Structure.hpp / HashTable.hpp (un-vendored magic_enum: unbuildable here), so --
+   exactly like Collider::resolveCollision above -- the per-particle bodies are spelled out over the reference's OWN pieces, which do
+   build: make_local_arena / LocalArena::{range, coord, diff, weight} and the 2-argument unpack_coord_in_grid
+   (simulation/Utils.hpp), compute_stress_* and the *Config structs, lame_parameters, vec, matrixMatrixMultiplication3d.  Only the
+   containers are replaced: the partition (HashTable query of a block coordinate) by a std::map over the caller's block keys, the
+   Grids block (grid_block(chn, cellid), Structure.hpp:323-333 coord_to_cellid for a power-of-two side: (x << b | y) << b | z) by a
+   [nblocks][7][side^3] float array, atomic_add by += under the SequentialExecutionPolicy's particle order 0..n-1. */
+struct RefGrid {
+  std::map<std::array<int, 3>, int> blocks;
+  float *data;
+  int side, ncell, bits;
+  float *chan(const vec<int, 3> &blk, int chn) const {
+    auto it = blocks.find({blk[0], blk[1], blk[2]});
+    return it == blocks.end() ? nullptr : data + ((size_t)it->second * 7 + chn) * ncell;
+  }
+  int cellid(const vec<int, 3> &loc) const { return (((loc[0] << bits) | loc[1]) << bits) | loc[2]; }
+};
+static RefGrid make_ref_grid(int side, int nblocks, const int *keys, float *data) {
+  RefGrid g;
+  g.data = data;
+  g.side = side;
+  g.ncell = side * side * side;
+  g.bits = side == 4 ? 2 : 3;
+  for (int b = 0; b < nblocks; ++b) g.blocks[{keys[3 * b], keys[3 * b + 1], keys[3 * b + 2]}] = b;
+  return g;
+}
+template <class model_t>
+static int ref_p2g_with(const model_t &model, float dx, float dt, const RefGrid &grids, size_t n, const float *massA, const float *posA,
+                        const float *velA, const float *CA, const float *FA, float *logJpA) {
+  using vec3 = vec<float, 3>;
+  using vec9 = vec<float, 9>;
+  int missed = 0;
+  float const dx_inv = 1.0f / dx; /* dxinv(): static_cast<decltype(grids._dx)>(1.0) / grids._dx */
+  float const D_inv = 4.f * dx_inv * dx_inv;
+  for (size_t parid = 0; parid < n; ++parid) {
+    vec3 local_pos{posA[3 * parid], posA[3 * parid + 1], posA[3 * parid + 2]};
+    vec3 vel{velA[3 * parid], velA[3 * parid + 1], velA[3 * parid + 2]};
+    float mass = massA[parid];
+    vec9 contrib{vec9::zeros()}, C{};
+    for (int d = 0; d < 9; ++d) C[d] = CA[9 * parid + d];
+    if constexpr (is_same_v<model_t, EquationOfStateConfig>) {
+      float J = FA[9 * parid]; /* the J attribute is handed over in component 0 of the F slot */
+      float vol = model.volume * J;
+      float pressure = model.bulk;
+      {
+        float J2 = J * J;
+        float J4 = J2 * J2;
+        pressure = pressure * (1 / (J * J2 * J4) - 1);
+      }
+      contrib[0] = ((C[0] + C[0]) * model.viscosity - pressure) * vol;
+      contrib[1] = (C[1] + C[3]) * model.viscosity * vol;
+      contrib[2] = (C[2] + C[6]) * model.viscosity * vol;
+      contrib[3] = (C[3] + C[1]) * model.viscosity * vol;
+      contrib[4] = ((C[4] + C[4]) * model.viscosity - pressure) * vol;
+      contrib[5] = (C[5] + C[7]) * model.viscosity * vol;
+      contrib[6] = (C[6] + C[2]) * model.viscosity * vol;
+      contrib[7] = (C[7] + C[5]) * model.viscosity * vol;
+      contrib[8] = ((C[8] + C[8]) * model.viscosity - pressure) * vol;
+    } else {
+      const auto [mu, lambda] = lame_parameters(model.E, model.nu);
+      vec9 F{};
+      for (int d = 0; d < 9; ++d) F[d] = FA[9 * parid + d];
+      if constexpr (is_same_v<model_t, FixedCorotatedConfig>) {
+        compute_stress_fixedcorotated(model.volume, mu, lambda, F, contrib);
+      } else if constexpr (is_same_v<model_t, VonMisesFixedCorotatedConfig>) {
+        compute_stress_vonmisesfixedcorotated(model.volume, mu, lambda, model.yieldStress, F, contrib);
+      } else {
+        float logJp = logJpA[parid];
+        if constexpr (is_same_v<model_t, DruckerPragerConfig>) {
+          compute_stress_sand(model.volume, mu, lambda, model.cohesion, model.beta, model.yieldSurface, model.volumeCorrection, logJp, F,
+                              contrib);
+        } else if constexpr (is_same_v<model_t, NACCConfig>) {
+          compute_stress_nacc(model.volume, mu, lambda, model.bulk(), model.xi, model.beta, model.Msqr(), model.hardeningOn, logJp, F,
+                              contrib);
+        }
+        logJpA[parid] = logJp;
+      }
+    }
+    contrib = contrib * -dt * D_inv;
+    auto arena = make_local_arena((float)dx, local_pos);
+    for (auto loc : arena.range()) {
+      auto [blockCoord, local_index] = unpack_coord_in_grid(arena.coord(loc), grids.side);
+      auto xixp = arena.diff(loc);
+      float W = arena.weight(loc);
+      const auto cellid = grids.cellid(local_index);
+      float *m = grids.chan(blockCoord, 0);
+      if (!m) {
+        ++missed;
+        continue;
+      }
+      m[cellid] += mass * W;
+      for (int d = 0; d != 3; ++d) {
+        grids.chan(blockCoord, 1 + d)[cellid] += W * mass * (vel[d] + (C[d] * xixp[0] + C[3 + d] * xixp[1] + C[6 + d] * xixp[2]));
+        grids.chan(blockCoord, 3 + 1 + d)[cellid] += (contrib[d] * xixp[0] + contrib[3 + d] * xixp[1] + contrib[6 + d] * xixp[2]) * W;
+      }
+    }
+  }
+  return missed;
+}
+template <class model_t>
+static int ref_g2p_with(const model_t &model, float dx, float dt, const RefGrid &grids, size_t n, float *posA, float *velA, float *CA,
+                        float *FA) {
+  using value_type = float;
+  using vec3 = vec<value_type, 3>;
+  using vec9 = vec<value_type, 9>;
+  int missed = 0;
+  value_type const dx_inv = (value_type)1 / dx;
+  value_type const D_inv = 4.f * dx_inv * dx_inv;
+  for (size_t parid = 0; parid < n; ++parid) {
+    vec3 pos{posA[3 * parid], posA[3 * parid + 1], posA[3 * parid + 2]};
+    vec3 vel{vec3::zeros()};
+    vec9 C{vec9::zeros()};
+    auto arena = make_local_arena(dx, pos);
+    for (auto loc : arena.range()) {
+      auto [blockCoord, local_index] = unpack_coord_in_grid(arena.coord(loc), grids.side);
+      auto xixp = arena.diff(loc);
+      float W = arena.weight(loc);
+      const auto cellid = grids.cellid(local_index);
+      if (!grids.chan(blockCoord, 1)) {
+        ++missed;
+        continue;
+      }
+      vec3 vi{grids.chan(blockCoord, 1)[cellid], grids.chan(blockCoord, 2)[cellid], grids.chan(blockCoord, 3)[cellid]}; /* pack<3>(1, cellid) */
+      vel += vi * W;
+      for (int d = 0; d < 9; ++d) C[d] += W * vi(d % 3) * xixp(d / 3) * D_inv;
+    }
+    pos += vel * dt;
+    if constexpr (is_same_v<model_t, EquationOfStateConfig>) {
+      float J = FA[9 * parid];
+      J = (1 + (C[0] + C[4] + C[8]) * dt) * J;
+      FA[9 * parid] = J;
+    } else {
+      vec9 oldF{}, tmp{}, F{};
+      for (int d = 0; d < 9; ++d) oldF[d] = FA[9 * parid + d];
+      for (int d = 0; d < 9; ++d) tmp(d) = C[d] * dt + ((d & 0x3) ? 0.f : 1.f);
+      matrixMatrixMultiplication3d(tmp.data(), oldF.data(), F.data());
+      for (int d = 0; d < 9; ++d) FA[9 * parid + d] = F[d];
+    }
+    for (int d = 0; d < 3; ++d) posA[3 * parid + d] = pos[d];
+    for (int d = 0; d < 3; ++d) velA[3 * parid + d] = vel[d];
+    for (int d = 0; d < 9; ++d) CA[9 * parid + d] = C[d];
+  }
+  return missed;
+}
+/* prm: {volume, E, nu, cohesion, beta, yieldSurface, volumeCorrection, yieldStress, xi, fa, hardeningOn, bulk, viscosity} */
+template <class Fn> static int ref_with_model(int model, const float *prm, Fn &&fn) {
+  if (model == 0) {
+    FixedCorotatedConfig c{};
+    c.volume = prm[0], c.E = prm[1], c.nu = prm[2];
+    return fn(c);
+  } else if (model == 1) {
+    DruckerPragerConfig c{};
+    c.volume = prm[0], c.E = prm[1], c.nu = prm[2], c.cohesion = prm[3], c.beta = prm[4], c.yieldSurface = prm[5], c.volumeCorrection = prm[6] != 0;
+    return fn(c);
+  } else if (model == 2) {
+    VonMisesFixedCorotatedConfig c{};
+    c.volume = prm[0], c.E = prm[1], c.nu = prm[2], c.yieldStress = prm[7];
+    return fn(c);
+  } else if (model == 3) {
+    NACCConfig c{};
+    c.volume = prm[0], c.E = prm[1], c.nu = prm[2], c.beta = prm[4], c.xi = prm[8], c.fa = prm[9], c.hardeningOn = prm[10] != 0;
+    return fn(c);
+  }
+  EquationOfStateConfig c{};
+  c.volume = prm[0], c.bulk = prm[11], c.viscosity = prm[12];
+  return fn(c);
+}
+
 extern "C" {
+
+/* grid: [nblocks][7][side^3] accumulated in place; returns the number of stencil nodes whose block is not in blockKeys (must be 0) */
+int ref_mpm_p2g(int model, const float *prm, float dx, float dt, int side, int nblocks, const int *blockKeys, float *grid, size_t n,
+                const float *mass, const float *pos, const float *vel, const float *C, const float *F, float *logJp) {
+  RefGrid g = make_ref_grid(side, nblocks, blockKeys, grid);
+  return ref_with_model(model, prm, [&](const auto &m) { return ref_p2g_with(m, dx, dt, g, n, mass, pos, vel, C, F, logJp); });
+}
+int ref_mpm_g2p(int model, const float *prm, float dx, float dt, int side, int nblocks, const int *blockKeys, const float *grid, size_t n,
+                float *pos, float *vel, float *C, float *F) {
+  RefGrid g = make_ref_grid(side, nblocks, blockKeys, const_cast<float *>(grid));
+  return ref_with_model(model, prm, [&](const auto &m) { return ref_g2p_with(m, dx, dt, g, n, pos, vel, C, F); });
+}
 
 /* column-major 9-vectors, argument order as at the reference call sites
  * (physics/ConstitutiveModel_Vol_dP.hpp:14-16) */

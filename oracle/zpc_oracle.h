@@ -176,6 +176,9 @@ typedef struct {
   float xi, Msqr;     /* model 3 = NACC (also E, nu, beta) */
   int hardeningOn;
   float bulk, viscosity; /* model 4 = EquationOfState: J lives in component 0 of the F slot */
+  int hostVariant;    /* von Mises / NACC only: 0 = cuda/physics/ConstitutiveModel.hpp (what CudaExecutionPolicy callers run, the
+                         form the GPU path is compared with), 1 = physics/ConstitutiveModel_Vol_dP.hpp (the host header
+                         simulation/transfer/P2G.hpp includes; the form tests/golden/p2g_g2p.npz holds) */
 } orc_mpm_params;
 void orc_stress_vonmises(float volume, float mu, float lam, float yieldStress, int hostVariant, float F[9], float PF[9]);
 void orc_stress_nacc(float volume, float mu, float lam, float bm, float xi, float beta, float Msqr, int hardeningOn, int hostVariant,

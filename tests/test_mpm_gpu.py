@@ -502,3 +502,110 @@ def test_reordering_fused_step_matches_in_place_steps(pol, oracle, model, side):
         assert (np.abs(a.sum(0) - b.sum(0)) <= 2e-5 * scale).all(), k
         assert (np.abs((a ** 2).sum(0) - (b ** 2).sum(0)) <= 1e-4 * (a ** 2).sum(0) + 1e-30).all(), k
     _compare_grids(ga, gb, 3e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Whole-function parity against the REFERENCE (tests/golden/p2g_g2p.npz: P2GTransfer / G2PTransfer spelled over the reference's own
+# LocalArena, compute_stress_*, matrixMatrixMultiplication3d; tools/gen_golden.py + oracle/ref_shim.cpp).  The fixtures are in
+# SequentialExecutionPolicy order; the GPU sums the same terms in another order, so the tolerances are those of an order-dependent
+# float sum of ~64 like-signed terms (mass, momentum: 2e-6 of the channel maximum) and, for the force channels, the stress budget
+# of the per-particle pin (5e-5 of the elastic force scale of the cloud; von Mises / NACC follow cuda/physics/ConstitutiveModel.hpp
+# where it differs from the host header the fixture was made with, see DESIGN.md "Oracle").
+def _golden_setup(pol, name, side, cache_stress, binned=True, lane_width=64):
+    from util import golden_p2g_g2p
+    from zpc_amd.mpm import MpmTransfer
+    g = golden_p2g_g2p(name, side)
+    kw = dict(g["kw"])
+    mt = MpmTransfer(pol, g["pos"].shape[0], g["dx"], g["dt"], model=g["model"], side=side, volume=g["volume"], lane_width=lane_width,
+                     cache_stress=cache_stress, **kw)
+    mt.upload(g["mass"], g["pos"], g["vel"], g["C"], g["F"][:, :mt.nF], g["logJp"] if g["model"] in (1, 3) else None)
+    keys = torch.from_numpy(np.ascontiguousarray(g["keys"])).cuda()
+    mt.adopt_partition(keys.data_ptr(), g["keys"].shape[0])     # block i = fixture key i: grids compare index for index
+    pol.syncCtx()
+    if binned:
+        mt.rebin()
+    return g, mt
+
+
+def _grid_err(mt, want, rhs_scale):
+    got = mt.grid.cpu().numpy().reshape(want.shape)
+    scale = np.abs(want).max(axis=(0, 2))
+    scale[4:] = rhs_scale
+    return np.abs(got - want).max(axis=(0, 2)) / scale
+
+
+def _particles_in_input_order(mt, binned):
+    d = mt.download()
+    if not binned:
+        return d
+    inv = np.empty(mt.n, np.int64)
+    inv[mt.order.cpu().numpy()] = np.arange(mt.n)   # stored row r holds input particle order[r]
+    return {k: v[inv] for k, v in d.items()}
+
+
+GOLDEN_GPU_CASES = [("fixedcorotated", 4), ("fixedcorotated", 8), ("sand", 4), ("sand", 8), ("vonmises", 8), ("nacc", 8), ("eos", 8)]
+# force-channel budget per model (fraction of the cloud's elastic force scale)
+RHS_TOL = {"fixedcorotated": 5e-5, "sand": 5e-5, "eos": 5e-5, "vonmises": 3e-4, "nacc": 3e-4}
+
+
+@pytest.mark.parametrize("binned", [True, False])
+@pytest.mark.parametrize("name,side", GOLDEN_GPU_CASES)
+def test_p2g_g2p_match_reference_golden(pol, name, side, binned):
+    """zs_rocm_mpm_p2g and zs_rocm_mpm_g2p (reference order: constitutive update inside P2G) vs the reference-made fixture."""
+    g, mt = _golden_setup(pol, name, side, cache_stress=False, binned=binned)
+    mt.clear_grid()
+    mt.p2g()
+    pol.syncCtx()
+    err = _grid_err(mt, g["grid"], g["rhs_scale"])
+    assert (err[:4] <= 2e-6).all() and (err[4:] <= RHS_TOL[name]).all(), err
+    if name in ("sand", "nacc"):
+        lj = _particles_in_input_order(mt, binned)["logJp"]
+        assert np.abs(lj - g["logJp1"]).max() <= 2e-5
+    # G2P from the fixture's velocity grid
+    mt.grid.copy_(torch.from_numpy(g["gridv"]).reshape(-1))
+    mt.g2p()
+    pol.syncCtx()
+    d = _particles_in_input_order(mt, binned)
+    assert np.abs(d["x"] - g["pos1"]).max() <= 1e-7
+    assert np.abs(d["v"] - g["vel1"]).max() <= 2e-6 * np.abs(g["vel1"]).max()
+    assert np.abs(d["C"] - g["C1"]).max() <= 1e-5 * np.abs(g["C1"]).max()
+    if name == "eos":
+        assert np.abs(d["J"][:, 0] - g["F1"][:, 0]).max() <= 1e-6
+    else:
+        assert np.abs(d["F"] - g["F1"]).max() <= 2e-6
+    assert __import__("zpc_amd").lib().zs_rocm_last_error(-1) == 0
+
+
+@pytest.mark.parametrize("name,side", GOLDEN_GPU_CASES)
+def test_fused_g2p2g_matches_reference_golden(pol, name, side):
+    """The bench's flagship kernel (zs_rocm_mpm_g2p2g: G2P of step n + P2G of step n+1, binned, cached stress; sand / side 8 is the
+    headline instantiation) DIRECTLY against the reference-made fixture: particle state after G2P and the next step's grid."""
+    g, mt = _golden_setup(pol, name, side, cache_stress=True)
+    mt.grid.copy_(torch.from_numpy(g["gridv"]).reshape(-1))
+    # the fused pass reads the logJp the previous P2G left behind (reference: P2G.hpp:101 stores it), F unprojected
+    if name in ("sand", "nacc"):
+        o = mt.order.cpu().numpy()
+        lj1 = torch.from_numpy(g["logJp1"][o]).cuda()
+        lib = __import__("zpc_amd").lib()
+        tmp = torch.empty(mt.n, mt.nchn, device="cuda")
+        lib.zs_rocm_tv_to_aos_f32(pol.handle, mt.buf.data_ptr(), mt.n, mt.nchn, mt.L, tmp.data_ptr())
+        pol.syncCtx()
+        tmp[:, mt.off["logJp"]] = lj1
+        lib.zs_rocm_tv_from_aos_f32(pol.handle, tmp.data_ptr(), mt.n, mt.nchn, mt.L, mt.buf.data_ptr())
+        pol.syncCtx()
+    mt.g2p2g(write_all=True)
+    pol.syncCtx()
+    d = _particles_in_input_order(mt, True)
+    assert np.abs(d["x"] - g["pos1"]).max() <= 1e-7
+    assert np.abs(d["v"] - g["vel1"]).max() <= 2e-6 * np.abs(g["vel1"]).max()
+    assert np.abs(d["C"] - g["C1"]).max() <= 1e-5 * np.abs(g["C1"]).max()
+    if name == "eos":
+        assert np.abs(d["J"][:, 0] - g["F1"][:, 0]).max() <= 1e-6
+    else:
+        assert np.abs(d["F"] - g["F1"]).max() <= 2e-6
+    err = _grid_err(mt, g["grid2"], g["rhs_scale"])
+    assert (err[:4] <= 5e-6).all() and (err[4:] <= RHS_TOL[name]).all(), err
+    if name in ("sand", "nacc"):
+        assert np.abs(d["logJp"] - g["logJp2"]).max() <= 2e-5
+    assert not mt.left_partition()
+    assert __import__("zpc_amd").lib().zs_rocm_last_error(-1) == 0

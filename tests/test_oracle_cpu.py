@@ -493,3 +493,64 @@ def test_oracle_c2_transfers_are_consistent(oracle):
     r = pos - np.floor(pos / dx + 0.5) * dx
     grad = (Bo.reshape(-1, 3, 3) * (2.0 / (dx * dx - 2 * r * r))[:, :, None]).transpose(0, 2, 1)
     assert np.abs(grad - A[None]).max() < 2e-3
+
+
+# rounding of (sigma - 1) inside the stress is amplified by mu relative to the net force on a node (sums of +- contributions
+# that cancel to ~|F - I|): the same budget as the per-particle stress pin above (5e-5 (2 mu + lambda) vol), relative to the
+# largest rhs entry of the fixture
+STRESS_TOL = 5e-5
+
+
+def _oracle_on_golden(oracle, name, side):
+    from util import OracleMpm, golden_p2g_g2p
+    g = golden_p2g_g2p(name, side)
+    # host_variant=1: the fixture comes from the host header P2G.hpp includes (ConstitutiveModel_Vol_dP.hpp)
+    om = OracleMpm(oracle, g["model"], g["dx"], g["dt"], side, g["volume"], host_variant=1, **g["kw"])
+    om.adopt_partition(g["keys"])
+    return g, om
+
+
+@pytest.mark.parametrize("name,side", [("fixedcorotated", 4), ("fixedcorotated", 8), ("sand", 4), ("sand", 8), ("vonmises", 8), ("nacc", 8),
+                                       ("eos", 8)])
+def test_p2g_g2p_whole_function_matches_reference_golden(oracle, name, side):
+    """P2GTransfer / G2PTransfer as WHOLE functions (simulation/transfer/P2G.hpp:51-125, G2P.hpp:44-83): the restatement in
+    oracle/mpm.c against tests/golden/p2g_g2p.npz, which tools/gen_golden.py produces from the reference's own make_local_arena /
+    unpack_coord_in_grid / compute_stress_* / matrixMatrixMultiplication3d in sequential particle order (oracle/ref_shim.cpp).
+    Same summation order on both sides: the tolerance only has to absorb compiler-level differences inside the SVD / stress code
+    (the oracle is built with -ffp-contract=off at -O2, the reference headers with g++ -O3)."""
+    g, om = _oracle_on_golden(oracle, name, side)
+    lj = g["logJp"].copy()
+    om.p2g(g["mass"], g["pos"], g["vel"], g["C"], g["F"], lj)
+    scale = np.abs(g["grid"]).max(axis=(0, 2))
+    scale[4:] = g["rhs_scale"]
+    err = np.abs(om.grid - g["grid"]).max(axis=(0, 2)) / scale
+    assert (err[:4] <= 1e-6).all(), err                          # mass + momentum: no stress involved -> same bits up to contraction
+    assert (err[4:] <= STRESS_TOL * (6 if name == 'vonmises' else 1)).all(), err  # (host von Mises: sqrtNewtonRaphson stops at an absolute step)
+    #                   # stress channels: through the 4-sweep SVD
+    if name in ("sand", "nacc"):
+        assert np.abs(lj - g["logJp1"]).max() <= 5e-6              # sums of log(sigma): float rounding of the SVD
+    # G2P on the fixture's own velocity grid
+    om.grid[:] = g["gridv"]
+    pos, vel, Cm, F = g["pos"].copy(), g["vel"].copy(), g["C"].copy(), g["F"].copy()
+    om.g2p(pos, vel, Cm, F)
+    assert np.abs(pos - g["pos1"]).max() <= 1e-7
+    assert np.abs(vel - g["vel1"]).max() <= 1e-6 * np.abs(g["vel1"]).max()
+    assert np.abs(Cm - g["C1"]).max() <= 1e-6 * np.abs(g["C1"]).max()
+    assert np.abs(F - g["F1"]).max() <= 1e-6
+    # next step's P2G on the G2P outputs (second half of the fused G2P2G pass)
+    om.grid[:] = 0
+    lj2 = g["logJp1"].copy()
+    om.p2g(g["mass"], g["pos1"], g["vel1"], g["C1"], g["F1"], lj2)
+    scale2 = np.abs(g["grid2"]).max(axis=(0, 2))
+    scale2[4:] = g["rhs_scale"]
+    err2 = np.abs(om.grid - g["grid2"]).max(axis=(0, 2)) / scale2
+    assert (err2[:4] <= 1e-6).all() and (err2[4:] <= STRESS_TOL * (6 if name == 'vonmises' else 1)).all(), err2
+
+
+def test_golden_p2g_grid_update_input_is_the_oracle_grid_update(oracle):
+    """the `gridv` arrays of the fixture (input of the G2P leg) are what ComputeGridBlockVelocity (GridOp.hpp:71-108, restated in
+    orc_mpm_grid_update) makes of the reference's P2G grid"""
+    g, om = _oracle_on_golden(oracle, "sand", 8)
+    om.grid[:] = g["grid"]
+    om.grid_update(g["gravity"])
+    assert np.abs(om.grid[:, :4] - g["gridv"][:, :4]).max() <= 1e-6 * np.abs(g["gridv"][:, 1:4]).max()

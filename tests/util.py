@@ -47,7 +47,8 @@ class OrcMpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
                 ("volCorrection", C.c_int), ("side", C.c_int), ("nthreads", C.c_int), ("yieldStress", C.c_float),
-                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int), ("bulk", C.c_float), ("viscosity", C.c_float)]
+                ("xi", C.c_float), ("Msqr", C.c_float), ("hardeningOn", C.c_int), ("bulk", C.c_float), ("viscosity", C.c_float),
+                ("hostVariant", C.c_int)]
 
 
 YIELD_SURFACE = 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5)  # DruckerPragerConfig default
@@ -72,11 +73,11 @@ class OracleMpm:
     """Drives oracle/mpm.c + oracle/bht.c: the CPU restatement of partition build, P2G, grid update, G2P."""
 
     def __init__(self, oracle, model, dx, dt, side, volume, E=5e4, nu=0.4, nthreads=1, cohesion=0.0, beta=1.0, yield_stress=240e6,
-                 xi=0.8, friction_angle=45.0, hardening=True, bulk=4e4, viscosity=0.0):
+                 xi=0.8, friction_angle=45.0, hardening=True, bulk=4e4, viscosity=0.0, host_variant=0):
         self.o = oracle
         oracle.orc_nacc_msqr.restype = C.c_float
         self.p = OrcMpmParams(model, dx, dt, volume, E, nu, cohesion, beta, YIELD_SURFACE, 1, side, nthreads, yield_stress, xi,
-                              oracle.orc_nacc_msqr(C.c_float(friction_angle)), int(hardening), bulk, viscosity)
+                              oracle.orc_nacc_msqr(C.c_float(friction_angle)), int(hardening), bulk, viscosity, int(host_variant))
         self.side = side
         self.o.orc_bht_create.restype = C.c_void_p
         self.o.orc_bht_active_keys.restype = C.POINTER(C.c_int32)
@@ -90,6 +91,18 @@ class OracleMpm:
         self.nblocks = self.o.orc_bht_size(self.table)
         keys = np.ctypeslib.as_array(self.o.orc_bht_active_keys(self.table), shape=(self.nblocks, 3)).copy()
         self.keys = keys
+        self.grid = np.zeros((self.nblocks, 7, self.side ** 3), np.float32)
+        return self.nblocks
+
+    def adopt_partition(self, keys):
+        """Number the partition by a given key list (block i = keys[i]) instead of building it from particle positions."""
+        keys = np.ascontiguousarray(keys, np.int32)
+        self.table = C.c_void_p(self.o.orc_bht_create(3, C.c_size_t(keys.shape[0])))
+        ret = np.zeros(keys.shape[0], np.int32)
+        self.o.orc_bht_insert_many(self.table, ptr(keys), C.c_size_t(keys.shape[0]), ptr(ret))
+        assert np.array_equal(ret, np.arange(keys.shape[0]))
+        self.nblocks = keys.shape[0]
+        self.keys = keys.copy()
         self.grid = np.zeros((self.nblocks, 7, self.side ** 3), np.float32)
         return self.nblocks
 
@@ -185,3 +198,40 @@ def collider_struct(cs):
                     ("R", C.c_float * 9), ("omega", C.c_float * 3), ("b", C.c_float * 3), ("dbdt", C.c_float * 3)]
     return Col(int(cs[0]), int(cs[1]), (C.c_float * 8)(*cs[2:10]), float(cs[10]), float(cs[11]), (C.c_float * 9)(*cs[12:21]),
                (C.c_float * 3)(*cs[21:24]), (C.c_float * 3)(*cs[24:27]), (C.c_float * 3)(*cs[27:30]))
+
+
+# ---------------------------------------------------------------------------------------- whole-function golden fixtures
+GOLDEN_MODELS = {"fixedcorotated": 0, "sand": 1, "vonmises": 2, "nacc": 3, "eos": 4}
+GOLDEN_CASES = [("fixedcorotated", 4), ("fixedcorotated", 8), ("sand", 4), ("sand", 8), ("vonmises", 8), ("nacc", 8), ("eos", 8)]
+
+
+def golden_p2g_g2p(name, side):
+    """One case of tests/golden/p2g_g2p.npz (made by tools/gen_golden.py from the reference's own LocalArena / compute_stress_* /
+    matrixMatrixMultiplication3d, oracle/ref_shim.cpp): dict with the inputs, the reference's P2G grid, the grid handed to G2P, the
+    G2P outputs and the next step's P2G grid, plus the model number / parameters in this repo's convention."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "p2g_g2p.npz"))
+    tag = "%s_s%d" % (name, side)
+    prm = z["prm_" + name]
+    F = z["F"].copy()
+    if name == "eos":
+        F[:, 0] = z["J"]
+    # oracle / zs_rocm model numbering: 0 FixedCorotated, 1 DruckerPrager, 2 VonMises, 3 NACC, 4 EquationOfState
+    kw = dict(E=float(prm[1]) if name != "eos" else 5e4, nu=float(prm[2]) if name != "eos" else 0.4)
+    if name == "sand":
+        kw.update(cohesion=float(prm[3]), beta=float(prm[4]))
+    if name == "vonmises":
+        kw.update(yield_stress=float(prm[7]))
+    if name == "nacc":
+        kw.update(beta=float(prm[4]), xi=float(prm[8]), friction_angle=float(prm[9]), hardening=bool(prm[10]))
+    if name == "eos":
+        kw.update(bulk=float(prm[11]), viscosity=float(prm[12]))
+    return dict(model=GOLDEN_MODELS[name], side=side, dx=float(z["dx"]), dt=float(z["dt"]), volume=float(prm[0]), kw=kw,
+                gravity=tuple(float(v) for v in z["gravity"]), keys=z["keys_s%d" % side], mass=z["mass"], pos=z["pos"], vel=z["vel"],
+                C=z["C"], F=F, logJp=z["logJp"], grid=z["grid_" + tag], logJp1=z["logJp1_" + tag], gridv=z["gridv_" + tag],
+                pos1=z["pos_" + tag], vel1=z["vel_" + tag], C1=z["C_" + tag], F1=z["F_" + tag], grid2=z["grid2_" + tag],
+                logJp2=z["logJp2_" + tag],
+                # physical scale of a nodal force entry for this cloud: the elastic (FixedCorotated) response to the same F set.
+                # The NACC case projects every particle onto the tip of the yield surface, where P F^T is the difference of
+                # nearly equal numbers (1e-4 of the elastic stress), so "relative to its own maximum" would measure noise.
+                rhs_scale=float(np.abs(z["grid_fixedcorotated_s8"][:, 4:]).max()))

@@ -21,6 +21,87 @@ def P(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+MODEL_NAMES = ["fixedcorotated", "sand", "vonmises", "nacc", "eos"]
+
+
+def partition_keys(pos, dx, side):
+    """ComputeSparsity (offset -2, displacement 0.5) + EnlargeSparsity {0,1}^3 (simulation/sparsity/SparsityOp.hpp:59-115) as plain
+    integer arithmetic; keys in lexicographic order (the table's numbering is an implementation detail, results are keyed)."""
+    coord = np.floor(pos / np.float32(dx) + np.float32(0.5)).astype(np.int64) - 2
+    base = np.unique(np.floor_divide(coord, side), axis=0)
+    off = np.stack(np.meshgrid([0, 1], [0, 1], [0, 1], indexing="ij"), -1).reshape(-1, 3)
+    return np.ascontiguousarray(np.unique((base[:, None, :] + off[None]).reshape(-1, 3), axis=0).astype(np.int32))
+
+
+def gen_p2g_g2p():
+    """Whole-function fixtures for P2GTransfer / G2PTransfer (simulation/transfer/P2G.hpp:51-125, G2P.hpp:44-83): 4096 particles, every
+    constitutive model, block sides 4 and 8; outputs = the reference's own arena / stress / matrix code driven by oracle/ref_shim.cpp
+    in SequentialExecutionPolicy order.  One fixture = inputs, the P2G grid, the grid handed to G2P (the P2G grid after the
+    ComputeGridBlockVelocity arithmetic done here in float32 -- an INPUT of the G2P leg, stored), the G2P outputs, and the grid of
+    the next step's P2G on those outputs (what the fused G2P2G pass produces)."""
+    g = np.random.default_rng(20251003)
+    dx, dt = np.float32(1.0 / 128), np.float32(1e-4)
+    ppc, ncs = 2, 8
+    k = ncs * ppc
+    idx = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)
+    h = dx / ppc
+    pos0 = (np.array([0.3021, 0.2871, 0.3127]) + (idx + 0.5) * h + (g.random(idx.shape) - 0.5) * h * 0.9).astype(np.float32)
+    n = pos0.shape[0]
+    vel0 = (0.6 * g.standard_normal((n, 3)) + np.array([0.3, -1.0, 0.2])).astype(np.float32)
+    C0 = (2.0 * g.standard_normal((n, 9))).astype(np.float32)
+    F0 = (np.eye(3).reshape(1, 9) + 0.04 * g.standard_normal((n, 9))).astype(np.float32)
+    J0 = (1 + 0.02 * g.standard_normal(n)).astype(np.float32)
+    lj0 = (0.01 * g.standard_normal(n)).astype(np.float32)
+    vol = np.float32(float(dx) ** 3 / ppc ** 3)
+    mass = np.full(n, 1000.0 * vol, np.float32) * (1 + 0.1 * g.random(n)).astype(np.float32)
+    # {volume, E, nu, cohesion, beta, yieldSurface, volumeCorrection, yieldStress, xi, fa, hardeningOn, bulk, viscosity}
+    prm = {0: [vol, 5e4, 0.4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+           1: [vol, 5e4, 0.4, 0.0, 1.0, 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5), 1, 0, 0, 0, 0, 0, 0],
+           2: [vol, 5e4, 0.4, 0, 0, 0, 0, 500.0, 0, 0, 0, 0, 0],
+           3: [vol, 5e4, 0.4, 0, 0.5, 0, 0, 0, 0.8, 45.0, 1, 0, 0],
+           4: [vol, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4e4, 0.01]}
+    ref.ref_mpm_p2g.restype = C.c_int
+    ref.ref_mpm_g2p.restype = C.c_int
+    out = dict(dx=dx, dt=dt, mass=mass, pos=pos0, vel=vel0, C=C0, F=F0, J=J0, logJp=lj0, gravity=np.array([0, -9.8, 0], np.float32))
+    for model in range(5):
+        out["prm_%s" % MODEL_NAMES[model]] = np.array(prm[model], np.float32)
+        for side in ((4, 8) if model < 2 else (8,)):
+            keys = partition_keys(pos0, dx, side)
+            nb, nc = keys.shape[0], side ** 3
+            pr = np.array(prm[model], np.float32)
+            Fin = F0.copy()
+            if model == 4:
+                Fin[:, 0] = J0
+            lj = lj0.copy()
+            grid = np.zeros((nb, 7, nc), np.float32)
+            args = (model, P(pr), C.c_float(dx), C.c_float(dt), side, nb, P(keys))
+            miss = ref.ref_mpm_p2g(*args, P(grid), C.c_size_t(n), P(mass), P(pos0), P(vel0), P(C0), P(Fin), P(lj))
+            assert miss == 0
+            # ComputeGridBlockVelocity arithmetic (simulation/grid/GridOp.hpp:71-108) in float32: an input of the G2P leg
+            gv = grid.copy()
+            m = gv[:, 0, :]
+            nz = m != 0
+            inv = np.where(nz, np.float32(1) / np.where(nz, m, np.float32(1)), np.float32(0)).astype(np.float32)
+            for d in range(3):
+                gv[:, 1 + d, :] = np.where(nz, gv[:, 1 + d, :] * inv + out["gravity"][d] * dt, gv[:, 1 + d, :]).astype(np.float32)
+            pos, vel, Cm, Fm = pos0.copy(), vel0.copy(), C0.copy(), Fin.copy()
+            miss = ref.ref_mpm_g2p(*args, P(gv), C.c_size_t(n), P(pos), P(vel), P(Cm), P(Fm))
+            assert miss == 0
+            # P2G of the next step on the G2P outputs (the second half of the fused G2P2G pass)
+            keys2 = partition_keys(pos, dx, side)
+            assert {tuple(r) for r in keys2} <= {tuple(r) for r in keys}, "particles left the partition within one step"
+            grid2 = np.zeros((nb, 7, nc), np.float32)
+            lj2 = lj.copy()
+            miss = ref.ref_mpm_p2g(*args, P(grid2), C.c_size_t(n), P(mass), P(pos), P(vel), P(Cm), P(Fm), P(lj2))
+            assert miss == 0
+            tag = "%s_s%d" % (MODEL_NAMES[model], side)
+            out.update({"keys_s%d" % side: keys, "grid_" + tag: grid, "logJp1_" + tag: lj, "gridv_" + tag: gv, "pos_" + tag: pos,
+                        "vel_" + tag: vel, "C_" + tag: Cm, "F_" + tag: Fm, "grid2_" + tag: grid2, "logJp2_" + tag: lj2})
+            print("p2g_g2p %s: %d blocks, |m| %.3e, |v_p| max %.3f, plastic %d" %
+                  (tag, nb, grid[:, 0].sum(), np.abs(vel).max(), (lj != lj0).sum()))
+    np.savez_compressed(os.path.join(OUT, "p2g_g2p.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     g = np.random.Generator(np.random.PCG64(0x9E3779B97F4A7C15 ^ 77))
@@ -160,6 +241,7 @@ def main():
                                                  P(cx[k, i]), P(cout[k, i]))
     np.savez_compressed(os.path.join(OUT, "collider.npz"), cases=cases, x=cx, v=cv, v_out=cout, inside=cin)
     print("collider: %d of %d points inside" % (cin.sum(), cin.size))
+    gen_p2g_g2p()
     print("wrote", os.listdir(OUT))
 
 
