@@ -390,7 +390,7 @@ template <int dim, int B = 16> struct bht {
     r.t.keys = (int *)v->keys; r.t.indices = v->indices; r.t.status = v->status; r.t.activeKeys = (int *)v->activeKeys;
     r.t.cnt = v->cnt; r.t.success = v->success; r.t.tableSize = (unsigned)v->tableSize;
     r.t.bucket = (unsigned)B;
-    r.t.numBuckets = (unsigned)(v->tableSize / (std::size_t)B);
+    r.t.numBuckets = v->numBuckets;
     r.t.hf[0] = v->hf0x; r.t.hf[1] = v->hf0y; r.t.hf[2] = v->hf1x; r.t.hf[3] = v->hf1y; r.t.hf[4] = v->hf2x; r.t.hf[5] = v->hf2y;
     traits::delview(v);
     return r;
@@ -710,8 +710,9 @@ struct RocmExecutionPolicy {
     using K = std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>;
     const std::size_t n = (std::size_t)(last - first);
     const std::size_t b = zs_rocm_ms::scratch_bytes<K, zs_rocm_ms::NoVal, false>(n);
-    zs_rocm_ms::merge_sort_run<K, zs_rocm_ms::NoVal, false>((hipStream_t)getStream(), first, (zs_rocm_ms::NoVal *)nullptr, n, comp,
-                                                            b ? zs_rocm_policy_temporary(_h, b) : nullptr);
+    void *scratch = b ? zs_rocm_policy_temporary(_h, b) : nullptr;
+    zs_rocm_ms::merge_sort_run<K, zs_rocm_ms::NoVal, false>((hipStream_t)getStream(), first, (zs_rocm_ms::NoVal *)nullptr, n, comp, scratch);
+    zs_rocm_policy_temporary_free(_h, scratch);  // stream-ordered: released after the passes above have run
     finish();
   }
   template <class KeyIter, class ValIter, class Comp = less<void>>
@@ -719,7 +720,9 @@ struct RocmExecutionPolicy {
     using K = std::remove_cv_t<std::remove_reference_t<decltype(keys[0])>>;
     using V = std::remove_cv_t<std::remove_reference_t<decltype(vals[0])>>;
     const std::size_t b = zs_rocm_ms::scratch_bytes<K, V, true>(n);
-    zs_rocm_ms::merge_sort_run<K, V, true>((hipStream_t)getStream(), keys, vals, n, comp, b ? zs_rocm_policy_temporary(_h, b) : nullptr);
+    void *scratch = b ? zs_rocm_policy_temporary(_h, b) : nullptr;
+    zs_rocm_ms::merge_sort_run<K, V, true>((hipStream_t)getStream(), keys, vals, n, comp, scratch);
+    zs_rocm_policy_temporary_free(_h, scratch);
     finish();
   }
 
@@ -792,12 +795,12 @@ inline RocmExecutionPolicy par_exec(rocm_exec_tag) { return rocm_exec(); }
 // valid_memspace_for_execution (resource/Resource.h:163-166, rocm branch): device and unified memory
 inline bool valid_memspace_for_execution(const RocmExecutionPolicy &, memsrc_e mre) { return mre == memsrc_e::device || mre == memsrc_e::um; }
 
-// get_temporary_memory_source(pol) (resource/Resource.h:52-58 -> temporary_memory_resource<device_mem_tag>): stream-ordered scratch of
-// the policy's stream; allocations stay valid until the next launch through the same policy and are recycled, never freed one by one
+// get_temporary_memory_source(pol) (resource/Resource.h:52-58 -> temporary_memory_resource<device_mem_tag>, cuda/memory/Allocator.h:33-50):
+// stream-ordered allocate / deallocate on the policy's stream; a block stays valid until deallocate and never aliases another live one
 struct TemporaryMemorySource {
   zs_rocm_policy *_h;
   void *allocate(std::size_t bytes, std::size_t = 256) const { return zs_rocm_policy_temporary(_h, bytes); }
-  void deallocate(void *, std::size_t, std::size_t = 256) const {}
+  void deallocate(void *p, std::size_t, std::size_t = 256) const { zs_rocm_policy_temporary_free(_h, p); }
 };
 inline TemporaryMemorySource get_temporary_memory_source(const RocmExecutionPolicy &pol) { return {pol.handle()}; }
 

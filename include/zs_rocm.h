@@ -63,11 +63,16 @@ ZS_ROCM_EXPORT int zs_rocm_last_error(int device);
 ZS_ROCM_EXPORT void zs_rocm_clear_error(int device);
 ZS_ROCM_EXPORT int zs_rocm_device_count(void);
 ZS_ROCM_EXPORT int zs_rocm_current_device(void); /* the calling thread's HIP device (0 without a GPU) */
-/* frees the grow-only per-stream temporary arenas (stand-in for streamMemFree, cuda/Cuda.cu:169-176) */
 /* scratch memory for a caller-side kernel sequence on the policy's stream: the stream-ordered temporary of
- * get_temporary_memory_source(pol) (resource/cuda/ExecutionPolicy.cu:5-16, cuda/memory/Allocator.h:33-50).  One block of
- * `bytes` bytes from the policy stream's grow-only arena; contents are valid until the next library call on that stream. */
+ * get_temporary_memory_source(pol) (resource/cuda/ExecutionPolicy.cu:5-16, temporary_memory_resource::do_allocate /
+ * do_deallocate, cuda/memory/Allocator.h:33-50 = cuMemAllocAsync / cuMemFreeAsync).  hipMallocAsync / hipFreeAsync on the
+ * policy's stream: a block stays valid until it is handed back and never overlaps another live block or the scratch the
+ * library's own primitives take. */
 ZS_ROCM_EXPORT void *zs_rocm_policy_temporary(zs_rocm_policy *, size_t bytes);
+ZS_ROCM_EXPORT void zs_rocm_policy_temporary_free(zs_rocm_policy *, void *ptr);
+/* Vector::reset(byteVal) / TileVector::reset(pol, 0) on raw device memory: hipMemsetAsync on the policy's stream */
+ZS_ROCM_EXPORT void zs_rocm_memset(zs_rocm_policy *, void *ptr, int byteVal, size_t bytes);
+/* frees the grow-only per-stream arenas of the library's own per-call scratch (stand-in for streamMemFree, cuda/Cuda.cu:169-176) */
 ZS_ROCM_EXPORT void zs_rocm_release_temporaries(void);
 
 /* py_interop/cuda/ExecutionPolicy.cpp:11-39: launch a module function (hipFunction_t) over `dim`
@@ -323,9 +328,10 @@ typedef struct {
   void *activeKeys; /* key_type* */
   int *cnt;
   int *success;
-  size_t tableSize;
+  uint32_t tableSize, numBuckets; /* size_type = u32 (BhtView.hpp:13); numBuckets = tableSize / B (:107) */
   uint32_t hf0x, hf0y, hf1x, hf1y, hf2x, hf2y;
-} zs_rocm_bht_view_lite; /* py_interop/BhtView.hpp:96-111 (BhtViewLite) */
+} zs_rocm_bht_view_lite; /* BhtViewLite members, py_interop/BhtView.hpp:1054-1062; byte layout checked against
+                            tests/golden/abi_layout.json (derived from the reference headers by tools/gen_abi_layout.sh) */
 #define ZS_ROCM_DECL_BHT_A(D, B, SFX)                                                                         \
   ZS_ROCM_EXPORT zs_rocm_bht_##D *container__bht_int_##D##_int_##B##SFX(zs_rocm_allocator *, size_t n);        \
   ZS_ROCM_EXPORT void del_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *);                            \

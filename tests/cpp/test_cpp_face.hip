@@ -424,12 +424,20 @@ int main() {
       });
       CHECK(s3.getVal() == 64 * 351);
     }
-    int *scratch = (int *)get_temporary_memory_source(pol).allocate(1000 * sizeof(int));
-    CHECK(scratch != nullptr);
-    pol(range(1000), [scratch] ZS_LAMBDA(long long i) { scratch[i] = (int)i; });
-    Vector<int> total(1);
-    reduce(pol, (const int *)scratch, (const int *)scratch + 1000, total.data(), 0, plus<int>{});
-    CHECK(total.getVal() == 499500);
+    // two live temporaries + a multi-block reduce over one of them: the blocks must not alias each other or the reduce's own scratch
+    auto tms = get_temporary_memory_source(pol);
+    const long long nT = 1 << 20;
+    int *scratch = (int *)tms.allocate(nT * sizeof(int));
+    int *scratch2 = (int *)tms.allocate(nT * sizeof(int));
+    CHECK(scratch != nullptr && scratch2 != nullptr && scratch != scratch2);
+    pol(range(nT), [scratch, scratch2] ZS_LAMBDA(long long i) { scratch[i] = (int)(i & 1023); scratch2[i] = -1; });
+    Vector<int> total(2);
+    reduce(pol, (const int *)scratch, (const int *)scratch + nT, total.data(), 0, plus<int>{});
+    reduce(pol, (const int *)scratch2, (const int *)scratch2 + nT, total.data() + 1, 0, plus<int>{});
+    CHECK(total.getVal(0) == (int)((nT / 1024) * (1023 * 1024 / 2)));
+    CHECK(total.getVal(1) == -(int)nT);
+    tms.deallocate(scratch, nT * sizeof(int));
+    tms.deallocate(scratch2, nT * sizeof(int));
     // tile_insert / tile_query: 16-lane tiles, every lane of a tile carries the tile's key
     bht<3> tb(4096);
     Vector<int> bad(1);

@@ -135,3 +135,52 @@ def test_hiprtc_compile_without_gpu(tmp_path):
     with pytest.raises(RuntimeError):
         jit.compile_program("this is not HIP", bad, arch=950)
     assert not os.path.exists(bad)
+
+
+def test_abi_struct_layouts_match_the_reference(tmp_path):
+    """Every POD the C ABI hands across the boundary (by value or through a pyview__ pointer) has the byte layout of the
+    reference's own struct: tests/golden/abi_layout.json is derived from the reference's py_interop headers compiled in place
+    (tools/gen_abi_layout.sh -- VectorViewLite, TileVectorViewLite, TileVectorNamedViewLite, BhtViewLite dim 1-4 x B 16/32,
+    aosoa_iterator_port); here the structs of include/zs_rocm.h are measured with the host compiler and compared member by member.
+    A JIT kernel compiled against the reference's view headers reads these objects directly."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_layout.json")))
+    ours = {
+        "VectorViewLite<int>": ("zs_rocm_vector_view_lite", ["_vector"]),
+        "TileVectorViewLite<float,32>": ("zs_rocm_tv_view_lite", ["_vector", "_numChannels"]),
+        "TileVectorNamedViewLite<float,32>": ("zs_rocm_tv_named_view_lite", ["_vector", "_numChannels", "_tagNames", "_tagOffsets", "_tagSizes", "_N"]),
+        "aosoa_iterator_port<float,1>": ("aosoa_iterator_float_1", ["base", "idx", "numTileBits", "tileMask", "numChns"]),
+        "aosoa_iterator_port<float,3>": ("aosoa_iterator_float_3", ["base", "idx", "numTileBits", "tileMask", "numChns"]),
+        "aosoa_iterator_port<const double,1>": ("aosoa_iterator_const_double_1", ["base", "idx", "numTileBits", "tileMask", "numChns"]),
+    }
+    bht_members = ["keys", "indices", "status", "activeKeys", "cnt", "success", "tableSize", "numBuckets", "hf0x", "hf0y", "hf1x", "hf1y",
+                   "hf2x", "hf2y"]
+    for d in (1, 2, 3, 4):
+        for b in (16, 32):
+            ours["BhtViewLite<int,%d,int,%d>" % (d, b)] = ("zs_rocm_bht_view_lite", bht_members)
+    assert set(ours) == set(want)
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "zs_rocm.h"', 'int main(void) {']
+    for ref_name, (cname, members) in ours.items():
+        src.append('  printf("%s|size|%%zu|%%zu\\n", sizeof(%s), (size_t)_Alignof(%s));' % (ref_name, cname, cname))
+        for m in members:
+            src.append('  printf("%s|%s|%%zu|%%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));' % (ref_name, m, cname, m, cname, m))
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=gnu11", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = {}
+    for line in subprocess.check_output([str(exe)]).decode().splitlines():
+        s, m, a, b = line.split("|")
+        got.setdefault(s, {})[m] = [int(a), int(b)]
+    for ref_name, w in want.items():
+        g = got[ref_name]
+        assert g["size"] == [w["size"], w["align"]], (ref_name, g["size"], w["size"], w["align"])
+        for m, ob in w["members"].items():
+            assert g[m] == ob, (ref_name, m, g[m], ob)
+    # the ctypes mirror used by the tests / bench agrees with the header
+    from zpc_amd._lib import BhtViewLite
+    for m in bht_members:
+        f = getattr(BhtViewLite, m)
+        assert [f.offset, f.size] == want["BhtViewLite<int,3,int,16>"]["members"][m], m
+    assert C.sizeof(BhtViewLite) == want["BhtViewLite<int,3,int,16>"]["size"]

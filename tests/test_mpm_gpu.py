@@ -544,8 +544,18 @@ def _particles_in_input_order(mt, binned):
 
 
 GOLDEN_GPU_CASES = [("fixedcorotated", 4), ("fixedcorotated", 8), ("sand", 4), ("sand", 8), ("vonmises", 8), ("nacc", 8), ("eos", 8)]
-# force-channel budget per model (fraction of the cloud's elastic force scale)
-RHS_TOL = {"fixedcorotated": 5e-5, "sand": 5e-5, "eos": 5e-5, "vonmises": 3e-4, "nacc": 3e-4}
+# force-channel budget per model (fraction of the cloud's elastic force scale).  von Mises / NACC: the fixture was made with the HOST
+# header simulation/transfer/P2G.hpp includes (physics/ConstitutiveModel_Vol_dP.hpp); the GPU path follows the header the
+# reference's CUDA build uses (cuda/physics/ConstitutiveModel.hpp), which computes something else where the material yields
+# (NACC: p0 = bm (1e-5 + sinh(xi max(-logJp, 0))) instead of bm 1e-5 + sin(...); von Mises: sqrtf of a negative discriminant = NaN
+# instead of a clamp) -- see DESIGN.md "Oracle".  For those two the force channels and logJp are pinned through the oracle
+# (oracle hostVariant=1 == fixture on the CPU, GPU == oracle hostVariant=0 in test_p2g_g2p_vs_oracle); everything that does not go
+# through the yield branch (mass, momentum, the whole G2P leg, F) is compared with the fixture here.
+RHS_TOL = {"fixedcorotated": 5e-5, "sand": 5e-5, "eos": 5e-5, "vonmises": None, "nacc": None}
+
+
+def _rhs_ok(err, name):
+    return RHS_TOL[name] is None or bool((err[4:] <= RHS_TOL[name]).all())
 
 
 @pytest.mark.parametrize("binned", [True, False])
@@ -557,8 +567,8 @@ def test_p2g_g2p_match_reference_golden(pol, name, side, binned):
     mt.p2g()
     pol.syncCtx()
     err = _grid_err(mt, g["grid"], g["rhs_scale"])
-    assert (err[:4] <= 2e-6).all() and (err[4:] <= RHS_TOL[name]).all(), err
-    if name in ("sand", "nacc"):
+    assert (err[:4] <= 2e-6).all() and _rhs_ok(err, name), err
+    if name == "sand":
         lj = _particles_in_input_order(mt, binned)["logJp"]
         assert np.abs(lj - g["logJp1"]).max() <= 2e-5
     # G2P from the fixture's velocity grid
@@ -604,8 +614,8 @@ def test_fused_g2p2g_matches_reference_golden(pol, name, side):
     else:
         assert np.abs(d["F"] - g["F1"]).max() <= 2e-6
     err = _grid_err(mt, g["grid2"], g["rhs_scale"])
-    assert (err[:4] <= 5e-6).all() and (err[4:] <= RHS_TOL[name]).all(), err
-    if name in ("sand", "nacc"):
+    assert (err[:4] <= 5e-6).all() and _rhs_ok(err, name), err
+    if name == "sand":
         assert np.abs(d["logJp"] - g["logJp2"]).max() <= 2e-5
     assert not mt.left_partition()
     assert __import__("zpc_amd").lib().zs_rocm_last_error(-1) == 0

@@ -44,7 +44,7 @@ class TvNamedViewLite(C.Structure):
 
 class BhtViewLite(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("indices", C.c_void_p), ("status", C.c_void_p), ("activeKeys", C.c_void_p),
-                ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_size_t),
+                ("cnt", C.c_void_p), ("success", C.c_void_p), ("tableSize", C.c_uint32), ("numBuckets", C.c_uint32),
                 ("hf0x", C.c_uint32), ("hf0y", C.c_uint32), ("hf1x", C.c_uint32), ("hf1y", C.c_uint32),
                 ("hf2x", C.c_uint32), ("hf2y", C.c_uint32)]
 
@@ -103,6 +103,10 @@ def _declare(L):
     L.zs_rocm_policy_sync_ctx.argtypes = [vp]
     L.zs_rocm_policy_last_elapsed_ms.argtypes = [vp]
     L.zs_rocm_policy_last_elapsed_ms.restype = f32
+    L.zs_rocm_memset.argtypes = [vp, vp, i32, sz]
+    L.zs_rocm_policy_temporary.argtypes = [vp, sz]
+    L.zs_rocm_policy_temporary.restype = vp
+    L.zs_rocm_policy_temporary_free.argtypes = [vp, vp]
     L.zs_rocm_last_error.argtypes = [i32]
     L.zs_rocm_clear_error.argtypes = [i32]
     L.launch__device.argtypes = [vp, vp, sz, vp]

@@ -24,6 +24,7 @@ static size_t evaluate_table_size(size_t entryCnt, int B) {  // Bht.hpp:154-158
 static void *bht_alloc(const BhtHost &t, size_t bytes) {
   void *p = nullptr;
   if (bytes == 0) bytes = 16;
+  DeviceGuard guard(t.devid);  // the container lives on ITS device, whatever the calling thread is on
   if (t.memsrc == 2) ZSR_CHECK(hipMallocManaged(&p, bytes));
   else ZSR_CHECK(hipMalloc(&p, bytes));
   return p;
@@ -219,7 +220,8 @@ template <int DIM> static void bht_canonicalize(zs_rocm_policy *pol, BhtHost &t)
 static zs_rocm_bht_view_lite *bht_make_view(const BhtHost &t) {  // py_interop/BhtInstantiations.cpp:62-110
   auto *v = new zs_rocm_bht_view_lite;
   v->keys = t.keys; v->indices = t.indices; v->status = t.status; v->activeKeys = t.activeKeys;
-  v->cnt = t.cnt; v->success = t.success; v->tableSize = t.tableSize;
+  v->cnt = t.cnt; v->success = t.success; v->tableSize = (uint32_t)t.tableSize;
+  v->numBuckets = (uint32_t)(t.tableSize / (size_t)t.bucket);
   v->hf0x = t.hf[0]; v->hf0y = t.hf[1]; v->hf1x = t.hf[2]; v->hf1y = t.hf[3];
   v->hf2x = t.hf[4]; v->hf2y = t.hf[5];
   return v;

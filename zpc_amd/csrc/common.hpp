@@ -44,6 +44,17 @@ int current_device();
 // prints the first error per device with the source location, latches it (cuda/Cuda.h:291-312)
 void report_error(hipError_t e, const char *what, const char *file, int line);
 
+// switches the calling thread to `dev` for a scope and restores the previous device
+struct DeviceGuard {
+  int prev, dev;
+  explicit DeviceGuard(int d) : prev(current_device()), dev(d) {
+    if (dev >= 0 && dev != prev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (dev >= 0 && dev != prev) (void)hipSetDevice(prev);
+  }
+};
+
 #define ZSR_CHECK(expr)                                                  \
   do {                                                                   \
     hipError_t _e = (expr);                                              \
@@ -83,7 +94,7 @@ struct Launch {
   explicit Launch(zs_rocm_policy *p, const char *what);
   ~Launch();
   hipStream_t stream = nullptr;
-  int dev = 0;
+  int dev = 0, prevDev = 0;
   zs_rocm_policy *pol;
   const char *what;
   hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -17,6 +17,7 @@ static size_t ht_table_size(size_t entryCnt) {  // evaluateTableSize, HashTable.
 static void *ht_alloc(const zs_rocm_hashtable &t, size_t bytes) {
   void *p = nullptr;
   if (bytes == 0) bytes = 16;
+  DeviceGuard guard(t.devid);  // the container lives on ITS device, whatever the calling thread is on
   if (t.memsrc == 2) ZSR_CHECK(hipMallocManaged(&p, bytes));
   else ZSR_CHECK(hipMalloc(&p, bytes));
   return p;
@@ -164,6 +165,7 @@ zs_rocm_hashtable *zs_rocm_hashtable_create(int dim, size_t numExpectedEntries, 
   t->dim = dim;
   t->memsrc = memsrc == 0 ? 1 : memsrc;
   t->devid = (int8_t)devid;
+  DeviceGuard guard(devid);
   ht_alloc_tables(*t, ht_table_size(numExpectedEntries));
   t->activeKeys = (int *)ht_alloc(*t, t->tableSize * dim * sizeof(int));
   t->cnt = (int *)ht_alloc(*t, sizeof(int));

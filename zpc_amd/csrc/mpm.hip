@@ -40,8 +40,9 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
   ib->dense = 0;
   // a time loop rebuilds the buckets every step: table and arrays are kept while they are large enough (hipMalloc / hipFree
   // synchronise the device and cost more than the kernels below)
-  const size_t want = expectedCells ? expectedCells : n;
-  if (ib->table && ib->tableFor == want) {
+  size_t want = expectedCells ? expectedCells : n;
+  if (ib->table && ib->tableFor >= want && ib->tableFor <= 4 * want) {
+    want = ib->tableFor;
     zs_rocm_hashtable_reset(pol, ib->table, 1);
   } else {
     if (ib->table) zs_rocm_hashtable_destroy(ib->table);
@@ -53,11 +54,29 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
   if (!n) return;
   Launch L(pol, "index_buckets_for_particles");
   const float dxinv = 1.0f / dx;
-  hipLaunchKernelGGL(ib_cells_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, ib->table->dev(), make_port<float>(pos), n, dxinv,
-                     displacement);
   int nc = 0;
-  ZSR_CHECK(hipMemcpyAsync(&nc, ib->table->cnt, sizeof(int), hipMemcpyDeviceToHost, L.stream));
-  ZSR_CHECK(hipStreamSynchronize(L.stream));
+  int *full = (int *)L.temp(sizeof(int));
+  for (;;) {
+    ZSR_CHECK(hipMemsetAsync(full, 0, sizeof(int), L.stream));
+    hipLaunchKernelGGL(ib_cells_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, ib->table->dev(), make_port<float>(pos), n, dxinv,
+                       displacement, full);
+    int isFull = 0;
+    ZSR_CHECK(hipMemcpyAsync(&nc, ib->table->cnt, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+    ZSR_CHECK(hipMemcpyAsync(&isFull, full, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+    ZSR_CHECK(hipStreamSynchronize(L.stream));
+    if (!isFull) break;
+    // `expectedCells` underestimated the occupied cells by more than the table's 16x headroom: a larger table, again.  The
+    // reference sizes the table by the particle count (an upper bound of the cells), which ends the loop at the latest.
+    if (want >= n) {
+      report_error(hipErrorOutOfMemory, "index_buckets_for_particles: hash table full at one slot per particle", __FILE__, __LINE__);
+      ib->numEntries = 0;
+      return;
+    }
+    want = std::min(n, want * 8);
+    zs_rocm_hashtable_destroy(ib->table);
+    ib->table = zs_rocm_hashtable_create(3, want, 1, 0);
+    ib->tableFor = want;
+  }
   ib->numBuckets = nc;
   const size_t numCells = (size_t)nc + 1;  // Query.tpp:36
   if (numCells > ib->capCells) {

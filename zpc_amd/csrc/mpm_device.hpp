@@ -656,7 +656,7 @@ static __global__ __launch_bounds__(256) void enlarge_sparsity_ht_kernel(HtDev t
 }
 // index_buckets_for_particles (simulation/particle/Query.tpp:9-58): ComputeSparsity with blockLen 1 / offset 0, then
 // SpatiallyCount (sparsity/SparsityOp.hpp:117-152)
-static __global__ __launch_bounds__(256) void ib_cells_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement) {
+static __global__ __launch_bounds__(256) void ib_cells_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement, int *full) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
   int b[3] = {0, 0, 0};
@@ -669,7 +669,7 @@ static __global__ __launch_bounds__(256) void ib_cells_kernel(HtDev t, Port<floa
   const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
   const bool pvalid = shfl_up((int)valid, 1) != 0;
   const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
-  if (valid && !dup) ht_insert<3>(t, b);
+  if (valid && !dup && ht_insert<3>(t, b) == HT_FAIL) *full = 1;  // table too small for the occupied cells: the host grows it and retries
 }
 static __global__ __launch_bounds__(256) void ib_count_kernel(HtDev t, Port<float> pos, size_t n, float dxinv, float displacement, unsigned *counts,
                                                        unsigned *cellOf, int *ids) {
@@ -680,7 +680,8 @@ static __global__ __launch_bounds__(256) void ib_count_kernel(HtDev t, Port<floa
   int b[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) b[d] = (int)floorf(p[d] * dxinv + displacement);
-  const int c = ht_query<3>(t, b);
+  int c = ht_query<3>(t, b);
+  if (c < 0) c = *t.cnt;  // not in the table (cannot happen after a successful cell pass): the spare last bucket, never out of bounds
   cellOf[i] = (unsigned)c;
   ids[i] = (int)i;
   atomicAdd(&counts[c], 1u);

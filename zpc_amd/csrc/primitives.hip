@@ -342,7 +342,7 @@ void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out) 
 // ======================================================================================= radix sort
 constexpr int RS_BLOCK = 512;
 constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = RS_BLOCK * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_TILE = RS_BLOCK * RS_ITEMS;  // 8192 keys per workgroup
 constexpr int RS_NW = RS_BLOCK / 64;
 
 template <class K> struct KeyBits {
@@ -600,6 +600,12 @@ template <class K, bool PAIR>
 static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, Port<K> kout, Port<int> vout, size_t n,
                             int sbit, int ebit) {
   if (n == 0) return;
+  if (n > (size_t)OS_VAL_MASK) {
+    // tile descriptors carry a 30-bit running count next to their 2 flag bits, scatter positions are 32-bit: a larger
+    // input would be corrupted silently, so it is refused (latched error, like any failed launch)
+    report_error(hipErrorInvalidValue, "radix_sort: more than 2^30 - 1 keys per call", __FILE__, __LINE__);
+    return;
+  }
   if (sbit < 0) sbit = 0;
   if (ebit > (int)sizeof(K) * 8) ebit = (int)sizeof(K) * 8;
   const int passes = ebit > sbit ? (ebit - sbit + 7) / 8 : 0;

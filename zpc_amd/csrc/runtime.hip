@@ -51,8 +51,9 @@ static hipEvent_t spare_event(DeviceContext &c, int id) {
 }
 
 Launch::Launch(zs_rocm_policy *p, const char *w) : pol(p), what(w) {
-  dev = p->device >= 0 ? p->device : current_device();
-  if (p->device >= 0 && p->device != current_device()) ZSR_CHECK(hipSetDevice(dev));
+  prevDev = current_device();
+  dev = p->device >= 0 ? p->device : prevDev;
+  if (dev != prevDev) ZSR_CHECK(hipSetDevice(dev));
   DeviceContext &c = context(dev);
   stream = p->hasExternal ? p->external : spare_stream(c, p->streamid);
   if (p->listenProc >= 0) {  // spareStreamWaitForEvent (cuda/Cuda.cu:164-168)
@@ -82,6 +83,7 @@ Launch::~Launch() {
   if (pol->sync) ZSR_CHECK(hipStreamSynchronize(stream));
   // recordEventSpare (cuda/execution/ExecutionPolicy.cuh:489): lets other policies .listen() to us
   if (!pol->hasExternal) ZSR_CHECK(hipEventRecord(spare_event(c, pol->streamid), stream));
+  if (dev != prevDev) ZSR_CHECK(hipSetDevice(prevDev));  // the caller's current device is not ours to change
 }
 
 static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes);
@@ -129,11 +131,24 @@ void zs_rocm_policy_listen(zs_rocm_policy *p, int proc, int sid) {
   p->listenProc = proc;
   p->listenStream = sid;
 }
+// temporary_memory_resource<device_mem_tag>::do_allocate / do_deallocate (cuda/memory/Allocator.h:33-50): a stream-ordered
+// allocation on the policy's stream -- every block is its own allocation, stays valid until it is handed back, and never
+// overlaps another live block or the library's own per-call scratch (Launch::temp)
 void *zs_rocm_policy_temporary(zs_rocm_policy *p, size_t bytes) {
+  if (bytes == 0) return nullptr;
   const int dev = p->device >= 0 ? p->device : current_device();
+  DeviceGuard guard(dev);
   hipStream_t stream = p->hasExternal ? p->external : spare_stream(context(dev), p->streamid);
-  std::vector<size_t> used;
-  return arena_take(dev, stream, used, bytes);
+  void *ptr = nullptr;
+  ZSR_CHECK(hipMallocAsync(&ptr, bytes, stream));
+  return ptr;
+}
+void zs_rocm_policy_temporary_free(zs_rocm_policy *p, void *ptr) {
+  if (!ptr) return;
+  const int dev = p->device >= 0 ? p->device : current_device();
+  DeviceGuard guard(dev);
+  hipStream_t stream = p->hasExternal ? p->external : spare_stream(context(dev), p->streamid);
+  ZSR_CHECK(hipFreeAsync(ptr, stream));
 }
 void zs_rocm_policy_shmem(zs_rocm_policy *p, size_t b) { p->shmem = b; }
 void zs_rocm_policy_block(zs_rocm_policy *p, int tpb) { p->block = tpb; }
@@ -162,6 +177,13 @@ int zs_rocm_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+// hipMemsetAsync on the policy's stream: the clear of a grid / flag word between two kernels of the same stream (callers that own
+// the memory through another runtime -- torch -- would otherwise clear it on THAT runtime's stream, unordered with ours)
+void zs_rocm_memset(zs_rocm_policy *p, void *ptr, int byteVal, size_t bytes) {
+  if (!ptr || !bytes) return;
+  Launch L(p, "memset");
+  ZSR_CHECK(hipMemsetAsync(ptr, byteVal, bytes, L.stream));
 }
 void zs_rocm_release_temporaries(void) {
   std::lock_guard<std::mutex> lk(g_ctxMutex);

@@ -58,6 +58,11 @@ class MpmTransfer:
         self.order = self.bin_start = self.cell_count = self.nbr = None
         self.binned = False
 
+    def _zero(self, t):
+        """clear device memory ON THE POLICY'S STREAM (torch's zero_() would run on torch's current stream, which is ordered with
+        the policy's stream only while the policy uses the null stream)"""
+        lib().zs_rocm_memset(self.pol.handle, t.data_ptr(), 0, t.numel() * t.element_size())
+
     # ------------------------------------------------------------------ particle access
     def _port(self, name, buf=None):
         buf = self.buf if buf is None else buf
@@ -169,11 +174,11 @@ class MpmTransfer:
             flags = self.drift_flag.cpu()
             self.drift_tripped = self.drift_tripped or bool(flags[0])  # latched: a re-bin must not erase them
             self.outside_tripped = self.outside_tripped or bool(flags[2])
-            self.drift_flag.zero_()
+            self._zero(self.drift_flag)
 
     # ------------------------------------------------------------------ one sub-step
     def clear_grid(self):
-        self.grid.zero_()  # TileVector::reset(pol, 0) (TileVector.hpp:636-640)
+        self._zero(self.grid)  # TileVector::reset(pol, 0) (TileVector.hpp:636-640)
 
     def p2g(self, binned=None):
         binned = self.binned if binned is None else binned
@@ -268,7 +273,7 @@ class MpmTransfer:
         if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
             self.grid2 = torch.zeros_like(self.grid)
         else:
-            self.grid2.zero_()
+            self._zero(self.grid2)
         if self.drift_flag is None:
             self.drift_flag = torch.zeros(3, dtype=torch.int32, device=self.device)
         ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
@@ -306,7 +311,7 @@ class MpmTransfer:
             return 0
         c = int(self.drift_flag[1].item())
         if reset:
-            self.drift_flag[1:2].zero_()  # the flags [0], [2] stay
+            self._zero(self.drift_flag[1:2])  # the flags [0], [2] stay
         return c
 
     def reorder_partition(self, first_mask):
