@@ -445,10 +445,20 @@ def main():
 
     run_steps(a.warmup, False)
     barrier()
+    probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_debug_probe")  # measurement builds only (tools/ablate.sh PROBE)
+    if probe:
+        import ctypes
+        pv = (ctypes.c_ulonglong * 16)()
+        lib().zs_rocm_debug_probe(pv, 1)
     t0 = time.perf_counter()
     run_steps(a.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    if probe:
+        lib().zs_rocm_debug_probe(pv, 0)
+        wgs = max(int(pv[7]), 1)
+        print("probe (cycles per workgroup, 100 MHz-agnostic s_memtime ticks): " +
+              " ".join("[%d]=%.0f" % (k, pv[k] / wgs / (4 if k in (0, 1, 4, 5, 6) else 8)) for k in range(7)) + " wgs=%d" % wgs, file=sys.stderr)
     if a.fused and a.checksum:
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()

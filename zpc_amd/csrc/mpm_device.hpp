@@ -2033,11 +2033,28 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
       } else {
         float vel[3], C[9];
+#ifdef ZS_ABLATE_GATHER  // measurement-only build: the 27-node gather replaced by three LDS reads
+        {
+          const float *g0 = varena + AL::at(ocx, ocy, ocz);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) vel[d] = g0[d * AL::CH];
+#pragma unroll
+          for (int d = 0; d < 9; ++d) C[d] = vel[d % 3] * D_inv * 1e-9f;
+        }
+#else
         g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+#endif
         const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
         float pos[3];
+#ifdef ZS_ABLATE_FREEZE  // measurement-only builds: garbage velocities must not move particles or blow F up (same instruction count)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * 1e-14f;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) C[d] *= 1e-14f;
+#else
 #pragma unroll
         for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
+#endif
         float F[9], PF[9];
         advance_state<model_is_fluid(SMODEL)>(cur.F, C, mp.dt, F);
         pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
@@ -2046,7 +2063,12 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         {  // F has been stored above: the plastic models may project this local copy
           float lj = 0.f;
           if constexpr (DP) lj = cur.logJp;
+#ifdef ZS_ABLATE_STRESS  // measurement-only build (tools/ablate.sh): constitutive update replaced by a copy, to time its marginal cost
+#pragma unroll
+          for (int d = 0; d < 9; ++d) PF[d] = F[d] * mp.mat.mu;
+#else
           model_stress<SMODEL>(mp.mat, lj, F, PF, C);
+#endif
           if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
         }
         // where is it now?  same cell as this lane: register accumulation (phase 2).  Another cell of the same bin: queued in
@@ -2096,7 +2118,11 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     for (int rr = R0; rr < R0 + 2; ++rr) {
       const unsigned long long vm = smask[par * 4 + rr];
       if (vm == 0ull) continue;
+#ifdef ZS_ABLATE_CONSUME  // measurement-only build: the phase-2 stencil accumulation replaced by one add per staged record
+      if ((vm >> lane) & 1ull) acc[0][0] += stage[(size_t)(par * 4 + rr) * (G2P2G_NF * 64) + lane];
+#else
       if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
+#endif
     }
     par ^= 1;
     cur = nxt;
@@ -2105,13 +2131,18 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     any = any1;
   }
   float *a0 = parena + (size_t)(W & 1) * (7 * AL::CH) + AL::at(cx, cy, cz);
+  // Every wave owns its (arena, channel set): waves 0/2 write arena 0 (channels 0-3 / 4-6), waves 1/3 arena 1.  In phase k the 64
+  // lanes of a wave add to 64 distinct nodes; the next phase touches nodes other lanes wrote in this one, so the phases must stay
+  // ordered -- but only inside the wave: LDS operations of one wave execute in order, so a wavefront-scope fence (no instruction,
+  // it only keeps the compiler from hoisting the next phase's reads over this phase's writes) replaces the 27 workgroup barriers.
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
 #pragma unroll
     for (int q = 0; q < NCH; ++q) g[((STRESS ? 4 : 0) + q) * AL::CH] += acc[k][q];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  __syncthreads();  // the post-pass and the flush read both arenas
 }
 
 template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, bool REORDER = false>
@@ -2137,11 +2168,17 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+#ifdef ZS_ABLATE_PROLOGUE  // measurement-only build: no nbr / grid A loads at the head of a bin
+    float *a = varena + AL::at(x, y, z);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = 0.01f + 1e-9f * (float)(slot + cell);
+#else
     const int bn = nbr[(size_t)geo.block * 8 + slot];
     float *a = varena + AL::at(x, y, z);
     const float *g = gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
+#endif
   }
   for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
@@ -2202,7 +2239,12 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+#ifdef ZS_ABLATE_EPILOGUE  // measurement-only build: one atomic per workgroup instead of the arena flush
+    const int bn = -1;
+    if (tid == 0) unsafeAtomicAdd(gridB + (size_t)geo.block * 7 * NC, parena[AL::at(x, y, z)]);
+#else
     const int bn = nbr[(size_t)geo.block * 8 + slot];
+#endif
     const float *a = parena + AL::at(x, y, z);
     if (bn >= 0) {
       float *g = gridB + (size_t)bn * 7 * NC + cell;
@@ -2211,10 +2253,383 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
         const float v = a[ch * AL::CH] + a[(7 + ch) * AL::CH];
         if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
       }
-    } else if (a[0] + a[7 * AL::CH] != 0.f) {
+    }
+#ifndef ZS_ABLATE_EPILOGUE
+    else if (a[0] + a[7 * AL::CH] != 0.f) {
       staleGCount[9] = 1;  // mass for a node whose block is not in the partition: the partition no longer covers the particles
     }
+#endif
   }
+}
+// ---------------------------------------------------------------------------------------------------------------------------
+// Role-split variant of the fused pass (the default; g2p2g_binned_kernel above stays for the re-ordering step and for A/B runs
+// with ZS_ROCM_G2P2G_CLASSIC=1).  Measured on the four-wave kernel (tools/ablate.sh, 64 Mi particles): the costs of its parts
+// ADD UP instead of overlapping -- constitutive update 1.0 ms + phase-2 accumulation 0.9 + gather 0.5 + streaming skeleton 2.2
+// + head/tail of a bin 0.45 = 5.0 ms -- because at 223 VGPRs / 74.5 KB LDS only two waves share a SIMD, each of them parked 37 %
+// of its life (SQ_WAIT_ANY), and one wave alone issues a VALU instruction only every ~5 cycles.  The accumulators (27 nodes x 7
+// channels per cell) are what costs the registers, so they move to waves of their own:
+//   waves 0-3  PRODUCERS  round 4c + w of chunk c: G2P from the LDS velocity arena, advection, F update, constitutive model,
+//                         stores, {m, x', v', C', P F^T} staged in LDS -- no accumulators: < 128 VGPRs
+//   waves 4-7  CONSUMERS  of the chunk staged one iteration earlier: each owns a channel set {m, mv_x} {mv_y, mv_z} {f_x, f_y}
+//                         {f_z} of ALL four staged rounds: 54 accumulators, < 128 VGPRs; each channel of the bin's single LDS
+//                         arena belongs to one wave, so the final flush needs no barrier between its 27 phases
+// One barrier per chunk (stage double-buffered), 512 threads, 66 KB LDS: two workgroups = 16 waves per CU = 4 per SIMD.  The
+// per-record arena / weight set-up is repeated by four consumers instead of two (+190 VALU per 64 particles, +9 %).
+#ifdef ZS_PROBE  // measurement-only build (tools/ablate.sh PROBE): s_memtime stamps of a workgroup's phases, summed over all workgroups
+__device__ unsigned long long g_probe[16];
+#define ZS_STAMP(slot, t0) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 127) == 0) atomicAdd(&g_probe[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
+#else
+#define ZS_STAMP(slot, t0) do { } while (0)
+#endif
+template <int CS> struct ConsumerSet {  // CS 0: m + mv_x, 1: mv_y + mv_z, 2: f_x + f_y, 3: f_z
+  static constexpr bool STRESS = CS >= 2;
+  static constexpr bool MASS = CS == 0;
+  static constexpr int NV = CS == 1 || CS == 2 ? 2 : 1;        // vector-valued channels (a direction d each)
+  static constexpr int NA = NV + (MASS ? 1 : 0);               // accumulators per node
+  static constexpr int D0 = CS == 0 ? 0 : (CS == 1 ? 1 : (CS == 2 ? 0 : 2));  // first direction; the second is D0 + 1
+  static constexpr int CH0 = CS == 0 ? 0 : (CS == 1 ? 2 : (CS == 2 ? 4 : 6));  // first grid channel of the set
+};
+template <int CS>
+__device__ __forceinline__ void g2p2g_consume_set(const MpmDev &mp, const float *st, int lane, float kscale,
+                                                  float (&acc)[27][ConsumerSet<CS>::NA]) {
+  using S = ConsumerSet<CS>;
+  auto f = [&](int k) { return st[k * 64 + lane]; };
+  const float pos[3] = {f(1), f(2), f(3)};
+  Arena ar;
+  make_arena(mp.dx, pos, ar);
+  float xo[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
+  float Px[S::NV][3], Py[S::NV][3], Pz[S::NV][3], wzs[3];
+#pragma unroll
+  for (int j = 0; j < S::NV; ++j) {
+    const int d = S::D0 + j;
+    const int cb = S::STRESS ? 16 : 7;
+    const float c0 = f(cb + d), c1 = f(cb + 3 + d), c2 = f(cb + 6 + d);
+    const float v = S::STRESS ? 0.f : f(4 + d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Px[j][k] = c0 * xo[0][k];
+      Py[j][k] = c1 * xo[1][k];
+      Pz[j][k] = S::STRESS ? c2 * xo[2][k] : fmaf(c2, xo[2][k], v);
+    }
+  }
+  const float scale = S::STRESS ? kscale : f(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float wxy = ar.w[0][a] * ar.w[1][bb];
+      float q[S::NV];
+#pragma unroll
+      for (int j = 0; j < S::NV; ++j) q[j] = Px[j][a] + Py[j][bb];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float Ws = wxy * wzs[c];
+        auto &A = acc[(a * 3 + bb) * 3 + c];
+        if constexpr (S::MASS) A[0] += Ws;
+#pragma unroll
+        for (int j = 0; j < S::NV; ++j) A[(S::MASS ? 1 : 0) + j] = fmaf(Ws, q[j] + Pz[j][c], A[(S::MASS ? 1 : 0) + j]);
+      }
+    }
+}
+template <int CS>
+__device__ __forceinline__ void g2p2g_rs_consumer(const MpmDev &mp, int lane, int nchunks, const float *stage, const unsigned long long *smask,
+                                                  float *parena) {
+  using S = ConsumerSet<CS>;
+  using AL = ArenaLds;
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const float dxi = 1.0f / mp.dx;
+  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  float acc[27][S::NA];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
+  for (int k = (int)threadIdx.x - 256; k < 7 * AL::CH; k += 256) parena[k] = 0.f;  // the four consumer waves clear the bin's arena
+  __syncthreads();  // (the producers fill the velocity arena meanwhile)
+  for (int it = 0; it <= nchunks; ++it) {
+    if (it > 0) {
+      const int par = (it - 1) & 1;
+#pragma unroll 1
+      for (int rr = 0; rr < 4; ++rr) {
+        const unsigned long long vm = smask[par * 4 + rr];
+        if (vm == 0ull) continue;
+        if ((vm >> lane) & 1ull) g2p2g_consume_set<CS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
+      }
+    }
+    __syncthreads();
+  }
+  // the set's channels of the bin's arena belong to this wave alone; phases ordered inside the wave (see g2p2g_body)
+  float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+    for (int q = 0; q < S::NA; ++q) g[q * AL::CH] += acc[k][q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+// producer wave W (0..3): round 4c + W of every chunk c
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL, int W>
+__device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int start, unsigned cnt,
+                                                  int lane, int nchunks, float *varena, float *stage, unsigned long long *smask,
+                                                  int *staleG, int *staleGCount, int *staleP, int *stalePCount, int *mq, int *mqCount,
+                                                  const float *gridA, const int *nbr) {
+  using AL = ArenaLds;
+  constexpr bool DP = model_uses_logjp(SMODEL);
+  constexpr bool FLUID = model_is_fluid(SMODEL);
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const float dxi = 1.0f / mp.dx;
+  const float D_inv = 4.f * dxi * dxi;
+  RoundWalk walk(cnt, start);
+  auto next_chunk = [&](int &idx, bool &has) {
+    has = false;
+    idx = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int i;
+      bool a;
+      const bool h = walk.next(i, a);
+      if (r == W) {
+        idx = i;
+        has = h;
+      }
+    }
+  };
+  int i0 = 0, i1 = 0;
+  bool has0 = false, has1 = false;
+  RecG<LW, DP, FLUID> cur, nxt;
+  // head of the bin: the first records are requested BEFORE the velocity arena is filled -- both need only what the bin number
+  // gives (binStart / cellCount / block key / nbr row arrive together), so a bin starts after two memory round trips, not four
+  if (nchunks > 0) {
+    next_chunk(i0, has0);
+    if (has0) cur.load(ps, (size_t)i0);
+  }
+  {
+    constexpr int NC = SIDE * SIDE * SIDE;
+    const int tid = (int)threadIdx.x;  // the four producer waves are threads 0..255
+    if (tid < 216) {  // node decoded once for the 3 velocity channels
+      const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
+      int slot, cell;
+      arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+      const int bn = nbr[(size_t)geo.block * 8 + slot];
+      float *a = varena + AL::at(x, y, z);
+      const float *g = gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
+    }
+  }
+#ifdef ZS_PROBE
+  const unsigned long long tP0 = __builtin_readcyclecounter();
+#endif
+  __syncthreads();
+  ZS_STAMP(4, tP0);  // [4] producers: wait at the barrier behind the arena fill (grid loads landing)
+#ifdef ZS_PROBE
+  unsigned long long tBar = 0, tP1 = __builtin_readcyclecounter();
+#endif
+  for (int it = 0; it <= nchunks; ++it) {
+    if (it < nchunks) {
+      const int par = it & 1;
+      float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
+      has1 = false;
+      if (it + 1 < nchunks) {
+        next_chunk(i1, has1);
+        if (has1) nxt.load(ps, (size_t)i1);  // in flight during this chunk
+      }
+      bool valid = false;
+      if (has0) {
+        Arena ar;
+        make_arena(mp.dx, cur.pos, ar);
+        const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+        if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
+          staleG[atomicAdd(staleGCount, 1)] = i0;  // outside the bin: exact gather + scatter afterwards
+          if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
+        } else {
+          float vel[3], C[9];
+          g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+          const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
+          float pos[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
+          float F[9], PF[9];
+          advance_state<FLUID>(cur.F, C, mp.dt, F);
+          pstore_state<LW, FLUID>(ps.F, o, F);
+          pstore<LW, 3>(ps.pos, o, pos);
+          {  // F has been stored above: the plastic models may project this local copy
+            float lj = 0.f;
+            if constexpr (DP) lj = cur.logJp;
+            model_stress<SMODEL>(mp.mat, lj, F, PF, C);
+            if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
+          }
+          const int ncx = (int)floorf(pos[0] * dxi - 0.5f) - geo.org[0], ncy = (int)floorf(pos[1] * dxi - 0.5f) - geo.org[1],
+                    ncz = (int)floorf(pos[2] * dxi - 0.5f) - geo.org[2];
+          const bool moved = ncx != cx || ncy != cy || ncz != cz;
+          if (WRITE_ALL || moved) {
+            pstore<LW, 3>(ps.vel, o, vel);
+            pstore<LW, 9>(ps.C, o, C);
+            pstore<LW, 9>(ps.stress, o, PF);
+          }
+          if (moved) {
+            bool queued = false;
+            if ((unsigned)ncx < 4u && (unsigned)ncy < 4u && (unsigned)ncz < 4u) {
+              const int slot = atomicAdd(mqCount, 1);
+              if (slot < G2P2G_MQ_CAP) {
+                mq[slot] = i0;
+                queued = true;
+              }
+            }
+            if (!queued) {
+              staleP[atomicAdd(stalePCount, 1)] = i0;  // left the bin during this step: exact scatter afterwards
+              if ((unsigned)(ncx + 4) >= 12u || (unsigned)(ncy + 4) >= 12u || (unsigned)(ncz + 4) >= 12u) staleGCount[8] = 1;
+            }
+          } else {
+            valid = true;
+            myStage[0 * 64 + lane] = cur.m;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = pos[d];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
+          }
+        }
+      }
+      {
+        const unsigned long long vm = __ballot(valid);
+        if (lane == 0) smask[par * 4 + W] = vm;
+      }
+      cur = nxt;
+      has0 = has1;
+      i0 = i1;
+    }
+#ifdef ZS_PROBE
+    const unsigned long long tb = __builtin_readcyclecounter();
+    __syncthreads();
+    tBar += __builtin_readcyclecounter() - tb;
+#else
+    __syncthreads();
+#endif
+  }
+#ifdef ZS_PROBE
+  if (lane == 0 && (blockIdx.x & 127) == 0) {
+    atomicAdd(&g_probe[5], tBar);                                    // [5] producers: time inside the per-chunk barriers
+    atomicAdd(&g_probe[6], __builtin_readcyclecounter() - tP1);      // [6] producers: the chunk loop
+  }
+#endif
+}
+
+template <int SIDE, int SMODEL, int LW, bool WRITE_ALL>
+static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
+                                                          const int *binStart, const unsigned *cellCount, const int *nbr, int *staleG,
+                                                          int *staleGCount, int *staleP, int *stalePCount, int binBase) {
+  using AL = ArenaLds;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  __shared__ float varena[3 * AL::CH];
+  __shared__ float parena[7 * AL::CH];
+  __shared__ float stage[2 * 4 * G2P2G_NF * 64];
+  __shared__ unsigned long long smask[2 * 4];
+  __shared__ int mq[G2P2G_MQ_CAP];
+  __shared__ int mqCount;
+  if (threadIdx.x == 0) mqCount = 0;
+#ifdef ZS_PROBE
+  const unsigned long long tEntry = __builtin_readcyclecounter();
+#endif
+  const int bin = blockIdx.x + binBase;
+  const int start = binStart[bin], end = binStart[bin + 1];
+  if (start == end) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
+  // rounds of this bin = the fullest cell; every wave needs the number of chunks (uniform loop with one barrier per chunk)
+  unsigned mx = cnt;
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)mx, sft, 64);
+    mx = o > mx ? o : mx;
+  }
+  const int nchunks = (int)((mx + 3u) >> 2);
+  if (w == 0) g2p2g_rs_producer<SIDE, SMODEL, LW, WRITE_ALL, 0>(mp, ps, geo, start, cnt, lane, nchunks, varena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, gridA, nbr);
+  else if (w == 1) g2p2g_rs_producer<SIDE, SMODEL, LW, WRITE_ALL, 1>(mp, ps, geo, start, cnt, lane, nchunks, varena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, gridA, nbr);
+  else if (w == 2) g2p2g_rs_producer<SIDE, SMODEL, LW, WRITE_ALL, 2>(mp, ps, geo, start, cnt, lane, nchunks, varena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, gridA, nbr);
+  else if (w == 3) g2p2g_rs_producer<SIDE, SMODEL, LW, WRITE_ALL, 3>(mp, ps, geo, start, cnt, lane, nchunks, varena, stage, smask, staleG, staleGCount, staleP, stalePCount, mq, &mqCount, gridA, nbr);
+  else if (w == 4) g2p2g_rs_consumer<0>(mp, lane, nchunks, stage, smask, parena);
+  else if (w == 5) g2p2g_rs_consumer<1>(mp, lane, nchunks, stage, smask, parena);
+  else if (w == 6) g2p2g_rs_consumer<2>(mp, lane, nchunks, stage, smask, parena);
+  else g2p2g_rs_consumer<3>(mp, lane, nchunks, stage, smask, parena);
+  ZS_STAMP(w < 4 ? 0 : 1, tEntry);  // [0] producers / [1] consumers: entry -> end of the role body (summed over 4 waves each)
+  __syncthreads();  // all channel sets are in the arena
+  ZS_STAMP(2, tEntry);              // [2] entry -> past the barrier behind the bodies (8 waves)
+  // in-bin movers: dense post-pass with LDS atomics (see g2p2g_binned_kernel)
+  {
+    const int nm = mqCount < G2P2G_MQ_CAP ? mqCount : G2P2G_MQ_CAP;
+    const float dxi = 1.0f / mp.dx;
+    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    for (int q = tid; q < nm; q += 512) {
+      const size_t i = (size_t)mq[q];
+      auto cload = [&](const Port<float> &p, int comp) {
+        return __hip_atomic_load(p.base + p.off(i) + (size_t)comp * p.cstride(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      const float m = ps.mass.base[ps.mass.off(i)];
+      float pos[3], vel[3], C[9], PF[9];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { pos[d] = cload(ps.pos, d); vel[d] = cload(ps.vel, d); }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { C[d] = cload(ps.C, d); PF[d] = cload(ps.stress, d) * kscale; }
+      Arena ar;
+      make_arena(mp.dx, pos, ar);
+      const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
+      if ((unsigned)kx >= 4u || (unsigned)ky >= 4u || (unsigned)kz >= 4u) {
+        staleP[atomicAdd(stalePCount, 1)] = (int)i;
+        continue;
+      }
+      float *a0 = parena + AL::at(kx, ky, kz);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
+            const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
+            float *g = a0 + AL::at(a, b, c);
+            atomicAdd(g, W * m);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              atomicAdd(g + (1 + d) * AL::CH, W * m * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
+              atomicAdd(g + (4 + d) * AL::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
+            }
+          }
+    }
+    __syncthreads();
+  }
+  if (tid < 216) {
+    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
+    int slot, cell;
+    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
+    const int bn = nbr[(size_t)geo.block * 8 + slot];
+    const float *a = parena + AL::at(x, y, z);
+    if (bn >= 0) {
+      float *g = gridB + (size_t)bn * 7 * NC + cell;
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        const float v = a[ch * AL::CH];
+        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
+      }
+    } else if (a[0] != 0.f) {
+      staleGCount[9] = 1;  // mass for a node whose block is not in the partition
+    }
+  }
+  ZS_STAMP(3, tEntry);  // [3] entry -> exit (8 waves)
+#ifdef ZS_PROBE
+  if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) atomicAdd(&g_probe[7], 1ull);  // sampled workgroups
+#endif
 }
 // queue G: gather from grid A with hash queries (stores the full state), then scatter to grid B; queue P: scatter only
 template <int SIDE, int SMODEL>
