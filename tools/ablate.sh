@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p zpc_amd/lib/ablate
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-result -I include -fno-slp-vectorize"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-result -I include -fno-slp-vectorize -DZS_FUSED_FAST_BUILD -DZS_ROCM_WITH_PERSIST"
 for v in "$@"; do
   name=$(echo $v | tr ' ' '_')
   defs=""; case "$v" in *STRESS*|*CONSUME*|*GATHER*|*PROLOGUE*|*EPILOGUE*) defs="-DZS_ABLATE_FREEZE";; esac
