@@ -617,6 +617,22 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2c2p_step(zs_rocm_policy *, const zs_rocm_mpm_pa
 ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles,
                                     const zs_rocm_bht_3 *, const float *grid, size_t nblocks, const int *binStart,
                                     const unsigned *cellCount, const int *nbr);
+/* ---- slotted particle storage: the motion-robust form of the fused step (zpc_amd/csrc/mpm_slotted.hip).  Storage = bins x K rounds x
+ * 64 lanes in ONE TileVector<f32, 64> (slot (bin, r, lane) = element (bin K + r) 64 + lane), cellMask[bin][lane] = occupied rounds of the
+ * cell; a particle is always stored under the cell of its base node, and the step keeps it so: particles that change cell go through
+ * per-bin outboxes and are pulled, scattered and re-homed by their destination bin (no re-bin, no exact-path queues in the time loop).
+ * The per-particle arithmetic is that of zs_rocm_mpm_g2p2g (G2P.hpp:44-83 + P2G.hpp:51-125). */
+ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int outboxCap, int which); /* 0 moverCount, 1 moverDest, 2 moverRec */
+ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors27(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr27 /* [nblocks][27] */, int keyStride);
+/* src: TileVector<f32,64> with C channels and n particles in any order -> dst: nbins*K tiles; status: int[8] (latched flags, see the .hip) */
+ZS_ROCM_EXPORT int zs_rocm_mpm_slot_particles(zs_rocm_policy *, const zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n, float dx, int side,
+                                              int keyIsOrigin, int K, const float *src, float *dst, int C, unsigned *cellMask, int *status);
+/* occupied slots in slot order (slots may be NULL: count only); synchronises */
+ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_list(zs_rocm_policy *, const unsigned *cellMask, size_t nbins, int K, int *slots);
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
+                                             const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr,
+                                             const int *nbr27, int *moverCount, long long *moverDest, float *moverRec, int outboxCap,
+                                             int writeAll, int *status);
 /* particles.stress := model(F, logJp) * volume, logJp updated (no-op when particles.stress.base == NULL) */
 /* Fused transfer: G2P of step n (from gridA: velocities after zs_rocm_mpm_grid_update) and P2G of step n+1 (into gridB,
  * zeroed by the caller) in one pass over the binned particles -- the reference's G2P2GTransfer idea

@@ -619,3 +619,108 @@ def test_fused_g2p2g_matches_reference_golden(pol, name, side):
         assert np.abs(d["logJp"] - g["logJp2"]).max() <= 2e-5
     assert not mt.left_partition()
     assert __import__("zpc_amd").lib().zs_rocm_last_error(-1) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Slotted particle storage (zpc_amd/csrc/mpm_slotted.hip): the fused step that keeps its own storage order while particles move.
+def _id_order(m, x):
+    """particles carry their identity in their mass (a few fixture masses coincide: the position breaks the tie)"""
+    return np.lexsort((x[:, 2], x[:, 1], x[:, 0], m))
+
+
+def _by_mass(d):
+    o = _id_order(d["m"], d["x"])
+    return {k: v[o] for k, v in d.items()}
+
+
+@pytest.mark.parametrize("name,side", [("fixedcorotated", 4), ("fixedcorotated", 8), ("sand", 4), ("sand", 8), ("eos", 8)])
+def test_slotted_fused_matches_reference_golden(pol, name, side):
+    """zs_rocm_mpm_g2p2g_slotted (main kernel + mover pull) against the reference-made fixture: particle state after G2P and the next
+    step's grid, as test_fused_g2p2g_matches_reference_golden; the fixture's particles move (|v| ~ 1, dt 1e-4, dx 1/128: a few change
+    cell), so outboxes, pull and re-homing are on the path."""
+    g, mt = _golden_setup(pol, name, side, cache_stress=True, binned=False)
+    if name == "sand":   # the fused pass reads the logJp the previous P2G left behind
+        tmp = torch.empty(mt.n, mt.nchn, device="cuda")
+        lib = __import__("zpc_amd").lib()
+        lib.zs_rocm_tv_to_aos_f32(pol.handle, mt.buf.data_ptr(), mt.n, mt.nchn, mt.L, tmp.data_ptr())
+        pol.syncCtx()
+        tmp[:, mt.off["logJp"]] = torch.from_numpy(g["logJp1"]).cuda()
+        lib.zs_rocm_tv_from_aos_f32(pol.handle, tmp.data_ptr(), mt.n, mt.nchn, mt.L, mt.buf.data_ptr())
+        pol.syncCtx()
+    mt.slot(K=16)
+    assert int(mt.cell_mask.cpu().numpy().view(np.uint32).astype(np.uint64).sum()) > 0
+    mt.grid.copy_(torch.from_numpy(g["gridv"]).reshape(-1))
+    mt.g2p2g(write_all=True)
+    pol.syncCtx()
+    st = mt.check_slots()
+    d = _by_mass(mt.download())
+    o = _id_order(g["mass"], g["pos1"])
+    assert np.array_equal(d["m"], g["mass"][o])                       # every particle is still there, exactly once
+    assert np.abs(d["x"] - g["pos1"][o]).max() <= 1e-7
+    assert np.abs(d["v"] - g["vel1"][o]).max() <= 2e-6 * np.abs(g["vel1"]).max()
+    assert np.abs(d["C"] - g["C1"][o]).max() <= 1e-5 * np.abs(g["C1"]).max()
+    if name == "eos":
+        assert np.abs(d["J"][:, 0] - g["F1"][o, 0]).max() <= 1e-6
+    else:
+        assert np.abs(d["F"] - g["F1"][o]).max() <= 2e-6
+    err = _grid_err(mt, g["grid2"], g["rhs_scale"])
+    assert (err[:4] <= 5e-6).all() and _rhs_ok(err, name), err
+    if name == "sand":
+        assert np.abs(d["logJp"] - g["logJp2"][o]).max() <= 2e-5
+    # the storage invariant: every particle sits under the cell of its base node
+    assert st[5] == st[6]
+
+
+@pytest.mark.parametrize("side,model", [(8, 1), (4, 1), (8, 0)])
+def test_slotted_steps_of_a_moving_cloud_vs_oracle(pol, oracle, side, model):
+    """six fused steps of a cloud drifting ~0.3 cell per step (most particles change cell, many change bin / block): the slotted
+    step (no re-bin anywhere) against the oracle's g2p -> p2g sequence, particle for particle and node for node."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-3
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=77 + side, vel_scale=0.3)
+    n = pos.shape[0]
+    mass = (mass * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)   # identity tag
+    assert len(np.unique(mass)) == n
+    vel += np.array([4.0, -5.0, 3.0], np.float32)                      # 0.25-0.32 cell per step
+    vol = dx ** 3 / 8
+    lj = (0.01 * rng(5).standard_normal(n)).astype(np.float32)
+    om = OracleMpm(oracle, model, dx, dt, side, vol)
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
+    mt.upload(mass, pos, vel, Cm, F, lj if model == 1 else None)
+    mt.build_partition(n, margin=1)
+    keys = mt.active_keys()
+    om.adopt_partition(keys)
+    # step 0: P2G on both sides (the GPU primes its grid through the binned path), then grid update
+    ljo = lj.copy()
+    om.p2g(mass, pos, vel, Cm, F, ljo)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    om.grid_update((0.0, -9.8, 0.0))
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.slot(K=24, outbox_cap=512)
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    # the binned priming pass re-ordered the particles and evaluated the model once (logJp): continue from that state
+    for step in range(6):
+        om.g2p(po, vo, Co, Fo)
+        om.grid[:] = 0
+        om.p2g(mass, po, vo, Co, Fo, ljo)
+        mt.g2p2g(write_all=(step == 5))
+        pol.syncCtx()
+        mt.check_slots()
+        ga = mt.grid.cpu().numpy().reshape(om.grid.shape)
+        scale = np.abs(om.grid).max(axis=(0, 2)) + 1e-30
+        assert (np.abs(ga - om.grid).max(axis=(0, 2)) <= 3e-4 * scale).all(), (step, np.abs(ga - om.grid).max(axis=(0, 2)) / scale)
+        om.grid_update((0.0, -9.8, 0.0))
+        mt.grid_update((0.0, -9.8, 0.0))
+    d = _by_mass(mt.download())
+    o = _id_order(mass, po)
+    assert np.array_equal(d["m"], mass[o])
+    assert np.abs(d["x"] - po[o]).max() <= 2e-6
+    assert np.abs(d["v"] - vo[o]).max() <= 2e-4 * np.abs(vo).max()
+    assert np.abs(d["F"] - Fo[o]).max() <= 5e-5
+    # most particles changed cell at least once
+    c0 = np.floor(pos / dx - 0.5).astype(int)
+    c1 = np.floor(po / dx - 0.5).astype(int)
+    assert (np.abs(c1 - c0).max(axis=1) >= 1).mean() > 0.8

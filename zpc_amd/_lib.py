@@ -107,6 +107,13 @@ def _declare(L):
     L.zs_rocm_policy_last_elapsed_ms.argtypes = [vp]
     L.zs_rocm_policy_last_elapsed_ms.restype = f32
     L.zs_rocm_memset.argtypes = [vp, vp, i32, sz]
+    L.zs_rocm_mpm_slot_outbox_bytes.argtypes = [sz, i32, i32]
+    L.zs_rocm_mpm_slot_outbox_bytes.restype = sz
+    L.zs_rocm_mpm_build_neighbors27.argtypes = [vp, vp, vp, i32]
+    L.zs_rocm_mpm_slot_particles.argtypes = [vp, vp, Port, sz, f32, i32, i32, i32, vp, vp, i32, vp, vp]
+    L.zs_rocm_mpm_slot_particles.restype = i32
+    L.zs_rocm_mpm_slot_list.argtypes = [vp, vp, sz, i32, vp]
+    L.zs_rocm_mpm_slot_list.restype = sz
     L.zs_rocm_policy_temporary.argtypes = [vp, sz]
     L.zs_rocm_policy_temporary.restype = vp
     L.zs_rocm_policy_temporary_free.argtypes = [vp, vp]
@@ -303,6 +310,8 @@ def _declare_containers(L):
     L.zs_rocm_mpm_owner_rank.argtypes = [vp, Port, sz, f32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]
     L.zs_rocm_mpm_g2p2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32]
     L.zs_rocm_mpm_g2p2g_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
+    L.zs_rocm_mpm_g2p2g_slotted.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.zs_rocm_mpm_g2p2g_slotted.restype = i32
     L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

@@ -57,6 +57,9 @@ class MpmTransfer:
         self.nblocks = 0
         self.order = self.bin_start = self.cell_count = self.nbr = None
         self.binned = False
+        self.slotted = False   # slotted storage (zs_rocm_mpm_slot_particles): self.buf holds nbins * K tiles, cell_mask says which
+        self.n_slots = 0
+        self.K = 0
 
     def _zero(self, t):
         """clear device memory ON THE POLICY'S STREAM (torch's zero_() would run on torch's current stream, which is ordered with
@@ -73,7 +76,7 @@ class MpmTransfer:
         null = Port(None, 0, 0, 0, 1)
         return Particles(self._port("m", buf), self._port("x", buf), self._port("v", buf), self._port("C", buf), self._port("F", buf),
                          self._port("logJp", buf) if self.model in HAS_LOGJP else null,
-                         self._port("PF", buf) if self.cache_stress else null, self.n)
+                         self._port("PF", buf) if self.cache_stress else null, self.n_slots if self.slotted else self.n)
 
     def set_particles(self, buf, n):
         """Adopt a new AoSoA particle buffer (after an inter-rank migration): the partition and the bins are void."""
@@ -104,8 +107,12 @@ class MpmTransfer:
         self.binned = False
 
     def download(self):
+        buf = self.buf
+        if self.slotted:  # the occupied slots, in slot order
+            buf, cnt = self._compact_copy()
+            assert cnt == self.n, "slotted storage holds %d particles, expected %d" % (cnt, self.n)
         aos = torch.empty(self.n, self.nchn, dtype=torch.float32, device=self.device)
-        lib().zs_rocm_tv_to_aos_f32(self.pol.handle, self.buf.data_ptr(), self.n, self.nchn, self.L, aos.data_ptr())
+        lib().zs_rocm_tv_to_aos_f32(self.pol.handle, buf.data_ptr(), self.n, self.nchn, self.L, aos.data_ptr())
         self.pol.syncCtx()
         a = aos.cpu().numpy()
         out = {"m": a[:, 0].copy(), "x": a[:, 1:4].copy(), "v": a[:, 4:7].copy(), "C": a[:, 7:16].copy(),
@@ -115,15 +122,19 @@ class MpmTransfer:
         return out
 
     # ------------------------------------------------------------------ partition (SparsityCompute.tpp:5-24)
-    def build_partition(self, expected_blocks):
+    def build_partition(self, expected_blocks, margin=0):
+        """ComputeSparsity + EnlargeSparsity{0, 2} (the reference's partition); margin = m enlarges by m more blocks on every side
+        (lo = -m, hi = 2 + m): room for the particles to travel m blocks before the partition has to be rebuilt"""
         self.table = Bht(3, int(expected_blocks))
         L = lib()
         L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
                                        int(self.key_is_origin))
-        lo, hi = (C.c_int * 3)(0, 0, 0), (C.c_int * 3)(2, 2, 2)
+        m = int(margin)
+        lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
         self.nblocks = self.table.size()
+        self.slotted = False
         nc = self.side ** 3
         self.grid = torch.zeros(self.nblocks * 7 * nc, dtype=torch.float32, device=self.device)
         self.nbr = torch.empty(self.nblocks * 8, dtype=torch.int32, device=self.device)
@@ -175,6 +186,71 @@ class MpmTransfer:
             self.drift_tripped = self.drift_tripped or bool(flags[0])  # latched: a re-bin must not erase them
             self.outside_tripped = self.outside_tripped or bool(flags[2])
             self._zero(self.drift_flag)
+
+    # ------------------------------------------------------------------ slotted storage (zpc_amd/csrc/mpm_slotted.hip)
+    def slot(self, K=16, outbox_cap=96):
+        """compact particle buffer -> slotted storage (bins x K rounds x 64 lanes, one tile row per (bin, round)): the form the
+        fused step keeps valid by itself while particles move (no re-bins).  Needs the partition; lane width 64."""
+        assert self.L == 64 and not self.aos and self.table is not None and not self.slotted
+        L = lib()
+        self.K = int(K)
+        self.outbox_cap = int(outbox_cap)   # movers one bin can send per step (a bin holds 512 particles at 8 per cell)
+        self.nbins = self.nblocks * (self.side // 4) ** 3
+        self.n_slots = self.nbins * self.K * 64
+        sbuf = torch.empty(self.nbins * self.K * 64 * self.nchn, dtype=torch.float32, device=self.device)
+        self.cell_mask = torch.empty(self.nbins * 64, dtype=torch.int32, device=self.device)
+        self.slot_status = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.nbr27 = torch.empty(self.nblocks * 27, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_build_neighbors27(self.pol.handle, self.table.handle, self.nbr27.data_ptr(), self.kstride)
+        rc = L.zs_rocm_mpm_slot_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
+                                          int(self.key_is_origin), self.K, self.buf.data_ptr(), sbuf.data_ptr(), self.nchn,
+                                          self.cell_mask.data_ptr(), self.slot_status.data_ptr())
+        if rc != 0:
+            raise RuntimeError("zs_rocm_mpm_slot_particles refused its arguments")
+        self.mover_count = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 0) // 4, dtype=torch.int32, device=self.device)
+        self.mover_dest = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 1) // 8, dtype=torch.int64, device=self.device)
+        self.mover_rec = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 2) // 4, dtype=torch.float32, device=self.device)
+        self.pol.syncCtx()
+        st = self.slot_status.cpu().numpy()
+        if st[1] or st[2]:
+            raise RuntimeError("slot(): %s" % ("a cell holds more than K = %d particles" % self.K if st[1] else "particles outside the partition"))
+        self.buf, self.buf2 = sbuf, None
+        self.slotted, self.binned = True, False
+        self.order = self.bin_start = self.cell_count = None
+
+    def _compact_copy(self):
+        """(compact TileVector buffer of the occupied slots in slot order, particle count)"""
+        L = lib()
+        slots = torch.empty(self.n_slots, dtype=torch.int32, device=self.device)
+        cnt = int(L.zs_rocm_mpm_slot_list(self.pol.handle, self.cell_mask.data_ptr(), self.nbins, self.K, slots.data_ptr()))
+        tiles = (cnt + 63) // 64
+        out = torch.zeros(max(tiles, 1) * 64 * self.nchn, dtype=torch.float32, device=self.device)
+        if cnt:
+            L.zs_rocm_tv_gather_f32(self.pol.handle, self.buf.data_ptr(), out.data_ptr(), cnt, self.nchn, 64, slots.data_ptr())
+        self.pol.syncCtx()
+        return out, cnt
+
+    def unslot(self):
+        """slotted storage -> compact buffer (before a re-partition / migration)"""
+        assert self.slotted
+        out, cnt = self._compact_copy()
+        self.slotted = False
+        self.n = cnt
+        self.tiles = (cnt + 63) // 64
+        self.buf, self.buf2 = out, None
+        self.binned = False
+
+    def check_slots(self):
+        """raise if the slotted step reported a capacity overflow, a broken storage invariant or a lost mover"""
+        st = [int(v) for v in self.slot_status.cpu().numpy()]
+        names = ["outbox full", "a cell is full (K)", "mass for a block outside the partition", "inbox full",
+                 "a particle was not stored under its cell"]
+        bad = [names[k] for k in range(5) if st[k]]
+        if st[5] != st[6]:
+            bad.append("%d movers sent, %d delivered (destination block not in the partition)" % (st[5], st[6]))
+        if bad:
+            raise RuntimeError("slotted G2P2G: " + "; ".join(bad))
+        return st
 
     # ------------------------------------------------------------------ one sub-step
     def clear_grid(self):
@@ -255,6 +331,22 @@ class MpmTransfer:
         reorder=True: the particles are binned anew by their current positions (count / scan / distribute only) and the step
         itself carries them into that order -- inputs read from the old buffer through the permutation, results stored to the
         other buffer (zs_rocm_mpm_g2p2g_reorder_range): a re-bin without the separate reorder pass."""
+        if self.slotted:
+            if reorder or split:
+                raise ValueError("slotted storage: no re-ordering / split launches (the step keeps the order itself)")
+            if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
+                self.grid2 = torch.zeros_like(self.grid)
+            else:
+                self._zero(self.grid2)
+            src, dst = self.grid, self.grid2
+            self.grid, self.grid2 = dst, src
+            rc = lib().zs_rocm_mpm_g2p2g_slotted(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
+                                                 dst.data_ptr(), self.nblocks, self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(),
+                                                 self.nbr27.data_ptr(), self.mover_count.data_ptr(), self.mover_dest.data_ptr(),
+                                                 self.mover_rec.data_ptr(), self.outbox_cap, int(write_all), self.slot_status.data_ptr())
+            if rc != 0:
+                raise RuntimeError("zs_rocm_mpm_g2p2g_slotted refused the call")
+            return
         if not (self.cache_stress and self.binned):
             raise RuntimeError("g2p2g needs cache_stress=True and rebin()")
         src_buf = None
