@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--migrate-every", type=int, default=0,
                     help="every K steps: move particles to the rank that owns their cell, rebuild partition / halo lists / bins "
                          "(0 = never; the default bench window moves particles < 0.1 cell)")
-    ap.add_argument("--drift", type=str, default="0,0,0", help="uniform velocity added to every particle (m/s), e.g. 0,6,0")
+    ap.add_argument("--drift", type=str, default="0,-1.0,0",
+                    help="uniform velocity added to every particle (m/s).  Default 0,-1,0: the column falls at 1 m/s = 0.051 cell per "
+                         "step (dx = 1/512, dt = 1e-4) -- the operating point: 5 %% of the particles change cell every step")
     ap.add_argument("--rebin-check", type=int, default=4,
                     help="fused step: every K..8K steps look at the step times since the last re-bin; once the time lost to "
                          "particles that left their cell (sum of step time - best step time) exceeds the cost of a re-bin, the "
@@ -73,6 +75,15 @@ def parse():
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
     ap.add_argument("--checksum", action="store_true", help="print global sums of particle state after the run (N-rank vs 1-rank check)")
+    ap.add_argument("--compact", action="store_true",
+                    help="compact round-robin particle order + re-bin controller (round 1's storage) instead of the slotted storage "
+                         "the fused step keeps valid by itself (zpc_amd/csrc/mpm_slotted.hip)")
+    ap.add_argument("--slot-rounds", type=int, default=24, help="slotted storage: rounds (particle capacity) per cell, <= 32")
+    ap.add_argument("--outbox-cap", type=int, default=128, help="slotted storage: movers one 4^3-cell bin can send per step")
+    ap.add_argument("--margin", type=int, default=1,
+                    help="slotted storage: extra layers of grid blocks around the occupied ones (room to travel before a re-partition)")
+    ap.add_argument("--no-at-rest", action="store_true",
+                    help="skip the secondary at-rest measurement (a second, short run of this script with --drift 0,0,0)")
     return ap.parse_args()
 
 
@@ -165,6 +176,7 @@ def cpu_baseline(sample, dx, dt, model, side, vol):
 def main():
     a = parse()
     a.fused = not (a.unfused or a.unbinned or a.no_cache_stress)
+    a.slotted = a.fused and not a.compact and a.lane_width == 64
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,10 +213,10 @@ def main():
 
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
-    drift = [float(x) for x in a.drift.split(",")]
+    drift_v = [float(x) for x in a.drift.split(",")]
     for k in range(3):
-        if drift[k] != 0.0:
-            aos[:, 4 + k] += drift[k]
+        if drift_v[k] != 0.0:
+            aos[:, 4 + k] += drift_v[k]
     n_local = aos.shape[0]
     mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device,
                      cache_stress=not a.no_cache_stress)
@@ -216,7 +228,8 @@ def main():
     # ---- partition, block numbering, bins, halo lists (re-run after every re-partition)
     nc = a.side ** 3
     stage = {}
-    overlap = world > 1 and a.fused and not a.no_overlap
+    # (slotted storage: the mover kernel adds to boundary blocks after the main kernel, so the exchange follows both)
+    overlap = world > 1 and a.fused and not a.no_overlap and not a.slotted
     comm_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
     pol_comm = zpc_amd.rocm_exec().sync(False).external_stream(comm_stream.cuda_stream) if overlap else pol
     ev_boundary, ev_comm = torch.cuda.Event(), torch.cuda.Event()
@@ -253,7 +266,7 @@ def main():
         numbered first; bins; ghost-block lists"""
         nonlocal n_boundary
         from zpc_amd.dist import gather_block_keys, near_shared_mask
-        nb_ = mt.build_partition(max(4096, mt.n // 128))
+        nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0)
         all_keys = None
         if world > 1:
             all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
@@ -323,7 +336,7 @@ def main():
     def step_fused(timed, write_all=False, reorder=False):
         # grid holds the velocities of the current step (after grid_update): G2P from it, P2G of the next step into the
         # second (zeroed) grid, which then becomes the current one
-        track = timed or a.rebin_check > 0
+        track = timed or (a.rebin_check > 0 and not a.slotted)
         if track:
             e0, e1 = ev(), ev()
             e0.record()
@@ -369,12 +382,16 @@ def main():
         nonlocal halo, nblocks, migrated
         from zpc_amd.dist import migrate_particles
         moved = (0, 0)
+        if mt.slotted:
+            mt.unslot()   # occupied slots -> compact buffer (the step before a re-map stored v, C and the stress as well)
         if world > 1:
             to_c = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
             moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device))
         nblocks, halo = partition_and_halo()
         if a.fused:
             prime_grid()
+        if a.slotted:
+            mt.slot(K=a.slot_rounds, outbox_cap=a.outbox_cap)
         migrated += moved[0]
         return moved
 
@@ -382,6 +399,8 @@ def main():
         if a.unbinned or not mt.cache_stress:
             raise SystemExit("--fused needs the binned path with cached stress")
         prime_grid()
+        if a.slotted:
+            mt.slot(K=a.slot_rounds, outbox_cap=a.outbox_cap)
         unfused_step = step
         step = lambda timed, write_all=False, reorder=False: step_fused(timed, write_all, reorder)
 
@@ -415,7 +434,7 @@ def main():
                 remap()
                 ctrl_ev.clear()
                 best_ms, lost_ms = None, 0.0
-            elif a.fused and a.rebin_check > 0 and done >= next_check:
+            elif a.fused and not a.slotted and a.rebin_check > 0 and done >= next_check:
                 ctrl_ev[-1][1].synchronize()  # the look stalls the stream: done less often while nothing is being lost
                 for e0, e1 in ctrl_ev:
                     t = e0.elapsed_time(e1)
@@ -469,6 +488,13 @@ def main():
         raise SystemExit("rank %d: particles drifted more than one bin from their bins -- re-bin more often (--migrate-every) "
                          "or run with --no-overlap" % rank)
 
+    movers_per_step = None
+    if a.slotted:
+        try:
+            st = mt.check_slots()
+        except RuntimeError as e:
+            raise SystemExit("rank %d: %s -- raise --slot-rounds / --outbox-cap / --margin, or re-partition (--migrate-every)" % (rank, e))
+        movers_per_step = st[5] / max(a.steps + a.warmup, 1)
     if a.fused and mt.left_partition():
         # the reference does not check this either (P2G.hpp:109-110), but a benchmark that loses mass is not a benchmark
         raise SystemExit("rank %d: particles left the sparse-grid partition (contributions dropped) -- use --migrate-every K to "
@@ -485,8 +511,12 @@ def main():
     checksum = None
     if a.checksum:
         # order-independent global sums of the particle state (float64): equal for any number of ranks up to rounding
-        v = mt.buf.view(mt.tiles, mt.nchn, mt.L).double()
-        valid = (torch.arange(mt.tiles * mt.L, device=device) < n_local).view(mt.tiles, 1, mt.L)
+        cbuf, ctiles = mt.buf, mt.tiles
+        if mt.slotted:
+            cbuf, _ = mt._compact_copy()
+            ctiles = cbuf.numel() // (mt.nchn * mt.L)
+        v = cbuf.view(ctiles, mt.nchn, mt.L).double()
+        valid = (torch.arange(ctiles * mt.L, device=device) < n_local).view(ctiles, 1, mt.L)
         sums = (v * valid).sum(dim=(0, 2))
         sq = ((v * valid) ** 2).sum(dim=(0, 2))
         cs = torch.cat([sums, sq]).to(comm_dev)
@@ -529,7 +559,12 @@ def main():
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
-                       "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated},
+                       "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated,
+                       "drift_m_per_s": drift_v, "cells_per_step": max(abs(x) for x in drift_v) * dt / dx,
+                       "storage": ("slotted: bins x %d rounds x 64 lanes + per-cell occupancy masks; movers travel through per-bin outboxes "
+                                   "(%d records) and are pulled by their destination bin -- no re-bins in the time loop"
+                                   % (a.slot_rounds, a.outbox_cap)) if a.slotted else "compact round-robin order + re-bin controller",
+                       "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
@@ -556,13 +591,13 @@ def main():
                     pass
             out["config"]["workload"] = out["config"]["workload"].replace("step = grid reset + P2G + grid update + G2P",
                                                                           "step = grid reset + fused G2P2G (G2P of step n, P2G of step n+1) + grid update")
-            out["roofline"] = {"bound": "hbm", "kernel": "g2p2g_binned_kernel", "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline"] = {"bound": "hbm", "kernel": "g2p2g_slot_kernel + mover_pull_kernel" if a.slotted else "g2p2g_rs_kernel", "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": fach / HBM_PEAK_GBS, "traffic": ftraffic, "bytes_per_particle": fb,
                                "particles_per_launch": n_local, "launch_ms": fused_ms,
                                "fused_min_bytes_per_particle": fmin,
                                "note": "bytes_per_particle = SURVEY 8(d) P2G + G2P; the fused pass keeps v, C and the stress on chip "
-                                       "(traffic < algorithmic bytes) and is VALU-limited: SQ_INSTS_VALU x 4 cycles = 81 % of the SIMD "
-                                       "cycles (profiles/r01_pmc_g2p2g.md)"}
+                                       "(traffic < algorithmic bytes) and is bound by VALU issue, not by HBM (profiles/r02_pmc_g2p2g.md); "
+                                       "launch_ms = HIP-event time of the fused launches of one step (main kernel + mover kernel)"}
         # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
         # bytes over HIP-event time, after the timed region)
         try:
@@ -583,6 +618,19 @@ def main():
             pass
         if checksum is not None:
             out["checksum"] = checksum
+        if world == 1 and a.slotted and not a.no_at_rest and any(abs(x) > 0 for x in drift_v):
+            # secondary number: the same column at rest (no movers), a second short run of this script
+            import subprocess
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--drift", "0,0,0", "--no-at-rest", "--no-cpu-baseline", "--steps", "10",
+                       "--warmup", "3", "--grid", str(a.grid), "--cells", a.cells, "--model", a.model, "--side", str(a.side),
+                       "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin)]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                out["config"]["at_rest_ms_per_step"] = j["ms_per_step"]
+            except Exception as e:
+                out["config"]["at_rest_ms_per_step"] = None
+                print("at-rest run failed: %r" % (e,), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, dx, dt, model, a.side, vol)
         print(json.dumps(out), flush=True)

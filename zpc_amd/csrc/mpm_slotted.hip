@@ -206,14 +206,17 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             nc[d] = (int)fl - geo.org[d];
             lpn[d] = X - fl;
           }
+#ifdef ZS_SLOT_NOMOVER  // measurement build: what does the presence of the mover path cost a step without movers?
+          const bool moved = false;
+#else
           const bool moved = nc[0] != cx || nc[1] != cy || nc[2] != cz;
+#endif
           float *rec = nullptr;
           if (moved) {
             const int k = atomicAdd(outCount, 1);
             if (k < A.cap) {
               rec = A.moverRec + ((size_t)bin * A.cap + (size_t)k) * SL_REC;
               A.moverDest[(size_t)bin * A.cap + (size_t)k] = pack_cell(nc[0] + geo.org[0], nc[1] + geo.org[1], nc[2] + geo.org[2]);
-              rec[0] = cur.m;
 #pragma unroll
               for (int d = 0; d < 3; ++d) rec[1 + d] = pos[d];
 #pragma unroll
@@ -233,13 +236,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
               pstore<LW, 3>(ps.vel, o, vel);
               pstore<LW, 9>(ps.C, o, C);
             }
-            myStage[0 * 64 + lane] = cur.m;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
           }
           {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
             float lj = 0.f;
@@ -247,6 +243,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             model_stress<SMODEL>(mp.mat, lj, F, PF, C);
             if (moved) {
               if (rec) {
+                rec[0] = cur.m;  // (the mass is the last value of the record load: stored here, its wait does not hold up the stores above)
                 rec[13] = lj;
 #pragma unroll
                 for (int d = 0; d < 9; ++d) rec[26 + d] = PF[d];
@@ -257,7 +254,17 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             }
           }
           if (!moved) {
+            // staged AFTER the constitutive update, as in g2p2g_rs_producer: with m, x', v', C' dead before it the compiler
+            // reuses their registers for the SVD at once and waits for the particle stores just issued (s_waitcnt vmcnt(1)
+            // in front of the SVD: 2 ms per 64 Mi particles)
             valid = true;
+            myStage[0 * 64 + lane] = cur.m;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
 #pragma unroll
             for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
           }
@@ -340,16 +347,35 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
 
 // ------------------------------------------------------------------------------------------------------------------ mover kernel
 // One workgroup (4 waves = the 4 channel sets of ConsumerSet) per destination bin.
+// what channel set CS needs of a record: position, mass / v_d / C column entries (or P F^T entries)
+template <int CS> struct MoverFields {
+  using S = ConsumerSet<CS>;
+  float pos[3], m, c0[S::NV], c1[S::NV], c2[S::NV], v[S::NV];
+  __device__ __forceinline__ void load(const float *rec) {
+    constexpr int cb = S::STRESS ? 26 : 17;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos[d] = rec[1 + d];
+    m = S::STRESS ? 0.f : rec[0];
+#pragma unroll
+    for (int j = 0; j < S::NV; ++j) {
+      const int d = S::D0 + j;
+      c0[j] = rec[cb + d];
+      c1[j] = rec[cb + 3 + d];
+      c2[j] = rec[cb + 6 + d];
+      v[j] = S::STRESS ? 0.f : rec[14 + d];
+    }
+  }
+};
 template <int CS>
-__device__ __forceinline__ void mover_accumulate(const MpmDev &mp, const float *rec, const int (&org)[3], int cx, int cy, int cz, float kscale,
-                                                 float (&acc)[27][ConsumerSet<CS>::NA]) {
+__device__ __forceinline__ void mover_accumulate(const MpmDev &mp, const MoverFields<CS> &f, const int (&org)[3], int cx, int cy, int cz,
+                                                 float kscale, float (&acc)[27][ConsumerSet<CS>::NA]) {
   using S = ConsumerSet<CS>;
   const float dxi = 1.0f / mp.dx;
   Arena ar;
   const int cc[3] = {cx, cy, cz};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {  // the record's position lies in this lane's cell: same arithmetic as the main kernel's staging
-    const float X = rec[1 + d] * dxi;
+    const float X = f.pos[d] * dxi;
     const float fl = (float)(org[d] + cc[d]);
     const float d0 = X - fl;
     ar.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
@@ -359,34 +385,27 @@ __device__ __forceinline__ void mover_accumulate(const MpmDev &mp, const float *
     ar.w[d][2] = 0.5f * zz * zz;
     ar.lp[d] = d0 * mp.dx;
   }
-  constexpr int cb = S::STRESS ? 26 : 17;
-  const float scale = S::STRESS ? kscale : rec[0];
-  float wzs[3], Pz[S::NV][3], c0[S::NV], c1[S::NV];
+  const float scale = S::STRESS ? kscale : f.m;
+  float wzs[3], Pz[S::NV][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
 #pragma unroll
-  for (int j = 0; j < S::NV; ++j) {
-    const int d = S::D0 + j;
-    c0[j] = rec[cb + d];
-    c1[j] = rec[cb + 3 + d];
-    const float c2 = rec[cb + 6 + d];
-    const float v = S::STRESS ? 0.f : rec[14 + d];
+  for (int j = 0; j < S::NV; ++j)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(c2, (float)k * mp.dx - ar.lp[2], v);
-  }
+    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(f.c2[j], (float)k * mp.dx - ar.lp[2], f.v[j]);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float x0 = (float)a * mp.dx - ar.lp[0];
     float Pxa[S::NV];
 #pragma unroll
-    for (int j = 0; j < S::NV; ++j) Pxa[j] = c0[j] * x0;
+    for (int j = 0; j < S::NV; ++j) Pxa[j] = f.c0[j] * x0;
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
       const float x1 = (float)bb * mp.dx - ar.lp[1];
       const float wxy = ar.w[0][a] * ar.w[1][bb];
       float q[S::NV];
 #pragma unroll
-      for (int j = 0; j < S::NV; ++j) q[j] = fmaf(c1[j], x1, Pxa[j]);
+      for (int j = 0; j < S::NV; ++j) q[j] = fmaf(f.c1[j], x1, Pxa[j]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float Ws = wxy * wzs[c];
@@ -399,12 +418,16 @@ __device__ __forceinline__ void mover_accumulate(const MpmDev &mp, const float *
   }
 }
 
+// wave CS of a destination bin: its channel set of every arrival; the lightest set (CS == 3: one channel) also gives the arrivals
+// their new home (lowest free round of the cell that was free BEFORE this step's departures).  Records are fetched one round ahead.
 template <int SIDE, int CS, bool FLUID, bool DP, bool WRITE_ALL>
 __device__ __forceinline__ void mover_role(const MpmDev &mp, const ParticlesDev &ps, const SlotArgs &A, int bin, const int (&org)[3], int lane,
                                            int rounds, const int *inboxCount, const int (*inbox)[SL_MAXIN], float *parena) {
   using S = ConsumerSet<CS>;
   using AL = ArenaLds;
   constexpr int LW = 64;
+  constexpr bool REHOME = CS == 3;
+  constexpr int NH = WRITE_ALL ? 35 : 14;  // floats of the record the new home needs: m, x, F, logJp (, v, C, P F^T)
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const float dxi = 1.0f / mp.dx;
   const float kscale = -mp.dt * (4.f * dxi * dxi);
@@ -415,12 +438,23 @@ __device__ __forceinline__ void mover_role(const MpmDev &mp, const ParticlesDev 
     for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
   const int mine = inboxCount[lane] < SL_MAXIN ? inboxCount[lane] : SL_MAXIN;
   unsigned m = 0u;
-  if constexpr (CS == 0) m = A.cellMask[(size_t)bin * 64 + lane];
+  if constexpr (REHOME) m = A.cellMask[(size_t)bin * 64 + lane];
+  MoverFields<CS> cur, nxt;
+  float hcur[REHOME ? NH : 1], hnxt[REHOME ? NH : 1];
+  auto fetch = [&](int r, MoverFields<CS> &f, float (&h)[REHOME ? NH : 1]) {
+    const float *rec = A.moverRec + (size_t)inbox[lane][r] * SL_REC;
+    f.load(rec);
+    if constexpr (REHOME) {
+#pragma unroll
+      for (int d = 0; d < NH; ++d) h[d] = rec[d];
+    }
+  };
+  if (mine > 0) fetch(0, cur, hcur);
   for (int r = 0; r < rounds; ++r) {
+    if (r + 1 < mine) fetch(r + 1, nxt, hnxt);
     if (r < mine) {
-      const float *rec = A.moverRec + (size_t)inbox[lane][r] * SL_REC;
-      mover_accumulate<CS>(mp, rec, org, cx, cy, cz, kscale, acc);
-      if constexpr (CS == 0) {  // wave 0 also gives the particle its new home: the lowest free round of the cell
+      mover_accumulate<CS>(mp, cur, org, cx, cy, cz, kscale, acc);
+      if constexpr (REHOME) {
         const unsigned freeBits = ~m & (A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u));
         if (freeBits == 0u) {
           A.status[1] = 1;  // cell full
@@ -431,19 +465,19 @@ __device__ __forceinline__ void mover_role(const MpmDev &mp, const ParticlesDev 
           const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
           float x[3], F[9];
 #pragma unroll
-          for (int d = 0; d < 3; ++d) x[d] = rec[1 + d];
+          for (int d = 0; d < 3; ++d) x[d] = hcur[1 + d];
 #pragma unroll
-          for (int d = 0; d < 9; ++d) F[d] = rec[4 + d];
-          pstore1<LW>(ps.mass, o, rec[0]);
+          for (int d = 0; d < 9; ++d) F[d] = hcur[4 + d];
+          pstore1<LW>(ps.mass, o, hcur[0]);
           pstore<LW, 3>(ps.pos, o, x);
           pstore_state<LW, FLUID>(ps.F, o, F);
-          if constexpr (DP) pstore1<LW>(ps.logJp, o, rec[13]);
-          if (WRITE_ALL) {
+          if constexpr (DP) pstore1<LW>(ps.logJp, o, hcur[13]);
+          if constexpr (WRITE_ALL) {
             float v[3], C[9], PF[9];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) v[d] = rec[14 + d];
+            for (int d = 0; d < 3; ++d) v[d] = hcur[14 + d];
 #pragma unroll
-            for (int d = 0; d < 9; ++d) { C[d] = rec[17 + d]; PF[d] = rec[26 + d]; }
+            for (int d = 0; d < 9; ++d) { C[d] = hcur[17 + d]; PF[d] = hcur[26 + d]; }
             pstore<LW, 3>(ps.vel, o, v);
             pstore<LW, 9>(ps.C, o, C);
             pstore<LW, 9>(ps.stress, o, PF);
@@ -451,8 +485,13 @@ __device__ __forceinline__ void mover_role(const MpmDev &mp, const ParticlesDev 
         }
       }
     }
+    cur = nxt;
+    if constexpr (REHOME) {
+#pragma unroll
+      for (int d = 0; d < NH; ++d) hcur[d] = hnxt[d];
+    }
   }
-  if constexpr (CS == 0) {
+  if constexpr (REHOME) {
     if (mine > 0) A.cellMask[(size_t)bin * 64 + lane] = m;
   }
   float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
@@ -475,6 +514,7 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
   __shared__ int inbox[64][SL_MAXIN];
   __shared__ int srcBin[27];
   __shared__ int srcCnt[27];
+  __shared__ int srcOff[28];
   __shared__ int total;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int bin = blockIdx.x + A.binBase;
@@ -489,17 +529,16 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
       sb = A.nbr27[(size_t)geo.block * 27 + tid];
     } else {
       const int sub = bin % BPB;
-      int s[3] = {((sub >> 2) & 1) + dd[0], ((sub >> 1) & 1) + dd[1], (sub & 1) + dd[2]};
+      int sx[3] = {((sub >> 2) & 1) + dd[0], ((sub >> 1) & 1) + dd[1], (sub & 1) + dd[2]};
       int bo[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        bo[d] = s[d] < 0 ? -1 : (s[d] > 1 ? 1 : 0);
-        s[d] &= 1;
+        bo[d] = sx[d] < 0 ? -1 : (sx[d] > 1 ? 1 : 0);
+        sx[d] &= 1;
       }
       const int nb = A.nbr27[(size_t)geo.block * 27 + ((bo[0] + 1) * 9 + (bo[1] + 1) * 3 + (bo[2] + 1))];
-      sb = nb < 0 ? -1 : nb * BPB + ((s[0] * 2 + s[1]) * 2 + s[2]);
+      sb = nb < 0 ? -1 : nb * BPB + ((sx[0] * 2 + sx[1]) * 2 + sx[2]);
     }
-    // only bins of this launch's table are valid sources; the outbox counters of every bin are written by the main kernel
     int c = 0;
     if (sb >= 0) c = A.moverCount[sb];
     srcBin[tid] = sb;
@@ -508,20 +547,31 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
   }
   __syncthreads();
   if (total == 0) return;  // nothing addressed to anybody around here (uniform)
-  for (int k = tid; k < 7 * AL::CH; k += 256) parena[k] = 0.f;
-  for (int sidx = 0; sidx < 27; ++sidx) {
-    const int c = srcCnt[sidx];
-    const int sb = srcBin[sidx];
-    for (int k = tid; k < c; k += 256) {
-      int x, y, z;
-      unpack_cell(A.moverDest[(size_t)sb * A.cap + (size_t)k], x, y, z);
-      const int rx = x - geo.org[0], ry = y - geo.org[1], rz = z - geo.org[2];
-      if ((unsigned)rx < 4u && (unsigned)ry < 4u && (unsigned)rz < 4u) {
-        const int l2 = (rx * 4 + ry) * 4 + rz;
-        const int slot = atomicAdd(&inboxCount[l2], 1);
-        if (slot < SL_MAXIN) inbox[l2][slot] = sb * A.cap + k;
-        else A.status[3] = 1;
-      }
+  // every record of the 27 outboxes is looked at by one thread; all destination loads of the workgroup are in flight together
+  // (a loop over the outboxes pays 27 memory latencies in a row: 2.8 -> 2.0 ms; fetching the first 32 destinations of every
+  // outbox together with its count, to save the second latency, costs more in wasted reads than it gains: 2.25 ms)
+  if (tid == 0) {
+    int o = 0;
+    for (int k = 0; k < 27; ++k) {
+      srcOff[k] = o;
+      o += srcCnt[k];
+    }
+    srcOff[27] = o;
+  }
+  __syncthreads();
+  const int tot = srcOff[27];
+  for (int tt = tid; tt < tot; tt += 256) {
+    int sidx = 0;
+    while (tt >= srcOff[sidx + 1]) ++sidx;
+    const int k = tt - srcOff[sidx], sb = srcBin[sidx];
+    int x, y, z;
+    unpack_cell(A.moverDest[(size_t)sb * A.cap + (size_t)k], x, y, z);
+    const int rx = x - geo.org[0], ry = y - geo.org[1], rz = z - geo.org[2];
+    if ((unsigned)rx < 4u && (unsigned)ry < 4u && (unsigned)rz < 4u) {
+      const int l2 = (rx * 4 + ry) * 4 + rz;
+      const int slot = atomicAdd(&inboxCount[l2], 1);
+      if (slot < SL_MAXIN) inbox[l2][slot] = sb * A.cap + k;
+      else A.status[3] = 1;
     }
   }
   __syncthreads();
@@ -534,8 +584,10 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
     got += __shfl_xor(got, sft, 64);
   }
   if (rounds > SL_MAXIN) rounds = SL_MAXIN;
-  if (rounds == 0) return;  // movers around, none for this bin (uniform)
+  if (rounds == 0) return;  // nothing addressed to this bin (uniform)
   if (tid == 0) atomicAdd(&A.status[6], got);
+  for (int k = tid; k < 7 * AL::CH; k += 256) parena[k] = 0.f;
+  __syncthreads();
   if (w == 0) mover_role<SIDE, 0, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
   else if (w == 1) mover_role<SIDE, 1, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
   else if (w == 2) mover_role<SIDE, 2, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);

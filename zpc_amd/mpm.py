@@ -188,7 +188,7 @@ class MpmTransfer:
             self._zero(self.drift_flag)
 
     # ------------------------------------------------------------------ slotted storage (zpc_amd/csrc/mpm_slotted.hip)
-    def slot(self, K=16, outbox_cap=96):
+    def slot(self, K=24, outbox_cap=128):
         """compact particle buffer -> slotted storage (bins x K rounds x 64 lanes, one tile row per (bin, round)): the form the
         fused step keeps valid by itself while particles move (no re-bins).  Needs the partition; lane width 64."""
         assert self.L == 64 and not self.aos and self.table is not None and not self.slotted
