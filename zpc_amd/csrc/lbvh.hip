@@ -96,16 +96,10 @@ __global__ void lbvh_box_final_kernel(const float *partial, int nblocks, float *
   for (int b = 1; b < nblocks; ++b) r = c < 3 ? fminf(r, partial[(size_t)b * 6 + c]) : fmaxf(r, partial[(size_t)b * 6 + c]);
   out[c] = r;
 }
-// _build_init_mc_id + _build_init_depths
-__global__ __launch_bounds__(256) void lbvh_morton_kernel(const AABB3 *bvs, int n, const float *whole, unsigned *mcs, int *indices,
-                                                          unsigned *lDepths) {
+// morton code of every box centre in the unit cube of the whole box (what zs::LBvh's build computes, Bvh.hpp:177-188)
+__global__ __launch_bounds__(256) void lbvh_morton_kernel(const AABB3 *bvs, int n, const float *whole, unsigned *mcs, int *indices) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  if (i == n) {
-    lDepths[n] = 0;
-    return;
-  }
-  lDepths[i] = 1;
+  if (i >= n) return;
   const AABB3 b = bvs[i];
   unsigned code = 0;
 #pragma unroll
@@ -120,104 +114,132 @@ __global__ __launch_bounds__(256) void lbvh_morton_kernel(const AABB3 *bvs, int 
   mcs[i] = code;
   indices[i] = i;
 }
-// _build_build_topo (Bvh.hpp:200-287), one lane per trunk node
-__global__ __launch_bounds__(256) void lbvh_topo_kernel(const unsigned *mcs, int numTrunk, int *tPars, int *tLs, int *tRs, int *lPars,
-                                                        unsigned *lDepths) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= numTrunk) return;
-  const int numLeaves = numTrunk + 1;
-  int i = 0, j = 0;
-  if (idx == 0) {
-    j = numLeaves - 1;
+// ---------------------------------------------------------------------------------------------------------------- topology + layout
+// Built from Karras' construction ("Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012) over
+// ONE ordering function instead of per-case code, and laid out by walking left spines DOWN from their heads; the arrays that come
+// out (pre-order nodes, parents, levels, escape indices, leaf positions) are those of zs::LBvh (container/Bvh.hpp:86-175), which the
+// tests compare bit for bit.
+//
+// plen(a, b), a < b: length of the common prefix of the sorted codes a and b -- with equal codes ranked ABOVE every real prefix and
+// increasing with a (33 + a).  Adjacent equal codes therefore form a strictly increasing sequence, whose Cartesian tree is the
+// right-leaning chain zs::LBvh builds over a run of duplicates (Karras' own tie-break, 32 + clz(a ^ b), would balance the run
+// instead).  Outside [0, n) the length is -1.
+__device__ __forceinline__ int lbvh_plen(const unsigned *codes, int n, int a, int b) {
+  if (a < 0 || b < 0 || a >= n || b >= n) return -1;
+  const int lo = a < b ? a : b;
+  const unsigned x = codes[a] ^ codes[b];
+  return x ? __clz((int)x) : 33 + lo;
+}
+// One lane per internal ("trunk") node k in Karras' numbering: the node sits at one end of its leaf range, on the side of the
+// neighbour it shares the longer prefix with.  Outputs: the range [first, last], the parent link of both children, and whether a
+// trunk child is a RIGHT child (= the head of a left spine).
+__global__ __launch_bounds__(256) void lbvh_ranges_kernel(const unsigned *codes, int nLeaves, int *rangeFirst, int *rangeLast, int *leftTrunk,
+                                                          int *trunkParent, int *leafParent, unsigned char *spineHead) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nTrunk = nLeaves - 1;
+  if (k >= nTrunk) return;
+  int first, last;
+  if (k == 0) {
+    first = 0;
+    last = nLeaves - 1;
   } else {
-    const int left = idx;
-    int right = idx;
-    const unsigned pre = mcs[idx - 1], cur = mcs[idx], nxt = mcs[idx + 1];
-    if (pre == cur && cur == nxt) {
-      for (++right; right < numLeaves - 1; ++right)
-        if (mcs[right] != mcs[right + 1]) break;
-      j = right;
-      i = left;
-    } else {
-      const unsigned lLZ = count_lz(pre ^ cur), rLZ = count_lz(nxt ^ cur);
-      const int dir = lLZ > rLZ ? -1 : 1;
-      const unsigned minLZ = lLZ > rLZ ? rLZ : lLZ;
-      int step;
-      for (step = 2;; step <<= 1) {
-        right = left + step * dir;
-        if (!(right < numLeaves && right >= 0 && count_lz(mcs[right] ^ cur) > minLZ)) break;
-      }
-      int len = 0;
-      for (step >>= 1; step >= 1; step >>= 1) {
-        right = left + (len + step) * dir;
-        if (right < numLeaves && right >= 0)
-          if (count_lz(mcs[right] ^ cur) > minLZ) len += step;
-      }
-      if (dir == 1) { i = left; j = left + len; } else { i = left - len; j = left; }
-    }
-  }
-  atomicAdd(&lDepths[i], 1u);
-  tLs[idx] = i;
-  tRs[idx] = j;
-  int gamma;
-  const unsigned lCode = mcs[i], rCode = mcs[j];
-  if (lCode == rCode)
-    gamma = i;
-  else {
-    const unsigned LZ = count_lz(lCode ^ rCode);
+    const int toRight = lbvh_plen(codes, nLeaves, k, k + 1), toLeft = lbvh_plen(codes, nLeaves, k - 1, k);
+    const int dir = toLeft > toRight ? -1 : 1;  // (two neighbours never share the same length: sorted codes, ranked ties)
+    const int floorLen = toLeft > toRight ? toRight : toLeft;  // everything in the range shares MORE than this with k
+    // gallop to an upper bound of the range length, then bisect
+    int reach = 2;
+    while (lbvh_plen(codes, nLeaves, k, k + reach * dir) > floorLen) reach <<= 1;
     int len = 0;
-    for (int step = (j - i + 1) >> 1;; step = (step + 1) >> 1) {
-      if (i + len + step <= numTrunk)
-        if (count_lz(mcs[i + len + step] ^ lCode) > LZ) len += step;
-      if (step <= 1) break;
+    for (int t = reach >> 1; t > 0; t >>= 1)
+      if (lbvh_plen(codes, nLeaves, k, k + (len + t) * dir) > floorLen) len += t;
+    const int other = k + len * dir;
+    first = dir > 0 ? k : other;
+    last = dir > 0 ? other : k;
+  }
+  rangeFirst[k] = first;
+  rangeLast[k] = last;
+  // split: the last leaf that shares more with `first` than the whole range does
+  const int nodeLen = lbvh_plen(codes, nLeaves, first, last);
+  int cut = 0;
+  for (int t = (last - first + 1) >> 1;; t = (t + 1) >> 1) {
+    if (first + cut + t < last && lbvh_plen(codes, nLeaves, first, first + cut + t) > nodeLen) cut += t;
+    if (t <= 1) break;
+  }
+  // children: [first, split] and [split + 1, last].  A one-leaf child is the leaf itself; a longer left half is trunk node `split`
+  // (it sits at the END of its range), a longer right half trunk node `split + 1` (at the START of its range)
+  const int split = first + cut;
+  leftTrunk[k] = split == first ? -1 : split;
+  if (split == first) leafParent[split] = k;
+  else trunkParent[split] = k;
+  if (split + 1 == last) leafParent[last] = k;
+  else {
+    trunkParent[split + 1] = k;
+    spineHead[split + 1] = 1;  // a right child starts a new left spine
+  }
+  if (k == 0) {
+    trunkParent[0] = -1;
+    spineHead[0] = 1;
+  }
+}
+// A left spine = the trunk nodes that share their first leaf, from the head (the root or a right child) down through left children.
+// In pre-order they occupy consecutive positions right in front of that leaf.  Pass 1 (count): the head walks its spine and writes its
+// length to spineLen[first leaf] (one writer per leaf: no atomics).  Pass 2 (place): with the exclusive scan `slot` of (spineLen + 1)
+// the head walks again: the r-th node of the spine gets position slot[first] + r and level (length - r).
+template <bool PLACE>
+__global__ __launch_bounds__(256) void lbvh_spine_kernel(int nLeaves, const int *rangeFirst, const int *leftTrunk, const unsigned char *spineHead,
+                                                         unsigned *spineLen, const unsigned *slot, int *trunkPos, int *levels) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nTrunk = nLeaves - 1;
+  if (k >= nTrunk || !spineHead[k]) return;
+  const int first = rangeFirst[k];
+  if (!PLACE) {
+    unsigned len = 0;
+    for (int node = k;;) {
+      ++len;
+      const int cand = leftTrunk[node];
+      if (cand < 0) break;
+      node = cand;
     }
-    gamma = i + len;
+    spineLen[first] = len;
+  } else {
+    const unsigned len = spineLen[first];
+    const unsigned base = slot[first];
+    unsigned r = 0;
+    for (int node = k;; ++r) {
+      trunkPos[node] = (int)(base + r);
+      levels[base + r] = (int)(len - r);
+      const int cand = leftTrunk[node];
+      if (cand < 0) break;
+      node = cand;
+    }
   }
-  // children: trunk children are named by their index, leaf children by index + numTrunk (only the parent links are kept:
-  // the pre-order layout makes the child arrays of the reference redundant)
-  if (i == gamma) lPars[gamma] = idx; else tPars[gamma] = idx;
-  if (j == gamma + 1) lPars[gamma + 1] = idx; else tPars[gamma + 1] = idx;
-  if (idx == 0) tPars[0] = -1;
 }
-// _build_supp_topo (Bvh.hpp:288-303)
-__global__ __launch_bounds__(256) void lbvh_supp_topo_kernel(int numLeaves, int *levels, const unsigned *lOffsets, const int *lPars,
-                                                             int *lLcas, const int *tPars, int *tDst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= numLeaves) return;
-  const int numTrunk = numLeaves - 1;
-  int depth = (int)(lOffsets[idx + 1] - lOffsets[idx]);
-  int dst = (int)lOffsets[idx + 1] - 2;
-  int node = lPars[idx], ch = idx + numTrunk, level = 0;
-  for (; --depth; node = tPars[node], --dst) {
-    tDst[node] = dst;
-    levels[dst] = ++level;
-    ch = node;
+// pre-order records: position of every node, its parent's position, escape index (the node that follows the subtree in pre-order =
+// the first node of the spine in front of leaf last + 1, i.e. slot[last + 1]) or the primitive index of a leaf
+__global__ __launch_bounds__(256) void lbvh_emit_kernel(int nLeaves, const int *rangeLast, const int *trunkParent, const int *leafParent,
+                                                        const int *trunkPos, const unsigned *slot, const unsigned *spineLen, const int *sortedPrim,
+                                                        int *auxIndices, int *parents, int *levels, int *leafInds) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nTrunk = nLeaves - 1;
+  if (g < nTrunk) {
+    const int pos = trunkPos[g];
+    const int last = rangeLast[g];
+    auxIndices[pos] = last == nTrunk ? -1 : (int)slot[last + 1];
+    const int par = trunkParent[g];
+    parents[pos] = par < 0 ? -1 : trunkPos[par];
+  } else if (g < nTrunk + nLeaves) {
+    const int leaf = g - nTrunk;
+    const int pos = (int)(slot[leaf] + spineLen[leaf]);
+    auxIndices[pos] = sortedPrim[leaf];
+    parents[pos] = trunkPos[leafParent[leaf]];
+    levels[pos] = 0;
+    leafInds[leaf] = pos;
   }
-  lLcas[idx] = ch;
 }
-// _build_reorder_leaf (Bvh.hpp:304-319)
-__global__ __launch_bounds__(256) void lbvh_reorder_leaf_kernel(int numLeaves, const unsigned *lOffsets, const int *lPars, int *auxIndices,
-                                                                int *parents, int *levels, const int *pInds, int *lInds, const int *tDst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= numLeaves) return;
-  const int dst = (int)lOffsets[idx + 1] - 1;
-  auxIndices[dst] = pInds[idx];
-  parents[dst] = tDst[lPars[idx]];
-  levels[dst] = 0;
-  lInds[idx] = dst;
-}
-// _build_reorder_trunk (Bvh.hpp:320-338)
-__global__ __launch_bounds__(256) void lbvh_reorder_trunk_kernel(int numTrunk, const int *lLcas, const unsigned *lOffsets, int *auxIndices,
-                                                                 int *parents, const int *tRs, const int *tPars, const int *tDst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= numTrunk) return;
-  const int dst = tDst[idx], r = tRs[idx];
-  if (r != numTrunk) {
-    const int lca = lLcas[r + 1];
-    auxIndices[dst] = lca < numTrunk ? tDst[lca] : (int)lOffsets[r + 1];
-  } else
-    auxIndices[dst] = -1;
-  parents[dst] = idx != 0 ? tDst[tPars[idx]] : -1;
+__global__ __launch_bounds__(256) void lbvh_spine_depths_kernel(int nLeaves, const unsigned *spineLen, unsigned *depth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nLeaves) depth[i] = spineLen[i] + 1u;
+  else if (i == nLeaves) depth[i] = 0u;
 }
 // agent-scope box accesses (sc1: served at the device coherence point, never from a CU- or XCD-local cache line), so the
 // bottom-up walk needs no __threadfence (on gfx950 a device fence writes back / invalidates L2: measured 94 ms per refit
@@ -499,20 +521,27 @@ void zs_rocm_lbvh_build(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primB
   float *partial = (float *)L.temp(sizeof(float) * 6 * rb), *whole = (float *)L.temp(sizeof(float) * 8);
   unsigned *mcs = (unsigned *)L.temp(sizeof(unsigned) * n), *sortedMcs = (unsigned *)L.temp(sizeof(unsigned) * n);
   int *indices = (int *)L.temp(sizeof(int) * n), *pInds = (int *)L.temp(sizeof(int) * n);
-  unsigned *lDepths = (unsigned *)L.temp(sizeof(unsigned) * (n + 1)), *lOffsets = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
-  int *tPars = (int *)L.temp(sizeof(int) * n), *tLs = (int *)L.temp(sizeof(int) * n), *tRs = (int *)L.temp(sizeof(int) * n);
-  int *tDst = (int *)L.temp(sizeof(int) * n), *lPars = (int *)L.temp(sizeof(int) * n), *lLcas = (int *)L.temp(sizeof(int) * n);
+  unsigned *spineLen = (unsigned *)L.temp(sizeof(unsigned) * (n + 1)), *depth = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
+  unsigned *slot = (unsigned *)L.temp(sizeof(unsigned) * (n + 1));
+  int *rangeFirst = (int *)L.temp(sizeof(int) * n), *rangeLast = (int *)L.temp(sizeof(int) * n), *leftTrunk = (int *)L.temp(sizeof(int) * n);
+  int *trunkParent = (int *)L.temp(sizeof(int) * n), *leafParent = (int *)L.temp(sizeof(int) * n), *trunkPos = (int *)L.temp(sizeof(int) * n);
+  unsigned char *spineHead = (unsigned char *)L.temp(n);
   hipLaunchKernelGGL(lbvh_box_reduce_kernel, dim3(rb), dim3(BOX_BLOCK), 0, L.stream, primBvs, n, partial, 1);
   hipLaunchKernelGGL(lbvh_box_final_kernel, dim3(1), dim3(64), 0, L.stream, partial, rb, whole);
-  hipLaunchKernelGGL(lbvh_morton_kernel, dim3(ceil_div(n + 1, 256)), dim3(256), 0, L.stream, primBvs, numLeaves, whole, mcs, indices, lDepths);
+  hipLaunchKernelGGL(lbvh_morton_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, primBvs, numLeaves, whole, mcs, indices);
   radix_sort_pair_u32(L, mcs, indices, sortedMcs, pInds, n, 0, 32);
-  hipLaunchKernelGGL(lbvh_topo_kernel, dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, sortedMcs, numTrunk, tPars, tLs, tRs, lPars, lDepths);
-  exclusive_scan_u32(L, lDepths, n + 1, lOffsets);
-  hipLaunchKernelGGL(lbvh_supp_topo_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, numLeaves, b->levels, lOffsets, lPars, lLcas, tPars, tDst);
-  hipLaunchKernelGGL(lbvh_reorder_leaf_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, numLeaves, lOffsets, lPars, b->auxIndices,
-                     b->parents, b->levels, pInds, b->leafInds, tDst);
-  hipLaunchKernelGGL(lbvh_reorder_trunk_kernel, dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, numTrunk, lLcas, lOffsets, b->auxIndices,
-                     b->parents, tRs, tPars, tDst);
+  ZSR_CHECK(hipMemsetAsync(spineHead, 0, n, L.stream));
+  ZSR_CHECK(hipMemsetAsync(spineLen, 0, sizeof(unsigned) * (n + 1), L.stream));
+  hipLaunchKernelGGL(lbvh_ranges_kernel, dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, sortedMcs, numLeaves, rangeFirst, rangeLast, leftTrunk,
+                     trunkParent, leafParent, spineHead);
+  hipLaunchKernelGGL((lbvh_spine_kernel<false>), dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, numLeaves, rangeFirst, leftTrunk, spineHead,
+                     spineLen, (const unsigned *)nullptr, (int *)nullptr, (int *)nullptr);
+  hipLaunchKernelGGL(lbvh_spine_depths_kernel, dim3(ceil_div(n + 1, 256)), dim3(256), 0, L.stream, numLeaves, spineLen, depth);
+  exclusive_scan_u32(L, depth, n + 1, slot);
+  hipLaunchKernelGGL((lbvh_spine_kernel<true>), dim3(ceil_div(numTrunk, 256)), dim3(256), 0, L.stream, numLeaves, rangeFirst, leftTrunk, spineHead,
+                     spineLen, (const unsigned *)slot, trunkPos, b->levels);
+  hipLaunchKernelGGL(lbvh_emit_kernel, dim3(ceil_div(2 * n, 256)), dim3(256), 0, L.stream, numLeaves, rangeLast, trunkParent, leafParent, trunkPos,
+                     (const unsigned *)slot, (const unsigned *)spineLen, (const int *)pInds, b->auxIndices, b->parents, b->levels, b->leafInds);
   if (refit) lbvh_refit_impl(L, *b, primBvs);
 }
 int zs_rocm_lbvh_refit(zs_rocm_policy *pol, zs_rocm_lbvh *b, const float *primBvs, size_t n) {
