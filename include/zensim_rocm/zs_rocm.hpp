@@ -155,6 +155,26 @@ namespace detail {
   template <> struct c_name<double> { static constexpr int id = 2; };
 }  // namespace detail
 
+// memory locations and allocators (resource/Resource.h:29-146, 199-245; types/Property.h): a container is built as
+// Container{allocator, n}; get_memory_source(memsrc, devid) names plain device / unified / host memory,
+// get_temporary_memory_source(pol) the stream-ordered scratch of a policy's stream
+struct MemoryLocation {
+  memsrc_e _memsrc = memsrc_e::device;
+  ProcID _devid = 0;
+  constexpr memsrc_e memspace() const { return _memsrc; }
+  constexpr ProcID devid() const { return _devid; }
+};
+struct ZSPmrAllocator {
+  MemoryLocation location{};
+};
+inline ZSPmrAllocator get_memory_source(memsrc_e mre, ProcID devid = 0) { return {MemoryLocation{mre, devid}}; }
+// get_temporary_memory_source(pol) (resource/Resource.h:52-58 -> temporary_memory_resource<device_mem_tag>, cuda/memory/Allocator.h:33-50):
+// stream-ordered allocate / deallocate on the policy's stream; a block stays valid until deallocate and never aliases another live one
+struct TemporaryMemorySource {
+  zs_rocm_policy *_h;
+  void *allocate(std::size_t bytes, std::size_t = 256) const { return zs_rocm_policy_temporary(_h, bytes); }
+  void deallocate(void *p, std::size_t, std::size_t = 256) const { zs_rocm_policy_temporary_free(_h, p); }
+};
 // zs::Vector<T> (container/Vector.hpp:11-421) for device / um memory; T in {int, float, double} own their storage through
 // the C ABI, any other trivially copyable T through hipMalloc directly.
 template <class T> struct Vector {
@@ -167,13 +187,27 @@ template <class T> struct Vector {
     }
     (void)devid;
   }
+  // Vector{allocator, n} (Vector.hpp:47-60)
+  Vector(const ZSPmrAllocator &a, std::size_t n) : Vector(n, a.location.memspace(), a.location.devid()) {}
+  Vector(const MemoryLocation &l, std::size_t n) : Vector(n, l.memspace(), l.devid()) {}
+  Vector(const TemporaryMemorySource &a, std::size_t n) : _size(n), _cap(n), _mre(memsrc_e::device), _tmp(a._h) {
+    if (n) _data = (T *)zs_rocm_policy_temporary(a._h, n * sizeof(T));
+  }
   ~Vector() { release(); }
   Vector(const Vector &o) : Vector(o._size, o._mre) {
     if (_size) (void)hipMemcpy(_data, o._data, _size * sizeof(T), hipMemcpyDefault);
   }
   Vector(Vector &&o) noexcept { swap(o); }
   Vector &operator=(Vector o) { swap(o); return *this; }
-  void swap(Vector &o) { std::swap(_data, o._data); std::swap(_size, o._size); std::swap(_cap, o._cap); std::swap(_mre, o._mre); }
+  void swap(Vector &o) {
+    std::swap(_data, o._data); std::swap(_size, o._size); std::swap(_cap, o._cap); std::swap(_mre, o._mre); std::swap(_tmp, o._tmp);
+  }
+  // element access on the host side: host / unified memory only (device vectors go through getVal / setVal)
+  T &operator[](std::size_t i) { return _data[i]; }
+  const T &operator[](std::size_t i) const { return _data[i]; }
+  const T *begin() const { return _data; }
+  const T *end() const { return _data + _size; }
+  Vector clone(const MemoryLocation &l) const { return clone(l.memspace()); }
   std::size_t size() const { return _size; }
   std::size_t capacity() const { return _cap; }
   T *data() { return _data; }
@@ -213,13 +247,15 @@ template <class T> struct Vector {
 private:
   void release() {
     if (!_data) return;
-    if (_mre == memsrc_e::host) std::free(_data);
+    if (_tmp) zs_rocm_policy_temporary_free(_tmp, _data);
+    else if (_mre == memsrc_e::host) std::free(_data);
     else (void)hipFree(_data);
     _data = nullptr;
   }
   T *_data = nullptr;
   std::size_t _size = 0, _cap = 0;
   memsrc_e _mre = memsrc_e::device;
+  zs_rocm_policy *_tmp = nullptr;  // set: stream-ordered temporary of that policy (get_temporary_memory_source)
 };
 template <class T> struct VectorView {
   T *_p;
@@ -228,6 +264,86 @@ template <class T> struct VectorView {
   ZS_FUNCTION T &operator()(std::size_t i) const { return _p[i]; }
   ZS_FUNCTION std::size_t size() const { return _n; }
 };
+
+// ------------------------------------------------------------------------------------ iterators and ranges
+// (ZpcIterator.hpp:504-560, 637-704; container/TileVector.hpp:299-322; container/Vector.hpp begin / end)
+// POD random-access iterators that are passed to kernels by value; zip / enumerate ranges whose dereference is a tuple of
+// references; range(container), range(tilevector, "property") and range(n).
+template <class T, int L> struct TileVectorIterator {  // one channel of a TileVector: element i at ((i / L) C + chn) L + i % L
+  using iterator_category = std::random_access_iterator_tag;
+  using value_type = std::remove_const_t<T>;
+  using difference_type = long long;
+  using pointer = T *;
+  using reference = T &;
+  T *_base;  // channel offset folded in
+  long long _i;
+  int _C;
+  ZS_FUNCTION reference operator*() const { return (*this)[0]; }
+  ZS_FUNCTION reference operator[](difference_type k) const {
+    const unsigned long long j = (unsigned long long)(_i + k);
+    return _base[(j / L) * (unsigned long long)_C * L + j % L];
+  }
+  ZS_FUNCTION TileVectorIterator operator+(difference_type k) const { return {_base, _i + k, _C}; }
+  ZS_FUNCTION TileVectorIterator operator-(difference_type k) const { return {_base, _i - k, _C}; }
+  ZS_FUNCTION difference_type operator-(const TileVectorIterator &o) const { return _i - o._i; }
+  ZS_FUNCTION TileVectorIterator &operator++() { ++_i; return *this; }
+  ZS_FUNCTION TileVectorIterator &operator+=(difference_type k) { _i += k; return *this; }
+  ZS_FUNCTION bool operator==(const TileVectorIterator &o) const { return _i == o._i && _base == o._base; }
+  ZS_FUNCTION bool operator!=(const TileVectorIterator &o) const { return !(*this == o); }
+};
+struct IndexIterator {  // range(n): dereferences to the index itself
+  using iterator_category = std::random_access_iterator_tag;
+  using value_type = long long;
+  using difference_type = long long;
+  using pointer = const long long *;
+  using reference = long long;
+  long long _i;
+  ZS_FUNCTION long long operator*() const { return _i; }
+  ZS_FUNCTION long long operator[](long long k) const { return _i + k; }
+  ZS_FUNCTION IndexIterator operator+(long long k) const { return {_i + k}; }
+  ZS_FUNCTION long long operator-(const IndexIterator &o) const { return _i - o._i; }
+  ZS_FUNCTION bool operator!=(const IndexIterator &o) const { return _i != o._i; }
+};
+template <class It> struct iterator_range {
+  It _b, _e;
+  It begin() const { return _b; }
+  It end() const { return _e; }
+};
+template <class... Its> struct zip_iterator {  // dereference: std::tuple of the member iterators' references
+  using iterator_category = std::random_access_iterator_tag;
+  using difference_type = long long;
+  using reference = std::tuple<typename std::iterator_traits<Its>::reference...>;
+  using value_type = reference;
+  using pointer = void;
+  std::tuple<Its...> iters;
+  template <std::size_t... Is> ZS_FUNCTION reference deref(long long k, std::index_sequence<Is...>) const {
+    return reference{std::get<Is>(iters)[k]...};
+  }
+  ZS_FUNCTION reference operator[](long long k) const { return deref(k, std::index_sequence_for<Its...>{}); }
+  ZS_FUNCTION reference operator*() const { return (*this)[0]; }
+  ZS_FUNCTION difference_type operator-(const zip_iterator &o) const { return std::get<0>(iters) - std::get<0>(o.iters); }
+};
+template <class T> struct is_zip_iterator : std::false_type {};
+template <class... Its> struct is_zip_iterator<zip_iterator<Its...>> : std::true_type {};
+namespace detail {
+  template <class R> auto range_begin(R &&r) { return std::begin(r); }
+  template <class R> auto range_end(R &&r) { return std::end(r); }
+}  // namespace detail
+inline iterator_range<IndexIterator> range(index_range r) { return {{r.b}, {r.e}}; }
+template <class T> iterator_range<T *> range(Vector<T> &v) { return {v.data(), v.data() + v.size()}; }
+template <class T> iterator_range<const T *> range(const Vector<T> &v) { return {v.data(), v.data() + v.size()}; }
+template <class It> std::size_t range_size(const iterator_range<It> &r) { return (std::size_t)(r.end() - r.begin()); }
+template <class T> std::size_t range_size(const Vector<T> &v) { return v.size(); }
+// zip(r0, r1, ...): ranges or containers with begin() / end(); the length is that of the first
+template <class... Rs> auto zip(Rs &&...rs) {
+  using ZI = zip_iterator<std::decay_t<decltype(std::begin(rs))>...>;
+  return iterator_range<ZI>{ZI{{std::begin(rs)...}}, ZI{{std::end(rs)...}}};
+}
+// enumerate(r0, ...) = zip(range(n), r0, ...)
+template <class R0, class... Rs> auto enumerate(R0 &&r0, Rs &&...rs) {
+  const long long n = (long long)(std::end(r0) - std::begin(r0));
+  return zip(iterator_range<IndexIterator>{{0}, {n}}, std::forward<R0>(r0), std::forward<Rs>(rs)...);
+}
 
 struct PropertyTag {
   std::string name;
@@ -305,6 +421,14 @@ template <class T, int L> struct TileVector {
   T *data() { return _buf.data(); }
   const T *data() const { return _buf.data(); }
   void reset(int ch) { _buf.reset(ch); }
+  bool hasProperty(const std::string &name) const { return getPropertyOffset(name) >= 0; }
+  int getPropertySize(const std::string &name) const {
+    for (auto &t : _tags) if (t.name == name) return t.numChannels;
+    return 0;
+  }
+  // begin / end of one channel of a property (TileVector.hpp:285-322)
+  auto begin(const std::string &prop, int d = 0);
+  auto end(const std::string &prop, int d = 0);
   // maintenance ops that take a policy (TileVector.hpp:583-640); defined after RocmExecutionPolicy below
   template <class Pol> void append_channels(const Pol &pol, const std::vector<PropertyTag> &tags);
   template <class Pol> void reset(const Pol &pol, T val);
@@ -327,6 +451,40 @@ template <class T, int L> struct TileVector {
   Vector<T> _buf;
 };
 
+template <class T, int L> auto TileVector<T, L>::begin(const std::string &prop, int d) {
+  return TileVectorIterator<T, L>{_buf.data() + (std::size_t)(getPropertyOffset(prop) + d) * L, 0, _C};
+}
+template <class T, int L> auto TileVector<T, L>::end(const std::string &prop, int d) {
+  return TileVectorIterator<T, L>{_buf.data() + (std::size_t)(getPropertyOffset(prop) + d) * L, (long long)_size, _C};
+}
+// range(tv, "prop"): the first channel of a property as a random-access range (TileVector.hpp:299-322 + ZpcIterator.hpp range())
+template <class T, int L> iterator_range<TileVectorIterator<T, L>> range(TileVector<T, L> &tv, const std::string &prop) {
+  if (tv.getPropertyOffset(prop) < 0) throw std::runtime_error("range(TileVector, \"" + prop + "\"): no such property");
+  return {tv.begin(prop), tv.end(prop)};
+}
+// TileVectorNamedView (container/TileVector.hpp:1150-1540): tv("name", d, i) / tv("name", i) / tv.pack(dim_c<N>, "name", i); the
+// property table travels by value (up to 16 properties, names up to 23 characters) and is searched linearly, as in the reference
+template <class T, int L> struct TileVectorNamedView : TileVectorView<T, L> {
+  static constexpr int max_props = 16, max_name = 24;
+  char _names[max_props][max_name];
+  int _offs[max_props], _sizes[max_props], _np = 0;
+  ZS_FUNCTION int propertyOffset(const char *name) const {
+    for (int k = 0; k < _np; ++k) {
+      int c = 0;
+      while (c < max_name && _names[k][c] == name[c] && name[c]) ++c;
+      if (c < max_name && _names[k][c] == name[c]) return _offs[k];
+    }
+    return -1;
+  }
+  ZS_FUNCTION bool hasProperty(const char *name) const { return propertyOffset(name) >= 0; }
+  using TileVectorView<T, L>::operator();
+  using TileVectorView<T, L>::pack;
+  using TileVectorView<T, L>::set;
+  ZS_FUNCTION T &operator()(const char *name, int d, std::size_t i) const { return (*this)(propertyOffset(name) + d, i); }
+  ZS_FUNCTION T &operator()(const char *name, std::size_t i) const { return (*this)(propertyOffset(name), i); }
+  template <int N> ZS_FUNCTION small_vec<T, N> pack(dim_t<N> t, const char *name, std::size_t i) const { return this->pack(t, propertyOffset(name), i); }
+  template <int N> ZS_FUNCTION void set(const char *name, std::size_t i, const small_vec<T, N> &v) const { this->set(propertyOffset(name), i, v); }
+};
 // zs::bht<int, dim, int, B> (container/Bht.hpp), dim 1-4, B 16|32 -- owning handle over the C ABI, device view = zsr::BhtDev
 template <int dim, int B> struct bht_traits;
 #define ZS_ROCM_BHT_TRAITS(D, B)                                                                          \
@@ -376,9 +534,15 @@ template <int dim> struct BHTView {  // BHTView (Bht.hpp:403-1072): insert / que
   }
   int *_activeKeys() const { return t.activeKeys; }
 };
-template <int dim, int B = 16> struct bht {
+// template head of the reference (container/Bht.hpp:16-18: Tn, dim, Index, B = 32, allocator); the C ABI instantiates Tn = Index = int,
+// dim 1-4, B 16 | 32 (py_interop/BhtInstantiations.cpp)
+template <class Tn_, int dim_, class Index = int, int B = 32> struct bht {
+  static_assert(std::is_same_v<Tn_, int> && std::is_same_v<Index, int>, "the rocm backend instantiates bht<int, dim, int, B>");
+  static constexpr int dim = dim_;
+  static constexpr int bucket_size = B;
   using traits = bht_traits<dim, B>;
   explicit bht(std::size_t n) : _h(traits::create(n)) {}
+  template <class Alloc> bht(const Alloc &, std::size_t n) : _h(traits::create(n)) {}  // bht{allocator, numExpectedEntries} (Bht.hpp:160-171)
   ~bht() { traits::destroy(_h); }
   bht(const bht &) = delete;
   std::size_t size() const { return traits::size(_h); }
@@ -556,7 +720,7 @@ template <int Side = 8> struct SparseGrid {
     v._background = _background;
     return v;
   }
-  bht<3, 16> _table;
+  bht<int, 3, int, 16> _table;
   TileVector<float, Side * Side * Side> _grid;
   float _dx = 1.f, _origin[3] = {0.f, 0.f, 0.f};
   float _background = 0.f;
@@ -595,8 +759,24 @@ template <execspace_e space, class T> VectorView<T> view(Vector<T> &v) {
   return {v.data(), v.size()};
 }
 template <execspace_e space, class T, int L> TileVectorView<T, L> view(TileVector<T, L> &v) { return {v.data(), v.size(), v.numChannels()}; }
-template <execspace_e space, class T, int L> TileVectorView<T, L> view(std::initializer_list<const char *>, TileVector<T, L> &v) { return view<space>(v); }
-template <execspace_e space, int dim, int B> BHTView<dim> view(bht<dim, B> &t) { return t.view(); }
+// view<space>({"a", "b"}, tv) / proxy<space>({...}, tv): the named view over the listed properties (TileVector.hpp:1513-1540)
+template <execspace_e space, class T, int L> TileVectorNamedView<T, L> view(std::initializer_list<const char *> names, TileVector<T, L> &v) {
+  TileVectorNamedView<T, L> r{};
+  static_cast<TileVectorView<T, L> &>(r) = view<space>(v);
+  for (const char *nm : names) {
+    if (r._np == r.max_props) throw std::runtime_error("named TileVector view: more than 16 properties");
+    const int off = v.getPropertyOffset(nm);
+    if (off < 0) throw std::runtime_error(std::string("named TileVector view: no property \"") + nm + "\"");
+    int c = 0;
+    for (; nm[c] && c < r.max_name - 1; ++c) r._names[r._np][c] = nm[c];
+    r._names[r._np][c] = 0;
+    r._offs[r._np] = off;
+    r._sizes[r._np] = v.getPropertySize(nm);
+    ++r._np;
+  }
+  return r;
+}
+template <execspace_e space, class Tn, int dim, class Ix, int B> BHTView<dim> view(bht<Tn, dim, Ix, B> &t) { return t.view(); }
 template <execspace_e space, int dim> HashTableView<dim> view(HashTable<dim> &t) { return t.view(); }
 template <execspace_e space, int Side> SparseGridView<Side> view(SparseGrid<Side> &g) { return g.view(); }
 template <execspace_e space> LBvhView view(const LBvh &b) { return b.view(); }
@@ -621,6 +801,59 @@ namespace detail {
     if (id >= n) return;
     if constexpr (fn_traits<F>::arity == 1) f(b + id);
     else f((typename fn_traits<F>::first)zs_rocm_dyn_shmem, b + id);
+  }
+  // range_launch / range_launch_with_params (:245-322): one thread per element of a zip range; the functor is called with the
+  // dereferenced members, optionally preceded by the element index and / or the dynamic-LDS base, optionally followed by the
+  // parameter tuple -- the arity dispatch of detail::deduce_fts (:40-155):
+  //   arity == members            f(refs...)                 members + 1, first integral   f(i, refs...)
+  //   members + 1, first pointer  f(shmem*, refs...)         members + 2                   f(shmem*, i, refs...)
+  template <class F, class Ref, std::size_t... Is, class... Pre> __device__ __forceinline__ void range_call(F &f, Ref &&ref, std::index_sequence<Is...>, Pre... pre) {
+    f(pre..., std::get<Is>(ref)...);
+  }
+  template <class F, class Ref, class Params, std::size_t... Is, class... Pre>
+  __device__ __forceinline__ void range_call_p(F &f, Ref &&ref, const Params &params, std::index_sequence<Is...>, Pre... pre) {
+    f(pre..., std::get<Is>(ref)..., params);
+  }
+  template <class F, class ZipIter> __global__ void range_launch(long long n, F f, ZipIter iter) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    using TR = fn_traits<F>;
+    constexpr int members = (int)std::tuple_size_v<typename ZipIter::reference>;
+    constexpr auto seq = std::make_index_sequence<members>{};
+    static_assert(TR::arity >= members && TR::arity <= members + 2, "range_launch: functor arity does not match the zipped ranges");
+    if constexpr (TR::arity == members) range_call(f, iter[id], seq);
+    else if constexpr (TR::arity == members + 1) {
+      using first = std::remove_reference_t<typename TR::first>;
+      static_assert(std::is_integral_v<first> || std::is_pointer_v<first>, "range_launch: the extra leading argument is an index or a shmem pointer");
+      if constexpr (std::is_integral_v<first>) range_call(f, iter[id], seq, (first)id);
+      else range_call(f, iter[id], seq, (first)zs_rocm_dyn_shmem);
+    } else {
+      using first = std::remove_reference_t<typename TR::first>;
+      static_assert(std::is_pointer_v<first>, "range_launch: with two extra leading arguments the first is a shmem pointer");
+      range_call(f, iter[id], seq, (first)zs_rocm_dyn_shmem, id);
+    }
+  }
+  template <class F, class ZipIter, class Params> __global__ void range_launch_with_params(long long n, F f, ZipIter iter, Params params) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    using TR = fn_traits<F>;
+    constexpr int members = (int)std::tuple_size_v<typename ZipIter::reference>;
+    constexpr auto seq = std::make_index_sequence<members>{};
+    static_assert(TR::arity >= members + 1 && TR::arity <= members + 3, "range_launch_with_params: functor arity does not match");
+    if constexpr (TR::arity == members + 1) range_call_p(f, iter[id], params, seq);
+    else if constexpr (TR::arity == members + 2) {
+      using first = std::remove_reference_t<typename TR::first>;
+      if constexpr (std::is_integral_v<first>) range_call_p(f, iter[id], params, seq, (first)id);
+      else range_call_p(f, iter[id], params, seq, (first)zs_rocm_dyn_shmem);
+    } else {
+      using first = std::remove_reference_t<typename TR::first>;
+      range_call_p(f, iter[id], params, seq, (first)zs_rocm_dyn_shmem, id);
+    }
+  }
+  // dst[i] = src[i] between any two random-access iterators (staging of non-contiguous ranges for the primitives)
+  template <class Src, class Dst> __global__ void iter_copy_launch(long long n, Src src, Dst dst) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n) dst[id] = src[id];
   }
   // block_thread_launch (:228-243): f(block, thread) or f(shmem*, block, thread)
   template <class F> __global__ void block_thread_launch(F f) {
@@ -666,6 +899,25 @@ struct RocmExecutionPolicy {
                        (hipStream_t)getStream(), r.b, n, f);
     finish();
   }
+  // pol(range, f) / pol(range, params, f) for zip / enumerate / container ranges (ExecutionPolicy.cuh:458-535): a range that is not a
+  // zip range is wrapped in one, so pol(range(tv, "b"), [](int &v) {...}) and pol(enumerate(vals), [](auto i, int &v) {...}) both work
+  template <class It, class F> void operator()(const iterator_range<It> &r, F &&f) const {
+    if constexpr (is_zip_iterator<It>::value) launch_zip(r.begin(), (long long)(r.end() - r.begin()), std::forward<F>(f));
+    else launch_zip(zip_iterator<It>{{r.begin()}}, (long long)(r.end() - r.begin()), std::forward<F>(f));
+  }
+  template <class It, class... Ps, class F> void operator()(const iterator_range<It> &r, const std::tuple<Ps...> &params, F &&f) const {
+    const long long n = (long long)(r.end() - r.begin());
+    if (n <= 0) return;
+    const int bs = _block > 0 ? _block : 256;
+    if constexpr (is_zip_iterator<It>::value)
+      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, It, std::tuple<Ps...>>), dim3((unsigned)((n + bs - 1) / bs)), dim3(bs),
+                         _shmem, (hipStream_t)getStream(), n, f, r.begin(), params);
+    else
+      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, zip_iterator<It>, std::tuple<Ps...>>), dim3((unsigned)((n + bs - 1) / bs)),
+                         dim3(bs), _shmem, (hipStream_t)getStream(), n, f, zip_iterator<It>{{r.begin()}}, params);
+    finish();
+  }
+  template <class T, class F> void operator()(Vector<T> &v, F &&f) const { (*this)(range(v), std::forward<F>(f)); }
   // pol(Collapse{...}, f)
   template <class F> void operator()(Collapse c, F &&f) const {
     using FT = std::decay_t<F>;
@@ -726,7 +978,60 @@ struct RocmExecutionPolicy {
     finish();
   }
 
+  // reduce / scans over ANY random-access device iterators (TileVector channels, strided views, ...): contiguous pointers go
+  // straight to the C ABI; anything else is staged through stream-ordered temporaries of this policy
+  template <class InIt, class OutIt, class T, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+  void reduce(InIt first, InIt last, OutIt out, T init, Op op) const {
+    const std::size_t n = (std::size_t)(last - first);
+    T *in = stage_in<T>(first, n), *res = (T *)zs_rocm_policy_temporary(_h, sizeof(T));
+    reduce((const T *)in, (const T *)in + n, res, init, op);
+    stage_out(res, out, 1);
+    zs_rocm_policy_temporary_free(_h, res);
+    if (n) zs_rocm_policy_temporary_free(_h, in);
+    finish();
+  }
+  template <class InIt, class OutIt, class T, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+  void exclusive_scan(InIt first, InIt last, OutIt out, T init, Op op) const {
+    const std::size_t n = (std::size_t)(last - first);
+    if (!n) return;
+    T *in = stage_in<T>(first, n);
+    exclusive_scan((const T *)in, (const T *)in + n, in, init, op);
+    stage_out(in, out, n);
+    zs_rocm_policy_temporary_free(_h, in);
+    finish();
+  }
+  template <class InIt, class OutIt, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+  void inclusive_scan(InIt first, InIt last, OutIt out, Op op) const {
+    using T = std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>;
+    const std::size_t n = (std::size_t)(last - first);
+    if (!n) return;
+    T *in = stage_in<T>(first, n);
+    inclusive_scan((const T *)in, (const T *)in + n, in, op);
+    stage_out(in, out, n);
+    zs_rocm_policy_temporary_free(_h, in);
+    finish();
+  }
+
 private:
+  template <class ZI, class F> void launch_zip(ZI it, long long n, F &&f) const {
+    if (n <= 0) return;
+    const int bs = _block > 0 ? _block : 256;
+    hipLaunchKernelGGL((detail::range_launch<std::decay_t<F>, ZI>), dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), _shmem,
+                       (hipStream_t)getStream(), n, f, it);
+    finish();
+  }
+  template <class T, class It> T *stage_in(It first, std::size_t n) const {
+    if (!n) return nullptr;
+    T *tmp = (T *)zs_rocm_policy_temporary(_h, n * sizeof(T));
+    hipLaunchKernelGGL((detail::iter_copy_launch<It, T *>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)getStream(), (long long)n,
+                       first, tmp);
+    return tmp;
+  }
+  template <class T, class It> void stage_out(T *src, It dst, std::size_t n) const {
+    if (!n) return;
+    hipLaunchKernelGGL((detail::iter_copy_launch<T *, It>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)getStream(), (long long)n,
+                       src, dst);
+  }
   void finish() const {
     if (_sync) (void)hipStreamSynchronize((hipStream_t)getStream());
   }
@@ -750,7 +1055,7 @@ private:
   int _block = 0;
 };
 inline RocmExecutionPolicy rocm_exec() { return RocmExecutionPolicy{}; }
-template <int dim, int B> void bht<dim, B>::resize(const RocmExecutionPolicy &pol, std::size_t newCapacity) {
+template <class Tn, int dim, class Ix, int B> void bht<Tn, dim, Ix, B>::resize(const RocmExecutionPolicy &pol, std::size_t newCapacity) {
   traits::resize(pol.handle(), _h, newCapacity);
 }
 
@@ -762,6 +1067,18 @@ template <class T, class Op = plus<T>> void exclusive_scan(const RocmExecutionPo
   pol.exclusive_scan(first, last, out, init, op);
 }
 template <class T, class Op = plus<T>> void inclusive_scan(const RocmExecutionPolicy &pol, const T *first, const T *last, T *out, Op op = {}) {
+  pol.inclusive_scan(first, last, out, op);
+}
+template <class InIt, class OutIt, class T, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+void reduce(const RocmExecutionPolicy &pol, InIt first, InIt last, OutIt out, T init, Op op) {
+  pol.reduce(first, last, out, init, op);
+}
+template <class InIt, class OutIt, class T, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+void exclusive_scan(const RocmExecutionPolicy &pol, InIt first, InIt last, OutIt out, T init, Op op) {
+  pol.exclusive_scan(first, last, out, init, op);
+}
+template <class InIt, class OutIt, class Op, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+void inclusive_scan(const RocmExecutionPolicy &pol, InIt first, InIt last, OutIt out, Op op) {
   pol.inclusive_scan(first, last, out, op);
 }
 template <class K> void radix_sort(const RocmExecutionPolicy &pol, const K *first, const K *last, K *out, int sbit = 0, int ebit = sizeof(K) * 8) {
@@ -795,13 +1112,6 @@ inline RocmExecutionPolicy par_exec(rocm_exec_tag) { return rocm_exec(); }
 // valid_memspace_for_execution (resource/Resource.h:163-166, rocm branch): device and unified memory
 inline bool valid_memspace_for_execution(const RocmExecutionPolicy &, memsrc_e mre) { return mre == memsrc_e::device || mre == memsrc_e::um; }
 
-// get_temporary_memory_source(pol) (resource/Resource.h:52-58 -> temporary_memory_resource<device_mem_tag>, cuda/memory/Allocator.h:33-50):
-// stream-ordered allocate / deallocate on the policy's stream; a block stays valid until deallocate and never aliases another live one
-struct TemporaryMemorySource {
-  zs_rocm_policy *_h;
-  void *allocate(std::size_t bytes, std::size_t = 256) const { return zs_rocm_policy_temporary(_h, bytes); }
-  void deallocate(void *p, std::size_t, std::size_t = 256) const { zs_rocm_policy_temporary_free(_h, p); }
-};
 inline TemporaryMemorySource get_temporary_memory_source(const RocmExecutionPolicy &pol) { return {pol.handle()}; }
 
 // zs::make_monoid(op).identity() (ZpcFunctional.hpp): the identities the primitives use as `init`

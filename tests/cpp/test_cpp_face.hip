@@ -26,6 +26,41 @@
 using namespace zs;
 constexpr auto space = execspace_e::rocm;
 
+
+// The reference's own primitive test, with its statements (test/utils/parallel_primitives.hpp:9-32, test/parallel_primitives.cpp:9-33):
+// reduce over range(tv, "b") into a Vector built from the policy's temporary allocator, a zip-range copy through the policy, a clone
+// to host memory and a serial fold.  It compiles against this header unchanged except for the policy type.
+template <typename Pol, typename Range, typename Op> bool test_reduction(Pol &&policy, Range &&r, Op op) {
+  using namespace zs;
+  static_assert(std::is_lvalue_reference_v<decltype(*std::begin(r))>, "deref of the iterator shall be a lvalue");
+  using value_t = std::remove_reference_t<decltype(*std::begin(r))>;
+  static_assert(std::is_fundamental_v<value_t>, "value_t should be a fundamental type");
+  const auto sz = range_size(r);
+  auto mop = make_monoid(op);
+  auto allocator = get_temporary_memory_source(policy);
+  Vector<value_t> res{allocator, 1};
+  reduce(policy, std::begin(r), std::end(r), std::begin(res), mop.identity(), op);
+  Vector<value_t> vals{allocator, (size_t)sz};
+  policy(zip(r, vals), [] ZS_LAMBDA(const value_t &src, value_t &dst) mutable { dst = src; });
+  vals = vals.clone({memsrc_e::host, -1});
+  value_t e = mop.identity();
+  for (size_t i = 0; i != sz; ++i) e = op(e, vals[i]);
+  if constexpr (std::is_integral_v<value_t>) return e == res.getVal();
+  else return std::abs(e - res.getVal()) / e < 1e-6;
+}
+// gen_rnd_tv_ints (test/utils/initialization.hpp): TileVector<int, 32> {a:3, b:2, c:1} filled with pseudo-random ints < bound
+static zs::TileVector<int, 32> gen_rnd_tv_ints(size_t n, int bound) {
+  using namespace zs;
+  TileVector<int, 32> tv({{"a", 3}, {"b", 2}, {"c", 1}}, n, memsrc_e::um);
+  unsigned long long x = 88172645463325252ull;
+  auto v = view<execspace_e::rocm>(tv);
+  for (size_t i = 0; i < n; ++i)
+    for (int c = 0; c < 6; ++c) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      v(c, i) = (int)(x % (unsigned long long)(bound > 0 ? bound : 1 << 30)) - (bound > 0 ? 0 : (1 << 29));
+    }
+  return tv;
+}
 int main() {
   auto pol = rocm_exec();
   CHECK(pol.shouldSync());
@@ -176,7 +211,7 @@ int main() {
   // ---- bht: insert / query inside lambdas (Bht.hpp:490-542, 667-698), set semantics
   {
     const int n = 50000;
-    bht<3> tab(n);
+    bht<int, 3, int, 16> tab(n);
     Vector<int> ret(n, memsrc_e::um);
     pol(range(n), [tb = view<space>(tab), r = view<space>(ret)] ZS_LAMBDA(long long i) {
       small_vec<int, 3> k{{(int)(i % 37) - 18, (int)((i / 37) % 11), (int)(i % 5)}};
@@ -439,7 +474,7 @@ int main() {
     tms.deallocate(scratch, nT * sizeof(int));
     tms.deallocate(scratch2, nT * sizeof(int));
     // tile_insert / tile_query: 16-lane tiles, every lane of a tile carries the tile's key
-    bht<3> tb(4096);
+    bht<int, 3, int, 16> tb(4096);
     Vector<int> bad(1);
     bad.setVal(0);
     pol(range(64 * 16), [t = view<space>(tb), b = view<space>(bad)] ZS_LAMBDA(long long i) {
@@ -457,6 +492,65 @@ int main() {
       if (t.tile_query(tile, key) < 0 || t.tile_query(tile, absent) != -1) atomic_add(exec_rocm, &b[0], 1);
     });
     CHECK(bad.getVal() == 0);
+  }
+  {  // ---- the reference's reduction test over range(tv, "b") (test/parallel_primitives.cpp:9-33)
+    for (size_t n : {(size_t)1, (size_t)2, (size_t)7, (size_t)16, (size_t)128, (size_t)1024, (size_t)200000}) {
+      auto vals = gen_rnd_tv_ints(n, 0);
+      CHECK(test_reduction(pol, range(vals, "b"), getmax<int>()));
+      CHECK(test_reduction(pol, range(vals, "b"), getmin<int>()));
+      vals = gen_rnd_tv_ints(n, 100);
+      CHECK(test_reduction(pol, range(vals, "b"), plus<int>()));
+    }
+  }
+  {  // ---- range launches: arity dispatch of range_launch / range_launch_with_params (ExecutionPolicy.cuh:245-322, 40-155)
+    const size_t n = 5000;
+    TileVector<float, 64> tv({{"x", 3}, {"m", 1}}, n, memsrc_e::device);
+    Vector<float> a(n), b(n);
+    Vector<int> cnt(1);
+    cnt.setVal(0);
+    pol(enumerate(a, b), [] ZS_LAMBDA(long long i, float &x, float &y) { x = (float)i; y = 2.f * (float)i; });          // (i, refs...)
+    pol(zip(a, b), [] ZS_LAMBDA(float &x, const float &y) { x += y; });                                                   // (refs...)
+    pol(range(tv, "m"), [] ZS_LAMBDA(float &m) { m = 1.5f; });                                                            // single range
+    pol(zip(range(tv, "m"), a), std::make_tuple(0.5f, 3), [] ZS_LAMBDA(float &m, const float &x, const std::tuple<float, int> &p) {
+      m = m * std::get<0>(p) + x * (float)std::get<1>(p);                                                                 // (refs..., params)
+    });
+    pol.shmem(256 * sizeof(float));
+    pol(enumerate(a), [c = view<space>(cnt)] ZS_LAMBDA(float *shm, long long i, float &x) {                               // (shmem*, i, refs...)
+      shm[threadIdx.x] = x;
+      __syncthreads();
+      if (shm[threadIdx.x] != 3.f * (float)i) atomic_add(exec_rocm, &c[0], 1);
+    });
+    pol.shmem(0);
+    CHECK(cnt.getVal() == 0);
+    auto mh = tv.clone(memsrc_e::um);
+    auto mv = view<space>(mh);
+    bool ok = true;
+    for (size_t i = 0; i < n; i += 97) ok = ok && mv(3, i) == 0.75f + 9.f * (float)i;
+    CHECK(ok);
+    // named view: tv("name", d, i), pack / set by name (TileVector.hpp:1150-1540)
+    pol(range(n), [t = proxy<space>({"x", "m"}, tv)] ZS_LAMBDA(long long i) {
+      t("x", 0, (size_t)i) = t("m", (size_t)i);
+      t("x", 1, (size_t)i) = 2.f;
+      t.set("x", (size_t)i, small_vec<float, 3>{{t("x", 0, (size_t)i), 4.f, (float)t.hasProperty("nope")}});
+    });
+    auto th = tv.clone(memsrc_e::um);
+    auto tvw = view<space>(th);
+    CHECK(tvw(0, 4850) == 0.75f + 9.f * 4850.f && tvw(1, 4850) == 4.f && tvw(2, 4850) == 0.f);
+    // generic-iterator scans: a TileVector channel as input, a Vector as output
+    TileVector<int, 32> ti({{"k", 1}, {"pad", 2}}, 3000, memsrc_e::um);
+    auto tiv = view<space>(ti);
+    for (size_t i = 0; i < 3000; ++i) tiv(0, i) = (int)(i % 7);
+    Vector<int> sc(3000, memsrc_e::um);
+    exclusive_scan(pol, ti.begin("k"), ti.end("k"), sc.begin(), 0, plus<int>{});
+    int run = 0;
+    bool sok = true;
+    for (size_t i = 0; i < 3000; ++i) { sok = sok && sc[i] == run; run += (int)(i % 7); }
+    CHECK(sok);
+    // Vector{allocator, n} / get_memory_source / MemoryLocation
+    Vector<double> vd{get_memory_source(memsrc_e::um, 0), 16};
+    CHECK(vd.size() == 16 && vd.memspace() == memsrc_e::um);
+    bht<int, 2, int, 32> t2{get_memory_source(memsrc_e::device, 0), 100};
+    CHECK(t2.size() == 0);
   }
   std::printf("cpp face ok\n");
   return 0;
