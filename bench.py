@@ -146,8 +146,8 @@ def cpu_baseline(sample, dx, dt, model, side, vol):
     so = os.path.join(ROOT, "oracle", "libzpc_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libzpc_oracle.so"])
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from util import OracleMpm
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from orc import OracleMpm  # the checker's own wrapper (oracle/orc.py): the cpu_baseline leg is its only use here
     o = C.CDLL(so)
     cores = os.cpu_count() or 1
     nth = max(1, cores - 1)  # omp_exec() = hardware_concurrency() - 1 (omp/execution/ExecutionPolicy.hpp:1192-1194)
