@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, fused step: exchange the ghost blocks after the whole transfer kernel instead of overlapping "
                          "it with the interior blocks")
+    ap.add_argument("--comm", type=str, default="native", choices=["native", "torch"],
+                    help="native: halo exchange, CFL allreduce and migration through libzsrocm.so's zs_rocm_dist_* (RCCL from C++); "
+                         "torch: the same steps through torch.distributed (always used with --backend gloo)")
+    ap.add_argument("--no-cfl", action="store_true", help="skip the per-step maxVelSqr allreduce(max) (CFL time-step control)")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
@@ -177,6 +181,16 @@ def main():
     a = parse()
     a.fused = not (a.unfused or a.unbinned or a.no_cache_stress)
     a.slotted = a.fused and not a.compact and a.lane_width == 64
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU of this node, rendezvous on the loopback address
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -199,7 +213,7 @@ def main():
     import zpc_amd
     from zpc_amd import lib
     from zpc_amd.mpm import MpmTransfer
-    from zpc_amd.dist import cell_box, HaloExchange
+    from zpc_amd.dist import cell_box, HaloExchange, NativeComm
     if a.decomp and world > 1:
         zpc_amd.dist.set_split_dims(world, [int(v) for v in a.decomp.split("x")])
 
@@ -212,6 +226,10 @@ def main():
     vol = dx ** 3 / 8
 
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
+    # the exchange steps run inside libzsrocm.so on RCCL (zs_rocm_dist_*); torch.distributed only launches the ranks, carries the
+    # unique id and brackets the timed region
+    comm = NativeComm(rank, world, local_rank, dist) if (world > 1 and a.backend == "nccl" and a.comm == "native") else None
+    max_vel = torch.zeros(1, dtype=torch.float32, device=device)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
     drift_v = [float(x) for x in a.drift.split(",")]
     for k in range(3):
@@ -260,6 +278,32 @@ def main():
 
     pack, unpack_add = make_pack(pol), make_unpack(pol)
     pack_c, unpack_add_c = make_pack(pol_comm), make_unpack(pol_comm)
+
+    def exchange(on_comm_stream=False):
+        """ghost-block sums of the grid just written: += every peer's partial sums"""
+        if halo is None:
+            return
+        if comm is not None:
+            halo.exchange_native(comm, pol_comm if on_comm_stream else pol, mt.grid, a.side)
+        elif on_comm_stream:
+            halo.exchange(pack_c, unpack_add_c)
+        else:
+            halo.exchange(pack, unpack_add)
+
+    def grid_update():
+        """grid momenta -> velocities; the CFL bound max |v|^2 over ALL ranks' nodes lands in max_vel (device)"""
+        if a.no_cfl:
+            mt.grid_update((0.0, -9.8, 0.0))
+            return
+        mt._zero(max_vel)
+        mt.grid_update((0.0, -9.8, 0.0), max_vel)
+        if comm is not None:
+            comm.allreduce(pol, max_vel, "max")
+        elif dist is not None:
+            t = max_vel if a.backend == "nccl" else max_vel.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if t is not max_vel:
+                max_vel.copy_(t)
 
     def partition_and_halo():
         """sparse-grid partition of the local particles; with the overlapped exchange the blocks near a rank boundary are
@@ -316,9 +360,8 @@ def main():
         if timed:
             e1.record()
             p2g_ev.append((e0, e1))
-        if halo is not None:
-            halo.exchange(pack, unpack_add)
-        mt.grid_update((0.0, -9.8, 0.0))
+        exchange()
+        grid_update()
         if floor is not None:
             mt.apply_boundary(floor)
         if timed:
@@ -350,7 +393,7 @@ def main():
                 fused_ev.append((e0, e1))
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev_boundary)
-                halo.exchange(pack_c, unpack_add_c)
+                exchange(on_comm_stream=True)
                 ev_comm.record()
             torch.cuda.current_stream().wait_event(ev_comm)
         else:
@@ -360,9 +403,8 @@ def main():
                 ctrl_ev.append((e0, e1))
             if timed:
                 fused_ev.append((e0, e1))
-            if halo is not None:
-                halo.exchange(pack, unpack_add)
-        mt.grid_update((0.0, -9.8, 0.0))
+            exchange()
+        grid_update()
         if floor is not None:
             mt.apply_boundary(floor)
 
@@ -371,9 +413,8 @@ def main():
     def prime_grid():
         mt.clear_grid()
         mt.p2g()
-        if halo is not None:
-            halo.exchange(pack, unpack_add)
-        mt.grid_update((0.0, -9.8, 0.0))
+        exchange()
+        grid_update()
         if floor is not None:
             mt.apply_boundary(floor)
 
@@ -386,7 +427,7 @@ def main():
             mt.unslot()   # occupied slots -> compact buffer (the step before a re-map stored v, C and the stress as well)
         if world > 1:
             to_c = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
-            moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device))
+            moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device), comm=comm)
         nblocks, halo = partition_and_halo()
         if a.fused:
             prime_grid()
@@ -558,7 +599,8 @@ def main():
             "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
-                       "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "boundary_blocks_rank0": n_boundary,
+                       "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
+                       "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": a.migrate_every, "migrated_rank0": migrated,
                        "drift_m_per_s": drift_v, "cells_per_step": max(abs(x) for x in drift_v) * dt / dx,
                        "storage": ("slotted: bins x %d rounds x 64 lanes + per-cell occupancy masks; movers travel through per-bin outboxes "

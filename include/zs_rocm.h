@@ -684,6 +684,29 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_halo_pack(zs_rocm_policy *, const float *grid, c
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_unpack(zs_rocm_policy *, float *grid, const int *blocks, size_t nb, int side,
                                             int chn0, int nchn, const float *buf, int add);
 
+
+/* ======================================================================== (B) multi-GPU exchange steps on RCCL (zpc_amd/csrc/dist.hip)
+ * One process per GPU, one communicator per process; the reference has no collective layer, these are the exchange
+ * steps the spatially sharded MPM path has: ghost-block halo exchange (grouped ncclSend / ncclRecv over the point-to-point xGMI
+ * links), allreduce(max) for the CFL step, counts + uneven all-to-all for particle migration.  All calls enqueue on the policy's
+ * stream.  Return 0, or -1 after an RCCL error (also latched in zs_rocm_last_error). */
+typedef struct zs_rocm_dist zs_rocm_dist;
+ZS_ROCM_EXPORT size_t zs_rocm_dist_unique_id_bytes(void);
+ZS_ROCM_EXPORT int zs_rocm_dist_unique_id(void *out); /* rank 0; the launcher distributes the bytes */
+ZS_ROCM_EXPORT zs_rocm_dist *zs_rocm_dist_create(int rank, int world, const void *uniqueId, int device);
+ZS_ROCM_EXPORT void zs_rocm_dist_destroy(zs_rocm_dist *);
+ZS_ROCM_EXPORT int zs_rocm_dist_rank(const zs_rocm_dist *);
+ZS_ROCM_EXPORT int zs_rocm_dist_world(const zs_rocm_dist *);
+ZS_ROCM_EXPORT int zs_rocm_dist_halo_exchange(zs_rocm_dist *, zs_rocm_policy *, float *grid, int side, int chn0, int nchn, const int *blocks,
+                                              size_t totalBlocks, int npeers, const int *peerRank, const size_t *peerOffset,
+                                              const size_t *peerCount, float *sendbuf, float *recvbuf);
+ZS_ROCM_EXPORT int zs_rocm_dist_allreduce_f32(zs_rocm_dist *, zs_rocm_policy *, float *buf, size_t n, int op); /* 0 sum, 1 max, 2 min */
+ZS_ROCM_EXPORT int zs_rocm_dist_allreduce_i64(zs_rocm_dist *, zs_rocm_policy *, long long *buf, size_t n, int op);
+ZS_ROCM_EXPORT int zs_rocm_dist_alltoall_i64(zs_rocm_dist *, zs_rocm_policy *, const long long *send, long long *recv);
+ZS_ROCM_EXPORT int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *, zs_rocm_policy *, const float *send, const size_t *sendCounts,
+                                              const size_t *sendOffsets, float *recv, const size_t *recvCounts, const size_t *recvOffsets);
+ZS_ROCM_EXPORT int zs_rocm_dist_barrier(zs_rocm_dist *, zs_rocm_policy *);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,19 @@ def _declare(L):
     L.zs_rocm_policy_last_elapsed_ms.argtypes = [vp]
     L.zs_rocm_policy_last_elapsed_ms.restype = f32
     L.zs_rocm_memset.argtypes = [vp, vp, i32, sz]
+    L.zs_rocm_dist_unique_id_bytes.restype = sz
+    L.zs_rocm_dist_unique_id.argtypes = [vp]
+    L.zs_rocm_dist_create.argtypes = [i32, i32, vp, i32]
+    L.zs_rocm_dist_create.restype = vp
+    L.zs_rocm_dist_destroy.argtypes = [vp]
+    L.zs_rocm_dist_rank.argtypes = [vp]
+    L.zs_rocm_dist_world.argtypes = [vp]
+    L.zs_rocm_dist_halo_exchange.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, i32, vp, vp, vp, vp, vp]
+    L.zs_rocm_dist_allreduce_f32.argtypes = [vp, vp, vp, sz, i32]
+    L.zs_rocm_dist_allreduce_i64.argtypes = [vp, vp, vp, sz, i32]
+    L.zs_rocm_dist_alltoall_i64.argtypes = [vp, vp, vp, vp]
+    L.zs_rocm_dist_alltoallv_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.zs_rocm_dist_barrier.argtypes = [vp, vp]
     L.zs_rocm_mpm_slot_outbox_bytes.argtypes = [sz, i32, i32]
     L.zs_rocm_mpm_slot_outbox_bytes.restype = sz
     L.zs_rocm_mpm_build_neighbors27.argtypes = [vp, vp, vp, i32]

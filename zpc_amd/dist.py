@@ -166,8 +166,94 @@ class HaloExchange:
             w.wait()
         unpack_add(self.blocks_all, self.total_blocks, self.recvbuf)
 
+    def exchange_native(self, comm, pol, grid, side, chn0=0, nchn=7):
+        """the same exchange through zs_rocm_dist_halo_exchange: pack kernel, grouped ncclSend / ncclRecv, atomic unpack-add, all
+        enqueued on `pol`'s stream by the library (no Python between the three)"""
+        if not self.peers:
+            return
+        import ctypes as C
+        from ._lib import lib
+        if getattr(self, "_native_args", None) is None:
+            n = len(self.peers)
+            self._native_args = ((C.c_int * n)(*[p for p, _, _ in self.peers]), (C.c_size_t * n)(*[o for _, o, _ in self.peers]),
+                                 (C.c_size_t * n)(*[c for _, _, c in self.peers]), n)
+        pr, po, pc, n = self._native_args
+        if lib().zs_rocm_dist_halo_exchange(comm._h, pol.handle, grid.data_ptr(), int(side), chn0, nchn, self.blocks_all.data_ptr(),
+                                            self.total_blocks, n, pr, po, pc, self.sendbuf.data_ptr(), self.recvbuf.data_ptr()) != 0:
+            raise RuntimeError("zs_rocm_dist_halo_exchange failed")
 
-def migrate_particles(mt, pol, dist, rank, world_size, glo, ghi, align, to_comm=None, from_comm=None):
+
+class NativeComm:
+    """Thin mirror of zs_rocm_dist (zpc_amd/csrc/dist.hip): the RCCL communicator of this process.  The unique id is created on
+    rank 0 and handed round by whatever the launcher offers -- here a torch.distributed broadcast; a C++ host passes the bytes
+    itself (file, MPI, environment)."""
+
+    def __init__(self, rank=0, world=1, device=0, dist=None, bcast_device=None):
+        import ctypes as C
+        import torch
+        from ._lib import lib
+        L = lib()
+        nb = L.zs_rocm_dist_unique_id_bytes()
+        buf = (C.c_ubyte * nb)()
+        if rank == 0:
+            if L.zs_rocm_dist_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+        if world > 1:
+            t = torch.tensor(list(buf), dtype=torch.uint8, device=bcast_device or torch.device("cuda", device))
+            dist.broadcast(t, 0)
+            buf = (C.c_ubyte * nb)(*t.cpu().tolist())
+        self.rank, self.world = rank, world
+        self._h = L.zs_rocm_dist_create(rank, world, buf, device)
+        if not self._h:
+            raise RuntimeError("zs_rocm_dist_create (ncclCommInitRank) failed")
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if self._h:
+                lib().zs_rocm_dist_destroy(self._h)
+        except Exception:
+            pass
+
+    def allreduce(self, pol, t, op="sum"):
+        """in place, on the policy's stream; float32 or int64 tensors"""
+        import torch
+        from ._lib import lib
+        code = {"sum": 0, "max": 1, "min": 2}[op]
+        f = lib().zs_rocm_dist_allreduce_f32 if t.dtype == torch.float32 else lib().zs_rocm_dist_allreduce_i64
+        if f(self._h, pol.handle, t.data_ptr(), t.numel(), code) != 0:
+            raise RuntimeError("RCCL allreduce failed")
+
+    def alltoall_counts(self, pol, send):
+        import torch
+        from ._lib import lib
+        recv = torch.empty_like(send)
+        if lib().zs_rocm_dist_alltoall_i64(self._h, pol.handle, send.data_ptr(), recv.data_ptr()) != 0:
+            raise RuntimeError("RCCL counts all-to-all failed")
+        return recv
+
+    def alltoallv(self, pol, send, send_counts, recv, recv_counts):
+        """float32 buffers; counts in floats per rank (python lists)"""
+        import ctypes as C
+        from ._lib import lib
+        w = self.world
+        so, ro, a, b = [0], [0], 0, 0
+        for r in range(w - 1):
+            a += send_counts[r]
+            b += recv_counts[r]
+            so.append(a)
+            ro.append(b)
+        A = lambda v: (C.c_size_t * w)(*[int(x) for x in v])
+        if lib().zs_rocm_dist_alltoallv_f32(self._h, pol.handle, send.data_ptr(), A(send_counts), A(so), recv.data_ptr(), A(recv_counts),
+                                            A(ro)) != 0:
+            raise RuntimeError("RCCL all-to-all failed")
+
+    def barrier(self, pol):
+        from ._lib import lib
+        lib().zs_rocm_dist_barrier(self._h, pol.handle)
+
+
+def migrate_particles(mt, pol, dist, rank, world_size, glo, ghi, align, to_comm=None, from_comm=None, comm=None):
     """Move every particle to the rank that owns the cell it is in now.  `mt` is a MpmTransfer whose full
     particle state is in memory (after g2p / g2p2g(write_all=True)).  Device work is done by libzsrocm kernels:
     owner classification, a stable radix partition of the particle ids by destination, AoSoA -> AoS row gather into the send
@@ -207,15 +293,25 @@ def migrate_particles(mt, pol, dist, rank, world_size, glo, ghi, align, to_comm=
     pol.syncCtx()
     to_comm = to_comm or (lambda t: t)
     from_comm = from_comm or (lambda t: t)
-    sc = to_comm(torch.tensor(send_rows, dtype=torch.int64, device=dev))
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc)
-    recv_rows = [int(x) for x in rc.cpu().tolist()]
-    n_recv = sum(recv_rows)
-    recvbuf = to_comm(torch.empty(max(n_recv, 1) * nchn, dtype=torch.float32, device=dev))
-    dist.all_to_all_single(recvbuf[: n_recv * nchn], to_comm(sendbuf)[: n_leave * nchn], [r * nchn for r in recv_rows],
-                           [r * nchn for r in send_rows])
-    recvbuf = from_comm(recvbuf)
+    if comm is not None:  # RCCL through the C ABI (zs_rocm_dist_alltoall_i64 / _alltoallv_f32)
+        sc = torch.tensor(send_rows, dtype=torch.int64, device=dev)
+        rc = comm.alltoall_counts(pol, sc)
+        pol.syncCtx()
+        recv_rows = [int(x) for x in rc.cpu().tolist()]
+        n_recv = sum(recv_rows)
+        recvbuf = torch.empty(max(n_recv, 1) * nchn, dtype=torch.float32, device=dev)
+        comm.alltoallv(pol, sendbuf, [r * nchn for r in send_rows], recvbuf, [r * nchn for r in recv_rows])
+        pol.syncCtx()
+    else:
+        sc = to_comm(torch.tensor(send_rows, dtype=torch.int64, device=dev))
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc)
+        recv_rows = [int(x) for x in rc.cpu().tolist()]
+        n_recv = sum(recv_rows)
+        recvbuf = to_comm(torch.empty(max(n_recv, 1) * nchn, dtype=torch.float32, device=dev))
+        dist.all_to_all_single(recvbuf[: n_recv * nchn], to_comm(sendbuf)[: n_leave * nchn], [r * nchn for r in recv_rows],
+                               [r * nchn for r in send_rows])
+        recvbuf = from_comm(recvbuf)
     n_new = n_keep + n_recv
     tiles = (n_new + lw - 1) // lw
     newbuf = torch.zeros(max(tiles, 1) * lw * nchn, dtype=torch.float32, device=dev)
