@@ -15,10 +15,18 @@
  *     integer add, stable sort) and cross-checked against numpy in tests; the reference's only
  *     in-tree test for them (test/utils/parallel_primitives.hpp:9-32, reduce == serial fold) is
  *     replayed in tests/test_oracle_primitives.py.
- *   - bht / P2G / G2P as whole functions: the reference's containers and policies need the
- *     un-vendored magic_enum / plog submodule headers and are unbuildable in this image, and the
+ *   - P2G / G2P (and through them the fused G2P2G step) as whole functions: PINNED.  The functor
+ *     bodies (simulation/transfer/P2G.hpp:51-125, G2P.hpp:44-83) are spelled in oracle/ref_shim.cpp over
+ *     the reference's own make_local_arena / unpack_coord_in_grid / compute_stress_* /
+ *     matrixMatrixMultiplication3d (all header-only, built in place); tools/gen_golden.py writes
+ *     tests/golden/p2g_g2p.npz (4096 particles, 5 models, block sides 4 and 8) and
+ *     tests/test_oracle_cpu.py compares mpm.c with it.  The von Mises / NACC models exist in a host
+ *     and a CUDA spelling that differ (sqrt iteration, NACC yield pressure): orc_mpm_params.hostVariant
+ *     = 1 follows the host header (what the golden vectors were made with), 0 the CUDA header.
+ *   - bht / HashTable / P2C2G / G2C2P as whole functions: the reference's containers and policies need
+ *     the un-vendored magic_enum / plog submodule headers and are unbuildable in this image, and the
  *     reference holds no tests for them: PARITY UNPINNED at whole-function level (their numeric
- *     building blocks are pinned as above; conservation properties are tested).
+ *     building blocks are pinned as above; set semantics and conservation properties are tested).
  */
 #ifndef ZPC_ORACLE_H
 #define ZPC_ORACLE_H
