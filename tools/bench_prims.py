@@ -43,7 +43,8 @@ def main():
         print("%-44s n=%-10d %9.4f ms  %9.2f G/s  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, n, ms, n / ms / 1e6, gbs, 100 * gbs / PEAK), flush=True)
 
     g = torch.Generator(device="cuda").manual_seed(1)
-    for n in (1_000_000, 16_000_000, 64_000_000) if want("prims") else ():
+    sizes = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(",")) if "--sizes" in sys.argv else (1_000_000, 16_000_000, 64_000_000)
+    for n in sizes if want("prims") else ():
         a = torch.randint(-2**30, 2**30, (n,), dtype=torch.int32, device="cuda", generator=g)
         out1 = torch.zeros(1, dtype=torch.int32, device="cuda")
         out = torch.empty_like(a)

@@ -318,6 +318,7 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
 }
 template <int OP, class T, bool EXCL> static void scan_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
   if (n == 0) return;
+  // (r02: 4-row and 16-row tiles re-measured at 16 M / 64 M / 256 M elements: 2.5 / 2.9 / 3.2 and 3.0 / 3.0 / 3.2 TB/s against 2.9 / 3.4 / 3.8 for 8 rows)
   if (n >= ((size_t)1 << 23)) scan_launch<OP, T, EXCL, 8>(L, in, n, out, init);
   else scan_launch<OP, T, EXCL, 2>(L, in, n, out, init);
 }
@@ -385,40 +386,26 @@ __global__ __launch_bounds__(256) void radix_global_hist_kernel(Port<const K> ke
   for (int p = 0; p < NPASS; ++p)
     if (h[p][threadIdx.x]) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
 }
-// exclusive scan of each pass's 256-bin histogram (one block of 256 threads per pass)
-__global__ __launch_bounds__(256) void radix_hist_scan_kernel(unsigned *ghist) {
-  __shared__ unsigned sm[4];
-  unsigned *h = ghist + blockIdx.x * 256;
-  const unsigned v = h[threadIdx.x];
-  unsigned s = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    unsigned o = shfl_up(s, d);
-    if (lane_id() >= d) s += o;
-  }
-  if (lane_id() == 63) sm[wave_id()] = s;
-  __syncthreads();
-  unsigned base = 0;
-  for (int w = 0; w < wave_id(); ++w) base += sm[w];
-  h[threadIdx.x] = base + s - v;
-}
-
-template <class K, bool PAIR, int BLOCK, int ITEMS>
+template <class K, bool PAIR, int BLOCK, int ITEMS, int LBN>
 __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin, Port<const int> vin, Port<K> kout, Port<int> vout,
-                                                               size_t n, int st, unsigned mask, const unsigned *gbase,
+                                                               size_t n, int st, unsigned mask, const unsigned *ghistPass,
                                                                unsigned *desc, unsigned *ticket) {
   constexpr int NW = BLOCK / 64, TILE = BLOCK * ITEMS;
   static_assert(BLOCK >= 256 && BLOCK % 256 == 0, "one thread per digit in the first 256 threads");
   __shared__ unsigned cnt[NW][256];      // per-wave digit counters -> per-wave exclusive offsets inside the digit run
   __shared__ unsigned tileStart[256];    // start of digit d inside the tile-local sorted order
   __shared__ unsigned globalStart[256];  // start of this tile's run of digit d in the output
-  __shared__ unsigned sWave[4];
+  __shared__ unsigned sWave[4], sWave2[4];
   __shared__ unsigned sTile;
   __shared__ K keyS[TILE];
   __shared__ int valS[PAIR ? TILE : 1];
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
   if (t == 0) sTile = atomicAdd(ticket, 1u);
   for (int i = t; i < NW * 256; i += BLOCK) (&cnt[0][0])[i] = 0;
+  // global start of digit t = exclusive scan of this pass's 256-bin histogram (every tile redoes the 256-element scan: cheaper than
+  // a launch of its own); partial sums of the four waves go through sWave
+  // (the load is issued here and consumed after the ranking)
+  const unsigned ghv = t < 256 ? ghistPass[t] : 0u;
   __syncthreads();
   const unsigned tile = sTile;
   const size_t tileBase = (size_t)tile * TILE;
@@ -502,17 +489,28 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
       unsigned o = shfl_up(s, d);
       if (lane >= d) s += o;
     }
-    if (lane == 63) sWave[w] = s;
+    if (lane == 63) sWave2[w] = s;
     tileStart[t] = s - myCount;
+    unsigned sc = ghv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = shfl_up(sc, d);
+      if (lane >= d) sc += o;
+    }
+    if (lane == 63) sWave[w] = sc;
+    const unsigned gstart = sc - ghv;  // + the sums of the lower waves, added after the barrier
     // look back over the predecessors' descriptors of digit t
     if (tile != 0) {
       // look back over the predecessors' descriptors of digit t, LB tiles per round trip: the loads of one batch are
       // independent, so a walk over many aggregate-only tiles (the tiles that started together with this one) costs one L2
       // latency per batch instead of one per tile
-      constexpr int LB = 8;
+      // The first batch is short (in a long launch the tiles are staggered and an inclusive prefix is a few tiles away); when the
+      // whole launch starts together (small inputs: every tile is aggregate-only until tile 0's chain reaches it) the walk continues
+      // LBN tiles per round trip (64 in the small-tile instantiation).
       long long p = (long long)tile - 1;
       bool done = false;
-      while (!done) {
+      auto batch = [&](auto lbTag) {
+        constexpr int LB = decltype(lbTag)::value;
         unsigned v[LB];
 #pragma unroll
         for (int j = 0; j < LB; ++j)
@@ -532,18 +530,20 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
         }
         p -= used;
         if (!done && used < LB) __builtin_amdgcn_s_sleep(1);  // ran into a tile that has not published yet
-      }
+      };
+      batch(std::integral_constant<int, 8>{});
+      while (!done) batch(std::integral_constant<int, LBN>{});
       __hip_atomic_store(myDesc, OS_FLAG_PREFIX | (excl + myCount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    globalStart[t] = gbase[t] + excl;
+    globalStart[t] = gstart + excl;
   }
   __syncthreads();
   if (t < 256) {
-    unsigned b = 0;
-    for (int i = 0; i < w; ++i) b += sWave[i];
+    unsigned b = 0, gb = 0;
+    for (int i = 0; i < w; ++i) b += sWave2[i], gb += sWave[i];
     const unsigned ts = tileStart[t] + b;
     tileStart[t] = ts;
-    globalStart[t] -= ts;  // (wrapping) so that dst = globalStart[d] + position in the tile-sorted order
+    globalStart[t] += gb - ts;  // (wrapping) so that dst = globalStart[d] + position in the tile-sorted order
 #pragma unroll
     for (int i = 0; i < NW; ++i) cnt[i][t] += ts;  // tile-sorted position = cnt[w][d] + rank
   }
@@ -623,14 +623,18 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
                        contiguous_port<const K>(tmpK), contiguous_port<const int>(tmpV), kout, vout, n);
     return;
   }
+  // 8192-key tiles at every size.  Measured at 1 M keys (122 tiles, all resident at once, so the look-back walks aggregates): smaller
+  // tiles (2048 / 4096 keys) or wider look-back batches (16 / 32 / 64 descriptors per round trip) are all slower -- a pass costs
+  // ~10 us + ~45 ns per tile of chain (r02 measurements).
   const unsigned numTiles = ceil_div(n, RS_TILE);
   constexpr int MAXPASS = (int)sizeof(K);
   // [MAXPASS][256] global digit starts + per pass: ticket + [numTiles][256] descriptors (re-initialised every call)
   const size_t descBytes = sizeof(unsigned) * (256 * (size_t)numTiles + 64);
-  unsigned *ghist = (unsigned *)L.temp(sizeof(unsigned) * 256 * MAXPASS);
-  char *descMem = (char *)L.temp(descBytes * (size_t)passes);
-  ZSR_CHECK(hipMemsetAsync(ghist, 0, sizeof(unsigned) * 256 * MAXPASS, L.stream));
-  ZSR_CHECK(hipMemsetAsync(descMem, 0, descBytes * (size_t)passes, L.stream));
+  const size_t ghistBytes = sizeof(unsigned) * 256 * MAXPASS;
+  char *ctl = (char *)L.temp(ghistBytes + descBytes * (size_t)passes);  // one block, one memset
+  unsigned *ghist = (unsigned *)ctl;
+  char *descMem = ctl + ghistBytes;
+  ZSR_CHECK(hipMemsetAsync(ctl, 0, ghistBytes + descBytes * (size_t)passes, L.stream));
   K *tk[2] = {nullptr, nullptr};
   int *tv[2] = {nullptr, nullptr};
   const int ntemp = passes >= 3 ? 2 : passes - 1;
@@ -639,9 +643,9 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
     if (PAIR) tv[i] = (int *)L.temp(sizeof(int) * n);
   }
   {
+    // every block ends with 256 x passes global atomics on the same addresses: few, fat blocks for small inputs
     const unsigned hb = (unsigned)std::min<size_t>(ceil_div(n, 256 * 16), 2048);
     hipLaunchKernelGGL((radix_global_hist_kernel<K, MAXPASS>), dim3(hb), dim3(256), 0, L.stream, kin, n, sbit, ebit, ghist);
-    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(256), 0, L.stream, ghist);
   }
   Port<const K> srcK = kin;
   Port<const int> srcV = vin;
@@ -659,8 +663,8 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
     }
     unsigned *desc = (unsigned *)(descMem + descBytes * (size_t)p);
     unsigned *ticket = desc + 256 * (size_t)numTiles;
-    hipLaunchKernelGGL((radix_onesweep_kernel<K, PAIR, RS_BLOCK, RS_ITEMS>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, srcV, dstK, dstV, n, st,
-                       mask, (const unsigned *)(ghist + 256 * p), desc, ticket);
+    hipLaunchKernelGGL((radix_onesweep_kernel<K, PAIR, RS_BLOCK, RS_ITEMS, 8>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, srcK, srcV, dstK, dstV,
+                         n, st, mask, (const unsigned *)(ghist + 256 * p), desc, ticket);
     srcK = Port<const K>{dstK.base, dstK.idx, dstK.bits, dstK.mask, dstK.chns};
     if (PAIR) srcV = Port<const int>{dstV.base, dstV.idx, dstV.bits, dstV.mask, dstV.chns};
   }
