@@ -432,6 +432,10 @@ template <class T, int L> struct TileVector {
   // maintenance ops that take a policy (TileVector.hpp:583-640); defined after RocmExecutionPolicy below
   template <class Pol> void append_channels(const Pol &pol, const std::vector<PropertyTag> &tags);
   template <class Pol> void reset(const Pol &pol, T val);
+  // reorderTiles(pol, map[, wrapv<Scatter>]) (TileVector.hpp:641-691): whole tiles move; gather: tile i := old tile map[i], scatter:
+  // tile map[i] := old tile i.  `map`: a zs::Vector of integers or any iterator_range over integers, one entry per tile
+  template <class Pol, class MapRange, bool Scatter = false> void reorderTiles(const Pol &pol, MapRange &&map, wrapv<Scatter> = {});
+  std::size_t numTiles() const { return tiles(); }
   TileVector clone(memsrc_e mre) const {
     TileVector r(_tags, _size, mre);
     if (_buf.size()) (void)hipMemcpy(r._buf.data(), _buf.data(), _buf.size() * sizeof(T), hipMemcpyDefault);
@@ -594,137 +598,10 @@ template <int dim> struct HashTable {
   zs_rocm_hashtable *_h;
 };
 
-// zs::SparseGrid<3, f32, Side> (geometry/SparseGrid.hpp:16-188): bht<int,3,int,16> keyed by block ORIGIN coordinates
-// (multiples of Side) + TileVector<f32, Side^3>; index<->world transform restricted to uniform scale + translation
-// (what `scale(dx)` / `translate(t)` produce, :170-182).
-template <int Side = 8> struct SparseGridView {  // SparseGridView (geometry/SparseGrid.hpp:199-916)
-  static constexpr int dim = 3, side_length = Side, block_size = Side * Side * Side;
-  static constexpr int sentinel_v = -1;
-  using coord_t = small_vec<float, 3>;
-  using icoord_t = small_vec<int, 3>;
-  BHTView<3> _table;
-  TileVectorView<float, Side * Side * Side> _grid;
-  float _dx;
-  coord_t _origin;
-  float _background;
-  ZS_FUNCTION coord_t indexToWorld(const coord_t &X) const { return coord_t{{X[0] * _dx + _origin[0], X[1] * _dx + _origin[1], X[2] * _dx + _origin[2]}}; }
-  ZS_FUNCTION coord_t worldToIndex(const coord_t &x) const { return coord_t{{(x[0] - _origin[0]) / _dx, (x[1] - _origin[1]) / _dx, (x[2] - _origin[2]) / _dx}}; }
-  ZS_FUNCTION float voxelSize(int = 0) const { return _dx; }
-  __device__ __forceinline__ int numActiveBlocks() const { return _table.size(); }
-  // linear cell index <-> in-block coordinate (:266-292): offset = (x * Side + y) * Side + z
-  ZS_FUNCTION static icoord_t local_offset_to_coord(int offset) {
-    icoord_t r;
-    for (int d = 2; d >= 0; --d, offset /= Side) r[d] = offset % Side;
-    return r;
-  }
-  ZS_FUNCTION static int local_coord_to_offset(const icoord_t &c) { return (c[0] * Side + c[1]) * Side + c[2]; }
-  ZS_FUNCTION static int global_coord_to_local_offset(const icoord_t &c) {
-    return (((c[0] & (Side - 1)) * Side) + (c[1] & (Side - 1))) * Side + (c[2] & (Side - 1));
-  }
-  struct BlockCell { int bno, cno; };
-  // decomposeCoord (:305-309): cell = coord & (Side-1), block origin = coord - cell -> (table.query(origin), offset)
-  __device__ __forceinline__ BlockCell decomposeCoord(const icoord_t &c) const {
-    const icoord_t cell{{c[0] & (Side - 1), c[1] & (Side - 1), c[2] & (Side - 1)}};
-    const icoord_t org{{c[0] - cell[0], c[1] - cell[1], c[2] - cell[2]}};
-    return {_table.query(org), local_coord_to_offset(cell)};
-  }
-  ZS_FUNCTION float &operator()(int chn, int bno, int cno) const { return _grid(chn, (std::size_t)bno, cno); }
-  // valueOr (:344-367)
-  ZS_FUNCTION float valueOr(int chn, int bno, int cno, float defaultVal) const { return bno == sentinel_v ? defaultVal : _grid(chn, (std::size_t)bno, cno); }
-  __device__ __forceinline__ float valueOr(int chn, const icoord_t &c, float defaultVal) const {  // valueOr(false_c, ...)
-    const BlockCell bc = decomposeCoord(c);
-    return valueOr(chn, bc.bno, bc.cno, defaultVal);
-  }
-  __device__ __forceinline__ float valueOr(int chn, const icoord_t &c, int orientation, float defaultVal) const {  // valueOr(true_c, ...)
-    icoord_t cc = c;
-    const int f = orientation % 6;
-    if (f >= 3) ++cc[f - 3];
-    return valueOr(chn, cc, defaultVal);
-  }
-  // iCoord / wCoord (:404-417), staggered (:419-440)
-  __device__ __forceinline__ icoord_t iCoord(int bno, int cno) const {
-    const icoord_t l = local_offset_to_coord(cno);
-    const int *k = _table.t.activeKeys + 3 * (std::size_t)bno;
-    return icoord_t{{k[0] + l[0], k[1] + l[1], k[2] + l[2]}};
-  }
-  __device__ __forceinline__ icoord_t iCoord(std::size_t cellno) const { return iCoord((int)(cellno / block_size), (int)(cellno % block_size)); }
-  __device__ __forceinline__ coord_t wCoord(int bno, int cno) const {
-    const icoord_t c = iCoord(bno, cno);
-    return indexToWorld(coord_t{{(float)c[0], (float)c[1], (float)c[2]}});
-  }
-  __device__ __forceinline__ coord_t iStaggeredCoord(int bno, int cno, int f) const {
-    const icoord_t c = iCoord(bno, cno);
-    coord_t r{{(float)c[0], (float)c[1], (float)c[2]}};
-    r[f] -= 0.5f;
-    return r;
-  }
-  __device__ __forceinline__ coord_t wStaggeredCoord(int bno, int cno, int f) const { return indexToWorld(iStaggeredCoord(bno, cno, f)); }
-  // insert / query by world position (:442-457): X = floor(worldToIndex(x) + 0.5), block origin = X - (X & (Side-1))
-  __device__ __forceinline__ icoord_t blockOriginOf(const coord_t &x) const {
-    const coord_t X_ = worldToIndex(x);
-    icoord_t X;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      X[d] = (int)floorf(X_[d] + 0.5f);
-      X[d] -= X[d] & (Side - 1);
-    }
-    return X;
-  }
-  __device__ __forceinline__ int insert(const coord_t &x) const { return _table.insert(blockOriginOf(x)); }
-  __device__ __forceinline__ int query(const coord_t &x) const { return _table.query(blockOriginOf(x)); }
-  // iSample / wSample (:459-516) with the linear kernel: GridArena<linear> (math/curve/InterpolationKernel.hpp:271-456):
-  // corner = floor(X), w = {1 - d, d}, sum over the 2^3 nodes of w * valueOr(node, background)
-  __device__ __forceinline__ float iSample(int chn, const coord_t &X) const {
-    int c[3];
-    float w[3][2];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      c[d] = (int)floorf(X[d]);
-      const float t = X[d] - (float)c[d];
-      w[d][0] = 1.f - t;
-      w[d][1] = t;
-    }
-    float ret = 0.f;
-    for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < 2; ++j)
-        for (int k = 0; k < 2; ++k) ret += w[0][i] * w[1][j] * w[2][k] * valueOr(chn, icoord_t{{c[0] + i, c[1] + j, c[2] + k}}, _background);
-    return ret;
-  }
-  __device__ __forceinline__ float wSample(int chn, const coord_t &x) const { return iSample(chn, worldToIndex(x)); }
-  template <int N> __device__ __forceinline__ small_vec<float, N> iPack(dim_t<N>, int chn, const coord_t &X) const {  // :640-700
-    small_vec<float, N> r;
-#pragma unroll
-    for (int d = 0; d < N; ++d) r[d] = iSample(chn + d, X);
-    return r;
-  }
-  template <int N> __device__ __forceinline__ small_vec<float, N> wPack(dim_t<N> t, int chn, const coord_t &x) const { return iPack(t, chn, worldToIndex(x)); }
-};
-template <int Side = 8> struct SparseGrid {
-  static constexpr int dim = 3, side_length = Side, block_size = Side * Side * Side;
-  SparseGrid(const std::vector<PropertyTag> &tags, std::size_t numBlocks, memsrc_e mre = memsrc_e::device)
-      : _table(numBlocks), _grid(tags, numBlocks * (std::size_t)block_size, mre) {}
-  SparseGrid(int numChns, std::size_t numBlocks, memsrc_e mre = memsrc_e::device)
-      : SparseGrid(std::vector<PropertyTag>{{"unnamed", numChns}}, numBlocks, mre) {}
-  std::size_t numBlocks() const { return _table.size(); }
-  int numChannels() const { return _grid.numChannels(); }
-  int getPropertyOffset(const std::string &n) const { return _grid.getPropertyOffset(n); }
-  void scale(float s) { _dx *= s; }                                               // :181-182
-  void translate(float x, float y, float z) { _origin[0] += x; _origin[1] += y; _origin[2] += z; }  // :170-172
-  float voxelSize() const { return _dx; }
-  SparseGridView<Side> view() {
-    SparseGridView<Side> v;
-    v._table = _table.view();
-    v._grid = TileVectorView<float, block_size>{_grid.data(), _grid.size(), _grid.numChannels()};
-    v._dx = _dx;
-    v._origin = small_vec<float, 3>{{_origin[0], _origin[1], _origin[2]}};
-    v._background = _background;
-    return v;
-  }
-  bht<int, 3, int, 16> _table;
-  TileVector<float, Side * Side * Side> _grid;
-  float _dx = 1.f, _origin[3] = {0.f, 0.f, 0.f};
-  float _background = 0.f;
-};
+// zs::SparseGrid<dim, T, Side>, SparseGridView, GridArena<view, kernel, deriv_order> (geometry/SparseGrid.hpp, math/curve/InterpolationKernel.hpp)
+}  // namespace zs
+#include "sparse_grid.hpp"
+namespace zs {
 
 // zs::LBvh<3, int, f32> (container/Bvh.hpp:86-1248) over a zs::Vector<AABBBox<3, f32>> of primitive boxes
 using AABBBox3f = zsr::AABB3;  // {lo[3], hi[3]} == AABBBox<3, f32> {_min, _max}
@@ -778,7 +655,7 @@ template <execspace_e space, class T, int L> TileVectorNamedView<T, L> view(std:
 }
 template <execspace_e space, class Tn, int dim, class Ix, int B> BHTView<dim> view(bht<Tn, dim, Ix, B> &t) { return t.view(); }
 template <execspace_e space, int dim> HashTableView<dim> view(HashTable<dim> &t) { return t.view(); }
-template <execspace_e space, int Side> SparseGridView<Side> view(SparseGrid<Side> &g) { return g.view(); }
+template <execspace_e space, int dim, class T, int Side> SparseGridView<dim, T, Side> view(SparseGrid<dim, T, Side> &g) { return g.view(); }
 template <execspace_e space> LBvhView view(const LBvh &b) { return b.view(); }
 template <execspace_e space, class C> auto proxy(C &c) { return view<space>(c); }
 template <execspace_e space, class T, int L> auto proxy(std::initializer_list<const char *> l, TileVector<T, L> &v) { return view<space>(l, v); }
@@ -1146,6 +1023,29 @@ template <class T, int L> template <class Pol> void TileVector<T, L>::append_cha
     dst[tile * Cn * L + r] = src[e];  // the old channels keep their offsets, so a tile's first Co rows copy straight over
   });
   *this = std::move(grown);
+}
+namespace detail {
+  template <class T> ZS_FUNCTION const T *map_begin(const Vector<T> &v) { return v.data(); }
+  template <class T> ZS_FUNCTION T *map_begin(Vector<T> &v) { return v.data(); }
+  template <class It> ZS_FUNCTION It map_begin(const iterator_range<It> &r) { return r.begin(); }
+}  // namespace detail
+template <class T, int L> template <class Pol, class MapRange, bool Scatter>
+void TileVector<T, L>::reorderTiles(const Pol &pol, MapRange &&map, wrapv<Scatter>) {
+  if (range_size(map) != tiles()) throw std::runtime_error("index mapping range size mismatch");
+  TileVector ordered(_tags, _size, _mre);
+  const T *src = _buf.data();
+  T *dst = ordered._buf.data();
+  const int C = _C;
+  auto m = detail::map_begin(map);
+  static_assert(std::is_integral_v<std::decay_t<decltype(m[0])>>, "the mapping range must yield integers");
+  // one thread per (tile, channel row, lane): a wave moves whole 4 L-byte rows
+  pol(range((long long)tiles() * C * L), [=] ZS_LAMBDA(long long e) {
+    const long long tile = e / ((long long)C * L), r = e % ((long long)C * L);
+    const long long other = (long long)m[tile];
+    if constexpr (Scatter) dst[other * C * L + r] = src[e];
+    else dst[e] = src[other * C * L + r];
+  });
+  *this = std::move(ordered);
 }
 // TileVector::reset(pol, val) (TileVector.hpp:624-640)
 template <class T, int L> template <class Pol> void TileVector<T, L>::reset(const Pol &pol, T val) {

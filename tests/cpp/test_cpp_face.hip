@@ -262,10 +262,32 @@ int main() {
     });
     for (int i = 0; i < n; ++i) CHECK(ret.data()[i] == 1);
   }
-  // ---- SparseGrid<8>: world-space insert / query, decomposeCoord, valueOr, trilinear wSample of a linear field
+  // ---- TileVector::reorderTiles: gather and scatter of whole tiles by an index map (TileVector.hpp:641-691)
+  {
+    TileVector<float, 32> tvr(std::vector<PropertyTag>{{"a", 2}, {"b", 1}}, 32 * 7 - 5, memsrc_e::um);
+    const int nt = (int)tvr.numTiles();
+    CHECK(nt == 7);
+    auto hv = view<space>(tvr);
+    for (int i = 0; i < 32 * 7 - 5; ++i)
+      for (int c = 0; c < 3; ++c) hv(c, (std::size_t)i) = (float)(1000 * c + i);
+    Vector<int> map(nt, memsrc_e::um);
+    const int perm[7] = {3, 0, 6, 1, 5, 2, 4};
+    for (int i = 0; i < nt; ++i) map.data()[i] = perm[i];
+    tvr.reorderTiles(pol, map);  // gather: new tile i = old tile perm[i]
+    hv = view<space>(tvr);
+    for (int t = 0; t < nt; ++t)
+      for (int l = 0; l < 32; ++l)
+        if (perm[t] * 32 + l < 32 * 7 - 5)
+          for (int c = 0; c < 3; ++c) CHECK(hv(c, (std::size_t)t, l) == (float)(1000 * c + perm[t] * 32 + l));
+    tvr.reorderTiles(pol, map, wrapv<true>{});  // scatter by the same map undoes the gather
+    hv = view<space>(tvr);
+    for (int i = 0; i < 32 * 7 - 5; ++i)
+      for (int c = 0; c < 3; ++c) CHECK(hv(c, (std::size_t)i) == (float)(1000 * c + i));
+  }
+  // ---- SparseGrid<3, f32, 8>: world-space insert / query, decomposeCoord, valueOr, trilinear wSample of a linear field
   {
     const float dx = 0.125f;
-    SparseGrid<8> sg(std::vector<PropertyTag>{{"sdf", 1}, {"v", 3}}, 64);
+    SparseGrid<3, float, 8> sg(std::vector<PropertyTag>{{"sdf", 1}, {"v", 3}}, 64);
     sg.scale(dx);
     sg.translate(-1.f, -1.f, -1.f);
     sg._background = 7.f;
@@ -305,6 +327,99 @@ int main() {
     float worst = 0.f;
     for (int i = 0; i < np; ++i) worst = std::max(worst, err.data()[i]);
     CHECK(worst < 2e-5f);  // trilinear interpolation reproduces linear fields
+    // the same grid through the other kernels of GridArena: every B-spline reproduces linear fields, the quadratic and cubic ones with
+    // exact gradients (sum_i grad w_i = 0, sum_i grad w_i * f_i = grad f); the delta kernels are partitions of unity; name-keyed access
+    pol(range(np), [g = view<space>(sg), p = view<space>(px), e = view<space>(err)] ZS_LAMBDA(long long i) {
+      using V3 = small_vec<float, 3>;
+      const V3 x{{p[3 * i] * 0.5f, p[3 * i + 1] * 0.5f, p[3 * i + 2] * 0.5f}};  // keep the wider stencils inside the allocated blocks
+      const float ref = 2.f * x[0] - x[1] + 0.5f * x[2] + 1.f;
+      float m = 0.f;
+      auto aq = g.wArena<kernel_e::quadratic, 1>(x);
+      auto ac = g.wArena<kernel_e::cubic, 2>(x);
+      bool covered = true;  // all nodes of the widest stencil exist
+      for (auto loc : ac.range()) covered = covered && g.decomposeCoord(ac.coord(loc)).bno >= 0;
+      if (covered) {
+        m = fmaxf(m, fabsf(aq.isample(0, 7.f) - ref));
+        m = fmaxf(m, fabsf(ac.isample("sdf", 0, 7.f) - ref));
+        m = fmaxf(m, fabsf(g.wSample(0, x, kernel_c<kernel_e::quadratic>) - ref));
+        float sw = 0.f, sw3 = 0.f, sw4 = 0.f, gsum[3] = {0.f, 0.f, 0.f}, gf[3] = {0.f, 0.f, 0.f}, lap = 0.f;
+        for (auto loc : aq.range()) {
+          sw += aq.weight(loc);
+          const V3 gw = aq.weightsGradient(loc);
+          const float f = aq.val(0, loc);
+          for (int d = 0; d < 3; ++d) { gsum[d] += gw[d]; gf[d] += gw[d] * f; }
+        }
+        for (auto loc : ac.range()) lap += ac.w[2][0][loc[0]] * ac.w[0][1][loc[1]] * ac.w[0][2][loc[2]] * ac.val(0, loc);  // d2/dX2 of a linear field
+        m = fmaxf(m, fabsf(sw - 1.f));
+        const float want[3] = {2.f, -1.f, 0.5f};  // d sdf / d world; the arena's gradients are per index unit: * dx
+        for (int d = 0; d < 3; ++d) m = fmaxf(m, fmaxf(fabsf(gsum[d]), fabsf(gf[d] / 0.125f - want[d]) * 0.02f));
+        m = fmaxf(m, fabsf(lap) * 1e-2f);
+        for (auto loc : g.wArena<kernel_e::delta3>(x).range()) sw3 += g.wArena<kernel_e::delta3>(x).weight(loc);
+        for (auto loc : g.wArena<kernel_e::delta4>(x).range()) sw4 += g.wArena<kernel_e::delta4>(x).weight(loc);
+        m = fmaxf(m, fmaxf(fabsf(sw3 - 1.f), fabsf(sw4 - 1.f)));
+        const float lo = aq.minimum(0), hi = aq.maximum(0);
+        if (!(lo <= ref + 1e-5f && ref <= hi + 1e-5f)) m = 1e30f;
+        // staggered: "v" holds the world coordinate of the NODE; component f sampled as a face value sits half a cell lower along f
+        const V3 vs = g.wStaggeredPack(1, x);
+        for (int d = 0; d < 3; ++d) m = fmaxf(m, fabsf(vs[d] - (x[d] + 0.5f * 0.125f)));
+        if (g.propertyOffset("v") != 1 || g.propertyOffset("nope") != -1 || !g.hasProperty("sdf")) m = 1e30f;
+      }
+      e[i] = covered ? m : -1.f;
+    });
+    worst = 0.f;
+    int ncov = 0;
+    for (int i = 0; i < np; ++i) { worst = std::max(worst, err.data()[i]); ncov += err.data()[i] >= 0.f; }
+    CHECK(ncov > np / 2);
+    CHECK(worst < 5e-5f);
+  }
+  // ---- SparseGrid<2, f64, 8> (64-cell blocks) and SparseGrid<1, f32, 32>: the generic head; cell <-> coordinate maps, staggered cell
+  //      averages of a MAC field, cubic sampling of a linear field in double precision
+  {
+    SparseGrid<2, double, 8> g2(std::vector<PropertyTag>{{"u", 2}, {"p", 1}}, 32);
+    g2.scale(0.25);
+    g2.translate(-2.0, 1.0);
+    static_assert(SparseGrid<2, double, 8>::block_size == 64 && SparseGrid<1, float, 32>::block_size == 32 && SparseGrid<3, float, 4>::block_size == 64, "");
+    Vector<double> e2(1, memsrc_e::um);
+    e2.reset(0);
+    pol(range(16 * 16), [g = view<space>(g2)] ZS_LAMBDA(long long i) {
+      g.insert(small_vec<double, 2>{{-2.0 + 0.25 * (double)(i / 16) * 2.0, 1.0 + 0.25 * (double)(i % 16) * 2.0}});  // 32 x 32 cells
+    });
+    const std::size_t nb2 = g2.numBlocks();
+    CHECK(nb2 == 16);
+    pol(range((long long)nb2 * 64), [g = view<space>(g2)] ZS_LAMBDA(long long c) {
+      const int b = (int)(c / 64), k = (int)(c % 64);
+      const auto ic = g.iCoord(b, k);
+      const auto w = g.wCoord(b, k);
+      // MAC field u = (3 x - y, x + 2 y) stored at the face centres, p = 1 - x + 4 y at the nodes
+      const auto f0 = g.wStaggeredCoord(b, k, 0), f1 = g.wStaggeredCoord(b, k, 1);
+      g(0, b, k) = 3.0 * f0[0] - f0[1];
+      g(1, b, k) = f1[0] + 2.0 * f1[1];
+      g("p", 0, b, k) = 1.0 - w[0] + 4.0 * w[1];
+      const auto bc = g.decomposeCoord(ic);
+      if (bc.bno != b || bc.cno != k || g.local_coord_to_offset(g.local_offset_to_coord(k)) != k) g(2, b, k) = 1e300;
+    });
+    pol(range(2000), [g = view<space>(g2), e = view<space>(e2)] ZS_LAMBDA(long long i) {
+      unsigned s = 7u + (unsigned)i * 2654435761u;
+      auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / (double)(1u << 24); };
+      const small_vec<double, 2> x{{-2.0 + 1.0 + 5.5 * rnd(), 1.0 + 1.0 + 5.5 * rnd()}};  // one cell away from the border at least
+      double m = fabs(g.wSample("p", 0, x, kernel_c<kernel_e::cubic>) - (1.0 - x[0] + 4.0 * x[1]));
+      const auto u = g.wStaggeredPack(0, x);
+      m = fmax(m, fabs(u[0] - (3.0 * x[0] - x[1])));
+      m = fmax(m, fabs(u[1] - (x[0] + 2.0 * x[1])));
+      // component 1 of the MAC field at the centre of face 0 of the cell that holds x: mean of the four surrounding 1-faces
+      const auto X = g.worldToIndex(x);
+      const small_vec<int, 2> c{{(int)floor(X[0]), (int)floor(X[1])}};
+      const auto fc = g.indexToWorld(small_vec<double, 2>{{(double)c[0] - 0.5, (double)c[1]}});
+      m = fmax(m, fabs(g.iStaggeredCellSample(0, 1, c, 0) - (fc[0] + 2.0 * fc[1])));
+      m = fmax(m, fabs(g.iStaggeredCellPack(0, c, 0)[0] - (3.0 * fc[0] - fc[1])));
+      // orientation >= dim reads the opposite face = the same face of the next cell
+      m = fmax(m, fabs(g.valueOr(true_c, 0, c, 2, -1.0) - g.valueOr(false_c, 0, small_vec<int, 2>{{c[0] + 1, c[1]}}, -1.0)));
+      atomicMax((unsigned long long *)&e[0], (unsigned long long)__double_as_longlong(m));  // non-negative doubles order like integers
+    });
+    CHECK(e2.data()[0] < 1e-12);
+    SparseGrid<1, float, 32> g1(1, 8);
+    pol(range(4), [g = view<space>(g1)] ZS_LAMBDA(long long i) { g.insert(small_vec<float, 1>{{(float)(32 * i)}}); });
+    CHECK(g1.numBlocks() == 4);
   }
   // ---- LBvh: build, iter_neighbors / self_iter_neighbors inside lambdas (Bvh.hpp:644-728) vs brute force
   {

@@ -64,7 +64,7 @@ def build_cpp_face_test(verbose=True):
     (include/zensim_rocm/zs_rocm.hpp) -- proves that the face compiles with hipcc and links libzsrocm.so."""
     src = os.path.join(ROOT, "tests", "cpp", "test_cpp_face.hip")
     out = os.path.join(LIBDIR, "test_cpp_face")
-    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "bht_device.hpp"),
+    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "bht_device.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "sparse_grid.hpp"),
             os.path.join(ROOT, "include", "zensim_rocm", "collider_device.hpp"), LIB]
     if os.path.exists(src) and any(_newer(d, out) for d in deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "include"), src,
