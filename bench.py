@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: halo buffers staged through host memory -- lets N ranks share ONE GPU to validate the multi-rank path")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
+    ap.add_argument("--slot-stats", action="store_true", help="report the occupancy statistics of the slotted storage after the run")
     ap.add_argument("--checksum", action="store_true", help="print global sums of particle state after the run (N-rank vs 1-rank check)")
     ap.add_argument("--compact", action="store_true",
                     help="compact round-robin particle order + re-bin controller (round 1's storage) instead of the slotted storage "
@@ -549,6 +550,23 @@ def main():
         nt = torch.tensor([n_local], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(nt)
         n_total = int(nt.item())
+    slot_stats = None
+    if a.slotted and a.slot_stats:
+        # occupancy of the slotted storage at the end of the run: rounds a bin's producers walk (highest occupied round + 1, in chunks of
+        # four) against the particles it holds
+        m = mt.cell_mask.view(mt.nbins, 64).to(torch.int64) & 0xFFFFFFFF
+        top = torch.zeros_like(m)
+        cnt = torch.zeros_like(m)
+        for r in range(mt.K):
+            bit = (m >> r) & 1
+            top = torch.where(bit > 0, torch.full_like(top, r + 1), top)
+            cnt += bit
+        rounds = top.max(dim=1).values.float()
+        occ = rounds > 0
+        per_bin = cnt.sum(dim=1).float()
+        slot_stats = {"bins_occupied": int(occ.sum()), "mean_rounds": float(rounds[occ].mean()), "mean_chunk_rounds": float((torch.ceil(rounds[occ] / 4) * 4).mean()),
+                      "mean_particles_per_bin_div64": float(per_bin[occ].mean() / 64), "max_rounds": int(rounds.max()),
+                      "mean_max_cell_count": float(cnt.max(dim=1).values.float()[occ].mean())}
     checksum = None
     if a.checksum:
         # order-independent global sums of the particle state (float64): equal for any number of ranks up to rounding
@@ -660,6 +678,8 @@ def main():
             pass
         if checksum is not None:
             out["checksum"] = checksum
+        if slot_stats is not None:
+            out["slot_stats"] = slot_stats
         if world == 1 and a.slotted and not a.no_at_rest and any(abs(x) > 0 for x in drift_v):
             # secondary number: the same column at rest (no movers), a second short run of this script
             import subprocess

@@ -1592,10 +1592,19 @@ static __global__ __launch_bounds__(256) void grid_update_kernel(float *grid, si
       vsq = v0 * v0 + v1 * v1 + v2 * v2;
     }
   }
-  if (maxVelSqr) {  // atomic_max(maxVel, |v|^2) (GridOp.hpp:103-104): wave max, then one int-ordered atomic
+  if (maxVelSqr) {  // atomic_max(maxVel, |v|^2) (GridOp.hpp:103-104): workgroup max, then at most one int-ordered atomic
+    // One device-wide word takes ~90 atomics per microsecond: an atomic per wave of a 27 200-block grid (217 k of them) cost 2.4 ms.
+    // The maximum only grows, so a workgroup first looks at the current value and stays silent unless it can raise it.
+    __shared__ float wmax[4];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) vsq = fmaxf(vsq, shfl_down(vsq, d));
-    if (lane_id() == 0 && vsq > 0.f) atomicMax((int *)maxVelSqr, __float_as_int(vsq));
+    if (lane_id() == 0) wmax[wave_id()] = vsq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (m > 0.f && __float_as_int(m) > __hip_atomic_load((int *)maxVelSqr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax((int *)maxVelSqr, __float_as_int(m));
+    }
   }
 }
 

@@ -40,13 +40,15 @@ struct SlotArgs {
   int *moverCount;      // [nbins]
   long long *moverDest; // [nbins][cap] destination cell, packed 21 bits per axis (biased)
   float *moverRec;      // [nbins][cap][SL_REC]
-  int *status;          // [0] outbox full, [1] cell full (K), [2] mass for a block outside the partition, [3] inbox full,
-                        // [4] a particle was not stored under its cell, [5] records sent, [6] records delivered (running sums:
-                        // unequal after a step = a mover's destination block is not in the partition)
+  int *status;          // [0] outbox full, [1] cell full (K), [2] mass for a block outside the partition, [3] more than SL_MAXIN
+                        // arrivals in one cell, [4] a particle was not stored under its cell; [8 .. 8 + 256) records sent,
+                        // [264 .. 264 + 256) records delivered (running sums spread over 256 words each: unequal totals after a step = a
+                        // mover's destination block is not in the partition)
   int binBase, nbins;
   int cap;              // outbox records per bin and step (caller's choice: a bin holds 512 particles at 8 per cell)
 };
 
+constexpr int SL_NCTR = 256, SL_SENT = 8, SL_DELIVERED = 8 + SL_NCTR;  // layout of the status words (zs_rocm.h: ZS_ROCM_SLOT_STATUS_WORDS)
 __device__ __forceinline__ long long pack_cell(int x, int y, int z) {
   return ((long long)(x + (1 << 20)) << 42) | ((long long)(y + (1 << 20)) << 21) | (long long)(z + (1 << 20));
 }
@@ -131,30 +133,60 @@ static __global__ __launch_bounds__(256) void build_neighbors27_kernel(BhtDev t,
   nbr27[g] = bht_query<3>(t, k);
 }
 
+// bin next to `bin` in direction code (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1), dx, dy, dz in {-1, 0, 1}: same block or the block next to it
+template <int SIDE> __device__ __forceinline__ int neighbour_bin(const int *nbr27, int block, int bin, int code) {
+  if constexpr (SIDE == 4) {
+    return nbr27[(size_t)block * 27 + code];
+  } else {
+    const int dd[3] = {code / 9 - 1, (code / 3) % 3 - 1, code % 3 - 1};
+    const int sub = bin & 7;
+    int sx[3] = {((sub >> 2) & 1) + dd[0], ((sub >> 1) & 1) + dd[1], (sub & 1) + dd[2]}, bo[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      bo[d] = sx[d] < 0 ? -1 : (sx[d] > 1 ? 1 : 0);
+      sx[d] &= 1;
+    }
+    const int nb = nbr27[(size_t)block * 27 + ((bo[0] + 1) * 9 + (bo[1] + 1) * 3 + (bo[2] + 1))];
+    return nb < 0 ? -1 : nb * 8 + ((sx[0] * 2 + sx[1]) * 2 + sx[2]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ main kernel
-// producer wave W (0..3): round 4c + W of every chunk c; see g2p2g_rs_producer -- differences: slot addressing through the cell
-// masks, movers go to the outbox, no exact-path queues
+// Packed rounds.  The storage keeps lane = cell (a consumer lane accumulates the 27 nodes of ITS cell in registers), so a bin has as
+// many rounds as its fullest cell: 10-12 for a falling column that averages 7.5 particles per cell, i.e. a third of all (round, lane)
+// slots are holes.  The producers -- gather, advection, F, SVD + model: two thirds of the step's instructions -- do not need lane =
+// cell (they read the velocity arena by the particle's own base node), so they walk the bin's OCCUPIED slots instead, 64 at a time in
+// round-major order: entry e of the bin <-> (round r, cell c) through a table built from the occupancy words at the head of the
+// kernel.  Results are staged by entry; a consumer lane finds the entry of (r, its cell) by the same enumeration
+// (off[r] + popcount of the occupied cells below it) and consumes a round as soon as all of its entries have been produced.
+constexpr int SL_NG = 9;       // staged entry groups of 64: a chunk being produced (4) + the chunk being consumed (4) + a straddling round
+constexpr int SL_KMAX = 32;    // rounds per bin the 32-bit occupancy words allow
+
+// producer wave W (0..3): entries [64 (4c + W), +64) of every chunk c
 template <int SIDE, int SMODEL, bool WRITE_ALL, int W>
-__device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int bin, unsigned mask,
+__device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int bin, int total,
                                                     int lane, int nchunks, float *varena, float *stage, unsigned long long *smask,
-                                                    int *outCount, unsigned *clrAll, const SlotArgs &A) {
+                                                    const unsigned short *tab, int *outCount, unsigned *clrAll, const SlotArgs &A) {
   using AL = ArenaLds;
   constexpr int LW = 64;
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool FLUID = model_is_fluid(SMODEL);
   constexpr int NC = SIDE * SIDE * SIDE;
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
   const size_t rowBase = (size_t)bin * (size_t)A.K;
   RecG<LW, DP, FLUID> cur, nxt;
   bool has0 = false, has1 = false;
   size_t i0 = 0, i1 = 0;
-  unsigned clr = 0u;
+  unsigned code0 = 0, code1 = 0;
   if (nchunks > 0) {
-    has0 = (mask >> W) & 1u;
-    i0 = (rowBase + (size_t)W) * 64 + (size_t)lane;
-    if (has0) cur.load(ps, i0);
+    const int j = 64 * W + lane;
+    has0 = j < total;
+    if (has0) {
+      code0 = tab[j];
+      i0 = (rowBase + (size_t)(code0 >> 6)) * 64 + (size_t)(code0 & 63u);
+      cur.load(ps, i0);
+    }
   }
   {
     const int tid = (int)threadIdx.x;  // the four producer waves are threads 0..255
@@ -172,21 +204,26 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
   __syncthreads();
   for (int it = 0; it <= nchunks; ++it) {
     if (it < nchunks) {
-      const int par = it & 1;
-      const int r = 4 * it + W;
-      float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
+      const int grp = 4 * it + W;
+      float *myStage = stage + (size_t)(grp % SL_NG) * (G2P2G_NF * 64);
       has1 = false;
       if (it + 1 < nchunks) {
-        has1 = (mask >> (r + 4)) & 1u;
-        i1 = (rowBase + (size_t)(r + 4)) * 64 + (size_t)lane;
-        if (has1) nxt.load(ps, i1);  // in flight during this chunk
+        const int j1 = 64 * (grp + 4) + lane;
+        has1 = j1 < total;
+        if (has1) {
+          code1 = tab[j1];
+          i1 = (rowBase + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
+          nxt.load(ps, i1);  // in flight during this chunk
+        }
       }
       bool valid = false;
       if (has0) {
+        const int cell = (int)(code0 & 63u), r = (int)(code0 >> 6);
+        const int cx = cell >> 4, cy = (cell >> 2) & 3, cz = cell & 3;
         Arena ar;
         make_arena(mp.dx, cur.pos, ar);
         const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
-        if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
+        if (ocx != cx || ocy != cy || ocz != cz) {
           A.status[4] = 1;  // the storage invariant is broken (the caller moved particles without re-slotting them)
         } else {
           float vel[3], C[9];
@@ -228,7 +265,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             } else {
               A.status[0] = 1;  // outbox full: the particle (and its contribution) would be lost -- reported, the caller must react
             }
-            clr |= 1u << r;
+            atomicOr(&clrAll[cell], 1u << r);  // its slot becomes a hole
           } else {
             pstore_state<LW, FLUID>(ps.F, o, F);
             pstore<LW, 3>(ps.pos, o, pos);
@@ -272,15 +309,64 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
       }
       {
         const unsigned long long vm = __ballot(valid);
-        if (lane == 0) smask[par * 4 + W] = vm;
+        if (lane == 0) smask[grp % SL_NG] = vm;
       }
       cur = nxt;
       has0 = has1;
       i0 = i1;
+      code0 = code1;
     }
     __syncthreads();
   }
-  if (clr) atomicOr(&clrAll[lane], clr);
+}
+// consumer wave of channel set CS: lane = cell; after chunk c has been produced every round whose last entry lies below 256 (c + 1)
+// is complete and is consumed while the producers work on chunk c + 1
+template <int CS>
+__device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, unsigned mask, int total, int lane, int nchunks, const float *stage,
+                                                    const unsigned long long *smask, float *parena) {
+  using S = ConsumerSet<CS>;
+  using AL = ArenaLds;
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const float dxi = 1.0f / mp.dx;
+  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  const unsigned long long lt = lanemask_lt();
+  float acc[27][S::NA];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
+  for (int k = (int)threadIdx.x - 256; k < 7 * AL::CH; k += 256) parena[k] = 0.f;  // the four consumer waves clear the bin's arena
+  __syncthreads();  // (the producers fill the velocity arena meanwhile)
+  int r = 0, off = 0;  // next round to consume, entry number of its first particle
+  for (int it = 0; it <= nchunks; ++it) {
+    if (it > 0) {
+      const int produced = 256 * it < total ? 256 * it : total;
+#pragma unroll 1
+      while (off < total) {
+        const bool has = (mask >> r) & 1u;
+        const unsigned long long occ = __ballot(has);
+        const int cnt = __popcll(occ);
+        if (off + cnt > produced) break;  // the round's last entries belong to the chunk in production
+        if (has) {
+          const int e = off + __popcll(occ & lt);
+          const int grp = (e >> 6) % SL_NG, pos = e & 63;
+          if ((smask[grp] >> pos) & 1ull) g2p2g_consume_set<CS>(mp, stage, grp * (G2P2G_NF * 64) + pos, kscale, acc);
+        }
+        off += cnt;
+        ++r;
+      }
+    }
+    __syncthreads();
+  }
+  // the set's channels of the bin's arena belong to this wave alone; phases ordered inside the wave (see g2p2g_body)
+  float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+    for (int q = 0; q < S::NA; ++q) g[q * AL::CH] += acc[k][q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
 }
 
 template <int SIDE, int SMODEL, bool WRITE_ALL>
@@ -289,14 +375,15 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float varena[3 * AL::CH];
   __shared__ float parena[7 * AL::CH];
-  __shared__ float stage[2 * 4 * G2P2G_NF * 64];
-  __shared__ unsigned long long smask[2 * 4];
+  __shared__ float stage[SL_NG * G2P2G_NF * 64];
+  __shared__ unsigned long long smask[SL_NG];
+  __shared__ unsigned short tab[SL_KMAX * 64];  // entry -> round * 64 + cell
   __shared__ unsigned clrAll[64];
   __shared__ int outCount;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int bin = blockIdx.x + A.binBase;
   const unsigned mask = A.cellMask[(size_t)bin * 64 + lane];
-  // rounds of this bin = the highest occupied round of any of its cells (uniform loop, one barrier per chunk)
+  // round-major enumeration of the occupied slots (every wave walks the rounds; wave w fills the table rows of rounds = w mod 8)
   unsigned any = mask;
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) any |= (unsigned)__shfl_xor((int)any, sft, 64);
@@ -304,27 +391,41 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
     if (tid == 0) A.moverCount[bin] = 0;
     return;
   }
-  const int nchunks = (32 - __clz((int)any) + 3) >> 2;
+  const int nrounds = 32 - __clz((int)any);
+  int total = 0;
+  {
+    const unsigned long long lt = lanemask_lt();
+    for (int r = 0; r < nrounds; ++r) {
+      const bool has = (mask >> r) & 1u;
+      const unsigned long long occ = __ballot(has);
+      if ((r & 7) == w && has) tab[total + __popcll(occ & lt)] = (unsigned short)(r * 64 + lane);
+      total += __popcll(occ);
+    }
+  }
+  const int nchunks = (total + 255) >> 8;
   if (tid < 64) clrAll[tid] = 0u;
   if (tid == 0) outCount = 0;
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, mask, lane, nchunks, varena, stage, smask, &outCount, clrAll, A);
-  else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, mask, lane, nchunks, varena, stage, smask, &outCount, clrAll, A);
-  else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, mask, lane, nchunks, varena, stage, smask, &outCount, clrAll, A);
-  else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, mask, lane, nchunks, varena, stage, smask, &outCount, clrAll, A);
-  else if (w == 4) g2p2g_rs_consumer<0>(mp, lane, nchunks, stage, smask, parena);
-  else if (w == 5) g2p2g_rs_consumer<1>(mp, lane, nchunks, stage, smask, parena);
-  else if (w == 6) g2p2g_rs_consumer<2>(mp, lane, nchunks, stage, smask, parena);
-  else g2p2g_rs_consumer<3>(mp, lane, nchunks, stage, smask, parena);
+  __syncthreads();  // the table is complete
+  if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
+  else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
+  else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
+  else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
+  else if (w == 4) g2p2g_slot_consumer<0>(mp, mask, total, lane, nchunks, stage, smask, parena);
+  else if (w == 5) g2p2g_slot_consumer<1>(mp, mask, total, lane, nchunks, stage, smask, parena);
+  else if (w == 6) g2p2g_slot_consumer<2>(mp, mask, total, lane, nchunks, stage, smask, parena);
+  else g2p2g_slot_consumer<3>(mp, mask, total, lane, nchunks, stage, smask, parena);
   __syncthreads();  // all channel sets are in the arena, every mover is in the outbox
   if (tid < 64) {
     const unsigned c = clrAll[tid];
     if (c) A.cellMask[(size_t)bin * 64 + tid] = mask & ~c;  // (tid < 64: lane == tid, `mask` is this cell's)
   }
   if (tid == 0) {
+    // movers sent (the mover kernel counts the deliveries): running sums spread over SL_NCTR words -- one device-wide word serves ~90
+    // atomics per microsecond, i.e. 1.5 ms for one add per bin of the 64 M-particle column
     const int oc = outCount < A.cap ? outCount : A.cap;
     A.moverCount[bin] = oc;
-    if (oc) atomicAdd(&A.status[5], oc);
+    if (oc) atomicAdd(&A.status[SL_SENT + (bin & (SL_NCTR - 1))], oc);
   }
   if (tid < 216) {
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
@@ -522,23 +623,7 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
   if (tid < 64) inboxCount[tid] = 0;
   if (tid == 0) total = 0;
   if (tid < 27) {
-    // neighbour bin in direction (dx, dy, dz) in {-1,0,1}^3: same block or the block next to it
-    const int dd[3] = {tid / 9 - 1, (tid / 3) % 3 - 1, tid % 3 - 1};
-    int sb = -1;
-    if (SIDE == 4) {
-      sb = A.nbr27[(size_t)geo.block * 27 + tid];
-    } else {
-      const int sub = bin % BPB;
-      int sx[3] = {((sub >> 2) & 1) + dd[0], ((sub >> 1) & 1) + dd[1], (sub & 1) + dd[2]};
-      int bo[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        bo[d] = sx[d] < 0 ? -1 : (sx[d] > 1 ? 1 : 0);
-        sx[d] &= 1;
-      }
-      const int nb = A.nbr27[(size_t)geo.block * 27 + ((bo[0] + 1) * 9 + (bo[1] + 1) * 3 + (bo[2] + 1))];
-      sb = nb < 0 ? -1 : nb * BPB + ((sx[0] * 2 + sx[1]) * 2 + sx[2]);
-    }
+    const int sb = neighbour_bin<SIDE>(A.nbr27, geo.block, bin, tid);
     int c = 0;
     if (sb >= 0) c = A.moverCount[sb];
     srcBin[tid] = sb;
@@ -585,7 +670,7 @@ static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, Parti
   }
   if (rounds > SL_MAXIN) rounds = SL_MAXIN;
   if (rounds == 0) return;  // nothing addressed to this bin (uniform)
-  if (tid == 0) atomicAdd(&A.status[6], got);
+  if (tid == 0) atomicAdd(&A.status[SL_DELIVERED + (bin & (SL_NCTR - 1))], got);
   for (int k = tid; k < 7 * AL::CH; k += 256) parena[k] = 0.f;
   __syncthreads();
   if (w == 0) mover_role<SIDE, 0, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);

@@ -199,7 +199,7 @@ class MpmTransfer:
         self.n_slots = self.nbins * self.K * 64
         sbuf = torch.empty(self.nbins * self.K * 64 * self.nchn, dtype=torch.float32, device=self.device)
         self.cell_mask = torch.empty(self.nbins * 64, dtype=torch.int32, device=self.device)
-        self.slot_status = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.slot_status = torch.zeros(8 + 2 * 256, dtype=torch.int32, device=self.device)  # ZS_ROCM_SLOT_STATUS_WORDS
         self.nbr27 = torch.empty(self.nblocks * 27, dtype=torch.int32, device=self.device)
         L.zs_rocm_mpm_build_neighbors27(self.pol.handle, self.table.handle, self.nbr27.data_ptr(), self.kstride)
         rc = L.zs_rocm_mpm_slot_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
@@ -246,11 +246,12 @@ class MpmTransfer:
         names = ["outbox full", "a cell is full (K)", "mass for a block outside the partition", "inbox full",
                  "a particle was not stored under its cell"]
         bad = [names[k] for k in range(5) if st[k]]
+        st[5], st[6] = sum(st[8:264]), sum(st[264:520])  # the counters are spread over 256 words each
         if st[5] != st[6]:
             bad.append("%d movers sent, %d delivered (destination block not in the partition)" % (st[5], st[6]))
         if bad:
             raise RuntimeError("slotted G2P2G: " + "; ".join(bad))
-        return st
+        return st[:8]
 
     # ------------------------------------------------------------------ one sub-step
     def clear_grid(self):
