@@ -15,7 +15,7 @@ done
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$O/pmc/$name; mkdir -p $out
-  timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot_kernel|mover_pull_kernel" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-at-rest > $out/bench.json 2> $out/stderr.txt
+  timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot_kernel|mover_pull_kernel" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-at-rest > $out/bench.json 2> $out/stderr.txt
   find $out -name '*.csv' -size +8M -delete
 done
 python3 - $O <<'PY'
