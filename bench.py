@@ -313,7 +313,7 @@ def main():
         from zpc_amd.dist import gather_block_keys, near_shared_mask
         nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0)
         all_keys = None
-        if world > 1:
+        if world > 1 and (overlap or comm is None):
             all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
             if overlap:
                 # blocks whose launch must precede the exchange: 8^3 blocks hold their 4^3 bins and those bins' exact-path particles
@@ -324,7 +324,12 @@ def main():
             mt.rebin()
         stage.clear()
         h = None
-        if world > 1:
+        if world > 1 and comm is not None and not overlap:
+            # key all-gather, shared-block lists and exchange buffers inside the library (zs_rocm_dist_halo_plan_*)
+            from zpc_amd.dist import NativeHaloPlan
+            pol.syncCtx()
+            h = NativeHaloPlan(comm, pol, mt.table, mt.nblocks, a.side)
+        elif world > 1:
             my_keys = mt.active_keys()
 
             def lookup(sk):

@@ -712,6 +712,22 @@ ZS_ROCM_EXPORT int zs_rocm_dist_alltoall_i64(zs_rocm_dist *, zs_rocm_policy *, c
 ZS_ROCM_EXPORT int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *, zs_rocm_policy *, const float *send, const size_t *sendCounts,
                                               const size_t *sendOffsets, float *recv, const size_t *recvCounts, const size_t *recvOffsets);
 ZS_ROCM_EXPORT int zs_rocm_dist_barrier(zs_rocm_dist *, zs_rocm_policy *);
+/* The halo plan: which of this rank's grid blocks do other ranks hold as well (set at partition-build time).  _from_keys is the pure host
+ * part (callable without a GPU): keysAll = the ranks' key lists back to back (counts[r] keys of 3 ints, each list in its rank's block-number
+ * order); per peer that shares blocks with `rank`, in rank order: the shared keys in lexicographic order as positions in this rank's list
+ * (both sides of a pair derive the same order).  peerRank / peerOffset / peerCount: capacity world - 1; blocks: capacity = the return value
+ * (call with NULL outputs to size).  _create is collective: RCCL all-gather of the key lists (keys = the partition's activeKeys, device),
+ * plan on the host, exchange buffers allocated; _exchange = zs_rocm_dist_halo_exchange over the plan's lists and buffers. */
+typedef struct zs_rocm_halo_plan zs_rocm_halo_plan;
+ZS_ROCM_EXPORT size_t zs_rocm_halo_plan_from_keys(const int *keysAll, const size_t *counts, int world, int rank, int *npeers, int *peerRank,
+                                                  size_t *peerOffset, size_t *peerCount, int *blocks);
+ZS_ROCM_EXPORT zs_rocm_halo_plan *zs_rocm_dist_halo_plan_create(zs_rocm_dist *, zs_rocm_policy *, const int *keys, size_t nblocks, int side);
+ZS_ROCM_EXPORT void zs_rocm_dist_halo_plan_destroy(zs_rocm_halo_plan *);
+ZS_ROCM_EXPORT int zs_rocm_dist_halo_plan_npeers(const zs_rocm_halo_plan *);
+ZS_ROCM_EXPORT size_t zs_rocm_dist_halo_plan_blocks(const zs_rocm_halo_plan *);
+ZS_ROCM_EXPORT size_t zs_rocm_dist_halo_plan_bytes(const zs_rocm_halo_plan *);   /* bytes sent (= received) per exchange of all 7 channels */
+ZS_ROCM_EXPORT const int *zs_rocm_dist_halo_plan_block_list(const zs_rocm_halo_plan *);   /* device */
+ZS_ROCM_EXPORT int zs_rocm_dist_halo_plan_exchange(zs_rocm_halo_plan *, zs_rocm_dist *, zs_rocm_policy *, float *grid, int chn0, int nchn);
 
 #ifdef __cplusplus
 }

@@ -184,3 +184,37 @@ def test_abi_struct_layouts_match_the_reference(tmp_path):
         f = getattr(BhtViewLite, m)
         assert [f.offset, f.size] == want["BhtViewLite<int,3,int,16>"]["members"][m], m
     assert C.sizeof(BhtViewLite) == want["BhtViewLite<int,3,int,16>"]["size"]
+
+
+def test_native_halo_plan_matches_the_python_plan():
+    """zs_rocm_halo_plan_from_keys (host part of the native multi-GPU set-up, callable without a GPU) against the numpy construction
+    HaloExchange uses: same peers, same per-peer block lists in the same (lexicographic key) order, for every rank of random
+    overlapping partitions; both sides of every pair list the same keys in the same order."""
+    from zpc_amd.dist import halo_plan_from_keys, shared_keys
+    rng = np.random.default_rng(11)
+    for world in (1, 2, 5):
+        allk = []
+        for r in range(world):
+            k = np.unique(rng.integers(-6, 7, (int(rng.integers(0, 160)), 3)).astype(np.int32) * 8, axis=0)
+            allk.append(k[rng.permutation(k.shape[0])])  # block-number order is not key order
+        plans = [halo_plan_from_keys(allk, r) for r in range(world)]
+        for r in range(world):
+            peers, blocks = plans[r]
+            want = []
+            for p in range(world):
+                if p == r:
+                    continue
+                sk = shared_keys(allk[r], allk[p])
+                if sk.shape[0]:
+                    want.append((p, sk))
+            assert [p for p, _, _ in peers] == [p for p, _ in want]
+            off = 0
+            for (p, o, c), (_, sk) in zip(peers, want):
+                assert o == off and c == sk.shape[0]
+                assert np.array_equal(allk[r][blocks[o:o + c]], sk)  # my block numbers, in the shared (sorted) key order
+                # the peer lists the same keys in the same order
+                pp, pb = plans[p]
+                q = [x for x in pp if x[0] == r][0]
+                assert np.array_equal(allk[p][pb[q[1]:q[1] + q[2]]], sk)
+                off += c
+            assert blocks.shape[0] == off

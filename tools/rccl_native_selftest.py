@@ -82,6 +82,13 @@ for side in (4, 8):
     want[1, 1:4] *= 9
     assert torch.allclose(grid, want, rtol=1e-6), side
 
+# the halo plan (key all-gather + plan + buffers inside the library): world 1 = nobody to share with
+from zpc_amd.dist import NativeHaloPlan  # noqa: E402
+keys = torch.tensor([[0, 0, 0], [8, 0, 0], [8, 8, -16]], dtype=torch.int32, device=dev)
+plan = NativeHaloPlan(comm, pol, keys.data_ptr(), 3, 8)
+assert plan.total_blocks == 0 and len(plan.peers) == 0 and plan.bytes_per_exchange == 0
+plan.exchange_native(comm, pol, torch.zeros(3, 7, 512, device=dev), 8)  # no-op
+del plan
 comm.barrier(pol)
 assert zpc_amd.lib().zs_rocm_last_error(0) == 0
 del comm

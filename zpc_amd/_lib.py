@@ -120,6 +120,21 @@ def _declare(L):
     L.zs_rocm_dist_alltoall_i64.argtypes = [vp, vp, vp, vp]
     L.zs_rocm_dist_alltoallv_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.zs_rocm_dist_barrier.argtypes = [vp, vp]
+    L.zs_rocm_halo_plan_from_keys.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.zs_rocm_halo_plan_from_keys.restype = sz
+    L.zs_rocm_dist_halo_plan_create.argtypes = [vp, vp, vp, sz, i32]
+    L.zs_rocm_dist_halo_plan_create.restype = vp
+    L.zs_rocm_dist_halo_plan_destroy.argtypes = [vp]
+    L.zs_rocm_dist_halo_plan_npeers.argtypes = [vp]
+    L.zs_rocm_dist_halo_plan_npeers.restype = i32
+    L.zs_rocm_dist_halo_plan_blocks.argtypes = [vp]
+    L.zs_rocm_dist_halo_plan_blocks.restype = sz
+    L.zs_rocm_dist_halo_plan_bytes.argtypes = [vp]
+    L.zs_rocm_dist_halo_plan_bytes.restype = sz
+    L.zs_rocm_dist_halo_plan_block_list.argtypes = [vp]
+    L.zs_rocm_dist_halo_plan_block_list.restype = vp
+    L.zs_rocm_dist_halo_plan_exchange.argtypes = [vp, vp, vp, vp, i32, i32]
+    L.zs_rocm_dist_halo_plan_exchange.restype = i32
     L.zs_rocm_mpm_slot_outbox_bytes.argtypes = [sz, i32, i32]
     L.zs_rocm_mpm_slot_outbox_bytes.restype = sz
     L.zs_rocm_mpm_build_neighbors27.argtypes = [vp, vp, vp, i32]

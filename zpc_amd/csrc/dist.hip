@@ -11,7 +11,10 @@
 // all-to-all, which needs the receive counts on the host to size the buffer (the caller passes them in).
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "common.hpp"
 
@@ -89,6 +92,156 @@ int zs_rocm_dist_halo_exchange(zs_rocm_dist *d, zs_rocm_policy *pol, float *grid
   }
   zs_rocm_mpm_halo_unpack(pol, grid, blocks, totalBlocks, side, chn0, nchn, recvbuf, 2);  // atomic add: corner blocks appear once per peer
   return 0;
+}
+
+// ---- the halo plan: which of this rank's grid blocks do other ranks hold as well?
+// Pure host part (no GPU, no communicator: also what the CPU tests call): keysAll = the ranks' block-key lists back to back
+// (counts[r] keys of 3 ints each, rank r's list in ITS block-number order), rank = this rank.  For every peer that shares at least one
+// key, in rank order: the shared keys in lexicographic order (the order both sides derive independently) as positions in THIS rank's
+// list.  Outputs: peerRank / peerOffset / peerCount (capacity world - 1), blocks (capacity: returned total; pass NULL to size).
+// Returns the total number of (peer, block) pairs; *npeers = number of peers.
+size_t zs_rocm_halo_plan_from_keys(const int *keysAll, const size_t *counts, int world, int rank, int *npeers, int *peerRank,
+                                   size_t *peerOffset, size_t *peerCount, int *blocks) {
+  struct Key {
+    int k[3];
+    bool operator<(const Key &o) const { return k[0] != o.k[0] ? k[0] < o.k[0] : (k[1] != o.k[1] ? k[1] < o.k[1] : k[2] < o.k[2]); }
+    bool operator==(const Key &o) const { return k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
+  };
+  std::vector<size_t> start(world + 1, 0);
+  for (int r = 0; r < world; ++r) start[r + 1] = start[r] + counts[r];
+  // this rank's keys sorted, with their block numbers
+  std::vector<std::pair<Key, int>> mine(counts[rank]);
+  for (size_t i = 0; i < counts[rank]; ++i) {
+    const int *q = keysAll + 3 * (start[rank] + i);
+    mine[i] = {Key{{q[0], q[1], q[2]}}, (int)i};
+  }
+  std::sort(mine.begin(), mine.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+  size_t total = 0;
+  int np = 0;
+  std::vector<Key> theirs;
+  for (int p = 0; p < world; ++p) {
+    if (p == rank || counts[p] == 0 || mine.empty()) continue;
+    theirs.resize(counts[p]);
+    for (size_t i = 0; i < counts[p]; ++i) {
+      const int *q = keysAll + 3 * (start[p] + i);
+      theirs[i] = Key{{q[0], q[1], q[2]}};
+    }
+    std::sort(theirs.begin(), theirs.end());
+    size_t a = 0, b = 0, n = 0;
+    while (a < mine.size() && b < theirs.size()) {  // merge walk: both sides visit the shared keys in ascending order
+      if (mine[a].first < theirs[b]) ++a;
+      else if (theirs[b] < mine[a].first) ++b;
+      else {
+        if (blocks) blocks[total + n] = mine[a].second;
+        ++n, ++a, ++b;
+      }
+    }
+    if (n) {
+      if (peerRank) {
+        peerRank[np] = p;
+        peerOffset[np] = total;
+        peerCount[np] = n;
+      }
+      ++np;
+      total += n;
+    }
+  }
+  if (npeers) *npeers = np;
+  return total;
+}
+
+struct zs_rocm_halo_plan {
+  int device = 0, side = 0, npeers = 0;
+  size_t total = 0;
+  std::vector<int> peerRank;
+  std::vector<size_t> peerOffset, peerCount;
+  int *blocks = nullptr;            // device: [total] local block numbers, per-peer slices
+  float *sendbuf = nullptr, *recvbuf = nullptr;  // device: total * 7 * side^3 floats each
+};
+// Collective.  keys: device pointer to this rank's block keys (3 ints per block, block-number order: a bht's activeKeys), nblocks of
+// them; side = 4 | 8.  All-gathers the key lists over RCCL, derives the plan on the host and allocates the exchange buffers.
+zs_rocm_halo_plan *zs_rocm_dist_halo_plan_create(zs_rocm_dist *d, zs_rocm_policy *pol, const int *keys, size_t nblocks, int side) {
+  if (!d || (side != 4 && side != 8)) return nullptr;
+  Launch L(pol, "halo_plan");
+  auto *plan = new zs_rocm_halo_plan;
+  plan->device = d->device;
+  plan->side = side;
+  const int world = d->world;
+  // counts, then keys padded to the longest list
+  unsigned long long *cntD = (unsigned long long *)L.temp(sizeof(unsigned long long) * (size_t)(world + 1));
+  const unsigned long long mineCnt = nblocks;
+  std::vector<unsigned long long> cntH(world);
+  bool ok = hipMemcpyAsync(cntD + world, &mineCnt, sizeof(mineCnt), hipMemcpyHostToDevice, L.stream) == hipSuccess;
+  ok = ok && ncclAllGather(cntD + world, cntD, 1, ncclUint64, d->comm, L.stream) == ncclSuccess;
+  ok = ok && hipMemcpyAsync(cntH.data(), cntD, sizeof(unsigned long long) * world, hipMemcpyDeviceToHost, L.stream) == hipSuccess;
+  ok = ok && hipStreamSynchronize(L.stream) == hipSuccess;
+  if (!ok) {
+    report_error(hipErrorUnknown, "halo plan: count all-gather", __FILE__, __LINE__);
+    delete plan;
+    return nullptr;
+  }
+  size_t mx = 1;
+  for (int r = 0; r < world; ++r) mx = std::max<size_t>(mx, cntH[r]);
+  int *padD = (int *)L.temp(sizeof(int) * 3 * mx * (size_t)(world + 1));
+  int *mineD = padD + 3 * mx * (size_t)world;
+  ok = hipMemsetAsync(mineD, 0, sizeof(int) * 3 * mx, L.stream) == hipSuccess;
+  if (nblocks) ok = ok && hipMemcpyAsync(mineD, keys, sizeof(int) * 3 * nblocks, hipMemcpyDeviceToDevice, L.stream) == hipSuccess;
+  ok = ok && ncclAllGather(mineD, padD, 3 * mx, ncclInt32, d->comm, L.stream) == ncclSuccess;
+  std::vector<int> padH(3 * mx * (size_t)world);
+  ok = ok && hipMemcpyAsync(padH.data(), padD, sizeof(int) * padH.size(), hipMemcpyDeviceToHost, L.stream) == hipSuccess;
+  ok = ok && hipStreamSynchronize(L.stream) == hipSuccess;
+  if (!ok) {
+    report_error(hipErrorUnknown, "halo plan: key all-gather", __FILE__, __LINE__);
+    delete plan;
+    return nullptr;
+  }
+  std::vector<int> keysAll;
+  std::vector<size_t> counts(world);
+  for (int r = 0; r < world; ++r) {
+    counts[r] = cntH[r];
+    keysAll.insert(keysAll.end(), padH.begin() + 3 * mx * (size_t)r, padH.begin() + 3 * (mx * (size_t)r + counts[r]));
+  }
+  int np = 0;
+  const size_t total = zs_rocm_halo_plan_from_keys(keysAll.data(), counts.data(), world, d->rank, &np, nullptr, nullptr, nullptr, nullptr);
+  plan->npeers = np;
+  plan->total = total;
+  plan->peerRank.resize(np);
+  plan->peerOffset.resize(np);
+  plan->peerCount.resize(np);
+  std::vector<int> blocksH(total);
+  zs_rocm_halo_plan_from_keys(keysAll.data(), counts.data(), world, d->rank, &np, plan->peerRank.data(), plan->peerOffset.data(),
+                              plan->peerCount.data(), blocksH.data());
+  if (total) {
+    DeviceGuard guard(d->device);
+    const size_t bf = (size_t)7 * side * side * side;
+    ok = hipMalloc((void **)&plan->blocks, sizeof(int) * total) == hipSuccess && hipMalloc((void **)&plan->sendbuf, sizeof(float) * total * bf) == hipSuccess
+         && hipMalloc((void **)&plan->recvbuf, sizeof(float) * total * bf) == hipSuccess
+         && hipMemcpy(plan->blocks, blocksH.data(), sizeof(int) * total, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+      report_error(hipErrorOutOfMemory, "halo plan: buffers", __FILE__, __LINE__);
+      zs_rocm_dist_halo_plan_destroy(plan);
+      return nullptr;
+    }
+  }
+  return plan;
+}
+void zs_rocm_dist_halo_plan_destroy(zs_rocm_halo_plan *p) {
+  if (!p) return;
+  DeviceGuard guard(p->device);
+  if (p->blocks) (void)hipFree(p->blocks);
+  if (p->sendbuf) (void)hipFree(p->sendbuf);
+  if (p->recvbuf) (void)hipFree(p->recvbuf);
+  delete p;
+}
+int zs_rocm_dist_halo_plan_npeers(const zs_rocm_halo_plan *p) { return p ? p->npeers : 0; }
+size_t zs_rocm_dist_halo_plan_blocks(const zs_rocm_halo_plan *p) { return p ? p->total : 0; }
+size_t zs_rocm_dist_halo_plan_bytes(const zs_rocm_halo_plan *p) { return p ? p->total * (size_t)7 * p->side * p->side * p->side * sizeof(float) : 0; }
+const int *zs_rocm_dist_halo_plan_block_list(const zs_rocm_halo_plan *p) { return p ? p->blocks : nullptr; }
+// the exchange of zs_rocm_dist_halo_exchange over the plan's own lists and buffers
+int zs_rocm_dist_halo_plan_exchange(zs_rocm_halo_plan *p, zs_rocm_dist *d, zs_rocm_policy *pol, float *grid, int chn0, int nchn) {
+  if (!p || !p->total) return 0;
+  return zs_rocm_dist_halo_exchange(d, pol, grid, p->side, chn0, nchn, p->blocks, p->total, p->npeers, p->peerRank.data(), p->peerOffset.data(),
+                                    p->peerCount.data(), p->sendbuf, p->recvbuf);
 }
 
 // in-place allreduce of n floats / int64 on the device; op 0 = sum, 1 = max, 2 = min

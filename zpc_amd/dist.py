@@ -183,6 +183,50 @@ class HaloExchange:
             raise RuntimeError("zs_rocm_dist_halo_exchange failed")
 
 
+def halo_plan_from_keys(all_keys, rank):
+    """zs_rocm_halo_plan_from_keys (host part of the native halo plan, no GPU needed): list of (peer, offset, count) and the
+    concatenated local block numbers, from every rank's [n,3] key list"""
+    import ctypes as C
+    from ._lib import lib
+    world = len(all_keys)
+    counts = (C.c_size_t * world)(*[int(k.shape[0]) for k in all_keys])
+    cat = np.ascontiguousarray(np.concatenate([np.asarray(k, np.int32).reshape(-1, 3) for k in all_keys]), dtype=np.int32)
+    npeers = C.c_int(0)
+    pr, po, pc = (C.c_int * max(world, 1))(), (C.c_size_t * max(world, 1))(), (C.c_size_t * max(world, 1))()
+    total = lib().zs_rocm_halo_plan_from_keys(cat.ctypes.data, counts, world, rank, C.byref(npeers), None, None, None, None)
+    blocks = np.zeros(max(total, 1), np.int32)
+    lib().zs_rocm_halo_plan_from_keys(cat.ctypes.data, counts, world, rank, C.byref(npeers), pr, po, pc, blocks.ctypes.data)
+    return [(int(pr[k]), int(po[k]), int(pc[k])) for k in range(npeers.value)], blocks[:total]
+
+
+class NativeHaloPlan:
+    """zs_rocm_halo_plan: key all-gather (RCCL), plan and exchange buffers all inside libzsrocm.so; same face as HaloExchange"""
+
+    def __init__(self, comm, pol, table, nblocks, side):
+        from ._lib import lib
+        L = lib()
+        keys = table.view().activeKeys if hasattr(table, "view") else table
+        self._h = L.zs_rocm_dist_halo_plan_create(comm._h, pol.handle, keys, nblocks, side)
+        if not self._h:
+            raise RuntimeError("zs_rocm_dist_halo_plan_create failed")
+        self.total_blocks = L.zs_rocm_dist_halo_plan_blocks(self._h)
+        self.bytes_per_exchange = L.zs_rocm_dist_halo_plan_bytes(self._h)
+        self.peers = [None] * L.zs_rocm_dist_halo_plan_npeers(self._h)  # (only their number is needed on this side)
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if self._h:
+                lib().zs_rocm_dist_halo_plan_destroy(self._h)
+        except Exception:
+            pass
+
+    def exchange_native(self, comm, pol, grid, side, chn0=0, nchn=7):
+        from ._lib import lib
+        if lib().zs_rocm_dist_halo_plan_exchange(self._h, comm._h, pol.handle, grid.data_ptr(), chn0, nchn) != 0:
+            raise RuntimeError("zs_rocm_dist_halo_plan_exchange failed")
+
+
 class NativeComm:
     """Thin mirror of zs_rocm_dist (zpc_amd/csrc/dist.hip): the RCCL communicator of this process.  The unique id is created on
     rank 0 and handed round by whatever the launcher offers -- here a torch.distributed broadcast; a C++ host passes the bytes
