@@ -330,6 +330,8 @@ def main():
             pol.syncCtx()
             h = NativeHaloPlan(comm, pol, mt.table, mt.nblocks, a.side)
         elif world > 1:
+            if all_keys is None:
+                all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
             my_keys = mt.active_keys()
 
             def lookup(sk):
