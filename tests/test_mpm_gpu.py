@@ -724,3 +724,59 @@ def test_slotted_steps_of_a_moving_cloud_vs_oracle(pol, oracle, side, model):
     c0 = np.floor(pos / dx - 0.5).astype(int)
     c1 = np.floor(po / dx - 0.5).astype(int)
     assert (np.abs(c1 - c0).max(axis=1) >= 1).mean() > 0.8
+
+
+@pytest.mark.parametrize("side", [8, 4])
+def test_slotted_uneven_cells_many_sparse_rounds_vs_oracle(pol, oracle, side):
+    """A cloud whose density varies by a factor of ~25 from cell to cell (up to ~25 particles in a cell next to cells with one): the
+    bins have many sparse rounds, which the packed producers walk several to a group and the consumers still take one by one
+    (entry table, staged-entry ring, rounds completing in the middle of a chunk).  Four slotted steps with motion against the oracle."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-3
+    g = rng(2024 + side)
+    # a 10^3-cell box; per cell a particle count drawn from a heavy-tailed distribution
+    cells = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(10), indexing="ij"), -1).reshape(-1, 3)
+    cnt = np.minimum(1 + (g.pareto(1.2, cells.shape[0]) * 2).astype(int), 25)
+    org = np.array([0.30, 0.31, 0.29])
+    pos = np.concatenate([org + (c + 0.5 + g.random((k, 3))) * dx for c, k in zip(cells, cnt)]).astype(np.float32)  # base node = c
+    n = pos.shape[0]
+    assert cnt.max() >= 20 and (cnt == 1).sum() > 50
+    mass = (1000.0 * dx ** 3 / 8 * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)
+    vel = (0.3 * g.standard_normal((n, 3)) + np.array([3.0, -4.0, 2.0])).astype(np.float32)  # ~0.2-0.25 cell per step
+    Cm = (0.1 * g.standard_normal((n, 9))).astype(np.float32)
+    F = (np.eye(3).reshape(1, 9) + 0.01 * g.standard_normal((n, 9))).astype(np.float32)
+    lj = np.zeros(n, np.float32)
+    vol = dx ** 3 / 8
+    om = OracleMpm(oracle, 1, dx, dt, side, vol)
+    mt = MpmTransfer(pol, n, dx, dt, model=1, side=side, volume=vol, cache_stress=True)
+    mt.upload(mass, pos, vel, Cm, F, lj)
+    mt.build_partition(n, margin=1)
+    om.adopt_partition(mt.active_keys())
+    ljo = lj.copy()
+    om.p2g(mass, pos, vel, Cm, F, ljo)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    om.grid_update((0.0, -9.8, 0.0))
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.slot(K=32, outbox_cap=512)
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    for step in range(4):
+        om.g2p(po, vo, Co, Fo)
+        om.grid[:] = 0
+        om.p2g(mass, po, vo, Co, Fo, ljo)
+        mt.g2p2g(write_all=(step == 3))
+        pol.syncCtx()
+        mt.check_slots()
+        ga = mt.grid.cpu().numpy().reshape(om.grid.shape)
+        scale = np.abs(om.grid).max(axis=(0, 2)) + 1e-30
+        assert (np.abs(ga - om.grid).max(axis=(0, 2)) <= 3e-4 * scale).all(), (step, np.abs(ga - om.grid).max(axis=(0, 2)) / scale)
+        om.grid_update((0.0, -9.8, 0.0))
+        mt.grid_update((0.0, -9.8, 0.0))
+    d = _by_mass(mt.download())
+    o = _id_order(mass, po)
+    assert np.array_equal(d["m"], mass[o])
+    assert np.abs(d["x"] - po[o]).max() <= 2e-6
+    assert np.abs(d["v"] - vo[o]).max() <= 2e-4 * np.abs(vo).max()
+    assert np.abs(d["F"] - Fo[o]).max() <= 5e-5
