@@ -229,7 +229,12 @@ def main():
     pol = zpc_amd.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     # the exchange steps run inside libzsrocm.so on RCCL (zs_rocm_dist_*); torch.distributed only launches the ranks, carries the
     # unique id and brackets the timed region
-    comm = NativeComm(rank, world, local_rank, dist) if (world > 1 and a.backend == "nccl" and a.comm == "native") else None
+    comm = None
+    if world > 1 and a.backend == "nccl" and a.comm == "native":
+        try:
+            comm = NativeComm(rank, world, local_rank, dist)
+        except RuntimeError as e:  # (ncclCommInitRank is collective: it fails on every rank or on none)
+            print("[bench] native RCCL communicator unavailable (%s): exchange steps go through torch.distributed" % e, file=sys.stderr)
     max_vel = torch.zeros(1, dtype=torch.float32, device=device)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
     drift_v = [float(x) for x in a.drift.split(",")]
