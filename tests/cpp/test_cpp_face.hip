@@ -127,18 +127,18 @@ int main() {
     for (int i = 0; i < n; ++i) h[i] = (i * 7919) % 100003 - 50000;
     Vector<int> a(n), b(n);
     Vector<int> out(1, memsrc_e::um);
-    hipMemcpy(a.data(), h.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(a.data(), h.data(), n * 4, hipMemcpyHostToDevice);
     reduce(pol, a.data(), a.data() + n, out.data(), 0, plus<int>{});
     CHECK(out.data()[0] == (int)std::accumulate(h.begin(), h.end(), 0ll));
     reduce(pol, a.data(), a.data() + n, out.data(), std::numeric_limits<int>::lowest(), getmax<int>{});
     CHECK(out.data()[0] == *std::max_element(h.begin(), h.end()));
     exclusive_scan(pol, a.data(), a.data() + n, b.data());
     std::vector<int> r(n);
-    hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
     int acc = 0;
     for (int i = 0; i < n; ++i) { CHECK(r[i] == acc); acc += h[i]; }
     radix_sort(pol, a.data(), a.data() + n, b.data());
-    hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(r.data(), b.data(), n * 4, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     CHECK(r == h);
   }
@@ -149,8 +149,8 @@ int main() {
     unsigned s = 12345u;
     for (int i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; hk[i] = (int)(s >> 8) % 1000 - 500; hv[i] = i; }
     Vector<int> k(n, memsrc_e::device), v(n, memsrc_e::device);
-    hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
-    hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
     // order by |key| descending: a comparator no radix sort can express directly
     auto comp = [] ZS_LAMBDA(int a, int b) { return (a < 0 ? -a : a) > (b < 0 ? -b : b); };
     merge_sort_pair(pol, k.data(), v.data(), (std::size_t)n, comp);
@@ -158,16 +158,16 @@ int main() {
     std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::abs(hk[a]) > std::abs(hk[b]); });
     std::vector<int> rk(n), rv(n);
-    hipMemcpy(rk.data(), k.data(), n * 4, hipMemcpyDeviceToHost);
-    hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(rk.data(), k.data(), n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
     for (int i = 0; i < n; ++i) { CHECK(rv[i] == idx[i]); CHECK(rk[i] == hk[idx[i]]); }
     // indirect sort: permutation ordered by an external key array captured in the comparator (LBvh-style)
-    hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
-    hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(k.data(), hk.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(v.data(), hv.data(), n * 4, hipMemcpyHostToDevice);
     merge_sort(pol, v.data(), v.data() + n, [key = k.data()] ZS_LAMBDA(int a, int b) { return key[a] < key[b]; });
     std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hk[a] < hk[b]; });
-    hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(rv.data(), v.data(), n * 4, hipMemcpyDeviceToHost);
     CHECK(rv == idx);
     // struct keys (16 bytes) with the default zs::less through operator<
     struct Key { double d; int tag; int pad;
@@ -175,14 +175,14 @@ int main() {
     std::vector<Key> hs(5000);
     for (int i = 0; i < 5000; ++i) hs[i] = Key{(double)(hk[i] % 17), i, 0};
     Key *ds;
-    hipMalloc((void **)&ds, sizeof(Key) * hs.size());
-    hipMemcpy(ds, hs.data(), sizeof(Key) * hs.size(), hipMemcpyHostToDevice);
+    (void)hipMalloc((void **)&ds, sizeof(Key) * hs.size());
+    (void)hipMemcpy(ds, hs.data(), sizeof(Key) * hs.size(), hipMemcpyHostToDevice);
     sort(pol, ds, ds + hs.size());
     std::stable_sort(hs.begin(), hs.end());
     std::vector<Key> rs(hs.size());
-    hipMemcpy(rs.data(), ds, sizeof(Key) * hs.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(rs.data(), ds, sizeof(Key) * hs.size(), hipMemcpyDeviceToHost);
     for (size_t i = 0; i < hs.size(); ++i) CHECK(rs[i].tag == hs[i].tag);
-    hipFree(ds);
+    (void)hipFree(ds);
   }
   // ---- launcher shapes: Collapse{nb, nt}, Collapse{nb, ntiles, tileSize}, shmem-first lambdas
   {
@@ -432,7 +432,7 @@ int main() {
       for (int d = 0; d < 3; ++d) { b.lo[d] = c[d] - e; b.hi[d] = c[d] + e; }
     }
     Vector<AABBBox3f> bvs(n, memsrc_e::device);
-    hipMemcpy(bvs.data(), hb.data(), sizeof(AABBBox3f) * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(bvs.data(), hb.data(), sizeof(AABBBox3f) * n, hipMemcpyHostToDevice);
     LBvh bvh;
     bvh.build(pol, bvs);
     CHECK(bvh.getNumLeaves() == (std::size_t)n && bvh.getNumNodes() == (std::size_t)(2 * n - 1));
