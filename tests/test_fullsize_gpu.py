@@ -167,3 +167,19 @@ def test_config4_sand_64m_fused_equals_unfused():
     # mass channel: sum == n * m exactly in float64 (every particle still there, once)
     m = 1000.0 * (1.0 / 512) ** 3 / 8
     assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
+
+
+def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
+    """24 steps of the falling 64 Mi-particle column (1.3 cells of travel: a third of the particles change cell, every bin's rounds
+    have become uneven): the slotted step -- packed producers, movers through the outboxes, no re-bin -- against the compact storage
+    with the re-bin controller; same particle state, every mover delivered, nobody lost."""
+    base = ["--steps", "24", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"]
+    a = _bench(base + ["--slot-stats"])
+    b = _bench(base + ["--compact", "--rebin-check", "2"])
+    n = 67_108_864
+    assert a["config"]["particles"] == n and a["hip_error"] == 0 and b["hip_error"] == 0
+    assert a["config"]["rebins"] == 0 and b["config"]["rebins"] > 0
+    assert a["slot_stats"]["mean_rounds"] > a["slot_stats"]["mean_particles_per_bin_div64"] + 1.0  # the regime the packing is for
+    _same_state(a["checksum"], b["checksum"], n, 1e-4, 3e-4)
+    m = 1000.0 * (1.0 / 512) ** 3 / 8
+    assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
