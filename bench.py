@@ -702,6 +702,12 @@ def main():
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 j = json.loads(r.stdout.strip().splitlines()[-1])
                 out["config"]["at_rest_ms_per_step"] = j["ms_per_step"]
+                # ... and at rest on compact storage: the workload and storage round 1 quoted its headline on (role-split kernel)
+                r = subprocess.run(cmd + ["--compact"], capture_output=True, text=True, timeout=600)
+                j2 = json.loads(r.stdout.strip().splitlines()[-1])
+                out["secondary"] = {"at_rest_slotted": {"ms_per_step": j["ms_per_step"], "roofline_frac": j["roofline"]["frac"]},
+                                    "at_rest_compact": {"ms_per_step": j2["ms_per_step"], "roofline_frac": j2["roofline"]["frac"],
+                                                        "note": "particles at rest, dense binned storage: the r01 headline workload"}}
             except Exception as e:
                 out["config"]["at_rest_ms_per_step"] = None
                 print("at-rest run failed: %r" % (e,), file=sys.stderr)
