@@ -370,8 +370,7 @@ __global__ __launch_bounds__(256) void radix_global_hist_kernel(Port<const K> ke
   for (int p = 0; p < NPASS; ++p) h[p][threadIdx.x] = 0;
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const K k = keys[i];
+  auto count = [&](K k) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int st = sbit + 8 * p;
@@ -380,7 +379,18 @@ __global__ __launch_bounds__(256) void radix_global_hist_kernel(Port<const K> ke
         atomicAdd(&h[p][KeyBits<K>::digit(k, st, (1u << bits) - 1u)], 1u);  // ds_add_u32: full rate (unlike ds_add_f32)
       }
     }
+  };
+  // eight independent loads in flight per thread (one load per trip left the kernel at 1.9 TB/s: 64 M keys in 140 us)
+  constexpr int U = 8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    K k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = keys[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) count(k[u]);
   }
+  for (; i < n; i += stride) count(keys[i]);
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < NPASS; ++p)
