@@ -288,3 +288,14 @@ def test_empty_ranges(pol):
     zs.merge_sort(pol, guard[:0])
     pol.syncCtx()
     assert (guard.cpu().numpy() == -5).all() and zs.lib().zs_rocm_last_error(-1) == 0
+
+
+def test_radix_sort_randomised_stress():
+    """tools/sort_stress.py: 120 random sizes (1 .. 5 M keys, ragged last tiles), four key ranges (2 values .. 31 bits), keys and pairs,
+    against torch.sort(stable=True) -- the decoupled look-back with early tile aggregates must be independent of timing"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_stress.py"), "120"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])

@@ -407,11 +407,13 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
   __shared__ unsigned globalStart[256];  // start of this tile's run of digit d in the output
   __shared__ unsigned sWave[4], sWave2[4];
   __shared__ unsigned sTile;
+  __shared__ unsigned thist[256];        // the tile's digit histogram, taken BEFORE the ranking (see below)
   __shared__ K keyS[TILE];
   __shared__ int valS[PAIR ? TILE : 1];
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
   if (t == 0) sTile = atomicAdd(ticket, 1u);
   for (int i = t; i < NW * 256; i += BLOCK) (&cnt[0][0])[i] = 0;
+  if (t < 256) thist[t] = 0;
   // global start of digit t = exclusive scan of this pass's 256-bin histogram (every tile redoes the 256-element scan: cheaper than
   // a launch of its own); partial sums of the four waves go through sWave
   // (the load is issued here and consumed after the ranking)
@@ -446,6 +448,22 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
       }
     }
   }
+  // The tile's aggregate is published as early as possible: a plain LDS histogram of the digits (16 ds_add_u32 per thread) right after
+  // the loads, ~1 us into the tile, instead of after the ranking (~5 us later).  Measured before this change at 64 M keys: a look-back
+  // consumed 42 predecessor descriptors in 20 polling round trips -- most polls ran into tiles that were still ranking -- and the
+  // look-back cost 0.36 of the sort's 0.98 ms.  With early aggregates the successors' look-backs find their predecessors published.
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) atomicAdd(&thist[KeyBits<K>::digit(key[k], st, mask)], 1u);
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (base + (size_t)k * 64 < n) atomicAdd(&thist[KeyBits<K>::digit(key[k], st, mask)], 1u);
+  }
+  __syncthreads();
+  unsigned *myDesc = desc + (size_t)tile * 256 + t;
+  if (t < 256)
+    __hip_atomic_store(myDesc, (tile == 0 ? OS_FLAG_PREFIX : OS_FLAG_AGG) | thist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   volatile unsigned *wc = cnt[w];
   const unsigned long long lt = lanemask_lt();
   const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
@@ -481,7 +499,6 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
   __syncthreads();
   // thread t < 256 owns digit t: wave offsets, tile count, chained scan
   unsigned myCount = 0, excl = 0;
-  unsigned *myDesc = desc + (size_t)tile * 256 + t;
   if (t < 256) {
     unsigned run = 0;
 #pragma unroll
@@ -490,8 +507,7 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
       cnt[i][t] = run;
       run += c;
     }
-    myCount = run;
-    __hip_atomic_store(myDesc, (tile == 0 ? OS_FLAG_PREFIX : OS_FLAG_AGG) | myCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    myCount = run;  // (== thist[t], published above)
     // exclusive scan of the 256 tile counts -> tileStart (wave level, combined below)
     unsigned s = myCount;
 #pragma unroll
