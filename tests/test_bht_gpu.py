@@ -33,7 +33,9 @@ def _d2h(ptr, nbytes):
                                                (3, 1, 5, 16), (3, 100_000, 2, 16),
                                                # dim 4 (status-lock protocol) and bucket 32 (py_interop/BhtInstantiations.cpp:120-127)
                                                (4, 4096, 12, 16), (4, 200_000, 14, 16), (4, 100_000, 2, 16), (4, 1, 5, 32),
-                                               (1, 30_000, 20_000, 32), (2, 50_000, 300, 32), (3, 200_000, 40, 32), (4, 150_000, 10, 32)])
+                                               (1, 30_000, 20_000, 32), (2, 50_000, 300, 32), (3, 200_000, 40, 32), (4, 150_000, 10, 32),
+                                               # larger batches: mostly distinct keys, heavy duplication, few distinct keys, bucket 32
+                                               (3, 400_000, 60, 16), (3, 1_000_000, 30, 16), (3, 300_000, 3, 16), (3, 500_000, 50, 32)])
 def test_build_query_set_exact(pol, oracle, dim, n, span, bucket):
     from zpc_amd.containers import Bht
     g = rng(20 + dim)
@@ -126,3 +128,44 @@ def test_assign_adopts_external_numbering(pol, oracle):
     assert np.array_equal(ret.cpu().numpy(), np.arange(n))
     act = _d2h(tab.view().activeKeys, n * 12).reshape(n, 3)
     assert np.array_equal(act, keys)
+
+
+def test_three_batches_into_one_table(pol, oracle):
+    """three insert calls (50 k, 600 k, 20 k keys, overlapping) into one table: the union is what the oracle's sequential insertion of
+    all three batches holds; indices stay dense and unique; `ret` tells new keys (their index) from known ones (-1) in every batch."""
+    from zpc_amd.containers import Bht
+    g = rng(91)
+    a = g.integers(-40, 40, (50_000, 3), dtype=np.int32)
+    b = g.integers(-45, 45, (600_000, 3), dtype=np.int32)      # overlaps a
+    c = g.integers(-50, 50, (20_000, 3), dtype=np.int32)
+    allk = np.concatenate([a, b, c])
+    tab = Bht(3, allk.shape[0])
+    t, on, oact = _oracle_table(oracle, 3, allk, allk.shape[0])
+    seen = set()
+    base = 0
+    for batch in (a, b, c):
+        d = torch.from_numpy(batch).cuda()
+        ret = torch.empty(batch.shape[0], dtype=torch.int32, device="cuda")
+        tab.insert(pol, d.data_ptr(), batch.shape[0], ret.data_ptr())
+        r = ret.cpu().numpy()
+        size = tab.size()
+        won = r[r >= 0]
+        assert np.array_equal(np.sort(won), np.arange(base, size))     # the new keys took the next dense indices
+        newkeys = set(map(tuple, batch[r >= 0]))
+        assert len(newkeys) == won.size and not (newkeys & seen)
+        assert set(map(tuple, batch[r < 0])) <= (seen | newkeys)          # -1: known before, or a duplicate inside the batch
+        seen |= newkeys
+        base = size
+    assert base == on
+    act = _d2h(tab.view().activeKeys, on * 12).reshape(on, 3)
+    assert set(map(tuple, act)) == set(map(tuple, oact))
+    qr = torch.empty(allk.shape[0], dtype=torch.int32, device="cuda")
+    tab.query(pol, torch.from_numpy(allk).cuda().data_ptr(), allk.shape[0], qr.data_ptr())
+    qr = qr.cpu().numpy()
+    assert (qr >= 0).all() and np.array_equal(act[qr], allk)
+    tsz = tab.tableSize()
+    assert (_d2h(tab.view().status, tsz * 4) == -1).all()
+    raw = _d2h(tab.view().keys, tsz * 16).reshape(tsz, 4)
+    assert (raw[:, 3] == 0x3f3f3f3f).all()
+    filled = raw[(raw[:, :3] != 0x3f3f3f3f).any(axis=1)][:, :3]
+    assert filled.shape[0] == on and len(set(map(tuple, filled))) == on   # every key in exactly one slot
