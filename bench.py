@@ -653,8 +653,11 @@ def main():
             fmin = (56.0 + 52.0 if model == 1 else 52.0 + 48.0) + 1.5 + 7.0
             fach = fb * n_local / (fused_ms * 1e-3) / 1e9
             ftraffic = None
-            pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json")
-            if os.path.exists(pmcf):
+            # PMC traffic of the kernels this run used: slotted storage under motion (pmc_g2p2g.json, tools/refresh_r02.sh) or the
+            # compact-storage kernel at rest (pmc_g2p2g_compact.json); no figure was collected for the other combinations
+            moving = any(abs(x) > 0 for x in drift_v)
+            pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json" if (a.slotted and moving) else "pmc_g2p2g_compact.json")
+            if os.path.exists(pmcf) and (a.slotted == moving):
                 try:
                     j = json.load(open(pmcf))
                     if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model:

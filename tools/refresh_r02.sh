@@ -45,7 +45,7 @@ if "g2p2g_slot_kernel" in summ and "hbm_bytes_per_launch" in summ["g2p2g_slot_ke
                "source": "tools/refresh_r02.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read correction x2)"},
               open(os.path.join(O, "pmc_g2p2g.json"), "w"), indent=1)
 PY
-cp $O/pmc_g2p2g.json $R/profiles/pmc_g2p2g.json 2>/dev/null
+# (copy gpurun_out/r02/pmc_g2p2g.json to profiles/pmc_g2p2g.json by hand: only gpurun_out/ travels back from the GPU box)
 cd $R
 # 3. bench lines
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
