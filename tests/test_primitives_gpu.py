@@ -299,3 +299,15 @@ def test_radix_sort_randomised_stress():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_stress.py"), "120"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
+
+
+def test_scan_interleaved_types_share_the_control_block():
+    """tools/scan_stress.py: 300 scans alternating int32 (exclusive) and int64 (inclusive), 1 .. 3 M elements: scans of up to 4096 tiles run as
+    ONE launch on generation-tagged descriptors in the stream's control block (no memset); descriptors left by earlier calls, of either
+    layout, must read as invalid"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan_stress.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])

@@ -20,6 +20,12 @@ namespace zsr {
 
 constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kNumSpareStreams = 32; // cuda/Cuda.h:39
+// control block per (device, stream): [0, 32 KB) scan descriptors of 4-byte types ({status | value} words), [32 KB, 128 KB) those of 8-byte
+// types (status words, aggregates, prefixes in separate arrays of kCtlScanTiles entries -- a region that holds VALUES is never read as
+// status words by another instantiation), then the counters
+constexpr size_t kCtlBytes = 132 << 10;
+constexpr size_t kCtlDesc8 = 32 << 10, kCtlTicket = 128 << 10;
+constexpr size_t kCtlScanTiles = 4096;   // scans of up to this many tiles run without a descriptor memset
 
 // ------------------------------------------------------------------------------------ errors
 struct DeviceContext {
@@ -35,6 +41,10 @@ struct DeviceContext {
   };
   struct Arena {
     std::vector<Block> blocks;  // never moved or freed before zs_rocm_release_temporaries()
+    // dedicated control memory of the single-launch primitives (never handed out by temp(), zeroed once): generation-tagged scan
+    // descriptors and the scan's tile-ticket counter (never reset: the host keeps its value)
+    char *ctl = nullptr;
+    unsigned scanGen = 0, ticketShadow = 0;
   };
   std::map<hipStream_t, Arena> arenas;
 };
@@ -101,6 +111,8 @@ struct Launch {
   // grow-only temporaries bound to (device, stream); valid until the next call on the same stream
   void *temp(size_t bytes);
   std::vector<size_t> tempUsed;  // bytes handed out per arena block during this call
+  // control block of this (device, stream): kCtlBytes, zero-initialised on first use (stream-ordered); see DeviceContext::Arena
+  DeviceContext::Arena &control();
 };
 
 // ------------------------------------------------------------------------------------ iterator ports

@@ -65,6 +65,8 @@ template <int OP, class T> __device__ __forceinline__ T block_reduce(T v) {
   return r;  // thread 0
 }
 
+// (a single-launch form -- last workgroup to arrive folds the partials -- was measured in r02: the agent-scope release every workgroup needs
+// before it counts itself in costs more than the second launch: 64 M ints 0.100 ms instead of 0.043, 1 M 8.8 us instead of 7.5)
 template <int OP, class T, bool VEC>
 __global__ __launch_bounds__(RED_BLOCK) void reduce_partial_kernel(Port<const T> in, size_t n, T *partials) {
   T acc = identity_of<OP, T>();
@@ -124,38 +126,45 @@ enum : unsigned { ST_INVALID = 0, ST_AGG = 1, ST_PREFIX = 2 };
 // tile descriptor storage.  4-byte values: one packed u64 {status<<32 | bits}.  8-byte values: a flag
 // word plus separate aggregate / prefix slots, value written through and drained before the flag.
 template <class T, int W = sizeof(T)> struct Desc;
+// The status word carries the GENERATION of the call (gen << 2 | state): descriptors left behind by earlier calls in the stream's
+// dedicated control block read as invalid, so a scan of up to kCtlScanTiles tiles needs no memset launch in front of it.  (Temporary
+// memory is zeroed and used with generation 0.)
 template <class T> struct Desc<T, 4> {
   unsigned long long *d;
+  unsigned gen;
   static size_t bytes(size_t tiles) { return tiles * 8; }
-  __host__ __device__ explicit Desc(void *p, size_t) : d((unsigned long long *)p) {}
+  __host__ __device__ explicit Desc(void *p, size_t, unsigned g) : d((unsigned long long *)p), gen(g << 2) {}
   __device__ __forceinline__ void publish(size_t tile, unsigned st, T v) const {
     unsigned bits;
     __builtin_memcpy(&bits, &v, 4);
-    __hip_atomic_store(&d[tile], ((unsigned long long)st << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&d[tile], ((unsigned long long)(gen | st) << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ unsigned poll(size_t tile, T &v) const {
     unsigned long long x = __hip_atomic_load(&d[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned bits = (unsigned)x;
     __builtin_memcpy(&v, &bits, 4);
-    return (unsigned)(x >> 32);
+    const unsigned s = (unsigned)(x >> 32);
+    return (s & ~3u) == gen ? (s & 3u) : (unsigned)ST_INVALID;
   }
 };
 template <class T> struct Desc<T, 8> {
   unsigned *flag;
   unsigned long long *agg, *pre;
+  unsigned gen;
   static size_t bytes(size_t tiles) { return tiles * 24; }
-  __host__ __device__ explicit Desc(void *p, size_t tiles)
-      : flag((unsigned *)p + 0), agg((unsigned long long *)p + tiles), pre((unsigned long long *)p + 2 * tiles) {}
+  __host__ __device__ explicit Desc(void *p, size_t tiles, unsigned g)
+      : flag((unsigned *)p + 0), agg((unsigned long long *)p + tiles), pre((unsigned long long *)p + 2 * tiles), gen(g << 2) {}
   // layout: [tiles x u64 region used for flags (first 4 B of each 8)] [agg] [pre]; flags indexed densely
   __device__ __forceinline__ void publish(size_t tile, unsigned st, T v) const {
     unsigned long long bits;
     __builtin_memcpy(&bits, &v, 8);
     __hip_atomic_store(st == ST_AGG ? &agg[tile] : &pre[tile], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // value is at the coherence point before the flag
-    __hip_atomic_store(&flag[tile], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&flag[tile], gen | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ unsigned poll(size_t tile, T &v) const {
     unsigned st = __hip_atomic_load(&flag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st = (st & ~3u) == gen ? (st & 3u) : (unsigned)ST_INVALID;
     if (st != ST_INVALID) {
       unsigned long long bits =
           __hip_atomic_load(st == ST_AGG ? &agg[tile] : &pre[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -172,18 +181,19 @@ template <class T> struct Desc<T, 8> {
 // the registers per thread and twice the loads in flight per tile, 3.0 -> 3.35 TB/s at 64 M (1024 x 4: the same).
 template <int OP, class T, bool EXCL, int SCAN_ROWS>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(Port<const T> in, Port<T> out, size_t n, T init, void *descMem,
-                                                          size_t numTiles, unsigned *ticket) {
+                                                          size_t layoutTiles, unsigned *ticket, unsigned gen, unsigned ticketBase) {
   constexpr int V = 16 / sizeof(T);
   constexpr int ROWW = SCAN_BLOCK * V;       // elements per row
   constexpr int TILE = ROWW * SCAN_ROWS;     // 4096 (4-byte) / 2048 (8-byte)
   constexpr int NW = SCAN_BLOCK / 64;
   const T ident = identity_of<OP, T>();
-  Desc<T> desc(descMem, numTiles);
+  Desc<T> desc(descMem, layoutTiles, gen);  // (layoutTiles: array length of the 8-byte layout -- the call's tile count, or the fixed
+                                            // capacity of the control block)
 
   __shared__ unsigned sTile;
   __shared__ T sWave[SCAN_ROWS][NW];
   __shared__ T sTilePrefix;
-  if (threadIdx.x == 0) sTile = atomicAdd(ticket, 1u);
+  if (threadIdx.x == 0) sTile = atomicAdd(ticket, 1u) - ticketBase;  // (the dedicated counter is never reset: the host knows its value)
   __syncthreads();
   const size_t tile = sTile;
   const size_t tileBase = tile * (size_t)TILE;
@@ -310,11 +320,24 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
   constexpr size_t TILE = (size_t)SCAN_BLOCK * (16 / sizeof(T)) * ROWS;
   const size_t numTiles = (n + TILE - 1) / TILE;
   const size_t dbytes = Desc<T>::bytes(numTiles);
+  if (numTiles <= kCtlScanTiles) {
+    // the stream's control block: descriptors tagged with a fresh generation, a ticket counter that only ever counts up -> one launch
+    DeviceContext::Arena &a = L.control();
+    if (++a.scanGen >= (1u << 30)) {  // generation wrap: start over from clean memory
+      ZSR_CHECK(hipMemsetAsync(a.ctl, 0, kCtlTicket, L.stream));
+      a.scanGen = 1;
+    }
+    const unsigned base = a.ticketShadow;
+    a.ticketShadow += (unsigned)numTiles;
+    hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                       (void *)(a.ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(a.ctl + kCtlTicket), a.scanGen, base);
+    return;
+  }
   char *mem = (char *)L.temp(dbytes + 256);
   ZSR_CHECK(hipMemsetAsync(mem, 0, dbytes + 256, L.stream));  // descriptors + ticket re-initialised every call
   unsigned *ticket = (unsigned *)(mem + dbytes);
   hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
-                     (void *)mem, numTiles, ticket);
+                     (void *)mem, numTiles, ticket, 0u, 0u);
 }
 template <int OP, class T, bool EXCL> static void scan_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
   if (n == 0) return;

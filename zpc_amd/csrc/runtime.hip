@@ -88,6 +88,18 @@ Launch::~Launch() {
 
 static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes);
 void *Launch::temp(size_t bytes) { return arena_take(dev, stream, tempUsed, bytes); }
+DeviceContext::Arena &Launch::control() {
+  DeviceContext &c = context(dev);
+  std::lock_guard<std::mutex> lk(c.mtx);
+  auto &a = c.arenas[stream];
+  if (!a.ctl) {
+    ZSR_CHECK(hipMalloc((void **)&a.ctl, kCtlBytes));
+    ZSR_CHECK(hipMemsetAsync(a.ctl, 0, kCtlBytes, stream));  // ordered before every later use on this stream
+    a.scanGen = 0;
+    a.ticketShadow = 0;
+  }
+  return a;
+}
 
 static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes) {
   DeviceContext &c = context(dev);
@@ -189,9 +201,11 @@ void zs_rocm_release_temporaries(void) {
   std::lock_guard<std::mutex> lk(g_ctxMutex);
   for (auto &kv : g_contexts) {
     std::lock_guard<std::mutex> lk2(kv.second->mtx);
-    for (auto &a : kv.second->arenas)
+    for (auto &a : kv.second->arenas) {
       for (auto &b : a.second.blocks)
         if (b.ptr) (void)hipFree(b.ptr);
+      if (a.second.ctl) (void)hipFree(a.second.ctl);
+    }
     kv.second->arenas.clear();
   }
 }
