@@ -113,6 +113,8 @@ struct Launch {
   std::vector<size_t> tempUsed;  // bytes handed out per arena block during this call
   // control block of this (device, stream): kCtlBytes, zero-initialised on first use (stream-ordered); see DeviceContext::Arena
   DeviceContext::Arena &control();
+  // reserves generation + ticket range of one scan on this stream (under the context lock); *wrapped: the generation counter started over
+  char *scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase, bool &wrapped);
 };
 
 // ------------------------------------------------------------------------------------ iterator ports

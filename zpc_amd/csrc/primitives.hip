@@ -322,15 +322,12 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
   const size_t dbytes = Desc<T>::bytes(numTiles);
   if (numTiles <= kCtlScanTiles) {
     // the stream's control block: descriptors tagged with a fresh generation, a ticket counter that only ever counts up -> one launch
-    DeviceContext::Arena &a = L.control();
-    if (++a.scanGen >= (1u << 30)) {  // generation wrap: start over from clean memory
-      ZSR_CHECK(hipMemsetAsync(a.ctl, 0, kCtlTicket, L.stream));
-      a.scanGen = 1;
-    }
-    const unsigned base = a.ticketShadow;
-    a.ticketShadow += (unsigned)numTiles;
+    unsigned gen, base;
+    bool wrapped;
+    char *ctl = L.scan_control(numTiles, gen, base, wrapped);
+    if (wrapped) ZSR_CHECK(hipMemsetAsync(ctl, 0, kCtlTicket, L.stream));  // generation wrap: start over from clean descriptors
     hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
-                       (void *)(a.ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(a.ctl + kCtlTicket), a.scanGen, base);
+                       (void *)(ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(ctl + kCtlTicket), gen, base);
     return;
   }
   char *mem = (char *)L.temp(dbytes + 256);

@@ -101,6 +101,21 @@ DeviceContext::Arena &Launch::control() {
   return a;
 }
 
+char *Launch::scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase, bool &wrapped) {
+  DeviceContext::Arena &a = control();
+  DeviceContext &c = context(dev);
+  std::lock_guard<std::mutex> lk(c.mtx);
+  wrapped = false;
+  if (++a.scanGen >= (1u << 30)) {
+    a.scanGen = 1;
+    wrapped = true;
+  }
+  gen = a.scanGen;
+  ticketBase = a.ticketShadow;
+  a.ticketShadow += (unsigned)numTiles;
+  return a.ctl;
+}
+
 static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes) {
   DeviceContext &c = context(dev);
   bytes = (bytes + 255) & ~(size_t)255;
