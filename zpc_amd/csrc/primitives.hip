@@ -562,17 +562,17 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
         for (int j = 0; j < LB; ++j)
           v[j] = p - j >= 0 ? __hip_atomic_load(desc + (size_t)(p - j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                             : OS_FLAG_PREFIX;  // before tile 0: an empty inclusive prefix
+        // branch-free walk over the batch: `alive` while every descriptor so far was published and none was an inclusive prefix
         int used = 0;
+        bool alive = true;
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
-          if (!done && used == j) {
-            const unsigned f = v[j] & ~OS_VAL_MASK;
-            if (f != 0) {
-              excl += v[j] & OS_VAL_MASK;
-              ++used;
-              done = f == OS_FLAG_PREFIX;
-            }
-          }
+          const unsigned f = v[j] >> 30;  // 0 not published, 1 aggregate, 2 inclusive prefix
+          const bool take = alive && f != 0u;
+          excl += take ? (v[j] & OS_VAL_MASK) : 0u;
+          used += take ? 1 : 0;
+          done = done || (take && f == 2u);
+          alive = take && f != 2u;
         }
         p -= used;
         if (!done && used < LB) __builtin_amdgcn_s_sleep(1);  // ran into a tile that has not published yet
