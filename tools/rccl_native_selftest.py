@@ -89,6 +89,20 @@ plan = NativeHaloPlan(comm, pol, keys.data_ptr(), 3, 8)
 assert plan.total_blocks == 0 and len(plan.peers) == 0 and plan.bytes_per_exchange == 0
 plan.exchange_native(comm, pol, torch.zeros(3, 7, 512, device=dev), 8)  # no-op
 del plan
+# ... and from a real partition (the bht of an MpmTransfer), as bench.py builds it
+from zpc_amd.mpm import MpmTransfer  # noqa: E402
+import numpy as np  # noqa: E402
+g = np.random.default_rng(1)
+npart = 4000
+pos = (0.3 + 0.2 * g.random((npart, 3))).astype(np.float32)
+mt = MpmTransfer(pol, npart, 1.0 / 64, 1e-4, model=1, side=8, volume=1e-7, cache_stress=True)
+mt.upload(np.full(npart, 1e-3, np.float32), pos, np.zeros((npart, 3), np.float32), np.zeros((npart, 9), np.float32),
+          np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (npart, 1)), np.zeros(npart, np.float32))
+mt.build_partition(npart, margin=1)
+pol.syncCtx()
+plan = NativeHaloPlan(comm, pol, mt.table, mt.nblocks, 8)
+assert plan.total_blocks == 0 and mt.nblocks > 0
+del plan
 comm.barrier(pol)
 assert zpc_amd.lib().zs_rocm_last_error(0) == 0
 del comm
