@@ -88,7 +88,8 @@ def parse():
     ap.add_argument("--margin", type=int, default=1,
                     help="slotted storage: extra layers of grid blocks around the occupied ones (room to travel before a re-partition)")
     ap.add_argument("--no-at-rest", action="store_true",
-                    help="skip the secondary at-rest measurement (a second, short run of this script with --drift 0,0,0)")
+                    help="skip the secondary measurements (short sub-runs of this script at rest: slotted, compact, unfused stand-alone P2G / G2P; "
+                         "and the primitives / bht / TileVector rows of SURVEY 8(d))")
     return ap.parse_args()
 
 
@@ -709,24 +710,49 @@ def main():
         if slot_stats is not None:
             out["slot_stats"] = slot_stats
         if world == 1 and a.slotted and not a.no_at_rest and any(abs(x) > 0 for x in drift_v):
-            # secondary number: the same column at rest (no movers), a second short run of this script
+            # secondary numbers: the same column at rest (no movers) -- short sub-runs of this script after the timed region
             import subprocess
             try:
                 cmd = [sys.executable, os.path.abspath(__file__), "--drift", "0,0,0", "--no-at-rest", "--no-cpu-baseline", "--steps", "10",
                        "--warmup", "3", "--grid", str(a.grid), "--cells", a.cells, "--model", a.model, "--side", str(a.side),
                        "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin)]
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                j = json.loads(r.stdout.strip().splitlines()[-1])
+
+                def sub(extra):
+                    r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)
+                    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                j = sub([])
                 out["config"]["at_rest_ms_per_step"] = j["ms_per_step"]
-                # ... and at rest on compact storage: the workload and storage round 1 quoted its headline on (role-split kernel)
-                r = subprocess.run(cmd + ["--compact"], capture_output=True, text=True, timeout=600)
-                j2 = json.loads(r.stdout.strip().splitlines()[-1])
+                # ... at rest on compact storage: the workload and storage round 1 quoted its headline on (role-split kernel)
+                j2 = sub(["--compact"])
                 out["secondary"] = {"at_rest_slotted": {"ms_per_step": j["ms_per_step"], "roofline_frac": j["roofline"]["frac"]},
                                     "at_rest_compact": {"ms_per_step": j2["ms_per_step"], "roofline_frac": j2["roofline"]["frac"],
                                                         "note": "particles at rest, dense binned storage: the r01 headline workload"}}
+                # ... and the transfers as separate kernels: the stand-alone P2G is the kernel north_star sets its 0.60 target on
+                j3 = sub(["--compact", "--unfused"])
+                r3 = j3["roofline"]
+                out["p2g_standalone"] = {"kernel": r3["kernel"], "ms": r3["launch_ms"], "bytes_per_particle": r3["bytes_per_particle"],
+                                         "achieved_GBps": r3["achieved"], "frac": r3["frac"], "particles": r3["particles_per_launch"],
+                                         "target_frac": 0.60,
+                                         "note": "HIP-event time of the P2G launch alone (grid reset and update outside), column at rest, "
+                                                 "compact binned storage, cached stress (107 B/particle: SURVEY 8(d))"}
+                out["secondary"]["unfused_at_rest"] = {"ms_per_step": j3["ms_per_step"], "p2g_ms": r3["launch_ms"], "p2g_frac": r3["frac"],
+                                                       "g2p_ms": r3["g2p"]["launch_ms"],
+                                                       "g2p_frac": r3["g2p"]["achieved"] / HBM_PEAK_GBS}
             except Exception as e:
                 out["config"]["at_rest_ms_per_step"] = None
-                print("at-rest run failed: %r" % (e,), file=sys.stderr)
+                print("at-rest runs failed: %r" % (e,), file=sys.stderr)
+        if world == 1 and not a.no_at_rest:
+            # SURVEY 8(d) secondary metrics (BASELINE configs 1 and 2): reduce / exclusive_scan / radix_sort(_pair) at 1 M and 64 M ints,
+            # bht build over 16 M random particles, TileVector<f32,32> 25-channel load + store at 16 M -- each {ms, units_per_s, frac}
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_prims
+                rows = bench_prims.main(only=["prims", "tv", "bht"], sizes=(1_000_000, 64_000_000), quiet=True, tv_cases=((16_000_000, 32, 25),))
+                out.setdefault("secondary", {})["prims"] = [
+                    {"name": r["name"], "n": r["n"], "ms": r["ms"], "units_per_s": r["units_per_s"],
+                     "bytes_per_unit": r["algorithmic_bytes_per_unit"], "frac": r["frac_of_8TBps"]} for r in rows]
+            except Exception as e:
+                print("secondary primitives failed: %r" % (e,), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, dx, dt, model, a.side, vol)
         print(json.dumps(out), flush=True)

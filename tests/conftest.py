@@ -36,3 +36,11 @@ def pol():
         pytest.skip("no GPU")
     from zpc_amd import rocm_exec
     return rocm_exec()
+
+
+def pytest_collection_modifyitems(config, items):
+    """The full-size runs (minutes each, 64 Mi particles) go last: under `-x` one of them must never hide the parity tests."""
+    late = [it for it in items if "test_fullsize_gpu" in it.nodeid]
+    if late:
+        rest = [it for it in items if "test_fullsize_gpu" not in it.nodeid]
+        items[:] = rest + late

@@ -21,12 +21,21 @@ def _bench(args):
     return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
 
 
+CHANNELS = (["m"] + ["x%d" % k for k in range(3)] + ["v%d" % k for k in range(3)] + ["C%d" % k for k in range(9)]
+            + ["F%d" % k for k in range(9)] + ["logJp"] + ["PFt%d" % k for k in range(9)])
+
+
 def _same_state(a, b, npart, tol_sum, tol_sq):
+    """channel sums and sums of squares of two runs; the failure message names the channels and by how much"""
     a, b = np.array(a), np.array(b)
     nch = len(a) // 2
+    names = CHANNELS if nch >= 35 else [c for c in CHANNELS if c != "logJp"]
     scale = np.sqrt(npart * np.maximum(a[nch:], 1e-30))
-    assert (np.abs(a[:nch] - b[:nch]) <= tol_sum * scale + 1e-12).all(), np.abs(a[:nch] - b[:nch]) / scale
-    assert (np.abs(a[nch:] - b[nch:]) <= tol_sq * np.abs(a[nch:]) + 1e-12).all()
+    r_sum = np.abs(a[:nch] - b[:nch]) / (tol_sum * scale + 1e-12)
+    r_sq = np.abs(a[nch:] - b[nch:]) / (tol_sq * np.abs(a[nch:]) + 1e-12)
+    bad = [("sum " + names[k], float(r_sum[k]), float(a[k]), float(b[k])) for k in range(nch) if r_sum[k] > 1] + \
+          [("sq " + names[k], float(r_sq[k]), float(a[nch + k]), float(b[nch + k])) for k in range(nch) if r_sq[k] > 1]
+    assert not bad, "channels outside tolerance (name, |d|/tol, a, b): %r" % (bad,)
 
 
 def test_config1_primitives_at_1m_ints(pol):

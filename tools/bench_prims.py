@@ -30,20 +30,25 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps
 
 
-def main():
+def main(only=None, sizes=None, quiet=False, tv_cases=((16_000_000, 32, 25), (64_000_000, 64, 26))):
+    """only: subset of {"prims", "tv", "bht", "lbvh"}; sizes: element counts of the primitive rows.  Also called by bench.py
+    (secondary.prims of the driver line: the SURVEY 8(d) secondary metrics)."""
     pol = zs.rocm_exec().sync(False).external_stream(torch.cuda.current_stream().cuda_stream)
     rows = []
-    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None  # prims,tv,bht,lbvh
+    if only is None and "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1].split(",")  # prims,tv,bht,lbvh
     want = lambda k: only is None or k in only
 
     def add(name, n, unit_bytes, ms):
         gbs = unit_bytes * n / (ms * 1e-3) / 1e9
         rows.append({"name": name, "n": n, "ms": ms, "units_per_s": n / (ms * 1e-3), "algorithmic_bytes_per_unit": unit_bytes,
                      "GBps": gbs, "frac_of_8TBps": gbs / PEAK})
-        print("%-44s n=%-10d %9.4f ms  %9.2f G/s  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, n, ms, n / ms / 1e6, gbs, 100 * gbs / PEAK), flush=True)
+        if not quiet:
+            print("%-44s n=%-10d %9.4f ms  %9.2f G/s  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, n, ms, n / ms / 1e6, gbs, 100 * gbs / PEAK), flush=True)
 
     g = torch.Generator(device="cuda").manual_seed(1)
-    sizes = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(",")) if "--sizes" in sys.argv else (1_000_000, 16_000_000, 64_000_000)
+    if sizes is None:
+        sizes = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(",")) if "--sizes" in sys.argv else (1_000_000, 16_000_000, 64_000_000)
     for n in sizes if want("prims") else ():
         a = torch.randint(-2**30, 2**30, (n,), dtype=torch.int32, device="cuda", generator=g)
         out1 = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -66,14 +71,14 @@ def main():
             add("merge_sort_pair<i32,i32> (%d passes)" % passes, n, 16 * passes, t_all - t_copy)
         del a, out, v, vo
     # config 2: TileVector<f32,32>{m:1,x:3,v:3,F:9,C:9} load-all/store-all at 16M
-    for n, L, Cn in ((16_000_000, 32, 25), (64_000_000, 64, 26)) if want("tv") else ():
+    for n, L, Cn in tv_cases if want("tv") else ():
         tiles = (n + L - 1) // L
         tv = torch.rand(tiles * L * Cn, dtype=torch.float32, device="cuda", generator=g)
         add("TileVector<f32,%d> %d ch load+store" % (L, Cn), n, 8 * Cn, timeit(lambda: zs.lib().zs_rocm_tv_scale_f32(pol.handle, tv.data_ptr(), n, Cn, L, C.c_float(1.0001))))
         del tv
     # config 2: bht build, 16M random particles in [0,1)^3, dx = 1/256: cell keys (~10.6M distinct) and 8^3-block keys
     n = 16_000_000
-    pos = torch.rand(n, 3, device="cuda", generator=g)
+    pos = torch.rand(n, 3, device="cuda", generator=g) if want("bht") else None
     for name, keys in (("cell keys", torch.floor(pos * 256).to(torch.int32)), ("8^3-block keys", torch.floor(pos * 32).to(torch.int32))) if want("bht") else ():
         keys = keys.contiguous()
         tab = Bht(3, n)

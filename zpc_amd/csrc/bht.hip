@@ -260,7 +260,7 @@ extern "C" {
 #define ZSR_DEFINE_BHT_A(D, B, SFX)                                                                         \
   zs_rocm_bht_##D *container__bht_int_##D##_int_##B##SFX(zs_rocm_allocator *a, size_t n) {                   \
     auto *b = new zs_rocm_bht_##D;                                                                          \
-    bht_create(b->t, D, B, a ? a->memsrc : 1, a ? a->devid : 0, n);                                         \
+    bht_create(b->t, D, B, a ? a->memsrc : 1, a ? a->devid : (int8_t)current_device(), n);                                         \
     return b;                                                                                               \
   }                                                                                                         \
   void del_container__bht_int_##D##_int_##B##SFX(zs_rocm_bht_##D *b) {                                       \

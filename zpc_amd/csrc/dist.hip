@@ -34,6 +34,22 @@ static int nccl_check(ncclResult_t r, const char *what, const char *file, int li
   do {                                                               \
     if (::zsr::nccl_check((expr), #expr, __FILE__, __LINE__)) return -1; \
   } while (0)
+// inside an open ncclGroupStart(): a failed call closes the group before returning, so later RCCL calls of this thread do not
+// queue into a group nobody ends
+#define ZSR_NCCL_G(expr)                                             \
+  do {                                                               \
+    if (::zsr::nccl_check((expr), #expr, __FILE__, __LINE__)) {      \
+      (void)ncclGroupEnd();                                          \
+      return -1;                                                     \
+    }                                                                \
+  } while (0)
+// the policy must run on the communicator's device (its stream is handed to RCCL); device -1 = "current" is resolved by Launch
+static int same_device(const zs_rocm_dist *d, const Launch &L, const char *what) {
+  if (L.dev == d->device) return 0;
+  fprintf(stderr, "[zs_rocm | rccl] %s: policy runs on device %d, communicator lives on device %d\n", what, L.dev, d->device);
+  report_error(hipErrorInvalidDevice, what, __FILE__, __LINE__);
+  return -1;
+}
 }  // namespace zsr
 
 using namespace zsr;
@@ -79,14 +95,23 @@ int zs_rocm_dist_halo_exchange(zs_rocm_dist *d, zs_rocm_policy *pol, float *grid
                                size_t totalBlocks, int npeers, const int *peerRank, const size_t *peerOffset, const size_t *peerCount,
                                float *sendbuf, float *recvbuf) {
   if (!d || !totalBlocks || npeers <= 0) return 0;
+  // the grid has 7 channels {m, mv, f} (geometry/Structure.hpp:37-131 as used by simulation/mpm/Simulator.cpp:116-122)
+  if ((side != 4 && side != 8) || chn0 < 0 || nchn < 1 || chn0 + nchn > 7) {
+    report_error(hipErrorInvalidValue, "halo_exchange: side must be 4 | 8 and [chn0, chn0 + nchn) within the 7 grid channels", __FILE__, __LINE__);
+    return -1;
+  }
   const size_t bf = (size_t)nchn * side * side * side;
+  {
+    Launch L(pol, "halo_exchange");
+    if (same_device(d, L, "halo_exchange")) return -1;
+  }
   zs_rocm_mpm_halo_pack(pol, grid, blocks, totalBlocks, side, chn0, nchn, sendbuf);
   {
     Launch L(pol, "halo_exchange");
     ZSR_NCCL(ncclGroupStart());
     for (int k = 0; k < npeers; ++k) {
-      ZSR_NCCL(ncclSend(sendbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
-      ZSR_NCCL(ncclRecv(recvbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
+      ZSR_NCCL_G(ncclSend(sendbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
+      ZSR_NCCL_G(ncclRecv(recvbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
     }
     ZSR_NCCL(ncclGroupEnd());
   }
@@ -163,6 +188,7 @@ struct zs_rocm_halo_plan {
 zs_rocm_halo_plan *zs_rocm_dist_halo_plan_create(zs_rocm_dist *d, zs_rocm_policy *pol, const int *keys, size_t nblocks, int side) {
   if (!d || (side != 4 && side != 8)) return nullptr;
   Launch L(pol, "halo_plan");
+  if (same_device(d, L, "halo_plan_create")) return nullptr;
   auto *plan = new zs_rocm_halo_plan;
   plan->device = d->device;
   plan->side = side;
@@ -240,6 +266,11 @@ const int *zs_rocm_dist_halo_plan_block_list(const zs_rocm_halo_plan *p) { retur
 // the exchange of zs_rocm_dist_halo_exchange over the plan's own lists and buffers
 int zs_rocm_dist_halo_plan_exchange(zs_rocm_halo_plan *p, zs_rocm_dist *d, zs_rocm_policy *pol, float *grid, int chn0, int nchn) {
   if (!p || !p->total) return 0;
+  // the plan's buffers hold the 7 grid channels of every shared block: a wider or shifted channel window would run past them
+  if (chn0 < 0 || nchn < 1 || chn0 + nchn > 7) {
+    report_error(hipErrorInvalidValue, "halo_plan_exchange: [chn0, chn0 + nchn) must lie within the 7 grid channels", __FILE__, __LINE__);
+    return -1;
+  }
   return zs_rocm_dist_halo_exchange(d, pol, grid, p->side, chn0, nchn, p->blocks, p->total, p->npeers, p->peerRank.data(), p->peerOffset.data(),
                                     p->peerCount.data(), p->sendbuf, p->recvbuf);
 }
@@ -249,12 +280,14 @@ static ncclRedOp_t red_op(int op) { return op == 1 ? ncclMax : (op == 2 ? ncclMi
 int zs_rocm_dist_allreduce_f32(zs_rocm_dist *d, zs_rocm_policy *pol, float *buf, size_t n, int op) {
   if (!d || !n) return 0;
   Launch L(pol, "allreduce_f32");
+  if (same_device(d, L, "allreduce_f32")) return -1;
   ZSR_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, red_op(op), d->comm, L.stream));
   return 0;
 }
 int zs_rocm_dist_allreduce_i64(zs_rocm_dist *d, zs_rocm_policy *pol, long long *buf, size_t n, int op) {
   if (!d || !n) return 0;
   Launch L(pol, "allreduce_i64");
+  if (same_device(d, L, "allreduce_i64")) return -1;
   ZSR_NCCL(ncclAllReduce(buf, buf, n, ncclInt64, red_op(op), d->comm, L.stream));
   return 0;
 }
@@ -262,10 +295,11 @@ int zs_rocm_dist_allreduce_i64(zs_rocm_dist *d, zs_rocm_policy *pol, long long *
 int zs_rocm_dist_alltoall_i64(zs_rocm_dist *d, zs_rocm_policy *pol, const long long *send, long long *recv) {
   if (!d) return 0;
   Launch L(pol, "alltoall_i64");
+  if (same_device(d, L, "alltoall_i64")) return -1;
   ZSR_NCCL(ncclGroupStart());
   for (int r = 0; r < d->world; ++r) {
-    ZSR_NCCL(ncclSend(send + r, 1, ncclInt64, r, d->comm, L.stream));
-    ZSR_NCCL(ncclRecv(recv + r, 1, ncclInt64, r, d->comm, L.stream));
+    ZSR_NCCL_G(ncclSend(send + r, 1, ncclInt64, r, d->comm, L.stream));
+    ZSR_NCCL_G(ncclRecv(recv + r, 1, ncclInt64, r, d->comm, L.stream));
   }
   ZSR_NCCL(ncclGroupEnd());
   return 0;
@@ -276,10 +310,11 @@ int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *d, zs_rocm_policy *pol, const float
                                float *recv, const size_t *recvCounts, const size_t *recvOffsets) {
   if (!d) return 0;
   Launch L(pol, "alltoallv_f32");
+  if (same_device(d, L, "alltoallv_f32")) return -1;
   ZSR_NCCL(ncclGroupStart());
   for (int r = 0; r < d->world; ++r) {
-    if (sendCounts[r]) ZSR_NCCL(ncclSend(send + sendOffsets[r], sendCounts[r], ncclFloat, r, d->comm, L.stream));
-    if (recvCounts[r]) ZSR_NCCL(ncclRecv(recv + recvOffsets[r], recvCounts[r], ncclFloat, r, d->comm, L.stream));
+    if (sendCounts[r]) ZSR_NCCL_G(ncclSend(send + sendOffsets[r], sendCounts[r], ncclFloat, r, d->comm, L.stream));
+    if (recvCounts[r]) ZSR_NCCL_G(ncclRecv(recv + recvOffsets[r], recvCounts[r], ncclFloat, r, d->comm, L.stream));
   }
   ZSR_NCCL(ncclGroupEnd());
   return 0;
@@ -288,6 +323,7 @@ int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *d, zs_rocm_policy *pol, const float
 int zs_rocm_dist_barrier(zs_rocm_dist *d, zs_rocm_policy *pol) {
   if (!d) return 0;
   Launch L(pol, "dist_barrier");
+  if (same_device(d, L, "dist_barrier")) return -1;
   int *flag = (int *)L.temp(sizeof(int));
   ZSR_CHECK(hipMemsetAsync(flag, 0, sizeof(int), L.stream));
   ZSR_NCCL(ncclAllReduce(flag, flag, 1, ncclInt32, ncclSum, d->comm, L.stream));

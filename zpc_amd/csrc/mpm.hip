@@ -41,12 +41,15 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
   // a time loop rebuilds the buckets every step: table and arrays are kept while they are large enough (hipMalloc / hipFree
   // synchronise the device and cost more than the kernels below)
   size_t want = expectedCells ? expectedCells : n;
+  // the table lives on the device the policy runs on (one process per GPU: that is the rank's device, not device 0)
+  const int tdev = pol->device >= 0 ? pol->device : current_device();
+  if (ib->table && ib->table->devid != tdev) { zs_rocm_hashtable_destroy(ib->table); ib->table = nullptr; ib->tableFor = 0; }
   if (ib->table && ib->tableFor >= want && ib->tableFor <= 4 * want) {
     want = ib->tableFor;
     zs_rocm_hashtable_reset(pol, ib->table, 1);
   } else {
     if (ib->table) zs_rocm_hashtable_destroy(ib->table);
-    ib->table = zs_rocm_hashtable_create(3, want, 1, 0);  // Query.tpp:27 (created reset)
+    ib->table = zs_rocm_hashtable_create(3, want, 1, tdev);  // Query.tpp:27 (created reset)
     ib->tableFor = want;
   }
   ib->numEntries = (int)n;
@@ -74,7 +77,7 @@ void zs_rocm_index_buckets_for_particles(zs_rocm_policy *pol, zs_rocm_index_buck
     }
     want = std::min(n, want * 8);
     zs_rocm_hashtable_destroy(ib->table);
-    ib->table = zs_rocm_hashtable_create(3, want, 1, 0);
+    ib->table = zs_rocm_hashtable_create(3, want, 1, tdev);
     ib->tableFor = want;
   }
   ib->numBuckets = nc;
