@@ -192,3 +192,134 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     _same_state(a["checksum"], b["checksum"], n, 1e-4, 3e-4)
     m = 1000.0 * (1.0 / 512) ** 3 / 8
     assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
+
+
+# ------------------------------------------------------------------------------------------------ full-size runs anchored to the ORACLE
+def _id_box_step(pol, oracle, model, grid_n, cells, drift, box_lo, steps_before, K=24, outbox_cap=128):
+    """The full-size column of bench.py on slotted storage, moved for `steps_before` fused steps; then ONE more fused step whose inputs
+    (particle state of a 32^3-cell sub-box, node velocities of the enclosing grid blocks) are handed to the CPU oracle
+    (oracle/mpm.c: G2P, simulation/transfer/G2P.hpp:44-83, then P2G, P2G.hpp:51-125) and whose outputs are compared with it particle
+    for particle (identity = a unique mass given to the sub-box particles at t = 0) and node for node (interior nodes of the box).
+    Returns the dict of measured deviations / scales."""
+    import bench
+    from zpc_amd.mpm import MpmTransfer
+    from util import OracleMpm
+    dx, dt, side = 1.0 / grid_n, 1e-4, 8
+    glo = [(grid_n - cells[0]) // 2 // side * side, 0, (grid_n - cells[2]) // 2 // side * side]
+    ghi = [glo[d] + cells[d] for d in range(3)]
+    dev = torch.device("cuda", 0)
+    aos = bench.generate_particles(glo, ghi, dx, 1234, dev, model)
+    for k in range(3):
+        aos[:, 4 + k] += drift[k]
+    n = aos.shape[0]
+    # identities: the particles of the 32^3-cell box get pairwise different masses m0 (1 + j 2^-20); everybody else 0.99 m0
+    m0 = float(aos[0, 0].item())
+    cell = torch.floor(aos[:, 1:4] / dx).to(torch.int32)
+    box_hi = [box_lo[d] + 32 for d in range(3)]
+    inb = torch.ones(n, dtype=torch.bool, device=dev)
+    for d in range(3):
+        inb &= (cell[:, d] >= box_lo[d]) & (cell[:, d] < box_hi[d])
+    ids = torch.nonzero(inb).flatten()
+    nid = int(ids.numel())
+    assert nid == 32 ** 3 * 8
+    aos[:, 0] = 0.99 * m0
+    aos[ids, 0] = (m0 * (1.0 + torch.arange(nid, device=dev, dtype=torch.float64) * 2.0 ** -20)).float()
+    del cell, inb
+    vol = dx ** 3 / 8
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
+    aos = torch.cat([aos, torch.zeros(n, 9, dtype=torch.float32, device=dev)], dim=1).contiguous()
+    import zpc_amd
+    zpc_amd.lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n, mt.nchn, mt.L, mt.buf.data_ptr())
+    pol.syncCtx()
+    del aos
+    g = (0.0, -9.8, 0.0)
+    mt.build_partition(max(4096, n // 128), margin=1)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    mt.grid_update(g)
+    mt.slot(K=K, outbox_cap=outbox_cap)
+    for _ in range(steps_before):
+        mt.g2p2g()
+        mt.grid_update(g)
+    pol.syncCtx()
+    st0 = mt.check_slots()
+
+    def id_particles():
+        """[nid, nchn] rows of the particles that carry an identity, sorted by it"""
+        cbuf, cnt = mt._compact_copy()          # occupied slots only (a vacated slot keeps its stale record; its mask bit is clear)
+        assert cnt == n
+        v = cbuf.view(-1, mt.nchn, 64)
+        m = v[:, 0, :]
+        sel = torch.nonzero((m >= m0) & (m < 1.3 * m0))
+        rows = v[sel[:, 0], :, sel[:, 1]]
+        o = torch.argsort(rows[:, 0])
+        return rows[o].cpu().numpy()
+    a = id_particles()
+    assert a.shape[0] == nid and np.unique(a[:, 0]).shape[0] == nid            # every identity exactly once after the moving steps
+    keys = mt.active_keys()
+    base = np.floor(a[:, 1:4] / dx - 0.5).astype(np.int64)
+    klo, khi = base.min(0) // side - 1, (base.max(0) + 2) // side + 1
+    selb = np.nonzero(((keys >= klo) & (keys <= khi)).all(1))[0]
+    gridA = mt.grid.view(mt.nblocks, 7, side ** 3)[torch.from_numpy(selb).to(dev)].cpu().numpy()
+    kw = dict(E=5e4, nu=0.4)
+    om = OracleMpm(oracle, model, dx, dt, side, vol, nthreads=8, **kw)
+    om.adopt_partition(keys[selb])
+    om.grid[:] = gridA
+    mass = np.ascontiguousarray(a[:, 0])
+    pos, vel = np.ascontiguousarray(a[:, 1:4]), np.ascontiguousarray(a[:, 4:7])
+    Cm, F = np.ascontiguousarray(a[:, 7:16]), np.ascontiguousarray(a[:, 16:25])
+    lj = np.ascontiguousarray(a[:, 25]) if model == 1 else np.zeros(nid, np.float32)
+    om.g2p(pos, vel, Cm, F)
+    om.grid[:] = 0
+    om.p2g(mass, pos, vel, Cm, F, lj)
+    # the same step on the GPU (write_all: v, C of every particle are stored as well)
+    mt.g2p2g(write_all=True)
+    pol.syncCtx()
+    st1 = mt.check_slots()
+    b = id_particles()
+    assert np.array_equal(b[:, 0], mass)                                       # nobody lost, nobody duplicated
+    gridB = mt.grid.view(mt.nblocks, 7, side ** 3)[torch.from_numpy(selb).to(dev)].cpu().numpy()
+    out = {"movers_in_step": st1[5] - st0[5], "n_id": nid}
+    out["x"] = float(np.abs(b[:, 1:4] - pos).max())
+    out["v"] = float(np.abs(b[:, 4:7] - vel).max() / np.abs(vel).max())
+    out["C"] = float(np.abs(b[:, 7:16] - Cm).max() / np.abs(Cm).max())
+    out["F"] = float(np.abs(b[:, 16:25] - F).max())
+    if model == 1:
+        out["logJp"] = float(np.abs(b[:, 25] - lj).max())
+    # how many of the identified particles changed cell since t = 0 / in this step
+    out["changed_cell_in_step"] = int((np.floor(b[:, 1:4] / dx - 0.5).astype(np.int64) != base).any(1).sum())
+    # interior nodes: 3 cells inside the box faces (the box has fallen < 1 cell), so every contributor carries an identity
+    kk = keys[selb]
+    c = np.arange(side ** 3)
+    loc = np.stack([c // (side * side), (c // side) % side, c % side], 1)
+    node = kk[:, None, :] * side + loc[None, :, :]
+    interior = np.ones(node.shape[:2], bool)
+    for d in range(3):
+        interior &= (node[:, :, d] >= box_lo[d] + 3) & (node[:, :, d] < box_hi[d] - 3)
+    assert interior.sum() == 26 ** 3
+    scale = np.abs(om.grid).max(axis=(0, 2)) + 1e-30
+    diff = np.abs(gridB - om.grid)
+    out["grid"] = [float(diff[:, ch, :][interior].max() / scale[ch]) for ch in range(7)]
+    out["grid_mass_interior"] = float(om.grid[:, 0, :][interior].min())
+    return out
+
+
+def test_config4_sand_64m_slotted_moving_subbox_vs_oracle(pol, oracle):
+    """BASELINE config 4 at N = 1 anchored to the oracle: 64 Mi-particle DruckerPrager column falling at 0.05 cell per step on slotted
+    storage; after 8 moving steps the 9th step's G2P + P2G of a 262 144-particle sub-box (32^3 cells in the middle of the column) ==
+    oracle/mpm.c on exactly those particles with the GPU's node velocities as input.  Tolerances: x 1e-6, v / C 2e-4 of the channel
+    maximum, F and logJp 2e-5, grid channels 2e-4 of the channel maximum (float atomics: summation order)."""
+    r = _id_box_step(pol, oracle, 1, 512, (128, 512, 128), (0.0, -1.0, 0.0), (240, 256, 240), steps_before=8)
+    assert r["movers_in_step"] > 1_000_000 and r["changed_cell_in_step"] > 1000, r   # the step under test moves particles between cells
+    assert r["x"] <= 1e-6 and r["v"] <= 2e-4 and r["C"] <= 2e-4 and r["F"] <= 2e-5 and r["logJp"] <= 2e-5, r
+    assert max(r["grid"]) <= 2e-4 and r["grid_mass_interior"] > 0, r
+
+
+def test_config3_jello_8m_slotted_moving_subbox_vs_oracle(pol, oracle):
+    """BASELINE config 3 anchored to the oracle: the 8 M-particle FixedCorotated cube (256^3 grid) moving 0.013 cell per step; 8 slotted
+    steps, then the 9th step of a 32^3-cell sub-box against oracle/mpm.c (tolerances as above)."""
+    r = _id_box_step(pol, oracle, 0, 256, (100, 100, 100), (0.0, -0.5, 0.0), (112, 32, 112), steps_before=8)
+    assert r["x"] <= 1e-6 and r["v"] <= 2e-4 and r["C"] <= 2e-4 and r["F"] <= 2e-5, r
+    assert max(r["grid"]) <= 2e-4 and r["grid_mass_interior"] > 0, r
