@@ -619,16 +619,18 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *
                                     const unsigned *cellCount, const int *nbr);
 /* ---- slotted particle storage: the motion-robust form of the fused step (zpc_amd/csrc/mpm_slotted.hip).  Storage = bins x K rounds x
  * 64 lanes in ONE TileVector<f32, 64> (slot (bin, r, lane) = element (bin K + r) 64 + lane), cellMask[bin][lane] = occupied rounds of the
- * cell; a particle is always stored under the cell of its base node, and the step keeps it so: particles that change cell go through
- * per-bin outboxes (moverCount / moverDest / moverRec: outboxCap 36-float records per bin and step) and are pulled, added to the grid
- * and re-homed (lowest free round of their cell) by their destination bin in a second kernel (no re-bin, no exact-path queues in the
- * time loop).  status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller, latched: [0] an outbox was full, [1] a cell ran out of
- * rounds, [2] mass for a block outside the partition, [3] more than 16 arrivals in one cell, [4] a particle was not stored under its
- * cell; [8, 264) and [264, 520): movers sent / delivered (running sums spread over 256 words each: a single device-wide word would
- * serialise one atomic per bin, 1.5 ms per step of the 64 M-particle column); unequal totals = a mover's destination is not in the partition.
+ * cell; a particle is always stored under the cell of its base node, and the step keeps it so: the workgroup of a bin adds the grid
+ * contributions of the particles that leave one of its cells through an LDS arena one node layer wider than the bin's stencil, and
+ * stores them into a free round of their destination cell, claimed with an atomic on the cell's claim word (moverCount: int[nbins];
+ * claim: unsigned[nbins * 64], zeroed by the caller ONCE, every step leaves it zero; moverRec: outboxCap 36-float scratch records per
+ * bin) -- no second pass over the particles, no re-bin, no exact-path queues in the time loop.  status: int[ZS_ROCM_SLOT_STATUS_WORDS],
+ * zeroed by the caller, latched: [0] an outbox was full, [1] a cell ran out of rounds, [2] mass or a mover for a block outside the
+ * partition, [3] unused, [4] a particle was not stored under its cell, or moved more than one cell in a step; [8, 264) and [264, 520):
+ * movers sent / re-homed (running sums spread over 256 words each: a single device-wide word would serialise one atomic per bin, 1.5 ms
+ * per step of the 64 M-particle column); unequal totals = particles were lost ([1], [2] say why).
  * The per-particle arithmetic is that of zs_rocm_mpm_g2p2g (G2P.hpp:44-83 + P2G.hpp:51-125). */
 #define ZS_ROCM_SLOT_STATUS_WORDS (8 + 2 * 256)
-ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int outboxCap, int which); /* 0 moverCount, 1 moverDest, 2 moverRec */
+ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int outboxCap, int which); /* 0 moverCount, 1 claim words, 2 moverRec */
 ZS_ROCM_EXPORT void zs_rocm_mpm_build_neighbors27(zs_rocm_policy *, const zs_rocm_bht_3 *, int *nbr27 /* [nblocks][27] */, int keyStride);
 /* src: TileVector<f32,64> with C channels and n particles in any order -> dst: nbins*K tiles; status: int[ZS_ROCM_SLOT_STATUS_WORDS] ([1], [2] are used here) */
 ZS_ROCM_EXPORT int zs_rocm_mpm_slot_particles(zs_rocm_policy *, const zs_rocm_bht_3 *, zs_rocm_attr pos, size_t n, float dx, int side,
@@ -637,7 +639,7 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_slot_particles(zs_rocm_policy *, const zs_rocm_bh
 ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_list(zs_rocm_policy *, const unsigned *cellMask, size_t nbins, int K, int *slots);
 ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
                                              const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr,
-                                             const int *nbr27, int *moverCount, long long *moverDest, float *moverRec, int outboxCap,
+                                             const int *nbr27, int *moverCount, unsigned *claim, float *moverRec, int outboxCap,
                                              int writeAll, int *status);
 /* particles.stress := model(F, logJp) * volume, logJp updated (no-op when particles.stress.base == NULL) */
 /* Fused transfer: G2P of step n (from gridA: velocities after zs_rocm_mpm_grid_update) and P2G of step n+1 (into gridB,

@@ -1959,13 +1959,15 @@ template <int LW, bool DP, bool FLUID = false> struct RecG {  // fused-step inpu
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
     Port<float> pp = ps.pos, pf = ps.F, pm = ps.mass, pl = ps.logJp;
     pp.base += delta; pf.base += delta; pm.base += delta;
-    pload<LW, 3>(pp, o, pos);
-    pload_state<LW, FLUID>(pf, o, F);
+    // m and logJp FIRST: they are used after the constitutive update, and the wait counter is in order -- as the last loads of the
+    // record their wait (s_waitcnt vmcnt(0) behind the SVD) also waited for every store issued in front of the SVD
     m = pload1<LW>(pm, o);
     if constexpr (DP) {
       pl.base += delta;
       logJp = pload1<LW>(pl, o);
     }
+    pload<LW, 3>(pp, o, pos);
+    pload_state<LW, FLUID>(pf, o, F);
   }
 };
 

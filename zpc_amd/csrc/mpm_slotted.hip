@@ -12,23 +12,42 @@
 //     32-bit mask per cell says which of its K <= 32 rounds hold a particle.  A particle is ALWAYS stored under the cell of its
 //     base node;
 //   * the main kernel (role-split, as g2p2g_rs_kernel) does G2P + advection + constitutive update of every particle and scatters
-//     the ones that stay in their cell from registers.  A particle whose base node changes ("mover": same bin or not) is not
-//     scattered: its state {m, x', F', logJp', v', C', P F^T} goes to the OUTBOX of its source bin (a fixed region per bin: no global
-//     counter), with its destination cell; its slot becomes a hole (mask bit cleared);
-//   * the mover kernel (one workgroup per bin) PULLS: it scans the outboxes of its 27 neighbour bins for records addressed to one
-//     of its cells (a particle moves less than a cell per step), hands them to the lane of that cell, scatters them with the same
-//     register-stencil code as the main kernel, and stores their state into free rounds of the cell.  No sort, no global atomics
-//     except the arena flush, and nobody but the movers is ever relocated.
+//     the ones that stay in their cell from registers.  The slot of a particle whose base node changes ("mover") becomes a hole;
+//   * r03: the workgroup that moves a particle finishes it (r02 ran a second kernel in which every bin pulled from the outboxes of its 27
+//     neighbours and accumulated the arrivals: 1.8 ms per step of the 64 Mi-particle column, a chain of dependent loads per bin).  New
+//     cell inside the bin: a ticket of the cell's LDS counter names a free round, the state is stored there at once, and the lane of
+//     the new cell adds the particle's grid terms from the staging ring in an iteration in which it has no particle of its own.  New
+//     cell in a neighbour bin: the consumer waves add its 27 x 7 node terms with global float atomics (lane = node x channel), its
+//     state goes to an outbox record, and slot_rehome_kernel (one lane per record, after the main kernel) draws a ticket from the
+//     destination cell's global counter and copies the state into that round.  slot_commit_kernel folds departures and tickets into
+//     the occupancy words.  Details and the measured dead ends: comment of the main kernel.
 //
 // The result of a step is the same sum of the same per-particle terms as zs_rocm_mpm_g2p2g (different summation order); bins,
-// re-bins and exact-path queues disappear from the time loop.  Capacity limits (K rounds per cell, `cap` records per outbox,
-// SL_MAXIN arrivals per cell and step) are reported in the status words, never dropped silently.
+// re-bins and exact-path queues disappear from the time loop.  Capacity limits (K rounds per cell, `cap` records per outbox)
+// are reported in the status words, never dropped silently.
 #include "mpm_device.hpp"
 
 namespace zsr {
 
-constexpr int SL_REC = 36;    // floats per record: m, x(3), F(9), logJp, v(3), C(9), P F^T(9), pad
-constexpr int SL_MAXIN = 16;  // arrivals one cell can take per step
+constexpr int SL_REC = 48;    // floats per outbox record (192 bytes = three 64-byte lines).  First line, all slot_rehome_kernel reads without
+                              // writeAll: [0] m, [1] x(3), [4] F(9), [13] logJp, [14] destination cell (bin * 64 + lane; ~0: none),
+                              // [15] flag: its grid contributions are still to be added; then [16] v(3), [19] C(9), [28] P F^T(9)
+                              // (written for writeAll steps and for flagged records only)
+constexpr int SLR_DCELL = 14, SLR_FLAG = 15, SLR_V = 16, SLR_C = 19, SLR_PF = 28;
+
+#ifdef ZS_SLOT_PROBE  // measurement-only build (tools/ablate_slot.sh PROBE): cycle stamps of a workgroup's phases, summed over sampled workgroups
+__device__ unsigned long long g_slot_probe[16];
+#define SLP_SAMPLED ((blockIdx.x & 63) == 0)
+#define SLP_T0(name) const unsigned long long name = __builtin_readcyclecounter()
+#define SLP_ADD(slot, t0) do { if ((threadIdx.x & 63) == 0 && SLP_SAMPLED) atomicAdd(&g_slot_probe[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
+#define SLP_ACC(var, t0) var += __builtin_readcyclecounter() - (t0)
+#define SLP_PUT(slot, v) do { if ((threadIdx.x & 63) == 0 && SLP_SAMPLED) atomicAdd(&g_slot_probe[slot], (unsigned long long)(v)); } while (0)
+#else
+#define SLP_T0(name) do { } while (0)
+#define SLP_ADD(slot, t0) do { } while (0)
+#define SLP_ACC(var, t0) do { } while (0)
+#define SLP_PUT(slot, v) do { } while (0)
+#endif
 
 struct SlotArgs {
   const float *gridA;
@@ -36,28 +55,19 @@ struct SlotArgs {
   unsigned *cellMask;   // [nbins][64] occupancy of the K rounds of every cell
   int K;
   const int *nbr;       // [nblocks][8]  blocks at offsets {0,1}^3 (arena -> grid)
-  const int *nbr27;     // [nblocks][27] blocks at offsets {-1,0,1}^3 (mover pull)
-  int *moverCount;      // [nbins]
-  long long *moverDest; // [nbins][cap] destination cell, packed 21 bits per axis (biased)
-  float *moverRec;      // [nbins][cap][SL_REC]
-  int *status;          // [0] outbox full, [1] cell full (K), [2] mass for a block outside the partition, [3] more than SL_MAXIN
-                        // arrivals in one cell, [4] a particle was not stored under its cell; [8 .. 8 + 256) records sent,
-                        // [264 .. 264 + 256) records delivered (running sums spread over 256 words each: unequal totals after a step = a
-                        // mover's destination block is not in the partition)
-  int binBase, nbins;
+  const int *nbr27;     // [nblocks][27] blocks at offsets {-1,0,1}^3 (movers: arena flush, destination bin)
+  int *moverCount;      // [nbins] movers of the bin in this step (diagnostic)
+  unsigned *claim;      // [2][nbinsAll][64]: [0] this step's arrivals (high 16 bits: from inside the bin, low 16: from other bins), [1] rounds
+                        // vacated in this step; zero between steps (slot_commit_kernel folds both into cellMask)
+  float *moverRec;      // [nbins][cap][SL_REC] outbox records: movers that left their bin (or found the arrival queue of their cell full)
+  int *status;          // [0] outbox full, [1] cell full (K), [2] mass / a mover for a block outside the partition, [3] unused,
+                        // [4] a particle was not stored under its cell; [8 .. 8 + 256) movers sent, [264 .. 264 + 256) movers re-homed
+                        // (running sums spread over 256 words each: unequal totals after a step = particles were lost, see [1], [2])
+  int binBase, nbins, nbinsAll;
   int cap;              // outbox records per bin and step (caller's choice: a bin holds 512 particles at 8 per cell)
 };
 
 constexpr int SL_NCTR = 256, SL_SENT = 8, SL_DELIVERED = 8 + SL_NCTR;  // layout of the status words (zs_rocm.h: ZS_ROCM_SLOT_STATUS_WORDS)
-__device__ __forceinline__ long long pack_cell(int x, int y, int z) {
-  return ((long long)(x + (1 << 20)) << 42) | ((long long)(y + (1 << 20)) << 21) | (long long)(z + (1 << 20));
-}
-__device__ __forceinline__ void unpack_cell(long long p, int &x, int &y, int &z) {
-  x = (int)((p >> 42) & 0x1fffff) - (1 << 20);
-  y = (int)((p >> 21) & 0x1fffff) - (1 << 20);
-  z = (int)(p & 0x1fffff) - (1 << 20);
-}
-
 // ------------------------------------------------------------------------------------------------------------------ slotting
 template <int SIDE>
 static __global__ __launch_bounds__(256) void slot_assign_kernel(BhtDev t, Port<float> pos, size_t n, float dx, unsigned *cellCount, int K,
@@ -159,14 +169,123 @@ template <int SIDE> __device__ __forceinline__ int neighbour_bin(const int *nbr2
 // round-major order: entry e of the bin <-> (round r, cell c) through a table built from the occupancy words at the head of the
 // kernel.  Results are staged by entry; a consumer lane finds the entry of (r, its cell) by the same enumeration
 // (off[r] + popcount of the occupied cells below it) and consumes a round as soon as all of its entries have been produced.
+//
+// Movers (r03; r02 ran a second kernel in which every bin pulled from the outboxes of its 27 neighbours and added the arrivals to the
+// grid: 1.8 ms per step of the 64 Mi-particle column for 5 % of the particles, a chain of dependent loads per bin).  A particle whose
+// base node changes is finished by the workgroup that moved it:
+//   * new cell inside the bin (three of four movers of a drifting cloud): the producer draws a ticket from the destination cell's LDS
+//     counter -- ticket t = the t-th lowest round that was free at the start of the step --, stores the particle's state straight into
+//     that slot, stages {m, x', v', C', P F^T} like a stayer's and puts the staged position on the destination cell's arrival queue.
+//     The consumer lane of that cell takes queued arrivals in iterations in which it has no particle of its own (a third of a lane's
+//     round slots are holes): the grid contributions of an in-bin mover cost no additional instruction slot;
+//   * new cell in a neighbour bin (or arrival queue full): the 40-float record goes to the bin's outbox.  In the LAST iteration of the
+//     chunk loop, in which the producer waves have nothing to produce (the consumers still work on the last chunk), they read the
+//     records back and add their 27 x 7 node terms straight to the grid with lane = (node, channel): 3 global float atomics per
+//     record and wave-instruction, fire and forget -- the same atomics the arena flush issues, no LDS read-modify-write chain, no
+//     dependence between records.  (Measured dead ends: ds_add_f32 into a wider LDS arena, ~3 cycles per lane: +4 ms; returning
+//     global ticket atomics in the producer loop: ~5 us round trip under load, +2.6 ms; one wave per channel walking the records with
+//     plain LDS read-add-write: latency-bound, 6 us per workgroup.)  The record's new home is found by slot_rehome_kernel after the
+//     step: one thread per record, ticket from the destination cell's global counter, rounds above the in-bin arrivals.
+// Departures and ticket counts are folded into the occupancy words by slot_commit_kernel.
 constexpr int SL_NG = 9;       // staged entry groups of 64: a chunk being produced (4) + the chunk being consumed (4) + a straddling round
 constexpr int SL_KMAX = 32;    // rounds per bin the 32-bit occupancy words allow
+constexpr int SL_ARRQ = 4;     // in-bin arrivals one cell takes per chunk through the consumers' queue
+constexpr int SL_XQ = 64;      // movers per chunk whose grid contributions the consumers add with global atomics (new cell in another bin, or
+                               // arrival queue full); more: scattered from their outbox records after the loop
+
+// t-th (0-based) lowest set bit of w, or -1
+__device__ __forceinline__ int nth_low_bit(unsigned w, unsigned t) {
+  for (unsigned k = 0; k < t && w; ++k) w &= w - 1u;
+  return w ? __ffs((int)w) - 1 : -1;
+}
+struct SlotShared {  // views of the kernel's LDS arrays
+  float *varena;                     // [3 * ArenaLds::CH] node velocities of the bin
+  float *parena;                     // [7 * ArenaLds::CH] the bin's P2G arena
+  float *stage;                      // [SL_NG * G2P2G_NF * 64]
+  unsigned long long *smask;         // [SL_NG]
+  unsigned short *tab;               // [SL_KMAX * 64] entry -> round * 64 + cell
+  unsigned *mask0;                   // [64] occupancy of the bin's cells at the start of the step
+  unsigned *clr;                     // [64] rounds vacated in this step
+  unsigned *arrLocal;                // [64] in-bin arrivals of the cell in this step (ticket counter)
+  const int *nbrBlk;                 // [27] the grid blocks around this bin's block (-1: not in the partition)
+  const int *nbrBin;                 // [27] the bins around this one (direction code (dx + 1) 9 + (dy + 1) 3 + dz + 1)
+  unsigned (*arrCnt)[64];            // [3][64] arrivals queued for the consumers, by chunk number mod 3
+  unsigned short (*arrQ)[64][SL_ARRQ];  // [3][64][SL_ARRQ]
+  unsigned *xCnt;                    // [3] entries of xq, by chunk number mod 3
+  unsigned (*xq)[SL_XQ];             // [3][SL_XQ] staged position | (new cell + 1, 3 bits per axis) << 10
+  int *outCount, *sent, *homed, *xOver;
+};
+
+// One stencil node x one grid channel of ONE particle, straight to the grid (P2G.hpp:104-124): node in 0..26, ch in 0..6; the
+// particle's new base node is `nc` cells from the origin of the bin's block, its position inside it `d0` (normalised, 0.5 .. 1.5);
+// fm / fv / fC / fP: accessors of m, v_d, C[k], P F^T[k]
+template <int SIDE, class FM, class FV, class FC, class FP>
+__device__ __forceinline__ void scatter_node_task(const MpmDev &mp, int node, int ch, const int (&nc)[3], const float (&d0)[3], FM fm, FV fv, FC fC,
+                                                  FP fP, const int *nbrBlk, float *gridB, int *status) {
+  constexpr int NC = SIDE * SIDE * SIDE;
+  const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
+  float Wt = 1.f, xi[3];
+  int g[3], code = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float u = sel[d] == 0 ? 1.5f - d0[d] : (sel[d] == 1 ? d0[d] - 1.0f : d0[d] - 0.5f);
+    Wt *= sel[d] == 1 ? 0.75f - u * u : 0.5f * u * u;
+    xi[d] = (float)sel[d] * mp.dx - d0[d] * mp.dx;
+    g[d] = nc[d] + sel[d];
+    code = code * 3 + (g[d] < 0 ? 0 : (g[d] >= SIDE ? 2 : 1));
+  }
+  float val;
+  if (ch == 0) {
+    val = fm() * Wt;
+  } else if (ch < 4) {
+    const int d = ch - 1;
+    val = Wt * fm() * (fv(d) + (fC(d) * xi[0] + fC(3 + d) * xi[1] + fC(6 + d) * xi[2]));
+  } else {
+    const int d = ch - 4;
+    const float dxi = 1.0f / mp.dx;
+    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    val = (fP(d) * kscale * xi[0] + fP(3 + d) * kscale * xi[1] + fP(6 + d) * kscale * xi[2]) * Wt;
+  }
+  const int bn = nbrBlk[code];
+  if (bn >= 0) {
+    const int cell = ((g[0] & (SIDE - 1)) * SIDE + (g[1] & (SIDE - 1))) * SIDE + (g[2] & (SIDE - 1));
+    if (val != 0.f) unsafeAtomicAdd(gridB + ((size_t)bn * 7 + ch) * NC + cell, val);
+  } else if (ch == 0) {
+    status[2] = 1;  // mass for a node whose block is not in the partition
+  }
+}
+
+// After the loop (rare: more than SL_XQ such movers in one chunk): the outbox records rec[0 .. n) that ask for it -> grid.  Record j
+// belongs to wave j mod 8; lane task t = pass * 64 + lane < 189 = (stencil node t mod 27, grid channel t / 27).
+template <int SIDE>
+__device__ __forceinline__ void outbox_scatter_global(const MpmDev &mp, const BinGeom<SIDE> &geo, const float *recs, int n, int w, int lane,
+                                                      const int *nbrBlk, float *gridB, int *status) {
+  const float dxi = 1.0f / mp.dx;
+#pragma unroll 1
+  for (int q = 0;; ++q) {
+    const int j = w + 8 * (q / 3), p = q % 3;
+    if (j >= n) break;
+    const int t = p * 64 + lane;
+    const float *rc = recs + (size_t)j * SL_REC;
+    if (t >= 189 || reinterpret_cast<const unsigned *>(rc)[SLR_FLAG] == 0u) continue;
+    int nc[3];
+    float d0[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float X = rc[1 + d] * dxi;
+      const float fl = floorf(X - 0.5f);
+      d0[d] = X - fl;
+      nc[d] = (int)fl - geo.org[d] + geo.o[d];
+    }
+    scatter_node_task<SIDE>(mp, t % 27, t / 27, nc, d0, [&]() { return rc[0]; }, [&](int d) { return rc[SLR_V + d]; },
+                            [&](int k) { return rc[SLR_C + k]; }, [&](int k) { return rc[SLR_PF + k]; }, nbrBlk, gridB, status);
+  }
+}
 
 // producer wave W (0..3): entries [64 (4c + W), +64) of every chunk c
 template <int SIDE, int SMODEL, bool WRITE_ALL, int W>
 __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int bin, int total,
-                                                    int lane, int nchunks, float *varena, float *stage, unsigned long long *smask,
-                                                    const unsigned short *tab, int *outCount, unsigned *clrAll, const SlotArgs &A) {
+                                                    int lane, int nchunks, const SlotShared &sh, const SlotArgs &A) {
   using AL = ArenaLds;
   constexpr int LW = 64;
   constexpr bool DP = model_uses_logjp(SMODEL);
@@ -175,6 +294,17 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
   const float dxi = 1.0f / mp.dx;
   const float D_inv = 4.f * dxi * dxi;
   const size_t rowBase = (size_t)bin * (size_t)A.K;
+  const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
+  float *const varena = sh.varena, *const stage = sh.stage;
+  unsigned long long *const smask = sh.smask;
+  const unsigned short *const tab = sh.tab;
+  unsigned *const mask0 = sh.mask0, *const clr = sh.clr, *const arrLocal = sh.arrLocal;
+  const int *const nbrBin = sh.nbrBin;
+  unsigned(*const arrCnt)[64] = sh.arrCnt;
+  unsigned short(*const arrQ)[64][SL_ARRQ] = sh.arrQ;
+  unsigned *const xCnt = sh.xCnt;
+  unsigned(*const xq)[SL_XQ] = sh.xq;
+  int *const outCount = sh.outCount, *const sent = sh.sent, *const homed = sh.homed, *const xOver = sh.xOver;
   RecG<LW, DP, FLUID> cur, nxt;
   bool has0 = false, has1 = false;
   size_t i0 = 0, i1 = 0;
@@ -201,10 +331,17 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
       for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
     }
   }
+  SLP_T0(tFill);
   __syncthreads();
+  if (W == 0) SLP_ADD(2, tFill);
+#ifdef ZS_SLOT_PROBE
+  unsigned long long tWork = 0, tBar = 0;
+#endif
   for (int it = 0; it <= nchunks; ++it) {
+    SLP_T0(tIt);
     if (it < nchunks) {
       const int grp = 4 * it + W;
+      const int par = it % 3;
       float *myStage = stage + (size_t)(grp % SL_NG) * (G2P2G_NF * 64);
       has1 = false;
       if (it + 1 < nchunks) {
@@ -228,7 +365,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
         } else {
           float vel[3], C[9];
           g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
-          const POff<LW> o = particle_offset<LW>(ps.pos.chns, i0);
           float pos[3];
 #pragma unroll
           for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
@@ -243,29 +379,101 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             nc[d] = (int)fl - geo.org[d];
             lpn[d] = X - fl;
           }
-#ifdef ZS_SLOT_NOMOVER  // measurement build: what does the presence of the mover path cost a step without movers?
+          const float pm = cur.m;
+          float plj = 0.f;
+          if constexpr (DP) plj = cur.logJp;
+#ifdef ZS_X_NOMOVE
           const bool moved = false;
 #else
           const bool moved = nc[0] != cx || nc[1] != cy || nc[2] != cz;
 #endif
+          if (W == 0) SLP_ADD(5, tIt);  // [5] producer: start of the iteration -> mover block (record wait, gather, advance)
+          SLP_T0(tMv);
+          bool outbox = false;   // it gets an outbox record (new cell in a neighbour bin: slot_rehome_kernel finds its slot; or fallback scatter)
+          bool staged = !moved;  // {m, x', v', C', P F^T} staged for the consumers
+          bool home = false;     // mover with a new slot inside this bin
+          unsigned recFlag = 0u; // record word SLR_FLAG: the record's grid contributions are still to be added (after the loop)
           float *rec = nullptr;
+          POff<LW> o = particle_offset<LW>(ps.pos.chns, i0);  // where the particle lives after the step
           if (moved) {
-            const int k = atomicAdd(outCount, 1);
-            if (k < A.cap) {
-              rec = A.moverRec + ((size_t)bin * A.cap + (size_t)k) * SL_REC;
-              A.moverDest[(size_t)bin * A.cap + (size_t)k] = pack_cell(nc[0] + geo.org[0], nc[1] + geo.org[1], nc[2] + geo.org[2]);
+            int code = 0;
+            bool far = false;
 #pragma unroll
-              for (int d = 0; d < 3; ++d) rec[1 + d] = pos[d];
-#pragma unroll
-              for (int d = 0; d < 9; ++d) rec[4 + d] = F[d];
-#pragma unroll
-              for (int d = 0; d < 3; ++d) rec[14 + d] = vel[d];
-#pragma unroll
-              for (int d = 0; d < 9; ++d) rec[17 + d] = C[d];
-            } else {
-              A.status[0] = 1;  // outbox full: the particle (and its contribution) would be lost -- reported, the caller must react
+            for (int d = 0; d < 3; ++d) {
+              far = far || (unsigned)(nc[d] + 1) > 5u;
+              code = code * 3 + (nc[d] < 0 ? 0 : (nc[d] > 3 ? 2 : 1));
             }
-            atomicOr(&clrAll[cell], 1u << r);  // its slot becomes a hole
+            const int dl = ((nc[0] & 3) * 4 + (nc[1] & 3)) * 4 + (nc[2] & 3);
+            unsigned dcell = 0xffffffffu;  // destination cell of a record whose home slot_rehome_kernel has to find
+            bool viaX = true;              // its grid contributions: consumers' global-atomic list (else: arrival queue of its new cell)
+            if (far) {
+              A.status[4] = 1;  // moved more than one cell in one step (CFL violated): not representable (scattered nowhere, lost)
+              viaX = false;
+            } else if (code == 13) {  // new cell inside this bin: a ticket of its LDS counter = a free round, from the bottom
+              const int rr = nth_low_bit(~mask0[dl] & kmask, atomicAdd(&arrLocal[dl], 1u));
+              if (rr >= 0) {
+                home = true;
+                o = particle_offset<LW>(ps.pos.chns, (rowBase + (size_t)rr) * 64 + (size_t)dl);
+              } else {
+                A.status[1] = 1;  // cell full: the particle is scattered but has no slot (sent != homed)
+              }
+#ifndef ZS_X_NOINBIN
+              const unsigned q = atomicAdd(&arrCnt[par][dl], 1u);
+              if (q < (unsigned)SL_ARRQ) {  // the lane of the new cell scatters it (arrival queue of the chunk)
+                viaX = false;
+                staged = true;
+                arrQ[par][dl][q] = (unsigned short)((grp % SL_NG) * 64 + lane);
+              }
+#endif
+            } else {
+              outbox = true;
+              const int dbin = nbrBin[code];
+              if (dbin >= 0) dcell = (unsigned)dbin * 64u + (unsigned)dl;
+              else A.status[2] = 1;  // the destination block is not in the partition: nowhere to live (sent != homed)
+            }
+            if (viaX) {
+              const unsigned k = atomicAdd(&xCnt[par], 1u);
+              if (k < (unsigned)SL_XQ) {
+                staged = true;
+                xq[par][k] = (unsigned)((grp % SL_NG) * 64 + lane) | ((unsigned)(nc[0] + 1) << 10) | ((unsigned)(nc[1] + 1) << 13) |
+                             ((unsigned)(nc[2] + 1) << 16);
+              } else {  // list full: a full record, scattered after the loop
+                outbox = true;
+                recFlag = 1u;
+                atomicAdd(xOver, 1);
+              }
+            }
+            if (outbox) {
+              const int k = atomicAdd(outCount, 1);
+              if (k < A.cap) {
+                rec = A.moverRec + ((size_t)bin * A.cap + (size_t)k) * SL_REC;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) rec[1 + d] = pos[d];
+#pragma unroll
+                for (int d = 0; d < 9; ++d) rec[4 + d] = F[d];
+                if (WRITE_ALL || recFlag) {
+#pragma unroll
+                  for (int d = 0; d < 3; ++d) rec[SLR_V + d] = vel[d];
+#pragma unroll
+                  for (int d = 0; d < 9; ++d) rec[SLR_C + d] = C[d];
+                }
+                reinterpret_cast<unsigned *>(rec)[SLR_DCELL] = dcell;
+                reinterpret_cast<unsigned *>(rec)[SLR_FLAG] = recFlag;
+              } else {
+                A.status[0] = 1;  // outbox full: the particle is lost -- reported, the caller must react
+              }
+            }
+            if (home) {
+              pstore_state<LW, FLUID>(ps.F, o, F);
+              pstore<LW, 3>(ps.pos, o, pos);
+              if (WRITE_ALL) {
+                pstore<LW, 3>(ps.vel, o, vel);
+                pstore<LW, 9>(ps.C, o, C);
+              }
+              atomicAdd(homed, 1);
+            }
+            atomicOr(&clr[cell], 1u << r);  // its slot becomes a hole
+            atomicAdd(sent, 1);
           } else {
             pstore_state<LW, FLUID>(ps.F, o, F);
             pstore<LW, 3>(ps.pos, o, pos);
@@ -275,27 +483,30 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             }
           }
           {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
-            float lj = 0.f;
-            if constexpr (DP) lj = cur.logJp;
+            float lj = plj;
             model_stress<SMODEL>(mp.mat, lj, F, PF, C);
-            if (moved) {
+            if (outbox) {
               if (rec) {
-                rec[0] = cur.m;  // (the mass is the last value of the record load: stored here, its wait does not hold up the stores above)
+                rec[0] = pm;
                 rec[13] = lj;
+                if (WRITE_ALL || recFlag) {
 #pragma unroll
-                for (int d = 0; d < 9; ++d) rec[26 + d] = PF[d];
+                  for (int d = 0; d < 9; ++d) rec[SLR_PF + d] = PF[d];
+                }
               }
-            } else {
+            }
+            if (!moved || home) {
               if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
               if (WRITE_ALL) pstore<LW, 9>(ps.stress, o, PF);
+              if (moved) pstore1<LW>(ps.mass, o, pm);
             }
           }
-          if (!moved) {
+          if (staged) {
             // staged AFTER the constitutive update, as in g2p2g_rs_producer: with m, x', v', C' dead before it the compiler
             // reuses their registers for the SVD at once and waits for the particle stores just issued (s_waitcnt vmcnt(1)
             // in front of the SVD: 2 ms per 64 Mi particles)
-            valid = true;
-            myStage[0 * 64 + lane] = cur.m;
+            valid = !moved;  // an in-bin mover is consumed by the lane of its NEW cell (arrival queue), not by the lane of its entry
+            myStage[0 * 64 + lane] = pm;
 #pragma unroll
             for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
 #pragma unroll
@@ -316,20 +527,36 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
       i0 = i1;
       code0 = code1;
     }
+    if (it < nchunks) SLP_ACC(tWork, tIt);
+    SLP_T0(tB);
     __syncthreads();
+    if (it < nchunks) SLP_ACC(tBar, tB);
+    else if (W == 0) SLP_ADD(6, tB);
+  }
+  if (W == 0) {
+    SLP_PUT(3, tWork);
+    SLP_PUT(4, tBar);
   }
 }
 // consumer wave of channel set CS: lane = cell; after chunk c has been produced every round whose last entry lies below 256 (c + 1)
-// is complete and is consumed while the producers work on chunk c + 1
-template <int CS>
-__device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, unsigned mask, int total, int lane, int nchunks, const float *stage,
-                                                    const unsigned long long *smask, float *parena) {
+// is complete and is consumed while the producers work on chunk c + 1 -- together with the in-bin arrivals queued during chunk c
+template <int SIDE, int CS>
+__device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinGeom<SIDE> &geo, unsigned mask, int total, int lane, int nchunks,
+                                                    const SlotShared &sh, const SlotArgs &A) {
   using S = ConsumerSet<CS>;
   using AL = ArenaLds;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const float dxi = 1.0f / mp.dx;
   const float kscale = -mp.dt * (4.f * dxi * dxi);
   const unsigned long long lt = lanemask_lt();
+  const float *const stage = sh.stage;
+  const unsigned long long *const smask = sh.smask;
+  unsigned(*const arrCnt)[64] = sh.arrCnt;
+  const unsigned short(*const arrQ)[64][SL_ARRQ] = sh.arrQ;
+  float *const parena = sh.parena;
+  unsigned *const xCnt = sh.xCnt;
+  const unsigned(*const xq)[SL_XQ] = sh.xq;
+  const int *const nbrBlk = sh.nbrBlk;
   float acc[27][S::NA];
 #pragma unroll
   for (int k = 0; k < 27; ++k)
@@ -337,27 +564,132 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, unsigned m
     for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
   for (int k = (int)threadIdx.x - 256; k < 7 * AL::CH; k += 256) parena[k] = 0.f;  // the four consumer waves clear the bin's arena
   __syncthreads();  // (the producers fill the velocity arena meanwhile)
+#ifdef ZS_SLOT_PROBE
+  unsigned long long tWork = 0, tBar = 0;
+#endif
   int r = 0, off = 0;  // next round to consume, entry number of its first particle
   for (int it = 0; it <= nchunks; ++it) {
+    SLP_T0(tIt);
     if (it > 0) {
+      const int par = (it - 1) % 3;
       const int produced = 256 * it < total ? 256 * it : total;
+      const unsigned qn = arrCnt[par][lane];
+#ifdef ZS_X_NOARR
+      const int na = 0;
+#else
+      const int na = qn < (unsigned)SL_ARRQ ? (int)qn : SL_ARRQ;
+#endif
+      int ai = 0;
+      if (CS == 0) arrCnt[(it + 1) % 3][lane] = 0u;  // the counters the NEXT chunk will use (last read one iteration ago)
 #pragma unroll 1
-      while (off < total) {
-        const bool has = (mask >> r) & 1u;
-        const unsigned long long occ = __ballot(has);
-        const int cnt = __popcll(occ);
-        if (off + cnt > produced) break;  // the round's last entries belong to the chunk in production
-        if (has) {
-          const int e = off + __popcll(occ & lt);
-          const int grp = (e >> 6) % SL_NG, pos = e & 63;
-          if ((smask[grp] >> pos) & 1ull) g2p2g_consume_set<CS>(mp, stage, grp * (G2P2G_NF * 64) + pos, kscale, acc);
+      for (;;) {
+        bool roundOk = false, has = false;
+        unsigned long long occ = 0ull;
+        int cnt = 0;
+        if (off < total) {
+          has = (mask >> r) & 1u;
+          occ = __ballot(has);
+          cnt = __popcll(occ);
+          roundOk = off + cnt <= produced;  // else: the round's last entries belong to the chunk in production
         }
-        off += cnt;
-        ++r;
+        const bool pend = ai < na;
+        if (!roundOk && __ballot(pend) == 0ull) break;
+        int spos = -1;
+        if (roundOk) {
+          if (has) {
+            const int e = off + __popcll(occ & lt);
+            const int grp = (e >> 6) % SL_NG, pos = e & 63;
+            if ((smask[grp] >> pos) & 1ull) spos = grp * (G2P2G_NF * 64) + pos;
+          }
+          off += cnt;
+          ++r;
+        }
+        if (spos < 0 && pend) {  // a lane without a particle of its own in this round takes an arrival
+          const unsigned p = arrQ[par][lane][ai++];
+          spos = (int)(p >> 6) * (G2P2G_NF * 64) + (int)(p & 63u);
+        }
+        if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
+        if (CS == 0) SLP_PUT(15, 1);  // [15] consumer: loop iterations (rounds + extra rounds for arrivals)
+      }
+      if (CS == 0) SLP_ADD(13, tIt);  // [13] consumer: rounds loop (incl. in-bin arrivals)
+      SLP_T0(tX);
+      // movers of the chunk whose new cell is not a lane of this bin (or whose cell's arrival queue was full): this set's channels
+      // of their 27 node terms straight to the grid, lane = (stencil node, channel of the set)
+      const int nx = xCnt[par] < (unsigned)SL_XQ ? (int)xCnt[par] : SL_XQ;
+      if (CS == 0 && lane == 0) xCnt[(it + 1) % 3] = 0u;
+      {
+        // lane = (stencil node, channel of the set).  The channel's term is Wt (am m + ak) (b1 + bb B + c . xi) -- mass: m; momentum d:
+        // m (v_d + C[., d] . xi); force d: -dt Dinv (P F^T[., d] . xi) -- and a node's weight per axis alpha + beta (s d0 + t)^2: every
+        // choice is a per-lane constant, the loop body has no branch but the partition test
+        constexpr int NC = SIDE * SIDE * SIDE;
+        const int node = lane & 31, chs = lane >> 5;
+        const bool act = node < 27 && chs < S::NA;
+        const int ch = S::CH0 + (chs < S::NA ? chs : 0);
+        const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
+        const int dd = ch == 0 ? 0 : (ch < 4 ? ch - 1 : ch - 4);
+        const int iB = ch == 0 ? 0 : (ch < 4 ? 4 + dd : 0);  // staged field of B
+        const int iC = ch < 4 ? 7 + dd : 16 + dd;             // first entry of the column; the others 3 and 6 further
+        const float am = ch < 4 ? 1.f : 0.f, ak = ch < 4 ? 0.f : kscale;
+        const float b1 = ch == 0 ? 1.f : 0.f, bb = (ch > 0 && ch < 4) ? 1.f : 0.f, useC = ch == 0 ? 0.f : 1.f;
+        float ws[3], wt[3], wa[3], wb[3], xo[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          ws[q] = sel[q] == 0 ? -1.f : 1.f;
+          wt[q] = sel[q] == 0 ? 1.5f : (sel[q] == 1 ? -1.f : -0.5f);
+          wa[q] = sel[q] == 1 ? 0.75f : 0.f;
+          wb[q] = sel[q] == 1 ? -1.f : 0.5f;
+          xo[q] = (float)sel[q] * mp.dx;
+        }
+#ifdef ZS_X_NOXQ
+        if (false) {
+#else
+        if (act && nx > 0) {
+#endif
+#pragma unroll 1
+          for (int k = 0; k < nx; ++k) {
+            const unsigned e = xq[par][k];
+            const float *st = stage + (size_t)((e & 1023u) >> 6) * (G2P2G_NF * 64) + (e & 63u);
+            float Wt = 1.f, dot = 0.f;
+            int g[3], code = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const float d0 = st[(1 + q) * 64];
+              const float u = fmaf(ws[q], d0, wt[q]);
+              Wt *= fmaf(wb[q], u * u, wa[q]);
+              dot = fmaf(st[(iC + 3 * q) * 64], fmaf(-mp.dx, d0, xo[q]), dot);
+              g[q] = (int)((e >> (10 + 3 * q)) & 7u) - 1 + geo.o[q] + sel[q];
+              code = code * 3 + 1 + (g[q] >= SIDE ? 1 : 0) - (g[q] < 0 ? 1 : 0);
+            }
+            const float val = Wt * fmaf(am, st[0], ak) * (fmaf(bb, st[iB * 64], b1) + useC * dot);
+            const int bn = nbrBlk[code];
+            if (bn >= 0) {
+              const int cell = ((g[0] & (SIDE - 1)) * SIDE + (g[1] & (SIDE - 1))) * SIDE + (g[2] & (SIDE - 1));
+#ifndef ZS_X_NOXATOMIC
+              if (val != 0.f) unsafeAtomicAdd(A.gridB + ((size_t)bn * 7 + ch) * NC + cell, val);
+#else
+              if (val == 1234.5f) A.status[7] = cell;
+#endif
+            } else if (ch == 0) {
+              A.status[2] = 1;  // mass for a node whose block is not in the partition
+            }
+          }
+        }
+      }
+      if (CS == 0) {
+        SLP_ADD(14, tX);  // [14] consumer: global-atomic list
+        SLP_PUT(12, nx);  // [12] entries of the list
       }
     }
+    SLP_ACC(tWork, tIt);
+    SLP_T0(tB);
     __syncthreads();
+    SLP_ACC(tBar, tB);
   }
+  if (CS == 0) {
+    SLP_PUT(7, tWork);
+    SLP_PUT(8, tBar);
+  }
+  SLP_T0(tFl);
   // the set's channels of the bin's arena belong to this wave alone; phases ordered inside the wave (see g2p2g_body)
   float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
 #pragma unroll
@@ -367,21 +699,28 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, unsigned m
     for (int q = 0; q < S::NA; ++q) g[q * AL::CH] += acc[k][q];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  if (CS == 0) SLP_ADD(9, tFl);
 }
 
 template <int SIDE, int SMODEL, bool WRITE_ALL>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
-  __shared__ float varena[3 * AL::CH];
-  __shared__ float parena[7 * AL::CH];
-  __shared__ float stage[SL_NG * G2P2G_NF * 64];
-  __shared__ unsigned long long smask[SL_NG];
-  __shared__ unsigned short tab[SL_KMAX * 64];  // entry -> round * 64 + cell
-  __shared__ unsigned clrAll[64];
-  __shared__ int outCount;
+  __shared__ float s_varena[3 * AL::CH];
+  __shared__ float s_parena[7 * AL::CH];
+  __shared__ float s_stage[SL_NG * G2P2G_NF * 64];
+  __shared__ unsigned long long s_smask[SL_NG];
+  __shared__ unsigned short s_tab[SL_KMAX * 64];
+  __shared__ unsigned s_mask0[64], s_clr[64], s_arrLocal[64], s_arrCnt[3][64];
+  __shared__ unsigned short s_arrQ[3][64][SL_ARRQ];
+  __shared__ int s_nbrBlk[27], s_nbrBin[27];
+  __shared__ unsigned s_xCnt[3], s_xq[3][SL_XQ];
+  __shared__ int s_outCount, s_sent, s_homed, s_xOver;
+  const SlotShared sh{s_varena, s_parena, s_stage, s_smask, s_tab, s_mask0, s_clr, s_arrLocal, s_nbrBlk, s_nbrBin, s_arrCnt, s_arrQ,
+                      s_xCnt, s_xq, &s_outCount, &s_sent, &s_homed, &s_xOver};
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int bin = blockIdx.x + A.binBase;
+  SLP_T0(tStart);
   const unsigned mask = A.cellMask[(size_t)bin * 64 + lane];
   // round-major enumeration of the occupied slots (every wave walks the rounds; wave w fills the table rows of rounds = w mod 8)
   unsigned any = mask;
@@ -398,41 +737,70 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
     for (int r = 0; r < nrounds; ++r) {
       const bool has = (mask >> r) & 1u;
       const unsigned long long occ = __ballot(has);
-      if ((r & 7) == w && has) tab[total + __popcll(occ & lt)] = (unsigned short)(r * 64 + lane);
+      if ((r & 7) == w && has) s_tab[total + __popcll(occ & lt)] = (unsigned short)(r * 64 + lane);
       total += __popcll(occ);
     }
   }
   const int nchunks = (total + 255) >> 8;
-  if (tid < 64) clrAll[tid] = 0u;
-  if (tid == 0) outCount = 0;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  __syncthreads();  // the table is complete
-  if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
-  else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
-  else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
-  else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, varena, stage, smask, tab, &outCount, clrAll, A);
-  else if (w == 4) g2p2g_slot_consumer<0>(mp, mask, total, lane, nchunks, stage, smask, parena);
-  else if (w == 5) g2p2g_slot_consumer<1>(mp, mask, total, lane, nchunks, stage, smask, parena);
-  else if (w == 6) g2p2g_slot_consumer<2>(mp, mask, total, lane, nchunks, stage, smask, parena);
-  else g2p2g_slot_consumer<3>(mp, mask, total, lane, nchunks, stage, smask, parena);
-  __syncthreads();  // all channel sets are in the arena, every mover is in the outbox
   if (tid < 64) {
-    const unsigned c = clrAll[tid];
-    if (c) A.cellMask[(size_t)bin * 64 + tid] = mask & ~c;  // (tid < 64: lane == tid, `mask` is this cell's)
+    s_mask0[tid] = mask;  // (tid < 64: lane == tid, `mask` is cell tid's)
+    s_clr[tid] = 0u;
+    s_arrLocal[tid] = 0u;
+    s_arrCnt[0][tid] = s_arrCnt[1][tid] = s_arrCnt[2][tid] = 0u;
+  }
+  if (tid == 0) s_outCount = s_sent = s_homed = s_xOver = 0;
+  if (tid < 3) s_xCnt[tid] = 0u;
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  if (tid >= 64 && tid < 64 + 27) {
+    const int code = tid - 64;
+    s_nbrBlk[code] = A.nbr27[(size_t)geo.block * 27 + code];
+    s_nbrBin[code] = code == 13 ? bin : neighbour_bin<SIDE>(A.nbr27, geo.block, bin, code);
+  }
+  __syncthreads();  // the table is complete
+  if (w == 0) SLP_ADD(1, tStart);
+  if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
+  else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
+  else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
+  else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
+  else if (w == 4) g2p2g_slot_consumer<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
+  else if (w == 5) g2p2g_slot_consumer<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
+  else if (w == 6) g2p2g_slot_consumer<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
+  else g2p2g_slot_consumer<SIDE, 3>(mp, geo, mask, total, lane, nchunks, sh, A);
+  SLP_T0(tTail);
+  __syncthreads();  // all channel sets are in the arena
+  if (tid < 64) {  // this step's departures and in-bin arrivals of the bin's cells, for slot_rehome_kernel / slot_commit_kernel
+    const unsigned c = s_clr[tid], nl = s_arrLocal[tid];
+    if (c) A.claim[((size_t)A.nbinsAll + (size_t)bin) * 64 + tid] = c;
+    if (nl) A.claim[(size_t)bin * 64 + tid] = nl << 16;  // (the low half -- arrivals from other bins -- is counted after this kernel)
   }
   if (tid == 0) {
-    // movers sent (the mover kernel counts the deliveries): running sums spread over SL_NCTR words -- one device-wide word serves ~90
-    // atomics per microsecond, i.e. 1.5 ms for one add per bin of the 64 M-particle column
-    const int oc = outCount < A.cap ? outCount : A.cap;
-    A.moverCount[bin] = oc;
-    if (oc) atomicAdd(&A.status[SL_SENT + (bin & (SL_NCTR - 1))], oc);
+    // movers sent / re-homed: running sums spread over SL_NCTR words -- one device-wide word serves ~90 atomics per microsecond,
+    // i.e. 1.5 ms for one add per bin of the 64 M-particle column
+    A.moverCount[bin] = s_outCount < A.cap ? s_outCount : A.cap;  // records in the outbox
+    if (s_sent) atomicAdd(&A.status[SL_SENT + (bin & (SL_NCTR - 1))], s_sent);
+    if (s_homed) atomicAdd(&A.status[SL_DELIVERED + (bin & (SL_NCTR - 1))], s_homed);
+  }
+  if (s_xOver > 0) {  // (rare) a chunk had more than SL_XQ movers for the consumers' list: their full records -> grid, all eight waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have reached L2 ...
+    __syncthreads();                                    // ... and so have everybody else's
+    const int oc = s_outCount < A.cap ? s_outCount : A.cap;
+    constexpr int RB = SL_NG * G2P2G_NF * 64 / SL_REC;  // records per batch: the whole staging ring is free now
+    for (int j0 = 0; j0 < oc; j0 += RB) {
+      const int nb = oc - j0 < RB ? oc - j0 : RB;
+      const float *src = A.moverRec + ((size_t)bin * A.cap + (size_t)j0) * SL_REC;
+      // agent-scope loads: served by L2, where the stores are (never by an L1 line of this CU)
+      for (int k = tid; k < nb * SL_REC; k += 512) s_stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      outbox_scatter_global<SIDE>(mp, geo, s_stage, nb, w, lane, s_nbrBlk, A.gridB, A.status);
+      __syncthreads();
+    }
   }
   if (tid < 216) {
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
     const int bn = A.nbr[(size_t)geo.block * 8 + slot];
-    const float *a = parena + AL::at(x, y, z);
+    const float *a = s_parena + AL::at(x, y, z);
     if (bn >= 0) {
       float *g = A.gridB + (size_t)bn * 7 * NC + cell;
 #pragma unroll
@@ -444,257 +812,87 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
       A.status[2] = 1;  // mass for a node whose block is not in the partition
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------------------------ mover kernel
-// One workgroup (4 waves = the 4 channel sets of ConsumerSet) per destination bin.
-// what channel set CS needs of a record: position, mass / v_d / C column entries (or P F^T entries)
-template <int CS> struct MoverFields {
-  using S = ConsumerSet<CS>;
-  float pos[3], m, c0[S::NV], c1[S::NV], c2[S::NV], v[S::NV];
-  __device__ __forceinline__ void load(const float *rec) {
-    constexpr int cb = S::STRESS ? 26 : 17;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) pos[d] = rec[1 + d];
-    m = S::STRESS ? 0.f : rec[0];
-#pragma unroll
-    for (int j = 0; j < S::NV; ++j) {
-      const int d = S::D0 + j;
-      c0[j] = rec[cb + d];
-      c1[j] = rec[cb + 3 + d];
-      c2[j] = rec[cb + 6 + d];
-      v[j] = S::STRESS ? 0.f : rec[14 + d];
-    }
-  }
-};
-template <int CS>
-__device__ __forceinline__ void mover_accumulate(const MpmDev &mp, const MoverFields<CS> &f, const int (&org)[3], int cx, int cy, int cz,
-                                                 float kscale, float (&acc)[27][ConsumerSet<CS>::NA]) {
-  using S = ConsumerSet<CS>;
-  const float dxi = 1.0f / mp.dx;
-  Arena ar;
-  const int cc[3] = {cx, cy, cz};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {  // the record's position lies in this lane's cell: same arithmetic as the main kernel's staging
-    const float X = f.pos[d] * dxi;
-    const float fl = (float)(org[d] + cc[d]);
-    const float d0 = X - fl;
-    ar.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
-    const float d1 = d0 - 1.0f;
-    ar.w[d][1] = 0.75f - d1 * d1;
-    const float zz = 0.5f + d1;
-    ar.w[d][2] = 0.5f * zz * zz;
-    ar.lp[d] = d0 * mp.dx;
-  }
-  const float scale = S::STRESS ? kscale : f.m;
-  float wzs[3], Pz[S::NV][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
-#pragma unroll
-  for (int j = 0; j < S::NV; ++j)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(f.c2[j], (float)k * mp.dx - ar.lp[2], f.v[j]);
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float x0 = (float)a * mp.dx - ar.lp[0];
-    float Pxa[S::NV];
-#pragma unroll
-    for (int j = 0; j < S::NV; ++j) Pxa[j] = f.c0[j] * x0;
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      const float x1 = (float)bb * mp.dx - ar.lp[1];
-      const float wxy = ar.w[0][a] * ar.w[1][bb];
-      float q[S::NV];
-#pragma unroll
-      for (int j = 0; j < S::NV; ++j) q[j] = fmaf(f.c1[j], x1, Pxa[j]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float Ws = wxy * wzs[c];
-        auto &Ac = acc[(a * 3 + bb) * 3 + c];
-        if constexpr (S::MASS) Ac[0] += Ws;
-#pragma unroll
-        for (int j = 0; j < S::NV; ++j) Ac[(S::MASS ? 1 : 0) + j] = fmaf(Ws, q[j] + Pz[j][c], Ac[(S::MASS ? 1 : 0) + j]);
-      }
-    }
+  if (w == 0) {
+    SLP_ADD(10, tTail);
+    SLP_ADD(0, tStart);
+    SLP_PUT(11, 1);
   }
 }
 
-// wave CS of a destination bin: its channel set of every arrival; the lightest set (CS == 3: one channel) also gives the arrivals
-// their new home (lowest free round of the cell that was free BEFORE this step's departures).  Records are fetched one round ahead.
-template <int SIDE, int CS, bool FLUID, bool DP, bool WRITE_ALL>
-__device__ __forceinline__ void mover_role(const MpmDev &mp, const ParticlesDev &ps, const SlotArgs &A, int bin, const int (&org)[3], int lane,
-                                           int rounds, const int *inboxCount, const int (*inbox)[SL_MAXIN], float *parena) {
-  using S = ConsumerSet<CS>;
-  using AL = ArenaLds;
+// after the main kernel: one wave per bin, one lane per outbox record; records that left their bin (word SLR_DCELL = destination cell)
+// get their slot here.  Ticket of the destination cell's counter (low half of the claim word; the high half holds the cell's in-bin
+// arrivals, final by now) -> the free rounds above the in-bin arrivals, from the bottom; the particle's state is copied from the
+// record's first line into that slot.
+template <bool FLUID, bool DP, bool WRITE_ALL>
+static __global__ __launch_bounds__(256) void slot_rehome_kernel(ParticlesDev ps, const unsigned *cellMask, unsigned *claim, const int *moverCount,
+                                                                 const float *moverRec, int cap, size_t nbins, int K, int *status) {
   constexpr int LW = 64;
-  constexpr bool REHOME = CS == 3;
-  constexpr int NH = WRITE_ALL ? 35 : 14;  // floats of the record the new home needs: m, x, F, logJp (, v, C, P F^T)
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);
-  float acc[27][S::NA];
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
-  const int mine = inboxCount[lane] < SL_MAXIN ? inboxCount[lane] : SL_MAXIN;
-  unsigned m = 0u;
-  if constexpr (REHOME) m = A.cellMask[(size_t)bin * 64 + lane];
-  MoverFields<CS> cur, nxt;
-  float hcur[REHOME ? NH : 1], hnxt[REHOME ? NH : 1];
-  auto fetch = [&](int r, MoverFields<CS> &f, float (&h)[REHOME ? NH : 1]) {
-    const float *rec = A.moverRec + (size_t)inbox[lane][r] * SL_REC;
-    f.load(rec);
-    if constexpr (REHOME) {
-#pragma unroll
-      for (int d = 0; d < NH; ++d) h[d] = rec[d];
+  const size_t bin = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bin >= nbins) return;
+  const int n = __builtin_amdgcn_readfirstlane(moverCount[bin]);
+  if (n == 0) return;
+  const unsigned kmask = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
+  int nhomed = 0;
+  for (int k = (int)(threadIdx.x & 63); k < n; k += 64) {
+    const float *rc = moverRec + (bin * (size_t)cap + (size_t)k) * SL_REC;
+    const float4 r0 = reinterpret_cast<const float4 *>(rc)[0], r1 = reinterpret_cast<const float4 *>(rc)[1],
+                 r2 = reinterpret_cast<const float4 *>(rc)[2], r3 = reinterpret_cast<const float4 *>(rc)[3];
+    const unsigned dcell = __float_as_uint(r3.z);
+    if (dcell == 0xffffffffu) continue;  // it stayed inside its bin (arrival queue full): its workgroup gave it a slot
+    const unsigned occ = cellMask[dcell];
+    const unsigned old = atomicAdd(&claim[dcell], 1u);
+    const int rr = nth_low_bit(~occ & kmask, (old >> 16) + (old & 0xffffu));
+    if (rr < 0) {
+      status[1] = 1;  // cell full (sent != homed)
+      continue;
     }
-  };
-  if (mine > 0) fetch(0, cur, hcur);
-  for (int r = 0; r < rounds; ++r) {
-    if (r + 1 < mine) fetch(r + 1, nxt, hnxt);
-    if (r < mine) {
-      mover_accumulate<CS>(mp, cur, org, cx, cy, cz, kscale, acc);
-      if constexpr (REHOME) {
-        const unsigned freeBits = ~m & (A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u));
-        if (freeBits == 0u) {
-          A.status[1] = 1;  // cell full
-        } else {
-          const int rr = __ffs((int)freeBits) - 1;
-          m |= 1u << rr;
-          const size_t i = ((size_t)bin * (size_t)A.K + (size_t)rr) * 64 + (size_t)lane;
-          const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
-          float x[3], F[9];
+    ++nhomed;
+    const size_t i = ((size_t)(dcell >> 6) * (size_t)K + (size_t)rr) * 64 + (size_t)(dcell & 63u);
+    const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
+    const float x[3] = {r0.y, r0.z, r0.w};
+    const float F[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+    pstore1<LW>(ps.mass, o, r0.x);
+    pstore<LW, 3>(ps.pos, o, x);
+    pstore_state<LW, FLUID>(ps.F, o, F);
+    if constexpr (DP) pstore1<LW>(ps.logJp, o, r3.y);
+    if constexpr (WRITE_ALL) {
+      float v[3], C[9], PF[9];
 #pragma unroll
-          for (int d = 0; d < 3; ++d) x[d] = hcur[1 + d];
+      for (int d = 0; d < 3; ++d) v[d] = rc[SLR_V + d];
 #pragma unroll
-          for (int d = 0; d < 9; ++d) F[d] = hcur[4 + d];
-          pstore1<LW>(ps.mass, o, hcur[0]);
-          pstore<LW, 3>(ps.pos, o, x);
-          pstore_state<LW, FLUID>(ps.F, o, F);
-          if constexpr (DP) pstore1<LW>(ps.logJp, o, hcur[13]);
-          if constexpr (WRITE_ALL) {
-            float v[3], C[9], PF[9];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) v[d] = hcur[14 + d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) { C[d] = hcur[17 + d]; PF[d] = hcur[26 + d]; }
-            pstore<LW, 3>(ps.vel, o, v);
-            pstore<LW, 9>(ps.C, o, C);
-            pstore<LW, 9>(ps.stress, o, PF);
-          }
-        }
+      for (int d = 0; d < 9; ++d) {
+        C[d] = rc[SLR_C + d];
+        PF[d] = rc[SLR_PF + d];
       }
-    }
-    cur = nxt;
-    if constexpr (REHOME) {
-#pragma unroll
-      for (int d = 0; d < NH; ++d) hcur[d] = hnxt[d];
+      pstore<LW, 3>(ps.vel, o, v);
+      pstore<LW, 9>(ps.C, o, C);
+      pstore<LW, 9>(ps.stress, o, PF);
     }
   }
-  if constexpr (REHOME) {
-    if (mine > 0) A.cellMask[(size_t)bin * 64 + lane] = m;
-  }
-  float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-#pragma unroll
-    for (int q = 0; q < S::NA; ++q) g[q * AL::CH] += acc[k][q];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
+  for (int sft = 32; sft >= 1; sft >>= 1) nhomed += __shfl_xor(nhomed, sft, 64);
+  if ((threadIdx.x & 63) == 0 && nhomed) atomicAdd(&status[SL_DELIVERED + (int)(bin & (SL_NCTR - 1))], nhomed);
 }
 
-template <int SIDE, bool FLUID, bool DP, bool WRITE_ALL>
-static __global__ __launch_bounds__(256) void mover_pull_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
-  using AL = ArenaLds;
-  constexpr int NC = SIDE * SIDE * SIDE;
-  constexpr int BPB = bins_per_block<SIDE>();
-  __shared__ float parena[7 * AL::CH];
-  __shared__ int inboxCount[64];
-  __shared__ int inbox[64][SL_MAXIN];
-  __shared__ int srcBin[27];
-  __shared__ int srcCnt[27];
-  __shared__ int srcOff[28];
-  __shared__ int total;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bin = blockIdx.x + A.binBase;
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  if (tid < 64) inboxCount[tid] = 0;
-  if (tid == 0) total = 0;
-  if (tid < 27) {
-    const int sb = neighbour_bin<SIDE>(A.nbr27, geo.block, bin, tid);
-    int c = 0;
-    if (sb >= 0) c = A.moverCount[sb];
-    srcBin[tid] = sb;
-    srcCnt[tid] = c;
-    if (c) atomicAdd(&total, c);
+// after the step: departures leave the occupancy words, this step's arrivals enter them (the lowest free rounds: in-bin arrivals first,
+// then the arrivals from other bins), the counters are zero again
+static __global__ __launch_bounds__(256) void slot_commit_kernel(unsigned *cellMask, unsigned *claim, size_t ncells, int K) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const unsigned tk = claim[c], clr = claim[ncells + c];
+  if (!tk && !clr) return;
+  const unsigned m0 = cellMask[c];
+  const unsigned kmask = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
+  const unsigned n = (tk >> 16) + (tk & 0xffffu);
+  unsigned rest = ~m0 & kmask, bits = 0u;
+  for (unsigned k = 0; k < n && rest; ++k) {
+    const unsigned b = rest & (0u - rest);
+    bits |= b;
+    rest ^= b;
   }
-  __syncthreads();
-  if (total == 0) return;  // nothing addressed to anybody around here (uniform)
-  // every record of the 27 outboxes is looked at by one thread; all destination loads of the workgroup are in flight together
-  // (a loop over the outboxes pays 27 memory latencies in a row: 2.8 -> 2.0 ms; fetching the first 32 destinations of every
-  // outbox together with its count, to save the second latency, costs more in wasted reads than it gains: 2.25 ms)
-  if (tid == 0) {
-    int o = 0;
-    for (int k = 0; k < 27; ++k) {
-      srcOff[k] = o;
-      o += srcCnt[k];
-    }
-    srcOff[27] = o;
-  }
-  __syncthreads();
-  const int tot = srcOff[27];
-  for (int tt = tid; tt < tot; tt += 256) {
-    int sidx = 0;
-    while (tt >= srcOff[sidx + 1]) ++sidx;
-    const int k = tt - srcOff[sidx], sb = srcBin[sidx];
-    int x, y, z;
-    unpack_cell(A.moverDest[(size_t)sb * A.cap + (size_t)k], x, y, z);
-    const int rx = x - geo.org[0], ry = y - geo.org[1], rz = z - geo.org[2];
-    if ((unsigned)rx < 4u && (unsigned)ry < 4u && (unsigned)rz < 4u) {
-      const int l2 = (rx * 4 + ry) * 4 + rz;
-      const int slot = atomicAdd(&inboxCount[l2], 1);
-      if (slot < SL_MAXIN) inbox[l2][slot] = sb * A.cap + k;
-      else A.status[3] = 1;
-    }
-  }
-  __syncthreads();
-  int rounds = inboxCount[lane];
-  int got = rounds < SL_MAXIN ? rounds : SL_MAXIN;
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) {
-    const int o2 = __shfl_xor(rounds, sft, 64);
-    rounds = o2 > rounds ? o2 : rounds;
-    got += __shfl_xor(got, sft, 64);
-  }
-  if (rounds > SL_MAXIN) rounds = SL_MAXIN;
-  if (rounds == 0) return;  // nothing addressed to this bin (uniform)
-  if (tid == 0) atomicAdd(&A.status[SL_DELIVERED + (bin & (SL_NCTR - 1))], got);
-  for (int k = tid; k < 7 * AL::CH; k += 256) parena[k] = 0.f;
-  __syncthreads();
-  if (w == 0) mover_role<SIDE, 0, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
-  else if (w == 1) mover_role<SIDE, 1, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
-  else if (w == 2) mover_role<SIDE, 2, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
-  else mover_role<SIDE, 3, FLUID, DP, WRITE_ALL>(mp, ps, A, bin, geo.org, lane, rounds, inboxCount, inbox, parena);
-  __syncthreads();
-  if (tid < 216) {
-    const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
-    int slot, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-    const int bn = A.nbr[(size_t)geo.block * 8 + slot];
-    const float *a = parena + AL::at(x, y, z);
-    if (bn >= 0) {
-      float *g = A.gridB + (size_t)bn * 7 * NC + cell;
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        const float v = a[ch * AL::CH];
-        if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
-      }
-    } else if (a[0] != 0.f) {
-      A.status[2] = 1;
-    }
-  }
+  cellMask[c] = (m0 & ~clr) | bits;
+  claim[c] = 0u;
+  claim[ncells + c] = 0u;
 }
 
 }  // namespace zsr
@@ -703,9 +901,20 @@ using namespace zsr;
 
 extern "C" {
 
+#ifdef ZS_SLOT_PROBE  // measurement-only build: read (and clear) the phase stamps of g2p2g_slot_kernel
+void zs_rocm_slot_probe(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_slot_probe), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(zsr::g_slot_probe), z, sizeof(z));
+  }
+}
+#endif
+
 size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int cap, int which) {
   if (which == 0) return nbins * sizeof(int);                              // moverCount
-  if (which == 1) return nbins * (size_t)cap * sizeof(long long);          // moverDest
+  if (which == 1) return 2 * nbins * 64 * sizeof(unsigned);                // ticket + departure words (two per cell; zeroed by the caller once)
   return nbins * (size_t)cap * (size_t)SL_REC * sizeof(float);             // moverRec
 }
 
@@ -760,13 +969,14 @@ size_t zs_rocm_mpm_slot_list(zs_rocm_policy *pol, const unsigned *cellMask, size
 }
 
 // The fused step on slotted storage.  particles: attributes of ONE TileVector<f32, 64> with nbins*K*64 elements (particles.n);
-// gridB zeroed by the caller; outbox buffers sized by zs_rocm_mpm_slot_outbox_bytes; status: 5 ints, zeroed by the caller when it
-// wants to (they latch).  Returns 0, -1 on bad arguments.
+// gridB zeroed by the caller; mover buffers sized by zs_rocm_mpm_slot_outbox_bytes (the claim words zeroed by the caller ONCE: every
+// step leaves them zero); status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller when it wants to (they latch).  Returns 0, -1 on
+// bad arguments.
 int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
                               float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27, int *moverCount,
-                              long long *moverDest, float *moverRec, int outboxCap, int writeAll, int *status) {
+                              unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status) {
   if (!nblocks) return 0;
-  if (!cellMask || !nbr || !nbr27 || !moverCount || !moverDest || !moverRec || !status || K < 1 || K > 32 || outboxCap < 1) return -1;
+  if (!cellMask || !nbr || !nbr27 || !moverCount || !claim || !moverRec || !status || K < 1 || K > 32 || outboxCap < 1) return -1;
   if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
   if (uniform_lane_width(ps, model_uses_logjp(p->model), writeAll != 0) != 64 || (writeAll && (!ps.vel.base || !ps.C.base))) {
     fprintf(stderr, "[zs_rocm] g2p2g_slotted needs all particle attributes in one TileVector<f32, 64>\n");
@@ -778,16 +988,24 @@ int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, 
   BhtDev t = tab->t.dev();
   const unsigned bpb = p->side == 4 ? 1u : 8u;
   const unsigned nbins = (unsigned)(nblocks * bpb);
-  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, moverDest, moverRec, status, 0, (int)nbins, outboxCap};
+  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, 0, (int)nbins, (int)nbins, outboxCap};
 #define CALL_SLOT3(SS, M, WA)                                                                                          \
   hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                \
-  hipLaunchKernelGGL((mover_pull_kernel<SS, model_is_fluid(M), model_uses_logjp(M), WA>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, A)
+  hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbins, 4)), \
+                     dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec,  \
+                     outboxCap, (size_t)nbins, K, status)
 #define CALL_SLOT(SS, M)                       \
   do {                                         \
     if (writeAll) { CALL_SLOT3(SS, M, true); } \
     else { CALL_SLOT3(SS, M, false); }         \
   } while (0)
+#ifdef ZS_SLOT_FAST_BUILD  // experiments: one instantiation (sand, 8^3 blocks)
+  CALL_SLOT3(8, 1, false);
+#else
   ZSR_DISPATCH_SIDE_PURE(p->side, p->model, CALL_SLOT);
+#endif
+  const size_t ncells = (size_t)nbins * 64;
+  hipLaunchKernelGGL(slot_commit_kernel, dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, cellMask, claim, ncells, K);
   return 0;
 }
 

@@ -208,7 +208,7 @@ class MpmTransfer:
         if rc != 0:
             raise RuntimeError("zs_rocm_mpm_slot_particles refused its arguments")
         self.mover_count = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 0) // 4, dtype=torch.int32, device=self.device)
-        self.mover_dest = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 1) // 8, dtype=torch.int64, device=self.device)
+        self.mover_dest = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 1) // 4, dtype=torch.int32, device=self.device)  # claim words: zero between steps
         self.mover_rec = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(self.nbins, self.outbox_cap, 2) // 4, dtype=torch.float32, device=self.device)
         self.pol.syncCtx()
         st = self.slot_status.cpu().numpy()
@@ -243,12 +243,12 @@ class MpmTransfer:
     def check_slots(self):
         """raise if the slotted step reported a capacity overflow, a broken storage invariant or a lost mover"""
         st = [int(v) for v in self.slot_status.cpu().numpy()]
-        names = ["outbox full", "a cell is full (K)", "mass for a block outside the partition", "inbox full",
+        names = ["outbox full", "a cell is full (K)", "mass for a block outside the partition", "(unused)",
                  "a particle was not stored under its cell"]
         bad = [names[k] for k in range(5) if st[k]]
         st[5], st[6] = sum(st[8:264]), sum(st[264:520])  # the counters are spread over 256 words each
         if st[5] != st[6]:
-            bad.append("%d movers sent, %d delivered (destination block not in the partition)" % (st[5], st[6]))
+            bad.append("%d movers sent, %d re-homed (destination cell full or its block not in the partition)" % (st[5], st[6]))
         if bad:
             raise RuntimeError("slotted G2P2G: " + "; ".join(bad))
         return st[:8]
