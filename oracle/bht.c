@@ -196,6 +196,7 @@ int32_t orc_bht_build_success(const orc_bht *t) { return t->success; }
 const int32_t *orc_bht_active_keys(const orc_bht *t) { return t->activeKeys; }
 const int32_t *orc_bht_keys(const orc_bht *t) { return t->keys; }
 const int32_t *orc_bht_indices(const orc_bht *t) { return t->indices; }
+const int32_t *orc_bht_status(const orc_bht *t) { return t->status; }
 int orc_bht_key_stride(const orc_bht *t) { return t->kstride; }
 
 /* bht::resize, Bht.hpp:320-340: grow, reset, re-insert activeKeys[i] with fixed index i */

@@ -138,6 +138,8 @@ void orc_hashtable_query_many(const orc_hashtable *t, const int32_t *keys, size_
 int32_t orc_hashtable_size(const orc_hashtable *t) { return t->cnt; }
 int32_t orc_hashtable_get_table_size(const orc_hashtable *t) { return t->tableSize; }
 const int32_t *orc_hashtable_active_keys(const orc_hashtable *t) { return t->activeKeys; }
+const int32_t *orc_hashtable_keys(const orc_hashtable *t) { return t->keys; }
+const int32_t *orc_hashtable_indices(const orc_hashtable *t) { return t->indices; }
 
 /* resize, :281-292: grow, reset (cnt kept), re-insert activeKeys[i] with id i */
 void orc_hashtable_resize(orc_hashtable *t, size_t nExpected) {

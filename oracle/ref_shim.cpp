@@ -22,8 +22,11 @@
 #include "zensim/simulation/Utils.hpp"         /* LocalArena / make_local_arena, unpack_coord_in_grid(coord, side) */
 #include "zensim/math/matrix/MatrixUtils.h"    /* matrixMatrixMultiplication3d */
 #include <array>
+#include <cstring>
+#include <limits>
 #include <map>
 #include <random>
+#include <vector>
 
 using namespace zs;
 
@@ -382,5 +385,288 @@ int ref_hashtable_do_hash(const int *key, int dim) {
   size_t ret = key[0];
   for (int d = 1; d < dim; ++d) hash_combine(ret, key[d]);
   return static_cast<int>(ret);
+}
+}
+
+/* ---- bht<int, dim, int, B> and HashTable<int, dim, int> as whole functions under sequential insertion ----------------------------------
+   container/Bht.hpp and HashTable.hpp include the execution-policy headers (un-vendored magic_enum: unbuildable here), so -- like
+   Collider::resolveCollision and the transfer functors above -- the member bodies are spelled out over the reference's OWN pieces that do
+   build: universal_hash_base (py_interop/HashUtils.hpp:7-47) with hash_combine (math/Hash.hpp), storage_key_type_impl (the padded slot,
+   HashUtils.hpp:49-87), next_2pow (math/bit/Bits.h), vec; seeds from std::mt19937(2) exactly as universal_hash(std::mt19937 &) draws them
+   (Bcht.hpp:39-43, Bht.hpp:165-169).  Under the SequentialExecutionPolicy atomicLoad / atomicSwitchIfEqual / atomic_add reduce to a plain
+   load, "if the slot holds the sentinel store the key", and ++cnt. */
+template <int dim, int B> struct RefBht {
+  using key_t = vec<int, dim>;
+  using slot_t = storage_key_type_impl<key_t>;
+  static constexpr int threshold = B - 2;                                  /* Bht.hpp:34 */
+  size_t tableSize = 0, numBuckets = 0;
+  std::vector<slot_t> keys;
+  std::vector<int> indices, status, activeKeys;
+  int cnt = 0, success = 1;
+  universal_hash_base<key_t> hf[3];
+  static size_t evaluateTableSize(size_t entryCnt) {                         /* Bht.hpp:154-158 */
+    if (entryCnt == 0) return 0;
+    size_t n = next_2pow(entryCnt) * 2;
+    return n + (B - n % B);
+  }
+  static key_t sentinel() {                                                  /* deduce_key_sentinel, Bht.hpp:126-131 */
+    int v = 0;
+    for (int i = 0; i != (int)sizeof(int); ++i) v = (v << 8) | 0x3f;
+    return key_t::constant(v);
+  }
+  explicit RefBht(size_t nExpected) {
+    tableSize = evaluateTableSize(nExpected);
+    numBuckets = tableSize / B;
+    keys.resize(tableSize);
+    std::memset((void *)keys.data(), 0x3f, sizeof(slot_t) * tableSize);      /* Table::reset, Bht.hpp:108-112 */
+    indices.assign(tableSize, 0);
+    status.assign(tableSize, -1);
+    activeKeys.assign(tableSize * dim, 0);
+    unsigned p[6];
+    ref_bht_hash_params(p);
+    for (int f = 0; f < 3; ++f) hf[f] = universal_hash_base<key_t>{p[2 * f], p[2 * f + 1]};
+  }
+  int insert(const key_t &key) {                                             /* BHTView::insert, host execution, Bht.hpp:612-664 */
+    if (numBuckets == 0) return std::numeric_limits<int>::lowest();
+    const key_t key_sentinel_v = sentinel();
+    int iter = 0, load = 0;
+    size_t bucketOffset = hf[0](key) % numBuckets * B;
+    while (iter < 3) {
+      for (; load != B; ++load) {
+        key_t curKey = keys[bucketOffset + load].val;
+        if (curKey == key) {
+          load = -1;
+          break;
+        } else if (curKey == key_sentinel_v)
+          break;
+      }
+      if (load < 0)
+        return -1;
+      else if (load <= threshold) {
+        if (keys[bucketOffset + load].val == key_sentinel_v) {                /* atomicSwitchIfEqual */
+          keys[bucketOffset + load].val = key;
+          int localno = cnt++;
+          indices[bucketOffset + load] = localno;
+          for (int d = 0; d < dim; ++d) activeKeys[(size_t)localno * dim + d] = key[d];
+          if (localno >= (int)tableSize - 20) {
+            success = 0;
+            localno = std::numeric_limits<int>::lowest();
+          }
+          return localno;
+        }
+      } else {
+        ++iter;
+        load = 0;
+        if (iter == 1)
+          bucketOffset = hf[1](key) % numBuckets * B;
+        else if (iter == 2)
+          bucketOffset = hf[2](key) % numBuckets * B;
+        else
+          break;
+      }
+    }
+    success = 0;
+    return std::numeric_limits<int>::lowest();
+  }
+  int query(const key_t &key) const {                                        /* Bht.hpp:667-698 */
+    if (numBuckets == 0) return -1;
+    int loc = 0;
+    size_t bucketOffset = hf[0](key) % numBuckets * B;
+    for (int iter = 0; iter < 3;) {
+      for (loc = 0; loc != B; ++loc)
+        if (keys[bucketOffset + loc].val == key) break;
+      if (loc != B) return indices[bucketOffset + loc];
+      ++iter;
+      if (iter == 1)
+        bucketOffset = hf[1](key) % numBuckets * B;
+      else if (iter == 2)
+        bucketOffset = hf[2](key) % numBuckets * B;
+    }
+    return -1;
+  }
+};
+template <int dim, int B>
+static void ref_bht_seq_run(size_t nExpected, const int *keysIn, size_t n, int *ret, int *keysTable, int *indices, int *status, int *activeKeys,
+                            int *cntSuccess, const int *queries, size_t nq, int *qret) {
+  RefBht<dim, B> t(nExpected);
+  for (size_t i = 0; i < n; ++i) {
+    typename RefBht<dim, B>::key_t k;
+    for (int d = 0; d < dim; ++d) k[d] = keysIn[i * dim + d];
+    ret[i] = t.insert(k);
+  }
+  std::memcpy(keysTable, (const void *)t.keys.data(), sizeof(typename RefBht<dim, B>::slot_t) * t.tableSize);
+  std::memcpy(indices, t.indices.data(), sizeof(int) * t.tableSize);
+  std::memcpy(status, t.status.data(), sizeof(int) * t.tableSize);
+  std::memcpy(activeKeys, t.activeKeys.data(), sizeof(int) * (size_t)t.cnt * dim);
+  cntSuccess[0] = t.cnt;
+  cntSuccess[1] = t.success;
+  for (size_t i = 0; i < nq; ++i) {
+    typename RefBht<dim, B>::key_t k;
+    for (int d = 0; d < dim; ++d) k[d] = queries[i * dim + d];
+    qret[i] = t.query(k);
+  }
+}
+
+/* HashTable<int, dim, int>: size next_2pow(n) * 16 (HashTable.hpp:88-91), hash = hash_combine fold of the raw coordinates (do_hash,
+   :496-500), linear probing with stride 127 (insert, host execution, :383-400; query :454-463 incl. its `>` wrap) */
+template <int dim> struct RefHashTable {
+  using key_t = vec<int, dim>;
+  int tableSize = 0, cnt = 0;
+  std::vector<key_t> keys;
+  std::vector<int> indices, status, activeKeys;
+  explicit RefHashTable(size_t nExpected) {
+    tableSize = nExpected ? (int)(next_2pow(nExpected) * 16) : 0;
+    keys.assign(tableSize, key_t::constant(std::numeric_limits<int>::max()));   /* key_scalar_sentinel_v */
+    indices.assign(tableSize, -1);
+    status.assign(tableSize, -1);
+    activeKeys.assign((size_t)tableSize * dim, 0);
+  }
+  static int do_hash(const key_t &key) {
+    size_t ret = key[0];
+    for (int d = 1; d < dim; ++d) hash_combine(ret, key[d]);
+    return static_cast<int>(ret);
+  }
+  int insert(const key_t &key) {
+    const key_t key_sentinel_v = key_t::constant(std::numeric_limits<int>::max());
+    int hashedentry = (do_hash(key) % tableSize + tableSize) % tableSize;
+    auto cas = [&](int e) {                                                   /* atomicKeyCAS, host: :546-563 */
+      key_t stored = keys[e];
+      if (stored == key_sentinel_v) keys[e] = key;
+      return stored;
+    };
+    key_t storedKey = cas(hashedentry);
+    for (; !(storedKey == key_sentinel_v || storedKey == key);) {
+      hashedentry = (hashedentry + 127) % tableSize;
+      storedKey = cas(hashedentry);
+    }
+    if (storedKey == key_sentinel_v) {
+      int localno = cnt++;
+      indices[hashedentry] = localno;
+      for (int d = 0; d < dim; ++d) activeKeys[(size_t)localno * dim + d] = key[d];
+      return localno;
+    }
+    return -1;
+  }
+  int query(const key_t &key) const {
+    int hashedentry = (do_hash(key) % tableSize + tableSize) % tableSize;
+    while (true) {
+      if (key == keys[hashedentry]) return indices[hashedentry];
+      if (indices[hashedentry] == -1) return -1;
+      hashedentry += 127;
+      if (hashedentry > tableSize) hashedentry = hashedentry % tableSize;
+    }
+  }
+};
+
+extern "C" {
+size_t ref_bht_table_size_b(size_t n, int B) { return B == 32 ? RefBht<3, 32>::evaluateTableSize(n) : RefBht<3, 16>::evaluateTableSize(n); }
+/* keysTable: [tableSize][next_2pow(dim)] ints (the padded slots, byte for byte); activeKeys: [cnt][dim]; cntSuccess: {cnt, success} */
+void ref_bht_seq(int dim, int B, size_t nExpected, const int *keysIn, size_t n, int *ret, int *keysTable, int *indices, int *status,
+                 int *activeKeys, int *cntSuccess, const int *queries, size_t nq, int *qret) {
+#define RB(D, BB) if (dim == D && B == BB) return ref_bht_seq_run<D, BB>(nExpected, keysIn, n, ret, keysTable, indices, status, activeKeys, cntSuccess, queries, nq, qret)
+  RB(1, 16); RB(2, 16); RB(3, 16); RB(4, 16); RB(3, 32);
+#undef RB
+}
+size_t ref_hashtable_table_size(size_t n) { return n ? next_2pow(n) * 16 : 0; }
+void ref_hashtable_seq(size_t nExpected, const int *keysIn, size_t n, int *ret, int *keysTable /*[tableSize][3]*/, int *indices, int *activeKeys,
+                       int *cnt, const int *queries, size_t nq, int *qret) {
+  RefHashTable<3> t(nExpected);
+  for (size_t i = 0; i < n; ++i) ret[i] = t.insert(vec<int, 3>{keysIn[3 * i], keysIn[3 * i + 1], keysIn[3 * i + 2]});
+  for (int e = 0; e < t.tableSize; ++e)
+    for (int d = 0; d < 3; ++d) keysTable[3 * (size_t)e + d] = t.keys[e][d];
+  std::memcpy(indices, t.indices.data(), sizeof(int) * t.tableSize);
+  std::memcpy(activeKeys, t.activeKeys.data(), sizeof(int) * (size_t)t.cnt * 3);
+  *cnt = t.cnt;
+  for (size_t i = 0; i < nq; ++i) qret[i] = t.query(vec<int, 3>{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]});
+}
+}
+
+/* ---- GridArena (math/curve/InterpolationKernel.hpp:271-560) over a caller-side grid view ------------------------------------------------
+   GridArena is a template over the grid view it samples; the reference instantiates it with SparseGridView (geometry/SparseGrid.hpp, which
+   needs the execution-policy headers: unbuildable here).  Here the REFERENCE'S OWN GridArena -- its constructors (collocated and staggered,
+   base_node + the six weight functions), weight / weightsGradient, arena, isample (xlerp for the linear kernel), minimum, maximum -- is
+   instantiated with a dense box of values as the caller's view type: the members GridArena asks of a view (the type aliases, worldToIndex,
+   valueOr(false_c, chn, coord, default)) are provided by DenseBoxView below, which is test scaffolding, not a reference header. */
+struct DenseBoxView {
+  using value_type = float;
+  using size_type = size_t;
+  using integer_coord_component_type = int;
+  using integer_coord_type = vec<int, 3>;
+  using coord_component_type = float;
+  using coord_type = vec<float, 3>;
+  using container_type = int;  /* (not an adaptive grid: is_ag_v<int> is false) */
+  static constexpr int dim = 3;
+  const float *data;           /* [nchn][ext][ext][ext] */
+  int lo[3], ext;
+  float dx;
+  template <typename VecT> constexpr coord_type worldToIndex(const VecInterface<VecT> &x) const noexcept {
+    return coord_type{x[0] / dx, x[1] / dx, x[2] / dx};
+  }
+  template <typename VecT> constexpr float valueOr(false_type, size_t chn, const VecInterface<VecT> &c, float def) const noexcept {
+    int k[3];
+    for (int d = 0; d < 3; ++d) {
+      k[d] = c[d] - lo[d];
+      if (k[d] < 0 || k[d] >= ext) return def;
+    }
+    return data[((chn * ext + k[0]) * ext + k[1]) * ext + k[2]];
+  }
+};
+template <kernel_e kt, int order>
+static void ref_grid_arena_run(const DenseBoxView &gv, const float *X, int f, float def, float *out /* see gen_golden.py */) {
+  using Arena = GridArena<const DenseBoxView, kt, order>;
+  vec<float, 3> x{X[0], X[1], X[2]};
+  Arena ar = f < 0 ? Arena{false_c, &gv, x} : Arena{false_c, &gv, x, f};
+  constexpr int W = Arena::width;
+  float *o = out;
+  for (int d = 0; d < 3; ++d) *o++ = (float)ar.iCorner[d];
+  for (int d = 0; d < 3; ++d) *o++ = ar.iLocalPos[d];
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 4; ++k) *o++ = k < W ? get<0>(ar.weights)(d, k) : 0.f;
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (order > 0) *o++ = k < W ? get<1>(ar.weights)(d, k) : 0.f;
+      else *o++ = 0.f;
+    }
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (order > 1) *o++ = k < W ? get<2>(ar.weights)(d, k) : 0.f;
+      else *o++ = 0.f;
+    }
+  *o++ = ar.isample(0, def);
+  *o++ = ar.isample(1, def);
+  *o++ = ar.minimum(0);
+  *o++ = ar.maximum(1);
+  /* weight and weightsGradient of the stencil corner nodes (0,0,0), (W-1, 0, 1 % W) and (1 % W, W-1, W-1) */
+  const int locs[3][3] = {{0, 0, 0}, {W - 1, 0, 1 % W}, {1 % W, W - 1, W - 1}};
+  for (int l = 0; l < 3; ++l) {
+    auto loc = zs::make_tuple(locs[l][0], locs[l][1], locs[l][2]);
+    *o++ = ar.weight(loc);
+    if constexpr (order > 0) {
+      auto g = ar.weightsGradient(loc);
+      for (int d = 0; d < 3; ++d) *o++ = g[d];
+    } else {
+      for (int d = 0; d < 3; ++d) *o++ = 0.f;
+    }
+  }
+}
+extern "C" {
+/* kt: 0 linear, 1 quadratic, 2 cubic, 3 delta2, 4 delta3, 5 delta4 (kernel_e order); order: derivative order 0..2 (B-splines only);
+   f < 0: collocated, else the face whose values sit at -0.5 along axis f % 3; out: 58 floats per point */
+int ref_grid_arena(int kt, int order, const float *data, int nchn, const int *lo, int ext, float dx, const float *X, size_t npts, int f, float def,
+                   float *out) {
+  DenseBoxView gv{data, {lo[0], lo[1], lo[2]}, ext, dx};
+  (void)nchn;
+  for (size_t i = 0; i < npts; ++i) {
+    const float *x = X + 3 * i;
+    float *o = out + 58 * i;
+#define GA(K, KT, O) if (kt == K && order == O) { ref_grid_arena_run<KT, O>(gv, x, f, def, o); continue; }
+    GA(0, kernel_e::linear, 0) GA(0, kernel_e::linear, 1) GA(0, kernel_e::linear, 2)
+    GA(1, kernel_e::quadratic, 0) GA(1, kernel_e::quadratic, 1) GA(1, kernel_e::quadratic, 2)
+    GA(2, kernel_e::cubic, 0) GA(2, kernel_e::cubic, 1) GA(2, kernel_e::cubic, 2)
+    GA(3, kernel_e::delta2, 0) GA(4, kernel_e::delta3, 0) GA(5, kernel_e::delta4, 0)
+#undef GA
+    return -1;
+  }
+  return 0;
 }
 }

@@ -113,6 +113,7 @@ int32_t orc_bht_build_success(const orc_bht *);
 const int32_t *orc_bht_active_keys(const orc_bht *); /* [size][dim] */
 const int32_t *orc_bht_keys(const orc_bht *);        /* [tableSize][4 or dim-padded] storage keys */
 const int32_t *orc_bht_indices(const orc_bht *);
+const int32_t *orc_bht_status(const orc_bht *);       /* [tableSize], all -1 outside an insertion */
 int orc_bht_key_stride(const orc_bht *);
 void orc_bht_resize(orc_bht *, size_t newCapacity); /* Bht.hpp:320-340 */
 
@@ -133,6 +134,8 @@ void orc_hashtable_query_many(const orc_hashtable *, const int32_t *keys, size_t
 int32_t orc_hashtable_size(const orc_hashtable *);
 int32_t orc_hashtable_get_table_size(const orc_hashtable *);
 const int32_t *orc_hashtable_active_keys(const orc_hashtable *);
+const int32_t *orc_hashtable_keys(const orc_hashtable *);    /* [tableSize][dim] */
+const int32_t *orc_hashtable_indices(const orc_hashtable *); /* [tableSize] */
 void orc_hashtable_resize(orc_hashtable *, size_t nExpected);      /* :281-292 */
 void orc_hashtable_preserve(orc_hashtable *, size_t nExpected);    /* :258-279 */
 /* zs::IndexBuckets<3,i32,i32> via index_buckets_for_particles (simulation/particle/Query.tpp:9-58), sequential policy */

@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include <hip/hip_cooperative_groups.h>
@@ -61,7 +63,107 @@ static zs::TileVector<int, 32> gen_rnd_tv_ints(size_t n, int bound) {
     }
   return tv;
 }
-int main() {
+// ---- GridArena against the reference's own GridArena (tests/golden/grid_arena.npz, flattened to a binary file by the python wrapper):
+// 58 floats per (case, point) -- stencil corner, local position, weights / first / second derivatives per axis (4 slots each), isample of
+// two channels, minimum, maximum, weight + weightsGradient at three stencil nodes (oracle/ref_shim.cpp: ref_grid_arena)
+template <zs::kernel_e kt, int order, class View>
+__device__ void arena_record(const View &g, const float *X, int f, float dflt, float *o) {
+  using namespace zs;
+  const small_vec<float, 3> x{{X[0], X[1], X[2]}};
+  auto ar = f < 0 ? g.template iArena<kt, order>(x) : g.template iArena<kt, order>(x, f);
+  constexpr int W = decltype(ar)::width;
+  for (int d = 0; d < 3; ++d) *o++ = (float)ar.iCorner[d];
+  for (int d = 0; d < 3; ++d) *o++ = ar.iLocalPos[d];
+  for (int q = 0; q < 3; ++q)
+    for (int d = 0; d < 3; ++d)
+      for (int k = 0; k < 4; ++k) *o++ = (q <= order && k < W) ? ar.w[q <= order ? q : 0][d][k < W ? k : 0] : 0.f;
+  *o++ = ar.isample(0, dflt);
+  *o++ = ar.isample(1, dflt);
+  *o++ = ar.minimum(0);
+  *o++ = ar.maximum(1);
+  const int locs[3][3] = {{0, 0, 0}, {W - 1, 0, 1 % W}, {1 % W, W - 1, W - 1}};
+  for (int l = 0; l < 3; ++l) {
+    const small_vec<int, 3> loc{{locs[l][0], locs[l][1], locs[l][2]}};
+    *o++ = ar.weight(loc);
+    if constexpr (order > 0) {
+      const auto gw = ar.weightsGradient(loc);
+      for (int d = 0; d < 3; ++d) *o++ = gw[d];
+    } else {
+      for (int d = 0; d < 3; ++d) *o++ = 0.f;
+    }
+  }
+}
+static int grid_arena_against_reference(const char *path) {
+  using namespace zs;
+  constexpr auto space = execspace_e::rocm;
+  std::FILE *fp = std::fopen(path, "rb");
+  if (!fp) return 1;
+  int hdr[6];  // ncases, npts, ext, lo[3]
+  float fh[2];  // dx, default
+  if (std::fread(hdr, 4, 6, fp) != 6 || std::fread(fh, 4, 2, fp) != 2) return 1;
+  const int ncases = hdr[0], npts = hdr[1], ext = hdr[2];
+  const int lo[3] = {hdr[3], hdr[4], hdr[5]};
+  const float dx = fh[0], dflt = fh[1];
+  std::vector<int> cases(3 * ncases);
+  std::vector<float> data((size_t)2 * ext * ext * ext), X(3 * (size_t)npts), want((size_t)ncases * npts * 58);
+  if (std::fread(cases.data(), 4, cases.size(), fp) != cases.size() || std::fread(data.data(), 4, data.size(), fp) != data.size() ||
+      std::fread(X.data(), 4, X.size(), fp) != X.size() || std::fread(want.data(), 4, want.size(), fp) != want.size())
+    return 1;
+  std::fclose(fp);
+  auto pol = rocm_exec();
+  // the box [lo, lo + ext)^3 inside a SparseGrid<3, f32, 8>: every block the box touches is allocated; cells of those blocks outside
+  // the box hold the default value, which is what valueOr returns for unallocated cells (the reference's dense view returns it for both)
+  SparseGrid<3, float, 8> sg(std::vector<PropertyTag>{{"a", 1}, {"b", 1}}, 64);
+  sg.scale(dx);
+  sg._background = dflt;
+  Vector<float> dd(data.size(), memsrc_e::um), dX(X.size(), memsrc_e::um), got((size_t)npts * 58, memsrc_e::um);
+  std::copy(data.begin(), data.end(), dd.data());
+  std::copy(X.begin(), X.end(), dX.data());
+  const int nc = ext * ext * ext;
+  pol(range(nc), [g = view<space>(sg), dx, ext, l0 = lo[0], l1 = lo[1], l2 = lo[2]] ZS_LAMBDA(long long c) {
+    const int i = (int)(c / (ext * ext)), j = (int)(c / ext) % ext, k = (int)(c % ext);
+    g.insert(small_vec<float, 3>{{(l0 + i + 0.25f) * dx, (l1 + j + 0.25f) * dx, (l2 + k + 0.25f) * dx}});
+  });
+  const std::size_t nb = sg.numBlocks();
+  CHECK(nb >= 8 && nb <= 64);
+  pol(range((long long)nb * 512), [g = view<space>(sg), d = view<space>(dd), dflt, ext, l0 = lo[0], l1 = lo[1], l2 = lo[2]] ZS_LAMBDA(long long c) {
+    const int b = (int)(c / 512), k = (int)(c % 512);
+    const auto ic = g.iCoord(b, k);
+    const int i = ic[0] - l0, j = ic[1] - l1, q = ic[2] - l2;
+    const bool in = i >= 0 && i < ext && j >= 0 && j < ext && q >= 0 && q < ext;
+    for (int ch = 0; ch < 2; ++ch) g(ch, b, k) = in ? d[(((std::size_t)ch * ext + i) * ext + j) * ext + q] : dflt;
+  });
+  int bad = 0;
+  for (int ci = 0; ci < ncases; ++ci) {
+    const int kt = cases[3 * ci], order = cases[3 * ci + 1], f = cases[3 * ci + 2];
+    pol(range(npts), [g = view<space>(sg), x = view<space>(dX), o = view<space>(got), kt, order, f, dflt] ZS_LAMBDA(long long i) {
+      float *out = &o[(std::size_t)i * 58];
+      const float *X = &x[3 * i];
+#define GA(K, KT, O) if (kt == K && order == O) { arena_record<KT, O>(g, X, f, dflt, out); return; }
+      GA(0, kernel_e::linear, 0) GA(0, kernel_e::linear, 1) GA(0, kernel_e::linear, 2)
+      GA(1, kernel_e::quadratic, 0) GA(1, kernel_e::quadratic, 1) GA(1, kernel_e::quadratic, 2)
+      GA(2, kernel_e::cubic, 0) GA(2, kernel_e::cubic, 1) GA(2, kernel_e::cubic, 2)
+      GA(3, kernel_e::delta2, 0) GA(4, kernel_e::delta3, 0) GA(5, kernel_e::delta4, 0)
+#undef GA
+    });
+    for (int i = 0; i < npts; ++i)
+      for (int k = 0; k < 58; ++k) {
+        const float a = got.data()[(std::size_t)i * 58 + k], b = want[((std::size_t)ci * npts + i) * 58 + k];
+        // corner / local position: exact and 1e-6; weights: 2e-6 of values in [-6, 6] (second derivatives of the cubic);
+        // samples: 27 / 64-term sums of values of size ~3: 2e-5
+        const float tol = k < 3 ? 0.f : (k < 6 ? 1e-6f : (k < 42 ? 2e-6f * std::max(1.f, std::fabs(b)) : 2e-5f * std::max(1.f, std::fabs(b))));
+        if (!(std::fabs(a - b) <= tol)) {
+          if (bad < 8) std::printf("grid arena mismatch: case %d (kernel %d, order %d, face %d) point %d slot %d: %g vs reference %g\n", ci, kt, order, f, i, k, a, b);
+          ++bad;
+        }
+      }
+  }
+  std::printf("grid arena vs reference: %d cases x %d points, %d mismatches\n", ncases, npts, bad);
+  return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc > 2 && std::string(argv[1]) == "--grid-arena") return grid_arena_against_reference(argv[2]);
   auto pol = rocm_exec();
   CHECK(pol.shouldSync());
   // ---- Vector: fill on device, clone to host, compare (basic.cu:65-107)

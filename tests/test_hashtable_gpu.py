@@ -155,3 +155,36 @@ def test_partition_for_particles_matches_bht_partition_and_p2g(pol, oracle, side
         k = tuple(int(x) for x in hkeys[i])
         assert np.array_equal(g[i], got[k])
         assert (np.abs(g[i] - ref[k]).max(axis=1) <= 2e-4 * scale).all()
+
+
+def test_gpu_build_against_reference_made_table(pol):
+    """HashTable<int, 3, int> on the GPU against tests/golden/containers_seq.npz (table made by the reference's insert / query bodies over its
+    own hash_combine, oracle/ref_shim.cpp): table size, key set, count, queries found / not found, activeKeys[index] == key."""
+    import os
+    from zpc_amd.containers import HashTable
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "containers_seq.npz"))
+    keys = np.ascontiguousarray(z["ht_keys"])
+    n = keys.shape[0]
+    tab = HashTable(3, n)
+    assert tab.tableSize() == z["ht_table_keys"].shape[0]
+    ret = torch.empty(n, dtype=torch.int32, device="cuda")
+    tab.insert(pol, torch.from_numpy(keys).cuda().data_ptr(), n, ret.data_ptr())
+    cnt = int(z["ht_cnt"])
+    assert tab.size() == cnt
+    act = _d2h(tab.view().activeKeys, cnt * 12).reshape(cnt, 3)
+    assert set(map(tuple, act)) == set(map(tuple, z["ht_active_keys"]))
+    q = np.ascontiguousarray(z["ht_queries"])
+    qr = torch.empty(q.shape[0], dtype=torch.int32, device="cuda")
+    tab.query(pol, torch.from_numpy(q).cuda().data_ptr(), q.shape[0], qr.data_ptr())
+    qr = qr.cpu().numpy()
+    gq = z["ht_query_ret"]
+    assert np.array_equal(qr >= 0, gq >= 0) and np.array_equal(act[qr[qr >= 0]], q[qr >= 0])
+    # the occupied slots are the reference's occupied slots: same hash, same probe sequence, same keys at the same places whenever a
+    # key's probe path met no other key (arrival order only matters where two keys compete for a slot)
+    ts = tab.tableSize()
+    raw = _d2h(tab.view().keys, ts * 12).reshape(ts, 3)
+    gk = z["ht_table_keys"]
+    occ, gocc = (raw != INT_MAX).any(1), (gk != INT_MAX).any(1)
+    assert occ.sum() == gocc.sum() == cnt
+    same_place = (raw[occ & gocc] == gk[occ & gocc]).all(1).mean()
+    assert same_place > 0.95, same_place

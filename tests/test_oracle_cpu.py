@@ -554,3 +554,74 @@ def test_golden_p2g_grid_update_input_is_the_oracle_grid_update(oracle):
     om.grid[:] = g["grid"]
     om.grid_update(g["gravity"])
     assert np.abs(om.grid[:, :4] - g["gridv"][:, :4]).max() <= 1e-6 * np.abs(g["gridv"][:, 1:4]).max()
+
+
+# ------------------------------------------------------------------------------------------- whole-function pins of the containers
+BHT_SEQ_CASES = [("d3_b16", 3, 16), ("d3_b32", 3, 32), ("d3_b16_tight", 3, 16), ("d1_b16", 1, 16), ("d2_b16", 2, 16), ("d4_b16", 4, 16)]
+
+
+@pytest.mark.parametrize("tag,dim,bucket", BHT_SEQ_CASES)
+def test_bht_sequential_tables_match_reference_golden(oracle, tag, dim, bucket):
+    """oracle/bht.c against tests/golden/containers_seq.npz -- tables produced by the bodies of BHTView::insert / query (container/Bht.hpp:
+    612-698) spelled over the reference's own universal_hash_base / hash_combine / storage_key_type_impl / next_2pow (oracle/ref_shim.cpp)
+    under sequential insertion in input order: padded key slots byte for byte, indices of the occupied slots, status, activeKeys, count,
+    build-success flag, every insert return value (incl. the failure token of the over-full `tight` case) and the queries."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "containers_seq.npz"))
+    keys, nexp = np.ascontiguousarray(z[tag + "_keys"]), int(z[tag + "_n_expected"])
+    n = keys.shape[0]
+    oracle.orc_bht_create_b.restype = C.c_void_p
+    oracle.orc_bht_get_table_size.restype = C.c_size_t
+    oracle.orc_bht_size.restype = C.c_int32
+    oracle.orc_bht_build_success.restype = C.c_int32
+    for f in ("keys", "indices", "status", "active_keys"):
+        getattr(oracle, "orc_bht_" + f).restype = C.POINTER(C.c_int32)
+    t = C.c_void_p(oracle.orc_bht_create_b(dim, C.c_size_t(nexp), bucket))
+    ret = np.zeros(n, np.int32)
+    oracle.orc_bht_insert_many(t, ptr(keys), C.c_size_t(n), ptr(ret))
+    ts = oracle.orc_bht_get_table_size(t)
+    gk = z[tag + "_table_keys"]
+    assert ts == gk.shape[0] and oracle.orc_bht_key_stride(t) == gk.shape[1]
+    assert np.array_equal(ret, z[tag + "_ret"])
+    assert oracle.orc_bht_size(t) == int(z[tag + "_cnt"]) and oracle.orc_bht_build_success(t) == int(z[tag + "_success"])
+    if tag.endswith("tight"):
+        assert int(z[tag + "_success"]) == 0 and (z[tag + "_ret"] == np.iinfo(np.int32).min).any()   # the fixture does exercise the overflow path
+    tk = np.ctypeslib.as_array(oracle.orc_bht_keys(t), shape=gk.shape)
+    assert np.array_equal(tk, gk)                                                                    # pad words included
+    occ = (gk[:, :dim] != 0x3f3f3f3f).any(1)
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_bht_indices(t), shape=(ts,))[occ], z[tag + "_indices"][occ])
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_bht_status(t), shape=(ts,)), z[tag + "_status"])
+    cnt = int(z[tag + "_cnt"])
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_bht_active_keys(t), shape=(cnt, dim)), z[tag + "_active_keys"])
+    q = np.ascontiguousarray(z[tag + "_queries"])
+    qr = np.zeros(q.shape[0], np.int32)
+    oracle.orc_bht_query_many(t, ptr(q), C.c_size_t(q.shape[0]), ptr(qr))
+    assert np.array_equal(qr, z[tag + "_query_ret"])
+    oracle.orc_bht_destroy(t)
+
+
+def test_hashtable_sequential_table_matches_reference_golden(oracle):
+    """oracle/hashtable.c against the reference-made table of HashTable<int, 3, int> (container/HashTable.hpp:88-91 sizing, 383-400 insert,
+    454-463 query, 496-500 hash) under sequential insertion: keys, indices, activeKeys, count, return values, queries."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "containers_seq.npz"))
+    keys = np.ascontiguousarray(z["ht_keys"])
+    n = keys.shape[0]
+    oracle.orc_hashtable_create.restype = C.c_void_p
+    oracle.orc_hashtable_size.restype = C.c_int32
+    oracle.orc_hashtable_get_table_size.restype = C.c_int32
+    for f in ("keys", "indices", "active_keys"):
+        getattr(oracle, "orc_hashtable_" + f).restype = C.POINTER(C.c_int32)
+    t = C.c_void_p(oracle.orc_hashtable_create(3, C.c_size_t(n)))
+    ret = np.zeros(n, np.int32)
+    oracle.orc_hashtable_insert_many(t, ptr(keys), C.c_size_t(n), ptr(ret))
+    ts = oracle.orc_hashtable_get_table_size(t)
+    assert ts == z["ht_table_keys"].shape[0] and np.array_equal(ret, z["ht_ret"])
+    cnt = int(z["ht_cnt"])
+    assert oracle.orc_hashtable_size(t) == cnt
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_hashtable_keys(t), shape=(ts, 3)), z["ht_table_keys"])
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_hashtable_indices(t), shape=(ts,)), z["ht_indices"])
+    assert np.array_equal(np.ctypeslib.as_array(oracle.orc_hashtable_active_keys(t), shape=(cnt, 3)), z["ht_active_keys"])
+    q = np.ascontiguousarray(z["ht_queries"])
+    qr = np.zeros(q.shape[0], np.int32)
+    oracle.orc_hashtable_query_many(t, ptr(q), C.c_size_t(q.shape[0]), ptr(qr))
+    assert np.array_equal(qr, z["ht_query_ret"])
+    oracle.orc_hashtable_destroy(t)

@@ -102,6 +102,74 @@ def gen_p2g_g2p():
     np.savez_compressed(os.path.join(OUT, "p2g_g2p.npz"), **out)
 
 
+def gen_containers_seq():
+    """Whole-function fixtures for bht<int, dim, int, B> (container/Bht.hpp:154-158, 612-698) and HashTable<int, 3, int>
+    (container/HashTable.hpp:88-91, 383-400, 454-463, 496-500) under sequential insertion in input order: the tables byte for byte
+    (padded key slots, indices, status), activeKeys, insert return values and query results -- produced by oracle/ref_shim.cpp
+    over the reference's own universal_hash_base / hash_combine / storage_key_type_impl / next_2pow."""
+    g = np.random.default_rng(20260928)
+    ref.ref_bht_table_size_b.restype = C.c_size_t
+    ref.ref_hashtable_table_size.restype = C.c_size_t
+    out = {}
+    # (tag, dim, B, nExpected, keys): duplicates on purpose; the `tight` case overflows buckets (failure tokens, success = 0)
+    k3 = g.integers(-32, 32, (4096, 3), dtype=np.int32)
+    cases = [("d3_b16", 3, 16, 4096, k3), ("d3_b32", 3, 32, 4096, k3), ("d3_b16_tight", 3, 16, 600, g.integers(-7, 7, (4096, 3), dtype=np.int32)),
+             ("d1_b16", 1, 16, 1024, g.integers(-300, 300, (1024, 1), dtype=np.int32)),
+             ("d2_b16", 2, 16, 2048, g.integers(-40, 40, (2048, 2), dtype=np.int32)),
+             ("d4_b16", 4, 16, 2048, g.integers(-6, 6, (2048, 4), dtype=np.int32))]
+    for tag, dim, B, nexp, keys in cases:
+        keys = np.ascontiguousarray(keys)
+        n = keys.shape[0]
+        ts = int(ref.ref_bht_table_size_b(C.c_size_t(nexp), B))
+        ks = 1 << (dim - 1).bit_length()
+        ret = np.zeros(n, np.int32)
+        kt = np.zeros((ts, ks), np.int32)
+        ind, st = np.zeros(ts, np.int32), np.zeros(ts, np.int32)
+        act = np.zeros((ts, dim), np.int32)
+        cs = np.zeros(2, np.int32)
+        q = np.ascontiguousarray(np.concatenate([keys[::7], g.integers(-400, 400, (64, dim), dtype=np.int32)]))
+        qr = np.zeros(q.shape[0], np.int32)
+        ref.ref_bht_seq(dim, B, C.c_size_t(nexp), P(keys), C.c_size_t(n), P(ret), P(kt), P(ind), P(st), P(act), P(cs), P(q), C.c_size_t(q.shape[0]), P(qr))
+        out.update({tag + "_keys": keys, tag + "_n_expected": np.int64(nexp), tag + "_ret": ret, tag + "_table_keys": kt, tag + "_indices": ind,
+                    tag + "_status": st, tag + "_active_keys": act[: cs[0]].copy(), tag + "_cnt": cs[0], tag + "_success": cs[1],
+                    tag + "_queries": q, tag + "_query_ret": qr})
+        # (indices of never-written slots are whatever the allocation held: masked out by the comparison, which uses keys != sentinel)
+    hk = np.ascontiguousarray(g.integers(-64, 64, (4096, 3), dtype=np.int32))
+    ts = int(ref.ref_hashtable_table_size(C.c_size_t(4096)))
+    ret = np.zeros(4096, np.int32)
+    kt, ind, act = np.zeros((ts, 3), np.int32), np.zeros(ts, np.int32), np.zeros((ts, 3), np.int32)
+    cnt = C.c_int(0)
+    q = np.ascontiguousarray(np.concatenate([hk[::5], g.integers(-500, 500, (64, 3), dtype=np.int32)]))
+    qr = np.zeros(q.shape[0], np.int32)
+    ref.ref_hashtable_seq(C.c_size_t(4096), P(hk), C.c_size_t(4096), P(ret), P(kt), P(ind), P(act), C.byref(cnt), P(q), C.c_size_t(q.shape[0]), P(qr))
+    out.update({"ht_keys": hk, "ht_ret": ret, "ht_table_keys": kt, "ht_indices": ind, "ht_active_keys": act[: cnt.value].copy(), "ht_cnt": np.int32(cnt.value),
+                "ht_queries": q, "ht_query_ret": qr})
+    np.savez_compressed(os.path.join(OUT, "containers_seq.npz"), **out)
+    print("containers_seq.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith(("_cnt", "_success"))})
+
+
+def gen_grid_arena():
+    """GridArena (math/curve/InterpolationKernel.hpp:271-560) -- the reference's own class instantiated over a dense box of values
+    (oracle/ref_shim.cpp): stencil corner, local position, weights and their first / second derivatives per axis, isample of two channels,
+    minimum / maximum, weight and weightsGradient at three stencil nodes; six kernels, derivative orders 0-2, collocated and the three
+    staggered faces.  Points near the faces of the box exercise the default (background) value."""
+    g = np.random.default_rng(20260929)
+    ext, lo, dx, dflt = 12, np.array([-3, 2, -5], np.int32), np.float32(0.125), np.float32(7.0)
+    data = g.standard_normal((2, ext, ext, ext)).astype(np.float32)
+    npts = 96
+    X = (lo + g.random((npts, 3)) * ext).astype(np.float32)       # index space; some stencils reach outside the box
+    X[:8] = (lo + np.floor(g.random((8, 3)) * ext) + np.array([0.0, 0.5, 0.25])).astype(np.float32)   # on nodes / mid-cell planes
+    cases = [(kt, o, f) for kt in range(3) for o in range(3) for f in (-1, 1)] + [(kt, 0, f) for kt in (3, 4, 5) for f in (-1, 0, 2)] + \
+            [(1, 1, 0), (1, 1, 2), (2, 2, 0)]
+    outs = np.zeros((len(cases), npts, 58), np.float32)
+    for ci, (kt, o, f) in enumerate(cases):
+        rc = ref.ref_grid_arena(kt, o, P(data), 2, P(lo), ext, C.c_float(float(dx)), P(X), C.c_size_t(npts), f, C.c_float(float(dflt)), P(outs[ci]))
+        assert rc == 0
+    np.savez_compressed(os.path.join(OUT, "grid_arena.npz"), data=data, lo=lo, ext=np.int32(ext), dx=dx, default=dflt, X=X,
+                        cases=np.array(cases, np.int32), out=outs)
+    print("grid_arena.npz: %d cases x %d points" % (len(cases), npts))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     g = np.random.Generator(np.random.PCG64(0x9E3779B97F4A7C15 ^ 77))
@@ -242,6 +310,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "collider.npz"), cases=cases, x=cx, v=cv, v_out=cout, inside=cin)
     print("collider: %d of %d points inside" % (cin.sum(), cin.size))
     gen_p2g_g2p()
+    gen_containers_seq()
+    gen_grid_arena()
     print("wrote", os.listdir(OUT))
 
 
