@@ -70,7 +70,7 @@ def parse():
                     help="apply a Separate plane collider 1.5 cells above y = 0 after every grid update "
                          "(ApplyBoundaryConditionOnGridBlocks; off in the headline configuration)")
     ap.add_argument("--decomp", type=str, default="",
-                    help="rank grid AxBxC (default: slabs along y, 1xNx1); e.g. 2x2x2")
+                    help="rank grid AxBxC (default: 2x2x2 for 8 ranks, slabs along y, 1xNx1, otherwise)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, fused step: exchange the ghost blocks after the whole transfer kernel instead of overlapping "
                          "it with the interior blocks")
@@ -256,8 +256,8 @@ def main():
     # ---- partition, block numbering, bins, halo lists (re-run after every re-partition)
     nc = a.side ** 3
     stage = {}
-    # (slotted storage: the mover kernel adds to boundary blocks after the main kernel, so the exchange follows both)
-    overlap = world > 1 and a.fused and not a.no_overlap and not a.slotted
+    # boundary blocks first, their ghost sums travel on a second stream while the interior blocks compute (compact and slotted storage)
+    overlap = world > 1 and a.fused and not a.no_overlap
     comm_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
     pol_comm = zpc_amd.rocm_exec().sync(False).external_stream(comm_stream.cuda_stream) if overlap else pol
     ev_boundary, ev_comm = torch.cuda.Event(), torch.cuda.Event()
@@ -327,8 +327,10 @@ def main():
             if overlap:
                 # blocks whose launch must precede the exchange: 8^3 blocks hold their 4^3 bins and those bins' exact-path particles
                 # (at most one bin away, drift flag) within one block of themselves; 4^3 blocks (block = bin) within two
+                # (slotted storage: a bin writes grid nodes at most one block away from its own block -- its stencil arena, and the
+                # movers it finishes, which land at most one cell outside the bin)
                 n_boundary = mt.reorder_partition(near_shared_mask(all_keys[rank], all_keys, rank, mt.kstride,
-                                                                   margin=1 if a.side == 8 else 2))
+                                                                   margin=1 if (a.side == 8 or a.slotted) else 2))
         if not a.unbinned:
             mt.rebin()
         stage.clear()
@@ -390,6 +392,7 @@ def main():
             g2p_ev.append((e2, e3))
 
     fused_ev = []
+    node_trace = []
 
     ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
 
@@ -424,6 +427,21 @@ def main():
         grid_update()
         if floor is not None:
             mt.apply_boundary(floor)
+        if os.environ.get("ZS_BENCH_TRACE_NODES"):
+            # [hunting a rare deviation] grid nodes with mass whose v_y is far from the column's drift, after every step
+            g = mt.grid.view(mt.nblocks, 7, a.side ** 3)
+            vy_free = drift_v[1] - 9.8 * dt * (done + 1)   # free fall
+            dev = torch.where(g[:, 0] > 0, (g[:, 2] - vy_free).abs(), torch.zeros_like(g[:, 2]))
+            top = torch.topk(dev.flatten(), 4)
+            nc_ = a.side ** 3
+            if not hasattr(mt, "_trace_keys"):
+                mt._trace_keys = mt.active_keys()
+            def _desc(dv, i):
+                b, c = int(i) // nc_, int(i) % nc_
+                k = mt._trace_keys[b]
+                cell = (int(k[0]) * a.side + c // (a.side * a.side), int(k[1]) * a.side + (c // a.side) % a.side, int(k[2]) * a.side + c % a.side)
+                return ("%.3f" % float(dv), "m=%.2e" % float(g[b, 0, c]), "v=(%.3f,%.3f,%.3f)" % tuple(float(g[b, 1 + d, c]) for d in range(3)), cell)
+            node_trace.append((done + 1, int((dev > float(os.environ["ZS_BENCH_TRACE_NODES"])).sum()), [_desc(dv, i) for dv, i in zip(top.values, top.indices)]))
 
     migrated = 0
 
@@ -493,6 +511,7 @@ def main():
     best_ms, lost_ms, rebin_cost_ms = None, 0.0, None
 
     rebin_at = set(int(x) for x in a.rebin_at.split(",")) if a.rebin_at else None
+    rebin_steps = []
 
     def run_steps(count, timed):
         nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms
@@ -511,6 +530,7 @@ def main():
                 if done in rebin_at:
                     mt.rebin(inputs_only=True)
                     rebins += 1
+                    rebin_steps.append(done)
                 ctrl_ev.clear()
             elif a.fused and not a.slotted and a.rebin_check > 0 and done >= next_check:
                 ctrl_ev[-1][1].synchronize()  # the look stalls the stream: done less often while nothing is being lost
@@ -532,6 +552,7 @@ def main():
                     r1.synchronize()
                     rebin_cost_ms = r0.elapsed_time(r1)
                     rebins += 1
+                    rebin_steps.append(done)
                     best_ms, lost_ms = None, 0.0
                     check_iv = a.rebin_check
                 elif lost_ms < 0.1 * rebin_cost_ms:
@@ -564,6 +585,22 @@ def main():
         wgs = max(int(pv[7]), 1)
         print("probe (cycles per workgroup, 100 MHz-agnostic s_memtime ticks): " +
               " ".join("[%d]=%.0f" % (k, pv[k] / wgs / (4 if k in (0, 1, 4, 5, 6) else 8)) for k in range(7)) + " wgs=%d" % wgs, file=sys.stderr)
+    if a.fused and a.checksum and os.environ.get("ZS_BENCH_REPEAT_FINAL") and not a.slotted:
+        # [hunting a rare deviation] the final write-all step repeated from ONE saved state: does its result vary?
+        sb, sg = mt.buf.clone(), mt.grid.clone()
+        counts = []
+        thr = float(os.environ.get("ZS_BENCH_OUTLIERS", "4"))
+        for _ in range(int(os.environ["ZS_BENCH_REPEAT_FINAL"])):
+            mt.buf.copy_(sb)
+            mt.grid.copy_(sg)
+            step_fused(False, write_all=True)
+            torch.cuda.synchronize()
+            vv = mt.buf.view(mt.tiles, mt.nchn, mt.L)
+            counts.append(int((vv[:, 7:16, :].abs() > thr).any(dim=1).sum()))
+        print("[repeat-final] outlier counts: %s" % " ".join(map(str, counts)), file=sys.stderr)
+        mt.buf.copy_(sb)
+        mt.grid.copy_(sg)
+        del sb, sg
     if a.fused and a.checksum:
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
@@ -613,7 +650,7 @@ def main():
         slot_stats = {"bins_occupied": int(occ.sum()), "mean_rounds": float(rounds[occ].mean()), "mean_chunk_rounds": float((torch.ceil(rounds[occ] / 4) * 4).mean()),
                       "mean_particles_per_bin_div64": float(per_bin[occ].mean() / 64), "max_rounds": int(rounds.max()),
                       "mean_max_cell_count": float(cnt.max(dim=1).values.float()[occ].mean())}
-    checksum = None
+    checksum = checksum_trim = None
     if a.checksum:
         # order-independent global sums of the particle state (float64): equal for any number of ranks up to rounding
         cbuf, ctiles = mt.buf, mt.tiles
@@ -624,10 +661,35 @@ def main():
         valid = (torch.arange(ctiles * mt.L, device=device) < n_local).view(ctiles, 1, mt.L)
         sums = (v * valid).sum(dim=(0, 2))
         sq = ((v * valid) ** 2).sum(dim=(0, 2))
+        if os.environ.get("ZS_BENCH_TRACE_NODES"):
+            print("[trace] " + " ".join("%d:%d" % (t[0], t[1]) for t in node_trace), file=sys.stderr)
+            print("[trace-first] " + repr([t for t in node_trace if t[1] and t[0] > 8][-3:]), file=sys.stderr)
+        if os.environ.get("ZS_BENCH_OUTLIERS"):
+            print("[outliers] re-binned after steps %s" % ",".join(map(str, rebin_steps)), file=sys.stderr)
+            # where are velocity-gradient entries far outside the distribution (rms 0.44 in the default column)?  [hunting a rare difference]
+            big = (v[:, 7:16, :].abs() > float(os.environ["ZS_BENCH_OUTLIERS"])).any(dim=1) & valid[:, 0, :]
+            nbig = int(big.sum())
+            idx = torch.nonzero(big)[:8]
+            rows = [[int(t), int(l)] + [round(float(x), 4) for x in v[t, 1:4, l]] + [round(float(x), 3) for x in v[t, 7:16, l]] for t, l in idx.tolist()]
+            tl = torch.nonzero(big)[:, 0]
+            print("[outliers] |C| > %s: %d particles, tiles %s..%s; first: %r" % (os.environ["ZS_BENCH_OUTLIERS"], nbig, int(tl.min()) if nbig else -1,
+                                                                              int(tl.max()) if nbig else -1, rows), file=sys.stderr)
         cs = torch.cat([sums, sq]).to(comm_dev)
+        # ... and the same sums without the particles that carry a velocity-gradient entry beyond 8 rms.  v = mv / m of a grid node is
+        # ill-conditioned where the node's mass is only the far tail of a few weights (the free surface of the column: masses down to
+        # 1e-37, next to f32 denormals, which the hardware float atomics flush), and Dinv = 4 / dx^2 carries a deviation of such a node
+        # into C of the particles around it: a handful of particles whose C depends on the order of the atomic adds -- in this
+        # implementation as in the reference's (P2G.hpp:104-124 + GridOp.hpp:71-108).  Sum-of-squares comparisons between two runs use
+        # the trimmed sums and bound the number of trimmed particles.
+        c2 = v[:, 7:16, :] ** 2 * valid
+        thr2 = 64.0 * float(c2.sum()) / max(9 * n_local, 1)
+        keep = valid & ~((c2 > thr2).any(dim=1, keepdim=True))
+        cs_trim = torch.cat([(v * keep).sum(dim=(0, 2)), ((v * keep) ** 2).sum(dim=(0, 2)), (valid & ~keep).sum().double().view(1)]).to(comm_dev)
         if dist is not None:
             dist.all_reduce(cs)
+            dist.all_reduce(cs_trim)
         checksum = [float(x) for x in cs.cpu()]
+        checksum_trim = [float(x) for x in cs_trim.cpu()]
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
@@ -727,6 +789,7 @@ def main():
             pass
         if checksum is not None:
             out["checksum"] = checksum
+            out["checksum_trimmed"] = {"sums": checksum_trim[:-1], "trimmed_particles": int(checksum_trim[-1])}
         if slot_stats is not None:
             out["slot_stats"] = slot_stats
         if world == 1 and a.slotted and not a.no_at_rest and any(abs(x) > 0 for x in drift_v):

@@ -641,6 +641,13 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *, const zs_rocm_mpm
                                              const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr,
                                              const int *nbr27, int *moverCount, unsigned *claim, float *moverRec, int outboxCap,
                                              int writeAll, int *status);
+/* the same over blocks [blockBegin, blockEnd); finish != 0 (ONCE per step, with or after the last range): the step's outbox records get
+ * their slots and departures / arrivals enter the occupancy words.  Multi-GPU: boundary blocks first, their ghost sums travel while the
+ * interior range computes (zs_rocm_mpm_g2p2g_range is the compact-storage counterpart) */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
+                                                   const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr,
+                                                   const int *nbr27, int *moverCount, unsigned *claim, float *moverRec, int outboxCap,
+                                                   int writeAll, int *status, size_t blockBegin, size_t blockEnd, int finish);
 /* particles.stress := model(F, logJp) * volume, logJp updated (no-op when particles.stress.base == NULL) */
 /* Fused transfer: G2P of step n (from gridA: velocities after zs_rocm_mpm_grid_update) and P2G of step n+1 (into gridB,
  * zeroed by the caller) in one pass over the binned particles -- the reference's G2P2GTransfer idea

@@ -129,7 +129,11 @@ def test_long_run_with_rebins_is_rank_independent():
 
 
 @pytest.mark.parametrize("n,extra", [(2, []), (4, ["--decomp", "2x2x1"]), (2, ["--side", "4", "--cells", "16,96,16"]),
-                                     (2, ["--drift", "3,-4,2", "--outbox-cap", "512"])])
+                                     (2, ["--drift", "3,-4,2", "--outbox-cap", "512"]), (2, ["--no-overlap"]),
+                                     # 8 ranks in the default 2 x 2 x 2 grid, the cloud drifting obliquely through the corner all eight
+                                     # boxes share: movers cross faces, edges and the corner between ranks
+                                     (8, ["--cells", "32,64,32", "--drift", "3,-4,2", "--outbox-cap", "512"]),
+                                     (8, ["--cells", "24,128,24", "--decomp", "1x8x1"])])
 def test_slotted_default_n_ranks_reproduce_single_rank(n, extra):
     """the bench's default storage (slotted: the step keeps its own order, movers travel through outboxes) on N ranks sharing one GPU:
     the column falls at 0.05 cell per step (default) or drifts obliquely at up to 0.2 cell per step across the rank boundaries, no
@@ -140,6 +144,10 @@ def test_slotted_default_n_ranks_reproduce_single_rank(n, extra):
     assert out["n_gpus"] == n and out["config"]["particles"] == ref["config"]["particles"]
     assert "slotted" in out["config"]["storage"] and out["config"]["rebins"] == 0
     assert ref["config"]["movers_per_step_rank0"] > 0
+    # the exchange of the ghost-block sums is overlapped with the interior blocks on slotted storage too (boundary blocks first)
+    assert out["config"]["halo_overlap"] == ("--no-overlap" not in extra) and out["config"]["halo_bytes_per_step_rank0"] > 0
+    if n == 8 and "--decomp" not in extra:
+        assert out["config"]["decomposition"] == "2x2x2"
     a, b = np.array(ref["checksum"]), np.array(out["checksum"])
     nch = len(a) // 2
     scale = np.sqrt(ref["config"]["particles"] * np.maximum(a[nch:], 1e-30))

@@ -101,6 +101,45 @@ def test_config2_bht_16m_keys(pol, oracle):
     assert np.array_equal(act.reshape(size, 3)[qi[sample]], keys[sample])
 
 
+def test_config2_tilevector_16m_aosoa_load_store(pol):
+    """BASELINE config 2, TileVector half: TileVector<f32, 32>{m:1, x:3, v:3, F:9, C:9} (25 channels, 100 B per particle, 1.6 GB) at 16 M
+    particles -- the container through the reference's C ABI (container__tv_float_32, get_iterator_1__tv_float_32), element (chn, i) at
+    (i / L * C + chn) * L + i % L (container/TileVector.hpp:108, 397): an AoS -> AoSoA store of every channel, the load + store pass over
+    all channels (zs_rocm_tv_scale_f32, the kernel the secondary bench line times), and reads back through the channel iterators -- checked
+    against the closed form of the fill on a strided sample of particles and on per-channel sums (reduce over the iterator ABI)."""
+    import zpc_amd as zs
+    from zpc_amd.containers import TileVector
+    from zpc_amd.primitives import Iter
+    n, L = 16_000_000, 32
+    tags = [("m", 1), ("x", 3), ("v", 3), ("F", 9), ("C", 9)]
+    tv = TileVector("float", L, tags, n)
+    Cn = tv.numChannels()
+    assert Cn == 25 and tv.size() == n and [tv.getPropertyOffset(k) for k in ("m", "x", "v", "F", "C")] == [0, 1, 4, 7, 16]
+    # value of (particle i, channel c): small integers, exact in float32 and under the power-of-two scaling
+    i = torch.arange(n, device="cuda", dtype=torch.int64)
+    aos = torch.stack([((i * (c + 3) + c * 7) % 1021 - 510).float() for c in range(Cn)], dim=1).contiguous()
+    zs.lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n, Cn, L, tv.data())
+    zs.lib().zs_rocm_tv_scale_f32(pol.handle, tv.data(), n, Cn, L, C.c_float(0.5))
+    pol.syncCtx()
+    raw = np.empty(n * Cn, np.float32)   # n is a multiple of L: no padding tile
+    C.CDLL("libamdhip64.so").hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(tv.data()), C.c_size_t(raw.nbytes), 2)
+    sample = np.arange(0, n, 4099, dtype=np.int64)
+    for c in (0, 1, 6, 7, 15, 16, 24):
+        want = (((sample * (c + 3) + c * 7) % 1021) - 510).astype(np.float32) * np.float32(0.5)
+        got = raw[(sample // L * Cn + c) * L + sample % L]                       # the layout formula of the reference
+        assert np.array_equal(got, want), c
+    # per-channel sums through the reference's iterator ABI (exact: the addends are multiples of 0.5 and the sum fits in a double)
+    out = torch.zeros(1, dtype=torch.float32, device="cuda")
+    full = aos.double().sum(dim=0).cpu().numpy() * 0.5
+    for name, comp, c in (("m", 0, 0), ("v", 2, 6), ("C", 8, 24)):
+        it = tv.iterator(name) if comp == 0 else tv.iterator(tv.getPropertyOffset(name) + comp)
+        last = type(it)(it.base, it.idx + n, it.numTileBits, it.tileMask, it.numChns)
+        zs.lib().reduce_sum__rocm_float_1(pol.handle, it, last, Iter.aos(out).port)
+        # float32 tree sum of 16 M addends: a few ulp of the sum of magnitudes (the reference's own float test uses 1e-6 relative on
+        # 1000 elements, test/utils/parallel_primitives.hpp:30)
+        assert abs(float(out.item()) - full[c]) <= 4e-6 * aos[:, c].abs().double().sum().item() * 0.5, (name, float(out.item()), full[c])
+
+
 def test_config5_lbvh_10m_boxes(pol):
     """BASELINE config 5: LBvh over 10 M boxes: structural invariants of the pre-order layout (parents, levels, escape indices, leaf
     positions, boxes contain their children) and the self-collision pairs of sampled leaves against brute force"""
@@ -189,7 +228,12 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     assert a["config"]["particles"] == n and a["hip_error"] == 0 and b["hip_error"] == 0
     assert a["config"]["rebins"] == 0 and b["config"]["rebins"] > 0
     assert a["slot_stats"]["mean_rounds"] > a["slot_stats"]["mean_particles_per_bin_div64"] + 1.0  # the regime the packing is for
-    _same_state(a["checksum"], b["checksum"], n, 1e-4, 3e-4)
+    # the trimmed sums (bench.py: particles with a velocity-gradient entry beyond 8 rms are left out -- free-surface particles next to grid
+    # nodes whose mass is a far weight tail, where v = mv / m depends on the order of the float atomics; measured on the compact path: the
+    # same 76 particles at the foot of the column in 5 % of the runs, profiles/r03_compact_outliers.md) must agree, and few may be trimmed
+    ta, tb = a["checksum_trimmed"], b["checksum_trimmed"]
+    assert ta["trimmed_particles"] <= 512 and tb["trimmed_particles"] <= 512, (ta["trimmed_particles"], tb["trimmed_particles"])
+    _same_state(ta["sums"], tb["sums"], n, 1e-4, 3e-4)
     m = 1000.0 * (1.0 / 512) ** 3 / 8
     assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
 

@@ -340,6 +340,8 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2p2g_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_g2p2g_slotted.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]
     L.zs_rocm_mpm_g2p2g_slotted.restype = i32
+    L.zs_rocm_mpm_g2p2g_slotted_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, sz, sz, i32]
+    L.zs_rocm_mpm_g2p2g_slotted_range.restype = i32
     L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

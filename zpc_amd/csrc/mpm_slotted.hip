@@ -970,11 +970,16 @@ size_t zs_rocm_mpm_slot_list(zs_rocm_policy *pol, const unsigned *cellMask, size
 
 // The fused step on slotted storage.  particles: attributes of ONE TileVector<f32, 64> with nbins*K*64 elements (particles.n);
 // gridB zeroed by the caller; mover buffers sized by zs_rocm_mpm_slot_outbox_bytes (the claim words zeroed by the caller ONCE: every
-// step leaves them zero); status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller when it wants to (they latch).  Returns 0, -1 on
-// bad arguments.
-int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
-                              float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27, int *moverCount,
-                              unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status) {
+// step leaves them zero); status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller when it wants to (they latch).
+// blocks [blockBegin, blockEnd) only; finish != 0: also give the step's outbox records their new slots and fold departures / arrivals
+// into the occupancy words -- ONCE per step, after the ranges that cover all blocks.  Multi-GPU step (bench.py): the partition is
+// numbered with the blocks near a rank boundary first; their range is launched first and their ghost-block sums travel on a second
+// stream while the interior range computes (a bin writes grid nodes at most one block away from its own).
+// Returns 0, -1 on bad arguments.
+int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
+                                    const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27,
+                                    int *moverCount, unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status,
+                                    size_t blockBegin, size_t blockEnd, int finish) {
   if (!nblocks) return 0;
   if (!cellMask || !nbr || !nbr27 || !moverCount || !claim || !moverRec || !status || K < 1 || K > 32 || outboxCap < 1) return -1;
   if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
@@ -982,18 +987,23 @@ int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, 
     fprintf(stderr, "[zs_rocm] g2p2g_slotted needs all particle attributes in one TileVector<f32, 64>\n");
     return -1;
   }
+  if (blockEnd > nblocks) blockEnd = nblocks;
   Launch L(pol, "G2P2GTransfer(slotted)");
   MpmDev mp = make_dev(p);
   ParticlesDev pd = make_particles(ps);
   BhtDev t = tab->t.dev();
   const unsigned bpb = p->side == 4 ? 1u : 8u;
-  const unsigned nbins = (unsigned)(nblocks * bpb);
-  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, 0, (int)nbins, (int)nbins, outboxCap};
-#define CALL_SLOT3(SS, M, WA)                                                                                          \
-  hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                \
-  hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbins, 4)), \
-                     dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec,  \
-                     outboxCap, (size_t)nbins, K, status)
+  const unsigned nbinsAll = (unsigned)(nblocks * bpb);
+  const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
+  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap};
+#define CALL_SLOT3(SS, M, WA)                                                                                                          \
+  do {                                                                                                                                  \
+    if (nbins) hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                   \
+    if (finish)                                                                                                                         \
+      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 4)),         \
+                         dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
+                         outboxCap, (size_t)nbinsAll, K, status);                                                                       \
+  } while (0)
 #define CALL_SLOT(SS, M)                       \
   do {                                         \
     if (writeAll) { CALL_SLOT3(SS, M, true); } \
@@ -1004,9 +1014,18 @@ int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, 
 #else
   ZSR_DISPATCH_SIDE_PURE(p->side, p->model, CALL_SLOT);
 #endif
-  const size_t ncells = (size_t)nbins * 64;
-  hipLaunchKernelGGL(slot_commit_kernel, dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, cellMask, claim, ncells, K);
+  if (finish) {
+    const size_t ncells = (size_t)nbinsAll * 64;
+    hipLaunchKernelGGL(slot_commit_kernel, dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, cellMask, claim, ncells, K);
+  }
   return 0;
+}
+
+int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                              float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27, int *moverCount,
+                              unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status) {
+  return zs_rocm_mpm_g2p2g_slotted_range(pol, p, ps, tab, gridA, gridB, nblocks, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, outboxCap,
+                                         writeAll, status, 0, nblocks, 1);
 }
 
 }  // extern "C"

@@ -27,11 +27,13 @@ def set_split_dims(world_size, dims):
 
 
 def split_dims(world_size):
-    """Rank grid.  Default: slabs along y, the long axis of the column: (1, N, 1).  A slab has two neighbours (two messages per
-    step instead of up to seven for a 2x2x2 grid) and, for the 128 x 512 x 128 column, less ghost surface than the cubic
-    split up to N = 8."""
+    """Rank grid.  8 ranks: the 2 x 2 x 2 split SURVEY.md 8(e) / BASELINE config 4 name (every pair of ranks is one direct xGMI link; up
+    to seven peers per rank).  Other sizes: slabs along y, the long axis of the column, (1, N, 1): two neighbours per rank.
+    `set_split_dims` / bench.py --decomp override both."""
     if world_size in _SPLIT_OVERRIDE:
         return _SPLIT_OVERRIDE[world_size]
+    if world_size == 8:
+        return (2, 2, 2)
     return (1, world_size, 1)
 
 

@@ -133,6 +133,10 @@ class MpmTransfer:
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
+        import os
+        if os.environ.get("ZS_ROCM_CANONICAL_PARTITION"):  # block numbers = lexicographic rank of the keys (reproducible across runs)
+            self.table.canonicalize(self.pol)
+            self.pol.syncCtx()
         self.nblocks = self.table.size()
         self.slotted = False
         nc = self.side ** 3
@@ -333,20 +337,25 @@ class MpmTransfer:
         itself carries them into that order -- inputs read from the old buffer through the permutation, results stored to the
         other buffer (zs_rocm_mpm_g2p2g_reorder_range): a re-bin without the separate reorder pass."""
         if self.slotted:
-            if reorder or split:
-                raise ValueError("slotted storage: no re-ordering / split launches (the step keeps the order itself)")
+            if reorder:
+                raise ValueError("slotted storage: no re-ordering steps (the step keeps the order itself)")
             if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
                 self.grid2 = torch.zeros_like(self.grid)
             else:
                 self._zero(self.grid2)
             src, dst = self.grid, self.grid2
-            self.grid, self.grid2 = dst, src
-            rc = lib().zs_rocm_mpm_g2p2g_slotted(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
-                                                 dst.data_ptr(), self.nblocks, self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(),
-                                                 self.nbr27.data_ptr(), self.mover_count.data_ptr(), self.mover_dest.data_ptr(),
-                                                 self.mover_rec.data_ptr(), self.outbox_cap, int(write_all), self.slot_status.data_ptr())
-            if rc != 0:
-                raise RuntimeError("zs_rocm_mpm_g2p2g_slotted refused the call")
+            self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
+            ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
+            for k, (b0, b1) in enumerate(ranges):
+                rc = lib().zs_rocm_mpm_g2p2g_slotted_range(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
+                                                           dst.data_ptr(), self.nblocks, self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(),
+                                                           self.nbr27.data_ptr(), self.mover_count.data_ptr(), self.mover_dest.data_ptr(),
+                                                           self.mover_rec.data_ptr(), self.outbox_cap, int(write_all), self.slot_status.data_ptr(),
+                                                           b0, b1, int(k == len(ranges) - 1))
+                if rc != 0:
+                    raise RuntimeError("zs_rocm_mpm_g2p2g_slotted refused the call")
+                if k == 0 and between is not None:
+                    between()
             return
         if not (self.cache_stress and self.binned):
             raise RuntimeError("g2p2g needs cache_stress=True and rebin()")
