@@ -479,6 +479,79 @@ def main():
             mt.slot(K=a.slot_rounds, outbox_cap=a.outbox_cap)
         unfused_step = step
         step = lambda timed, write_all=False, reorder=False: step_fused(timed, write_all, reorder)
+        if os.environ.get("ZS_BENCH_AUDIT") and os.environ.get("ZS_BENCH_TRACE_NODES") and not a.slotted:
+            # [hunting a rare deviation] keep the state in front of every step; at the first step that leaves a deviating node: repeat it
+            # from that state (does the result vary?) and compare a write-all repetition with G2P + P2G (the unfused kernels) particle by particle
+            def step(timed, write_all=False, reorder=False):
+                sb, sg = mt.buf.clone(), mt.grid.clone()
+                step_fused(timed, write_all, reorder)
+                if os.environ.get("ZS_BENCH_AUDIT_EVERY") and not getattr(mt, "_audited", False):
+                    # every step: the same step by the unfused kernels from the same state; what the NEXT step reads (m, x, F, logJp, grid) must agree
+                    fb, fg = mt.buf.clone(), mt.grid.clone()
+                    mt.buf.copy_(sb); mt.grid.copy_(sg)
+                    mt.g2p(binned=True); mt.clear_grid(); mt.p2g(binned=True); exchange(); grid_update()
+                    Vv = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
+                    bad = []
+                    for c in [0, 1, 2, 3] + list(range(16, mt.nchn if mt.nchn <= 26 else 26)):
+                        d = (Vv(fb)[:, c, :] - Vv(mt.buf)[:, c, :]).abs()
+                        nb = int((d > 1e-4).sum()) if c >= 16 else int((d > 1e-6).sum())
+                        if nb:
+                            i = int(d.flatten().argmax())
+                            bad.append((c, nb, float(d.flatten()[i]), i))
+                    gd = (fg - mt.grid).abs().view(mt.nblocks, 7, -1)
+                    gbad = [(c, int((gd[:, c] > 1e-3 * float(mt.grid.view(mt.nblocks, 7, -1)[:, c].abs().max())).sum())) for c in range(7)]
+                    if bad or any(n for _, n in gbad):
+                        print("[audit-every] step %d: fused and unfused disagree: particle channels %r grid %r" % (done + 1, bad, gbad), file=sys.stderr)
+                    mt.buf.copy_(fb); mt.grid.copy_(fg)
+                    del fb, fg
+                if done < 5 or node_trace[-1][1] == 0 or getattr(mt, "_audited", False):
+                    return
+                mt._audited = True
+                torch.cuda.synchronize()
+                print("[audit] step %d left %d deviating nodes: %r" % (node_trace[-1][0], node_trace[-1][1], node_trace[-1][2]), file=sys.stderr)
+                keepb, keepg = mt.buf.clone(), mt.grid.clone()
+                counts = []
+                for _ in range(int(os.environ["ZS_BENCH_AUDIT"])):
+                    mt.buf.copy_(sb); mt.grid.copy_(sg)
+                    step_fused(False, True, False)
+                    counts.append(node_trace.pop()[1])
+                print("[audit] the step repeated from the saved state, deviating nodes: %s" % " ".join(map(str, counts)), file=sys.stderr)
+                fb, fg = mt.buf.clone(), mt.grid.clone()
+                mt.buf.copy_(sb); mt.grid.copy_(sg)
+                mt.g2p(binned=True); mt.clear_grid(); mt.p2g(binned=True); exchange(); grid_update()
+                torch.cuda.synchronize()
+                ub, ug = mt.buf, mt.grid
+                V = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
+                names = {0: "m", 1: "x", 4: "v", 7: "C", 16: "F", 25: "logJp"}
+                for c in range(mt.nchn):
+                    d = (V(fb)[:, c, :] - V(ub)[:, c, :]).abs()
+                    d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+                    sc = float(V(ub)[:, c, :].abs().max())
+                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
+                    if nb:
+                        i = int(d.flatten().argmax()); t, l = i // mt.L, i % mt.L
+                        print("[audit] particle channel %d (%s): %d entries off by more than 1e-3 of the channel's max %.3e; worst %.3e at particle %d (tile %d lane %d): fused %.6e unfused %.6e"
+                              % (c, names.get(c, ""), nb, sc, float(d.flatten()[i]), t * mt.L + l, t, l, float(V(fb)[t, c, l]), float(V(ub)[t, c, l])), file=sys.stderr)
+                G = lambda t: t.view(mt.nblocks, 7, a.side ** 3)
+                for c in range(7):
+                    d = (G(fg)[:, c] - G(ug)[:, c]).abs()
+                    sc = float(G(ug)[:, c].abs().max())
+                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
+                    print("[audit] grid channel %d: %d nodes off (repeated fused vs unfused), max %.3e of %.3e" % (c, nb, float(d.max()), sc), file=sys.stderr)
+                    d = (G(keepg)[:, c] - G(ug)[:, c]).abs()
+                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
+                    print("[audit] grid channel %d: %d nodes off (the deviating step itself vs unfused), max %.3e" % (c, nb, float(d.max())), file=sys.stderr)
+                    if nb and c == 2:
+                        keys = mt.active_keys()
+                        for i in torch.topk(d.flatten(), 6).indices.tolist():
+                            b, cc = i // a.side ** 3, i % a.side ** 3
+                            k = keys[b]
+                            print("[audit]    node %r: deviating step %.5f  unfused %.5f  mass %.3e" % (
+                                (int(k[0]) * a.side + cc // (a.side * a.side), int(k[1]) * a.side + (cc // a.side) % a.side, int(k[2]) * a.side + cc % a.side),
+                                float(G(keepg)[b, c, cc]), float(G(ug)[b, c, cc]), float(G(ug)[b, 0, cc])), file=sys.stderr)
+                # the particles around the worst node, as the deviating step left them (only the channels a non-write-all step stores are meaningful)
+                mt.buf, mt.grid = keepb, keepg
+                raise SystemExit(0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -531,6 +604,19 @@ def main():
                     mt.rebin(inputs_only=True)
                     rebins += 1
                     rebin_steps.append(done)
+                    if os.environ.get("ZS_BENCH_CHECK_REBIN"):
+                        # [hunting a rare deviation] is the order a permutation, and did every carried channel arrive?
+                        o = mt.order.long()
+                        perm = bool((torch.sort(o).values == torch.arange(mt.n, device=o.device)).all())
+                        Vv = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
+                        mism = {}
+                        for c in [0, 1, 2, 3] + list(range(16, min(mt.nchn, 26))):
+                            newc = Vv(mt.buf)[:, c, :].reshape(-1)[:mt.n]
+                            oldc = Vv(mt.buf2)[:, c, :].reshape(-1)[o]
+                            k = int((newc != oldc).sum())
+                            if k:
+                                mism[c] = k
+                        print("[rebin-check] after step %d: permutation %s, channel mismatches %r" % (done, perm, mism), file=sys.stderr)
                 ctrl_ev.clear()
             elif a.fused and not a.slotted and a.rebin_check > 0 and done >= next_check:
                 ctrl_ev[-1][1].synchronize()  # the look stalls the stream: done less often while nothing is being lost
@@ -752,23 +838,24 @@ def main():
             # PMC traffic of the kernels this run used: slotted storage under motion (pmc_g2p2g.json, tools/refresh_r02.sh) or the
             # compact-storage kernel at rest (pmc_g2p2g_compact.json); no figure was collected for the other combinations
             moving = any(abs(x) > 0 for x in drift_v)
+            fkernel = "g2p2g_slot_kernel + slot_rehome_kernel + slot_commit_kernel" if a.slotted else "g2p2g_rs_kernel"
             pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json" if (a.slotted and moving) else "pmc_g2p2g_compact.json")
             if os.path.exists(pmcf) and (a.slotted == moving):
                 try:
                     j = json.load(open(pmcf))
-                    if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model:
-                        ftraffic = j.get("hbm_bytes_per_launch")
+                    if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model and j.get("kernel") == fkernel:
+                        ftraffic = j.get("hbm_bytes_per_launch")   # (a figure collected for another kernel generation is not this run's traffic)
                 except Exception:
                     pass
             out["config"]["workload"] = out["config"]["workload"].replace("step = grid reset + P2G + grid update + G2P",
                                                                           "step = grid reset + fused G2P2G (G2P of step n, P2G of step n+1) + grid update")
-            out["roofline"] = {"bound": "hbm", "kernel": "g2p2g_slot_kernel + mover_pull_kernel" if a.slotted else "g2p2g_rs_kernel", "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline"] = {"bound": "hbm", "kernel": fkernel, "achieved": fach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": fach / HBM_PEAK_GBS, "traffic": ftraffic, "bytes_per_particle": fb,
                                "particles_per_launch": n_local, "launch_ms": fused_ms,
                                "fused_min_bytes_per_particle": fmin,
                                "note": "bytes_per_particle = SURVEY 8(d) P2G + G2P; the fused pass keeps v, C and the stress on chip "
                                        "(traffic < algorithmic bytes) and is bound by VALU issue, not by HBM (profiles/r02_pmc_g2p2g.md); "
-                                       "launch_ms = HIP-event time of the fused launches of one step (main kernel + mover kernel)"}
+                                       "launch_ms = HIP-event time of the fused launches of one step (slotted: main kernel + re-home + commit kernels)"}
         # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
         # bytes over HIP-event time, after the timed region)
         try:

@@ -146,8 +146,17 @@ static int grid_arena_against_reference(const char *path) {
       GA(3, kernel_e::delta2, 0) GA(4, kernel_e::delta3, 0) GA(5, kernel_e::delta4, 0)
 #undef GA
     });
-    for (int i = 0; i < npts; ++i)
+    const int widthOf[6] = {2, 3, 4, 2, 3, 4};  // linear, quadratic, cubic, delta2, delta3, delta4
+    for (int i = 0; i < npts; ++i) {
+      // minimum / maximum pad missing cells with +-max, not with the caller's default: the sparse grid of this test stores the default in the
+      // cells of allocated blocks outside the box, the reference's dense view has no such cells -- compared only where the arena stays inside
+      bool inside = true;
+      for (int d = 0; d < 3; ++d) {
+        const int c0 = (int)want[((std::size_t)ci * npts + i) * 58 + d];
+        inside = inside && c0 >= lo[d] && c0 + widthOf[kt] <= lo[d] + ext;
+      }
       for (int k = 0; k < 58; ++k) {
+        if (!inside && (k == 44 || k == 45)) continue;
         const float a = got.data()[(std::size_t)i * 58 + k], b = want[((std::size_t)ci * npts + i) * 58 + k];
         // corner / local position: exact and 1e-6; weights: 2e-6 of values in [-6, 6] (second derivatives of the cubic);
         // samples: 27 / 64-term sums of values of size ~3: 2e-5
@@ -157,6 +166,7 @@ static int grid_arena_against_reference(const char *path) {
           ++bad;
         }
       }
+    }
   }
   std::printf("grid arena vs reference: %d cases x %d points, %d mismatches\n", ncases, npts, bad);
   return bad ? 1 : 0;
