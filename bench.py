@@ -502,6 +502,45 @@ def main():
                     gbad = [(c, int((gd[:, c] > 1e-3 * float(mt.grid.view(mt.nblocks, 7, -1)[:, c].abs().max())).sum())) for c in range(7)]
                     if bad or any(n for _, n in gbad):
                         print("[audit-every] step %d: fused and unfused disagree: particle channels %r grid %r" % (done + 1, bad, gbad), file=sys.stderr)
+                        ub, ug = mt.buf.clone(), mt.grid.clone()
+                        keys = mt.active_keys()
+                        S3 = a.side ** 3
+                        G = lambda t: t.view(mt.nblocks, 7, S3)
+                        dm = (G(fg)[:, 0] - G(ug)[:, 0])
+                        for i in torch.topk(dm.abs().flatten(), 16).indices.tolist():
+                            b, cc = i // S3, i % S3
+                            k = keys[b]
+                            print("[audit-every]    node %r block %d: mass fused - unfused %+.3e (unfused %.3e)  v_y fused %.5f unfused %.5f" % (
+                                (int(k[0]) * a.side + cc // (a.side * a.side), int(k[1]) * a.side + (cc // a.side) % a.side, int(k[2]) * a.side + cc % a.side), b,
+                                float(dm[b, cc]), float(G(ug)[b, 0, cc]), float(G(fg)[b, 2, cc]), float(G(ug)[b, 2, cc])), file=sys.stderr)
+                        print("[audit-every]    total mass fused %.9e unfused %.9e" % (float(G(fg)[:, 0].double().sum()), float(G(ug)[:, 0].double().sum())), file=sys.stderr)
+                        reps = []
+                        for _ in range(4):
+                            mt.buf.copy_(sb); mt.grid.copy_(sg)
+                            step_fused(False, False, False)
+                            node_trace.pop()
+                            reps.append(int(((G(mt.grid)[:, 0] - G(ug)[:, 0]).abs() > 1e-3 * float(G(ug)[:, 0].max())).sum()))
+                        print("[audit-every]    fused step repeated from the same state, nodes with a mass difference: %r" % reps, file=sys.stderr)
+                        mt.buf.copy_(sb); mt.grid.copy_(sg)
+                        step_fused(False, True, False)
+                        node_trace.pop()
+                        for c in range(mt.nchn):
+                            d = (Vv(mt.buf)[:, c, :] - Vv(ub)[:, c, :]).abs()
+                            d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+                            sc = max(float(Vv(ub)[:, c, :].abs().max()), 1e-30)
+                            nb = int((d > 1e-3 * sc).sum())
+                            if nb:
+                                i = int(d.flatten().argmax()); t, l = i // mt.L, i % mt.L
+                                print("[audit-every]    write-all fused vs unfused, channel %d: %d entries off; worst at particle %d: %.6e vs %.6e" % (
+                                    c, nb, t * mt.L + l, float(Vv(mt.buf)[t, c, l]), float(Vv(ub)[t, c, l])), file=sys.stderr)
+                        # the bins around the worst node
+                        i = int(dm.abs().flatten().argmax()); b = i // S3
+                        bs, cc_ = mt.bin_start.cpu(), mt.cell_count.view(-1, 64).cpu()
+                        per = (a.side // 4) ** 3
+                        for bn in range(b * per, (b + 1) * per):
+                            print("[audit-every]    block %d bin %d: particles %d, cell counts max %d, cells %r" % (b, bn, int(bs[bn + 1] - bs[bn]), int(cc_[bn].max()), cc_[bn].tolist()), file=sys.stderr)
+                        mt._audited = True
+                        raise SystemExit(0)
                     mt.buf.copy_(fb); mt.grid.copy_(fg)
                     del fb, fg
                 if done < 5 or node_trace[-1][1] == 0 or getattr(mt, "_audited", False):

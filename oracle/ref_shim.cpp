@@ -211,6 +211,216 @@ static int ref_g2p_with(const model_t &model, float dx, float dt, const RefGrid 
   }
   return missed;
 }
+/* ---- P2C2GTransfer / G2C2PTransfer as whole functions (simulation/transfer/P2C2G.hpp:53-189, G2C2P.hpp:59-135) -----------------
+   Same treatment as P2G / G2P above: the per-(block, cell) functor bodies spelled over the reference's own vec, lower_trunc, zs::abs,
+   lame_parameters, compute_stress_*, the *Config structs and the 2-argument unpack_coord_in_grid.  Replaced: the partition and the grid
+   by RefGrid; IndexBuckets (bucketCoord = lower_trunc(pos / dx + 0), IndexBuckets.hpp:101-107; offsets / indices as the sequential
+   policy builds them: ascending particle ids per bucket) by a std::map from cell coordinate to id list; the Collapse{nblocks, side^3}
+   launch by the loop over (block, cell) in that order; atomic_add by +=. */
+struct RefBuckets {
+  std::map<std::array<int, 3>, std::vector<int>> cells;
+  const std::vector<int> *find(const vec<int, 3> &c) const {
+    auto it = cells.find({c[0], c[1], c[2]});
+    return it == cells.end() ? nullptr : &it->second;
+  }
+};
+static RefBuckets make_ref_buckets(float dx, size_t n, const float *posA) {
+  RefBuckets b;
+  const float dxinv = 1.0f / dx;
+  for (size_t i = 0; i < n; ++i) {
+    std::array<int, 3> c;
+    for (int d = 0; d < 3; ++d) c[d] = lower_trunc(posA[3 * i + d] * dxinv + 0.f, number_c<int>);
+    b.cells[c].push_back((int)i);
+  }
+  return b;
+}
+template <class model_t>
+static int ref_p2c2g_with(const model_t &model, float dx, float dt, const RefGrid &grids, int nblocks, const int *blockKeys, size_t n,
+                          const float *massA, const float *posA, const float *velA, const float *BA, const float *FA, float *logJpA) {
+  using value_type = float;
+  constexpr int dim = 3;
+  using TV = vec<value_type, dim>;
+  using TM = vec<value_type, dim * dim>;
+  using IV = vec<int, dim>;
+  const RefBuckets buckets = make_ref_buckets(dx, n, posA);
+  value_type const dx_inv = static_cast<float>(1.0) / dx;
+  int missed = 0;
+  for (int blockid = 0; blockid < nblocks; ++blockid)
+    for (int cellid = 0; cellid < grids.ncell; ++cellid) {
+      value_type m_c{(value_type)0};
+      TV mv_c{TV::zeros()};
+      TM QDinv_c{TM::zeros()};
+      TV QDinvXp_c{TV::zeros()};
+      /* cellid_to_coord, Structure.hpp:334-343 (power-of-two side): x = cellid >> 2b, y = (cellid >> b) & mask, z = cellid & mask */
+      IV coord{blockKeys[3 * blockid] * grids.side + (cellid >> (2 * grids.bits)),
+               blockKeys[3 * blockid + 1] * grids.side + ((cellid >> grids.bits) & (grids.side - 1)),
+               blockKeys[3 * blockid + 2] * grids.side + (cellid & (grids.side - 1))};
+      auto posc = (coord + (value_type)0.5) * dx;
+      auto checkInKernelRange = [&posc, dx](auto &&posp) -> bool {
+        for (int d = 0; d != dim; ++d)
+          if (zs::abs(posp[d] - posc[d]) > dx) return false;
+        return true;
+      };
+      coord = coord - 1;  /// move to base coord
+      for (int i0 = 0; i0 < 3; ++i0)
+        for (int i1 = 0; i1 < 3; ++i1)
+          for (int i2 = 0; i2 < 3; ++i2) { /* ndrange<dim>(3): the last index runs fastest */
+            const std::vector<int> *ids = buckets.find(coord + IV{i0, i1, i2});
+            if (!ids) continue;
+            for (int parid : *ids) {
+              TV posp{posA[3 * parid], posA[3 * parid + 1], posA[3 * parid + 2]};
+              if (!checkInKernelRange(posp)) continue;
+              TV Dinv{};
+              for (int d = 0; d != dim; ++d) {
+                Dinv[d] = posp[d] - lower_trunc(posp[d] * dx_inv + (value_type)0.5) * dx;
+                Dinv[d] = ((value_type)2 / (dx * dx - 2 * Dinv[d] * Dinv[d]));
+              }
+              TV vel{velA[3 * parid], velA[3 * parid + 1], velA[3 * parid + 2]};
+              auto mass = massA[parid];
+              TM C{};
+              for (int d = 0; d != dim * dim; ++d) C[d] = BA[9 * parid + d];
+              for (int d = 0; d != dim * dim; ++d) C[d] *= Dinv[d / dim];
+              TM contrib{};
+              if constexpr (is_same_v<model_t, EquationOfStateConfig>) {
+                float J = FA[9 * parid];
+                float vol = model.volume * J;
+                float pressure = model.bulk;
+                {
+                  float J2 = J * J;
+                  float J4 = J2 * J2;
+                  pressure = pressure * (1 / (J * J2 * J4) - 1);
+                }
+                contrib[0] = ((C[0] + C[0]) * model.viscosity - pressure) * vol;
+                contrib[1] = (C[1] + C[3]) * model.viscosity * vol;
+                contrib[2] = (C[2] + C[6]) * model.viscosity * vol;
+                contrib[3] = (C[3] + C[1]) * model.viscosity * vol;
+                contrib[4] = ((C[4] + C[4]) * model.viscosity - pressure) * vol;
+                contrib[5] = (C[5] + C[7]) * model.viscosity * vol;
+                contrib[6] = (C[6] + C[2]) * model.viscosity * vol;
+                contrib[7] = (C[7] + C[5]) * model.viscosity * vol;
+                contrib[8] = ((C[8] + C[8]) * model.viscosity - pressure) * vol;
+              } else {
+                const auto [mu, lambda] = lame_parameters(model.E, model.nu);
+                TM F{};
+                for (int d = 0; d < 9; ++d) F[d] = FA[9 * parid + d];
+                if constexpr (is_same_v<model_t, FixedCorotatedConfig>) {
+                  compute_stress_fixedcorotated(model.volume, mu, lambda, F, contrib);
+                } else if constexpr (is_same_v<model_t, VonMisesFixedCorotatedConfig>) {
+                  compute_stress_vonmisesfixedcorotated(model.volume, mu, lambda, model.yieldStress, F, contrib);
+                } else {
+                  float logJp = logJpA[parid];
+                  if constexpr (is_same_v<model_t, DruckerPragerConfig>) {
+                    compute_stress_sand(model.volume, mu, lambda, model.cohesion, model.beta, model.yieldSurface, model.volumeCorrection, logJp,
+                                        F, contrib);
+                  } else if constexpr (is_same_v<model_t, NACCConfig>) {
+                    compute_stress_nacc(model.volume, mu, lambda, model.bulk(), model.xi, model.beta, model.Msqr(), model.hardeningOn, logJp, F,
+                                        contrib);
+                  }
+                  logJpA[parid] = logJp;
+                }
+              }
+              for (int d = 0; d != dim * dim; ++d) contrib[d] *= Dinv[d / dim] * -dt;
+              contrib += C * mass;
+              auto xcxp = posc - posp;
+              value_type Wpc = 1.f;
+              auto diff = xcxp * dx_inv;
+              for (int d = 0; d != dim; ++d) Wpc *= ((value_type)1. - zs::abs(diff[d]));
+              m_c += mass * Wpc;
+              for (int d = 0; d != dim; ++d) {
+                mv_c[d] += mass * vel[d] * Wpc;
+                QDinvXp_c[d] += (contrib[d] * posp[0] + contrib[3 + d] * posp[1] + contrib[6 + d] * posp[2]) * Wpc;
+              }
+              for (int d = 0; d != dim * dim; ++d) QDinv_c[d] += contrib[d] * Wpc;
+            }
+          }
+      /// stage 2 (c -> i)
+      coord = coord + 1;  /// move to base coord
+      for (int i0 = 0; i0 < 2; ++i0)
+        for (int i1 = 0; i1 < 2; ++i1)
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const auto coordi = coord + IV{i0, i1, i2};
+            const auto posi = coordi * dx;
+            auto [blockCoord, local_index] = unpack_coord_in_grid(coordi, grids.side);
+            float *m = grids.chan(blockCoord, 0);
+            if (!m) { /* blockno < 0 */
+              ++missed;
+              continue;
+            }
+            constexpr value_type Wci = 1. / 8;
+            const auto cell = grids.cellid(local_index);
+            m[cell] += m_c * Wci;
+            for (int d = 0; d != dim; ++d)
+              grids.chan(blockCoord, 1 + d)[cell]
+                  += (mv_c[d] + ((QDinv_c[d] * posi[0] + QDinv_c[3 + d] * posi[1] + QDinv_c[6 + d] * posi[2]) - QDinvXp_c[d])) * Wci;
+          }
+    }
+  return missed;
+}
+/* G2C2PTransfer: v_p and B_p are accumulated (the caller zeroes them: PreG2C2PTransfer, G2C2P.hpp:215-218) */
+static int ref_g2c2p_run(float dx, const RefGrid &grids, int nblocks, const int *blockKeys, size_t n, const float *posA, float *velA, float *BA) {
+  using value_type = float;
+  constexpr int dim = 3;
+  using TV = vec<value_type, dim>;
+  using TM = vec<value_type, dim * dim>;
+  using IV = vec<int, dim>;
+  const RefBuckets buckets = make_ref_buckets(dx, n, posA);
+  value_type const dx_inv = (value_type)1 / dx;
+  int missed = 0;
+  for (int blockid = 0; blockid < nblocks; ++blockid)
+    for (int cellid = 0; cellid < grids.ncell; ++cellid) {
+      IV coord{blockKeys[3 * blockid] * grids.side + (cellid >> (2 * grids.bits)),
+               blockKeys[3 * blockid + 1] * grids.side + ((cellid >> grids.bits) & (grids.side - 1)),
+               blockKeys[3 * blockid + 2] * grids.side + (cellid & (grids.side - 1))};
+      TV v_c{TV::zeros()};
+      TM v_cross_x_c{TM::zeros()};
+      for (int i0 = 0; i0 < 2; ++i0)
+        for (int i1 = 0; i1 < 2; ++i1)
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const auto coordi = coord + IV{i0, i1, i2};
+            const auto posi = coordi * dx;
+            auto [blockCoord, local_index] = unpack_coord_in_grid(coordi, grids.side);
+            if (!grids.chan(blockCoord, 1)) {
+              ++missed;
+              continue;
+            }
+            value_type W = 1. / 8;
+            const auto cell = grids.cellid(local_index);
+            TV v_i{grids.chan(blockCoord, 1)[cell], grids.chan(blockCoord, 2)[cell], grids.chan(blockCoord, 3)[cell]};
+            v_c += v_i * W;
+            for (int d = 0; d < dim * dim; ++d) v_cross_x_c[d] += W * v_i(d % 3) * posi(d / 3);
+          }
+      auto posc = (coord + (value_type)0.5) * dx;
+      auto checkInKernelRange = [&posc, dx](auto &&posp) -> bool {
+        for (int d = 0; d != dim; ++d)
+          if (zs::abs(posp[d] - posc[d]) > dx) return false;
+        return true;
+      };
+      coord = coord - 1;
+      for (int i0 = 0; i0 < 3; ++i0)
+        for (int i1 = 0; i1 < 3; ++i1)
+          for (int i2 = 0; i2 < 3; ++i2) {
+            const std::vector<int> *ids = buckets.find(coord + IV{i0, i1, i2});
+            if (!ids) continue;
+            for (int parid : *ids) {
+              TV posp{posA[3 * parid], posA[3 * parid + 1], posA[3 * parid + 2]};
+              if (!checkInKernelRange(posp)) continue;
+              auto xcxp = posc - posp;
+              value_type W = 1.f;
+              auto diff = xcxp * dx_inv;
+              for (int d = 0; d != dim; ++d) {
+                const auto xabs = zs::abs(diff[d]);
+                if (xabs <= 1)
+                  W *= ((value_type)1. - xabs);
+                else
+                  W *= 0.f;
+              }
+              for (int d = 0; d != dim; ++d) velA[3 * parid + d] += v_c[d] * W;
+              for (int d = 0; d != dim * dim; ++d) BA[9 * parid + d] += W * (v_cross_x_c[d] - v_c(d % dim) * posp(d / dim));
+            }
+          }
+    }
+  return missed;
+}
 /* prm: {volume, E, nu, cohesion, beta, yieldSurface, volumeCorrection, yieldStress, xi, fa, hardeningOn, bulk, viscosity} */
 template <class Fn> static int ref_with_model(int model, const float *prm, Fn &&fn) {
   if (model == 0) {
@@ -242,6 +452,16 @@ int ref_mpm_p2g(int model, const float *prm, float dx, float dt, int side, int n
                 const float *mass, const float *pos, const float *vel, const float *C, const float *F, float *logJp) {
   RefGrid g = make_ref_grid(side, nblocks, blockKeys, grid);
   return ref_with_model(model, prm, [&](const auto &m) { return ref_p2g_with(m, dx, dt, g, n, mass, pos, vel, C, F, logJp); });
+}
+/* P2C2GTransfer over every cell of the partition; returns the number of (cell, node) pairs whose node block is not in blockKeys */
+int ref_mpm_p2c2g(int model, const float *prm, float dx, float dt, int side, int nblocks, const int *blockKeys, float *grid, size_t n,
+                  const float *mass, const float *pos, const float *vel, const float *B, const float *F, float *logJp) {
+  RefGrid g = make_ref_grid(side, nblocks, blockKeys, grid);
+  return ref_with_model(model, prm, [&](const auto &m) { return ref_p2c2g_with(m, dx, dt, g, nblocks, blockKeys, n, mass, pos, vel, B, F, logJp); });
+}
+int ref_mpm_g2c2p(float dx, int side, int nblocks, const int *blockKeys, const float *grid, size_t n, const float *pos, float *vel, float *B) {
+  RefGrid g = make_ref_grid(side, nblocks, blockKeys, const_cast<float *>(grid));
+  return ref_g2c2p_run(dx, g, nblocks, blockKeys, n, pos, vel, B);
 }
 int ref_mpm_g2p(int model, const float *prm, float dx, float dt, int side, int nblocks, const int *blockKeys, const float *grid, size_t n,
                 float *pos, float *vel, float *C, float *F) {

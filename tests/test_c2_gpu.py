@@ -312,3 +312,37 @@ def test_partition_buckets_with_unlisted_particles(pol, oracle):
 def zs_no_error():
     import zpc_amd
     return zpc_amd.lib().zs_rocm_last_error(-1) == 0
+
+
+@pytest.mark.parametrize("name,side", [("fixedcorotated", 4), ("fixedcorotated", 8), ("eos", 4), ("eos", 8)])
+def test_p2c2g_g2c2p_match_reference_golden(pol, name, side):
+    """zs_rocm_mpm_p2c2g / zs_rocm_mpm_g2c2p_step against tests/golden/c2.npz: P2C2GTransfer / G2C2PTransfer bodies spelled over the
+    reference's own headers (oracle/ref_shim.cpp, tools/gen_golden.py).  Grid channels to 2e-4 of their magnitude (summation order, a*b+c
+    contraction), v and B likewise; the partition is the fixture's, block for block.  (The fixture's von Mises case comes from the HOST
+    constitutive header and is compared with the oracle's host variant on the CPU; the GPU follows the CUDA header, which differs where the
+    material yields -- as for P2G, tests/test_mpm_gpu.py RHS_TOL.)"""
+    from util import golden_c2
+    from zpc_amd.mpm import MpmTransfer
+    g = golden_c2(name, side)
+    n = g["pos"].shape[0]
+    mt = MpmTransfer(pol, n, g["dx"], g["dt"], model=g["model"], side=side, volume=g["volume"], **g["kw"])
+    mt.upload(g["mass"], g["pos"], g["vel"], g["B"], g["F"][:, :mt.nF], None)
+    keys = torch.from_numpy(np.ascontiguousarray(g["keys"])).cuda()
+    mt.adopt_partition(keys.data_ptr(), g["keys"].shape[0])
+    mt.build_buckets()
+    mt.clear_grid()
+    mt.p2c2g(0)
+    pol.syncCtx()
+    got = mt.grid.cpu().numpy().reshape(g["keys"].shape[0], 7, side ** 3)
+    scale = np.abs(g["grid"]).max(axis=(0, 2))
+    err = np.abs(got[:, :4] - g["grid"]).max(axis=(0, 2)) / scale
+    assert (err <= 2e-4).all() and not got[:, 4:].any(), err
+    # G2C2P on the fixture's velocity grid
+    gv = np.zeros_like(got)
+    gv[:, 1:4] = g["gridv"]
+    mt.grid.copy_(torch.from_numpy(gv.reshape(-1)).cuda())
+    mt.g2c2p()
+    pol.syncCtx()
+    d = mt.download()
+    assert np.abs(d["v"] - g["vel1"]).max() <= 2e-4 * np.abs(g["vel1"]).max()
+    assert np.abs(d["C"] - g["B1"]).max() <= 2e-4 * np.abs(g["B1"]).max()

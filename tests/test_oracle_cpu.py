@@ -625,3 +625,38 @@ def test_hashtable_sequential_table_matches_reference_golden(oracle):
     oracle.orc_hashtable_query_many(t, ptr(q), C.c_size_t(q.shape[0]), ptr(qr))
     assert np.array_equal(qr, z["ht_query_ret"])
     oracle.orc_hashtable_destroy(t)
+
+
+@pytest.mark.parametrize("name,side", [("fixedcorotated", 4), ("fixedcorotated", 8), ("vonmises", 8), ("eos", 4), ("eos", 8)])
+def test_p2c2g_whole_function_matches_reference_golden(oracle, name, side):
+    """P2C2GTransfer as a WHOLE function (simulation/transfer/P2C2G.hpp:53-189): oracle/mpm.c against tests/golden/c2.npz, which
+    tools/gen_golden.py produces from the functor body spelled over the reference's own vec / lower_trunc / compute_stress_* /
+    unpack_coord_in_grid, cells in launch order, buckets in ascending particle id (oracle/ref_shim.cpp).  Same summation order on both
+    sides.  (The plastic models with logJp are not in the fixture: the reference functor re-runs their update per (cell, particle) pair.)"""
+    from util import OracleMpm, golden_c2
+    g = golden_c2(name, side)
+    om = OracleMpm(oracle, g["model"], g["dx"], g["dt"], side, g["volume"], host_variant=1, **g["kw"])
+    om.adopt_partition(g["keys"])
+    om.build_buckets(g["pos"])
+    om.p2c2g(0, g["mass"], g["pos"], g["vel"], g["B"], g["F"], None)
+    scale = np.abs(g["grid"]).max(axis=(0, 2))
+    err = np.abs(om.grid[:, :4] - g["grid"]).max(axis=(0, 2)) / scale
+    assert err[0] <= 1e-6 and (err[1:] <= (STRESS_TOL * 6 if name == "vonmises" else max(STRESS_TOL, 2e-6))).all(), err
+    assert not om.grid[:, 4:].any()
+
+
+@pytest.mark.parametrize("side", [4, 8])
+def test_g2c2p_whole_function_matches_reference_golden(oracle, side):
+    """G2C2PTransfer (simulation/transfer/G2C2P.hpp:59-135) on the fixture's velocity grid: v_p and B_p accumulated from zero"""
+    from util import OracleMpm, golden_c2
+    g = golden_c2("fixedcorotated", side)
+    om = OracleMpm(oracle, 0, g["dx"], g["dt"], side, g["volume"])
+    om.adopt_partition(g["keys"])
+    om.build_buckets(g["pos"])
+    om.grid[:, 1:4] = g["gridv"]
+    vel, Bm = np.zeros_like(g["vel"]), np.zeros_like(g["B"])
+    om.o.orc_mpm_g2c2p(__import__("ctypes").byref(om.p), om.table, om.buckets, om._ib[1], om._ib[2], g["pos"].ctypes.data_as(__import__("ctypes").c_void_p),
+                       vel.ctypes.data_as(__import__("ctypes").c_void_p), Bm.ctypes.data_as(__import__("ctypes").c_void_p),
+                       om.grid.ctypes.data_as(__import__("ctypes").c_void_p))
+    assert np.abs(vel - g["vel1"]).max() <= 1e-6 * np.abs(g["vel1"]).max()
+    assert np.abs(Bm - g["B1"]).max() <= 2e-6 * np.abs(g["B1"]).max()

@@ -141,3 +141,22 @@ def golden_p2g_g2p(name, side):
                 # The NACC case projects every particle onto the tip of the yield surface, where P F^T is the difference of
                 # nearly equal numbers (1e-4 of the elastic stress), so "relative to its own maximum" would measure noise.
                 rhs_scale=float(np.abs(z["grid_fixedcorotated_s8"][:, 4:]).max()))
+
+
+def golden_c2(name, side):
+    """One case of tests/golden/c2.npz (P2C2GTransfer / G2C2PTransfer bodies over the reference's own pieces, oracle/ref_shim.cpp via
+    tools/gen_golden.py): inputs, the reference's P2C2G grid (channels 0..3), a velocity grid and the reference's G2C2P v / B."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2.npz"))
+    prm = z["prm_" + name]
+    F = z["F"].copy()
+    if name == "eos":
+        F[:, 0] = z["J"]
+    kw = dict(E=float(prm[1]) if name != "eos" else 5e4, nu=float(prm[2]) if name != "eos" else 0.4)
+    if name == "vonmises":
+        kw.update(yield_stress=float(prm[7]))
+    if name == "eos":
+        kw.update(bulk=float(prm[11]), viscosity=float(prm[12]))
+    return dict(model=GOLDEN_MODELS[name], side=side, dx=float(z["dx"]), dt=float(z["dt"]), volume=float(prm[0]), kw=kw, keys=z["keys_s%d" % side],
+                mass=z["mass"], pos=z["pos"], vel=z["vel"], B=z["B"], F=F, grid=z["grid_%s_s%d" % (name, side)], gridv=z["gridv_s%d" % side],
+                vel1=z["g2c2p_vel_s%d" % side], B1=z["g2c2p_B_s%d" % side])

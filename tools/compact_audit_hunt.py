@@ -15,11 +15,11 @@ for k in range(reps):
     if lines or extra_lines or k == 0:
         for l in r.stderr.splitlines():
             if l.startswith("[audit-every]") or l.startswith("[rebin-check]"):
-                print("   ", l[:600], flush=True)
+                print("   ", l[:900], flush=True)
     print(k, "deviated" if lines else "clean", flush=True)
     for l in lines:
         print("   ", l[:2000], flush=True)
-    if lines:
+    if lines or extra_lines:
         hits += 1
         if hits >= 2:
             break

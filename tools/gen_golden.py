@@ -102,6 +102,59 @@ def gen_p2g_g2p():
     np.savez_compressed(os.path.join(OUT, "p2g_g2p.npz"), **out)
 
 
+def gen_c2():
+    """Whole-function fixtures for P2C2GTransfer / G2C2PTransfer (simulation/transfer/P2C2G.hpp:53-189, G2C2P.hpp:59-135): 4096 particles,
+    block sides 4 and 8, the reference's functor bodies driven by oracle/ref_shim.cpp over every (block, cell) of the partition in launch
+    order, buckets in ascending particle id.  P2C2G: the models whose constitutive update is a pure function of the particle (fixed
+    corotated, von Mises, the fluid) -- for the plastic models with logJp the reference functor re-runs the update once per (cell, particle)
+    pair and stores logJp each time, the restatement evaluates each particle once; they are pinned through P2G.  G2C2P: v and B
+    from a grid of velocities."""
+    g = np.random.default_rng(20260929)
+    dx, dt = np.float32(1.0 / 128), np.float32(1e-4)
+    ppc, ncs = 2, 8
+    k = ncs * ppc
+    idx = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)
+    h = dx / ppc
+    pos0 = (np.array([0.3021, 0.2871, 0.3127]) + (idx + 0.5) * h + (g.random(idx.shape) - 0.5) * h * 0.9).astype(np.float32)
+    n = pos0.shape[0]
+    vel0 = (0.6 * g.standard_normal((n, 3)) + np.array([0.3, -1.0, 0.2])).astype(np.float32)
+    B0 = (2.0 * g.standard_normal((n, 9)) * float(dx) ** 2 * 0.3).astype(np.float32)   # B = C / Dinv, Dinv in [2, 4] / dx^2
+    F0 = (np.eye(3).reshape(1, 9) + 0.04 * g.standard_normal((n, 9))).astype(np.float32)
+    J0 = (1 + 0.02 * g.standard_normal(n)).astype(np.float32)
+    vol = np.float32(float(dx) ** 3 / ppc ** 3)
+    mass = np.full(n, 1000.0 * vol, np.float32) * (1 + 0.1 * g.random(n)).astype(np.float32)
+    prm = {0: [vol, 5e4, 0.4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+           2: [vol, 5e4, 0.4, 0, 0, 0, 0, 500.0, 0, 0, 0, 0, 0],
+           4: [vol, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4e4, 0.01]}
+    ref.ref_mpm_p2c2g.restype = C.c_int
+    ref.ref_mpm_g2c2p.restype = C.c_int
+    out = dict(dx=dx, dt=dt, mass=mass, pos=pos0, vel=vel0, B=B0, F=F0, J=J0)
+    for side in (4, 8):
+        keys = partition_keys(pos0, dx, side)
+        nb, nc = keys.shape[0], side ** 3
+        out["keys_s%d" % side] = keys
+        for model in (0, 2, 4):
+            pr = np.array(prm[model], np.float32)
+            out["prm_%s" % MODEL_NAMES[model]] = pr
+            Fin = F0.copy()
+            if model == 4:
+                Fin[:, 0] = J0
+            lj = np.zeros(n, np.float32)
+            grid = np.zeros((nb, 7, nc), np.float32)
+            miss = ref.ref_mpm_p2c2g(model, P(pr), C.c_float(dx), C.c_float(dt), side, nb, P(keys), P(grid), C.c_size_t(n), P(mass), P(pos0),
+                                     P(vel0), P(B0), P(Fin), P(lj))
+            assert not grid[:, 4:].any() and abs(grid[:, 0].sum() - mass.sum()) < 1e-4 * mass.sum(), (miss, grid[:, 0].sum(), mass.sum())
+            out["grid_%s_s%d" % (MODEL_NAMES[model], side)] = grid[:, :4].copy()
+            print("c2 p2c2g %s side %d: %d blocks, %d (cell, node) pairs outside the partition, |m| %.3e" % (MODEL_NAMES[model], side, nb, miss, grid[:, 0].sum()))
+        gv = np.zeros((nb, 7, nc), np.float32)
+        gv[:, 1:4] = (0.5 * g.standard_normal((nb, 3, nc)) + np.array([0.3, -1.0, 0.2])[None, :, None]).astype(np.float32)
+        vel, Bm = np.zeros((n, 3), np.float32), np.zeros((n, 9), np.float32)
+        miss = ref.ref_mpm_g2c2p(C.c_float(dx), side, nb, P(keys), P(gv), C.c_size_t(n), P(pos0), P(vel), P(Bm))
+        out.update({"gridv_s%d" % side: gv[:, 1:4].copy(), "g2c2p_vel_s%d" % side: vel, "g2c2p_B_s%d" % side: Bm})
+        print("c2 g2c2p side %d: |v| max %.3f, |B| max %.3e, %d node lookups outside" % (side, np.abs(vel).max(), np.abs(Bm).max(), miss))
+    np.savez_compressed(os.path.join(OUT, "c2.npz"), **out)
+
+
 def gen_containers_seq():
     """Whole-function fixtures for bht<int, dim, int, B> (container/Bht.hpp:154-158, 612-698) and HashTable<int, 3, int>
     (container/HashTable.hpp:88-91, 383-400, 454-463, 496-500) under sequential insertion in input order: the tables byte for byte
@@ -312,6 +365,7 @@ def main():
     gen_p2g_g2p()
     gen_containers_seq()
     gen_grid_arena()
+    gen_c2()
     print("wrote", os.listdir(OUT))
 
 

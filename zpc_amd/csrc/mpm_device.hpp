@@ -2204,11 +2204,11 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
   // (Measured alternative: records parked in LDS and walked one by one with lane = node and plain read-add-write per wave-owned
   // channel -- no atomics, but a serial, latency-bound walk: 20 % slower on the 200-step free fall.)
   {
-    // The queued particles' state was stored by OTHER waves of this workgroup during the loop.  A barrier orders instructions, not the
-    // arrival of stores at L2 (outside threadgroup-split mode a workgroup-scope release does not wait for vmcnt), and the reads below
-    // are agent-scope loads served by L2: a read could overtake the store and pick up what the slot held before -- after an
-    // inputs-only re-bin the v / C / stress of some other particle.  Seen as a +-0.07 m/s dipole on two nodes at the foot of the 64 Mi
-    // column in 5-10 % of the runs (r03, profiles/r03_compact_outliers.md).  Every wave drains its stores, then a second barrier.
+    // The queued particles' state was stored by OTHER waves of this workgroup during the loop, with plain stores; the reads below are
+    // agent-scope loads.  A barrier orders instructions, not the arrival of stores at L2 (outside threadgroup-split mode a workgroup-scope
+    // release does not wait for vmcnt), so every wave drains its stores and the workgroup meets once more before the post-pass reads.
+    // (Added while hunting the rare deviation of the 24-step test; that turned out to be something else -- profiles/r03_compact_outliers.md --
+    // but the ordering is not guaranteed without it.)
     if (mqCount > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -2509,7 +2509,14 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
             lpn[d] = X - fl;
           }
           const int ncx = nc[0], ncy = nc[1], ncz = nc[2];
-          const bool moved = ncx != cx || ncy != cy || ncz != cz;
+          // The reference derives the weights from localPos - base_node(localPos) (InterpolationKernel.hpp:108) although localPos is already
+          // relative to the base node (simulation/Utils.hpp:59-60).  The second base_node is 0 -- except when X - floor(X - 0.5) ROUNDS up to
+          // 1.5, or X - 0.5 rounds up to an integer and leaves it just below 0.5 (only possible for |X| < 1, next to the coordinate origin):
+          // then it is +-1 and the weights are those of d0 -+ 1 on the unchanged corner.  make_arena restates that; the consumers take the
+          // staged lpn as d0 without the second floor, so such a particle goes the way of the in-bin movers (post-pass, make_arena) instead.
+          // profiles/r03_compact_outliers.md
+          const bool moved = ncx != cx || ncy != cy || ncz != cz ||
+                             !(lpn[0] >= 0.5f && lpn[0] < 1.5f && lpn[1] >= 0.5f && lpn[1] < 1.5f && lpn[2] >= 0.5f && lpn[2] < 1.5f);
           if (WRITE_ALL || moved) {
             pstore<LW, 3>(ps.vel, o, vel);
             pstore<LW, 9>(ps.C, o, C);
@@ -2609,11 +2616,11 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
   ZS_STAMP(2, tEntry);              // [2] entry -> past the barrier behind the bodies (8 waves)
   // in-bin movers: dense post-pass with LDS atomics (see g2p2g_binned_kernel)
   {
-    // The queued particles' state was stored by OTHER waves of this workgroup during the loop.  A barrier orders instructions, not the
-    // arrival of stores at L2 (outside threadgroup-split mode a workgroup-scope release does not wait for vmcnt), and the reads below
-    // are agent-scope loads served by L2: a read could overtake the store and pick up what the slot held before -- after an
-    // inputs-only re-bin the v / C / stress of some other particle.  Seen as a +-0.07 m/s dipole on two nodes at the foot of the 64 Mi
-    // column in 5-10 % of the runs (r03, profiles/r03_compact_outliers.md).  Every wave drains its stores, then a second barrier.
+    // The queued particles' state was stored by OTHER waves of this workgroup during the loop, with plain stores; the reads below are
+    // agent-scope loads.  A barrier orders instructions, not the arrival of stores at L2 (outside threadgroup-split mode a workgroup-scope
+    // release does not wait for vmcnt), so every wave drains its stores and the workgroup meets once more before the post-pass reads.
+    // (Added while hunting the rare deviation of the 24-step test; that turned out to be something else -- profiles/r03_compact_outliers.md --
+    // but the ordering is not guaranteed without it.)
     if (mqCount > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

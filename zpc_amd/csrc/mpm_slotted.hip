@@ -387,11 +387,21 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
 #else
           const bool moved = nc[0] != cx || nc[1] != cy || nc[2] != cz;
 #endif
+          // X - floor(X - 0.5) rounded up to 1.5, or X - 0.5 rounded up to an integer and left it below 0.5 (|X| < 1 only): the reference
+          // applies base_node to the local position once more and takes the weights of d0 -+ 1 on the unchanged corner
+          // (InterpolationKernel.hpp:108 on simulation/Utils.hpp:59-60; make_arena restates it).  The lane = cell consumers take the staged
+          // lpn as d0; such a particle is scattered through the consumers' list instead, which folds d0 as the reference does.
+#ifdef ZS_X_NOEDGE  // measurement / test-of-the-test build: the consumers take every staged lpn as d0
+          const bool edge = false;
+#else
+          const bool edge = !(lpn[0] >= 0.5f && lpn[0] < 1.5f && lpn[1] >= 0.5f && lpn[1] < 1.5f && lpn[2] >= 0.5f && lpn[2] < 1.5f);
+#endif
           if (W == 0) SLP_ADD(5, tIt);  // [5] producer: start of the iteration -> mover block (record wait, gather, advance)
           SLP_T0(tMv);
           bool outbox = false;   // it gets an outbox record (new cell in a neighbour bin: slot_rehome_kernel finds its slot; or fallback scatter)
           bool staged = !moved;  // {m, x', v', C', P F^T} staged for the consumers
           bool home = false;     // mover with a new slot inside this bin
+          bool byList = false;   // stayer scattered by the consumers' list (see `edge`)
           unsigned recFlag = 0u; // record word SLR_FLAG: the record's grid contributions are still to be added (after the loop)
           float *rec = nullptr;
           POff<LW> o = particle_offset<LW>(ps.pos.chns, i0);  // where the particle lives after the step
@@ -418,7 +428,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                 A.status[1] = 1;  // cell full: the particle is scattered but has no slot (sent != homed)
               }
 #ifndef ZS_X_NOINBIN
-              const unsigned q = atomicAdd(&arrCnt[par][dl], 1u);
+              const unsigned q = edge ? (unsigned)SL_ARRQ : atomicAdd(&arrCnt[par][dl], 1u);
               if (q < (unsigned)SL_ARRQ) {  // the lane of the new cell scatters it (arrival queue of the chunk)
                 viaX = false;
                 staged = true;
@@ -481,6 +491,14 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
               pstore<LW, 3>(ps.vel, o, vel);
               pstore<LW, 9>(ps.C, o, C);
             }
+            if (edge) {  // (see `edge`) a stayer, scattered by the list; a full list leaves it to its lane
+              const unsigned k = atomicAdd(&xCnt[par], 1u);
+              if (k < (unsigned)SL_XQ) {
+                byList = true;
+                xq[par][k] = (unsigned)((grp % SL_NG) * 64 + lane) | ((unsigned)(nc[0] + 1) << 10) | ((unsigned)(nc[1] + 1) << 13) |
+                             ((unsigned)(nc[2] + 1) << 16);
+              }
+            }
           }
           {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
             float lj = plj;
@@ -505,7 +523,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             // staged AFTER the constitutive update, as in g2p2g_rs_producer: with m, x', v', C' dead before it the compiler
             // reuses their registers for the SVD at once and waits for the particle stores just issued (s_waitcnt vmcnt(1)
             // in front of the SVD: 2 ms per 64 Mi particles)
-            valid = !moved;  // an in-bin mover is consumed by the lane of its NEW cell (arrival queue), not by the lane of its entry
+            valid = !moved && !byList;  // an in-bin mover is consumed by the lane of its NEW cell (arrival queue), not by the lane of its entry
             myStage[0 * 64 + lane] = pm;
 #pragma unroll
             for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
@@ -608,7 +626,11 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
           const unsigned p = arrQ[par][lane][ai++];
           spos = (int)(p >> 6) * (G2P2G_NF * 64) + (int)(p & 63u);
         }
+#ifdef ZS_X_HALFCONS  // measurement only: every second consumer iteration dropped (how much of the step is the consumers' VALU work?)
+        if (spos >= 0 && (r & 1)) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
+#else
         if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
+#endif
         if (CS == 0) SLP_PUT(15, 1);  // [15] consumer: loop iterations (rounds + extra rounds for arrivals)
       }
       if (CS == 0) SLP_ADD(13, tIt);  // [13] consumer: rounds loop (incl. in-bin arrivals)
@@ -654,7 +676,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
               const float d0 = st[(1 + q) * 64];
-              const float u = fmaf(ws[q], d0, wt[q]);
+              const float u = fmaf(ws[q], d0 - floorf(d0 - 0.5f), wt[q]);  // the reference's second base_node (see `edge` in the producer)
               Wt *= fmaf(wb[q], u * u, wa[q]);
               dot = fmaf(st[(iC + 3 * q) * 64], fmaf(-mp.dx, d0, xo[q]), dot);
               g[q] = (int)((e >> (10 + 3 * q)) & 7u) - 1 + geo.o[q] + sel[q];
