@@ -257,11 +257,28 @@ private:
   memsrc_e _mre = memsrc_e::device;
   zs_rocm_policy *_tmp = nullptr;  // set: stream-ordered temporary of that policy (get_temporary_memory_source)
 };
+// ZS_ENABLE_OFB_ACCESS_CHECK (container/Vector.hpp:471-480, TileVector.hpp:738-767; off by default like the reference's build option):
+// an out-of-range access prints the reference's message and returns a reference to the top of the address space, so that the access
+// faults instead of corrupting a neighbour
+#ifndef ZS_ENABLE_OFB_ACCESS_CHECK
+#define ZS_ENABLE_OFB_ACCESS_CHECK 0
+#endif
+namespace detail {
+template <class T> ZS_FUNCTION T &ofb_sentinel() { return *reinterpret_cast<T *>(~std::uintptr_t(0) - sizeof(T) + 1); }
+}  // namespace detail
 template <class T> struct VectorView {
   T *_p;
   std::size_t _n;
-  ZS_FUNCTION T &operator[](std::size_t i) const { return _p[i]; }
-  ZS_FUNCTION T &operator()(std::size_t i) const { return _p[i]; }
+  ZS_FUNCTION T &operator[](std::size_t i) const {
+#if ZS_ENABLE_OFB_ACCESS_CHECK
+    if (i >= _n) {
+      printf("vector [%s] ofb! accessing %lld out of [0, %lld)\n", "", (long long)i, (long long)_n);
+      return detail::ofb_sentinel<T>();
+    }
+#endif
+    return _p[i];
+  }
+  ZS_FUNCTION T &operator()(std::size_t i) const { return (*this)[i]; }
   ZS_FUNCTION std::size_t size() const { return _n; }
 };
 
@@ -388,8 +405,32 @@ template <class T, int L> struct TileVectorView {
   std::size_t _n;
   int _C;
   static constexpr int lane_width = L;
-  ZS_FUNCTION T &operator()(int chn, std::size_t i) const { return _p[(i / L * _C + chn) * L + i % L]; }
-  ZS_FUNCTION T &operator()(int chn, std::size_t tile, int lane) const { return _p[(tile * _C + chn) * L + lane]; }
+  ZS_FUNCTION T &operator()(int chn, std::size_t i) const {
+#if ZS_ENABLE_OFB_ACCESS_CHECK
+    if (chn < 0 || chn >= _C) {
+      printf("tilevector [%s] ofb! accessing chn [%d] out of [0, %d)\n", "", chn, _C);
+      return detail::ofb_sentinel<T>();
+    }
+    if (i >= _n) {
+      printf("tilevector [%s] ofb! global accessing ele [%lld] out of [0, %lld)\n", "", (long long)i, (long long)_n);
+      return detail::ofb_sentinel<T>();
+    }
+#endif
+    return _p[(i / L * _C + chn) * L + i % L];
+  }
+  ZS_FUNCTION T &operator()(int chn, std::size_t tile, int lane) const {
+#if ZS_ENABLE_OFB_ACCESS_CHECK
+    if (chn < 0 || chn >= _C) {
+      printf("tilevector [%s] ofb! accessing chn [%d] out of [0, %d)\n", "", chn, _C);
+      return detail::ofb_sentinel<T>();
+    }
+    if (lane < 0 || lane >= L) {
+      printf("tilevector [%s] ofb! in-tile accessing ele [%lld] out of [0, %lld)\n", "", (long long)lane, (long long)L);
+      return detail::ofb_sentinel<T>();
+    }
+#endif
+    return _p[(tile * _C + chn) * L + lane];
+  }
   template <int N> ZS_FUNCTION small_vec<T, N> pack(dim_t<N>, int chn, std::size_t i) const {  // TileVector.hpp:897-943
     small_vec<T, N> r;
     const T *b = &(*this)(chn, i);

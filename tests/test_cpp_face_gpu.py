@@ -40,3 +40,13 @@ def test_grid_arena_matches_the_references_own_grid_arena(tmp_path):
         build.build_cpp_face_test()
     r = subprocess.run([exe, "--grid-arena", str(blob)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b" 0 mismatches" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_views_with_the_ofb_access_check_option():
+    """ZS_ENABLE_OFB_ACCESS_CHECK=1: out-of-range view accesses yield the sentinel reference (tests/cpp/test_ofb.hip)"""
+    exe = os.path.join(ROOT, "zpc_amd", "lib", "test_ofb")
+    if not os.path.exists(exe):
+        from zpc_amd import build
+        build.build_ofb_test()
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"ofb access checks: 0 failures" in r.stdout, r.stdout.decode()[-2000:]

@@ -75,6 +75,20 @@ def build_cpp_face_test(verbose=True):
     return out
 
 
+def build_ofb_test(verbose=True):
+    """tests/cpp/test_ofb.hip: the C++ face compiled with ZS_ENABLE_OFB_ACCESS_CHECK=1 (the reference's bounds-check build option)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_ofb.hip")
+    out = os.path.join(LIBDIR, "test_ofb")
+    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), LIB]
+    if os.path.exists(src) and any(_newer(d, out) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-L", LIBDIR, "-lzsrocm",
+               "-Wl,-rpath,$ORIGIN", "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_oracle(verbose=True):
     """CPU restatement (always) and, where /root/reference exists, the in-place build of the reference's
     header-only numerics (oracle/_ref).  Building the checker is not using it."""
@@ -88,4 +102,5 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_hip(force=force))
     build_cpp_face_test()
+    build_ofb_test()
     build_oracle()

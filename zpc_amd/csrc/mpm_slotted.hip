@@ -636,23 +636,14 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
       if (CS == 0) SLP_ADD(13, tIt);  // [13] consumer: rounds loop (incl. in-bin arrivals)
       SLP_T0(tX);
       // movers of the chunk whose new cell is not a lane of this bin (or whose cell's arrival queue was full): this set's channels
-      // of their 27 node terms straight to the grid, lane = (stencil node, channel of the set)
+      // of their 27 node terms straight to the grid.  Two list entries per pass: lane = (entry parity, stencil node); the channels of
+      // the set are a compile-time loop, so only the node's weight formula (alpha + beta (s d0 + t)^2 per axis) is a per-lane constant
       const int nx = xCnt[par] < (unsigned)SL_XQ ? (int)xCnt[par] : SL_XQ;
       if (CS == 0 && lane == 0) xCnt[(it + 1) % 3] = 0u;
       {
-        // lane = (stencil node, channel of the set).  The channel's term is Wt (am m + ak) (b1 + bb B + c . xi) -- mass: m; momentum d:
-        // m (v_d + C[., d] . xi); force d: -dt Dinv (P F^T[., d] . xi) -- and a node's weight per axis alpha + beta (s d0 + t)^2: every
-        // choice is a per-lane constant, the loop body has no branch but the partition test
         constexpr int NC = SIDE * SIDE * SIDE;
-        const int node = lane & 31, chs = lane >> 5;
-        const bool act = node < 27 && chs < S::NA;
-        const int ch = S::CH0 + (chs < S::NA ? chs : 0);
+        const int node = lane & 31, half = lane >> 5;
         const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
-        const int dd = ch == 0 ? 0 : (ch < 4 ? ch - 1 : ch - 4);
-        const int iB = ch == 0 ? 0 : (ch < 4 ? 4 + dd : 0);  // staged field of B
-        const int iC = ch < 4 ? 7 + dd : 16 + dd;             // first entry of the column; the others 3 and 6 further
-        const float am = ch < 4 ? 1.f : 0.f, ak = ch < 4 ? 0.f : kscale;
-        const float b1 = ch == 0 ? 1.f : 0.f, bb = (ch > 0 && ch < 4) ? 1.f : 0.f, useC = ch == 0 ? 0.f : 1.f;
         float ws[3], wt[3], wa[3], wb[3], xo[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -665,33 +656,50 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
 #ifdef ZS_X_NOXQ
         if (false) {
 #else
-        if (act && nx > 0) {
+        if (node < 27 && nx > 0) {
 #endif
 #pragma unroll 1
-          for (int k = 0; k < nx; ++k) {
+          for (int k = half; k < nx; k += 2) {
             const unsigned e = xq[par][k];
             const float *st = stage + (size_t)((e & 1023u) >> 6) * (G2P2G_NF * 64) + (e & 63u);
-            float Wt = 1.f, dot = 0.f;
+            float Wt = 1.f, xi[3];
             int g[3], code = 0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
               const float d0 = st[(1 + q) * 64];
               const float u = fmaf(ws[q], d0 - floorf(d0 - 0.5f), wt[q]);  // the reference's second base_node (see `edge` in the producer)
               Wt *= fmaf(wb[q], u * u, wa[q]);
-              dot = fmaf(st[(iC + 3 * q) * 64], fmaf(-mp.dx, d0, xo[q]), dot);
+              xi[q] = fmaf(-mp.dx, d0, xo[q]);
               g[q] = (int)((e >> (10 + 3 * q)) & 7u) - 1 + geo.o[q] + sel[q];
               code = code * 3 + 1 + (g[q] >= SIDE ? 1 : 0) - (g[q] < 0 ? 1 : 0);
             }
-            const float val = Wt * fmaf(am, st[0], ak) * (fmaf(bb, st[iB * 64], b1) + useC * dot);
             const int bn = nbrBlk[code];
             if (bn >= 0) {
               const int cell = ((g[0] & (SIDE - 1)) * SIDE + (g[1] & (SIDE - 1))) * SIDE + (g[2] & (SIDE - 1));
+              float *gp = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + cell;
+              const float Wm = Wt * (S::STRESS ? kscale : st[0]);
+#pragma unroll
+              for (int q = 0; q < S::NA; ++q) {
+                float val;
+                if (S::MASS && q == 0) {
+                  val = Wm;  // mass
+                } else {
+                  // momentum d: m (v_d + C[., d] . xi); force d: -dt Dinv (P F^T[., d] . xi)
+                  const int d = S::D0 + q - (S::MASS ? 1 : 0);
+                  const int iC = (S::STRESS ? 16 : 7) + d;
+                  float t = st[iC * 64] * xi[0];
+                  t = fmaf(st[(iC + 3) * 64], xi[1], t);
+                  t = fmaf(st[(iC + 6) * 64], xi[2], t);
+                  if (!S::STRESS) t += st[(4 + d) * 64];  // v_d + (C . xi), the association of P2G.hpp:112
+                  val = Wm * t;
+                }
 #ifndef ZS_X_NOXATOMIC
-              if (val != 0.f) unsafeAtomicAdd(A.gridB + ((size_t)bn * 7 + ch) * NC + cell, val);
+                if (val != 0.f) unsafeAtomicAdd(gp + q * NC, val);
 #else
-              if (val == 1234.5f) A.status[7] = cell;
+                if (val == 1234.5f) A.status[7] = cell;
 #endif
-            } else if (ch == 0) {
+              }
+            } else if (S::MASS) {
               A.status[2] = 1;  // mass for a node whose block is not in the partition
             }
           }
