@@ -619,15 +619,20 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *
                                     const unsigned *cellCount, const int *nbr);
 /* ---- slotted particle storage: the motion-robust form of the fused step (zpc_amd/csrc/mpm_slotted.hip).  Storage = bins x K rounds x
  * 64 lanes in ONE TileVector<f32, 64> (slot (bin, r, lane) = element (bin K + r) 64 + lane), cellMask[bin][lane] = occupied rounds of the
- * cell; a particle is always stored under the cell of its base node, and the step keeps it so: the workgroup of a bin adds the grid
- * contributions of the particles that leave one of its cells through an LDS arena one node layer wider than the bin's stencil, and
- * stores them into a free round of their destination cell, claimed with an atomic on the cell's claim word (moverCount: int[nbins];
- * claim: unsigned[nbins * 64], zeroed by the caller ONCE, every step leaves it zero; moverRec: outboxCap 36-float scratch records per
- * bin) -- no second pass over the particles, no re-bin, no exact-path queues in the time loop.  status: int[ZS_ROCM_SLOT_STATUS_WORDS],
- * zeroed by the caller, latched: [0] an outbox was full, [1] a cell ran out of rounds, [2] mass or a mover for a block outside the
- * partition, [3] unused, [4] a particle was not stored under its cell, or moved more than one cell in a step; [8, 264) and [264, 520):
- * movers sent / re-homed (running sums spread over 256 words each: a single device-wide word would serialise one atomic per bin, 1.5 ms
- * per step of the 64 M-particle column); unequal totals = particles were lost ([1], [2] say why).
+ * cell; a particle is always stored under the cell of its base node, and the step keeps it so.  A particle that changes cell is finished
+ * by the workgroup that moves it: inside the bin it draws a ticket for the lowest free round of its new cell and is scattered by that
+ * cell's lane; across bins its grid terms are added by global float atomics and a record goes to the bin's outbox (outboxCap records
+ * per bin), from where a second, small kernel copies it into a free round of the destination cell (one ticket per record on claim[]),
+ * and a third folds tickets and departures into cellMask.  No re-bin, no exact-path queues in the time loop.  Buffers: moverCount (int),
+ * claim (unsigned; zeroed by the caller ONCE, every step leaves it zero), moverRec (float) -- their sizes in bytes come from
+ * zs_rocm_mpm_slot_outbox_bytes(nbins, outboxCap, which = 0 / 1 / 2).  status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller,
+ * latched: [0] an outbox was full, [1] a
+ * cell ran out of rounds, [2] mass or a mover for a block outside the partition, [3] unused, [4] a particle was not stored under its cell,
+ * or moved more than one cell in a step; [8, 264) and [264, 520): movers sent / re-homed (running sums spread over 256 words each: a
+ * single device-wide word would serialise one atomic per bin); unequal totals = particles were dropped ([1], [2] say why).  What a
+ * reported overflow costs: a mover that finds its outbox full, its new cell (inside the bin) full, or has moved too far KEEPS its old slot
+ * with its new state (nothing is lost; it is skipped -- [4] -- until the caller re-slots the storage); a record whose destination cell in
+ * ANOTHER bin has no free round, or whose block is not in the partition, is dropped.
  * The per-particle arithmetic is that of zs_rocm_mpm_g2p2g (G2P.hpp:44-83 + P2G.hpp:51-125). */
 #define ZS_ROCM_SLOT_STATUS_WORDS (8 + 2 * 256)
 ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int outboxCap, int which); /* 0 moverCount, 1 claim words, 2 moverRec */

@@ -848,3 +848,39 @@ def test_local_position_that_rounds_up_to_one_and_a_half_follows_the_reference(p
     d = _by_mass(mt.download())
     o = _id_order(mass, pos)
     assert np.array_equal(d["x"], pos[o]) and np.abs(d["v"]).max() == 0
+
+
+def test_slotted_capacity_overflow_is_reported_and_loses_no_particle(pol, oracle):
+    """A tiny outbox (and few spare rounds per cell): the step reports it through the status words, and a mover that found no new home
+    stays in its old slot with its new state -- after the failing step the storage still holds every particle (same set of masses),
+    so the caller can re-slot with a larger K / outboxCap instead of having lost mass."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt, side = 1.0 / 64, 1e-3, 8
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=401, vel_scale=0.3)
+    n = pos.shape[0]
+    mass = (mass * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)
+    vel += np.array([4.0, -5.0, 3.0], np.float32)
+    vol = dx ** 3 / 8
+    lj = np.zeros(n, np.float32)
+    mt = MpmTransfer(pol, n, dx, dt, model=1, side=side, volume=vol, cache_stress=True)
+    mt.upload(mass, pos, vel, Cm, F, lj)
+    mt.build_partition(n, margin=1)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.slot(K=32, outbox_cap=2)     # at 0.3 cell per step a bin sends dozens of movers to its neighbours: two records fit
+    reported = False
+    for step in range(3):
+        mt.g2p2g(write_all=True)
+        pol.syncCtx()
+        try:
+            mt.check_slots()
+        except RuntimeError as e:
+            reported = True
+            assert "full" in str(e) or "not stored under its cell" in str(e), str(e)
+        mt.grid_update((0.0, -9.8, 0.0))
+    assert reported
+    d = mt.download()
+    assert d["m"].shape[0] == n and np.array_equal(np.sort(d["m"]), np.sort(mass))

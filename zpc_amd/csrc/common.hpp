@@ -115,6 +115,8 @@ struct Launch {
   DeviceContext::Arena &control();
   // reserves generation + ticket range of one scan on this stream (under the context lock); *wrapped: the generation counter started over
   char *scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase, bool &wrapped);
+  // after a failed launch: control block zeroed (stream-ordered), generation and ticket shadow start over
+  void scan_control_reset();
 };
 
 // ------------------------------------------------------------------------------------ iterator ports

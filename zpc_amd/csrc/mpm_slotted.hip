@@ -309,13 +309,16 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
   bool has0 = false, has1 = false;
   size_t i0 = 0, i1 = 0;
   unsigned code0 = 0, code1 = 0;
+  // The record of a chunk is requested one chunk ahead and handed over (nxt -> cur) at the TOP of the iteration that uses it: a `cur` that
+  // is loaded directly on the entry path makes the compiler place its in-order vmcnt waits at the first uses inside the loop, where they
+  // also drain the prefetch issued a few hundred instructions earlier (seen in the ISA: s_waitcnt vmcnt(7..0) in front of the F update)
   if (nchunks > 0) {
     const int j = 64 * W + lane;
-    has0 = j < total;
-    if (has0) {
-      code0 = tab[j];
-      i0 = (rowBase + (size_t)(code0 >> 6)) * 64 + (size_t)(code0 & 63u);
-      cur.load(ps, i0);
+    has1 = j < total;
+    if (has1) {
+      code1 = tab[j];
+      i1 = (rowBase + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
+      nxt.load(ps, i1);
     }
   }
   {
@@ -337,12 +340,19 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0;
 #endif
+#ifdef ZS_X_PRIO
+  __builtin_amdgcn_s_setprio(ZS_X_PRIO);
+#endif
   for (int it = 0; it <= nchunks; ++it) {
     SLP_T0(tIt);
     if (it < nchunks) {
       const int grp = 4 * it + W;
       const int par = it % 3;
       float *myStage = stage + (size_t)(grp % SL_NG) * (G2P2G_NF * 64);
+      cur = nxt;
+      has0 = has1;
+      i0 = i1;
+      code0 = code1;
       has1 = false;
       if (it + 1 < nchunks) {
         const int j1 = 64 * (grp + 4) + lane;
@@ -402,6 +412,8 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
           bool staged = !moved;  // {m, x', v', C', P F^T} staged for the consumers
           bool home = false;     // mover with a new slot inside this bin
           bool byList = false;   // stayer scattered by the consumers' list (see `edge`)
+          bool keep = false;     // mover that found no new home (cell full, outbox full, moved too far): it stays in its OLD slot with its new
+                                 // state, occupancy bit set -- reported (status [0] / [1] / [4]); re-slotting the storage recovers it
           unsigned recFlag = 0u; // record word SLR_FLAG: the record's grid contributions are still to be added (after the loop)
           float *rec = nullptr;
           POff<LW> o = particle_offset<LW>(ps.pos.chns, i0);  // where the particle lives after the step
@@ -417,15 +429,17 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             unsigned dcell = 0xffffffffu;  // destination cell of a record whose home slot_rehome_kernel has to find
             bool viaX = true;              // its grid contributions: consumers' global-atomic list (else: arrival queue of its new cell)
             if (far) {
-              A.status[4] = 1;  // moved more than one cell in one step (CFL violated): not representable (scattered nowhere, lost)
+              A.status[4] = 1;  // moved more than one cell in one step (CFL violated): not representable (scattered nowhere)
               viaX = false;
+              keep = true;
             } else if (code == 13) {  // new cell inside this bin: a ticket of its LDS counter = a free round, from the bottom
               const int rr = nth_low_bit(~mask0[dl] & kmask, atomicAdd(&arrLocal[dl], 1u));
               if (rr >= 0) {
                 home = true;
                 o = particle_offset<LW>(ps.pos.chns, (rowBase + (size_t)rr) * 64 + (size_t)dl);
               } else {
-                A.status[1] = 1;  // cell full: the particle is scattered but has no slot (sent != homed)
+                A.status[1] = 1;  // cell full: the particle is scattered but has no new slot
+                keep = true;
               }
 #ifndef ZS_X_NOINBIN
               const unsigned q = edge ? (unsigned)SL_ARRQ : atomicAdd(&arrCnt[par][dl], 1u);
@@ -470,20 +484,23 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                 reinterpret_cast<unsigned *>(rec)[SLR_DCELL] = dcell;
                 reinterpret_cast<unsigned *>(rec)[SLR_FLAG] = recFlag;
               } else {
-                A.status[0] = 1;  // outbox full: the particle is lost -- reported, the caller must react
+                A.status[0] = 1;  // outbox full -- reported, the caller must react (raise outboxCap, re-slot)
+                keep = !home;     // (a mover that already has its new slot only loses the fallback scatter of its grid terms)
               }
             }
-            if (home) {
+            if (home || keep) {
               pstore_state<LW, FLUID>(ps.F, o, F);
               pstore<LW, 3>(ps.pos, o, pos);
               if (WRITE_ALL) {
                 pstore<LW, 3>(ps.vel, o, vel);
                 pstore<LW, 9>(ps.C, o, C);
               }
-              atomicAdd(homed, 1);
+              if (home) atomicAdd(homed, 1);
             }
-            atomicOr(&clr[cell], 1u << r);  // its slot becomes a hole
-            atomicAdd(sent, 1);
+            if (!keep) {
+              atomicOr(&clr[cell], 1u << r);  // its slot becomes a hole
+              atomicAdd(sent, 1);
+            }
           } else {
             pstore_state<LW, FLUID>(ps.F, o, F);
             pstore<LW, 3>(ps.pos, o, pos);
@@ -513,7 +530,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                 }
               }
             }
-            if (!moved || home) {
+            if (!moved || home || keep) {
               if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
               if (WRITE_ALL) pstore<LW, 9>(ps.stress, o, PF);
               if (moved) pstore1<LW>(ps.mass, o, pm);
@@ -540,10 +557,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
         const unsigned long long vm = __ballot(valid);
         if (lane == 0) smask[grp % SL_NG] = vm;
       }
-      cur = nxt;
-      has0 = has1;
-      i0 = i1;
-      code0 = code1;
     }
     if (it < nchunks) SLP_ACC(tWork, tIt);
     SLP_T0(tB);

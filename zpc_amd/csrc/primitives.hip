@@ -328,6 +328,14 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
     if (wrapped) ZSR_CHECK(hipMemsetAsync(ctl, 0, kCtlTicket, L.stream));  // generation wrap: start over from clean descriptors
     hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
                        (void *)(ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(ctl + kCtlTicket), gen, base);
+    // The host's shadow of the ticket counter was advanced for this launch.  A launch that never ran leaves the device counter behind
+    // it, and every later scan on the stream would derive wrong tile numbers: report, and bring both back to a clean control block.
+    // (One stream must not be driven by two host threads at once -- reservation and launch are not one atomic step -- nor be captured
+    // into a graph: the generation and ticket base are baked into the kernel arguments.)
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+      report_error(e, "scan_kernel launch", __FILE__, __LINE__);
+      L.scan_control_reset();
+    }
     return;
   }
   char *mem = (char *)L.temp(dbytes + 256);

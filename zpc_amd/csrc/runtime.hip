@@ -116,6 +116,15 @@ char *Launch::scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase,
   return a.ctl;
 }
 
+void Launch::scan_control_reset() {
+  DeviceContext::Arena &a = control();
+  DeviceContext &c = context(dev);
+  std::lock_guard<std::mutex> lk(c.mtx);
+  if (a.ctl) ZSR_CHECK(hipMemsetAsync(a.ctl, 0, kCtlBytes, stream));
+  a.scanGen = 0;
+  a.ticketShadow = 0;
+}
+
 static void *arena_take(int dev, hipStream_t stream, std::vector<size_t> &tempUsed, size_t bytes) {
   DeviceContext &c = context(dev);
   bytes = (bytes + 255) & ~(size_t)255;
