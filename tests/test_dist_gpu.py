@@ -14,7 +14,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the compact storage of round 1 (re-bin controller, overlapped exchange); the slotted default has its own test below
-ARGS = ["--cells", "24,48,24", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--compact", "--drift", "0,0,0"]
+# (--lift 8 everywhere: two runs are compared, and on y = 0 the reference arena's rounding case -- profiles/r03_compact_outliers.md -- can
+# hit one run and not the other)
+ARGS = ["--cells", "24,48,24", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--compact", "--drift", "0,0,0"]
 
 
 def _run(n, ARGS=ARGS):
@@ -68,7 +70,7 @@ def test_particle_migration_between_ranks(n, extra):
     """The column drifts upwards at 0.35 cell per step; every 3 steps particles are handed to the rank that now owns their
     cell (owner classification, radix partition by destination, all_to_all of AoS rows, AoSoA rebuild), partitions, halo
     lists and bins are rebuilt.  After 9 steps the N-rank state equals the single-rank state, which only re-partitions."""
-    args = ["--cells", "24,48,24", "--steps", "9", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--compact", "--drift", "0,7,0",
+    args = ["--cells", "24,48,24", "--steps", "9", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--compact", "--drift", "0,7,0",
             "--migrate-every", "3"] + extra
     ref = _run(1, args)
     out = _run(n, args)
@@ -88,7 +90,7 @@ def test_overlap_drift_guard_refuses_stale_bins():
     """Without re-binning, particles flying 3 cells per step leave the margin that keeps interior blocks away from the shared
     blocks: the overlapped step must refuse the run (device drift flag of zs_rocm_mpm_g2p2g_range) instead of silently
     dropping ghost contributions.  (A run like this needs --migrate-every anyway: the particles also leave the partition.)"""
-    args = ["--cells", "16,192,16", "--side", "4", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--compact", "--drift", "0,60,0"]
+    args = ["--cells", "16,192,16", "--side", "4", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--compact", "--drift", "0,60,0"]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -116,7 +118,7 @@ def test_long_run_with_rebins_is_rank_independent():
     """40 steps of a drifting tall column (0.05 cell per step, 2 cells in total -- inside the partition's margin, so no
     re-partition is needed: particles keep changing cells, the re-bin controller of bench.py fires at rank-dependent moments) on 1
     and on 2 ranks with the overlapped exchange: same final particle state."""
-    args = ["--cells", "16,192,16", "--side", "4", "--steps", "40", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--compact", "--drift", "0,1,0",
+    args = ["--cells", "16,192,16", "--side", "4", "--steps", "40", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--compact", "--drift", "0,1,0",
             "--rebin-check", "2"]
     ref = _run(1, args)
     out = _run(2, args)
@@ -138,7 +140,7 @@ def test_slotted_default_n_ranks_reproduce_single_rank(n, extra):
     """the bench's default storage (slotted: the step keeps its own order, movers travel through outboxes) on N ranks sharing one GPU:
     the column falls at 0.05 cell per step (default) or drifts obliquely at up to 0.2 cell per step across the rank boundaries, no
     re-bin and no re-partition anywhere; after 12 steps the N-rank particle state equals the single-rank one."""
-    args = ["--cells", "24,48,24", "--steps", "12", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"] + extra
+    args = ["--cells", "24,48,24", "--steps", "12", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--no-at-rest"] + extra
     ref = _run(1, args)
     out = _run(n, args)
     assert out["n_gpus"] == n and out["config"]["particles"] == ref["config"]["particles"]
@@ -180,7 +182,7 @@ def test_rccl_backend_on_all_visible_gpus_reproduces_single_rank(extra):
     if n < 2:
         pytest.skip("needs >= 2 visible GPUs (found %d)" % n)
     n = 8 if n >= 8 else (4 if n >= 4 else 2)
-    args = ["--cells", "24,48,24", "--steps", "6", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"] + extra
+    args = ["--cells", "24,48,24", "--steps", "6", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--no-at-rest"] + extra
     ref = _run(1, args)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=900)

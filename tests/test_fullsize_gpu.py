@@ -190,7 +190,7 @@ def test_config5_lbvh_10m_boxes(pol):
 def test_config3_jello_8m_fused_equals_unfused():
     """BASELINE config 3 (8 M-particle FixedCorotated cube on the 256^3 grid): three steps, slotted fused == compact fused == unfused"""
     base = ["--cells", "100,100,100", "--model", "jello", "--grid", "256", "--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--checksum",
-            "--no-at-rest", "--drift", "0,-0.5,0"]
+            "--no-at-rest", "--drift", "0,-0.5,0", "--lift", "8"]  # (lift: see the 24-step test)
     a = _bench(base)
     b = _bench(base + ["--compact"])
     # (with --checksum the fused variants run one more step that materialises v, C and the stress of every particle)
@@ -204,7 +204,7 @@ def test_config4_sand_64m_fused_equals_unfused():
     """BASELINE config 4 at N = 1 (64 Mi-particle DruckerPrager column, dx = 1/512) falling at 0.05 cell per step: after three steps the
     slotted fused step, the compact fused step and the unfused P2G / G2P kernels hold the same particle state (channel sums and sums of
     squares); the slotted run delivered every mover it sent and lost no particle"""
-    base = ["--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"]
+    base = ["--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest", "--lift", "8"]  # (lift: see the 24-step test)
     a = _bench(base)
     b = _bench(base + ["--compact"])
     c = _bench([x if x != "3" else "4" for x in base] + ["--compact", "--unfused"])
@@ -221,16 +221,17 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     """24 steps of the falling 64 Mi-particle column (1.3 cells of travel: a third of the particles change cell, every bin's rounds
     have become uneven): the slotted step -- packed producers, movers through the outboxes, no re-bin -- against the compact storage
     with the re-bin controller; same particle state, every mover delivered, nobody lost."""
-    base = ["--steps", "24", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"]
+    # (--lift 8: the column stands one block above y = 0, where the reference's arena has no local position that rounds to 1.5 -- on y = 0
+    # one foot particle is weighted a cell off in ~3 % of the runs of ANY path, profiles/r03_compact_outliers.md; two runs then differ)
+    base = ["--steps", "24", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest", "--lift", "8"]
     a = _bench(base + ["--slot-stats"])
     b = _bench(base + ["--compact", "--rebin-check", "2"])
     n = 67_108_864
     assert a["config"]["particles"] == n and a["hip_error"] == 0 and b["hip_error"] == 0
     assert a["config"]["rebins"] == 0 and b["config"]["rebins"] > 0
     assert a["slot_stats"]["mean_rounds"] > a["slot_stats"]["mean_particles_per_bin_div64"] + 1.0  # the regime the packing is for
-    # the trimmed sums (bench.py: particles with a velocity-gradient entry beyond 8 rms are left out -- free-surface particles next to grid
-    # nodes whose mass is a far weight tail, where v = mv / m depends on the order of the float atomics; measured on the compact path: the
-    # same 76 particles at the foot of the column in 5 % of the runs, profiles/r03_compact_outliers.md) must agree, and few may be trimmed
+    # the trimmed sums (bench.py: particles with a velocity-gradient entry beyond 8 rms are left out: what a hit of the arena's rounding
+    # case leaves behind, and the two edge particles of the column that carry such entries in every run) must agree, and few may be trimmed
     ta, tb = a["checksum_trimmed"], b["checksum_trimmed"]
     assert ta["trimmed_particles"] <= 512 and tb["trimmed_particles"] <= 512, (ta["trimmed_particles"], tb["trimmed_particles"])
     _same_state(ta["sums"], tb["sums"], n, 1e-4, 3e-4)
