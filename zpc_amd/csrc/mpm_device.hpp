@@ -1875,12 +1875,26 @@ __device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
+    // the slab's 27 node values first, then the arithmetic: one LDS latency per slab instead of one per pair of reads
+    float nv[3][3][3];
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
       const float *g = a0 + AL::at(a, bb, 0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float v0 = g[j * AL::CH], v1 = g[j * AL::CH + 1], v2 = g[j * AL::CH + 2];
+        nv[bb][j][0] = g[j * AL::CH];
+        nv[bb][j][1] = g[j * AL::CH + 1];
+        nv[bb][j][2] = g[j * AL::CH + 2];
+      }
+    }
+#ifndef ZS_GATHER_NO_FENCE
+    asm volatile("" ::: "memory");  // (keeps the compiler from sinking the reads back between the fmas)
+#endif
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v0 = nv[bb][j][0], v1 = nv[bb][j][1], v2 = nv[bb][j][2];
         const float s0 = fmaf(ar.w[2][2], v2, fmaf(ar.w[2][1], v1, ar.w[2][0] * v0));
         const float s1 = fmaf(xz[2], v2, fmaf(xz[1], v1, xz[0] * v0));
         t0[j] = fmaf(ar.w[1][bb], s0, t0[j]);

@@ -745,7 +745,10 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   if (CS == 0) SLP_ADD(9, tFl);
 }
 
-template <int SIDE, int SMODEL, bool WRITE_ALL>
+#ifdef ZS_SLOT_WITH_NS  // measurement builds only: node-split consumers + list wave (see the header for what was measured)
+#include "../../tools/measure/slot_consumer_ns.hpp"
+#endif
+template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -805,10 +808,26 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
-  else if (w == 4) g2p2g_slot_consumer<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
-  else if (w == 5) g2p2g_slot_consumer<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
-  else if (w == 6) g2p2g_slot_consumer<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
-  else g2p2g_slot_consumer<SIDE, 3>(mp, geo, mask, total, lane, nchunks, sh, A);
+#ifdef ZS_SLOT_WITH_NS
+  else if constexpr (NS) {
+    if (w == 4) g2p2g_slot_consumer_ns<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 5) g2p2g_slot_consumer_ns<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 6) g2p2g_slot_consumer_ns<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else g2p2g_slot_lister<SIDE>(mp, geo, lane, nchunks, sh, A);
+  }
+#endif
+  else {
+    if (w == 4) g2p2g_slot_consumer<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 5) g2p2g_slot_consumer<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 6) g2p2g_slot_consumer<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else g2p2g_slot_consumer<SIDE, 3>(mp, geo, mask, total, lane, nchunks, sh, A);
+  }
+  if constexpr (NS) {
+    if (w < 4) {
+#pragma unroll 1
+      for (int s3 = 0; s3 < 3; ++s3) __syncthreads();  // the consumers' three flush stages
+    }
+  }
   SLP_T0(tTail);
   __syncthreads();  // all channel sets are in the arena
   if (tid < 64) {  // this step's departures and in-bin arrivals of the bin's cells, for slot_rehome_kernel / slot_commit_kernel
@@ -1039,9 +1058,20 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
   const unsigned nbinsAll = (unsigned)(nblocks * bpb);
   const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
   const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap};
+#ifdef ZS_SLOT_WITH_NS
+#define ZS_SLOT_NS_AVAILABLE 1
+#else
+#define ZS_SLOT_NS_AVAILABLE 0
+#endif
+  // measurement builds (-DZS_SLOT_WITH_NS): ZS_ROCM_SLOT_CONSUMERS=nodes selects the node-split consumers + list wave
+  static const bool nodeSplit = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'n'; }();
 #define CALL_SLOT3(SS, M, WA)                                                                                                          \
   do {                                                                                                                                  \
-    if (nbins) hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                   \
+    if (nbins) {                                                                                                                       \
+      if (ZS_SLOT_NS_AVAILABLE && nodeSplit)                                                                                            \
+        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, ZS_SLOT_NS_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
+      else hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                 \
+    }                                                                                                                                  \
     if (finish)                                                                                                                         \
       hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 4)),         \
                          dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
