@@ -745,10 +745,13 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   if (CS == 0) SLP_ADD(9, tFl);
 }
 
+#ifdef ZS_SLOT_WITH_FLAT  // measurement builds only: every wave produces, then consumes (9 % slower, see the header)
+#include "../../tools/measure/mpm_slotted_flat.hpp"
+#endif
 #ifdef ZS_SLOT_WITH_NS  // measurement builds only: node-split consumers + list wave (see the header for what was measured)
 #include "../../tools/measure/slot_consumer_ns.hpp"
 #endif
-template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS>
+template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS, bool FLAT = false>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -804,6 +807,18 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   }
   __syncthreads();  // the table is complete
   if (w == 0) SLP_ADD(1, tStart);
+#ifdef ZS_SLOT_WITH_FLAT
+  if constexpr (FLAT) {
+    if (w == 0) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 1) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 2) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 3) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 4) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 4>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 5) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 5>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else if (w == 6) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 6>(mp, ps, geo, bin, mask, total, lane, sh, A);
+    else g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 7>(mp, ps, geo, bin, mask, total, lane, sh, A);
+  } else
+#endif
   if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
@@ -1064,12 +1079,21 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
 #define ZS_SLOT_NS_AVAILABLE 0
 #endif
   // measurement builds (-DZS_SLOT_WITH_NS): ZS_ROCM_SLOT_CONSUMERS=nodes selects the node-split consumers + list wave
+#ifdef ZS_SLOT_WITH_FLAT
+#define ZS_SLOT_FLAT_AVAILABLE 1
+#else
+#define ZS_SLOT_FLAT_AVAILABLE 0
+#endif
+  // measurement builds (-DZS_SLOT_WITH_FLAT): ZS_ROCM_SLOT_SCHEDULE=flat -- every wave produces, then consumes (tools/measure/mpm_slotted_flat.hpp)
+  static const bool flat = [] { const char *e = getenv("ZS_ROCM_SLOT_SCHEDULE"); return e && e[0] == 'f'; }();
   static const bool nodeSplit = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'n'; }();
 #define CALL_SLOT3(SS, M, WA)                                                                                                          \
   do {                                                                                                                                  \
     if (nbins) {                                                                                                                       \
       if (ZS_SLOT_NS_AVAILABLE && nodeSplit)                                                                                            \
         hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, ZS_SLOT_NS_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
+      else if (ZS_SLOT_FLAT_AVAILABLE && flat)                                                                                          \
+        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false, ZS_SLOT_FLAT_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
       else hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                 \
     }                                                                                                                                  \
     if (finish)                                                                                                                         \
