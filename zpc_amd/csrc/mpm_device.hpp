@@ -2452,9 +2452,10 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
   RecG<LW, DP, FLUID> cur, nxt;
   // head of the bin: the first records are requested BEFORE the velocity arena is filled -- both need only what the bin number
   // gives (binStart / cellCount / block key / nbr row arrive together), so a bin starts after two memory round trips, not four
+  // (requested into `nxt` and handed over at the top of the iteration that uses it: see g2p2g_slot_producer)
   if (nchunks > 0) {
-    next_chunk(i0, has0);
-    if (has0) cur.load(ps, (size_t)i0);
+    next_chunk(i1, has1);
+    if (has1) nxt.load(ps, (size_t)i1);
   }
   {
     constexpr int NC = SIDE * SIDE * SIDE;
@@ -2482,6 +2483,9 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
     if (it < nchunks) {
       const int par = it & 1;
       float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
+      cur = nxt;
+      has0 = has1;
+      i0 = i1;
       has1 = false;
       if (it + 1 < nchunks) {
         next_chunk(i1, has1);
@@ -2567,9 +2571,6 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
         const unsigned long long vm = __ballot(valid);
         if (lane == 0) smask[par * 4 + W] = vm;
       }
-      cur = nxt;
-      has0 = has1;
-      i0 = i1;
     }
 #ifdef ZS_PROBE
     const unsigned long long tb = __builtin_readcyclecounter();
