@@ -748,10 +748,13 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
 #ifdef ZS_SLOT_WITH_FLAT  // measurement builds only: every wave produces, then consumes (9 % slower, see the header)
 #include "../../tools/measure/mpm_slotted_flat.hpp"
 #endif
+#ifdef ZS_SLOT_WITH_NC  // measurement builds only: consumers as 2 node halves x 2 channel groups
+#include "../../tools/measure/slot_consumer_nc.hpp"
+#endif
 #ifdef ZS_SLOT_WITH_NS  // measurement builds only: node-split consumers + list wave (see the header for what was measured)
 #include "../../tools/measure/slot_consumer_ns.hpp"
 #endif
-template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS, bool FLAT = false>
+template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS, bool FLAT = false, bool NCSPLIT = false>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -823,6 +826,14 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
+#ifdef ZS_SLOT_WITH_NC
+  else if constexpr (NCSPLIT) {
+    if (w == 4) g2p2g_slot_consumer_nc<SIDE, 0, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 5) g2p2g_slot_consumer_nc<SIDE, 1, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else if (w == 6) g2p2g_slot_consumer_nc<SIDE, 0, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
+    else g2p2g_slot_consumer_nc<SIDE, 1, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
+  }
+#endif
 #ifdef ZS_SLOT_WITH_NS
   else if constexpr (NS) {
     if (w == 4) g2p2g_slot_consumer_ns<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
@@ -841,6 +852,12 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
     if (w < 4) {
 #pragma unroll 1
       for (int s3 = 0; s3 < 3; ++s3) __syncthreads();  // the consumers' three flush stages
+    }
+  }
+  if constexpr (NCSPLIT) {
+    if (w < 4) {
+      __syncthreads();  // the consumers' two flush stages
+      __syncthreads();
     }
   }
   SLP_T0(tTail);
@@ -1086,12 +1103,20 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
 #endif
   // measurement builds (-DZS_SLOT_WITH_FLAT): ZS_ROCM_SLOT_SCHEDULE=flat -- every wave produces, then consumes (tools/measure/mpm_slotted_flat.hpp)
   static const bool flat = [] { const char *e = getenv("ZS_ROCM_SLOT_SCHEDULE"); return e && e[0] == 'f'; }();
+#ifdef ZS_SLOT_WITH_NC
+#define ZS_SLOT_NC_AVAILABLE 1
+#else
+#define ZS_SLOT_NC_AVAILABLE 0
+#endif
+  static const bool halves = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'h'; }();
   static const bool nodeSplit = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'n'; }();
 #define CALL_SLOT3(SS, M, WA)                                                                                                          \
   do {                                                                                                                                  \
     if (nbins) {                                                                                                                       \
       if (ZS_SLOT_NS_AVAILABLE && nodeSplit)                                                                                            \
         hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, ZS_SLOT_NS_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
+      else if (ZS_SLOT_NC_AVAILABLE && halves)                                                                                          \
+        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false, false, ZS_SLOT_NC_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
       else if (ZS_SLOT_FLAT_AVAILABLE && flat)                                                                                          \
         hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false, ZS_SLOT_FLAT_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
       else hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                 \
