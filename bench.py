@@ -897,7 +897,8 @@ def main():
                                "particles_per_launch": n_local, "launch_ms": fused_ms,
                                "fused_min_bytes_per_particle": fmin,
                                "note": "bytes_per_particle = SURVEY 8(d) P2G + G2P; the fused pass keeps v, C and the stress on chip "
-                                       "(traffic < algorithmic bytes) and is bound by VALU issue, not by HBM (profiles/r02_pmc_g2p2g.md); "
+                                       "(traffic < algorithmic bytes) and is bound by instruction issue and the waves' own chains, not by HBM "
+                                       "(profiles/r03_pmc_g2p2g.md, r03_slot_probe.md); "
                                        "launch_ms = HIP-event time of the fused launches of one step (slotted: main kernel + re-home + commit kernels)"}
         # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
         # bytes over HIP-event time, after the timed region)
