@@ -921,13 +921,15 @@ template <bool FLUID, bool DP, bool WRITE_ALL>
 static __global__ __launch_bounds__(256) void slot_rehome_kernel(ParticlesDev ps, const unsigned *cellMask, unsigned *claim, const int *moverCount,
                                                                  const float *moverRec, int cap, size_t nbins, int K, int *status) {
   constexpr int LW = 64;
-  const size_t bin = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bin >= nbins) return;
-  const int n = __builtin_amdgcn_readfirstlane(moverCount[bin]);
-  if (n == 0) return;
+  // a wave takes EIGHT bins, eight records of each per pass (a bin sends ~7 records per step): the kernel is a chain of dependent round
+  // trips (count -> record -> ticket -> stores), so what matters is how many waves stand in line, not how busy their lanes are --
+  // one bin per wave: 0.43 ms per step of the 64 Mi column
+  const size_t bin = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ((threadIdx.x & 63) >> 3);
+  const int n = bin < nbins ? moverCount[bin] : 0;
+  if (__ballot(n > 0) == 0ull) return;
   const unsigned kmask = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
   int nhomed = 0;
-  for (int k = (int)(threadIdx.x & 63); k < n; k += 64) {
+  for (int k = (int)(threadIdx.x & 7); k < n; k += 8) {
     const float *rc = moverRec + (bin * (size_t)cap + (size_t)k) * SL_REC;
     const float4 r0 = reinterpret_cast<const float4 *>(rc)[0], r1 = reinterpret_cast<const float4 *>(rc)[1],
                  r2 = reinterpret_cast<const float4 *>(rc)[2], r3 = reinterpret_cast<const float4 *>(rc)[3];
@@ -965,7 +967,7 @@ static __global__ __launch_bounds__(256) void slot_rehome_kernel(ParticlesDev ps
   }
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) nhomed += __shfl_xor(nhomed, sft, 64);
-  if ((threadIdx.x & 63) == 0 && nhomed) atomicAdd(&status[SL_DELIVERED + (int)(bin & (SL_NCTR - 1))], nhomed);
+  if ((threadIdx.x & 63) == 0 && nhomed) atomicAdd(&status[SL_DELIVERED + (int)((bin >> 3) & (SL_NCTR - 1))], nhomed);
 }
 
 // after the step: departures leave the occupancy words, this step's arrivals enter them (the lowest free rounds: in-bin arrivals first,
@@ -1122,7 +1124,7 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
       else hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                 \
     }                                                                                                                                  \
     if (finish)                                                                                                                         \
-      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 4)),         \
+      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 32)),         \
                          dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
                          outboxCap, (size_t)nbinsAll, K, status);                                                                       \
   } while (0)
