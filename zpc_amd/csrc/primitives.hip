@@ -347,7 +347,12 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
 template <int OP, class T, bool EXCL> static void scan_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
   if (n == 0) return;
   // (r02: 4-row and 16-row tiles re-measured at 16 M / 64 M / 256 M elements: 2.5 / 2.9 / 3.2 and 3.0 / 3.0 / 3.2 TB/s against 2.9 / 3.4 / 3.8 for 8 rows)
-  if (n >= ((size_t)1 << 23)) scan_launch<OP, T, EXCL, 8>(L, in, n, out, init);
+  // rows per tile by size (r03, i32 exclusive scan on one MI355X, us for 2 / 4 / 8 rows): 250 K 5.4 / 6.5 / 8.6, 500 K 6.5 / 6.3 / 9.5,
+  // 1 M 8.6 / 7.7 / 9.1, 2 M 14.2 / 10.2 / 10.9, 4 M 24.3 / 16.5 / 13.7, 8 M 38.7 / 29.7 / 21.3, 16 M 63.9 / 48.2 / 38.7
+  static const int rowsOverride = [] { const char *e = getenv("ZS_ROCM_SCAN_ROWS"); return e ? atoi(e) : 0; }();  // measurement only
+  const int rows = rowsOverride ? rowsOverride : (n >= (size_t)3000000 ? 8 : (n >= (size_t)400000 ? 4 : 2));
+  if (rows == 8) scan_launch<OP, T, EXCL, 8>(L, in, n, out, init);
+  else if (rows == 4) scan_launch<OP, T, EXCL, 4>(L, in, n, out, init);
   else scan_launch<OP, T, EXCL, 2>(L, in, n, out, init);
 }
 
