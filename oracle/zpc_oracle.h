@@ -23,10 +23,18 @@
  *     tests/test_oracle_cpu.py compares mpm.c with it.  The von Mises / NACC models exist in a host
  *     and a CUDA spelling that differ (sqrt iteration, NACC yield pressure): orc_mpm_params.hostVariant
  *     = 1 follows the host header (what the golden vectors were made with), 0 the CUDA header.
- *   - bht / HashTable / P2C2G / G2C2P as whole functions: the reference's containers and policies need
- *     the un-vendored magic_enum / plog submodule headers and are unbuildable in this image, and the
- *     reference holds no tests for them: PARITY UNPINNED at whole-function level (their numeric
- *     building blocks are pinned as above; set semantics and conservation properties are tested).
+ *   - bht / HashTable (sequential insert + query) and P2C2G / G2C2P as whole functions: PINNED (r03).  The
+ *     reference's containers, policies and functor headers need the un-vendored magic_enum / plog
+ *     submodule headers and are unbuildable in this image, so -- as for P2G -- the bodies are spelled in
+ *     oracle/ref_shim.cpp over the reference's own pieces (universal_hash_base, hash_combine, next_2pow,
+ *     the mt19937 seeds; vec, lower_trunc, compute_stress_*, unpack_coord_in_grid); tools/gen_golden.py
+ *     writes tests/golden/containers_seq.npz (tables byte for byte) and c2.npz, tests/test_oracle_cpu.py
+ *     compares bht.c / hashtable.c / mpm.c with them.  Not covered by a fixture: P2C2G with the plastic
+ *     models that carry logJp (the reference functor re-runs their update per (cell, particle) pair, this
+ *     restatement once per particle), and the parallel policies' arrival-order-dependent table layouts
+ *     (set semantics are what is compared there).
+ *   - GridArena (math/curve/InterpolationKernel.hpp:272-470): the reference's own template instantiated
+ *     over a dense box in ref_shim.cpp -> tests/golden/grid_arena.npz, compared with the C++ face on the GPU.
  */
 #ifndef ZPC_ORACLE_H
 #define ZPC_ORACLE_H

@@ -459,8 +459,9 @@ def test_vonmises_and_nacc_match_reference_golden(oracle):
 
 
 def test_oracle_c2_transfers_are_consistent(oracle):
-    """P2C2G / G2C2P restatement (oracle/mpm.c; no reference test or fixture exists for these functors: parity unpinned at
-    whole-function level): partition of unity, Transfer == Momentum + Force, and exact reproduction of an affine grid field."""
+    """P2C2G / G2C2P restatement (oracle/mpm.c; the reference has no test for these functors -- the whole-function pin against its own
+    headers is test_p2c2g_whole_function_matches_reference_golden below): partition of unity, Transfer == Momentum + Force, and exact
+    reproduction of an affine grid field."""
     from util import OracleMpm, make_cloud
     dx, dt, side = 1.0 / 64, 1e-4, 4
     mass, pos, vel, Bm, F = make_cloud(5, dx, 2, seed=71, vel_scale=0.3)
