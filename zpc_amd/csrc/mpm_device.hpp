@@ -2703,6 +2703,9 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
   if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) atomicAdd(&g_probe[7], 1ull);  // sampled workgroups
 #endif
 }
+#ifdef ZS_ROCM_WITH_P2G_HALF  // measurement builds only: two waves per bin, half of the stencil nodes each
+#include "../../tools/measure/p2g_half.hpp"
+#endif
 #ifdef ZS_ROCM_WITH_P2G_RS  // measurement builds only: role-split stand-alone P2G (slower than p2g_wide_kernel, see the header)
 #include "../../tools/measure/p2g_rs.hpp"
 #endif

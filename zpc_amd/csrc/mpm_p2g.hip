@@ -21,6 +21,19 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
     // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
     static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
+#ifdef ZS_ROCM_WITH_P2G_HALF  // measurement builds: ZS_ROCM_P2G_KERNEL=half selects two waves per bin (p2g_half_kernel)
+    static const bool halfKernel = [] { const char *e = getenv("ZS_ROCM_P2G_KERNEL"); return e && e[0] == 'h'; }();
+    if (kmodel == MPM_CACHED_STRESS && !split4 && halfKernel) {
+#define CALL_P2G_HALF(S, M, LWv)                                                                                                        \
+  hipLaunchKernelGGL((p2g_half_kernel<S, LWv>), dim3(nbins), dim3(128), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale,   \
+                     staleCount);                                                                                                       \
+  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
+                     (const int *)staleCount)
+      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_HALF, 4, 0);
+      else ZSR_DISPATCH_LW(lw, CALL_P2G_HALF, 8, 0);
+      return;
+    }
+#endif
 #ifdef ZS_ROCM_WITH_P2G_RS  // measurement builds: ZS_ROCM_P2G_KERNEL=rs selects loader waves + channel-set consumer waves (p2g_rs_kernel)
     static const bool rsKernel = [] { const char *e = getenv("ZS_ROCM_P2G_KERNEL"); return e && e[0] == 'r'; }();
     if (kmodel == MPM_CACHED_STRESS && !split4 && rsKernel) {
