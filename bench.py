@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--lift", type=int, default=0,
                     help="raise the column by this many cells (rounded to whole blocks).  Default 0: it stands on y = 0 as in BASELINE config 4. "
                          "Next to the coordinate origin the reference's arena weights a particle one cell off when its local position rounds to "
-                         "exactly 1.5 (profiles/r03_compact_outliers.md): one foot particle in ~3 %% of the runs; comparisons of two runs lift the column")
+                         "exactly 1.5 (profiles/r03_compact_outliers.md): one foot particle in ~3 %% of the compact-storage runs; comparisons of two runs lift the column")
     ap.add_argument("--model", type=str, default="sand", choices=["sand", "jello"])
     ap.add_argument("--side", type=int, default=8, choices=[4, 8],
                     help="grid block side: 8 = SparseGrid<3,f32,8> blocks (default, the '512^3 sparse grid' of BASELINE.json), 4 = Grids<f32,3,4>")
@@ -807,7 +807,7 @@ def main():
         # ... and the same sums without the particles that carry a velocity-gradient entry beyond 8 rms.  Two kinds exist: the two edge
         # particles of the column that have such entries in every run, and what a hit of the reference arena's rounding case leaves behind
         # (a local position that rounds to exactly 1.5 next to the coordinate origin is weighted one cell off and G2P returns C ~ 4 v / dx:
-        # one foot particle in ~3 % of the runs with the column on y = 0, 76 particles with |C| > 4 two steps later --
+        # one foot particle in ~3 % of the compact-storage runs with the column on y = 0, 76 particles with |C| > 4 two steps later --
         # profiles/r03_compact_outliers.md; the reference computes the same).  Sum-of-squares comparisons between two runs use the
         # trimmed sums and bound the number of trimmed particles.
         c2 = v[:, 7:16, :] ** 2 * valid

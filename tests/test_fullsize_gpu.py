@@ -222,7 +222,7 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     have become uneven): the slotted step -- packed producers, movers through the outboxes, no re-bin -- against the compact storage
     with the re-bin controller; same particle state, every mover delivered, nobody lost."""
     # (--lift 8: the column stands one block above y = 0, where the reference's arena has no local position that rounds to 1.5 -- on y = 0
-    # one foot particle is weighted a cell off in ~3 % of the runs of ANY path, profiles/r03_compact_outliers.md; two runs then differ)
+    # one foot particle is weighted a cell off in ~3 % of the compact-storage runs, profiles/r03_compact_outliers.md; two runs then differ)
     base = ["--steps", "24", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest", "--lift", "8"]
     a = _bench(base + ["--slot-stats"])
     b = _bench(base + ["--compact", "--rebin-check", "2"])
