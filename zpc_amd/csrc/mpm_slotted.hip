@@ -412,6 +412,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
           bool staged = !moved;  // {m, x', v', C', P F^T} staged for the consumers
           bool home = false;     // mover with a new slot inside this bin
           bool byList = false;   // stayer scattered by the consumers' list (see `edge`)
+          bool lowered = false;  // stayer re-homed into a lower round of its own cell
           bool keep = false;     // mover that found no new home (cell full, outbox full, moved too far): it stays in its OLD slot with its new
                                  // state, occupancy bit set -- reported (status [0] / [1] / [4]); re-slotting the storage recovers it
           unsigned recFlag = 0u; // record word SLR_FLAG: the record's grid contributions are still to be added (after the loop)
@@ -502,6 +503,26 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
               atomicAdd(sent, 1);
             }
           } else {
+#ifndef ZS_X_NOLOWER
+            {
+              // A stayer that holds the TOP round of its cell while a round below is free re-homes downwards: the rounds of a bin are set by
+              // the highest occupied round of its cells, and a particle that once sat on top of a crowd keeps the bin tall long after the
+              // crowd has left (200 steps of the falling column: 11.6 rounds for a fullest cell of 9.1).  It draws a ticket like an in-bin
+              // arrival (whatever round the ticket gives is taken, so that tickets and stored particles stay one to one) and is still
+              // consumed from the staging ring by the lane of its cell: only where it is stored changes.  One per cell and step, and only
+              // while the cell has rounds to spare: the vacated round is not reusable before the step's commit, so every re-homing costs
+              // the step's arrivals a free round (lowering every particle above the cell's compact height filled crowded cells).
+              const unsigned m0 = mask0[cell];
+              if (r > 0 && (m0 >> r) == 1u && (m0 & ((1u << r) - 1u)) != ((1u << r) - 1u) && __popc(~m0 & kmask) >= 8) {
+                const int rr = nth_low_bit(~m0 & kmask, atomicAdd(&arrLocal[cell], 1u));
+                if (rr >= 0) {
+                  o = particle_offset<LW>(ps.pos.chns, (rowBase + (size_t)rr) * 64 + (size_t)cell);
+                  atomicOr(&clr[cell], 1u << r);
+                  lowered = true;
+                }
+              }
+            }
+#endif
             pstore_state<LW, FLUID>(ps.F, o, F);
             pstore<LW, 3>(ps.pos, o, pos);
             if (WRITE_ALL) {
@@ -533,7 +554,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             if (!moved || home || keep) {
               if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
               if (WRITE_ALL) pstore<LW, 9>(ps.stress, o, PF);
-              if (moved) pstore1<LW>(ps.mass, o, pm);
+              if (moved || lowered) pstore1<LW>(ps.mass, o, pm);
             }
           }
           if (staged) {
