@@ -19,8 +19,13 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
     const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
-    // cached stress: the one-wave "wide" kernel (ZS_ROCM_P2G_SPLIT=1 selects the four-wave channel split for comparison)
+    // cached stress: the one-wave "wide" kernel (measurement builds with -DZS_ROCM_WITH_P2G_SPLIT: ZS_ROCM_P2G_SPLIT=1 selects the r01
+    // four-wave channel split for comparison)
+#ifdef ZS_ROCM_WITH_P2G_SPLIT
     static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
+#else
+    constexpr bool split4 = false;
+#endif
 #ifdef ZS_ROCM_WITH_P2G_HALF  // measurement builds: ZS_ROCM_P2G_KERNEL=half selects two waves per bin (p2g_half_kernel)
     static const bool halfKernel = [] { const char *e = getenv("ZS_ROCM_P2G_KERNEL"); return e && e[0] == 'h'; }();
     if (kmodel == MPM_CACHED_STRESS && !split4 && halfKernel) {
@@ -57,6 +62,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
       else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
       return;
     }
+#ifdef ZS_ROCM_WITH_P2G_SPLIT
     if (kmodel == MPM_CACHED_STRESS) {
 #define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
   hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
@@ -67,6 +73,7 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
       else ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 8, 0);
       return;
     }
+#endif
 #define CALL_P2G_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((p2g_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \
