@@ -189,7 +189,10 @@ template <int SIDE> __device__ __forceinline__ int neighbour_bin(const int *nbr2
 // Departures and ticket counts are folded into the occupancy words by slot_commit_kernel.
 constexpr int SL_NG = 9;       // staged entry groups of 64: a chunk being produced (4) + the chunk being consumed (4) + a straddling round
 constexpr int SL_KMAX = 32;    // rounds per bin the 32-bit occupancy words allow
-constexpr int SL_ARRQ = 4;     // in-bin arrivals one cell takes per chunk through the consumers' queue
+#ifndef ZS_SL_ARRQ
+#define ZS_SL_ARRQ 4
+#endif
+constexpr int SL_ARRQ = ZS_SL_ARRQ;     // in-bin arrivals one cell takes per chunk through the consumers' queue
 constexpr int SL_XQ = 64;      // movers per chunk whose grid contributions the consumers add with global atomics (new cell in another bin, or
                                // arrival queue full); more: scattered from their outbox records after the loop
 
