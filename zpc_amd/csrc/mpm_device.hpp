@@ -2172,10 +2172,25 @@ __device__ __forceinline__ void g2p2g_consume_set(const MpmDev &mp, const float 
   // staged slots 1..3: lpn = x'/dx - base node of the particle's NEW position (the producer has it from its moved-out-of-the-cell
   // test; a staged particle sits in this lane's cell, so lpn is in [0.5, 1.5) and make_arena's d0 == lpn): the four consumers
   // do not repeat the floor / re-centering arithmetic
+  constexpr int cb = S::STRESS ? 16 : 7;
+  // every staged value of the set first (12 LDS reads in one go), then the arithmetic: one LDS latency per particle instead of four
+  float d0s[3], c0[S::NV], c1[S::NV], c2s[S::NV], vs[S::NV];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) d0s[d] = f(1 + d);
+  const float scale = S::STRESS ? kscale : f(0);
+#pragma unroll
+  for (int j = 0; j < S::NV; ++j) {
+    const int d = S::D0 + j;
+    c0[j] = f(cb + d);
+    c1[j] = f(cb + 3 + d);
+    c2s[j] = f(cb + 6 + d);
+    vs[j] = S::STRESS ? 0.f : f(4 + d);
+  }
+  asm volatile("" ::: "memory");  // (keeps the compiler from sinking the reads back between the fmas)
   Arena ar;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const float d0 = f(1 + d);
+    const float d0 = d0s[d];
     ar.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
     const float d1 = d0 - 1.0f;
     ar.w[d][1] = 0.75f - d1 * d1;
@@ -2183,20 +2198,13 @@ __device__ __forceinline__ void g2p2g_consume_set(const MpmDev &mp, const float 
     ar.w[d][2] = 0.5f * zz * zz;
     ar.lp[d] = d0 * mp.dx;
   }
-  constexpr int cb = S::STRESS ? 16 : 7;
-  const float scale = S::STRESS ? kscale : f(0);
-  float wzs[3], Pz[S::NV][3], c0[S::NV], c1[S::NV];
+  float wzs[3], Pz[S::NV][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
 #pragma unroll
   for (int j = 0; j < S::NV; ++j) {
-    const int d = S::D0 + j;
-    c0[j] = f(cb + d);
-    c1[j] = f(cb + 3 + d);
-    const float c2 = f(cb + 6 + d);
-    const float v = S::STRESS ? 0.f : f(4 + d);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(c2, (float)k * mp.dx - ar.lp[2], v);
+    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(c2s[j], (float)k * mp.dx - ar.lp[2], vs[j]);
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
