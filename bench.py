@@ -858,8 +858,9 @@ def main():
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": K, "migrated_rank0": migrated,
                        "drift_m_per_s": drift_v, "cells_per_step": max(abs(x) for x in drift_v) * dt / dx,
-                       "storage": ("slotted: bins x %d rounds x 64 lanes + per-cell occupancy masks; movers travel through per-bin outboxes "
-                                   "(%d records) and are pulled by their destination bin -- no re-bins in the time loop"
+                       "storage": ("slotted: bins x %d rounds x 64 lanes + per-cell occupancy masks; a mover is finished by the workgroup that "
+                                   "moves it (new slot by ticket inside its bin; across bins: global atomics + an outbox record of %d per bin, "
+                                   "re-homed by a second small kernel) -- no re-bins in the time loop"
                                    % (a.slot_rounds, a.outbox_cap)) if a.slotted else "compact round-robin order + re-bin controller",
                        "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
