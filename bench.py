@@ -603,19 +603,29 @@ def main():
         torch.cuda.synchronize()
 
     K = a.migrate_every
+    remaps = [0]
+    next_remap = None   # slotted, no --migrate-every: step count after which the next re-partition is due (derived, see below)
+
+    def steps_in_margin(s0):
+        """how many steps from step s0 on the column (initial drift + gravity, the fastest component) stays inside the partition's margin"""
+        safe_cells = max(a.margin, 0) * a.side + a.side // 2 - 2
+        v0 = max(abs(x) for x in drift_v) + 9.8 * s0 * dt   # (upper bound: gravity added to the largest component)
+        k = 0
+        while k < 100000 and (v0 * (k + 1) * dt + 0.5 * 9.8 * ((k + 1) * dt) ** 2) / dx <= safe_cells:
+            k += 1
+        return k
     if K == 0 and a.slotted:
         # A long window moves the column out of the partition's margin (the fused launch reports that and the run is refused): re-partition
-        # in time, inside the timing.  Every rank derives the same period from the initial drift and gravity.
-        safe_cells = max(a.margin, 0) * a.side + a.side // 2 - 2
-        v0 = max(abs(x) for x in drift_v)
-        n_steps, k = a.warmup + a.steps + 2, 0
-        while k < n_steps and (v0 * (k + 1) * dt + 0.5 * 9.8 * ((k + 1) * dt) ** 2) / dx <= safe_cells:
-            k += 1
+        # in time, inside the timing.  Every rank derives the same schedule from the initial drift and gravity; the period shrinks as the
+        # column accelerates (a fixed period derived at step 0 let a 3000-step run leave the partition).
+        n_steps = a.warmup + a.steps + 2
+        k = steps_in_margin(0)
         if k < n_steps:
-            K = max(k, 8)
+            next_remap = max(k, 8)
             if rank == 0:
-                print("[bench] %d steps move the column %.1f cells: re-partitioning every %d steps (inside the timing)"
-                      % (n_steps, (v0 * n_steps * dt + 0.5 * 9.8 * (n_steps * dt) ** 2) / dx, K), file=sys.stderr)
+                v0 = max(abs(x) for x in drift_v)
+                print("[bench] %d steps move the column %.1f cells: re-partitioning inside the timing, first after %d steps"
+                      % (n_steps, (v0 * n_steps * dt + 0.5 * 9.8 * (n_steps * dt) ** 2) / dx, next_remap), file=sys.stderr)
     done = 0
 
     # re-bin controller: particles that leave their cell make the fused launch slower step by step (LDS queue, exact path); a
@@ -630,9 +640,9 @@ def main():
     rebin_steps = []
 
     def run_steps(count, timed):
-        nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms
+        nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms, next_remap
         for _ in range(count):
-            remap_now = K > 0 and (done + 1) % K == 0
+            remap_now = (K > 0 and (done + 1) % K == 0) or (next_remap is not None and done + 1 >= next_remap)
             if a.fused:
                 step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
             else:
@@ -640,6 +650,9 @@ def main():
             done += 1
             if remap_now:
                 remap()
+                remaps[0] += 1
+                if next_remap is not None:
+                    next_remap = done + max(steps_in_margin(done), 8)
                 ctrl_ev.clear()
                 best_ms, lost_ms = None, 0.0
             elif a.fused and not a.slotted and rebin_at is not None:
@@ -856,7 +869,7 @@ def main():
                        "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
-                       "rebin_ms_once": rebin_ms, "migrate_every": K, "migrated_rank0": migrated,
+                       "rebin_ms_once": rebin_ms, "migrate_every": K, "repartitions": remaps[0], "migrated_rank0": migrated,
                        "drift_m_per_s": drift_v, "cells_per_step": max(abs(x) for x in drift_v) * dt / dx,
                        "storage": ("slotted: bins x %d rounds x 64 lanes + per-cell occupancy masks; a mover is finished by the workgroup that "
                                    "moves it (new slot by ticket inside its bin; across bins: global atomics + an outbox record of %d per bin, "
