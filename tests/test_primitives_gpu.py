@@ -140,6 +140,63 @@ def test_radix_sort_pair_stable_and_window(pol, oracle, n, sbit, ebit):
     assert np.array_equal(vo.cpu().numpy(), ev)  # stability: unique permutation
 
 
+def _small_path_keys(kind, n, g):
+    u = lambda: g.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    if kind == "uniform":        # three launches, buckets finished in LDS
+        return u()
+    if kind == "morton":         # 30 significant bits under the 32-bit window: the split digit sits under the highest differing bit
+        return g.integers(0, 2**30, n, dtype=np.int32)
+    if kind == "narrow":
+        return g.integers(0, 70000, n, dtype=np.int32)
+    if kind == "sorted":
+        return np.sort(u())
+    if kind == "equal":          # nothing differs: copy
+        return np.full(n, -7, np.int32)
+    if kind == "two_values":     # <= 8 differing bits: the split is the sort
+        return (g.integers(0, 2, n, dtype=np.int32) * 200 - 3).astype(np.int32)
+    if kind == "sentinel":       # one bucket too large for LDS: sorted by all workgroups inside the finish launch
+        a = u()
+        a[g.random(n) < 0.2] = 2**31 - 1
+        return a
+    if kind == "few_values":     # several such buckets: LSD passes inside the finish launch
+        return (g.integers(-8, 8, n, dtype=np.int32) * (1 << 27) + g.integers(0, 3, n, dtype=np.int32)).astype(np.int32)
+    if kind == "outlier":        # tiles disagree about the highest differing bit, rows cannot be rebuilt
+        a = g.integers(0, 70000, n, dtype=np.int32)
+        a[n // 3], a[n - 1] = 70000 * 5, 70000 * 3
+        return a
+    if kind == "far_outlier":    # ... and can: every other tile's keys share one digit of the true window
+        a = g.integers(0, 70000, n, dtype=np.int32)
+        a[n // 2] = 2**30 + 12345
+        return a
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "morton", "narrow", "sorted", "equal", "two_values", "sentinel", "few_values", "outlier",
+                                  "far_outlier"])
+@pytest.mark.parametrize("n,sbit,ebit", [(8193, 0, 32), (300_001, 0, 32), (300_001, 5, 29), (1_000_000, 0, 32), (1_572_864, 0, 32),
+                                         (1_572_865, 0, 32)])
+def test_radix_sort_small_input_path_every_mode(pol, oracle, kind, n, sbit, ebit):
+    """The three-launch path for <= 1.5 M 4-byte keys (primitives.hip, "split + finish") in each of its modes, keys and pairs, against the
+    oracle's restatement of the reference's stable LSD sort (execution/ExecutionPolicy.hpp:777-781 semantics: order by the bits
+    [sbit, ebit) of the sign-flipped key, ties in input order); 1 572 865 keys is the first size on the ordinary passes again."""
+    import zpc_amd as zs
+    k = _small_path_keys(kind, n, rng(n % 1000 + len(kind)))
+    v = np.arange(n, dtype=np.int32)
+    ko, vo, k1 = (torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(3))
+    zs.radix_sort_pair(pol, dev(k), dev(v), ko, vo, sbit=sbit, ebit=ebit)
+    zs.radix_sort(pol, dev(k), k1, sbit=sbit, ebit=ebit)
+    ek, ev = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    oracle.orc_radix_sort_pair_i32(k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), ek.ctypes.data_as(C.c_void_p),
+                                   ev.ctypes.data_as(C.c_void_p), C.c_size_t(n), c_int(sbit), c_int(ebit))
+    assert np.array_equal(ko.cpu().numpy(), ek)
+    assert np.array_equal(vo.cpu().numpy(), ev)
+    assert np.array_equal(k1.cpu().numpy(), ek)
+    # in place (execution/ExecutionPolicy.hpp stages through temporaries, so aliasing is legal there)
+    kk = dev(k)
+    zs.radix_sort(pol, kk, kk, sbit=sbit, ebit=ebit)
+    assert np.array_equal(kk.cpu().numpy(), ek)
+
+
 @pytest.mark.parametrize("dtype", ["u32", "i64", "u64"])
 def test_radix_sort_other_key_widths(pol, oracle, dtype):
     import zpc_amd as zs

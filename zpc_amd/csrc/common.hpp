@@ -34,6 +34,7 @@ struct DeviceContext {
   hipEvent_t events[kNumSpareStreams + 1] = {};
   int errorStatus = 0;
   bool errorPrinted = false;
+  int cuCount = 0;  // compute units of the device (0: not asked yet)
   std::mutex mtx;
   struct Block {
     char *ptr = nullptr;
@@ -117,6 +118,8 @@ struct Launch {
   char *scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase, bool &wrapped);
   // after a failed launch: control block zeroed (stream-ordered), generation and ticket shadow start over
   void scan_control_reset();
+  // compute units of this launch's device (kernels with an in-launch grid barrier size their grid by it)
+  unsigned cu_count();
 };
 
 // ------------------------------------------------------------------------------------ iterator ports

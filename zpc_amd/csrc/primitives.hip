@@ -394,6 +394,11 @@ template <class K> struct KeyBits {
 // its 256 digit runs by a chained scan over per-(tile, digit) descriptors (decoupled look-back, dynamic tile ticket) and
 // scatters.  Keys are first permuted into tile-local digit order in LDS so that a wave writes contiguous runs.
 // Traffic: 4 B/key (histograms) + passes x (4 R + 4 W) instead of passes x (4 + 4 + 4) + count scans.
+// small-input path (below, "split + finish")
+constexpr unsigned RS_SMALL_CAP = RS_TILE;          // keys one workgroup finishes in LDS
+constexpr size_t RS_SMALL_MAX_N = 1536 * 1024;      // uniform keys: a bucket holds n/256 +- a few sqrt(n/256)
+constexpr int RS_CTL_MODE = 257, RS_CTL_BAR = 258, RS_CTL_TOP = 259, RS_CTL_EBIT = 260, RS_CTL_BIG = 261, RS_CTL_WORDS = 320;
+enum : unsigned { RS_FAST = 0, RS_LSD = 1, RS_COPY_IN = 2, RS_COPY_SPLIT = 3, RS_ONE_BIG = 4 };
 constexpr unsigned OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
 
 template <class K, int NPASS>
@@ -655,6 +660,490 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
   }
 }
 
+// ---------------------------------------------------------------------------------------- small inputs: split + finish
+// Below ~1.5 M 4-byte keys every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
+// all predecessors -> scatter) four times over, plus six launches.  The small path sorts in three launches, with no look-back and no memset:
+//   1. radix_small_hist_kernel: per-tile histogram of the TOP 8-bit digit of the bits that actually differ between the keys (below), by
+//      plain stores;
+//   2. radix_small_split_kernel: every tile sums the histograms of the tiles before it (independent loads, no waiting on anybody) and
+//      scatters its keys into the 256 top-digit buckets (stable);
+//   3. radix_small_finish_kernel: one workgroup per bucket sorts it by the remaining low bits inside LDS (LSD passes over <= 8192 keys
+//      held in registers) and writes it out.
+// Which bits differ: a tile ORs (key ^ keys[0]) over its own keys and over 512 keys sampled across the whole input, and counts the window
+// under the highest differing bit hb_j it sees.  The split kernel takes the maximum hb over the tiles -- exact, every key is in some tile.
+// A tile that counted a lower window (the sample missed the top bit: outliers) still yields its row when all its keys share the digit of
+// keys[0] in the true window (hb_j below it); otherwise the input goes the slow way.  So narrow key ranges under a wide [sbit, ebit), morton
+// codes, sorted inputs and equal keys all take the three launches.
+// The slow ways, all inside the finish launch (grid = one workgroup per CU at most, every one resident, so it can run a grid barrier; the
+// host takes the ordinary passes when the tiles outnumber the CUs):
+//   * one bucket above 8192 keys (a sentinel value, say): the other buckets are finished as usual, then all workgroups sort that one by
+//     LSD passes over its own range -- tile histograms, barrier, histogram-sum split, barrier;
+//   * several: the same LSD passes over the whole input and only the differing bits.  Slower than the ordinary passes (a barrier costs more
+//     than a launch), the price of not launching passes that would return at once in the common case.
+// Same stable order every way.
+template <class K, bool PAIR> struct RsLds {
+  unsigned cnt[RS_NW][256];  // per-wave digit counters -> offsets
+  unsigned tileStart[256], globalStart[256];
+  unsigned sTot[RS_NW][256], sBelow[RS_NW][256];  // per-wave partial sums of the tiles' histogram rows
+  int hbS[256];              // highest differing bit seen by tile j
+  unsigned sWave[8], sWave2[4];
+  unsigned sBad, sOverCnt, sBig;
+  K keyS[RS_TILE];
+  int valS[PAIR ? RS_TILE : 1];
+};
+
+// ballot multisplit of one item per lane (the ranking step of radix_onesweep_kernel, see there)
+__device__ __forceinline__ unsigned rs_rank_one(unsigned d, bool valid, volatile unsigned *wc, unsigned ltlo, unsigned lthi) {
+  if (!valid) d = 0u;
+  const unsigned long long vb = __ballot(valid);
+  unsigned plo = (unsigned)vb, phi = (unsigned)(vb >> 32);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned tb = (unsigned)__builtin_amdgcn_sbfe((int)d, b, 1);
+    const unsigned long long m = __ballot(tb != 0u);
+    plo = __builtin_amdgcn_bitop3_b32(plo, (unsigned)m, tb, 0x90);
+    phi = __builtin_amdgcn_bitop3_b32(phi, (unsigned)(m >> 32), tb, 0x90);
+  }
+  const unsigned below = (unsigned)__popc(plo & ltlo) + (unsigned)__popc(phi & lthi);
+  const unsigned old = wc[d];
+  __builtin_amdgcn_wave_barrier();
+  if (valid && below == 0) wc[d] = old + (unsigned)__popc(plo) + (unsigned)__popc(phi);
+  __builtin_amdgcn_wave_barrier();
+  return old + below;
+}
+
+// all workgroups of the launch (every one resident): stores before it are visible to plain loads after it
+__device__ __forceinline__ void rs_grid_barrier(unsigned *counter, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int rs_top_of(int hb, int sbit) {  // start of the 8-bit window under the highest differing bit
+  const int tp = hb + 1 - 8;
+  return tp < sbit ? sbit : tp;
+}
+
+// histogram of the digit (st, mask) over one tile -> row[256] (plain stores); h: 256 words of LDS
+template <class K>
+__device__ __forceinline__ void rs_count_tile(unsigned *h, const K *keys, unsigned n, unsigned tile, int st, unsigned mask, unsigned *row) {
+  const int t = threadIdx.x;
+  if (t < 256) h[t] = 0u;
+  __syncthreads();
+  const unsigned base = tile * RS_TILE + (unsigned)wave_id() * (64 * RS_ITEMS) + lane_id();
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k)
+    if (base + k * 64 < n) atomicAdd(&h[KeyBits<K>::digit(keys[base + k * 64], st, mask)], 1u);
+  __syncthreads();
+  if (t < 256) row[t] = h[t];
+}
+
+// part[tile][2][256]: row 0 = the tile's top window, row 1 = lowest digit [sbit, sbit + 8) (first pass of the whole-input LSD fallback);
+// meta[tile] = highest differing bit the tile saw (-1: none)
+template <class K>
+__global__ __launch_bounds__(RS_BLOCK) void radix_small_hist_kernel(const K *keys, unsigned n, int sbit, int ebit, unsigned *part, int *meta,
+                                                                    unsigned *ctl) {
+  using U = typename KeyBits<K>::U;
+  __shared__ unsigned h[2][256];
+  __shared__ unsigned sOr[RS_NW];
+  const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+  h[t >> 8][t & 255] = 0u;
+  const unsigned tile = blockIdx.x;
+  const unsigned base = tile * RS_TILE + (unsigned)w * (64 * RS_ITEMS) + lane;
+  K key[RS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k)
+    if (base + k * 64 < n) key[k] = keys[base + k * 64];
+  const U k0 = (U)keys[0];
+  const U ks = (U)keys[(size_t)t * n / RS_BLOCK];
+  if (tile == 0 && t == 0) ctl[RS_CTL_BAR] = 0u;
+  U diff = ks ^ k0;
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k)
+    if (base + k * 64 < n) diff |= (U)key[k] ^ k0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) diff |= (U)__shfl_xor((unsigned)diff, d, 64);
+  if (lane == 0) sOr[w] = (unsigned)diff;
+  __syncthreads();
+  unsigned all = 0;
+#pragma unroll
+  for (int i = 0; i < RS_NW; ++i) all |= sOr[i];
+  all &= (ebit >= 32 ? 0xFFFFFFFFu : (1u << ebit) - 1u) & ~((1u << sbit) - 1u);
+  const int hb = all ? 31 - __clz((int)all) : -1;
+  const int top = rs_top_of(hb, sbit);
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k)
+    if (base + k * 64 < n) {
+      atomicAdd(&h[0][KeyBits<K>::digit(key[k], top, 0xFFu)], 1u);
+      atomicAdd(&h[1][KeyBits<K>::digit(key[k], sbit, 0xFFu)], 1u);
+    }
+  __syncthreads();
+  part[(size_t)tile * 512 + t] = h[t >> 8][t & 255];
+  if (t == 0) meta[tile] = hb;
+}
+
+// One tile of a stable split of kin by the digit (st, mask): start of each digit's run for this tile = sum of the tiles' histogram rows
+// (row of tile j at rows + j * 512), then rank, tile-local digit order in LDS, coalesced runs out.
+// FIRST (the split kernel): the digit is the window under the highest differing bit of all tiles (meta), rows of tiles that counted a
+// lower window are rebuilt (see the head comment); tile 0 records bucket starts, window and mode in ctl; nothing moves unless the mode
+// is RS_FAST / RS_ONE_BIG / RS_COPY_SPLIT.
+template <class K, bool PAIR, bool FIRST>
+__device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, const int *vin, K *kout, int *vout, unsigned n, int st,
+                                              unsigned mask, const unsigned *rows, unsigned numTiles, unsigned tile, const int *meta,
+                                              int sbit, unsigned *ctl) {
+  constexpr int NW = RS_NW, ITEMS = RS_ITEMS, TILE = RS_TILE, BLOCK = RS_BLOCK;
+  const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+  const unsigned tileBase = tile * TILE;
+  const unsigned tileCount = n - tileBase < (unsigned)TILE ? n - tileBase : (unsigned)TILE;
+  const bool full = tileCount == (unsigned)TILE;
+  for (int i = t; i < NW * 256; i += BLOCK) (&S.cnt[0][0])[i] = 0;
+  K key[ITEMS];
+  int val[ITEMS];
+  unsigned rank[ITEMS];
+  const unsigned base = tileBase + (unsigned)w * (64 * ITEMS) + lane;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (full || base + k * 64 < n) {
+      key[k] = kin[base + k * 64];
+      if constexpr (PAIR) val[k] = vin[base + k * 64];
+    }
+  // histogram rows: wave w reads the rows of the tiles j = w (mod 8), a whole row per load (lane q: digits 4q .. 4q + 3), all of them in
+  // flight at once -- one memory round trip for the lot (workgroups have a CU each here: registers are free, latency is not)
+  constexpr int RB = (int)((RS_SMALL_MAX_N / RS_TILE + NW - 1) / NW);
+  uint4 rv[RB];
+#pragma unroll
+  for (int u = 0; u < RB; ++u) {
+    const unsigned j = (unsigned)w + (unsigned)NW * u;
+    rv[u] = j < numTiles ? *reinterpret_cast<const uint4 *>(rows + (size_t)j * 512 + 4 * lane) : uint4{0u, 0u, 0u, 0u};
+  }
+  int hbG = -1;
+  unsigned dref = 0;
+  if constexpr (FIRST) {
+    if (t == 0) S.sBad = 0u, S.sOverCnt = 0u, S.sBig = 0u;
+    int hj = -1;
+    if (t < 256) {
+      hj = t < (int)numTiles ? meta[t] : -1;
+      S.hbS[t] = hj;
+    }
+    const K k0 = kin[0];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int o = __shfl_xor(hj, d, 64);
+      hj = o > hj ? o : hj;
+    }
+    if (lane == 0) S.sWave[w] = (unsigned)hj;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) hbG = (int)S.sWave[i] > hbG ? (int)S.sWave[i] : hbG;
+    st = rs_top_of(hbG, sbit);
+    mask = 0xFFu;
+    dref = KeyBits<K>::digit(k0, st, mask);
+  }
+  {
+    unsigned tot[4] = {0u, 0u, 0u, 0u}, below[4] = {0u, 0u, 0u, 0u};
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const unsigned j = (unsigned)w + (unsigned)NW * u;
+      if (j < numTiles) {  // (wave-uniform)
+        unsigned v[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+        if constexpr (FIRST) {
+          const int hj = S.hbS[j];
+          if (rs_top_of(hj, sbit) != st) {  // this tile counted a lower window: all its keys sit in keys[0]'s digit, or the row is lost
+            bad = bad || hj >= st;
+            const unsigned cj = j == numTiles - 1 ? n - j * TILE : (unsigned)TILE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = 4u * lane + i == dref ? cj : 0u;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          tot[i] += v[i];
+          below[i] += j < tile ? v[i] : 0u;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      S.sTot[w][4 * lane + i] = tot[i];
+      S.sBelow[w][4 * lane + i] = below[i];
+    }
+    if (FIRST && bad) S.sBad = 1u;
+  }
+  __syncthreads();
+  unsigned bstart = 0, below = 0;
+  if (t < 256) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tot += S.sTot[i][t], below += S.sBelow[i][t];
+    if (FIRST && tot > RS_SMALL_CAP) {
+      atomicAdd(&S.sOverCnt, 1u);
+      S.sBig = (unsigned)t;
+    }
+    unsigned sc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = shfl_up(sc, d);
+      if (lane >= d) sc += o;
+    }
+    if (lane == 63) S.sWave2[w] = sc;
+    bstart = sc - tot;
+  }
+  __syncthreads();
+  if (t < 256)
+    for (int i = 0; i < w; ++i) bstart += S.sWave2[i];
+  if constexpr (FIRST) {
+    unsigned mode = RS_FAST;
+    if (hbG < 0) mode = RS_COPY_IN;              // no key differs from keys[0] inside the window: the input is its own sorted order
+    else if (S.sBad) mode = RS_LSD;
+    else if (st == sbit) mode = RS_COPY_SPLIT;   // at most 8 differing bits: the split is the sort
+    else if (S.sOverCnt == 1u) mode = RS_ONE_BIG;
+    else if (S.sOverCnt > 1u) mode = RS_LSD;
+    if (tile == 0 && t < 256) {
+      ctl[t] = bstart;
+      if (t == 255) ctl[256] = n;
+      if (t == 0) {
+        ctl[RS_CTL_MODE] = mode;
+        ctl[RS_CTL_TOP] = (unsigned)st;
+        ctl[RS_CTL_EBIT] = (unsigned)(hbG + 1);
+        ctl[RS_CTL_BIG] = S.sBig;
+      }
+    }
+    if (mode == RS_COPY_IN || mode == RS_LSD) return;  // (uniform)
+  }
+  __syncthreads();  // (sWave2 is reused below)
+  volatile unsigned *wc = S.cnt[w];
+  const unsigned long long lt = lanemask_lt();
+  const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const bool valid = full || base + k * 64 < n;
+    rank[k] = rs_rank_one(valid ? KeyBits<K>::digit(key[k], st, mask) : 0u, valid, wc, ltlo, lthi);
+  }
+  __syncthreads();
+  if (t < 256) {
+    unsigned run = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const unsigned c = S.cnt[i][t];
+      S.cnt[i][t] = run;
+      run += c;
+    }
+    unsigned s = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned o = shfl_up(s, d);
+      if (lane >= d) s += o;
+    }
+    if (lane == 63) S.sWave2[w] = s;
+    S.tileStart[t] = s - run;
+  }
+  __syncthreads();
+  if (t < 256) {
+    unsigned b = 0;
+    for (int i = 0; i < w; ++i) b += S.sWave2[i];
+    const unsigned ts = S.tileStart[t] + b;
+    S.globalStart[t] = bstart + below - ts;  // (wrapping) dst = globalStart[d] + position in the tile-sorted order
+#pragma unroll
+    for (int i = 0; i < NW; ++i) S.cnt[i][t] += ts;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (full || base + k * 64 < n) {
+      const unsigned lp = S.cnt[w][KeyBits<K>::digit(key[k], st, mask)] + rank[k];
+      S.keyS[lp] = key[k];
+      if constexpr (PAIR) S.valS[lp] = val[k];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
+    if (full || lp < tileCount) {
+      const K kk = S.keyS[lp];
+      const unsigned dst = S.globalStart[KeyBits<K>::digit(kk, st, mask)] + lp;
+      kout[dst] = kk;
+      if constexpr (PAIR) vout[dst] = S.valS[lp];
+    }
+  }
+}
+
+template <class K, bool PAIR>
+__global__ __launch_bounds__(RS_BLOCK) void radix_small_split_kernel(const K *kin, const int *vin, K *kout, int *vout, unsigned n, int sbit,
+                                                                     const unsigned *part, const int *meta, unsigned numTiles,
+                                                                     unsigned *ctl) {
+  __shared__ RsLds<K, PAIR> S;
+  rs_split_tile<K, PAIR, true>(S, kin, vin, kout, vout, n, 0, 0u, part, numTiles, blockIdx.x, meta, sbit, ctl);
+}
+
+// LSD passes over src[0, n) by the bits [sbit, ebit) by the first ceil(n / 8192) workgroups of the launch, one tile each (the others leave):
+// hop p writes out on the last pass, else bufA / bufB alternately (B first).  Row 1 of `part` carries the tile histograms; rowValid: it
+// already holds the first pass's (radix_small_hist_kernel counted it over the input).
+template <class K, bool PAIR>
+__device__ __forceinline__ void rs_coop_lsd(RsLds<K, PAIR> &S, const K *src, const int *srcV, K *bufA, int *bufAV, K *bufB, int *bufBV, K *out,
+                                            int *outV, unsigned n, int sbit, int ebit, unsigned *part, unsigned *counter, unsigned &bar,
+                                            bool rowValid) {
+  const int passes = (ebit - sbit + 7) / 8;
+  const unsigned tile = blockIdx.x, numTiles = (n + RS_TILE - 1) / RS_TILE;
+  if (tile >= numTiles) return;  // the barriers below count the tiles' workgroups only
+  const unsigned G = numTiles;
+  for (int p = 0; p < passes; ++p) {
+    const int st = sbit + 8 * p;
+    const int bits = ebit - st < 8 ? ebit - st : 8;
+    const unsigned mask = (1u << bits) - 1u;
+    const bool last = p == passes - 1;
+    K *dstK = last ? out : ((p & 1) ? bufA : bufB);
+    int *dstV = last ? outV : ((p & 1) ? bufAV : bufBV);
+    if (p > 0 || !rowValid) {
+      rs_count_tile<K>(S.tileStart, src, n, tile, st, mask, part + (size_t)tile * 512 + 256);
+      rs_grid_barrier(counter, ++bar * G);
+    }
+    rs_split_tile<K, PAIR, false>(S, src, srcV, dstK, dstV, n, st, mask, part + 256, numTiles, tile, nullptr, sbit, nullptr);
+    if (!last) rs_grid_barrier(counter, ++bar * G);
+    src = dstK;
+    srcV = dstV;
+  }
+}
+
+// buckets: tk0 (written by the split kernel) -> kout; the other modes as the head comment says
+template <class K, bool PAIR>
+__global__ __launch_bounds__(RS_BLOCK) void radix_small_finish_kernel(const K *kin, const int *vin, K *tk0, int *tv0, K *tk1, int *tv1, K *kout,
+                                                                      int *vout, unsigned n, int sbit, unsigned *part, unsigned *ctl) {
+  constexpr int NW = RS_NW, ITEMS = RS_ITEMS, BLOCK = RS_BLOCK;
+  __shared__ RsLds<K, PAIR> S;
+  const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+  const unsigned mode = ctl[RS_CTL_MODE];
+  const int top = (int)ctl[RS_CTL_TOP];
+  const unsigned start0 = ctl[blockIdx.x], end0 = ctl[blockIdx.x + 1];  // (gridDim.x <= 256) this workgroup's first bucket, fetched with the mode
+  unsigned bar = 0;
+  if (mode == RS_COPY_IN || mode == RS_COPY_SPLIT) {
+    const K *sk = mode == RS_COPY_IN ? kin : tk0;
+    const int *sv = mode == RS_COPY_IN ? vin : tv0;
+    if (sk != kout)
+      for (unsigned i = blockIdx.x * BLOCK + t; i < n; i += gridDim.x * BLOCK) {
+        kout[i] = sk[i];
+        if constexpr (PAIR) vout[i] = sv[i];
+      }
+    return;
+  }
+  const unsigned big = mode == RS_ONE_BIG ? ctl[RS_CTL_BIG] : 256u;
+  volatile unsigned *wc = S.cnt[w];
+  const unsigned long long lt = lanemask_lt();
+  const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
+  for (unsigned b = blockIdx.x; b < (mode == RS_LSD ? 0u : 256u); b += gridDim.x) {
+    const unsigned start = b == blockIdx.x ? start0 : ctl[b], c = (b == blockIdx.x ? end0 : ctl[b + 1]) - start;
+    if (c == 0u || b == big) continue;
+    __syncthreads();  // (a second bucket of this workgroup: the first one's copy out of keyS is finished)
+    const int KI = (int)((c + BLOCK - 1) / BLOCK);  // items per thread for this bucket (<= ITEMS): positions stay (wave, item, lane)-ordered
+    const unsigned wpos = (unsigned)w * 64u * (unsigned)KI + (unsigned)lane;
+    const K *bk = tk0 + start;
+    const int *bv = PAIR ? tv0 + start : nullptr;
+    K key[ITEMS];
+    int val[ITEMS];
+    unsigned rank[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (k < KI && wpos + k * 64 < c) {
+        key[k] = bk[wpos + k * 64];
+        if constexpr (PAIR) val[k] = bv[wpos + k * 64];
+      }
+    for (int st = sbit; st < top; st += 8) {
+      const int bits = top - st < 8 ? top - st : 8;
+      const unsigned mask = (1u << bits) - 1u;
+      for (int i = t; i < NW * 256; i += BLOCK) (&S.cnt[0][0])[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k)
+        if (k < KI) {
+          const bool valid = wpos + k * 64 < c;
+          rank[k] = rs_rank_one(valid ? KeyBits<K>::digit(key[k], st, mask) : 0u, valid, wc, ltlo, lthi);
+        }
+      __syncthreads();
+      unsigned excl = 0;
+      if (t < 256) {
+        unsigned run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+          const unsigned cc = S.cnt[i][t];
+          S.cnt[i][t] = run;
+          run += cc;
+        }
+        unsigned s = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          unsigned o = shfl_up(s, d);
+          if (lane >= d) s += o;
+        }
+        if (lane == 63) S.sWave2[w] = s;
+        excl = s - run;
+      }
+      __syncthreads();
+      if (t < 256) {
+        for (int i = 0; i < w; ++i) excl += S.sWave2[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) S.cnt[i][t] += excl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k)
+        if (k < KI && wpos + k * 64 < c) {
+          const unsigned lp = S.cnt[w][KeyBits<K>::digit(key[k], st, mask)] + rank[k];
+          S.keyS[lp] = key[k];
+          if constexpr (PAIR) S.valS[lp] = val[k];
+        }
+      __syncthreads();
+      if (st + 8 < top) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)
+          if (k < KI && wpos + k * 64 < c) {
+            key[k] = S.keyS[wpos + k * 64];
+            if constexpr (PAIR) val[k] = S.valS[wpos + k * 64];
+          }
+      } else {
+        for (unsigned i = t; i < c; i += BLOCK) {
+          kout[start + i] = S.keyS[i];
+          if constexpr (PAIR) vout[start + i] = S.valS[i];
+        }
+      }
+    }
+  }
+  if (mode == RS_ONE_BIG || mode == RS_LSD) {
+    // RS_ONE_BIG: the one bucket too large for LDS -- its range of tk0 -> ... -> the same range of kout, by the bits below the top window.
+    // RS_LSD: the whole input -> ... -> kout by all differing bits.  (One call site: the body is inlined once.)
+    const bool whole = mode == RS_LSD;
+    const unsigned start = whole ? 0u : ctl[big], c = whole ? n : ctl[big + 1] - start;
+    __syncthreads();
+    rs_coop_lsd<K, PAIR>(S, whole ? kin : tk0 + start, !PAIR ? nullptr : (whole ? vin : tv0 + start), tk0 + start,
+                         PAIR ? tv0 + start : nullptr, tk1 + start, PAIR ? tv1 + start : nullptr, kout + start,
+                         PAIR ? vout + start : nullptr, c, sbit, whole ? (int)ctl[RS_CTL_EBIT] : top, part, ctl + RS_CTL_BAR, bar, whole);
+  }
+}
+
+// host side of the small path (see above).  grid of the finish launch: one workgroup per bucket, at most one per CU
+template <class K, bool PAIR>
+static void radix_sort_small(Launch &L, const K *kin, const int *vin, K *kout, int *vout, unsigned n, int sbit, int ebit, unsigned cus) {
+  const unsigned numTiles = ceil_div(n, RS_TILE);
+  const size_t partWords = (size_t)numTiles * 512;
+  unsigned *mem = (unsigned *)L.temp(sizeof(unsigned) * (RS_CTL_WORDS + 256 + partWords));
+  unsigned *ctl = mem, *part = mem + RS_CTL_WORDS + 256;
+  int *meta = (int *)(mem + RS_CTL_WORDS);
+  K *tk[2] = {(K *)L.temp(sizeof(K) * (size_t)n), (K *)L.temp(sizeof(K) * (size_t)n)};
+  int *tv[2] = {nullptr, nullptr};
+  if (PAIR) tv[0] = (int *)L.temp(sizeof(int) * (size_t)n), tv[1] = (int *)L.temp(sizeof(int) * (size_t)n);
+  hipLaunchKernelGGL((radix_small_hist_kernel<K>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, kin, n, sbit, ebit, part, meta, ctl);
+  hipLaunchKernelGGL((radix_small_split_kernel<K, PAIR>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0], n, sbit,
+                     (const unsigned *)part, (const int *)meta, numTiles, ctl);
+  hipLaunchKernelGGL((radix_small_finish_kernel<K, PAIR>), dim3(std::min(256u, cus)), dim3(RS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0],
+                     tk[1], tv[1], kout, vout, n, sbit, part, ctl);
+}
+
 template <class K, bool PAIR>
 static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, Port<K> kout, Port<int> vout, size_t n,
                             int sbit, int ebit) {
@@ -681,6 +1170,16 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
     hipLaunchKernelGGL((radix_copy_kernel<K, PAIR>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream,
                        contiguous_port<const K>(tmpK), contiguous_port<const int>(tmpV), kout, vout, n);
     return;
+  }
+  if constexpr (sizeof(K) == 4) {
+    static const int smallOff = [] { const char *e = getenv("ZS_ROCM_SORT_SMALL"); return e && atoi(e) == 0 ? 1 : 0; }();  // measurement only
+    // (the in-launch fallback needs every tile's workgroup resident at once: one per CU)
+    if (!smallOff && passes >= 2 && n <= RS_SMALL_MAX_N && ceil_div(n, RS_TILE) <= L.cu_count() && kin.contiguous() && kout.contiguous() &&
+        (!PAIR || (vin.contiguous() && vout.contiguous()))) {
+      radix_sort_small<K, PAIR>(L, kin.base + kin.idx, PAIR ? vin.base + vin.idx : nullptr, kout.base + kout.idx,
+                                PAIR ? vout.base + vout.idx : nullptr, (unsigned)n, sbit, ebit, L.cu_count());
+      return;
+    }
   }
   // 8192-key tiles at every size.  Measured at 1 M keys (122 tiles, all resident at once, so the look-back walks aggregates): smaller
   // tiles (2048 / 4096 keys) or wider look-back batches (16 / 32 / 64 descriptors per round trip) are all slower -- a pass costs

@@ -116,6 +116,17 @@ char *Launch::scan_control(size_t numTiles, unsigned &gen, unsigned &ticketBase,
   return a.ctl;
 }
 
+unsigned Launch::cu_count() {
+  DeviceContext &c = context(dev);
+  std::lock_guard<std::mutex> lk(c.mtx);
+  if (c.cuCount == 0) {
+    int v = 0;
+    ZSR_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    c.cuCount = v > 0 ? v : 1;
+  }
+  return (unsigned)c.cuCount;
+}
+
 void Launch::scan_control_reset() {
   DeviceContext::Arena &a = control();
   DeviceContext &c = context(dev);
