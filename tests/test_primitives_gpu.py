@@ -144,6 +144,8 @@ def _small_path_keys(kind, n, g):
     u = lambda: g.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
     if kind == "uniform":        # three launches, buckets finished in LDS
         return u()
+    if kind == "half_range":     # BASELINE config 1's ints in [-2^30, 2^30): half of the top window's digits occur, buckets of n / 128
+        return g.integers(-2**30, 2**30, n, dtype=np.int32)
     if kind == "morton":         # 30 significant bits under the 32-bit window: the split digit sits under the highest differing bit
         return g.integers(0, 2**30, n, dtype=np.int32)
     if kind == "narrow":
@@ -171,14 +173,14 @@ def _small_path_keys(kind, n, g):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["uniform", "morton", "narrow", "sorted", "equal", "two_values", "sentinel", "few_values", "outlier",
+@pytest.mark.parametrize("kind", ["uniform", "half_range", "morton", "narrow", "sorted", "equal", "two_values", "sentinel", "few_values", "outlier",
                                   "far_outlier"])
-@pytest.mark.parametrize("n,sbit,ebit", [(8193, 0, 32), (300_001, 0, 32), (300_001, 5, 29), (1_000_000, 0, 32), (1_572_864, 0, 32),
-                                         (1_572_865, 0, 32)])
+@pytest.mark.parametrize("n,sbit,ebit", [(8193, 0, 32), (300_001, 0, 32), (300_001, 5, 29), (1_000_000, 0, 32), (2_048_000, 0, 32),
+                                         (2_048_001, 0, 32)])
 def test_radix_sort_small_input_path_every_mode(pol, oracle, kind, n, sbit, ebit):
-    """The three-launch path for <= 1.5 M 4-byte keys (primitives.hip, "split + finish") in each of its modes, keys and pairs, against the
+    """The three-launch path for <= 2 048 000 4-byte keys (primitives.hip, "split + finish") in each of its modes, keys and pairs, against the
     oracle's restatement of the reference's stable LSD sort (execution/ExecutionPolicy.hpp:777-781 semantics: order by the bits
-    [sbit, ebit) of the sign-flipped key, ties in input order); 1 572 865 keys is the first size on the ordinary passes again."""
+    [sbit, ebit) of the sign-flipped key, ties in input order); 2 048 001 keys is the first size on the ordinary passes again."""
     import zpc_amd as zs
     k = _small_path_keys(kind, n, rng(n % 1000 + len(kind)))
     v = np.arange(n, dtype=np.int32)

@@ -55,10 +55,13 @@ def main(only=None, sizes=None, quiet=False, tv_cases=((16_000_000, 32, 25), (64
         out = torch.empty_like(a)
         v = torch.arange(n, dtype=torch.int32, device="cuda")
         vo = torch.empty_like(v)
-        add("reduce<i32,plus>", n, 4, timeit(lambda: zs.reduce(pol, a, None, out1)))
-        add("exclusive_scan<i32>", n, 8, timeit(lambda: zs.exclusive_scan(pol, a, out)))
-        add("radix_sort<i32> (32 bit)", n, 32, timeit(lambda: zs.radix_sort(pol, a, out), reps=5))
-        add("radix_sort_pair<i32,i32> (32 bit)", n, 64, timeit(lambda: zs.radix_sort_pair(pol, a, v, out, vo), reps=5))
+        # repetitions by size: a timed window of a few milliseconds at least (five 40-us sorts between two events measure the events' own
+        # ramp as much as the sorts: 45 us against 38 us over 200 repetitions)
+        reps = max(5, min(200, 200_000_000 // n))
+        add("reduce<i32,plus>", n, 4, timeit(lambda: zs.reduce(pol, a, None, out1), reps=max(20, reps)))
+        add("exclusive_scan<i32>", n, 8, timeit(lambda: zs.exclusive_scan(pol, a, out), reps=max(20, reps)))
+        add("radix_sort<i32> (32 bit)", n, 32, timeit(lambda: zs.radix_sort(pol, a, out), reps=reps))
+        add("radix_sort_pair<i32,i32> (32 bit)", n, 64, timeit(lambda: zs.radix_sort_pair(pol, a, v, out, vo), reps=reps))
         if n <= 16_000_000:
             import math
             passes = 1 + max(0, math.ceil(math.log2(max(1, n / 2048))))  # tile sort + global merge passes, 16 B/pair each

@@ -16,6 +16,8 @@ g = torch.Generator(device="cuda").manual_seed(11)
 def keys(kind, n):
     if kind == "uniform":
         return torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+    if kind == "c1":          # BASELINE config 1: ints in [-2^30, 2^30) -- half of the top window's digits occur
+        return torch.randint(-2 ** 30, 2 ** 30, (n,), dtype=torch.int32, device="cuda", generator=g)
     if kind == "narrow":      # one top-digit bucket -> the fallback passes
         return torch.randint(0, 70000, (n,), dtype=torch.int32, device="cuda", generator=g)
     if kind == "sentinel":    # 20 % of the keys are INT_MAX
@@ -45,8 +47,8 @@ def keys(kind, n):
 
 
 bad = 0
-for n in (1, 63, 511, 8192, 8193, 100_000, 777_777, 1_000_000, 1_572_864, 1_572_865):
-    for kind in ("uniform", "narrow", "sentinel", "equal", "dups", "morton", "sorted", "outlier", "far", "two"):
+for n in (1, 63, 511, 8192, 8193, 100_000, 777_777, 1_000_000, 1_572_864, 2_048_000, 2_048_001):
+    for kind in ("uniform", "c1", "narrow", "sentinel", "equal", "dups", "morton", "sorted", "outlier", "far", "two"):
         for (sb, eb) in ((0, 32), (4, 27), (0, 9), (16, 32)):
             a = keys(kind, n)
             v = torch.arange(n, dtype=torch.int32, device="cuda")
@@ -82,9 +84,9 @@ def timeit(fn, reps=50, warm=5):
 
 
 print("mode ZS_ROCM_SORT_SMALL=%s; us per sort: keys / pairs" % os.environ.get("ZS_ROCM_SORT_SMALL", "1"))
-for n in (10_000, 50_000, 100_000, 250_000, 500_000, 1_000_000, 1_500_000):
+for n in (10_000, 100_000, 250_000, 500_000, 1_000_000, 1_500_000, 2_000_000):
     row = []
-    for kind in ("uniform", "narrow", "morton", "sorted", "sentinel", "dups", "outlier"):
+    for kind in ("uniform", "c1", "narrow", "morton", "sorted", "sentinel", "dups", "outlier"):
         a = keys(kind, n)
         v = torch.arange(n, dtype=torch.int32, device="cuda")
         ko, vo = torch.empty_like(a), torch.empty_like(v)

@@ -395,8 +395,12 @@ template <class K> struct KeyBits {
 // scatters.  Keys are first permuted into tile-local digit order in LDS so that a wave writes contiguous runs.
 // Traffic: 4 B/key (histograms) + passes x (4 R + 4 W) instead of passes x (4 + 4 + 4) + count scans.
 // small-input path (below, "split + finish")
-constexpr unsigned RS_SMALL_CAP = RS_TILE;          // keys one workgroup finishes in LDS
-constexpr size_t RS_SMALL_MAX_N = 1536 * 1024;      // uniform keys: a bucket holds n/256 +- a few sqrt(n/256)
+constexpr int RSS_BLOCK = 1024, RSS_ITEMS = RS_TILE / RSS_BLOCK, RSS_NW = RSS_BLOCK / 64;  // its workgroups: 16 waves x 8 keys per lane -- a
+                                                                                         // workgroup has a CU to itself there, waves hide latency
+constexpr int RSS_FITEMS = 16;                                  // finish kernel: keys per lane of the bucket it holds in registers
+constexpr unsigned RS_SMALL_CAP = RSS_BLOCK * RSS_FITEMS;       // = 16384 keys one workgroup finishes in LDS
+constexpr size_t RS_SMALL_MAX_N = 2048 * 1000;      // keys spread over half of the top window's digits (ints in [-2^30, 2^30)) fill 128 buckets
+                                                    // of n/128 +- a few sqrt(n/128): 16 000 +- 500 at this size
 constexpr int RS_CTL_MODE = 257, RS_CTL_BAR = 258, RS_CTL_TOP = 259, RS_CTL_EBIT = 260, RS_CTL_BIG = 261, RS_CTL_WORDS = 320;
 enum : unsigned { RS_FAST = 0, RS_LSD = 1, RS_COPY_IN = 2, RS_COPY_SPLIT = 3, RS_ONE_BIG = 4 };
 constexpr unsigned OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
@@ -661,14 +665,15 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 }
 
 // ---------------------------------------------------------------------------------------- small inputs: split + finish
-// Below ~1.5 M 4-byte keys every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
+// Up to ~2 M 4-byte keys every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
 // all predecessors -> scatter) four times over, plus six launches.  The small path sorts in three launches, with no look-back and no memset:
 //   1. radix_small_hist_kernel: per-tile histogram of the TOP 8-bit digit of the bits that actually differ between the keys (below), by
 //      plain stores;
 //   2. radix_small_split_kernel: every tile sums the histograms of the tiles before it (independent loads, no waiting on anybody) and
 //      scatters its keys into the 256 top-digit buckets (stable);
-//   3. radix_small_finish_kernel: one workgroup per bucket sorts it by the remaining low bits inside LDS (LSD passes over <= 8192 keys
-//      held in registers) and writes it out.
+//   3. radix_small_finish_kernel: one workgroup per bucket sorts it by the remaining low bits inside LDS (LSD passes over <= 16384 keys
+//      held in registers, 4 / 8 / 16 per lane by the bucket's size) and writes it out.
+// Workgroups are 1024 threads: at these sizes a workgroup has a CU to itself, and 16 waves hide each other's latencies.
 // Which bits differ: a tile ORs (key ^ keys[0]) over its own keys and over 512 keys sampled across the whole input, and counts the window
 // under the highest differing bit hb_j it sees.  The split kernel takes the maximum hb over the tiles -- exact, every key is in some tile.
 // A tile that counted a lower window (the sample missed the top bit: outliers) still yields its row when all its keys share the digit of
@@ -676,17 +681,17 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 // codes, sorted inputs and equal keys all take the three launches.
 // The slow ways, all inside the finish launch (grid = one workgroup per CU at most, every one resident, so it can run a grid barrier; the
 // host takes the ordinary passes when the tiles outnumber the CUs):
-//   * one bucket above 8192 keys (a sentinel value, say): the other buckets are finished as usual, then all workgroups sort that one by
+//   * one bucket above 16384 keys (a sentinel value, say): the other buckets are finished as usual, then all workgroups sort that one by
 //     LSD passes over its own range -- tile histograms, barrier, histogram-sum split, barrier;
 //   * several: the same LSD passes over the whole input and only the differing bits.  Slower than the ordinary passes (a barrier costs more
 //     than a launch), the price of not launching passes that would return at once in the common case.
 // Same stable order every way.
 template <class K, bool PAIR> struct RsLds {
-  unsigned cnt[RS_NW][256];  // per-wave digit counters -> offsets
+  unsigned cnt[RSS_NW][256];  // per-wave digit counters -> offsets
   unsigned tileStart[256], globalStart[256];
-  unsigned sTot[RS_NW][256], sBelow[RS_NW][256];  // per-wave partial sums of the tiles' histogram rows
+  unsigned sTot[RSS_NW][256], sBelow[RSS_NW][256];  // per-wave partial sums of the tiles' histogram rows
   int hbS[256];              // highest differing bit seen by tile j
-  unsigned sWave[8], sWave2[4];
+  unsigned sWave[RSS_NW], sWave2[4];
   unsigned sBad, sOverCnt, sBig;
   K keyS[RS_TILE];
   int valS[PAIR ? RS_TILE : 1];
@@ -737,9 +742,9 @@ __device__ __forceinline__ void rs_count_tile(unsigned *h, const K *keys, unsign
   const int t = threadIdx.x;
   if (t < 256) h[t] = 0u;
   __syncthreads();
-  const unsigned base = tile * RS_TILE + (unsigned)wave_id() * (64 * RS_ITEMS) + lane_id();
+  const unsigned base = tile * RS_TILE + (unsigned)wave_id() * (64 * RSS_ITEMS) + lane_id();
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k)
+  for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) atomicAdd(&h[KeyBits<K>::digit(keys[base + k * 64], st, mask)], 1u);
   __syncthreads();
   if (t < 256) row[t] = h[t];
@@ -748,25 +753,25 @@ __device__ __forceinline__ void rs_count_tile(unsigned *h, const K *keys, unsign
 // part[tile][2][256]: row 0 = the tile's top window, row 1 = lowest digit [sbit, sbit + 8) (first pass of the whole-input LSD fallback);
 // meta[tile] = highest differing bit the tile saw (-1: none)
 template <class K>
-__global__ __launch_bounds__(RS_BLOCK) void radix_small_hist_kernel(const K *keys, unsigned n, int sbit, int ebit, unsigned *part, int *meta,
+__global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *keys, unsigned n, int sbit, int ebit, unsigned *part, int *meta,
                                                                     unsigned *ctl) {
   using U = typename KeyBits<K>::U;
   __shared__ unsigned h[2][256];
-  __shared__ unsigned sOr[RS_NW];
+  __shared__ unsigned sOr[RSS_NW];
   const int t = threadIdx.x, lane = lane_id(), w = wave_id();
-  h[t >> 8][t & 255] = 0u;
+  if (t < 512) h[t >> 8][t & 255] = 0u;
   const unsigned tile = blockIdx.x;
-  const unsigned base = tile * RS_TILE + (unsigned)w * (64 * RS_ITEMS) + lane;
-  K key[RS_ITEMS];
+  const unsigned base = tile * RS_TILE + (unsigned)w * (64 * RSS_ITEMS) + lane;
+  K key[RSS_ITEMS];
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k)
+  for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) key[k] = keys[base + k * 64];
   const U k0 = (U)keys[0];
-  const U ks = (U)keys[(size_t)t * n / RS_BLOCK];
+  const U ks = (U)keys[(size_t)t * n / RSS_BLOCK];
   if (tile == 0 && t == 0) ctl[RS_CTL_BAR] = 0u;
   U diff = ks ^ k0;
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k)
+  for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) diff |= (U)key[k] ^ k0;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) diff |= (U)__shfl_xor((unsigned)diff, d, 64);
@@ -774,18 +779,18 @@ __global__ __launch_bounds__(RS_BLOCK) void radix_small_hist_kernel(const K *key
   __syncthreads();
   unsigned all = 0;
 #pragma unroll
-  for (int i = 0; i < RS_NW; ++i) all |= sOr[i];
+  for (int i = 0; i < RSS_NW; ++i) all |= sOr[i];
   all &= (ebit >= 32 ? 0xFFFFFFFFu : (1u << ebit) - 1u) & ~((1u << sbit) - 1u);
   const int hb = all ? 31 - __clz((int)all) : -1;
   const int top = rs_top_of(hb, sbit);
 #pragma unroll
-  for (int k = 0; k < RS_ITEMS; ++k)
+  for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) {
       atomicAdd(&h[0][KeyBits<K>::digit(key[k], top, 0xFFu)], 1u);
       atomicAdd(&h[1][KeyBits<K>::digit(key[k], sbit, 0xFFu)], 1u);
     }
   __syncthreads();
-  part[(size_t)tile * 512 + t] = h[t >> 8][t & 255];
+  if (t < 512) part[(size_t)tile * 512 + t] = h[t >> 8][t & 255];
   if (t == 0) meta[tile] = hb;
 }
 
@@ -798,7 +803,7 @@ template <class K, bool PAIR, bool FIRST>
 __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, const int *vin, K *kout, int *vout, unsigned n, int st,
                                               unsigned mask, const unsigned *rows, unsigned numTiles, unsigned tile, const int *meta,
                                               int sbit, unsigned *ctl) {
-  constexpr int NW = RS_NW, ITEMS = RS_ITEMS, TILE = RS_TILE, BLOCK = RS_BLOCK;
+  constexpr int NW = RSS_NW, ITEMS = RSS_ITEMS, TILE = RS_TILE, BLOCK = RSS_BLOCK;
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
   const unsigned tileBase = tile * TILE;
   const unsigned tileCount = n - tileBase < (unsigned)TILE ? n - tileBase : (unsigned)TILE;
@@ -816,7 +821,8 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
     }
   // histogram rows: wave w reads the rows of the tiles j = w (mod 8), a whole row per load (lane q: digits 4q .. 4q + 3), all of them in
   // flight at once -- one memory round trip for the lot (workgroups have a CU each here: registers are free, latency is not)
-  constexpr int RB = (int)((RS_SMALL_MAX_N / RS_TILE + NW - 1) / NW);
+  // (batches of NW * RB = 128 rows: one batch up to 1 M keys, two above)
+  constexpr int RB = 8;
   uint4 rv[RB];
 #pragma unroll
   for (int u = 0; u < RB; ++u) {
@@ -849,9 +855,17 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
   {
     unsigned tot[4] = {0u, 0u, 0u, 0u}, below[4] = {0u, 0u, 0u, 0u};
     bool bad = false;
+    for (unsigned j0 = 0; j0 < numTiles; j0 += (unsigned)(NW * RB)) {
+    if (j0 != 0u) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const unsigned j = j0 + (unsigned)w + (unsigned)NW * u;
+        rv[u] = j < numTiles ? *reinterpret_cast<const uint4 *>(rows + (size_t)j * 512 + 4 * lane) : uint4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
-      const unsigned j = (unsigned)w + (unsigned)NW * u;
+      const unsigned j = j0 + (unsigned)w + (unsigned)NW * u;
       if (j < numTiles) {  // (wave-uniform)
         unsigned v[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
         if constexpr (FIRST) {
@@ -869,6 +883,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
           below[i] += j < tile ? v[i] : 0u;
         }
       }
+    }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -976,7 +991,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
 }
 
 template <class K, bool PAIR>
-__global__ __launch_bounds__(RS_BLOCK) void radix_small_split_kernel(const K *kin, const int *vin, K *kout, int *vout, unsigned n, int sbit,
+__global__ __launch_bounds__(RSS_BLOCK) void radix_small_split_kernel(const K *kin, const int *vin, K *kout, int *vout, unsigned n, int sbit,
                                                                      const unsigned *part, const int *meta, unsigned numTiles,
                                                                      unsigned *ctl) {
   __shared__ RsLds<K, PAIR> S;
@@ -1012,12 +1027,104 @@ __device__ __forceinline__ void rs_coop_lsd(RsLds<K, PAIR> &S, const K *src, con
   }
 }
 
+// One bucket of c <= MAXI * 1024 keys: into registers (positions stay (wave, item, lane)-ordered), LSD passes over the bits [sbit, top)
+// through LDS, out.
+template <class K, bool PAIR, int MAXI>
+__device__ __forceinline__ void rs_finish_bucket(unsigned (*cnt)[256], unsigned *sWave2, K *keyS, int *valS, const K *bk, const int *bv, K *ok,
+                                                 int *ov, unsigned c, int sbit, int top) {
+  constexpr int NW = RSS_NW, BLOCK = RSS_BLOCK;
+  const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+  const int KI = (int)((c + BLOCK - 1) / BLOCK);
+  const unsigned wpos = (unsigned)w * 64u * (unsigned)KI + (unsigned)lane;
+  volatile unsigned *wc = cnt[w];
+  const unsigned long long lt = lanemask_lt();
+  const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
+  K key[MAXI];
+  int val[MAXI];
+  unsigned rank[MAXI];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k)
+    if (k < KI && wpos + k * 64 < c) {
+      key[k] = bk[wpos + k * 64];
+      if constexpr (PAIR) val[k] = bv[wpos + k * 64];
+    }
+  for (int st = sbit; st < top; st += 8) {
+    const int bits = top - st < 8 ? top - st : 8;
+    const unsigned mask = (1u << bits) - 1u;
+    for (int i = t; i < NW * 256; i += BLOCK) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k)
+      if (k < KI) {
+        const bool valid = wpos + k * 64 < c;
+        rank[k] = rs_rank_one(valid ? KeyBits<K>::digit(key[k], st, mask) : 0u, valid, wc, ltlo, lthi);
+      }
+    __syncthreads();
+    unsigned excl = 0;
+    if (t < 256) {
+      unsigned run = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const unsigned cc = cnt[i][t];
+        cnt[i][t] = run;
+        run += cc;
+      }
+      unsigned s = run;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        unsigned o = shfl_up(s, d);
+        if (lane >= d) s += o;
+      }
+      if (lane == 63) sWave2[w] = s;
+      excl = s - run;
+    }
+    __syncthreads();
+    if (t < 256) {
+      for (int i = 0; i < w; ++i) excl += sWave2[i];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) cnt[i][t] += excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k)
+      if (k < KI && wpos + k * 64 < c) {
+        const unsigned lp = cnt[w][KeyBits<K>::digit(key[k], st, mask)] + rank[k];
+        keyS[lp] = key[k];
+        if constexpr (PAIR) valS[lp] = val[k];
+      }
+    __syncthreads();
+    if (st + 8 < top) {
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k)
+        if (k < KI && wpos + k * 64 < c) {
+          key[k] = keyS[wpos + k * 64];
+          if constexpr (PAIR) val[k] = valS[wpos + k * 64];
+        }
+    } else {
+      for (unsigned i = t; i < c; i += BLOCK) {
+        ok[i] = keyS[i];
+        if constexpr (PAIR) ov[i] = valS[i];
+      }
+    }
+  }
+}
+
 // buckets: tk0 (written by the split kernel) -> kout; the other modes as the head comment says
 template <class K, bool PAIR>
-__global__ __launch_bounds__(RS_BLOCK) void radix_small_finish_kernel(const K *kin, const int *vin, K *tk0, int *tv0, K *tk1, int *tv1, K *kout,
+__global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *kin, const int *vin, K *tk0, int *tv0, K *tk1, int *tv1, K *kout,
                                                                       int *vout, unsigned n, int sbit, unsigned *part, unsigned *ctl) {
-  constexpr int NW = RS_NW, ITEMS = RS_ITEMS, BLOCK = RS_BLOCK;
-  __shared__ RsLds<K, PAIR> S;
+  constexpr int NW = RSS_NW, ITEMS = RSS_FITEMS, BLOCK = RSS_BLOCK;
+  // LDS: the bucket layout (counters + up to 16384 keys and values) and the tile layout of the in-launch LSD passes share the bytes
+  struct FinLds {
+    unsigned cnt[NW][256];
+    unsigned sWave2[4];
+    K keyS[RS_SMALL_CAP];
+    int valS[PAIR ? RS_SMALL_CAP : 1];
+  };
+  constexpr size_t ldsBytes = sizeof(FinLds) > sizeof(RsLds<K, PAIR>) ? sizeof(FinLds) : sizeof(RsLds<K, PAIR>);
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[ldsBytes];
+  RsLds<K, PAIR> &S = *reinterpret_cast<RsLds<K, PAIR> *>(ldsRaw);
+  FinLds &F = *reinterpret_cast<FinLds *>(ldsRaw);
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
   const unsigned mode = ctl[RS_CTL_MODE];
   const int top = (int)ctl[RS_CTL_TOP];
@@ -1034,85 +1141,17 @@ __global__ __launch_bounds__(RS_BLOCK) void radix_small_finish_kernel(const K *k
     return;
   }
   const unsigned big = mode == RS_ONE_BIG ? ctl[RS_CTL_BIG] : 256u;
-  volatile unsigned *wc = S.cnt[w];
-  const unsigned long long lt = lanemask_lt();
-  const unsigned ltlo = (unsigned)lt, lthi = (unsigned)(lt >> 32);
   for (unsigned b = blockIdx.x; b < (mode == RS_LSD ? 0u : 256u); b += gridDim.x) {
     const unsigned start = b == blockIdx.x ? start0 : ctl[b], c = (b == blockIdx.x ? end0 : ctl[b + 1]) - start;
     if (c == 0u || b == big) continue;
     __syncthreads();  // (a second bucket of this workgroup: the first one's copy out of keyS is finished)
-    const int KI = (int)((c + BLOCK - 1) / BLOCK);  // items per thread for this bucket (<= ITEMS): positions stay (wave, item, lane)-ordered
-    const unsigned wpos = (unsigned)w * 64u * (unsigned)KI + (unsigned)lane;
-    const K *bk = tk0 + start;
-    const int *bv = PAIR ? tv0 + start : nullptr;
-    K key[ITEMS];
-    int val[ITEMS];
-    unsigned rank[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-      if (k < KI && wpos + k * 64 < c) {
-        key[k] = bk[wpos + k * 64];
-        if constexpr (PAIR) val[k] = bv[wpos + k * 64];
-      }
-    for (int st = sbit; st < top; st += 8) {
-      const int bits = top - st < 8 ? top - st : 8;
-      const unsigned mask = (1u << bits) - 1u;
-      for (int i = t; i < NW * 256; i += BLOCK) (&S.cnt[0][0])[i] = 0;
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k)
-        if (k < KI) {
-          const bool valid = wpos + k * 64 < c;
-          rank[k] = rs_rank_one(valid ? KeyBits<K>::digit(key[k], st, mask) : 0u, valid, wc, ltlo, lthi);
-        }
-      __syncthreads();
-      unsigned excl = 0;
-      if (t < 256) {
-        unsigned run = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-          const unsigned cc = S.cnt[i][t];
-          S.cnt[i][t] = run;
-          run += cc;
-        }
-        unsigned s = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          unsigned o = shfl_up(s, d);
-          if (lane >= d) s += o;
-        }
-        if (lane == 63) S.sWave2[w] = s;
-        excl = s - run;
-      }
-      __syncthreads();
-      if (t < 256) {
-        for (int i = 0; i < w; ++i) excl += S.sWave2[i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) S.cnt[i][t] += excl;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k)
-        if (k < KI && wpos + k * 64 < c) {
-          const unsigned lp = S.cnt[w][KeyBits<K>::digit(key[k], st, mask)] + rank[k];
-          S.keyS[lp] = key[k];
-          if constexpr (PAIR) S.valS[lp] = val[k];
-        }
-      __syncthreads();
-      if (st + 8 < top) {
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k)
-          if (k < KI && wpos + k * 64 < c) {
-            key[k] = S.keyS[wpos + k * 64];
-            if constexpr (PAIR) val[k] = S.valS[wpos + k * 64];
-          }
-      } else {
-        for (unsigned i = t; i < c; i += BLOCK) {
-          kout[start + i] = S.keyS[i];
-          if constexpr (PAIR) vout[start + i] = S.valS[i];
-        }
-      }
-    }
+    // items per lane by the bucket's size (each instantiation unrolled for exactly its count)
+    if (c <= 4u * BLOCK) rs_finish_bucket<K, PAIR, 4>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
+                                                       PAIR ? vout + start : nullptr, c, sbit, top);
+    else if (c <= 8u * BLOCK) rs_finish_bucket<K, PAIR, 8>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
+                                                            PAIR ? vout + start : nullptr, c, sbit, top);
+    else rs_finish_bucket<K, PAIR, 16>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
+                                        PAIR ? vout + start : nullptr, c, sbit, top);
   }
   if (mode == RS_ONE_BIG || mode == RS_LSD) {
     // RS_ONE_BIG: the one bucket too large for LDS -- its range of tk0 -> ... -> the same range of kout, by the bits below the top window.
@@ -1137,10 +1176,10 @@ static void radix_sort_small(Launch &L, const K *kin, const int *vin, K *kout, i
   K *tk[2] = {(K *)L.temp(sizeof(K) * (size_t)n), (K *)L.temp(sizeof(K) * (size_t)n)};
   int *tv[2] = {nullptr, nullptr};
   if (PAIR) tv[0] = (int *)L.temp(sizeof(int) * (size_t)n), tv[1] = (int *)L.temp(sizeof(int) * (size_t)n);
-  hipLaunchKernelGGL((radix_small_hist_kernel<K>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, kin, n, sbit, ebit, part, meta, ctl);
-  hipLaunchKernelGGL((radix_small_split_kernel<K, PAIR>), dim3(numTiles), dim3(RS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0], n, sbit,
+  hipLaunchKernelGGL((radix_small_hist_kernel<K>), dim3(numTiles), dim3(RSS_BLOCK), 0, L.stream, kin, n, sbit, ebit, part, meta, ctl);
+  hipLaunchKernelGGL((radix_small_split_kernel<K, PAIR>), dim3(numTiles), dim3(RSS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0], n, sbit,
                      (const unsigned *)part, (const int *)meta, numTiles, ctl);
-  hipLaunchKernelGGL((radix_small_finish_kernel<K, PAIR>), dim3(std::min(256u, cus)), dim3(RS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0],
+  hipLaunchKernelGGL((radix_small_finish_kernel<K, PAIR>), dim3(std::min(256u, cus)), dim3(RSS_BLOCK), 0, L.stream, kin, vin, tk[0], tv[0],
                      tk[1], tv[1], kout, vout, n, sbit, part, ctl);
 }
 
