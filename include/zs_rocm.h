@@ -161,7 +161,11 @@ ZS_ROCM_EXPORT void zs_rocm_scan_i32(zs_rocm_policy *, const int32_t *in, size_t
 ZS_ROCM_EXPORT void zs_rocm_scan_i64(zs_rocm_policy *, const int64_t *in, size_t n, int64_t *out, int64_t init, int op, int exclusive);
 ZS_ROCM_EXPORT void zs_rocm_scan_f32(zs_rocm_policy *, const float *in, size_t n, float *out, float init, int op, int exclusive);
 ZS_ROCM_EXPORT void zs_rocm_scan_f64(zs_rocm_policy *, const double *in, size_t n, double *out, double init, int op, int exclusive);
-/* stable LSD radix sort on bits [sbit, ebit); vals may be NULL for keys-only */
+/* stable radix sort on bits [sbit, ebit) of the sign-flipped key -- the order of zs::radix_sort / radix_sort_pair
+ * (execution/ExecutionPolicy.hpp:765-781; cuda: cub::DeviceRadixSort, cuda/execution/ExecutionPolicy.cuh:755-881); vals may be NULL for
+ * keys-only; kout may alias kin (the reference stages through temporaries).  Temporaries come from the policy's stream arena.
+ * Up to 2 048 000 4-byte keys in contiguous arrays take three launches (top-digit split + buckets finished in LDS), everything else
+ * one onesweep pass per 8 bits; the result is the same stable order either way. */
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_i32(zs_rocm_policy *, const int32_t *kin, const int32_t *vin, int32_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_u32(zs_rocm_policy *, const uint32_t *kin, const int32_t *vin, uint32_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
 ZS_ROCM_EXPORT void zs_rocm_radix_sort_i64(zs_rocm_policy *, const int64_t *kin, const int32_t *vin, int64_t *kout, int32_t *vout, size_t n, int sbit, int ebit);
