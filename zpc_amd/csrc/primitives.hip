@@ -667,10 +667,10 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 // ---------------------------------------------------------------------------------------- small inputs: split + finish
 // Up to ~2 M 4-byte keys every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
 // all predecessors -> scatter) four times over, plus six launches.  The small path sorts in three launches, with no look-back and no memset:
-//   1. radix_small_hist_kernel: per-tile histogram of the TOP 8-bit digit of the bits that actually differ between the keys (below), by
-//      plain stores;
+//   1. radix_small_hist_kernel: per-tile histogram of the top 9 bits that actually differ between the keys (below), by plain stores;
 //   2. radix_small_split_kernel: every tile sums the histograms of the tiles before it (independent loads, no waiting on anybody) and
-//      scatters its keys into the 256 top-digit buckets (stable);
+//      scatters its keys into 256 buckets (stable): the 512 bins taken in pairs -- the top 8-bit digit -- or, when the bins in use span
+//      fewer than 256, one bin per bucket counted from the first bin in use;
 //   3. radix_small_finish_kernel: one workgroup per bucket sorts it by the remaining low bits inside LDS (LSD passes over <= 16384 keys
 //      held in registers, 4 / 8 / 16 per lane by the bucket's size) and writes it out.
 // Workgroups are 1024 threads: at these sizes a workgroup has a CU to itself, and 16 waves hide each other's latencies.
@@ -689,10 +689,10 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 template <class K, bool PAIR> struct RsLds {
   unsigned cnt[RSS_NW][256];  // per-wave digit counters -> offsets
   unsigned tileStart[256], globalStart[256];
-  unsigned sTot[RSS_NW][256], sBelow[RSS_NW][256];  // per-wave partial sums of the tiles' histogram rows
+  unsigned sTot9[512], sBelow9[512];  // sums of the tiles' histogram rows (all tiles / the tiles before this one), by LDS atomics
   int hbS[256];              // highest differing bit seen by tile j
   unsigned sWave[RSS_NW], sWave2[4];
-  unsigned sBad, sOverCnt, sBig;
+  unsigned sBad, sOverCnt, sBig, sLo, sHi;
   K keyS[RS_TILE];
   int valS[PAIR ? RS_TILE : 1];
 };
@@ -731,8 +731,8 @@ __device__ __forceinline__ void rs_grid_barrier(unsigned *counter, unsigned targ
   __syncthreads();
 }
 
-__device__ __forceinline__ int rs_top_of(int hb, int sbit) {  // start of the 8-bit window under the highest differing bit
-  const int tp = hb + 1 - 8;
+__device__ __forceinline__ int rs_top_of(int hb, int sbit) {  // start of the 9-bit window under the highest differing bit
+  const int tp = hb + 1 - 9;
   return tp < sbit ? sbit : tp;
 }
 
@@ -750,16 +750,17 @@ __device__ __forceinline__ void rs_count_tile(unsigned *h, const K *keys, unsign
   if (t < 256) row[t] = h[t];
 }
 
-// part[tile][2][256]: row 0 = the tile's top window, row 1 = lowest digit [sbit, sbit + 8) (first pass of the whole-input LSD fallback);
+// part[tile][2][256]: row 0 = the tile's top window (9 bits, 512 counts packed two per word), row 1 = lowest digit [sbit, sbit + 8)
+// (first pass of the whole-input LSD fallback);
 // meta[tile] = highest differing bit the tile saw (-1: none)
 template <class K>
 __global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *keys, unsigned n, int sbit, int ebit, unsigned *part, int *meta,
                                                                     unsigned *ctl) {
   using U = typename KeyBits<K>::U;
-  __shared__ unsigned h[2][256];
+  __shared__ unsigned h[512 + 256];  // [0, 512): the 9-bit window; [512, 768): the lowest 8-bit digit
   __shared__ unsigned sOr[RSS_NW];
   const int t = threadIdx.x, lane = lane_id(), w = wave_id();
-  if (t < 512) h[t >> 8][t & 255] = 0u;
+  if (t < 768) h[t] = 0u;
   const unsigned tile = blockIdx.x;
   const unsigned base = tile * RS_TILE + (unsigned)w * (64 * RSS_ITEMS) + lane;
   K key[RSS_ITEMS];
@@ -786,11 +787,17 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *ke
 #pragma unroll
   for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) {
-      atomicAdd(&h[0][KeyBits<K>::digit(key[k], top, 0xFFu)], 1u);
-      atomicAdd(&h[1][KeyBits<K>::digit(key[k], sbit, 0xFFu)], 1u);
+      atomicAdd(&h[KeyBits<K>::digit(key[k], top, 0x1FFu)], 1u);
+      atomicAdd(&h[512 + KeyBits<K>::digit(key[k], sbit, 0xFFu)], 1u);
     }
   __syncthreads();
-  if (t < 512) part[(size_t)tile * 512 + t] = h[t >> 8][t & 255];
+  // row 0: 512 counts of at most 8192 each, two per word.  The split kernel reads a whole row with one 16-byte load per lane; lane l's four
+  // words hold the bins l + 64 i (i = 0 .. 7), so that its LDS accumulation of a row is free of bank conflicts
+  if (t < 256) {
+    const int l = t >> 2, q = t & 3;
+    part[(size_t)tile * 512 + t] = h[l + 128 * q] | (h[l + 128 * q + 64] << 16);
+  }
+  else if (t < 512) part[(size_t)tile * 512 + t] = h[256 + t];
   if (t == 0) meta[tile] = hb;
 }
 
@@ -809,6 +816,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
   const unsigned tileCount = n - tileBase < (unsigned)TILE ? n - tileBase : (unsigned)TILE;
   const bool full = tileCount == (unsigned)TILE;
   for (int i = t; i < NW * 256; i += BLOCK) (&S.cnt[0][0])[i] = 0;
+  if (t < 512) S.sTot9[t] = 0u, S.sBelow9[t] = 0u;
   K key[ITEMS];
   int val[ITEMS];
   unsigned rank[ITEMS];
@@ -819,9 +827,9 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
       key[k] = kin[base + k * 64];
       if constexpr (PAIR) val[k] = vin[base + k * 64];
     }
-  // histogram rows: wave w reads the rows of the tiles j = w (mod 8), a whole row per load (lane q: digits 4q .. 4q + 3), all of them in
-  // flight at once -- one memory round trip for the lot (workgroups have a CU each here: registers are free, latency is not)
-  // (batches of NW * RB = 128 rows: one batch up to 1 M keys, two above)
+  // histogram rows: wave w reads the rows of the tiles j = w (mod 16), a whole 1 KB row per load, all of a batch in flight at once -- one
+  // memory round trip for the lot (workgroups have a CU each here: registers are free, latency is not).  Batches of NW * RB = 128 rows:
+  // one batch up to 1 M keys, two above.  FIRST: 512 two-byte counts per row (lane q: bins q + 64 i); else 256 words (digits 4q .. 4q + 3).
   constexpr int RB = 8;
   uint4 rv[RB];
 #pragma unroll
@@ -832,7 +840,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
   int hbG = -1;
   unsigned dref = 0;
   if constexpr (FIRST) {
-    if (t == 0) S.sBad = 0u, S.sOverCnt = 0u, S.sBig = 0u;
+    if (t == 0) S.sBad = 0u, S.sOverCnt = 0u, S.sBig = 0u, S.sLo = 512u, S.sHi = 0u;
     int hj = -1;
     if (t < 256) {
       hj = t < (int)numTiles ? meta[t] : -1;
@@ -849,55 +857,105 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
 #pragma unroll
     for (int i = 0; i < NW; ++i) hbG = (int)S.sWave[i] > hbG ? (int)S.sWave[i] : hbG;
     st = rs_top_of(hbG, sbit);
-    mask = 0xFFu;
+    mask = 0x1FFu;
     dref = KeyBits<K>::digit(k0, st, mask);
+  } else {
+    __syncthreads();
   }
   {
-    unsigned tot[4] = {0u, 0u, 0u, 0u}, below[4] = {0u, 0u, 0u, 0u};
+    constexpr int NV = FIRST ? 8 : 4;
+    unsigned tot[NV], below[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tot[i] = 0u, below[i] = 0u;
     bool bad = false;
     for (unsigned j0 = 0; j0 < numTiles; j0 += (unsigned)(NW * RB)) {
-    if (j0 != 0u) {
+      if (j0 != 0u) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const unsigned j = j0 + (unsigned)w + (unsigned)NW * u;
+          rv[u] = j < numTiles ? *reinterpret_cast<const uint4 *>(rows + (size_t)j * 512 + 4 * lane) : uint4{0u, 0u, 0u, 0u};
+        }
+      }
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const unsigned j = j0 + (unsigned)w + (unsigned)NW * u;
-        rv[u] = j < numTiles ? *reinterpret_cast<const uint4 *>(rows + (size_t)j * 512 + 4 * lane) : uint4{0u, 0u, 0u, 0u};
-      }
-    }
+        if (j < numTiles) {  // (wave-uniform)
+          unsigned v[NV];
+          if constexpr (FIRST) {
+            const unsigned q[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
 #pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      const unsigned j = j0 + (unsigned)w + (unsigned)NW * u;
-      if (j < numTiles) {  // (wave-uniform)
-        unsigned v[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
-        if constexpr (FIRST) {
-          const int hj = S.hbS[j];
-          if (rs_top_of(hj, sbit) != st) {  // this tile counted a lower window: all its keys sit in keys[0]'s digit, or the row is lost
-            bad = bad || hj >= st;
-            const unsigned cj = j == numTiles - 1 ? n - j * TILE : (unsigned)TILE;
+            for (int i = 0; i < 4; ++i) v[2 * i] = q[i] & 0xFFFFu, v[2 * i + 1] = q[i] >> 16;
+            const int hj = S.hbS[j];
+            if (rs_top_of(hj, sbit) != st) {  // this tile counted a lower window: all its keys sit in keys[0]'s bin, or the row is lost
+              bad = bad || hj >= st;
+              const unsigned cj = j == numTiles - 1 ? n - j * TILE : (unsigned)TILE;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = 4u * lane + i == dref ? cj : 0u;
+              for (int i = 0; i < NV; ++i) v[i] = (unsigned)(lane + 64 * i) == dref ? cj : 0u;
+            }
+          } else {
+            v[0] = rv[u].x, v[1] = rv[u].y, v[2] = rv[u].z, v[3] = rv[u].w;
+          }
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            tot[i] += v[i];
+            below[i] += j < tile ? v[i] : 0u;
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          tot[i] += v[i];
-          below[i] += j < tile ? v[i] : 0u;
-        }
       }
     }
-    }
+    // (FIRST: this lane's bins are lane + 64 i, see radix_small_hist_kernel; else the digits 4 lane + i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      S.sTot[w][4 * lane + i] = tot[i];
-      S.sBelow[w][4 * lane + i] = below[i];
+    for (int i = 0; i < NV; ++i) {
+      const int bin = FIRST ? lane + 64 * i : NV * lane + i;
+      if (tot[i]) atomicAdd(&S.sTot9[bin], tot[i]);
+      if (below[i]) atomicAdd(&S.sBelow9[bin], below[i]);
     }
     if (FIRST && bad) S.sBad = 1u;
+    if constexpr (FIRST) {
+      // first / last bin in use: this lane's bins of this wave's rows, folded over the wave, one LDS atomic pair per wave
+      unsigned lo = 512u, hi = 0u;  // hi = last bin + 1
+#pragma unroll
+      for (int i = NV - 1; i >= 0; --i)
+        if (tot[i]) lo = (unsigned)(lane + 64 * i);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (tot[i]) hi = (unsigned)(lane + 64 * i) + 1u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+      }
+      if (lane == 0 && hi != 0u) atomicMin(&S.sLo, lo), atomicMax(&S.sHi, hi);
+    }
   }
   __syncthreads();
+  // FIRST: 512 fine bins -> 256 buckets.  Bins in use spanning fewer than 256: bucket = bin - first bin in use (keys that straddle a
+  // power of two, e.g. ints in [-2^30, 2^30), get 256 buckets instead of 128); otherwise bucket = bin / 2, the 8-bit digit.
+  bool fine = false;
+  unsigned off = 0;
+  if constexpr (FIRST) {
+    const int lo = (int)S.sLo, hi = (int)S.sHi - 1;
+    fine = hi - lo < 256;
+    off = fine ? (unsigned)lo : 0u;
+  }
+  auto bucket_of = [&](K k) -> unsigned {
+    const unsigned d = KeyBits<K>::digit(k, st, mask);
+    if constexpr (FIRST) return fine ? d - off : d >> 1;
+    else return d;
+  };
   unsigned bstart = 0, below = 0;
   if (t < 256) {
     unsigned tot = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) tot += S.sTot[i][t], below += S.sBelow[i][t];
+    if constexpr (FIRST) {
+      if (fine) {
+        if ((unsigned)t + off < 512u) tot = S.sTot9[t + off], below = S.sBelow9[t + off];
+      } else {
+        tot = S.sTot9[2 * t] + S.sTot9[2 * t + 1], below = S.sBelow9[2 * t] + S.sBelow9[2 * t + 1];
+      }
+    } else {
+      tot = S.sTot9[t], below = S.sBelow9[t];
+    }
     if (FIRST && tot > RS_SMALL_CAP) {
       atomicAdd(&S.sOverCnt, 1u);
       S.sBig = (unsigned)t;
@@ -915,10 +973,11 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
   if (t < 256)
     for (int i = 0; i < w; ++i) bstart += S.sWave2[i];
   if constexpr (FIRST) {
+    const int below_top = fine ? st : st + 1;  // the finish kernel sorts the bits [sbit, below_top)
     unsigned mode = RS_FAST;
-    if (hbG < 0) mode = RS_COPY_IN;              // no key differs from keys[0] inside the window: the input is its own sorted order
+    if (hbG < 0) mode = RS_COPY_IN;                   // no key differs from keys[0] inside the window: the input is its own sorted order
     else if (S.sBad) mode = RS_LSD;
-    else if (st == sbit) mode = RS_COPY_SPLIT;   // at most 8 differing bits: the split is the sort
+    else if (below_top == sbit) mode = RS_COPY_SPLIT;  // nothing left under the buckets: the split is the sort
     else if (S.sOverCnt == 1u) mode = RS_ONE_BIG;
     else if (S.sOverCnt > 1u) mode = RS_LSD;
     if (tile == 0 && t < 256) {
@@ -926,7 +985,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
       if (t == 255) ctl[256] = n;
       if (t == 0) {
         ctl[RS_CTL_MODE] = mode;
-        ctl[RS_CTL_TOP] = (unsigned)st;
+        ctl[RS_CTL_TOP] = (unsigned)below_top;
         ctl[RS_CTL_EBIT] = (unsigned)(hbG + 1);
         ctl[RS_CTL_BIG] = S.sBig;
       }
@@ -940,7 +999,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const bool valid = full || base + k * 64 < n;
-    rank[k] = rs_rank_one(valid ? KeyBits<K>::digit(key[k], st, mask) : 0u, valid, wc, ltlo, lthi);
+    rank[k] = rs_rank_one(valid ? bucket_of(key[k]) : 0u, valid, wc, ltlo, lthi);
   }
   __syncthreads();
   if (t < 256) {
@@ -973,7 +1032,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)
     if (full || base + k * 64 < n) {
-      const unsigned lp = S.cnt[w][KeyBits<K>::digit(key[k], st, mask)] + rank[k];
+      const unsigned lp = S.cnt[w][bucket_of(key[k])] + rank[k];
       S.keyS[lp] = key[k];
       if constexpr (PAIR) S.valS[lp] = val[k];
     }
@@ -983,7 +1042,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
     const unsigned lp = (unsigned)t + (unsigned)k * BLOCK;
     if (full || lp < tileCount) {
       const K kk = S.keyS[lp];
-      const unsigned dst = S.globalStart[KeyBits<K>::digit(kk, st, mask)] + lp;
+      const unsigned dst = S.globalStart[bucket_of(kk)] + lp;
       kout[dst] = kk;
       if constexpr (PAIR) vout[dst] = S.valS[lp];
     }
