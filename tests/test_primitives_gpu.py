@@ -360,6 +360,19 @@ def test_radix_sort_randomised_stress():
     assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
 
 
+def test_radix_sort_small_path_randomised_stress():
+    """tools/sort_small_stress.py: 300 random sizes (1 .. 2.1 M keys) x eleven key distributions (random ranges and offsets, sentinels,
+    sorted / reverse-sorted / block-sorted inputs, few distinct values, outliers at random distances, equal keys, two clusters) x random bit
+    windows, keys and pairs, against torch.sort(stable=True): every mode of the three-launch path, including the in-launch grid barriers"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_small_stress.py"), "300", "7"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
+
+
 def test_scan_interleaved_types_share_the_control_block():
     """tools/scan_stress.py: 300 scans alternating int32 (exclusive) and int64 (inclusive), 1 .. 3 M elements: scans of up to 4096 tiles run as
     ONE launch on generation-tagged descriptors in the stream's control block (no memset); descriptors left by earlier calls, of either
