@@ -218,3 +218,28 @@ def test_native_halo_plan_matches_the_python_plan():
                 assert np.array_equal(allk[p][pb[q[1]:q[1] + q[2]]], sk)
                 off += c
             assert blocks.shape[0] == off
+
+
+def test_small_input_sort_kernels_use_no_scratch_memory(tmp_path):
+    """The three kernels of the small-input radix sort must not use private (scratch) memory in any instantiation: two builds that did
+    (a __noinline__ device function; spilled VGPRs) sorted correctly but made a later, unrelated kernel on the same queue return wrong
+    results ("radix sort, up to 2 M 4-byte keys").  Read from the built code object's metadata."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "zpc_amd", "lib", "obj", "primitives.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("object file or llvm tools not present")
+    fat, co = str(tmp_path / "p.fat"), str(tmp_path / "p.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                           "--output=" + co, "--unbundle"])
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    seen = 0
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name or "radix_small" not in name.group(1):
+            continue
+        seen += 1
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
+        assert re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk).group(1) == "false", name.group(1)
+    assert seen >= 12  # hist x 4 key types, split and finish x 4 key types x {keys, pairs} (minus duplicates the linker folds)

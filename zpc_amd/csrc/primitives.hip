@@ -397,10 +397,12 @@ template <class K> struct KeyBits {
 // small-input path (below, "split + finish")
 constexpr int RSS_BLOCK = 1024, RSS_ITEMS = RS_TILE / RSS_BLOCK, RSS_NW = RSS_BLOCK / 64;  // its workgroups: 16 waves x 8 keys per lane -- a
                                                                                          // workgroup has a CU to itself there, waves hide latency
-constexpr int RSS_FITEMS = 16;                                  // finish kernel: keys per lane of the bucket it holds in registers
-constexpr unsigned RS_SMALL_CAP = RSS_BLOCK * RSS_FITEMS;       // = 16384 keys one workgroup finishes in LDS
-constexpr size_t RS_SMALL_MAX_N = 2048 * 1000;      // keys spread over half of the top window's digits (ints in [-2^30, 2^30)) fill 128 buckets
-                                                    // of n/128 +- a few sqrt(n/128): 16 000 +- 500 at this size
+// keys one workgroup of the finish kernel holds in registers and sorts in LDS: 16 per lane (16384) for 4-byte keys, 8 per lane for 8-byte keys
+template <class K> constexpr int rss_fitems() { return sizeof(K) == 4 ? 16 : 8; }
+template <class K> constexpr unsigned rs_small_cap() { return (unsigned)(RSS_BLOCK * rss_fitems<K>()); }
+// largest input: keys that fill only 128 buckets still fit (n/128 +- a few sqrt(n/128): 16 000 +- 500 at 2 048 000 4-byte keys)
+template <class K> constexpr size_t rs_small_max_n() { return sizeof(K) == 4 ? (size_t)2048 * 1000 : (size_t)1024 * 1000; }
+constexpr size_t RS_SMALL_MAX_TILES = 256;
 constexpr int RS_CTL_MODE = 257, RS_CTL_BAR = 258, RS_CTL_TOP = 259, RS_CTL_EBIT = 260, RS_CTL_BIG = 261, RS_CTL_WORDS = 320;
 enum : unsigned { RS_FAST = 0, RS_LSD = 1, RS_COPY_IN = 2, RS_COPY_SPLIT = 3, RS_ONE_BIG = 4 };
 constexpr unsigned OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *ke
                                                                     unsigned *ctl) {
   using U = typename KeyBits<K>::U;
   __shared__ unsigned h[512 + 256];  // [0, 512): the 9-bit window; [512, 768): the lowest 8-bit digit
-  __shared__ unsigned sOr[RSS_NW];
+  __shared__ U sOr[RSS_NW];
   const int t = threadIdx.x, lane = lane_id(), w = wave_id();
   if (t < 768) h[t] = 0u;
   const unsigned tile = blockIdx.x;
@@ -775,14 +777,20 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *ke
   for (int k = 0; k < RSS_ITEMS; ++k)
     if (base + k * 64 < n) diff |= (U)key[k] ^ k0;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) diff |= (U)__shfl_xor((unsigned)diff, d, 64);
-  if (lane == 0) sOr[w] = (unsigned)diff;
+  for (int d = 32; d >= 1; d >>= 1) {
+    if constexpr (sizeof(U) == 8)
+      diff |= (U)__shfl_xor((unsigned)diff, d, 64) | ((U)__shfl_xor((unsigned)(diff >> 32), d, 64) << 32);
+    else
+      diff |= (U)__shfl_xor((unsigned)diff, d, 64);
+  }
+  if (lane == 0) sOr[w] = diff;
   __syncthreads();
-  unsigned all = 0;
+  U all = 0;
 #pragma unroll
   for (int i = 0; i < RSS_NW; ++i) all |= sOr[i];
-  all &= (ebit >= 32 ? 0xFFFFFFFFu : (1u << ebit) - 1u) & ~((1u << sbit) - 1u);
-  const int hb = all ? 31 - __clz((int)all) : -1;
+  constexpr int KB = (int)sizeof(K) * 8;
+  all &= (ebit >= KB ? ~(U)0 : (U)(((U)1 << ebit) - 1u)) & (U) ~(U)(((U)1 << sbit) - 1u);
+  const int hb = all ? 63 - __clzll((long long)(unsigned long long)all) : -1;
   const int top = rs_top_of(hb, sbit);
 #pragma unroll
   for (int k = 0; k < RSS_ITEMS; ++k)
@@ -830,7 +838,8 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
   // histogram rows: wave w reads the rows of the tiles j = w (mod 16), a whole 1 KB row per load, all of a batch in flight at once -- one
   // memory round trip for the lot (workgroups have a CU each here: registers are free, latency is not).  Batches of NW * RB = 128 rows:
   // one batch up to 1 M keys, two above.  FIRST: 512 two-byte counts per row (lane q: bins q + 64 i); else 256 words (digits 4q .. 4q + 3).
-  constexpr int RB = 8;
+  constexpr int RB = sizeof(K) == 4 ? 8 : 4;  // (8-byte keys: registers are short at 1024 threads, and no build of these kernels may spill --
+                                              // see DESIGN, the trap under the small-input sort)
   uint4 rv[RB];
 #pragma unroll
   for (int u = 0; u < RB; ++u) {
@@ -956,7 +965,7 @@ __device__ __forceinline__ void rs_split_tile(RsLds<K, PAIR> &S, const K *kin, c
     } else {
       tot = S.sTot9[t], below = S.sBelow9[t];
     }
-    if (FIRST && tot > RS_SMALL_CAP) {
+    if (FIRST && tot > rs_small_cap<K>()) {
       atomicAdd(&S.sOverCnt, 1u);
       S.sBig = (unsigned)t;
     }
@@ -1172,13 +1181,14 @@ __device__ __forceinline__ void rs_finish_bucket(unsigned (*cnt)[256], unsigned 
 template <class K, bool PAIR>
 __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *kin, const int *vin, K *tk0, int *tv0, K *tk1, int *tv1, K *kout,
                                                                       int *vout, unsigned n, int sbit, unsigned *part, unsigned *ctl) {
-  constexpr int NW = RSS_NW, ITEMS = RSS_FITEMS, BLOCK = RSS_BLOCK;
+  constexpr int NW = RSS_NW, BLOCK = RSS_BLOCK;
+  constexpr unsigned CAP = rs_small_cap<K>();
   // LDS: the bucket layout (counters + up to 16384 keys and values) and the tile layout of the in-launch LSD passes share the bytes
   struct FinLds {
     unsigned cnt[NW][256];
     unsigned sWave2[4];
-    K keyS[RS_SMALL_CAP];
-    int valS[PAIR ? RS_SMALL_CAP : 1];
+    K keyS[CAP];
+    int valS[PAIR ? CAP : 1];
   };
   constexpr size_t ldsBytes = sizeof(FinLds) > sizeof(RsLds<K, PAIR>) ? sizeof(FinLds) : sizeof(RsLds<K, PAIR>);
   __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[ldsBytes];
@@ -1209,8 +1219,9 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *
                                                        PAIR ? vout + start : nullptr, c, sbit, top);
     else if (c <= 8u * BLOCK) rs_finish_bucket<K, PAIR, 8>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
                                                             PAIR ? vout + start : nullptr, c, sbit, top);
-    else rs_finish_bucket<K, PAIR, 16>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
-                                        PAIR ? vout + start : nullptr, c, sbit, top);
+    else if constexpr (CAP > 8u * BLOCK)
+      rs_finish_bucket<K, PAIR, 16>(F.cnt, F.sWave2, F.keyS, F.valS, tk0 + start, PAIR ? tv0 + start : nullptr, kout + start,
+                                    PAIR ? vout + start : nullptr, c, sbit, top);
   }
   if (mode == RS_ONE_BIG || mode == RS_LSD) {
     // RS_ONE_BIG: the one bucket too large for LDS -- its range of tk0 -> ... -> the same range of kout, by the bits below the top window.
@@ -1269,10 +1280,10 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
                        contiguous_port<const K>(tmpK), contiguous_port<const int>(tmpV), kout, vout, n);
     return;
   }
-  if constexpr (sizeof(K) == 4) {
+  {
     static const int smallOff = [] { const char *e = getenv("ZS_ROCM_SORT_SMALL"); return e && atoi(e) == 0 ? 1 : 0; }();  // measurement only
     // (the in-launch fallback needs every tile's workgroup resident at once: one per CU)
-    if (!smallOff && passes >= 2 && n <= RS_SMALL_MAX_N && ceil_div(n, RS_TILE) <= L.cu_count() && kin.contiguous() && kout.contiguous() &&
+    if (!smallOff && passes >= 2 && n <= rs_small_max_n<K>() && ceil_div(n, RS_TILE) <= L.cu_count() && kin.contiguous() && kout.contiguous() &&
         (!PAIR || (vin.contiguous() && vout.contiguous()))) {
       radix_sort_small<K, PAIR>(L, kin.base + kin.idx, PAIR ? vin.base + vin.idx : nullptr, kout.base + kout.idx,
                                 PAIR ? vout.base + vout.idx : nullptr, (unsigned)n, sbit, ebit, L.cu_count());
