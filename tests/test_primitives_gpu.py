@@ -360,6 +360,42 @@ def test_radix_sort_randomised_stress():
     assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
 
 
+@pytest.mark.parametrize("kind", ["uniform", "narrow", "sorted", "equal", "sentinel", "few_values", "outlier"])
+@pytest.mark.parametrize("n,sbit,ebit", [(300_001, 0, 64), (1_000_000, 0, 64), (1_000_000, 7, 50), (1_024_001, 0, 64)])
+def test_radix_sort_small_input_path_8_byte_keys(pol, kind, n, sbit, ebit):
+    """The same path for 8-byte keys (buckets of up to 8192 keys, up to seven LDS passes; 1 024 001 keys: the ordinary passes again): order by
+    the bits [sbit, ebit) of the sign-flipped key, ties in input order (numpy stable argsort of the extracted window)."""
+    import zpc_amd as zs
+    g = rng(n % 977 + len(kind))
+    if kind == "uniform":
+        k = g.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    elif kind == "narrow":
+        k = g.integers(0, 70000, n, dtype=np.int64) + (1 << 40)
+    elif kind == "sorted":
+        k = np.sort(g.integers(-2**63, 2**63 - 1, n, dtype=np.int64))
+    elif kind == "equal":
+        k = np.full(n, -(1 << 50) + 3, np.int64)
+    elif kind == "sentinel":
+        k = g.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+        k[g.random(n) < 0.2] = 2**63 - 1
+    elif kind == "few_values":
+        k = g.integers(-8, 8, n, dtype=np.int64) * (1 << 59) + g.integers(0, 3, n, dtype=np.int64)
+    else:
+        k = g.integers(0, 70000, n, dtype=np.int64)
+        k[n // 3], k[n - 1] = 70000 * 5, 1 << 45
+    v = np.arange(n, dtype=np.int32)
+    ko = torch.empty(n, dtype=torch.int64, device="cuda")
+    vo = torch.empty(n, dtype=torch.int32, device="cuda")
+    k1 = torch.empty(n, dtype=torch.int64, device="cuda")
+    zs.radix_sort_pair(pol, dev(k), dev(v), ko, vo, sbit=sbit, ebit=ebit)
+    zs.radix_sort(pol, dev(k), k1, sbit=sbit, ebit=ebit)
+    w = ((k.view(np.uint64) ^ np.uint64(1 << 63)) >> np.uint64(sbit)) & np.uint64((1 << (ebit - sbit)) - 1 if ebit - sbit < 64 else 2**64 - 1)
+    order = np.argsort(w, kind="stable")
+    assert np.array_equal(vo.cpu().numpy(), v[order])
+    assert np.array_equal(ko.cpu().numpy(), k[order])
+    assert np.array_equal(k1.cpu().numpy(), k[order])
+
+
 def test_radix_sort_small_path_randomised_stress():
     """tools/sort_small_stress.py: 300 random sizes (1 .. 2.1 M keys) x eleven key distributions (random ranges and offsets, sentinels,
     sorted / reverse-sorted / block-sorted inputs, few distinct values, outliers at random distances, equal keys, two clusters) x random bit
