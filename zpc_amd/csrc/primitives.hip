@@ -1195,6 +1195,13 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *
   RsLds<K, PAIR> &S = *reinterpret_cast<RsLds<K, PAIR> *>(ldsRaw);
   FinLds &F = *reinterpret_cast<FinLds *>(ldsRaw);
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+#ifdef ZS_RS_FORCE_SCRATCH  // measurement builds only (tools/repro/): makes this kernel use private memory, see DESIGN "a trap met on the way"
+  {
+    volatile unsigned junk[ZS_RS_FORCE_SCRATCH];
+    for (int i = 0; i < ZS_RS_FORCE_SCRATCH; ++i) junk[(i + threadIdx.x) % ZS_RS_FORCE_SCRATCH] = (unsigned)i;
+    if (junk[threadIdx.x % ZS_RS_FORCE_SCRATCH] == 0xFFFFFFFFu) ctl[RS_CTL_WORDS - 1] = 1u;
+  }
+#endif
   const unsigned mode = ctl[RS_CTL_MODE];
   const int top = (int)ctl[RS_CTL_TOP];
   const unsigned start0 = ctl[blockIdx.x], end0 = ctl[blockIdx.x + 1];  // (gridDim.x <= 256) this workgroup's first bucket, fetched with the mode
