@@ -403,7 +403,8 @@ template <class K> constexpr unsigned rs_small_cap() { return (unsigned)(RSS_BLO
 // largest input: keys that fill only 128 buckets still fit (n/128 +- a few sqrt(n/128): 16 000 +- 500 at 2 048 000 4-byte keys)
 template <class K> constexpr size_t rs_small_max_n() { return sizeof(K) == 4 ? (size_t)2048 * 1000 : (size_t)1024 * 1000; }
 constexpr size_t RS_SMALL_MAX_TILES = 256;
-constexpr int RS_CTL_MODE = 257, RS_CTL_BAR = 258, RS_CTL_TOP = 259, RS_CTL_EBIT = 260, RS_CTL_BIG = 261, RS_CTL_WORDS = 320;
+constexpr int RS_CTL_MODE = 257, RS_CTL_TOP = 259, RS_CTL_EBIT = 260, RS_CTL_BIG = 261, RS_CTL_TICKET = 264, RS_CTL_DONE = 272 /* [16] */,
+              RS_CTL_WORDS = 320;
 enum : unsigned { RS_FAST = 0, RS_LSD = 1, RS_COPY_IN = 2, RS_COPY_SPLIT = 3, RS_ONE_BIG = 4 };
 constexpr unsigned OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
 
@@ -681,12 +682,12 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 // A tile that counted a lower window (the sample missed the top bit: outliers) still yields its row when all its keys share the digit of
 // keys[0] in the true window (hb_j below it); otherwise the input goes the slow way.  So narrow key ranges under a wide [sbit, ebit), morton
 // codes, sorted inputs and equal keys all take the three launches.
-// The slow ways, all inside the finish launch (grid = one workgroup per CU at most, every one resident, so it can run a grid barrier; the
-// host takes the ordinary passes when the tiles outnumber the CUs):
-//   * one bucket above 16384 keys (a sentinel value, say): the other buckets are finished as usual, then all workgroups sort that one by
-//     LSD passes over its own range -- tile histograms, barrier, histogram-sum split, barrier;
-//   * several: the same LSD passes over the whole input and only the differing bits.  Slower than the ordinary passes (a barrier costs more
-//     than a launch), the price of not launching passes that would return at once in the common case.
+// The slow ways, all inside the finish launch:
+//   * one bucket above the LDS capacity (a sentinel value, say): the other buckets are finished as usual, then the workgroups sort that one
+//     by LSD passes over its own range -- per pass the tiles' histograms, then the tiles' histogram-sum splits, handed out as tickets
+//     (rs_coop_lsd: no co-residency assumed, no grid barrier);
+//   * several: the same LSD passes over the whole input and only the differing bits.  Slower than the ordinary passes (waiting for a phase
+//     inside a launch costs more than a launch boundary), the price of not launching passes that would return at once in the common case.
 // Same stable order every way.
 template <class K, bool PAIR> struct RsLds {
   unsigned cnt[RSS_NW][256];  // per-wave digit counters -> offsets
@@ -717,20 +718,6 @@ __device__ __forceinline__ unsigned rs_rank_one(unsigned d, bool valid, volatile
   if (valid && below == 0) wc[d] = old + (unsigned)__popc(plo) + (unsigned)__popc(phi);
   __builtin_amdgcn_wave_barrier();
   return old + below;
-}
-
-// all workgroups of the launch (every one resident): stores before it are visible to plain loads after it
-__device__ __forceinline__ void rs_grid_barrier(unsigned *counter, unsigned target) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
 }
 
 __device__ __forceinline__ int rs_top_of(int hb, int sbit) {  // start of the 9-bit window under the highest differing bit
@@ -771,7 +758,7 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_hist_kernel(const K *ke
     if (base + k * 64 < n) key[k] = keys[base + k * 64];
   const U k0 = (U)keys[0];
   const U ks = (U)keys[(size_t)t * n / RSS_BLOCK];
-  if (tile == 0 && t == 0) ctl[RS_CTL_BAR] = 0u;
+  if (tile == 0 && t < 24) ctl[RS_CTL_TICKET + t] = 0u;  // ticket counter and phase-completion counters of the in-launch LSD passes
   U diff = ks ^ k0;
 #pragma unroll
   for (int k = 0; k < RSS_ITEMS; ++k)
@@ -1066,32 +1053,61 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_split_kernel(const K *k
   rs_split_tile<K, PAIR, true>(S, kin, vin, kout, vout, n, 0, 0u, part, numTiles, blockIdx.x, meta, sbit, ctl);
 }
 
-// LSD passes over src[0, n) by the bits [sbit, ebit) by the first ceil(n / 8192) workgroups of the launch, one tile each (the others leave):
-// hop p writes out on the last pass, else bufA / bufB alternately (B first).  Row 1 of `part` carries the tile histograms; rowValid: it
-// already holds the first pass's (radix_small_hist_kernel counted it over the input).
+// LSD passes over src[0, n) by the bits [sbit, ebit), all inside the calling launch, by whichever of its workgroups are running: hop p
+// writes `out` on the last pass, else bufA / bufB alternately (B first).  Row 1 of `part` carries the tile histograms; rowValid: it already
+// holds the first pass's (radix_small_hist_kernel counted it over the input).
+// The work is a list of phases -- per pass: the tiles' histograms of the digit (unless rowValid covers it), then the tiles' splits -- and a
+// workgroup draws (phase, tile) tickets from one counter until the list is exhausted.  Before a phase's tile it waits until every tile of
+// the previous phase is done (a completion counter per phase).  No co-residency is assumed: a ticket is only ever held by a running
+// workgroup, and it waits only for tickets drawn before its own, so any number of resident workgroups >= 1 makes progress -- two such sorts
+// on two streams, or a busy device, cannot deadlock it the way a grid barrier over a fixed set of workgroups could.
 template <class K, bool PAIR>
 __device__ __forceinline__ void rs_coop_lsd(RsLds<K, PAIR> &S, const K *src, const int *srcV, K *bufA, int *bufAV, K *bufB, int *bufBV, K *out,
-                                            int *outV, unsigned n, int sbit, int ebit, unsigned *part, unsigned *counter, unsigned &bar,
-                                            bool rowValid) {
+                                            int *outV, unsigned n, int sbit, int ebit, unsigned *part, unsigned *ctl, bool rowValid) {
   const int passes = (ebit - sbit + 7) / 8;
-  const unsigned tile = blockIdx.x, numTiles = (n + RS_TILE - 1) / RS_TILE;
-  if (tile >= numTiles) return;  // the barriers below count the tiles' workgroups only
-  const unsigned G = numTiles;
-  for (int p = 0; p < passes; ++p) {
+  const unsigned numTiles = (n + RS_TILE - 1) / RS_TILE;
+  const unsigned first = rowValid ? 1u : 0u;          // phases q = first .. 2 passes - 1: q even = histograms of pass q / 2, q odd = its splits
+  const unsigned numPhases = 2u * (unsigned)passes - first;
+  const int t = threadIdx.x;
+  if (blockIdx.x >= numTiles) return;  // a phase has numTiles tickets: more workgroups than that would only poll
+  // (drawing the next ticket while the current one is worked on was measured: slower -- 102 -> 108 us on the outlier case at 1 M keys)
+  for (;;) {
+    __syncthreads();  // (the previous ticket's work is finished with S)
+    if (t == 0) S.sBig = __hip_atomic_fetch_add(ctl + RS_CTL_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = S.sBig;
+    const unsigned ph = ticket / numTiles, tile = ticket % numTiles;
+    if (ph >= numPhases) break;
+    if (ph > 0u) {
+      if (t == 0) {
+        while (__hip_atomic_load(ctl + RS_CTL_DONE + (ph - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < numTiles) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+    const unsigned q = ph + first;
+    const int p = (int)(q >> 1);
     const int st = sbit + 8 * p;
     const int bits = ebit - st < 8 ? ebit - st : 8;
     const unsigned mask = (1u << bits) - 1u;
     const bool last = p == passes - 1;
-    K *dstK = last ? out : ((p & 1) ? bufA : bufB);
-    int *dstV = last ? outV : ((p & 1) ? bufAV : bufBV);
-    if (p > 0 || !rowValid) {
-      rs_count_tile<K>(S.tileStart, src, n, tile, st, mask, part + (size_t)tile * 512 + 256);
-      rs_grid_barrier(counter, ++bar * G);
+    const K *sK = p == 0 ? src : (((p - 1) & 1) ? bufA : bufB);
+    const int *sV = p == 0 ? srcV : (((p - 1) & 1) ? bufAV : bufBV);
+    if ((q & 1u) == 0u) {
+      rs_count_tile<K>(S.tileStart, sK, n, tile, st, mask, part + (size_t)tile * 512 + 256);
+    } else {
+      K *dK = last ? out : ((p & 1) ? bufA : bufB);
+      int *dV = last ? outV : ((p & 1) ? bufAV : bufBV);
+      rs_split_tile<K, PAIR, false>(S, sK, sV, dK, dV, n, st, mask, part + 256, numTiles, tile, nullptr, sbit, nullptr);
     }
-    rs_split_tile<K, PAIR, false>(S, src, srcV, dstK, dstV, n, st, mask, part + 256, numTiles, tile, nullptr, sbit, nullptr);
-    if (!last) rs_grid_barrier(counter, ++bar * G);
-    src = dstK;
-    srcV = dstV;
+    // this tile of the phase is done: stores drained and written back, then counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(ctl + RS_CTL_DONE + ph, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1205,7 +1221,6 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *
   const unsigned mode = ctl[RS_CTL_MODE];
   const int top = (int)ctl[RS_CTL_TOP];
   const unsigned start0 = ctl[blockIdx.x], end0 = ctl[blockIdx.x + 1];  // (gridDim.x <= 256) this workgroup's first bucket, fetched with the mode
-  unsigned bar = 0;
   if (mode == RS_COPY_IN || mode == RS_COPY_SPLIT) {
     const K *sk = mode == RS_COPY_IN ? kin : tk0;
     const int *sv = mode == RS_COPY_IN ? vin : tv0;
@@ -1238,7 +1253,7 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *
     __syncthreads();
     rs_coop_lsd<K, PAIR>(S, whole ? kin : tk0 + start, !PAIR ? nullptr : (whole ? vin : tv0 + start), tk0 + start,
                          PAIR ? tv0 + start : nullptr, tk1 + start, PAIR ? tv1 + start : nullptr, kout + start,
-                         PAIR ? vout + start : nullptr, c, sbit, whole ? (int)ctl[RS_CTL_EBIT] : top, part, ctl + RS_CTL_BAR, bar, whole);
+                         PAIR ? vout + start : nullptr, c, sbit, whole ? (int)ctl[RS_CTL_EBIT] : top, part, ctl, whole);
   }
 }
 
@@ -1289,8 +1304,7 @@ static void radix_sort_impl(Launch &L, Port<const K> kin, Port<const int> vin, P
   }
   {
     static const int smallOff = [] { const char *e = getenv("ZS_ROCM_SORT_SMALL"); return e && atoi(e) == 0 ? 1 : 0; }();  // measurement only
-    // (the in-launch fallback needs every tile's workgroup resident at once: one per CU)
-    if (!smallOff && passes >= 2 && n <= rs_small_max_n<K>() && ceil_div(n, RS_TILE) <= L.cu_count() && kin.contiguous() && kout.contiguous() &&
+    if (!smallOff && passes >= 2 && n <= rs_small_max_n<K>() && kin.contiguous() && kout.contiguous() &&
         (!PAIR || (vin.contiguous() && vout.contiguous()))) {
       radix_sort_small<K, PAIR>(L, kin.base + kin.idx, PAIR ? vin.base + vin.idx : nullptr, kout.base + kout.idx,
                                 PAIR ? vout.base + vout.idx : nullptr, (unsigned)n, sbit, ebit, L.cu_count());
