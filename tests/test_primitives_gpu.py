@@ -409,6 +409,19 @@ def test_radix_sort_small_path_randomised_stress():
     assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
 
 
+def test_two_streams_sorting_in_the_in_launch_lsd_mode_do_not_wait_for_each_other():
+    """tools/sort_two_streams.py: two streams, each sorting 2 M keys in the small path's slowest mode (245 tiles each: more workgroups than
+    CUs together) while a third stream keeps the device busy; 100 rounds under a two-minute limit.  The in-launch passes are ticketed
+    (no co-residency assumed), so this must neither hang nor mis-sort."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_two_streams.py"), "100"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=120)
+    assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
+
+
 def test_scan_interleaved_types_share_the_control_block():
     """tools/scan_stress.py: 300 scans alternating int32 (exclusive) and int64 (inclusive), 1 .. 3 M elements: scans of up to 4096 tiles run as
     ONE launch on generation-tagged descriptors in the stream's control block (no memset); descriptors left by earlier calls, of either
