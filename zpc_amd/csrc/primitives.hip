@@ -668,16 +668,16 @@ template <class K, bool PAIR> __global__ void radix_copy_kernel(Port<const K> ki
 }
 
 // ---------------------------------------------------------------------------------------- small inputs: split + finish
-// Up to ~2 M 4-byte keys every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
+// Up to ~2 M 4-byte keys (1 M 8-byte keys) every tile of a pass is resident at once and a pass costs its latency chain (loads -> ranking -> look-back over
 // all predecessors -> scatter) four times over, plus six launches.  The small path sorts in three launches, with no look-back and no memset:
 //   1. radix_small_hist_kernel: per-tile histogram of the top 9 bits that actually differ between the keys (below), by plain stores;
 //   2. radix_small_split_kernel: every tile sums the histograms of the tiles before it (independent loads, no waiting on anybody) and
 //      scatters its keys into 256 buckets (stable): the 512 bins taken in pairs -- the top 8-bit digit -- or, when the bins in use span
 //      fewer than 256, one bin per bucket counted from the first bin in use;
 //   3. radix_small_finish_kernel: one workgroup per bucket sorts it by the remaining low bits inside LDS (LSD passes over <= 16384 keys
-//      held in registers, 4 / 8 / 16 per lane by the bucket's size) and writes it out.
+//      -- 8192 8-byte keys -- held in registers, 4 / 8 / 16 per lane by the bucket's size) and writes it out.
 // Workgroups are 1024 threads: at these sizes a workgroup has a CU to itself, and 16 waves hide each other's latencies.
-// Which bits differ: a tile ORs (key ^ keys[0]) over its own keys and over 512 keys sampled across the whole input, and counts the window
+// Which bits differ: a tile ORs (key ^ keys[0]) over its own keys and over 1024 keys sampled across the whole input, and counts the window
 // under the highest differing bit hb_j it sees.  The split kernel takes the maximum hb over the tiles -- exact, every key is in some tile.
 // A tile that counted a lower window (the sample missed the top bit: outliers) still yields its row when all its keys share the digit of
 // keys[0] in the true window (hb_j below it); otherwise the input goes the slow way.  So narrow key ranges under a wide [sbit, ebit), morton
