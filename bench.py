@@ -94,6 +94,10 @@ def parse():
     ap.add_argument("--outbox-cap", type=int, default=128, help="slotted storage: movers one 4^3-cell bin can send per step")
     ap.add_argument("--margin", type=int, default=1,
                     help="slotted storage: extra layers of grid blocks around the occupied ones (room to travel before a re-partition)")
+    ap.add_argument("--repartition", type=str, default="closed", choices=["closed", "open"],
+                    help="slotted storage, when to re-partition: closed = when the step's own status words ask for it (a particle lives in a "
+                         "block next to the partition's edge; polled asynchronously every side / 4 steps); open = r03's schedule derived "
+                         "from drift + gravity alone (kept to show what it misses: flags are logged, not fatal)")
     ap.add_argument("--no-at-rest", action="store_true",
                     help="skip the secondary measurements (short sub-runs of this script at rest: slotted, compact, unfused stand-alone P2G / G2P; "
                          "and the primitives / bht / TileVector rows of SURVEY 8(d))")
@@ -396,7 +400,6 @@ def main():
             g2p_ev.append((e2, e3))
 
     fused_ev = []
-    node_trace = []
 
     ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
 
@@ -431,22 +434,6 @@ def main():
         grid_update()
         if floor is not None:
             mt.apply_boundary(floor)
-        if os.environ.get("ZS_BENCH_TRACE_NODES"):
-            # [hunting a rare deviation] grid nodes with mass whose v_y is far from the column's drift, after every step
-            g = mt.grid.view(mt.nblocks, 7, a.side ** 3)
-            vy_free = drift_v[1] - 9.8 * dt * (done + 1)   # free fall
-            dev = torch.where(g[:, 0] > 0, (g[:, 2] - vy_free).abs(), torch.zeros_like(g[:, 2]))
-            top = torch.topk(dev.flatten(), 4)
-            nc_ = a.side ** 3
-            if not hasattr(mt, "_trace_keys"):
-                mt._trace_keys = mt.active_keys()
-            def _desc(dv, i):
-                b, c = int(i) // nc_, int(i) % nc_
-                k = mt._trace_keys[b]
-                cell = (int(k[0]) * a.side + c // (a.side * a.side), int(k[1]) * a.side + (c // a.side) % a.side, int(k[2]) * a.side + c % a.side)
-                return ("%.3f" % float(dv), "m=%.2e" % float(g[b, 0, c]), "v=(%.3f,%.3f,%.3f)" % tuple(float(g[b, 1 + d, c]) for d in range(3)), cell)
-            node_trace.append((done + 1, int((dev > float(os.environ["ZS_BENCH_TRACE_NODES"])).sum()), [_desc(dv, i) for dv, i in zip(top.values, top.indices)]))
-
     migrated = 0
 
     def prime_grid():
@@ -463,7 +450,9 @@ def main():
         from zpc_amd.dist import migrate_particles
         moved = (0, 0)
         if mt.slotted:
-            mt.unslot()   # occupied slots -> compact buffer (the step before a re-map stored v, C and the stress as well)
+            # occupied slots -> compact buffer (the step before a re-map stored v, C and the stress as well).  The period's status words
+            # are checked and folded into mt.slot_record first, and the particle count must be unchanged: nothing is ever dropped
+            mt.unslot(strict=(a.repartition == "closed" and not os.environ.get("ZS_BENCH_ABLATION")))
         if world > 1:
             to_c = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
             moved = migrate_particles(mt, pol, dist, rank, world, glo, ghi, a.side, to_c, lambda t: t.to(device), comm=comm)
@@ -483,119 +472,6 @@ def main():
             mt.slot(K=a.slot_rounds, outbox_cap=a.outbox_cap)
         unfused_step = step
         step = lambda timed, write_all=False, reorder=False: step_fused(timed, write_all, reorder)
-        if os.environ.get("ZS_BENCH_AUDIT") and os.environ.get("ZS_BENCH_TRACE_NODES") and not a.slotted:
-            # [hunting a rare deviation] keep the state in front of every step; at the first step that leaves a deviating node: repeat it
-            # from that state (does the result vary?) and compare a write-all repetition with G2P + P2G (the unfused kernels) particle by particle
-            def step(timed, write_all=False, reorder=False):
-                sb, sg = mt.buf.clone(), mt.grid.clone()
-                step_fused(timed, write_all, reorder)
-                if os.environ.get("ZS_BENCH_AUDIT_EVERY") and not getattr(mt, "_audited", False):
-                    # every step: the same step by the unfused kernels from the same state; what the NEXT step reads (m, x, F, logJp, grid) must agree
-                    fb, fg = mt.buf.clone(), mt.grid.clone()
-                    mt.buf.copy_(sb); mt.grid.copy_(sg)
-                    mt.g2p(binned=True); mt.clear_grid(); mt.p2g(binned=True); exchange(); grid_update()
-                    Vv = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
-                    bad = []
-                    for c in [0, 1, 2, 3] + list(range(16, mt.nchn if mt.nchn <= 26 else 26)):
-                        d = (Vv(fb)[:, c, :] - Vv(mt.buf)[:, c, :]).abs()
-                        nb = int((d > 1e-4).sum()) if c >= 16 else int((d > 1e-6).sum())
-                        if nb:
-                            i = int(d.flatten().argmax())
-                            bad.append((c, nb, float(d.flatten()[i]), i))
-                    gd = (fg - mt.grid).abs().view(mt.nblocks, 7, -1)
-                    gbad = [(c, int((gd[:, c] > 1e-3 * float(mt.grid.view(mt.nblocks, 7, -1)[:, c].abs().max())).sum())) for c in range(7)]
-                    if bad or any(n for _, n in gbad):
-                        print("[audit-every] step %d: fused and unfused disagree: particle channels %r grid %r" % (done + 1, bad, gbad), file=sys.stderr)
-                        ub, ug = mt.buf.clone(), mt.grid.clone()
-                        keys = mt.active_keys()
-                        S3 = a.side ** 3
-                        G = lambda t: t.view(mt.nblocks, 7, S3)
-                        dm = (G(fg)[:, 0] - G(ug)[:, 0])
-                        for i in torch.topk(dm.abs().flatten(), 16).indices.tolist():
-                            b, cc = i // S3, i % S3
-                            k = keys[b]
-                            print("[audit-every]    node %r block %d: mass fused - unfused %+.3e (unfused %.3e)  v_y fused %.5f unfused %.5f" % (
-                                (int(k[0]) * a.side + cc // (a.side * a.side), int(k[1]) * a.side + (cc // a.side) % a.side, int(k[2]) * a.side + cc % a.side), b,
-                                float(dm[b, cc]), float(G(ug)[b, 0, cc]), float(G(fg)[b, 2, cc]), float(G(ug)[b, 2, cc])), file=sys.stderr)
-                        print("[audit-every]    total mass fused %.9e unfused %.9e" % (float(G(fg)[:, 0].double().sum()), float(G(ug)[:, 0].double().sum())), file=sys.stderr)
-                        reps = []
-                        for _ in range(4):
-                            mt.buf.copy_(sb); mt.grid.copy_(sg)
-                            step_fused(False, False, False)
-                            node_trace.pop()
-                            reps.append(int(((G(mt.grid)[:, 0] - G(ug)[:, 0]).abs() > 1e-3 * float(G(ug)[:, 0].max())).sum()))
-                        print("[audit-every]    fused step repeated from the same state, nodes with a mass difference: %r" % reps, file=sys.stderr)
-                        mt.buf.copy_(sb); mt.grid.copy_(sg)
-                        step_fused(False, True, False)
-                        node_trace.pop()
-                        for c in range(mt.nchn):
-                            d = (Vv(mt.buf)[:, c, :] - Vv(ub)[:, c, :]).abs()
-                            d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
-                            sc = max(float(Vv(ub)[:, c, :].abs().max()), 1e-30)
-                            nb = int((d > 1e-3 * sc).sum())
-                            if nb:
-                                i = int(d.flatten().argmax()); t, l = i // mt.L, i % mt.L
-                                print("[audit-every]    write-all fused vs unfused, channel %d: %d entries off; worst at particle %d: %.6e vs %.6e" % (
-                                    c, nb, t * mt.L + l, float(Vv(mt.buf)[t, c, l]), float(Vv(ub)[t, c, l])), file=sys.stderr)
-                        # the bins around the worst node
-                        i = int(dm.abs().flatten().argmax()); b = i // S3
-                        bs, cc_ = mt.bin_start.cpu(), mt.cell_count.view(-1, 64).cpu()
-                        per = (a.side // 4) ** 3
-                        for bn in range(b * per, (b + 1) * per):
-                            print("[audit-every]    block %d bin %d: particles %d, cell counts max %d, cells %r" % (b, bn, int(bs[bn + 1] - bs[bn]), int(cc_[bn].max()), cc_[bn].tolist()), file=sys.stderr)
-                        mt._audited = True
-                        raise SystemExit(0)
-                    mt.buf.copy_(fb); mt.grid.copy_(fg)
-                    del fb, fg
-                if done < 5 or node_trace[-1][1] == 0 or getattr(mt, "_audited", False):
-                    return
-                mt._audited = True
-                torch.cuda.synchronize()
-                print("[audit] step %d left %d deviating nodes: %r" % (node_trace[-1][0], node_trace[-1][1], node_trace[-1][2]), file=sys.stderr)
-                keepb, keepg = mt.buf.clone(), mt.grid.clone()
-                counts = []
-                for _ in range(int(os.environ["ZS_BENCH_AUDIT"])):
-                    mt.buf.copy_(sb); mt.grid.copy_(sg)
-                    step_fused(False, True, False)
-                    counts.append(node_trace.pop()[1])
-                print("[audit] the step repeated from the saved state, deviating nodes: %s" % " ".join(map(str, counts)), file=sys.stderr)
-                fb, fg = mt.buf.clone(), mt.grid.clone()
-                mt.buf.copy_(sb); mt.grid.copy_(sg)
-                mt.g2p(binned=True); mt.clear_grid(); mt.p2g(binned=True); exchange(); grid_update()
-                torch.cuda.synchronize()
-                ub, ug = mt.buf, mt.grid
-                V = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
-                names = {0: "m", 1: "x", 4: "v", 7: "C", 16: "F", 25: "logJp"}
-                for c in range(mt.nchn):
-                    d = (V(fb)[:, c, :] - V(ub)[:, c, :]).abs()
-                    d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
-                    sc = float(V(ub)[:, c, :].abs().max())
-                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
-                    if nb:
-                        i = int(d.flatten().argmax()); t, l = i // mt.L, i % mt.L
-                        print("[audit] particle channel %d (%s): %d entries off by more than 1e-3 of the channel's max %.3e; worst %.3e at particle %d (tile %d lane %d): fused %.6e unfused %.6e"
-                              % (c, names.get(c, ""), nb, sc, float(d.flatten()[i]), t * mt.L + l, t, l, float(V(fb)[t, c, l]), float(V(ub)[t, c, l])), file=sys.stderr)
-                G = lambda t: t.view(mt.nblocks, 7, a.side ** 3)
-                for c in range(7):
-                    d = (G(fg)[:, c] - G(ug)[:, c]).abs()
-                    sc = float(G(ug)[:, c].abs().max())
-                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
-                    print("[audit] grid channel %d: %d nodes off (repeated fused vs unfused), max %.3e of %.3e" % (c, nb, float(d.max()), sc), file=sys.stderr)
-                    d = (G(keepg)[:, c] - G(ug)[:, c]).abs()
-                    nb = int((d > 1e-3 * max(sc, 1e-30)).sum())
-                    print("[audit] grid channel %d: %d nodes off (the deviating step itself vs unfused), max %.3e" % (c, nb, float(d.max())), file=sys.stderr)
-                    if nb and c == 2:
-                        keys = mt.active_keys()
-                        for i in torch.topk(d.flatten(), 6).indices.tolist():
-                            b, cc = i // a.side ** 3, i % a.side ** 3
-                            k = keys[b]
-                            print("[audit]    node %r: deviating step %.5f  unfused %.5f  mass %.3e" % (
-                                (int(k[0]) * a.side + cc // (a.side * a.side), int(k[1]) * a.side + (cc // a.side) % a.side, int(k[2]) * a.side + cc % a.side),
-                                float(G(keepg)[b, c, cc]), float(G(ug)[b, c, cc]), float(G(ug)[b, 0, cc])), file=sys.stderr)
-                # the particles around the worst node, as the deviating step left them (only the channels a non-write-all step stores are meaningful)
-                mt.buf, mt.grid = keepb, keepg
-                raise SystemExit(0)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -604,28 +480,34 @@ def main():
 
     K = a.migrate_every
     remaps = [0]
-    next_remap = None   # slotted, no --migrate-every: step count after which the next re-partition is due (derived, see below)
+    remap_steps = []
+    next_remap = None   # --repartition open: step count after which the next re-partition is due
+    closed_loop = a.slotted and K == 0 and a.repartition == "closed"
+    poll_iv = max(1, a.side // 4)   # the early warning leaves `side` cells of travel; the answer lags one interval, the re-map one more step
+    pending_remap = False
 
     def steps_in_margin(s0):
-        """how many steps from step s0 on the column (initial drift + gravity, the fastest component) stays inside the partition's margin"""
+        """(--repartition open) how many steps from step s0 on the column (initial drift + gravity) stays inside the partition's margin"""
         safe_cells = max(a.margin, 0) * a.side + a.side // 2 - 2
         v0 = max(abs(x) for x in drift_v) + 9.8 * s0 * dt   # (upper bound: gravity added to the largest component)
         k = 0
         while k < 100000 and (v0 * (k + 1) * dt + 0.5 * 9.8 * ((k + 1) * dt) ** 2) / dx <= safe_cells:
             k += 1
         return k
-    if K == 0 and a.slotted:
-        # A long window moves the column out of the partition's margin (the fused launch reports that and the run is refused): re-partition
-        # in time, inside the timing.  Every rank derives the same schedule from the initial drift and gravity; the period shrinks as the
-        # column accelerates (a fixed period derived at step 0 let a 3000-step run leave the partition).
+    if K == 0 and a.slotted and a.repartition == "open":
         n_steps = a.warmup + a.steps + 2
         k = steps_in_margin(0)
         if k < n_steps:
             next_remap = max(k, 8)
-            if rank == 0:
-                v0 = max(abs(x) for x in drift_v)
-                print("[bench] %d steps move the column %.1f cells: re-partitioning inside the timing, first after %d steps"
-                      % (n_steps, (v0 * n_steps * dt + 0.5 * 9.8 * (n_steps * dt) ** 2) / dx, next_remap), file=sys.stderr)
+
+    def reduce_flags(t):
+        if comm is not None:
+            comm.allreduce(pol, t, "max")
+        elif dist is not None:
+            tt = t if a.backend == "nccl" else t.cpu()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if tt is not t:
+                t.copy_(tt)
     done = 0
 
     # re-bin controller: particles that leave their cell make the fused launch slower step by step (LDS queue, exact path); a
@@ -640,9 +522,9 @@ def main():
     rebin_steps = []
 
     def run_steps(count, timed):
-        nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms, next_remap
+        nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms, next_remap, pending_remap
         for _ in range(count):
-            remap_now = (K > 0 and (done + 1) % K == 0) or (next_remap is not None and done + 1 >= next_remap)
+            remap_now = (K > 0 and (done + 1) % K == 0) or (next_remap is not None and done + 1 >= next_remap) or pending_remap
             if a.fused:
                 step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
             else:
@@ -651,28 +533,21 @@ def main():
             if remap_now:
                 remap()
                 remaps[0] += 1
+                remap_steps.append(done)
+                pending_remap = False
                 if next_remap is not None:
                     next_remap = done + max(steps_in_margin(done), 8)
                 ctrl_ev.clear()
                 best_ms, lost_ms = None, 0.0
+            elif closed_loop and done % poll_iv == 0:
+                # the step's own status words ask for the re-partition (word [3]: a particle lives in a block next to the partition's
+                # edge; or an overflow flag): asynchronous copy, answer of the previous poll -- no stall, same decision on every rank
+                pending_remap = mt.poll_repartition(reduce_flags if world > 1 else None)
             elif a.fused and not a.slotted and rebin_at is not None:
                 if done in rebin_at:
                     mt.rebin(inputs_only=True)
                     rebins += 1
                     rebin_steps.append(done)
-                    if os.environ.get("ZS_BENCH_CHECK_REBIN"):
-                        # [hunting a rare deviation] is the order a permutation, and did every carried channel arrive?
-                        o = mt.order.long()
-                        perm = bool((torch.sort(o).values == torch.arange(mt.n, device=o.device)).all())
-                        Vv = lambda t: t.view(mt.tiles, mt.nchn, mt.L)
-                        mism = {}
-                        for c in [0, 1, 2, 3] + list(range(16, min(mt.nchn, 26))):
-                            newc = Vv(mt.buf)[:, c, :].reshape(-1)[:mt.n]
-                            oldc = Vv(mt.buf2)[:, c, :].reshape(-1)[o]
-                            k = int((newc != oldc).sum())
-                            if k:
-                                mism[c] = k
-                        print("[rebin-check] after step %d: permutation %s, channel mismatches %r" % (done, perm, mism), file=sys.stderr)
                 ctrl_ev.clear()
             elif a.fused and not a.slotted and a.rebin_check > 0 and done >= next_check:
                 ctrl_ev[-1][1].synchronize()  # the look stalls the stream: done less often while nothing is being lost
@@ -727,22 +602,6 @@ def main():
         wgs = max(int(pv[7]), 1)
         print("probe (cycles per workgroup, 100 MHz-agnostic s_memtime ticks): " +
               " ".join("[%d]=%.0f" % (k, pv[k] / wgs / (4 if k in (0, 1, 4, 5, 6) else 8)) for k in range(7)) + " wgs=%d" % wgs, file=sys.stderr)
-    if a.fused and a.checksum and os.environ.get("ZS_BENCH_REPEAT_FINAL") and not a.slotted:
-        # [hunting a rare deviation] the final write-all step repeated from ONE saved state: does its result vary?
-        sb, sg = mt.buf.clone(), mt.grid.clone()
-        counts = []
-        thr = float(os.environ.get("ZS_BENCH_OUTLIERS", "4"))
-        for _ in range(int(os.environ["ZS_BENCH_REPEAT_FINAL"])):
-            mt.buf.copy_(sb)
-            mt.grid.copy_(sg)
-            step_fused(False, write_all=True)
-            torch.cuda.synchronize()
-            vv = mt.buf.view(mt.tiles, mt.nchn, mt.L)
-            counts.append(int((vv[:, 7:16, :].abs() > thr).any(dim=1).sum()))
-        print("[repeat-final] outlier counts: %s" % " ".join(map(str, counts)), file=sys.stderr)
-        mt.buf.copy_(sb)
-        mt.grid.copy_(sg)
-        del sb, sg
     if a.fused and a.checksum:
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
@@ -754,14 +613,22 @@ def main():
                          "or run with --no-overlap" % rank)
 
     movers_per_step = None
+    slot_record = None
     if a.slotted:
         try:
-            st = mt.check_slots()
+            mt.check_slots(strict=(a.repartition == "closed"))   # the last period; earlier ones were folded in by every unslot()
         except RuntimeError as e:
             if not os.environ.get("ZS_BENCH_ABLATION"):  # (measurement builds with parts of the step stubbed lose particles by construction)
-                raise SystemExit("rank %d: %s -- raise --slot-rounds / --outbox-cap / --margin, or re-partition (--migrate-every)" % (rank, e))
-            st = [0] * 8
-        movers_per_step = st[5] / max(a.steps + a.warmup, 1)
+                raise SystemExit("rank %d: %s -- raise --slot-rounds / --outbox-cap / --margin" % (rank, e))
+        rec = mt.slot_record
+        cnt_now = int(lib().zs_rocm_mpm_slot_list(pol.handle, mt.cell_mask.data_ptr(), mt.nbins, mt.K, None))
+        if cnt_now != mt.n and not os.environ.get("ZS_BENCH_ABLATION"):
+            raise SystemExit("rank %d: the slotted storage holds %d particles, %d went in" % (rank, cnt_now, mt.n))
+        movers_per_step = rec["sent"] / max(a.steps + a.warmup, 1)
+        slot_record = {"movers_sent": rec["sent"], "movers_rehomed": rec["homed"], "periods": rec["periods"],
+                       "periods_with_edge_warning": rec["edge_periods"],
+                       "periods_with_flag": {mt.SLOT_FLAG_NAMES[k]: rec["flags"][k] for k in (0, 1, 2, 4)},
+                       "particles_in_storage": cnt_now, "log": rec["log"][:16]}
     if a.fused and mt.left_partition():
         # the reference does not check this either (P2G.hpp:109-110), but a benchmark that loses mass is not a benchmark
         raise SystemExit("rank %d: particles left the sparse-grid partition (contributions dropped) -- use --migrate-every K to "
@@ -803,19 +670,6 @@ def main():
         valid = (torch.arange(ctiles * mt.L, device=device) < n_local).view(ctiles, 1, mt.L)
         sums = (v * valid).sum(dim=(0, 2))
         sq = ((v * valid) ** 2).sum(dim=(0, 2))
-        if os.environ.get("ZS_BENCH_TRACE_NODES"):
-            print("[trace] " + " ".join("%d:%d" % (t[0], t[1]) for t in node_trace), file=sys.stderr)
-            print("[trace-first] " + repr([t for t in node_trace if t[1] and t[0] > 8][-3:]), file=sys.stderr)
-        if os.environ.get("ZS_BENCH_OUTLIERS"):
-            print("[outliers] re-binned after steps %s" % ",".join(map(str, rebin_steps)), file=sys.stderr)
-            # where are velocity-gradient entries far outside the distribution (rms 0.44 in the default column)?  [hunting a rare difference]
-            big = (v[:, 7:16, :].abs() > float(os.environ["ZS_BENCH_OUTLIERS"])).any(dim=1) & valid[:, 0, :]
-            nbig = int(big.sum())
-            idx = torch.nonzero(big)[:8]
-            rows = [[int(t), int(l)] + [round(float(x), 4) for x in v[t, 1:4, l]] + [round(float(x), 3) for x in v[t, 7:16, l]] for t, l in idx.tolist()]
-            tl = torch.nonzero(big)[:, 0]
-            print("[outliers] |C| > %s: %d particles, tiles %s..%s; first: %r" % (os.environ["ZS_BENCH_OUTLIERS"], nbig, int(tl.min()) if nbig else -1,
-                                                                              int(tl.max()) if nbig else -1, rows), file=sys.stderr)
         cs = torch.cat([sums, sq]).to(comm_dev)
         # ... and the same sums without the particles that carry a velocity-gradient entry beyond 8 rms.  Two kinds exist: the two edge
         # particles of the column that have such entries in every run, and what a hit of the reference arena's rounding case leaves behind
@@ -875,7 +729,10 @@ def main():
                                    "moves it (new slot by ticket inside its bin; across bins: global atomics + an outbox record of %d per bin, "
                                    "re-homed by a second small kernel) -- no re-bins in the time loop"
                                    % (a.slot_rounds, a.outbox_cap)) if a.slotted else "compact round-robin order + re-bin controller",
-                       "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0},
+                       "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0,
+                       "repartition_trigger": (("closed loop: status word [3] of the slotted step, polled every %d steps" % poll_iv) if closed_loop
+                                               else ("every %d steps" % K if K else ("open loop (drift + gravity)" if a.slotted else "none"))),
+                       "repartition_steps": remap_steps[:64], "slot_record_rank0": slot_record},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,

@@ -631,12 +631,15 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_g2p(zs_rocm_policy *, const zs_rocm_mpm_params *
  * claim (unsigned; zeroed by the caller ONCE, every step leaves it zero), moverRec (float) -- their sizes in bytes come from
  * zs_rocm_mpm_slot_outbox_bytes(nbins, outboxCap, which = 0 / 1 / 2).  status: int[ZS_ROCM_SLOT_STATUS_WORDS], zeroed by the caller,
  * latched: [0] an outbox was full, [1] a
- * cell ran out of rounds, [2] mass or a mover for a block outside the partition, [3] unused, [4] a particle was not stored under its cell,
- * or moved more than one cell in a step; [8, 264) and [264, 520): movers sent / re-homed (running sums spread over 256 words each: a
- * single device-wide word would serialise one atomic per bin); unequal totals = particles were dropped ([1], [2] say why).  What a
- * reported overflow costs: a mover that finds its outbox full, its new cell (inside the bin) full, or has moved too far KEEPS its old slot
- * with its new state (nothing is lost; it is skipped -- [4] -- until the caller re-slots the storage); a record whose destination cell in
- * ANOTHER bin has no free round, or whose block is not in the partition, is dropped.
+ * cell ran out of rounds, [2] mass or a mover for a block outside the partition, [3] early warning: a particle lives in a block flagged by
+ * blockEdge (re-partition within `side` steps), [4] a particle was not stored under its cell, or moved more than one cell in a step;
+ * [8, 264) and [264, 520): movers sent / re-homed (running sums spread over 256 words each: a single device-wide word would serialise one
+ * atomic per bin); the totals are equal after every step.  NO PARTICLE IS EVER DROPPED (the reference writes every particle back,
+ * G2P.hpp:67-82): a mover that finds its outbox full, its new cell full (inside the bin or, r04, in another bin: slot_rehome_kernel puts
+ * it back), its destination block missing from the partition (r04), or that has moved more than a cell KEEPS its old slot with its new
+ * state; it is then stored under the wrong cell and skipped ([4]) until the caller re-slots the storage (unslot / re-partition / slot),
+ * which the flags [0], [1], [2] ask for.  Only GRID contributions can be dropped ([2]: a stencil node whose block is missing; the
+ * reference does not check that either, P2G.hpp:109-110).
  * The per-particle arithmetic is that of zs_rocm_mpm_g2p2g (G2P.hpp:44-83 + P2G.hpp:51-125). */
 #define ZS_ROCM_SLOT_STATUS_WORDS (8 + 2 * 256)
 ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_outbox_bytes(size_t nbins, int outboxCap, int which); /* 0 moverCount, 1 claim words, 2 moverRec */
@@ -646,6 +649,27 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_slot_particles(zs_rocm_policy *, const zs_rocm_bh
                                               int keyIsOrigin, int K, const float *src, float *dst, int C, unsigned *cellMask, int *status);
 /* occupied slots in slot order (slots may be NULL: count only); synchronises */
 ZS_ROCM_EXPORT size_t zs_rocm_mpm_slot_list(zs_rocm_policy *, const unsigned *cellMask, size_t nbins, int K, int *slots);
+/* the slotted storage's buffers in one POD (all device pointers, owned by the caller) */
+typedef struct zs_rocm_slot_storage {
+  unsigned *cellMask; /* [nbins][64] */
+  int K;
+  const int *nbr;     /* [nblocks][8]  zs_rocm_mpm_build_neighbors */
+  const int *nbr27;   /* [nblocks][27] zs_rocm_mpm_build_neighbors27 */
+  int *moverCount;
+  unsigned *claim;
+  float *moverRec;
+  int outboxCap;
+  int *status;        /* [ZS_ROCM_SLOT_STATUS_WORDS] */
+  const unsigned char *blockEdge; /* [nblocks] from zs_rocm_mpm_partition_edge, or NULL (no early warning in status[3]) */
+} zs_rocm_slot_storage;
+/* edge[i] = 1 if one of the blocks at offsets [lo, hi]^3 of block i is not in the partition (lo = -1, hi = 2: a particle of a block with
+ * edge == 0 can move into any neighbouring block and still scatter its whole stencil) */
+ZS_ROCM_EXPORT void zs_rocm_mpm_partition_edge(zs_rocm_policy *, const zs_rocm_bht_3 *, unsigned char *edge /* [nblocks] */, int keyStride,
+                                               int lo, int hi);
+/* the step over blocks [blockBegin, blockEnd) on the storage `st` (see zs_rocm_mpm_g2p2g_slotted_range for finish) */
+ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
+                                           const float *gridA, float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll,
+                                           size_t blockBegin, size_t blockEnd, int finish);
 ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
                                              const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr,
                                              const int *nbr27, int *moverCount, unsigned *claim, float *moverRec, int outboxCap,
@@ -746,6 +770,35 @@ ZS_ROCM_EXPORT size_t zs_rocm_dist_halo_plan_blocks(const zs_rocm_halo_plan *);
 ZS_ROCM_EXPORT size_t zs_rocm_dist_halo_plan_bytes(const zs_rocm_halo_plan *);   /* bytes sent (= received) per exchange of all 7 channels */
 ZS_ROCM_EXPORT const int *zs_rocm_dist_halo_plan_block_list(const zs_rocm_halo_plan *);   /* device */
 ZS_ROCM_EXPORT int zs_rocm_dist_halo_plan_exchange(zs_rocm_halo_plan *, zs_rocm_dist *, zs_rocm_policy *, float *grid, int chn0, int nchn);
+/* a plan from explicit lists (host arrays): slice k of blocks[total] = local block numbers shared with rank peerRank[k] */
+ZS_ROCM_EXPORT zs_rocm_halo_plan *zs_rocm_dist_halo_plan_from_lists(zs_rocm_dist *, int side, int npeers, const int *peerRank,
+                                                                    const size_t *peerOffset, const size_t *peerCount, const int *blocks,
+                                                                    size_t total);
+/* One sub-step of the slotted MPM path in ONE call (zpc_amd/csrc/dist.hip): gridB := 0; fused G2P (gridA) + P2G (gridB) over the boundary
+ * blocks [0, nBoundary), then the interior blocks (+ re-home / commit); the ghost-block exchange of the plan on commPolicy's stream behind
+ * the boundary range, overlapping the interior; grid update of gridB (extf, maxVelSqr) [+ collider]; allreduce(max) of maxVelSqr.  Nothing
+ * of the caller runs between the kernels.  dist / plan / commPolicy / maxVelSqr / collider / haloGrid may be NULL (single rank: no exchange).
+ * haloGrid: the grid whose shared blocks are exchanged (NULL: gridB).  The reference's building blocks for such a schedule are
+ * pol.device(i) / .stream(i) / .listen() (cuda/execution/ExecutionPolicy.cuh:364-399). */
+typedef struct zs_rocm_mpm_step {
+  const zs_rocm_mpm_params *params;
+  zs_rocm_particles particles;
+  const zs_rocm_bht_3 *table;
+  const float *gridA;
+  float *gridB;
+  size_t nblocks;
+  const zs_rocm_slot_storage *storage;
+  int writeAll;
+  float extf[3];
+  float *maxVelSqr;
+  const zs_rocm_collider *collider;
+  size_t nBoundary;
+  zs_rocm_dist *dist;
+  zs_rocm_halo_plan *plan;
+  zs_rocm_policy *commPolicy;
+  float *haloGrid;
+} zs_rocm_mpm_step;
+ZS_ROCM_EXPORT int zs_rocm_mpm_step_slotted(zs_rocm_policy *, const zs_rocm_mpm_step *);
 
 #ifdef __cplusplus
 }

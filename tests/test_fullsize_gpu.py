@@ -368,3 +368,97 @@ def test_config3_jello_8m_slotted_moving_subbox_vs_oracle(pol, oracle):
     r = _id_box_step(pol, oracle, 0, 256, (100, 100, 100), (0.0, -0.5, 0.0), (112, 32, 112), steps_before=8)
     assert r["x"] <= 1e-6 and r["v"] <= 2e-4 and r["C"] <= 2e-4 and r["F"] <= 2e-5, r
     assert max(r["grid"]) <= 2e-4 and r["grid_mass_interior"] > 0, r
+
+
+# ------------------------------------------------------------------------------------------------ r04: conservation across re-partitions
+def test_config4_sand_64m_480_steps_closed_loop_repartitions_lose_nobody():
+    """The r03 soak lost 227 211 of the 67 108 864 particles over 3000 steps and 38 re-partitions without a word (a mover whose
+    destination block was not in the partition was dropped, and every re-partition started a fresh status buffer).  480 steps of the
+    accelerating column (30 cells of fall), re-partitioned whenever the slotted step's own status word asks for it: >= 3 re-partitions,
+    particle count exact, mass sum exact to 1e-9, every mover re-homed, no flag in any period.  Reference semantics: every particle is
+    written back, simulation/transfer/G2P.hpp:67-82."""
+    a = _bench(["--steps", "480", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest"])
+    n = 67_108_864
+    c = a["config"]
+    rec = c["slot_record_rank0"]
+    assert c["particles"] == n and a["hip_error"] == 0
+    assert c["repartitions"] >= 3 and c["repartition_trigger"].startswith("closed loop"), (c["repartitions"], c["repartition_steps"])
+    assert rec["particles_in_storage"] == n and rec["movers_sent"] == rec["movers_rehomed"] > 100_000_000, rec
+    assert not any(rec["periods_with_flag"].values()) and rec["periods"] == c["repartitions"] + 1, rec
+    assert rec["periods_with_edge_warning"] >= c["repartitions"], rec
+    m = 1000.0 * (1.0 / 512) ** 3 / 8
+    assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
+
+
+def test_config4_sand_64m_identities_survive_400_steps_and_repartitions(pol):
+    """The same property particle by particle: the 262 144 particles of a 32^3-cell sub-box at the FOOT of the 64 Mi column (where the
+    column leaves the partition first) carry pairwise different masses; after 400 closed-loop steps with >= 3 re-partitions the storage
+    holds exactly those identities once each, and exactly n particles."""
+    import bench
+    import zpc_amd
+    from zpc_amd.mpm import MpmTransfer
+    grid_n, cells, model, side = 512, (128, 512, 128), 1, 8
+    dx, dt = 1.0 / grid_n, 1e-4
+    glo = [(grid_n - cells[0]) // 2 // side * side, 0, (grid_n - cells[2]) // 2 // side * side]
+    ghi = [glo[d] + cells[d] for d in range(3)]
+    dev = torch.device("cuda", 0)
+    aos = bench.generate_particles(glo, ghi, dx, 1234, dev, model)
+    aos[:, 5] += -1.0
+    n = aos.shape[0]
+    m0 = float(aos[0, 0].item())
+    cell = torch.floor(aos[:, 1:4] / dx).to(torch.int32)
+    box_lo = (glo[0], 0, glo[2])          # a corner of the column's foot
+    inb = torch.ones(n, dtype=torch.bool, device=dev)
+    for d in range(3):
+        inb &= (cell[:, d] >= box_lo[d]) & (cell[:, d] < box_lo[d] + 32)
+    ids = torch.nonzero(inb).flatten()
+    nid = int(ids.numel())
+    assert nid == 32 ** 3 * 8
+    aos[:, 0] = 0.99 * m0
+    want_ids = (m0 * (1.0 + torch.arange(nid, device=dev, dtype=torch.float64) * 2.0 ** -20)).float()
+    aos[ids, 0] = want_ids
+    del cell, inb
+    vol = dx ** 3 / 8
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
+    aos = torch.cat([aos, torch.zeros(n, 9, dtype=torch.float32, device=dev)], dim=1).contiguous()
+    zpc_amd.lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n, mt.nchn, mt.L, mt.buf.data_ptr())
+    pol.syncCtx()
+    del aos
+    g = (0.0, -9.8, 0.0)
+
+    def prime():
+        mt.build_partition(max(4096, n // 128), margin=1)
+        mt.rebin()
+        mt.clear_grid()
+        mt.p2g()
+        mt.grid_update(g)
+        mt.slot(K=24, outbox_cap=128)
+    mt.build_partition(max(4096, n // 128), margin=1)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    mt.grid_update(g)
+    mt.slot(K=24, outbox_cap=128)
+    reparts, pending = [], False
+    for step in range(400):
+        mt.g2p2g(write_all=pending)
+        mt.grid_update(g)
+        if pending:
+            mt.unslot(strict=True)      # checks the period's flags, sent == re-homed, and the particle count
+            prime()
+            reparts.append(step)
+            pending = False
+        elif step % 2 == 1:
+            pending = mt.poll_repartition()
+    pol.syncCtx()
+    mt.check_slots(strict=True)
+    assert len(reparts) >= 3, reparts
+    rec = mt.slot_record
+    assert rec["sent"] == rec["homed"] > 100_000_000 and not any(rec["flags"][k] for k in (0, 1, 2, 4)), rec
+    cbuf, cnt = mt._compact_copy()
+    assert cnt == n
+    m = cbuf.view(-1, mt.nchn, 64)[:, 0, :].reshape(-1)[:cnt]
+    got = torch.sort(m[(m >= m0) & (m < 1.3 * m0)]).values
+    assert got.numel() == nid and torch.equal(got, want_ids)
+    assert int((m == np.float32(0.99 * m0)).sum()) == n - nid

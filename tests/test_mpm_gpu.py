@@ -884,3 +884,153 @@ def test_slotted_capacity_overflow_is_reported_and_loses_no_particle(pol, oracle
     assert reported
     d = mt.download()
     assert d["m"].shape[0] == n and np.array_equal(np.sort(d["m"]), np.sort(mass))
+
+
+# ------------------------------------------------------------------------------------------------ r04: the slotted step never drops a particle
+def _primed_slotted(pol, n, dx, dt, model, side, mass, pos, vel, Cm, F, lj, margin, K, outbox_cap):
+    from zpc_amd.mpm import MpmTransfer
+    vol = dx ** 3 / 8
+    mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
+    mt.upload(mass, pos, vel, Cm, F, lj if model == 1 else None)
+    mt.build_partition(n, margin=margin)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.slot(K=K, outbox_cap=outbox_cap)
+    return mt
+
+
+def _repartition(mt, pol, margin, K, outbox_cap, strict=True):
+    """what bench.py::remap does on one rank: the step before stored v, C and the stress of every particle"""
+    mt.unslot(strict=strict)
+    mt.build_partition(max(mt.n, 64), margin=margin)
+    mt.rebin()
+    mt.clear_grid()
+    mt.p2g()
+    mt.grid_update((0.0, -9.8, 0.0))
+    mt.slot(K=K, outbox_cap=outbox_cap)
+
+
+@pytest.mark.parametrize("side", [8, 4])
+def test_slotted_mover_without_a_destination_block_keeps_its_slot(pol, side):
+    """A partition without margin and a cloud that runs out of it (0.3 cell per step towards -x, -y: the blocks there are not in the
+    table): r03 dropped such movers (the 3000-step soak lost 0.34 % of the column this way).  Now a mover whose destination block is
+    missing keeps its old slot with its new state: after every step the storage holds every particle (same multiset of identity
+    masses), `sent == re-homed`, status word [2] reports it, the early warning [3] came first, and a re-partition + re-slot recovers
+    (the following steps run clean).  Reference semantics: every particle is written back, simulation/transfer/G2P.hpp:67-82."""
+    dx, dt = 1.0 / 64, 1e-3
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=431 + side, vel_scale=0.2)
+    n = pos.shape[0]
+    mass = (mass * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)
+    vel += np.array([-5.0, -4.0, 0.5], np.float32)
+    lj = np.zeros(n, np.float32)
+    mt = _primed_slotted(pol, n, dx, dt, 1, side, mass, pos, vel, Cm, F, lj, margin=0, K=24, outbox_cap=512)
+    warned_at = flagged_at = None
+    for step in range(side * 5):
+        mt.g2p2g(write_all=True)
+        mt.grid_update((0.0, -9.8, 0.0))
+        pol.syncCtx()
+        w = mt.slot_status[:5].cpu().numpy()
+        if w[3] and warned_at is None:
+            warned_at = step
+        if w[2] and flagged_at is None:
+            flagged_at = step
+        cnt = int(__import__("zpc_amd").lib().zs_rocm_mpm_slot_list(pol.handle, mt.cell_mask.data_ptr(), mt.nbins, mt.K, None))
+        assert cnt == n, (step, cnt, n)
+        if flagged_at is not None and step >= flagged_at + 2:
+            break
+    assert flagged_at is not None, "the cloud never left the partition: the test does not test"
+    assert warned_at is not None and warned_at < flagged_at, (warned_at, flagged_at)   # the early warning comes first
+    with pytest.raises(RuntimeError, match="outside the partition"):
+        mt.check_slots(strict=True)                                      # strict callers are stopped; the record keeps what happened
+    rec = mt.slot_record
+    assert rec["sent"] == rec["homed"] and rec["sent"] > 0               # every mover that was sent was re-homed
+    assert rec["flags"][2] == 1 and rec["log"], rec
+    # nobody lost, nobody duplicated; and a re-partition + re-slot takes everybody back into a valid storage
+    _repartition(mt, pol, 1, 24, 512, strict=False)
+    d = mt.download()
+    assert np.array_equal(np.sort(d["m"]), np.sort(mass))
+    for step in range(3):
+        mt.g2p2g(write_all=True)
+        mt.grid_update((0.0, -9.8, 0.0))
+        pol.syncCtx()
+        mt.check_slots(strict=True)
+    assert np.array_equal(np.sort(mt.download()["m"]), np.sort(mass))
+
+
+def test_slotted_full_destination_cell_in_another_bin_returns_the_mover(pol):
+    """One spare round per cell over the fullest cell of the start and a drift of 0.3 cell per step: cells overflow within a few steps,
+    inside a bin and across bins.  A record whose destination cell (another bin) has no free round goes BACK into the slot it left (slot_rehome_kernel, r04;
+    r03 dropped it); the in-bin case keeps its slot.  Reported in status word [1]; the storage holds every identity after every step."""
+    dx, dt, side = 1.0 / 64, 1e-3, 8
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=977, vel_scale=0.6)
+    n = pos.shape[0]
+    mass = (mass * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)
+    vel += np.array([4.0, -5.0, 3.0], np.float32)
+    lj = np.zeros(n, np.float32)
+    base = np.floor(pos / np.float32(dx) - np.float32(0.5)).astype(np.int64)
+    K = int(np.unique(base, axis=0, return_counts=True)[1].max()) + 1
+    mt = _primed_slotted(pol, n, dx, dt, 1, side, mass, pos, vel, Cm, F, lj, margin=2, K=K, outbox_cap=512)
+    full = False
+    for step in range(8):
+        mt.g2p2g(write_all=True)
+        mt.grid_update((0.0, -9.8, 0.0))
+        pol.syncCtx()
+        st = mt.check_slots(strict=False)
+        full = full or bool(st[1])
+        assert st[5] == st[6], st
+        d = mt.download()
+        assert np.array_equal(np.sort(d["m"]), np.sort(mass)), step
+    assert full, "no cell overflowed: the test does not test"
+
+
+def test_slotted_closed_loop_repartition_vs_oracle(pol, oracle):
+    """70 slotted steps of a cloud moving 0.3 cell per step (21 cells of travel through a partition with one block of margin), re-partitioned
+    whenever the step's own status word [3] asks for it (poll_repartition: asynchronous copy, one polling interval of lag) -- the
+    bench's closed loop.  The oracle's g2p -> p2g sequence runs beside it on the same partitions; after the last step every particle
+    agrees, no flag other than the early warning was ever raised, and at least two re-partitions happened."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt, side, model = 1.0 / 64, 1e-3, 8, 0
+    mass, pos, vel, Cm, F = make_cloud(8, dx, 2, seed=1311, vel_scale=0.2)
+    n = pos.shape[0]
+    mass = (mass * (1 + 1e-3 * np.arange(n) / n)).astype(np.float32)
+    vel += np.array([4.0, -5.0, 3.0], np.float32)
+    vol = dx ** 3 / 8
+    mt = _primed_slotted(pol, n, dx, dt, model, side, mass, pos, vel, Cm, F, None, margin=1, K=24, outbox_cap=512)
+    om = OracleMpm(oracle, model, dx, dt, side, vol)
+    om.adopt_partition(mt.active_keys())
+    om.p2g(mass, pos, vel, Cm, F, None)
+    om.grid_update((0.0, -9.8, 0.0))
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    reparts, pending = [], False
+    for step in range(70):
+        om.g2p(po, vo, Co, Fo)
+        om.grid[:] = 0
+        om.p2g(mass, po, vo, Co, Fo, None)
+        om.grid_update((0.0, -9.8, 0.0))
+        mt.g2p2g(write_all=pending or step == 69)
+        mt.grid_update((0.0, -9.8, 0.0))
+        if pending:
+            _repartition(mt, pol, 1, 24, 512, strict=True)
+            # the oracle moves to the same partition: its grid is a function of the particles it holds
+            om.adopt_partition(mt.active_keys())
+            om.grid[:] = 0
+            om.p2g(mass, po, vo, Co, Fo, None)
+            om.grid_update((0.0, -9.8, 0.0))
+            reparts.append(step)
+            pending = False
+        elif step % 2 == 1:
+            pending = mt.poll_repartition()
+    pol.syncCtx()
+    mt.check_slots(strict=True)
+    assert len(reparts) >= 2, reparts
+    rec = mt.slot_record
+    assert rec["sent"] == rec["homed"] and rec["flags"][0] == rec["flags"][1] == rec["flags"][2] == rec["flags"][4] == 0, rec
+    d = _by_mass(mt.download())
+    o = _id_order(mass, po)
+    assert np.array_equal(d["m"], mass[o])
+    assert np.abs(d["x"] - po[o]).max() <= 2e-5
+    assert np.abs(d["v"] - vo[o]).max() <= 1e-3 * np.abs(vo).max()
+    assert np.abs(d["F"] - Fo[o]).max() <= 5e-4

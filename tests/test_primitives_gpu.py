@@ -432,3 +432,33 @@ def test_scan_interleaved_types_share_the_control_block():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan_stress.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"0 mismatches" in r.stdout, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
+
+
+@pytest.mark.parametrize("n", [5000, 300_001, 1_000_000, 3_000_000])
+@pytest.mark.parametrize("case", ["constant_keys", "window_over_equal_bits", "ordinary"])
+def test_radix_sort_pair_keys_in_place_values_out_of_place(pol, case, n):
+    """radix_sort_pair(keys, iota, keys, perm): keys sorted IN PLACE while the values go to a separate array -- the argsort idiom.
+    When no key differs inside [sbit, ebit) the sort degenerates to a copy; the copy of the values must still happen although the key
+    arrays coincide (r03's small-input path skipped both copies behind one `keys_in != keys_out` test: ADVICE r03, medium).
+    Reference semantics: stable LSD sort carrying ValueT, execution/ExecutionPolicy.hpp:530-608; results are unique (bit-exact)."""
+    import zpc_amd as zs
+    g = np.random.default_rng(n + len(case))
+    sbit, ebit = 0, 32
+    if case == "constant_keys":
+        k = np.full(n, 12345, np.int32)
+    elif case == "window_over_equal_bits":
+        k = g.integers(0, 1 << 14, n, dtype=np.int32)     # bits 16..31 agree
+        sbit, ebit = 16, 32
+    else:
+        k = g.integers(-2 ** 30, 2 ** 30, n, dtype=np.int32)
+    keys = torch.from_numpy(k.copy()).cuda()
+    iota = torch.arange(n, dtype=torch.int32, device="cuda")
+    perm = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    zs.radix_sort_pair(pol, keys, iota, keys, perm, sbit=sbit, ebit=ebit)
+    pol.syncCtx()
+    kk = (k.astype(np.int64) >> sbit) & ((1 << (ebit - sbit)) - 1)
+    if ebit == 32:   # signed order on the top bit
+        kk = np.where(kk >= (1 << (ebit - sbit - 1)), kk - (1 << (ebit - sbit)), kk)
+    o = np.argsort(kk, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), o.astype(np.int32))
+    assert np.array_equal(keys.cpu().numpy(), k[o])

@@ -57,6 +57,13 @@ class Particles(C.Structure):
                 ("stress", Port), ("n", C.c_size_t)]
 
 
+class SlotStorage(C.Structure):
+    """zs_rocm_slot_storage: the slotted particle storage's device buffers (all owned by the caller)."""
+    _fields_ = [("cellMask", C.c_void_p), ("K", C.c_int), ("nbr", C.c_void_p), ("nbr27", C.c_void_p), ("moverCount", C.c_void_p),
+                ("claim", C.c_void_p), ("moverRec", C.c_void_p), ("outboxCap", C.c_int), ("status", C.c_void_p),
+                ("blockEdge", C.c_void_p)]
+
+
 class MpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
@@ -342,6 +349,9 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2p2g_slotted.restype = i32
     L.zs_rocm_mpm_g2p2g_slotted_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, sz, sz, i32]
     L.zs_rocm_mpm_g2p2g_slotted_range.restype = i32
+    L.zs_rocm_mpm_g2p2g_slots.argtypes = [vp, PP, Particles, vp, vp, vp, sz, C.POINTER(SlotStorage), i32, sz, sz, i32]
+    L.zs_rocm_mpm_g2p2g_slots.restype = i32
+    L.zs_rocm_mpm_partition_edge.argtypes = [vp, vp, vp, i32, i32, i32]
     L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

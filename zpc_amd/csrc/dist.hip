@@ -21,6 +21,7 @@
 struct zs_rocm_dist {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  bool broken = false;  // a grouped send / recv failed half-way: peers may be left waiting, nothing more is sent on this communicator
 };
 
 namespace zsr {
@@ -34,19 +35,29 @@ static int nccl_check(ncclResult_t r, const char *what, const char *file, int li
   do {                                                               \
     if (::zsr::nccl_check((expr), #expr, __FILE__, __LINE__)) return -1; \
   } while (0)
-// inside an open ncclGroupStart(): a failed call closes the group before returning, so later RCCL calls of this thread do not
-// queue into a group nobody ends
-#define ZSR_NCCL_G(expr)                                             \
+// inside an open ncclGroupStart(): a failed call closes the group before returning (so that later RCCL calls of this thread do not queue
+// into a group nobody ends) and marks the communicator unusable: the half-built group may have issued some of its sends / receives, a
+// retry on the same communicator would pair them with the wrong messages.  The caller tears the communicator down (zs_rocm_dist_destroy
+// aborts a broken one instead of draining it).
+#define ZSR_NCCL_G(d, expr)                                          \
   do {                                                               \
     if (::zsr::nccl_check((expr), #expr, __FILE__, __LINE__)) {      \
       (void)ncclGroupEnd();                                          \
+      (d)->broken = true;                                            \
       return -1;                                                     \
     }                                                                \
   } while (0)
-// the policy must run on the communicator's device (its stream is handed to RCCL); device -1 = "current" is resolved by Launch
-static int same_device(const zs_rocm_dist *d, const Launch &L, const char *what) {
-  if (L.dev == d->device) return 0;
-  fprintf(stderr, "[zs_rocm | rccl] %s: policy runs on device %d, communicator lives on device %d\n", what, L.dev, d->device);
+// the policy must run on the communicator's device (its stream is handed to RCCL); device -1 = the calling thread's current device.
+// (Resolved without constructing a Launch: its constructor / destructor wait on listened events, synchronise and print for profiling policies.)
+static int same_device(const zs_rocm_dist *d, const zs_rocm_policy *pol, const char *what) {
+  if (d->broken) {
+    fprintf(stderr, "[zs_rocm | rccl] %s: the communicator is unusable after a failed grouped exchange\n", what);
+    report_error(hipErrorUnknown, what, __FILE__, __LINE__);
+    return -1;
+  }
+  const int dev = pol->device >= 0 ? pol->device : current_device();
+  if (dev == d->device) return 0;
+  fprintf(stderr, "[zs_rocm | rccl] %s: policy runs on device %d, communicator lives on device %d\n", what, dev, d->device);
   report_error(hipErrorInvalidDevice, what, __FILE__, __LINE__);
   return -1;
 }
@@ -82,7 +93,7 @@ zs_rocm_dist *zs_rocm_dist_create(int rank, int world, const void *uniqueId, int
 }
 void zs_rocm_dist_destroy(zs_rocm_dist *d) {
   if (!d) return;
-  if (d->comm) (void)ncclCommDestroy(d->comm);
+  if (d->comm) (void)(d->broken ? ncclCommAbort(d->comm) : ncclCommDestroy(d->comm));
   delete d;
 }
 int zs_rocm_dist_rank(const zs_rocm_dist *d) { return d->rank; }
@@ -101,17 +112,14 @@ int zs_rocm_dist_halo_exchange(zs_rocm_dist *d, zs_rocm_policy *pol, float *grid
     return -1;
   }
   const size_t bf = (size_t)nchn * side * side * side;
-  {
-    Launch L(pol, "halo_exchange");
-    if (same_device(d, L, "halo_exchange")) return -1;
-  }
+  if (same_device(d, pol, "halo_exchange")) return -1;
   zs_rocm_mpm_halo_pack(pol, grid, blocks, totalBlocks, side, chn0, nchn, sendbuf);
   {
     Launch L(pol, "halo_exchange");
     ZSR_NCCL(ncclGroupStart());
     for (int k = 0; k < npeers; ++k) {
-      ZSR_NCCL_G(ncclSend(sendbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
-      ZSR_NCCL_G(ncclRecv(recvbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
+      ZSR_NCCL_G(d, ncclSend(sendbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
+      ZSR_NCCL_G(d, ncclRecv(recvbuf + peerOffset[k] * bf, peerCount[k] * bf, ncclFloat, peerRank[k], d->comm, L.stream));
     }
     ZSR_NCCL(ncclGroupEnd());
   }
@@ -176,6 +184,7 @@ size_t zs_rocm_halo_plan_from_keys(const int *keysAll, const size_t *counts, int
 }
 
 struct zs_rocm_halo_plan {
+  hipEvent_t evBoundary = nullptr, evDone = nullptr;  // the overlapped step's two hand-overs between the compute and the exchange stream
   int device = 0, side = 0, npeers = 0;
   size_t total = 0;
   std::vector<int> peerRank;
@@ -187,8 +196,8 @@ struct zs_rocm_halo_plan {
 // them; side = 4 | 8.  All-gathers the key lists over RCCL, derives the plan on the host and allocates the exchange buffers.
 zs_rocm_halo_plan *zs_rocm_dist_halo_plan_create(zs_rocm_dist *d, zs_rocm_policy *pol, const int *keys, size_t nblocks, int side) {
   if (!d || (side != 4 && side != 8)) return nullptr;
+  if (same_device(d, pol, "halo_plan_create")) return nullptr;
   Launch L(pol, "halo_plan");
-  if (same_device(d, L, "halo_plan_create")) return nullptr;
   auto *plan = new zs_rocm_halo_plan;
   plan->device = d->device;
   plan->side = side;
@@ -251,9 +260,38 @@ zs_rocm_halo_plan *zs_rocm_dist_halo_plan_create(zs_rocm_dist *d, zs_rocm_policy
   }
   return plan;
 }
+// A plan from explicit lists (callers with their own partition logic; the single-GPU rank proxy of bench.py, whose only "peer" is the
+// rank itself): blocks[total] = local block numbers (host), slice k = [peerOffset[k], + peerCount[k]) shared with rank peerRank[k].
+zs_rocm_halo_plan *zs_rocm_dist_halo_plan_from_lists(zs_rocm_dist *d, int side, int npeers, const int *peerRank, const size_t *peerOffset,
+                                                     const size_t *peerCount, const int *blocks, size_t total) {
+  if (!d || (side != 4 && side != 8) || npeers < 0 || (total && (!blocks || !peerRank || !peerOffset || !peerCount))) return nullptr;
+  auto *plan = new zs_rocm_halo_plan;
+  plan->device = d->device;
+  plan->side = side;
+  plan->npeers = npeers;
+  plan->total = total;
+  plan->peerRank.assign(peerRank, peerRank + npeers);
+  plan->peerOffset.assign(peerOffset, peerOffset + npeers);
+  plan->peerCount.assign(peerCount, peerCount + npeers);
+  if (total) {
+    DeviceGuard guard(d->device);
+    const size_t bf = (size_t)7 * side * side * side;
+    const bool ok = hipMalloc((void **)&plan->blocks, sizeof(int) * total) == hipSuccess && hipMalloc((void **)&plan->sendbuf, sizeof(float) * total * bf) == hipSuccess
+                    && hipMalloc((void **)&plan->recvbuf, sizeof(float) * total * bf) == hipSuccess
+                    && hipMemcpy(plan->blocks, blocks, sizeof(int) * total, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+      report_error(hipErrorOutOfMemory, "halo plan: buffers", __FILE__, __LINE__);
+      zs_rocm_dist_halo_plan_destroy(plan);
+      return nullptr;
+    }
+  }
+  return plan;
+}
 void zs_rocm_dist_halo_plan_destroy(zs_rocm_halo_plan *p) {
   if (!p) return;
   DeviceGuard guard(p->device);
+  if (p->evBoundary) (void)hipEventDestroy(p->evBoundary);
+  if (p->evDone) (void)hipEventDestroy(p->evDone);
   if (p->blocks) (void)hipFree(p->blocks);
   if (p->sendbuf) (void)hipFree(p->sendbuf);
   if (p->recvbuf) (void)hipFree(p->recvbuf);
@@ -279,27 +317,27 @@ int zs_rocm_dist_halo_plan_exchange(zs_rocm_halo_plan *p, zs_rocm_dist *d, zs_ro
 static ncclRedOp_t red_op(int op) { return op == 1 ? ncclMax : (op == 2 ? ncclMin : ncclSum); }
 int zs_rocm_dist_allreduce_f32(zs_rocm_dist *d, zs_rocm_policy *pol, float *buf, size_t n, int op) {
   if (!d || !n) return 0;
+  if (same_device(d, pol, "allreduce_f32")) return -1;
   Launch L(pol, "allreduce_f32");
-  if (same_device(d, L, "allreduce_f32")) return -1;
   ZSR_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, red_op(op), d->comm, L.stream));
   return 0;
 }
 int zs_rocm_dist_allreduce_i64(zs_rocm_dist *d, zs_rocm_policy *pol, long long *buf, size_t n, int op) {
   if (!d || !n) return 0;
+  if (same_device(d, pol, "allreduce_i64")) return -1;
   Launch L(pol, "allreduce_i64");
-  if (same_device(d, L, "allreduce_i64")) return -1;
   ZSR_NCCL(ncclAllReduce(buf, buf, n, ncclInt64, red_op(op), d->comm, L.stream));
   return 0;
 }
 // recv[r] = what rank r put into its send[this rank] (one int64 each): the counts exchange in front of an uneven all-to-all
 int zs_rocm_dist_alltoall_i64(zs_rocm_dist *d, zs_rocm_policy *pol, const long long *send, long long *recv) {
   if (!d) return 0;
+  if (same_device(d, pol, "alltoall_i64")) return -1;
   Launch L(pol, "alltoall_i64");
-  if (same_device(d, L, "alltoall_i64")) return -1;
   ZSR_NCCL(ncclGroupStart());
   for (int r = 0; r < d->world; ++r) {
-    ZSR_NCCL_G(ncclSend(send + r, 1, ncclInt64, r, d->comm, L.stream));
-    ZSR_NCCL_G(ncclRecv(recv + r, 1, ncclInt64, r, d->comm, L.stream));
+    ZSR_NCCL_G(d, ncclSend(send + r, 1, ncclInt64, r, d->comm, L.stream));
+    ZSR_NCCL_G(d, ncclRecv(recv + r, 1, ncclInt64, r, d->comm, L.stream));
   }
   ZSR_NCCL(ncclGroupEnd());
   return 0;
@@ -309,12 +347,12 @@ int zs_rocm_dist_alltoall_i64(zs_rocm_dist *d, zs_rocm_policy *pol, const long l
 int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *d, zs_rocm_policy *pol, const float *send, const size_t *sendCounts, const size_t *sendOffsets,
                                float *recv, const size_t *recvCounts, const size_t *recvOffsets) {
   if (!d) return 0;
+  if (same_device(d, pol, "alltoallv_f32")) return -1;
   Launch L(pol, "alltoallv_f32");
-  if (same_device(d, L, "alltoallv_f32")) return -1;
   ZSR_NCCL(ncclGroupStart());
   for (int r = 0; r < d->world; ++r) {
-    if (sendCounts[r]) ZSR_NCCL_G(ncclSend(send + sendOffsets[r], sendCounts[r], ncclFloat, r, d->comm, L.stream));
-    if (recvCounts[r]) ZSR_NCCL_G(ncclRecv(recv + recvOffsets[r], recvCounts[r], ncclFloat, r, d->comm, L.stream));
+    if (sendCounts[r]) ZSR_NCCL_G(d, ncclSend(send + sendOffsets[r], sendCounts[r], ncclFloat, r, d->comm, L.stream));
+    if (recvCounts[r]) ZSR_NCCL_G(d, ncclRecv(recv + recvOffsets[r], recvCounts[r], ncclFloat, r, d->comm, L.stream));
   }
   ZSR_NCCL(ncclGroupEnd());
   return 0;
@@ -322,13 +360,80 @@ int zs_rocm_dist_alltoallv_f32(zs_rocm_dist *d, zs_rocm_policy *pol, const float
 // all ranks have reached this point AND finished their stream's work (host-blocking)
 int zs_rocm_dist_barrier(zs_rocm_dist *d, zs_rocm_policy *pol) {
   if (!d) return 0;
+  if (same_device(d, pol, "dist_barrier")) return -1;
   Launch L(pol, "dist_barrier");
-  if (same_device(d, L, "dist_barrier")) return -1;
   int *flag = (int *)L.temp(sizeof(int));
   ZSR_CHECK(hipMemsetAsync(flag, 0, sizeof(int), L.stream));
   ZSR_NCCL(ncclAllReduce(flag, flag, 1, ncclInt32, ncclSum, d->comm, L.stream));
   ZSR_CHECK(hipStreamSynchronize(L.stream));
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- one step, one call
+// The whole sub-step of the slotted MPM path behind ONE C-ABI call: no host code of the caller runs between the kernels, so a C++ host
+//  and bench.py enqueue a step for the price of one call -- at 8 ranks a rank's step is ~1 ms and a Python loop of ~8
+// ctypes / RCCL calls per step is first-order.  Enqueued, in order, on the policy's stream:
+//   gridB := 0;  fused G2P (from gridA) + P2G (into gridB) of the blocks [0, nBoundary)   [boundary blocks: the partition is numbered with
+//   them first];  event;  the same for [nBoundary, nblocks) + re-home + commit;  wait for the exchange;  grid update of gridB (+ extf dt,
+//   max |v|^2 into maxVelSqr);  allreduce(max) of maxVelSqr over the ranks (CFL).
+// and on commPolicy's stream (a second stream), behind the event: pack -> grouped ncclSend / ncclRecv -> atomic unpack-add of the ghost
+// blocks' partial sums (zs_rocm_dist_halo_plan_exchange) -- it overlaps the interior range.  commPolicy == NULL or nBoundary == 0 or
+// == nblocks: one range, exchange on the main stream.  dist == NULL: single rank (no exchange, no allreduce).
+// What the reference offers for this: pol.device(i) + .listen() events between streams (cuda/execution/ExecutionPolicy.cuh:364-399);
+// the schedule itself has no counterpart (zpc has no collective layer).  Returns 0, -1 on bad arguments or an RCCL error.
+int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
+  if (!pol || !a || !a->params || !a->table || !a->gridA || !a->gridB || !a->storage) return -1;
+  const size_t nb = a->nblocks;
+  if (!nb) return 0;
+  const int side = a->params->side;
+  const size_t gridBytes = nb * (size_t)7 * side * side * side * sizeof(float);
+  zs_rocm_memset(pol, a->gridB, 0, gridBytes);
+  float *const hgrid = a->haloGrid ? a->haloGrid : a->gridB;
+  const bool exchange = a->dist && a->plan && a->plan->total;
+  const bool overlap = exchange && a->commPolicy && a->nBoundary > 0 && a->nBoundary < nb;
+  int rc = 0;
+  if (overlap) {
+    zs_rocm_halo_plan *p = a->plan;
+    if (!p->evBoundary) {
+      DeviceGuard guard(p->device);
+      ZSR_CHECK(hipEventCreateWithFlags(&p->evBoundary, hipEventDisableTiming));
+      ZSR_CHECK(hipEventCreateWithFlags(&p->evDone, hipEventDisableTiming));
+    }
+    rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, a->nBoundary, 0);
+    if (rc) return rc;
+    {
+      Launch L(pol, "step: boundary done");
+      ZSR_CHECK(hipEventRecord(p->evBoundary, L.stream));
+    }
+    {
+      Launch C(a->commPolicy, "step: exchange start");
+      ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evBoundary, 0));
+    }
+    rc = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, 7);
+    {
+      Launch C(a->commPolicy, "step: exchange done");
+      ZSR_CHECK(hipEventRecord(p->evDone, C.stream));
+    }
+    if (rc) return rc;
+    rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 1);
+    if (rc) return rc;
+    {
+      Launch L(pol, "step: wait for the exchange");
+      ZSR_CHECK(hipStreamWaitEvent(L.stream, p->evDone, 0));
+    }
+  } else {
+    rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, nb, 1);
+    if (rc) return rc;
+    if (exchange) {
+      rc = zs_rocm_dist_halo_plan_exchange(a->plan, a->dist, pol, hgrid, 0, 7);
+      if (rc) return rc;
+    }
+  }
+  if (a->maxVelSqr) zs_rocm_memset(pol, a->maxVelSqr, 0, sizeof(float));
+  zs_rocm_mpm_grid_update(pol, a->params, a->gridB, nb, a->extf, a->maxVelSqr);
+  if (a->collider) zs_rocm_mpm_apply_boundary(pol, a->params, a->table, a->gridB, nb, a->collider);
+  if (a->dist && a->maxVelSqr) rc = zs_rocm_dist_allreduce_f32(a->dist, pol, a->maxVelSqr, 1, 1);
+  return rc;
 }
 
 }  // extern "C"

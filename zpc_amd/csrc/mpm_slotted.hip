@@ -31,8 +31,9 @@ namespace zsr {
 
 constexpr int SL_REC = 48;    // floats per outbox record (192 bytes = three 64-byte lines).  First line, all slot_rehome_kernel reads without
                               // writeAll: [0] m, [1] x(3), [4] F(9), [13] logJp, [14] destination cell (bin * 64 + lane; ~0: none),
-                              // [15] flag: its grid contributions are still to be added; then [16] v(3), [19] C(9), [28] P F^T(9)
-                              // (written for writeAll steps and for flagged records only)
+                              // [15] bit 0: its grid contributions are still to be added, bits 1..: the slot it left inside its bin
+                              // (round * 64 + cell: where slot_rehome_kernel puts it back when the destination cell has no free round);
+                              // then [16] v(3), [19] C(9), [28] P F^T(9) (written for writeAll steps and for flagged records only)
 constexpr int SLR_DCELL = 14, SLR_FLAG = 15, SLR_V = 16, SLR_C = 19, SLR_PF = 28;
 
 #ifdef ZS_SLOT_PROBE  // measurement-only build (tools/ablate_slot.sh PROBE): cycle stamps of a workgroup's phases, summed over sampled workgroups
@@ -60,11 +61,13 @@ struct SlotArgs {
   unsigned *claim;      // [2][nbinsAll][64]: [0] this step's arrivals (high 16 bits: from inside the bin, low 16: from other bins), [1] rounds
                         // vacated in this step; zero between steps (slot_commit_kernel folds both into cellMask)
   float *moverRec;      // [nbins][cap][SL_REC] outbox records: movers that left their bin (or found the arrival queue of their cell full)
-  int *status;          // [0] outbox full, [1] cell full (K), [2] mass / a mover for a block outside the partition, [3] unused,
-                        // [4] a particle was not stored under its cell; [8 .. 8 + 256) movers sent, [264 .. 264 + 256) movers re-homed
-                        // (running sums spread over 256 words each: unequal totals after a step = particles were lost, see [1], [2])
+  int *status;          // [0] outbox full, [1] cell full (K), [2] mass / a mover for a block outside the partition, [3] a particle lives in a
+                        // block next to the partition's edge (blockEdge: re-partition soon), [4] a particle was not stored under its cell;
+                        // [8 .. 8 + 256) movers sent, [264 .. 264 + 256) movers re-homed (running sums spread over 256 words each; equal
+                        // after every step: a mover that finds no new home keeps or gets back its old slot -- no particle is ever dropped)
   int binBase, nbins, nbinsAll;
   int cap;              // outbox records per bin and step (caller's choice: a bin holds 512 particles at 8 per cell)
+  const unsigned char *blockEdge;  // [nblocks] or NULL: 1 = a block of {-1..2}^3 around this one is not in the partition (zs_rocm_mpm_partition_edge)
 };
 
 constexpr int SL_NCTR = 256, SL_SENT = 8, SL_DELIVERED = 8 + SL_NCTR;  // layout of the status words (zs_rocm.h: ZS_ROCM_SLOT_STATUS_WORDS)
@@ -141,6 +144,21 @@ static __global__ __launch_bounds__(256) void build_neighbors27_kernel(BhtDev t,
   int k[3] = {t.activeKeys[3 * (size_t)i] + (o / 9 - 1) * kscale, t.activeKeys[3 * (size_t)i + 1] + ((o / 3) % 3 - 1) * kscale,
               t.activeKeys[3 * (size_t)i + 2] + (o % 3 - 1) * kscale};
   nbr27[g] = bht_query<3>(t, k);
+}
+
+// edge[i] = 1 if a block at offset [lo, hi]^3 of block i is not in the partition
+static __global__ __launch_bounds__(256) void partition_edge_kernel(BhtDev t, int nblocks, unsigned char *edge, int kscale, int lo, int hi) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= nblocks) return;
+  const int k0[3] = {t.activeKeys[3 * (size_t)i], t.activeKeys[3 * (size_t)i + 1], t.activeKeys[3 * (size_t)i + 2]};
+  int missing = 0;
+  for (int a = lo; a <= hi; ++a)
+    for (int b = lo; b <= hi; ++b)
+      for (int c = lo; c <= hi; ++c) {
+        int k[3] = {k0[0] + a * kscale, k0[1] + b * kscale, k0[2] + c * kscale};
+        missing |= bht_query<3>(t, k) < 0;
+      }
+  edge[i] = (unsigned char)missing;
 }
 
 // bin next to `bin` in direction code (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1), dx, dy, dz in {-1, 0, 1}: same block or the block next to it
@@ -270,7 +288,7 @@ __device__ __forceinline__ void outbox_scatter_global(const MpmDev &mp, const Bi
     if (j >= n) break;
     const int t = p * 64 + lane;
     const float *rc = recs + (size_t)j * SL_REC;
-    if (t >= 189 || reinterpret_cast<const unsigned *>(rc)[SLR_FLAG] == 0u) continue;
+    if (t >= 189 || (reinterpret_cast<const unsigned *>(rc)[SLR_FLAG] & 1u) == 0u) continue;
     int nc[3];
     float d0[3];
 #pragma unroll
@@ -454,10 +472,14 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
               }
 #endif
             } else {
-              outbox = true;
               const int dbin = nbrBin[code];
-              if (dbin >= 0) dcell = (unsigned)dbin * 64u + (unsigned)dl;
-              else A.status[2] = 1;  // the destination block is not in the partition: nowhere to live (sent != homed)
+              if (dbin >= 0) {
+                outbox = true;
+                dcell = (unsigned)dbin * 64u + (unsigned)dl;
+              } else {
+                A.status[2] = 1;  // the destination block is not in the partition: the particle keeps its old slot with its new state
+                keep = true;      // (never dropped: G2P.hpp:67-82 writes every particle back); the caller re-partitions and re-slots
+              }
             }
             if (viaX) {
               const unsigned k = atomicAdd(&xCnt[par], 1u);
@@ -486,7 +508,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                   for (int d = 0; d < 9; ++d) rec[SLR_C + d] = C[d];
                 }
                 reinterpret_cast<unsigned *>(rec)[SLR_DCELL] = dcell;
-                reinterpret_cast<unsigned *>(rec)[SLR_FLAG] = recFlag;
+                reinterpret_cast<unsigned *>(rec)[SLR_FLAG] = recFlag | (code0 << 1);  // code0 = round * 64 + cell: the slot it leaves
               } else {
                 A.status[0] = 1;  // outbox full -- reported, the caller must react (raise outboxCap, re-slot)
                 keep = !home;     // (a mover that already has its new slot only loses the fallback scatter of its grid terms)
@@ -827,6 +849,9 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   if (tid == 0) s_outCount = s_sent = s_homed = s_xOver = 0;
   if (tid < 3) s_xCnt[tid] = 0u;
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  // early warning of the closed-loop re-partition: this bin holds particles and its block has a missing block within {-1..2}^3 -- a
+  // particle that crosses one more block could find no slot (or its stencil no node) there
+  if (tid == 0 && A.blockEdge && A.blockEdge[geo.block]) A.status[3] = 1;
   if (tid >= 64 && tid < 64 + 27) {
     const int code = tid - 64;
     s_nbrBlk[code] = A.nbr27[(size_t)geo.block * 27 + code];
@@ -958,16 +983,23 @@ static __global__ __launch_bounds__(256) void slot_rehome_kernel(ParticlesDev ps
     const float4 r0 = reinterpret_cast<const float4 *>(rc)[0], r1 = reinterpret_cast<const float4 *>(rc)[1],
                  r2 = reinterpret_cast<const float4 *>(rc)[2], r3 = reinterpret_cast<const float4 *>(rc)[3];
     const unsigned dcell = __float_as_uint(r3.z);
-    if (dcell == 0xffffffffu) continue;  // it stayed inside its bin (arrival queue full): its workgroup gave it a slot
+    if (dcell == 0xffffffffu) continue;  // it stayed inside its bin (arrival queue full) or kept its slot: its workgroup stored it
     const unsigned occ = cellMask[dcell];
     const unsigned old = atomicAdd(&claim[dcell], 1u);
     const int rr = nth_low_bit(~occ & kmask, (old >> 16) + (old & 0xffffu));
-    if (rr < 0) {
-      status[1] = 1;  // cell full (sent != homed)
-      continue;
+    size_t i;
+    if (rr >= 0) {
+      i = ((size_t)(dcell >> 6) * (size_t)K + (size_t)rr) * 64 + (size_t)(dcell & 63u);
+    } else {
+      // destination cell full: the particle goes back into the slot it left (still free: this step's arrivals only take rounds that
+      // were free when the step began) with its new state, and the departure is withdrawn before slot_commit_kernel folds it in.  It
+      // is then stored under the wrong cell -- reported ([1]); the caller re-slots the storage -- but it is not lost.
+      status[1] = 1;
+      const unsigned src = __float_as_uint(r3.w) >> 1;  // round * 64 + cell inside this bin
+      i = (bin * (size_t)K + (size_t)(src >> 6)) * 64 + (size_t)(src & 63u);
+      atomicAnd(&claim[(nbins + bin) * 64 + (size_t)(src & 63u)], ~(1u << (src >> 6)));
     }
     ++nhomed;
-    const size_t i = ((size_t)(dcell >> 6) * (size_t)K + (size_t)rr) * 64 + (size_t)(dcell & 63u);
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
     const float x[3] = {r0.y, r0.z, r0.w};
     const float F[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
@@ -1096,12 +1128,18 @@ size_t zs_rocm_mpm_slot_list(zs_rocm_policy *pol, const unsigned *cellMask, size
 // numbered with the blocks near a rank boundary first; their range is launched first and their ghost-block sums travel on a second
 // stream while the interior range computes (a bin writes grid nodes at most one block away from its own).
 // Returns 0, -1 on bad arguments.
-int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
-                                    const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27,
-                                    int *moverCount, unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status,
-                                    size_t blockBegin, size_t blockEnd, int finish) {
+int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
+                            const float *gridA, float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll,
+                            size_t blockBegin, size_t blockEnd, int finish) {
+  if (!st) return -1;
+  unsigned *const cellMask = st->cellMask;
+  const int K = st->K, outboxCap = st->outboxCap;
+  const int *const nbr = st->nbr, *const nbr27 = st->nbr27;
+  int *const moverCount = st->moverCount, *const status = st->status;
+  unsigned *const claim = st->claim;
+  float *const moverRec = st->moverRec;
   if (!nblocks) return 0;
-  if (!cellMask || !nbr || !nbr27 || !moverCount || !claim || !moverRec || !status || K < 1 || K > 32 || outboxCap < 1) return -1;
+  if (!cellMask || !nbr || !nbr27 || !moverCount || !claim || !moverRec || !status || K < 1 || K > 32 || outboxCap < 1 || outboxCap > (1 << 20)) return -1;
   if (p->model < ZS_MPM_FIXED_COROTATED || p->model > ZS_MPM_EQUATION_OF_STATE) return -1;
   if (uniform_lane_width(ps, model_uses_logjp(p->model), writeAll != 0) != 64 || (writeAll && (!ps.vel.base || !ps.C.base))) {
     fprintf(stderr, "[zs_rocm] g2p2g_slotted needs all particle attributes in one TileVector<f32, 64>\n");
@@ -1115,7 +1153,8 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
   const unsigned bpb = p->side == 4 ? 1u : 8u;
   const unsigned nbinsAll = (unsigned)(nblocks * bpb);
   const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
-  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap};
+  const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap,
+                   st->blockEdge};
 #ifdef ZS_SLOT_WITH_NS
 #define ZS_SLOT_NS_AVAILABLE 1
 #else
@@ -1169,11 +1208,29 @@ int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_param
   return 0;
 }
 
+int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
+                                    const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27,
+                                    int *moverCount, unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status,
+                                    size_t blockBegin, size_t blockEnd, int finish) {
+  const zs_rocm_slot_storage st{cellMask, K, nbr, nbr27, moverCount, claim, moverRec, outboxCap, status, nullptr};
+  return zs_rocm_mpm_g2p2g_slots(pol, p, ps, tab, gridA, gridB, nblocks, &st, writeAll, blockBegin, blockEnd, finish);
+}
+
 int zs_rocm_mpm_g2p2g_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
                               float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27, int *moverCount,
                               unsigned *claim, float *moverRec, int outboxCap, int writeAll, int *status) {
   return zs_rocm_mpm_g2p2g_slotted_range(pol, p, ps, tab, gridA, gridB, nblocks, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, outboxCap,
                                          writeAll, status, 0, nblocks, 1);
+}
+
+// edge[i] = 1 if one of the blocks at offsets [lo, hi]^3 (in blocks) of block i is missing from the partition.  With lo = -1, hi = 2 a block
+// with edge == 0 can lose a particle to any of its 26 neighbours and that particle's stencil (+{0,1}^3) still finds its nodes.
+void zs_rocm_mpm_partition_edge(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, unsigned char *edge, int keyStride, int lo, int hi) {
+  Launch L(pol, "partition_edge");
+  const int nb = bht_size(tab->t, L.stream);
+  if (!nb) return;
+  hipLaunchKernelGGL(partition_edge_kernel, dim3(ceil_div((size_t)nb, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb, edge,
+                     keyStride > 0 ? keyStride : 1, lo, hi);
 }
 
 }  // extern "C"

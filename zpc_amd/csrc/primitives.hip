@@ -1224,10 +1224,17 @@ __global__ __launch_bounds__(RSS_BLOCK) void radix_small_finish_kernel(const K *
   if (mode == RS_COPY_IN || mode == RS_COPY_SPLIT) {
     const K *sk = mode == RS_COPY_IN ? kin : tk0;
     const int *sv = mode == RS_COPY_IN ? vin : tv0;
-    if (sk != kout)
+    // keys and values are copied independently: a pair sort with the keys in place but separate value arrays
+    // (radix_sort_pair(keys, iota, keys, perm) on constant keys, or a bit window in which all keys agree) must still write vout
+    const bool copyK = sk != kout;
+    bool copyV = false;
+    if constexpr (PAIR) copyV = sv != vout;
+    if (copyK || copyV)
       for (unsigned i = blockIdx.x * BLOCK + t; i < n; i += gridDim.x * BLOCK) {
-        kout[i] = sk[i];
-        if constexpr (PAIR) vout[i] = sv[i];
+        if (copyK) kout[i] = sk[i];
+        if constexpr (PAIR) {
+          if (copyV) vout[i] = sv[i];
+        }
       }
     return;
   }

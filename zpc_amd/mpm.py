@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, Port, Particles, MpmParams
+from ._lib import lib, Port, Particles, MpmParams, SlotStorage
 from .containers import Bht
 
 FIXED_COROTATED, DRUCKER_PRAGER, VONMISES_FIXED_COROTATED, NACC = 0, 1, 2, 3  # ConstitutiveModelConfig members with F
@@ -60,6 +60,9 @@ class MpmTransfer:
         self.slotted = False   # slotted storage (zs_rocm_mpm_slot_particles): self.buf holds nbins * K tiles, cell_mask says which
         self.n_slots = 0
         self.K = 0
+        # run-level record of the slotted storage's status words: folded in by check_slots() (which unslot() calls), so that a
+        # re-partition (slot() starts a fresh status buffer) can never discard a latched flag or a lost-mover count
+        self.slot_record = {"sent": 0, "homed": 0, "flags": [0] * 5, "periods": 0, "edge_periods": 0, "log": []}
 
     def _zero(self, t):
         """clear device memory ON THE POLICY'S STREAM (torch's zero_() would run on torch's current stream, which is ordered with
@@ -192,6 +195,9 @@ class MpmTransfer:
             self._zero(self.drift_flag)
 
     # ------------------------------------------------------------------ slotted storage (zpc_amd/csrc/mpm_slotted.hip)
+    SLOT_FLAG_NAMES = ["outbox full", "a cell is full (K)", "mass or a mover for a block outside the partition",
+                       "early warning: a particle lives next to the partition's edge", "a particle was not stored under its cell"]
+
     def slot(self, K=24, outbox_cap=128):
         """compact particle buffer -> slotted storage (bins x K rounds x 64 lanes, one tile row per (bin, round)): the form the
         fused step keeps valid by itself while particles move (no re-bins).  Needs the partition; lane width 64."""
@@ -206,6 +212,9 @@ class MpmTransfer:
         self.slot_status = torch.zeros(8 + 2 * 256, dtype=torch.int32, device=self.device)  # ZS_ROCM_SLOT_STATUS_WORDS
         self.nbr27 = torch.empty(self.nblocks * 27, dtype=torch.int32, device=self.device)
         L.zs_rocm_mpm_build_neighbors27(self.pol.handle, self.table.handle, self.nbr27.data_ptr(), self.kstride)
+        # blocks from which a particle could reach the partition's edge in one more block of travel (status word [3]: re-partition soon)
+        self.block_edge = torch.empty(max(self.nblocks, 1), dtype=torch.uint8, device=self.device)
+        L.zs_rocm_mpm_partition_edge(self.pol.handle, self.table.handle, self.block_edge.data_ptr(), self.kstride, -1, 2)
         rc = L.zs_rocm_mpm_slot_particles(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
                                           int(self.key_is_origin), self.K, self.buf.data_ptr(), sbuf.data_ptr(), self.nchn,
                                           self.cell_mask.data_ptr(), self.slot_status.data_ptr())
@@ -221,6 +230,10 @@ class MpmTransfer:
         self.buf, self.buf2 = sbuf, None
         self.slotted, self.binned = True, False
         self.order = self.bin_start = self.cell_count = None
+        self._edge_host = self._edge_event = None
+        self.slot_storage = SlotStorage(self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(), self.nbr27.data_ptr(), self.mover_count.data_ptr(),
+                                        self.mover_dest.data_ptr(), self.mover_rec.data_ptr(), self.outbox_cap, self.slot_status.data_ptr(),
+                                        self.block_edge.data_ptr())
 
     def _compact_copy(self):
         """(compact TileVector buffer of the occupied slots in slot order, particle count)"""
@@ -234,28 +247,71 @@ class MpmTransfer:
         self.pol.syncCtx()
         return out, cnt
 
-    def unslot(self):
-        """slotted storage -> compact buffer (before a re-partition / migration)"""
+    def unslot(self, strict=True):
+        """slotted storage -> compact buffer (before a re-partition / migration).  The period's status words are folded into
+        slot_record first (strict: a raised flag other than the early warning, or sent != re-homed, raises); the particle count must
+        come out as it went in -- the slotted step never drops a particle."""
         assert self.slotted
+        self.check_slots(strict=strict)
         out, cnt = self._compact_copy()
+        if cnt != self.n:
+            raise RuntimeError("slotted storage holds %d particles, %d went in: particles were lost" % (cnt, self.n))
         self.slotted = False
-        self.n = cnt
         self.tiles = (cnt + 63) // 64
         self.buf, self.buf2 = out, None
         self.binned = False
 
-    def check_slots(self):
-        """raise if the slotted step reported a capacity overflow, a broken storage invariant or a lost mover"""
+    def check_slots(self, strict=True):
+        """Fold the status words of the slotted step into slot_record (and clear them on the device); strict: raise if a capacity
+        overflowed, a storage invariant broke or a mover was not re-homed.  Returns the period's first 8 words ([5], [6]: movers
+        sent / re-homed).  Word [3] (early warning: re-partition soon) never raises -- see repartition_requested()."""
         st = [int(v) for v in self.slot_status.cpu().numpy()]
-        names = ["outbox full", "a cell is full (K)", "mass for a block outside the partition", "(unused)",
-                 "a particle was not stored under its cell"]
-        bad = [names[k] for k in range(5) if st[k]]
         st[5], st[6] = sum(st[8:264]), sum(st[264:520])  # the counters are spread over 256 words each
+        self._zero(self.slot_status)
+        rec = self.slot_record
+        rec["sent"] += st[5]
+        rec["homed"] += st[6]
+        rec["periods"] += 1
+        rec["edge_periods"] += int(bool(st[3]))
+        for k in range(5):
+            rec["flags"][k] += int(bool(st[k]))
+        bad = [self.SLOT_FLAG_NAMES[k] for k in (0, 1, 2, 4) if st[k]]
         if st[5] != st[6]:
-            bad.append("%d movers sent, %d re-homed (destination cell full or its block not in the partition)" % (st[5], st[6]))
+            bad.append("%d movers sent, %d re-homed" % (st[5], st[6]))
         if bad:
-            raise RuntimeError("slotted G2P2G: " + "; ".join(bad))
+            rec["log"].append((rec["periods"], bad))
+            if strict:
+                raise RuntimeError("slotted G2P2G: " + "; ".join(bad))
         return st[:8]
+
+    def poll_repartition(self, reduce=None):
+        """Closed-loop re-partition trigger without a stall on the stream: returns the answer of the PREVIOUS call's copy of the status
+        words -- True if [3] (a particle lives in a block next to the partition's edge) or an overflow flag ([0], [1], [2], [4]) was
+        set -- and starts a new asynchronous device -> pinned-host copy behind the steps enqueued so far.  The answer lags one polling
+        interval and is the same on every call sequence (it waits for the previous copy's event, which has normally long fired), so
+        N ranks that poll at the same steps decide alike; `reduce(t)`: all-reduce(max) the float tensor t in place on the policy's
+        stream (multi-rank).  The warning is raised a whole block (side cells of travel) before a particle can run out of partition:
+        poll at least every side / 4 / (cells per step) steps."""
+        ready = False
+        if self._edge_event is not None:
+            self._edge_event.synchronize()
+            ready = bool(self._edge_host[:5].any())
+        if self._edge_host is None:
+            self._edge_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._edge_event = torch.cuda.Event()
+        sp = self.pol.getStream()  # the copy must be ordered behind the steps: the policy's stream
+        with torch.cuda.stream(torch.cuda.ExternalStream(sp) if sp else torch.cuda.default_stream(self.device)):
+            w = self.slot_status[:8].float()
+            if reduce is not None:
+                reduce(w)
+            self._edge_host.copy_(w, non_blocking=True)
+            self._edge_event.record()
+        return ready
+
+    def repartition_requested(self):
+        """synchronous form of poll_repartition(): reads the status words now"""
+        w = self.slot_status[:5].cpu()
+        return bool(w.any())
 
     # ------------------------------------------------------------------ one sub-step
     def clear_grid(self):
@@ -347,11 +403,9 @@ class MpmTransfer:
             self.grid, self.grid2 = dst, src  # `between` sees the grid being accumulated as self.grid
             ranges = [(0, self.nblocks)] if not split else [(0, int(split)), (int(split), self.nblocks)]
             for k, (b0, b1) in enumerate(ranges):
-                rc = lib().zs_rocm_mpm_g2p2g_slotted_range(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
-                                                           dst.data_ptr(), self.nblocks, self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(),
-                                                           self.nbr27.data_ptr(), self.mover_count.data_ptr(), self.mover_dest.data_ptr(),
-                                                           self.mover_rec.data_ptr(), self.outbox_cap, int(write_all), self.slot_status.data_ptr(),
-                                                           b0, b1, int(k == len(ranges) - 1))
+                rc = lib().zs_rocm_mpm_g2p2g_slots(self.pol.handle, C.byref(self.params), self.particles(), self.table.handle, src.data_ptr(),
+                                                   dst.data_ptr(), self.nblocks, C.byref(self.slot_storage), int(write_all),
+                                                   b0, b1, int(k == len(ranges) - 1))
                 if rc != 0:
                     raise RuntimeError("zs_rocm_mpm_g2p2g_slotted refused the call")
                 if k == 0 and between is not None:
