@@ -98,6 +98,13 @@ def parse():
                     help="slotted storage, when to re-partition: closed = when the step's own status words ask for it (a particle lives in a "
                          "block next to the partition's edge; polled asynchronously every side / 4 steps); open = r03's schedule derived "
                          "from drift + gravity alone (kept to show what it misses: flags are logged, not fatal)")
+    ap.add_argument("--py-step", action="store_true",
+                    help="slotted storage: enqueue the step's kernels / exchange from Python call by call (r03) instead of through the ONE "
+                         "C-ABI call zs_rocm_mpm_step_slotted")
+    ap.add_argument("--rank-proxy", type=int, default=0,
+                    help="N > 0 on ONE GPU: run this rank's share of an N-rank job with the N-rank schedule's launches -- boundary range, "
+                         "interior range, the ghost-block exchange over RCCL (world 1, the rank itself as its only peer, into a scratch grid) "
+                         "on the side stream, CFL allreduce -- to measure the fixed per-step host / launch / exchange cost of a rank")
     ap.add_argument("--no-at-rest", action="store_true",
                     help="skip the secondary measurements (short sub-runs of this script at rest: slotted, compact, unfused stand-alone P2G / G2P; "
                          "and the primitives / bht / TileVector rows of SURVEY 8(d))")
@@ -242,6 +249,9 @@ def main():
     # the exchange steps run inside libzsrocm.so on RCCL (zs_rocm_dist_*); torch.distributed only launches the ranks, carries the
     # unique id and brackets the timed region
     comm = None
+    proxy = a.rank_proxy > 0 and world == 1 and a.slotted
+    if proxy:
+        comm = NativeComm(0, 1, local_rank, None)
     if world > 1 and a.backend == "nccl" and a.comm == "native":
         try:
             comm = NativeComm(rank, world, local_rank, dist)
@@ -265,9 +275,11 @@ def main():
     nc = a.side ** 3
     stage = {}
     # boundary blocks first, their ghost sums travel on a second stream while the interior blocks compute (compact and slotted storage)
-    overlap = world > 1 and a.fused and not a.no_overlap
+    overlap = (world > 1 or proxy) and a.fused and not a.no_overlap
     comm_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
     pol_comm = zpc_amd.rocm_exec().sync(False).external_stream(comm_stream.cuda_stream) if overlap else pol
+    one_call = a.slotted and not a.py_step and (world == 1 or comm is not None)   # the step behind zs_rocm_mpm_step_slotted
+    proxy_grid = None
     ev_boundary, ev_comm = torch.cuda.Event(), torch.cuda.Event()
     n_boundary = 0
 
@@ -302,7 +314,7 @@ def main():
         if halo is None:
             return
         if comm is not None:
-            halo.exchange_native(comm, pol_comm if on_comm_stream else pol, mt.grid, a.side)
+            halo.exchange_native(comm, pol_comm if on_comm_stream else pol, proxy_grid if proxy else mt.grid, a.side)
         elif on_comm_stream:
             halo.exchange(pack_c, unpack_add_c)
         else:
@@ -326,7 +338,7 @@ def main():
     def partition_and_halo():
         """sparse-grid partition of the local particles; with the overlapped exchange the blocks near a rank boundary are
         numbered first; bins; ghost-block lists"""
-        nonlocal n_boundary
+        nonlocal n_boundary, proxy_grid
         from zpc_amd.dist import gather_block_keys, near_shared_mask
         nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0)
         all_keys = None
@@ -339,11 +351,39 @@ def main():
                 # movers it finishes, which land at most one cell outside the bin)
                 n_boundary = mt.reorder_partition(near_shared_mask(all_keys[rank], all_keys, rank, mt.kstride,
                                                                    margin=1 if (a.side == 8 or a.slotted) else 2))
+        proxy_blocks = None
+        if proxy:
+            # the blocks an N-rank job would share with its neighbours: the two outermost block layers of this box on every cut face
+            # (slabs along y for N < 8, 2x2x2 for 8: three cut faces) -- numbered first, exchanged with the rank itself over RCCL
+            from zpc_amd.dist import NativeHaloPlan
+            keys = mt.active_keys()
+            kb = keys // mt.kstride
+            lo_b, hi_b = kb.min(0), kb.max(0)
+            axes = (0, 1, 2) if a.rank_proxy >= 8 else (1,)
+            shared = np.zeros(keys.shape[0], bool)
+            for d in axes:
+                shared |= kb[:, d] >= hi_b[d] - 2
+                if a.rank_proxy < 8:
+                    shared |= kb[:, d] <= lo_b[d] + 2
+            near = shared.copy()
+            for d in axes:   # one more layer: launched before the exchange (see near_shared_mask)
+                near |= kb[:, d] >= hi_b[d] - 3
+                if a.rank_proxy < 8:
+                    near |= kb[:, d] <= lo_b[d] + 3
+            order = np.concatenate([np.nonzero(near)[0], np.nonzero(~near)[0]])
+            n_boundary = mt.reorder_partition(near)
+            blocks = np.nonzero(shared[order])[0].astype(np.int32)
+            proxy_blocks = blocks
         if not a.unbinned:
             mt.rebin()
         stage.clear()
         h = None
-        if world > 1 and comm is not None and not overlap:
+        if proxy:
+            from zpc_amd.dist import NativeHaloPlan
+            h = NativeHaloPlan.from_lists(comm, a.side, [(0, 0, proxy_blocks.shape[0])], proxy_blocks)
+            proxy_grid = torch.zeros_like(mt.grid)
+            return nb_, h
+        if world > 1 and comm is not None:
             # key all-gather, shared-block lists and exchange buffers inside the library (zs_rocm_dist_halo_plan_*)
             from zpc_amd.dist import NativeHaloPlan
             pol.syncCtx()
@@ -400,6 +440,8 @@ def main():
             g2p_ev.append((e2, e3))
 
     fused_ev = []
+    from zpc_amd.mpm import HipEvents
+    hip_events = HipEvents()
 
     ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
 
@@ -410,6 +452,14 @@ def main():
         if track:
             e0, e1 = ev(), ev()
             e0.record()
+        if one_call:
+            # grid reset, both block ranges, exchange on the side stream, re-home / commit, grid update, CFL allreduce: ONE call;
+            # the library records the event pair around the transfer kernels itself
+            mt.step_slotted((0.0, -9.8, 0.0), None if a.no_cfl else max_vel, write_all=write_all,
+                            n_boundary=n_boundary if (overlap and halo is not None) else 0, comm=comm, plan=halo if comm is not None else None,
+                            comm_pol=pol_comm if overlap else None, collider=floor, halo_grid=proxy_grid,
+                            events=hip_events.pair() if timed else None)
+            return
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
             mt.g2p2g(write_all=write_all, split=n_boundary, between=lambda: ev_boundary.record(), reorder=reorder)
@@ -588,6 +638,7 @@ def main():
         (lib().zs_rocm_slot_probe if slot_probe else lib().zs_rocm_debug_probe)(pv, 1)
     t0 = time.perf_counter()
     run_steps(a.steps, True)
+    host_enqueue_s = time.perf_counter() - t0   # when the last step was enqueued (== elapsed once the launch queue is full)
     barrier()
     elapsed = time.perf_counter() - t0
     if slot_probe:
@@ -689,8 +740,11 @@ def main():
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
+    if one_call and hip_events.pairs:
+        fused_list = hip_events.elapsed_ms()
+        fused_ms = float(np.mean(fused_list)) if fused_list else 0.0
     if os.environ.get("ZS_BENCH_PER_STEP") and rank == 0:
-        print("per-step fused ms:", " ".join("%.3f" % x.elapsed_time(y) for x, y in fused_ev), file=sys.stderr)
+        print("per-step fused ms:", " ".join("%.3f" % v for v in (hip_events.elapsed_ms() if one_call else [x.elapsed_time(y) for x, y in fused_ev])), file=sys.stderr)
 
     if rank == 0:
         value = n_total * a.steps / elapsed
@@ -732,7 +786,9 @@ def main():
                        "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0,
                        "repartition_trigger": (("closed loop: status word [3] of the slotted step, polled every %d steps" % poll_iv) if closed_loop
                                                else ("every %d steps" % K if K else ("open loop (drift + gravity)" if a.slotted else "none"))),
-                       "repartition_steps": remap_steps[:64], "slot_record_rank0": slot_record},
+                       "repartition_steps": remap_steps[:64], "slot_record_rank0": slot_record,
+                       "step_call": ("one C-ABI call per step (zs_rocm_mpm_step_slotted)" if one_call else "python: one call per kernel / exchange"),
+                       "host_enqueue_us_per_step": host_enqueue_s / a.steps * 1e6},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
@@ -787,6 +843,22 @@ def main():
             del ca, cb
             out["roofline"]["measured_copy"] = copy_gbs
             out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / copy_gbs
+            # ... and the read-only stream ceiling (P2G is 80 % reads: the copy ceiling understates what a read-dominated kernel can
+            # reach): zs::reduce<i32, plus> over 1 GiB, HIP-event time on the policy's stream
+            import zpc_amd as _zs
+            ra = torch.zeros(1 << 28, dtype=torch.int32, device=device)
+            r1 = torch.zeros(1, dtype=torch.int32, device=device)
+            _zs.reduce(pol, ra, None, r1)
+            ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ce[0].record()
+            for _ in range(5):
+                _zs.reduce(pol, ra, None, r1)
+            ce[1].record()
+            torch.cuda.synchronize()
+            read_gbs = ra.numel() * 4 * 5 / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+            del ra
+            out["roofline"]["measured_read"] = read_gbs
+            out["roofline"]["frac_of_measured_read"] = out["roofline"]["achieved"] / read_gbs
         except Exception:
             pass
         if checksum is not None:
@@ -827,12 +899,13 @@ def main():
                 out["config"]["at_rest_ms_per_step"] = None
                 print("at-rest runs failed: %r" % (e,), file=sys.stderr)
         if world == 1 and not a.no_at_rest:
-            # SURVEY 8(d) secondary metrics (BASELINE configs 1 and 2): reduce / exclusive_scan / radix_sort(_pair) at 1 M and 64 M ints,
-            # bht build over 16 M random particles, TileVector<f32,32> 25-channel load + store at 16 M -- each {ms, units_per_s, frac}
+            # SURVEY 8(d) secondary metrics (BASELINE configs 1, 2 and 5): reduce / exclusive_scan / radix_sort(_pair) at 1 M and 64 M ints,
+            # bht build over 16 M random particles, TileVector<f32,32> 25-channel load + store at 16 M, LBvh build / refit / queries /
+            # self-collision broadphase at 10 M boxes -- each {ms, units_per_s, frac}
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_prims
-                rows = bench_prims.main(only=["prims", "tv", "bht"], sizes=(1_000_000, 64_000_000), quiet=True, tv_cases=((16_000_000, 32, 25),))
+                rows = bench_prims.main(only=["prims", "tv", "bht", "lbvh"], sizes=(1_000_000, 64_000_000), quiet=True, tv_cases=((16_000_000, 32, 25),))
                 out.setdefault("secondary", {})["prims"] = [
                     {"name": r["name"], "n": r["n"], "ms": r["ms"], "units_per_s": r["units_per_s"],
                      "bytes_per_unit": r["algorithmic_bytes_per_unit"], "frac": r["frac_of_8TBps"]} for r in rows]

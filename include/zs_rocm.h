@@ -797,6 +797,7 @@ typedef struct zs_rocm_mpm_step {
   zs_rocm_halo_plan *plan;
   zs_rocm_policy *commPolicy;
   float *haloGrid;
+  void *evTransferBegin, *evTransferEnd; /* hipEvent_t or NULL: recorded on the policy's stream around the transfer kernels (timing) */
 } zs_rocm_mpm_step;
 ZS_ROCM_EXPORT int zs_rocm_mpm_step_slotted(zs_rocm_policy *, const zs_rocm_mpm_step *);
 

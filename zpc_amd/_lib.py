@@ -64,6 +64,15 @@ class SlotStorage(C.Structure):
                 ("blockEdge", C.c_void_p)]
 
 
+class MpmStep(C.Structure):
+    """zs_rocm_mpm_step: arguments of zs_rocm_mpm_step_slotted (one sub-step of the slotted MPM path in one call)."""
+    _fields_ = [("params", C.c_void_p), ("particles", Particles), ("table", C.c_void_p), ("gridA", C.c_void_p), ("gridB", C.c_void_p),
+                ("nblocks", C.c_size_t), ("storage", C.c_void_p), ("writeAll", C.c_int), ("extf", C.c_float * 3),
+                ("maxVelSqr", C.c_void_p), ("collider", C.c_void_p), ("nBoundary", C.c_size_t), ("dist", C.c_void_p),
+                ("plan", C.c_void_p), ("commPolicy", C.c_void_p), ("haloGrid", C.c_void_p), ("evTransferBegin", C.c_void_p),
+                ("evTransferEnd", C.c_void_p)]
+
+
 class MpmParams(C.Structure):
     _fields_ = [("model", C.c_int), ("dx", C.c_float), ("dt", C.c_float), ("volume", C.c_float), ("E", C.c_float),
                 ("nu", C.c_float), ("cohesion", C.c_float), ("beta", C.c_float), ("yieldSurface", C.c_float),
@@ -352,6 +361,11 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2p2g_slots.argtypes = [vp, PP, Particles, vp, vp, vp, sz, C.POINTER(SlotStorage), i32, sz, sz, i32]
     L.zs_rocm_mpm_g2p2g_slots.restype = i32
     L.zs_rocm_mpm_partition_edge.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.zs_rocm_mpm_step_slotted.argtypes = [vp, C.POINTER(MpmStep)]
+    L.zs_rocm_mpm_step_slotted.restype = i32
+    L.zs_rocm_dist_halo_plan_from_lists.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                                    C.POINTER(C.c_int), sz]
+    L.zs_rocm_dist_halo_plan_from_lists.restype = vp
     L.zs_rocm_mpm_g2p2g_reorder_range.argtypes = [vp, PP, Particles, Particles, vp, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_grid_update.argtypes = [vp, PP, vp, sz, C.POINTER(C.c_float), vp]
     L.zs_rocm_mpm_g2p.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]

@@ -392,6 +392,12 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
   const bool exchange = a->dist && a->plan && a->plan->total;
   const bool overlap = exchange && a->commPolicy && a->nBoundary > 0 && a->nBoundary < nb;
   int rc = 0;
+  auto stamp = [&](void *ev) {
+    if (!ev) return;
+    Launch L(pol, "step: event");
+    ZSR_CHECK(hipEventRecord((hipEvent_t)ev, L.stream));
+  };
+  stamp(a->evTransferBegin);
   if (overlap) {
     zs_rocm_halo_plan *p = a->plan;
     if (!p->evBoundary) {
@@ -417,6 +423,7 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
     if (rc) return rc;
     rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 1);
     if (rc) return rc;
+    stamp(a->evTransferEnd);
     {
       Launch L(pol, "step: wait for the exchange");
       ZSR_CHECK(hipStreamWaitEvent(L.stream, p->evDone, 0));
@@ -424,6 +431,7 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
   } else {
     rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, nb, 1);
     if (rc) return rc;
+    stamp(a->evTransferEnd);
     if (exchange) {
       rc = zs_rocm_dist_halo_plan_exchange(a->plan, a->dist, pol, hgrid, 0, 7);
       if (rc) return rc;

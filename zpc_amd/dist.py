@@ -215,6 +215,27 @@ class NativeHaloPlan:
         self.bytes_per_exchange = L.zs_rocm_dist_halo_plan_bytes(self._h)
         self.peers = [None] * L.zs_rocm_dist_halo_plan_npeers(self._h)  # (only their number is needed on this side)
 
+    @classmethod
+    def from_lists(cls, comm, side, peers, blocks):
+        """plan from explicit lists: peers = [(rank, offset, count)], blocks = int32 array of local block numbers (zs_rocm_dist_halo_plan_from_lists)"""
+        import ctypes as C
+        import numpy as np
+        from ._lib import lib
+        L = lib()
+        self = cls.__new__(cls)
+        npeers = len(peers)
+        pr = (C.c_int * max(npeers, 1))(*[p[0] for p in peers])
+        po = (C.c_size_t * max(npeers, 1))(*[p[1] for p in peers])
+        pc = (C.c_size_t * max(npeers, 1))(*[p[2] for p in peers])
+        b = np.ascontiguousarray(blocks, np.int32)
+        self._h = L.zs_rocm_dist_halo_plan_from_lists(comm._h, int(side), npeers, pr, po, pc, b.ctypes.data_as(C.POINTER(C.c_int)), b.shape[0])
+        if not self._h:
+            raise RuntimeError("zs_rocm_dist_halo_plan_from_lists failed")
+        self.total_blocks = L.zs_rocm_dist_halo_plan_blocks(self._h)
+        self.bytes_per_exchange = L.zs_rocm_dist_halo_plan_bytes(self._h)
+        self.peers = [None] * npeers
+        return self
+
     def __del__(self):
         try:
             from ._lib import lib

@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, Port, Particles, MpmParams, SlotStorage
+from ._lib import lib, Port, Particles, MpmParams, SlotStorage, MpmStep
 from .containers import Bht
 
 FIXED_COROTATED, DRUCKER_PRAGER, VONMISES_FIXED_COROTATED, NACC = 0, 1, 2, 3  # ConstitutiveModelConfig members with F
@@ -450,6 +450,39 @@ class MpmTransfer:
             if k == 0 and between is not None:
                 between()
 
+    def step_slotted(self, extf=(0.0, 0.0, 0.0), max_vel=None, write_all=False, n_boundary=0, comm=None, plan=None, comm_pol=None,
+                     collider=None, halo_grid=None, events=None):
+        """One whole sub-step on slotted storage behind ONE C-ABI call (zs_rocm_mpm_step_slotted): second grid := 0, fused G2P2G over the
+        boundary blocks [0, n_boundary) then the interior, ghost-block exchange of `plan` on comm_pol's stream overlapping the interior,
+        grid update (+ collider), CFL allreduce(max) of max_vel.  The grids swap: self.grid is the new one afterwards.
+        comm: NativeComm, plan: NativeHaloPlan (both None on a single rank)."""
+        assert self.slotted
+        if getattr(self, "grid2", None) is None or self.grid2.numel() != self.grid.numel():
+            self.grid2 = torch.empty_like(self.grid)
+        src, dst = self.grid, self.grid2
+        a = getattr(self, "_step_args", None)
+        if a is None:
+            a = self._step_args = MpmStep()
+        a.params = C.addressof(self.params)
+        a.particles = self.particles()
+        a.table = self.table.handle
+        a.gridA, a.gridB = src.data_ptr(), dst.data_ptr()
+        a.nblocks = self.nblocks
+        a.storage = C.addressof(self.slot_storage)
+        a.writeAll = int(write_all)
+        a.extf = (C.c_float * 3)(*extf)
+        a.maxVelSqr = max_vel.data_ptr() if max_vel is not None else None
+        a.collider = C.addressof(collider) if collider is not None else None
+        a.nBoundary = int(n_boundary)
+        a.dist = comm._h if comm is not None else None
+        a.plan = plan._h if plan is not None else None
+        a.commPolicy = comm_pol.handle if comm_pol is not None else None
+        a.haloGrid = halo_grid.data_ptr() if halo_grid is not None else None
+        a.evTransferBegin, a.evTransferEnd = (events[0], events[1]) if events is not None else (None, None)   # raw hipEvent_t (HipEvents)
+        if lib().zs_rocm_mpm_step_slotted(self.pol.handle, C.byref(a)) != 0:
+            raise RuntimeError("zs_rocm_mpm_step_slotted failed")
+        self.grid, self.grid2 = dst, src
+
     def margin_violated(self):
         """True if, since construction, an exact-path particle was ever farther than one bin from its bin during a fused step
         (the overlapped multi-GPU exchange is then not valid: see zs_rocm_mpm_g2p2g_range)."""
@@ -505,6 +538,40 @@ class MpmTransfer:
         k = keys.cpu().numpy().reshape(nb, 3)
         g = self.grid.cpu().numpy().reshape(nb, 7, self.side ** 3)
         return {tuple(int(x) for x in k[i]): g[i] for i in range(nb)}
+
+
+class HipEvents:
+    """raw hipEvent_t pairs for timing stretches the library enqueues itself (zs_rocm_mpm_step.evTransferBegin / End)"""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.pairs = []
+
+    def pair(self):
+        e = [C.c_void_p(), C.c_void_p()]
+        for x in e:
+            if self.hip.hipEventCreate(C.byref(x)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+        self.pairs.append(e)
+        return e[0], e[1]
+
+    def elapsed_ms(self):
+        """[ms] of every pair (the stream must have been synchronised)"""
+        out = []
+        for a, b in self.pairs:
+            ms = C.c_float(0)
+            if self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0:
+                out.append(ms.value)
+        return out
+
+    def __del__(self):
+        try:
+            for a, b in self.pairs:
+                self.hip.hipEventDestroy(a)
+                self.hip.hipEventDestroy(b)
+        except Exception:
+            pass
 
 
 PLANE, CUBOID, SPHERE, CYLINDER = 0, 1, 2, 3   # analytic_geometry_e members GeneralBoundary holds (geometry/Collider.h:246-252)
