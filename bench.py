@@ -575,10 +575,13 @@ def main():
         nonlocal done, rebins, check_iv, next_check, best_ms, lost_ms, rebin_cost_ms, next_remap, pending_remap
         for _ in range(count):
             remap_now = (K > 0 and (done + 1) % K == 0) or (next_remap is not None and done + 1 >= next_remap) or pending_remap
+            ts = time.perf_counter()
             if a.fused:
                 step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
             else:
                 step(timed)
+            if timed:
+                host_step_s[0] += time.perf_counter() - ts   # host time inside the step's own call(s): enqueue cost, no poll waits
             done += 1
             if remap_now:
                 remap()
@@ -628,6 +631,7 @@ def main():
                     check_iv = a.rebin_check
                 next_check = done + check_iv
 
+    host_step_s = [0.0]
     run_steps(a.warmup, False)
     barrier()
     probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_debug_probe")  # measurement builds only (tools/ablate.sh PROBE)
@@ -788,6 +792,9 @@ def main():
                                                else ("every %d steps" % K if K else ("open loop (drift + gravity)" if a.slotted else "none"))),
                        "repartition_steps": remap_steps[:64], "slot_record_rank0": slot_record,
                        "step_call": ("one C-ABI call per step (zs_rocm_mpm_step_slotted)" if one_call else "python: one call per kernel / exchange"),
+                       "host_step_call_us_per_step": host_step_s[0] / a.steps * 1e6,   # time the host spends inside the step's call(s)
+                       # wall clock until the last step was enqueued: includes the closed-loop poll, which waits for the status copy of
+                       # two steps earlier (so this follows the device time; the host cost proper is host_step_call_us_per_step)
                        "host_enqueue_us_per_step": host_enqueue_s / a.steps * 1e6},
             "roofline": {"bound": "hbm", "kernel": "p2g_wide_kernel" if not a.unbinned else "p2g_global_kernel",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

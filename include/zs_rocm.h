@@ -368,7 +368,12 @@ typedef struct {
                                                            const int *map, int scatter);                \
   /* (B) canonical form for bit-exact comparison (SURVEY.md 8a note): sort active keys               \
      lexicographically and renumber */                                                                  \
-  ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *);
+  ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *);  \
+  /* (B) renumber the active keys along the Z-order (Morton) curve of (key - min key): consecutive  \
+     entries are spatial neighbours -- the launch order the per-block MPM kernels want (no reference  \
+     counterpart: the reference's numbering is insertion order, Bht.hpp:612-664, and any numbering is \
+     a valid table) */                                                                                  \
+  ZS_ROCM_EXPORT void zs_rocm_order_morton__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *);
 typedef struct zs_rocm_bht_1 zs_rocm_bht_1; /* one handle type per dim; the bucket size is a field of the object */
 typedef struct zs_rocm_bht_2 zs_rocm_bht_2;
 typedef struct zs_rocm_bht_3 zs_rocm_bht_3;

@@ -289,7 +289,7 @@ def _id_box_step(pol, oracle, model, grid_n, cells, drift, box_lo, steps_before,
         mt.g2p2g()
         mt.grid_update(g)
     pol.syncCtx()
-    st0 = mt.check_slots()
+    mt.check_slots()   # folds the 8 warm-up steps into the run-level record and clears the device words
 
     def id_particles():
         """[nid, nchn] rows of the particles that carry an identity, sorted by it"""
@@ -326,7 +326,7 @@ def _id_box_step(pol, oracle, model, grid_n, cells, drift, box_lo, steps_before,
     b = id_particles()
     assert np.array_equal(b[:, 0], mass)                                       # nobody lost, nobody duplicated
     gridB = mt.grid.view(mt.nblocks, 7, side ** 3)[torch.from_numpy(selb).to(dev)].cpu().numpy()
-    out = {"movers_in_step": st1[5] - st0[5], "n_id": nid}
+    out = {"movers_in_step": st1[5], "n_id": nid}   # check_slots() returns the period since the previous call: this one step
     out["x"] = float(np.abs(b[:, 1:4] - pos).max())
     out["v"] = float(np.abs(b[:, 4:7] - vel).max() / np.abs(vel).max())
     out["C"] = float(np.abs(b[:, 7:16] - Cm).max() / np.abs(Cm).max())

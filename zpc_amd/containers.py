@@ -212,6 +212,10 @@ class Bht:
     def canonicalize(self, pol):
         getattr(lib(), "zs_rocm_canonicalize__" + self.s)(pol.handle, self._h)
 
+    def order_morton(self, pol):
+        """renumber the entries along the Z-order curve of their keys (the launch order of the per-block MPM kernels)"""
+        getattr(lib(), "zs_rocm_order_morton__" + self.s)(pol.handle, self._h)
+
 
 class HashTable:
     """zs::HashTable<i32, dim, int> (container/HashTable.hpp:16-592): hash_combine hash, linear probing with stride 127 --

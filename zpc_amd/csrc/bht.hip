@@ -9,6 +9,8 @@ namespace zsr {
 
 void exclusive_scan_u32(Launch &L, const unsigned *in, size_t n, unsigned *out);
 void radix_sort_pair_u32(Launch &L, const unsigned *kin, const int *vin, unsigned *kout, int *vout, size_t n, int sbit, int ebit);
+void radix_sort_pair_u64(Launch &L, const unsigned long long *kin, const int *vin, unsigned long long *kout, int *vout, size_t n, int sbit,
+                         int ebit);
 
 static size_t next_2pow(size_t n) {  // math/bit/Bits.h:177-184
   size_t p = 1;
@@ -217,6 +219,41 @@ template <int DIM> static void bht_canonicalize(zs_rocm_policy *pol, BhtHost &t)
   bht_reorder_impl<DIM>(L, t, perm[cur], /*scatter=*/false, n);  // new key i = old key perm[i]
 }
 
+// Morton numbering: active keys along the Z-order curve of (key - min key).  Consecutive numbers are spatial neighbours in every
+// dimension, which is what the per-block kernels of the MPM path want from their launch order (blocks that share apron nodes run
+// close in time and, with the chunked XCD mapping, in the same L2).  64 / DIM bits per component; an ordering only, any key range works.
+template <int DIM> __global__ void bht_key_min_kernel(const int *activeKeys, int n, int *mn) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    for (int d = 0; d < DIM; ++d) atomicMin(mn + d, activeKeys[(size_t)i * DIM + d]);
+}
+template <int DIM> __global__ void bht_morton_kernel(const int *activeKeys, int n, const int *mn, unsigned long long *code, int *perm) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int BITS = 64 / DIM;
+  unsigned long long c = 0;
+  for (int d = 0; d < DIM; ++d) {
+    const unsigned long long v = (unsigned long long)(unsigned)(activeKeys[(size_t)i * DIM + d] - mn[d]);
+    for (int b = 0; b < BITS && b < 32; ++b) c |= ((v >> b) & 1ull) << (b * DIM + (DIM - 1 - d));
+  }
+  code[i] = c;
+  perm[i] = i;
+}
+template <int DIM> static void bht_order_morton(zs_rocm_policy *pol, BhtHost &t) {
+  Launch L(pol, "bht_order_morton");
+  const int n = bht_size(t, L.stream);
+  if (n <= 1) return;
+  int *perm[2] = {(int *)L.temp(sizeof(int) * n), (int *)L.temp(sizeof(int) * n)};
+  unsigned long long *code = (unsigned long long *)L.temp(sizeof(unsigned long long) * n),
+                     *sorted = (unsigned long long *)L.temp(sizeof(unsigned long long) * n);
+  int *mn = (int *)L.temp(sizeof(int) * 4);
+  ZSR_CHECK(hipMemsetAsync(mn, 0x7f, sizeof(int) * 4, L.stream));
+  hipLaunchKernelGGL((bht_key_min_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.activeKeys, n, mn);
+  hipLaunchKernelGGL((bht_morton_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.activeKeys, n, mn, code, perm[0]);
+  radix_sort_pair_u64(L, code, perm[0], sorted, perm[1], (size_t)n, 0, 64);
+  bht_reorder_impl<DIM>(L, t, perm[1], /*scatter=*/false, n);
+}
+
 static zs_rocm_bht_view_lite *bht_make_view(const BhtHost &t) {  // py_interop/BhtInstantiations.cpp:62-110
   auto *v = new zs_rocm_bht_view_lite;
   v->keys = t.keys; v->indices = t.indices; v->status = t.status; v->activeKeys = t.activeKeys;
@@ -306,6 +343,9 @@ extern "C" {
   }                                                                                                         \
   void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
     bht_canonicalize<D>(pol, b->t);                                                                         \
+  }                                                                                                         \
+  void zs_rocm_order_morton__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
+    bht_order_morton<D>(pol, b->t);                                                                         \
   }
 ZSR_DEFINE_BHT(1, 16)
 ZSR_DEFINE_BHT(2, 16)

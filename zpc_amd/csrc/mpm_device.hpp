@@ -719,6 +719,21 @@ static __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, i
 // ======================================================================================= binning
 // A "bin" is a 4x4x4 group of cells = 64 cells = one wavefront.  SIDE 4: bin == grid block.  SIDE 8: a grid
 // block holds 2x2x2 bins, bin = block * 8 + sub, sub = ((lx>>2)*2 + (ly>>2))*2 + (lz>>2).
+// Launch order of the per-bin kernels.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup i -> XCD i % 8), each
+// with its own L2; bins that are neighbours in number (and, with a spatial numbering of the blocks, in space) add into the same apron
+// nodes.  `xcd_chunked` gives XCD k the k-th contiguous eighth of the launch, walked in order, so that a grid line under float
+// atomics stays in ONE L2 for as long as its bins run instead of bouncing between eight.  A bijection of [0, n); a performance
+// mapping only -- nothing depends on which XCD actually runs a workgroup.
+__device__ __forceinline__ unsigned xcd_chunked(unsigned i, unsigned n) {
+#ifdef ZS_ROCM_NO_XCD_CHUNKS
+  (void)n;
+  return i;
+#else
+  const unsigned q = n >> 3, rem = n & 7u, k = i & 7u, j = i >> 3;
+  return k * q + (k < rem ? k : rem) + j;
+#endif
+}
+
 template <int SIDE> constexpr int bins_per_block() { return (SIDE / 4) * (SIDE / 4) * (SIDE / 4); }
 
 template <int SIDE>
@@ -953,7 +968,7 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float arena[7 * AL::CH];
-  const int bin = blockIdx.x;
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x);
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;  // empty bin (ghost block): uniform exit
   const int lane = threadIdx.x;
@@ -1149,6 +1164,9 @@ constexpr int P2GW_MQ_CAP = 256;  // in-bin movers the wide P2G takes through it
 // `tileBase`: wave-uniform element offset of a tile at or before the bin's first particle.  The per-lane part of every address
 // is then a 32-bit byte offset from a scalar base (global_load_lds_dword v_off, s[base:base+1] offset:imm): ONE address VGPR
 // per round instead of a 64-bit pointer per attribute.
+#ifndef ZS_P2GW_AUX
+#define ZS_P2GW_AUX 0  // cache-policy bits of the record loads (measurement builds: 2 = nt)
+#endif
 template <int LW>
 __device__ __forceinline__ void p2gw_issue(const ParticlesDev &ps, size_t i, bool has, float *buf, size_t tileBase) {
   // every lane of the wave executes the 25 instructions (LDS destination = wave-uniform row + lane * 4); lanes without a
@@ -1162,15 +1180,15 @@ __device__ __forceinline__ void p2gw_issue(const ParticlesDev &ps, size_t i, boo
       else
         return p.base + p.off(o.o) + (size_t)comp * p.cstride();
     };
-    __builtin_amdgcn_global_load_lds(ptr(ps.mass, 0), (__attribute__((address_space(3))) void *)(buf + 0 * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(ptr(ps.mass, 0), (__attribute__((address_space(3))) void *)(buf + 0 * 64), 4, 0, ZS_P2GW_AUX);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.pos, d), (__attribute__((address_space(3))) void *)(buf + (1 + d) * 64), 4, 0, 0);
+    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.pos, d), (__attribute__((address_space(3))) void *)(buf + (1 + d) * 64), 4, 0, ZS_P2GW_AUX);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.vel, d), (__attribute__((address_space(3))) void *)(buf + (4 + d) * 64), 4, 0, 0);
+    for (int d = 0; d < 3; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.vel, d), (__attribute__((address_space(3))) void *)(buf + (4 + d) * 64), 4, 0, ZS_P2GW_AUX);
 #pragma unroll
-    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.C, d), (__attribute__((address_space(3))) void *)(buf + (7 + d) * 64), 4, 0, 0);
+    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.C, d), (__attribute__((address_space(3))) void *)(buf + (7 + d) * 64), 4, 0, ZS_P2GW_AUX);
 #pragma unroll
-    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, 0);
+    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, ZS_P2GW_AUX);
   }
 }
 template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const ParticlesDev &ps, int start) {
@@ -1264,7 +1282,7 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
   float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds);
   __shared__ int mq[P2GW_MQ_CAP];  // particles that sit in another cell of this bin (moved since the last re-bin)
   __shared__ int mqCount;
-  const int bin = blockIdx.x;
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x);
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int lane = threadIdx.x;
@@ -1599,7 +1617,7 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float arena[3 * AL::CH];
-  const int bin = blockIdx.x;
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x);
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int lane = threadIdx.x;
@@ -2023,7 +2041,7 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
   __shared__ int mq[G2P2G_MQ_CAP];
   __shared__ int mqCount;
   if (threadIdx.x == 0) mqCount = 0;
-  const int bin = blockIdx.x + binBase;  // a launch covers a range of blocks (boundary blocks first, see zs_rocm_mpm_g2p2g_range)
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x) + binBase;  // a launch covers a range of blocks (boundary blocks first, see zs_rocm_mpm_g2p2g_range)
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2451,7 +2469,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
 #ifdef ZS_PROBE
   const unsigned long long tEntry = __builtin_readcyclecounter();
 #endif
-  const int bin = blockIdx.x + binBase;
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x) + binBase;
   const int start = binStart[bin], end = binStart[bin + 1];
   if (start == end) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

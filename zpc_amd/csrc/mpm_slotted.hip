@@ -817,7 +817,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   const SlotShared sh{s_varena, s_parena, s_stage, s_smask, s_tab, s_mask0, s_clr, s_arrLocal, s_nbrBlk, s_nbrBin, s_arrCnt, s_arrQ,
                       s_xCnt, s_xq, &s_outCount, &s_sent, &s_homed, &s_xOver};
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bin = blockIdx.x + A.binBase;
+  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x) + A.binBase;
   SLP_T0(tStart);
   const unsigned mask = A.cellMask[(size_t)bin * 64 + lane];
   // round-major enumeration of the occupied slots (every wave walks the rounds; wave w fills the table rows of rounds = w mod 8)

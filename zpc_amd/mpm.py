@@ -137,7 +137,11 @@ class MpmTransfer:
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
         import os
-        if os.environ.get("ZS_ROCM_CANONICAL_PARTITION"):  # block numbers = lexicographic rank of the keys (reproducible across runs)
+        order = os.environ.get("ZS_ROCM_CANONICAL_PARTITION", "")
+        if order == "morton":  # block numbers along the Z-order curve of the block keys
+            self.table.order_morton(self.pol)
+            self.pol.syncCtx()
+        elif order:  # block numbers = lexicographic rank of the keys (reproducible across runs)
             self.table.canonicalize(self.pol)
             self.pol.syncCtx()
         self.nblocks = self.table.size()
