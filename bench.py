@@ -610,7 +610,7 @@ def main():
                     lost_ms += max(0.0, t - 1.01 * best_ms)
                 ctrl_ev.clear()
                 if rebin_cost_ms is None:
-                    rebin_cost_ms = 0.6 * best_ms  # first guess: 14 of 35 channels read + written, plus the ordering passes
+                    rebin_cost_ms = 0.6 * best_ms  # first guess: 14 of 32 channels read + written, plus the ordering passes
                 if lost_ms >= rebin_cost_ms:
                     # particles only (partition, block numbers and halo lists stay), and only the channels the next fused step
                     # reads: m, x, F, logJp -- v, C and the stress are recomputed from the grid.  (MpmTransfer.g2p2g(reorder=True)
@@ -634,8 +634,8 @@ def main():
     host_step_s = [0.0]
     run_steps(a.warmup, False)
     barrier()
-    probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_debug_probe")  # measurement builds only (tools/ablate.sh PROBE)
-    slot_probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_slot_probe")  # tools/ablate_slot.sh PROBE
+    probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_debug_probe")  # measurement builds only (-DZS_PROBE, tools/ab_build.sh)
+    slot_probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_slot_probe")  # -DZS_PROBE build of mpm_slotted.hip
     if probe or slot_probe:
         import ctypes
         pv = (ctypes.c_ulonglong * 16)()
@@ -752,9 +752,10 @@ def main():
 
     if rank == 0:
         value = n_total * a.steps / elapsed
-        # cached stress: P2G reads m,x,v,C + P F^T (100 B) + 7 B grid; G2P additionally reads/writes logJp and writes P F^T
+        # cached stress: the algorithmic figure stays SURVEY 8(d)'s 107 B (m, x, v, C + a 3x3 state + 7 B grid); the kernel itself
+        # reads the symmetric P F^T (6 floats: 88 + 7 B moved); G2P additionally reads/writes logJp and writes the 6 floats
         p2g_bytes = 107.0 if mt.cache_stress else P2G_BYTES[model]
-        g2p_bytes = G2P_BYTES + ((36.0 + (8.0 if model == 1 else 0.0)) if mt.cache_stress else 0.0)
+        g2p_bytes = G2P_BYTES + ((24.0 + (8.0 if model == 1 else 0.0)) if mt.cache_stress else 0.0)
         ach = p2g_bytes * n_local / (max(p2g_ms, 1e-9) * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_p2g.json")

@@ -468,7 +468,9 @@ typedef struct {
   zs_rocm_attr C;     /* 9, column-major */
   zs_rocm_attr F;     /* 9, column-major */
   zs_rocm_attr logJp; /* 1, plastic models only (base may be NULL otherwise) */
-  zs_rocm_attr stress; /* 9, optional (base NULL = off): cached P F^T * volume of the constitutive update.  When present,
+  zs_rocm_attr stress; /* 6 = {xx, xy, xz, yy, yz, zz} of the symmetric P F^T * volume (the Kirchhoff stress times the volume:
+                          symmetric for every isotropic model of P2G.hpp:82-101; r04, was 9), optional (base NULL = off): the
+                          cached result of the constitutive update.  When present,
                           zs_rocm_mpm_g2p evaluates the model on the F it has just updated (and updates logJp) and stores the
                           result here, and zs_rocm_mpm_p2g reads it instead of re-running the 3x3 SVD: the per-particle
                           constitutive work of the reference's P2G (P2G.hpp:60-101) moves to the tail of the previous G2P, where

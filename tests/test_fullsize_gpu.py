@@ -22,14 +22,14 @@ def _bench(args):
 
 
 CHANNELS = (["m"] + ["x%d" % k for k in range(3)] + ["v%d" % k for k in range(3)] + ["C%d" % k for k in range(9)]
-            + ["F%d" % k for k in range(9)] + ["logJp"] + ["PFt%d" % k for k in range(9)])
+            + ["F%d" % k for k in range(9)] + ["logJp"] + ["PFt%d" % k for k in range(6)])
 
 
 def _same_state(a, b, npart, tol_sum, tol_sq):
     """channel sums and sums of squares of two runs; the failure message names the channels and by how much"""
     a, b = np.array(a), np.array(b)
     nch = len(a) // 2
-    names = CHANNELS if nch >= 35 else [c for c in CHANNELS if c != "logJp"]
+    names = CHANNELS if nch >= 32 else [c for c in CHANNELS if c != "logJp"]
     scale = np.sqrt(npart * np.maximum(a[nch:], 1e-30))
     r_sum = np.abs(a[:nch] - b[:nch]) / (tol_sum * scale + 1e-12)
     r_sq = np.abs(a[nch:] - b[nch:]) / (tol_sq * np.abs(a[nch:]) + 1e-12)

@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = (["m"] + ["x%d" % k for k in range(3)] + ["v%d" % k for k in range(3)] + ["C%d" % k for k in range(9)] + ["F%d" % k for k in range(9)]
-         + ["logJp"] + ["PFt%d" % k for k in range(9)])
+         + ["logJp"] + ["PFt%d" % k for k in range(6)])
 
 
 def bench(args):

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libzsrocm.so")
-if os.environ.get("ZS_ROCM_LIB"):  # measurement builds of the SAME library (tools/ablate.sh); announced, never silent
+if os.environ.get("ZS_ROCM_LIB"):  # measurement builds of the SAME library (tools/ab_build.sh); announced, never silent
     LIB_PATH = os.environ["ZS_ROCM_LIB"]
     print("[zpc_amd] using HIP library %s" % LIB_PATH, flush=True)
 

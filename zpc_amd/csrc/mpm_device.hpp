@@ -191,6 +191,26 @@ __device__ __forceinline__ void pft_vol(const float (&P)[9], const float (&F)[9]
     for (int r = 0; r < 3; ++r) PF[r + 3 * c] = (P[r] * F[c] + P[r + 3] * F[c + 3] + P[r + 6] * F[c + 6]) * volume;
 }
 
+// The cached stress attribute (`particles.stress`, written by the tail of G2P / update_stress, read by P2G): P F^T vol is the Kirchhoff
+// stress times the volume, symmetric for every isotropic model of P2G.hpp:82-101 (and for the fluid: -p I + viscosity (C + C^T)), so it
+// is stored as its 6 distinct components {xx, xy, xz, yy, yz, zz} -- 24 instead of 36 bytes per particle on both the G2P write and the
+// P2G read (88 instead of 100 B of particle state per P2G particle).  The symmetric part is taken: the off-diagonal pairs of the
+// computed product differ by rounding only.
+constexpr int STRESS_N = 6;
+__device__ __forceinline__ void stress_pack(const float (&PF)[9], float (&S)[STRESS_N]) {
+  S[0] = PF[0];
+  S[1] = 0.5f * (PF[1] + PF[3]);
+  S[2] = 0.5f * (PF[2] + PF[6]);
+  S[3] = PF[4];
+  S[4] = 0.5f * (PF[5] + PF[7]);
+  S[5] = PF[8];
+}
+__device__ __forceinline__ void stress_unpack(const float (&S)[STRESS_N], float (&PF)[9]) {
+  PF[0] = S[0]; PF[1] = S[1]; PF[2] = S[2];
+  PF[3] = S[1]; PF[4] = S[3]; PF[5] = S[4];
+  PF[6] = S[2]; PF[7] = S[4]; PF[8] = S[5];
+}
+
 struct Material {
   float volume, mu, lam, cohesion, beta, yieldSurface;
   int volCorrection;
@@ -587,7 +607,9 @@ template <int MODEL>
 __device__ __forceinline__ void particle_contrib(const MpmDev &mp, const ParticlesDev &ps, size_t i, float D_inv, float (&contrib)[9]) {
   float F[9];
   if constexpr (MODEL == MPM_CACHED_STRESS) {
-    load_attr<9>(ps.stress, i, contrib);
+    float S[STRESS_N];
+    load_attr<STRESS_N>(ps.stress, i, S);
+    stress_unpack(S, contrib);
   } else {
     load_state<model_is_fluid(MODEL)>(ps.F, i, F);
     float Cp[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -719,18 +741,19 @@ static __global__ __launch_bounds__(256) void build_neighbors_kernel(BhtDev t, i
 // ======================================================================================= binning
 // A "bin" is a 4x4x4 group of cells = 64 cells = one wavefront.  SIDE 4: bin == grid block.  SIDE 8: a grid
 // block holds 2x2x2 bins, bin = block * 8 + sub, sub = ((lx>>2)*2 + (ly>>2))*2 + (lz>>2).
-// Launch order of the per-bin kernels.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup i -> XCD i % 8), each
-// with its own L2; bins that are neighbours in number (and, with a spatial numbering of the blocks, in space) add into the same apron
-// nodes.  `xcd_chunked` gives XCD k the k-th contiguous eighth of the launch, walked in order, so that a grid line under float
-// atomics stays in ONE L2 for as long as its bins run instead of bouncing between eight.  A bijection of [0, n); a performance
-// mapping only -- nothing depends on which XCD actually runs a workgroup.
+// Launch order of the per-bin kernels: plain blockIdx.  (r04, measured: giving XCD k the k-th contiguous eighth of the bins -- the
+// dispatcher deals workgroups round-robin over the 8 XCDs -- changes neither the atomics' write traffic, which is write-through per
+// touched 32-byte sector whatever the order, nor the time for the better: the empty apron bins end up on a few XCDs and the
+// stand-alone P2G runs 1.83 -> 2.09 ms, the slotted step 7.9 -> 11.3 ms; numbering the blocks lexicographically or along the Morton
+// curve instead of in insertion order: 1.86 / 1.91 ms and 8.5 / 8.2 ms.  profiles/r04_launch_order.md.  -DZS_ROCM_XCD_CHUNKS keeps
+// the mapping for measurement builds.)
 __device__ __forceinline__ unsigned xcd_chunked(unsigned i, unsigned n) {
-#ifdef ZS_ROCM_NO_XCD_CHUNKS
-  (void)n;
-  return i;
-#else
+#ifdef ZS_ROCM_XCD_CHUNKS
   const unsigned q = n >> 3, rem = n & 7u, k = i & 7u, j = i >> 3;
   return k * q + (k < rem ? k : rem) + j;
+#else
+  (void)n;
+  return i;
 #endif
 }
 
@@ -955,8 +978,11 @@ template <int MODEL, int LW> struct RecB {  // sweep B inputs: x, F (, logJp) --
   __device__ __forceinline__ void load(const ParticlesDev &ps, size_t i) {
     const POff<LW> o = particle_offset<LW>(ps.pos.chns, i);
     pload<LW, 3>(ps.pos, o, pos);
-    if constexpr (MODEL == MPM_CACHED_STRESS) pload<LW, 9>(ps.stress, o, F);
-    else pload_state<LW, model_is_fluid(MODEL)>(ps.F, o, F);
+    if constexpr (MODEL == MPM_CACHED_STRESS) {
+      float S[STRESS_N];
+      pload<LW, STRESS_N>(ps.stress, o, S);
+      stress_unpack(S, F);
+    } else pload_state<LW, model_is_fluid(MODEL)>(ps.F, o, F);
     if constexpr (model_uses_logjp(MODEL)) logJp = pload1<LW>(ps.logJp, o);
     if constexpr (MODEL == ZS_MPM_EQUATION_OF_STATE) pload<LW, 9>(ps.C, o, C);  // P2G sweep only (G2P recomputes C)
   }
@@ -1148,9 +1174,6 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
   }
 }
 
-#ifdef ZS_ROCM_WITH_P2G_SPLIT  // measurement builds only: the r01 four-wave channel-split P2G
-#include "../../tools/measure/p2g_split.hpp"
-#endif
 
 // ---- "wide" cached-stress P2G: ONE wave per bin carries all 7 channels (27 x 7 = 189 register accumulators).
 // The four-wave split above repeats the arena / weight / address work in every wave (PMC: 1113 VALU instructions per
@@ -1158,7 +1181,7 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
 // work is done once (~600 VALU per round).  The price is 2 waves per SIMD; the latency the occupancy no longer hides is
 // covered by asynchronous global -> LDS loads (global_load_lds_dword: no staging VGPRs) issued one round ahead into a
 // double-buffered record area of the LDS.
-constexpr int P2GW_NF = 25;
+constexpr int P2GW_NF = 16 + STRESS_N;  // rows of a record: m, x, v, C, symmetric stress
 constexpr int P2GW_MQ_CAP = 256;  // in-bin movers the wide P2G takes through its LDS queue  // m, x(3), v(3), C(9), P F^T vol(9)
 
 // `tileBase`: wave-uniform element offset of a tile at or before the bin's first particle.  The per-lane part of every address
@@ -1188,7 +1211,7 @@ __device__ __forceinline__ void p2gw_issue(const ParticlesDev &ps, size_t i, boo
 #pragma unroll
     for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.C, d), (__attribute__((address_space(3))) void *)(buf + (7 + d) * 64), 4, 0, ZS_P2GW_AUX);
 #pragma unroll
-    for (int d = 0; d < 9; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, ZS_P2GW_AUX);
+    for (int d = 0; d < STRESS_N; ++d) __builtin_amdgcn_global_load_lds(ptr(ps.stress, d), (__attribute__((address_space(3))) void *)(buf + (16 + d) * 64), 4, 0, ZS_P2GW_AUX);
   }
 }
 template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const ParticlesDev &ps, int start) {
@@ -1239,7 +1262,8 @@ __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &a
     float Px[3][3], Py[3][3], Pz[3][3], wzk[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float c0 = rec[(16 + d) * 64], c1 = rec[(19 + d) * 64], c2 = rec[(22 + d) * 64];
+      // row d of the symmetric P F^T vol {xx, xy, xz, yy, yz, zz} (rows 16..21 of the record)
+      const float c0 = rec[(16 + d) * 64], c1 = rec[(16 + (d == 0 ? 1 : d == 1 ? 3 : 4)) * 64], c2 = rec[(16 + (d == 0 ? 2 : d == 1 ? 4 : 5)) * 64];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         Px[k][d] = c0 * xo[0][k];
@@ -1267,30 +1291,54 @@ __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &a
   }
 }
 
-// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of 6.4 KB)
-template <int SIDE, int LW, int DEPTH>
-static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
-                                                       const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  using AL = ArenaLds;
+// LDS arena shared by the G bins of one workgroup of p2g_wide_kernel: G = 1 one bin (6^3 nodes, ArenaLds), G = 2 the two bins of a
+// block that are neighbours in z (4 x 4 x 8 cells, 6 x 6 x 10 nodes), G = 4 the four bins of a half block (4 x 8 x 8 cells, 6 x 10 x 10
+// nodes).  Strides from a search over (SY, SX): for a fixed stencil offset the 64 cells of a bin land on 32 distinct banks per half wave.
+template <int G> struct ArenaLdsG;
+template <> struct ArenaLdsG<1> {
+  static constexpr int WX = 6, WY = 6, WZ = 6, SY = ArenaLds::SY, SX = ArenaLds::SX, CH = WX * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+template <> struct ArenaLdsG<2> {
+  static constexpr int WX = 6, WY = 6, WZ = 10, SY = 12, SX = 80, CH = WX * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+template <> struct ArenaLdsG<4> {
+  static constexpr int WX = 6, WY = 10, WZ = 10, SY = 12, SX = 144, CH = WX * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+
+// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of P2GW_NF x 256 B per wave).
+// G = bins (= waves) per workgroup.  Every wave streams its own bin exactly as a one-wave workgroup would (nothing is shared while the
+// records flow); what the G waves share is the flush: their register stencils go into ONE arena and the workgroup issues one set of
+// global float atomics for it.  The atomics are what the kernel writes (every atomic instruction writes the 32-byte sectors it touches
+// through to memory, whatever the launch order: profiles/r04_launch_order.md), and neighbouring bins' aprons overlap: per 8^3 block
+// 8 x 7 x 36 rows x 1.5 sectors = 3024 sector writes with G = 1, 2016 with G = 2 (a row of 10 z-nodes = the block's own 32-byte row + 8
+// bytes of the next block's), 1680 with G = 4.
+template <int SIDE, int LW, int DEPTH, int G>
+static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+                                                           const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  static_assert(G == 1 || (SIDE == 8 && (G == 2 || G == 4)), "G bins of one block");
+  using AL = ArenaLdsG<G>;
   constexpr int NC = SIDE * SIDE * SIDE;
   constexpr int NB = DEPTH + 1;
-  // the record buffers and the flush arena are never live at the same time: one LDS region serves both, so that DEPTH = 2
-  // (19.2 KB) still leaves room for the 8 waves per CU the register file allows
-  constexpr int LDSF = NB * P2GW_NF * 64 > 7 * AL::CH ? NB * P2GW_NF * 64 : 7 * AL::CH;
+  constexpr int WBUF = NB * P2GW_NF * 64;  // floats of record buffers per wave
+  // the record buffers and the flush arena are never live at the same time: one LDS region serves both
+  constexpr int LDSF = G * WBUF > 7 * AL::CH ? G * WBUF : 7 * AL::CH;
   __shared__ float lds[LDSF];
+  __shared__ int mq[G][P2GW_MQ_CAP];  // particles that sit in another cell of their bin (moved since the last re-bin)
+  __shared__ int mqCount[G];
+  const int w = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (w in an SGPR)
+  const int bin0 = (int)xcd_chunked(blockIdx.x, gridDim.x) * G, bin = bin0 + w;
+  if (binStart[bin0] == binStart[bin0 + G]) return;  // none of the G bins holds a particle (workgroup-uniform)
   float *arena = lds;
-  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds);
-  __shared__ int mq[P2GW_MQ_CAP];  // particles that sit in another cell of this bin (moved since the last re-bin)
-  __shared__ int mqCount;
-  const int bin = (int)xcd_chunked(blockIdx.x, gridDim.x);
+  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds + w * WBUF);
   const int start = binStart[bin], end = binStart[bin + 1];
-  if (start == end) return;
-  const int lane = threadIdx.x;
-  if (lane == 0) mqCount = 0;
+  if (lane == 0) mqCount[w] = 0;
   __syncthreads();
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
+  const unsigned cnt = start == end ? 0u : cellCount[(size_t)bin * 64 + lane];
   const float dxi = 1.0f / mp.dx;
   const float kscale = -mp.dt * (4.f * dxi * dxi);  // contrib = -dt D_inv (P F^T vol)
   float acc[27][7];
@@ -1328,8 +1376,10 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
       }
     }
     // wait until only the records issued AFTER the current one are still in flight
-    if (issued >= 3) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+    // (a record is P2GW_NF loads; vmcnt holds 6 bits: two records in flight is the most that can be told apart)
+    static_assert(2 * P2GW_NF <= 63, "vmcnt range");
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P2GW_NF) : "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2GW_NF) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (has0) {
       const float *rec = pbuf[slot] + lane;
@@ -1340,12 +1390,12 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
       if (ocx == cx && ocy == cy && ocz == cz) {
         p2gw_accumulate(mp, ar, rec, kscale, acc);
       } else {
-        // another cell of the same bin: queued for the post-pass into this bin's arena; outside the bin: exact path afterwards
+        // another cell of the same bin: queued for the post-pass into the arena; outside the bin: exact path afterwards
         bool queued = false;
         if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
-          const int q = atomicAdd(&mqCount, 1);
+          const int q = atomicAdd(&mqCount[w], 1);
           if (q < P2GW_MQ_CAP) {
-            mq[q] = i0;
+            mq[w][q] = i0;
             queued = true;
           }
         }
@@ -1356,33 +1406,40 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
     slot = slot + 1 == NB ? 0 : slot + 1;
     has0 = walk.next(i0, any);
   }
-  __syncthreads();  // every record has been consumed: the region becomes the arena
-  for (int k = lane; k < 7 * AL::CH; k += 64) arena[k] = 0.f;
+  __syncthreads();  // every record of every wave has been consumed: the region becomes the arena
+  for (int k = threadIdx.x; k < 7 * AL::CH; k += 64 * G) arena[k] = 0.f;
   __syncthreads();
-  float *a0 = arena + AL::at(cx, cy, cz);
+  // this bin's corner inside the workgroup's arena: the G bins differ in z (G = 2) or in y and z (G = 4)
+  const int ay = G == 4 ? (w >> 1) * 4 : 0, az = G == 1 ? 0 : (w & 1) * 4;
+  float *a0 = arena + AL::at(cx, cy + ay, cz + az);
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases (one wave: its LDS operations execute in order)
+  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases: in a phase the 64 G lanes of the workgroup own 64 G distinct nodes
     float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
 #pragma unroll
     for (int ch = 0; ch < 7; ++ch) g[ch * AL::CH] += acc[k][ch];
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (G == 1) __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+    else __syncthreads();
   }
   __syncthreads();
   {  // post-pass: the queued in-bin particles, one lane each, added to the arena with LDS atomics (same values as the exact path)
-    const int nm = mqCount < P2GW_MQ_CAP ? mqCount : P2GW_MQ_CAP;
+    const int nm = mqCount[w] < P2GW_MQ_CAP ? mqCount[w] : P2GW_MQ_CAP;
     for (int q = lane; q < nm; q += 64) {
-      const size_t i = (size_t)mq[q];
+      const size_t i = (size_t)mq[w][q];
       float pos[3], vel[3], C[9], PF[9];
       load_attr<3>(ps.pos, i, pos);
       load_attr<3>(ps.vel, i, vel);
       load_attr<9>(ps.C, i, C);
-      load_attr<9>(ps.stress, i, PF);
+      {
+        float S[STRESS_N];
+        load_attr<STRESS_N>(ps.stress, i, S);
+        stress_unpack(S, PF);
+      }
       const float m = ps.mass.base[ps.mass.off(i)];
 #pragma unroll
       for (int d = 0; d < 9; ++d) PF[d] *= kscale;
       Arena ar;
       make_arena(mp.dx, pos, ar);
-      float *b0 = arena + AL::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1], ar.corner[2] - geo.org[2]);
+      float *b0 = arena + AL::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1] + ay, ar.corner[2] - geo.org[2] + az);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1402,10 +1459,12 @@ static __global__ __launch_bounds__(64, 2) void p2g_wide_kernel(MpmDev mp, Parti
     }
     __syncthreads();
   }
-  for (int node = lane; node < 216; node += 64) {
-    const int x = node / 36, y = (node / 6) % 6, z = node % 6;
+  // flush: origin of the workgroup's arena inside its block = the origin of its first bin
+  const int o0[3] = {geo.o[0], geo.o[1] - ay, geo.o[2] - az};
+  for (int node = threadIdx.x; node < AL::WX * AL::WY * AL::WZ; node += 64 * G) {
+    const int x = node / (AL::WY * AL::WZ), y = (node / AL::WZ) % AL::WY, z = node % AL::WZ;
     int slot2, cell;
-    arena_to_grid<SIDE>(geo.o, x, y, z, slot2, cell);
+    arena_to_grid<SIDE>(o0, x, y, z, slot2, cell);
     const int bn = nbr[(size_t)geo.block * 8 + slot2];
     if (bn >= 0) {
       const float *a = arena + AL::at(x, y, z);
@@ -1479,7 +1538,9 @@ __device__ __forceinline__ void update_stress(const MpmDev &mp, const ParticlesD
     if constexpr (model_uses_logjp(SMODEL)) lj = pload1<LW>(ps.logJp, o);
     model_stress<SMODEL>(mp.mat, lj, Fl, PF, C);
     if constexpr (model_uses_logjp(SMODEL)) pstore1<LW>(ps.logJp, o, lj);
-    pstore<LW, 9>(ps.stress, o, PF);
+    float S[STRESS_N];
+    stress_pack(PF, S);
+    pstore<LW, STRESS_N>(ps.stress, o, S);
   }
 }
 
@@ -1915,28 +1976,11 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
       } else {
         float vel[3], C[9];
-#ifdef ZS_ABLATE_GATHER  // measurement-only build: the 27-node gather replaced by three LDS reads
-        {
-          const float *g0 = varena + AL::at(ocx, ocy, ocz);
-#pragma unroll
-          for (int d = 0; d < 3; ++d) vel[d] = g0[d * AL::CH];
-#pragma unroll
-          for (int d = 0; d < 9; ++d) C[d] = vel[d % 3] * D_inv * 1e-9f;
-        }
-#else
         g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
-#endif
         const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
         float pos[3];
-#ifdef ZS_ABLATE_FREEZE  // measurement-only builds: garbage velocities must not move particles or blow F up (same instruction count)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * 1e-14f;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) C[d] *= 1e-14f;
-#else
 #pragma unroll
         for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
-#endif
         float F[9], PF[9];
         advance_state<model_is_fluid(SMODEL)>(cur.F, C, mp.dt, F);
         pstore_state<LW, model_is_fluid(SMODEL)>(ps.F, o, F);
@@ -1945,12 +1989,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         {  // F has been stored above: the plastic models may project this local copy
           float lj = 0.f;
           if constexpr (DP) lj = cur.logJp;
-#ifdef ZS_ABLATE_STRESS  // measurement-only build (tools/ablate.sh): constitutive update replaced by a copy, to time its marginal cost
-#pragma unroll
-          for (int d = 0; d < 9; ++d) PF[d] = F[d] * mp.mat.mu;
-#else
           model_stress<SMODEL>(mp.mat, lj, F, PF, C);
-#endif
           if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
         }
         // where is it now?  same cell as this lane: register accumulation (phase 2).  Another cell of the same bin: queued in
@@ -1961,7 +2000,11 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         if (WRITE_ALL || moved) {
           pstore<LW, 3>(ps.vel, o, vel);
           pstore<LW, 9>(ps.C, o, C);
-          pstore<LW, 9>(ps.stress, o, PF);
+          {
+            float S[STRESS_N];
+            stress_pack(PF, S);
+            pstore<LW, STRESS_N>(ps.stress, o, S);
+          }
         }
         if (moved) {
           bool queued = false;
@@ -2000,11 +2043,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     for (int rr = R0; rr < R0 + 2; ++rr) {
       const unsigned long long vm = smask[par * 4 + rr];
       if (vm == 0ull) continue;
-#ifdef ZS_ABLATE_CONSUME  // measurement-only build: the phase-2 stencil accumulation replaced by one add per staged record
-      if ((vm >> lane) & 1ull) acc[0][0] += stage[(size_t)(par * 4 + rr) * (G2P2G_NF * 64) + lane];
-#else
       if ((vm >> lane) & 1ull) g2p2g_consume<STRESS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
-#endif
     }
     par ^= 1;
     cur = nxt;
@@ -2050,17 +2089,11 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-#ifdef ZS_ABLATE_PROLOGUE  // measurement-only build: no nbr / grid A loads at the head of a bin
-    float *a = varena + AL::at(x, y, z);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = 0.01f + 1e-9f * (float)(slot + cell);
-#else
     const int bn = nbr[(size_t)geo.block * 8 + slot];
     float *a = varena + AL::at(x, y, z);
     const float *g = gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
-#endif
   }
   for (int k = tid; k < 2 * 7 * AL::CH; k += 256) parena[k] = 0.f;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
@@ -2097,7 +2130,13 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
 #pragma unroll
       for (int d = 0; d < 3; ++d) { pos[d] = cload(ps.pos, d); vel[d] = cload(ps.vel, d); }
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { C[d] = cload(ps.C, d); PF[d] = cload(ps.stress, d) * kscale; }
+      for (int d = 0; d < 9; ++d) C[d] = cload(ps.C, d);
+      {
+        float S[STRESS_N];
+#pragma unroll
+        for (int d = 0; d < STRESS_N; ++d) S[d] = cload(ps.stress, d) * kscale;
+        stress_unpack(S, PF);
+      }
       Arena ar;
       make_arena(mp.dx, pos, ar);
       const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
@@ -2130,12 +2169,7 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
     arena_to_grid<SIDE>(geo.o, x, y, z, slot, cell);
-#ifdef ZS_ABLATE_EPILOGUE  // measurement-only build: one atomic per workgroup instead of the arena flush
-    const int bn = -1;
-    if (tid == 0) unsafeAtomicAdd(gridB + (size_t)geo.block * 7 * NC, parena[AL::at(x, y, z)]);
-#else
     const int bn = nbr[(size_t)geo.block * 8 + slot];
-#endif
     const float *a = parena + AL::at(x, y, z);
     if (bn >= 0) {
       float *g = gridB + (size_t)bn * 7 * NC + cell;
@@ -2145,11 +2179,9 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
         if (v != 0.f) unsafeAtomicAdd(g + ch * NC, v);
       }
     }
-#ifndef ZS_ABLATE_EPILOGUE
     else if (a[0] + a[7 * AL::CH] != 0.f) {
       staleGCount[9] = 1;  // mass for a node whose block is not in the partition: the partition no longer covers the particles
     }
-#endif
   }
 }
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -2403,7 +2435,11 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
           if (WRITE_ALL || moved) {
             pstore<LW, 3>(ps.vel, o, vel);
             pstore<LW, 9>(ps.C, o, C);
-            pstore<LW, 9>(ps.stress, o, PF);
+            {
+            float S[STRESS_N];
+            stress_pack(PF, S);
+            pstore<LW, STRESS_N>(ps.stress, o, S);
+          }
           }
           if (moved) {
             bool queued = false;
@@ -2518,7 +2554,13 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
 #pragma unroll
       for (int d = 0; d < 3; ++d) { pos[d] = cload(ps.pos, d); vel[d] = cload(ps.vel, d); }
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { C[d] = cload(ps.C, d); PF[d] = cload(ps.stress, d) * kscale; }
+      for (int d = 0; d < 9; ++d) C[d] = cload(ps.C, d);
+      {
+        float S[STRESS_N];
+#pragma unroll
+        for (int d = 0; d < STRESS_N; ++d) S[d] = cload(ps.stress, d) * kscale;
+        stress_unpack(S, PF);
+      }
       Arena ar;
       make_arena(mp.dx, pos, ar);
       const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
@@ -2568,15 +2610,6 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
   if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) atomicAdd(&g_probe[7], 1ull);  // sampled workgroups
 #endif
 }
-#ifdef ZS_ROCM_WITH_P2G_HALF  // measurement builds only: two waves per bin, half of the stencil nodes each
-#include "../../tools/measure/p2g_half.hpp"
-#endif
-#ifdef ZS_ROCM_WITH_P2G_RS  // measurement builds only: role-split stand-alone P2G (slower than p2g_wide_kernel, see the header)
-#include "../../tools/measure/p2g_rs.hpp"
-#endif
-#ifdef ZS_ROCM_WITH_PERSIST  // measurement builds only (tools/ablate.sh): the persistent variant lives outside the product tree
-#include "../../tools/measure/g2p2g_persist.hpp"
-#endif
 // queue G: gather from grid A with hash queries (stores the full state), then scatter to grid B; queue P: scatter only
 template <int SIDE, int SMODEL>
 static __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *gridA, float *gridB,
@@ -2615,7 +2648,11 @@ static __global__ __launch_bounds__(256) void stale_scatter_coop_kernel(MpmDev m
     load_attr<3>(ps.pos, i, pos);
     load_attr<3>(ps.vel, i, vel);
     load_attr<9>(ps.C, i, C);
-    load_attr<9>(ps.stress, i, contrib);
+    {
+      float S[STRESS_N];
+      load_attr<STRESS_N>(ps.stress, i, S);
+      stress_unpack(S, contrib);
+    }
     const float mass = ps.mass.base[ps.mass.off(i)];
 #pragma unroll
     for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * kscale;

@@ -5,19 +5,8 @@
 namespace zsr {
 
 template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const ParticlesDev &pd, const BhtDev &t, const FusedArgs &a) {
-  // A/B runs only: ZS_ROCM_G2P2G_VARIANT=1 four-wave kernel, 3 persistent role-split (measurement builds); default: role-split, one workgroup per bin
+  // A/B runs only: ZS_ROCM_G2P2G_VARIANT=1 four-wave kernel; default: role-split, one workgroup per bin
   static const int variant = [] { const char *e = getenv("ZS_ROCM_G2P2G_VARIANT"); return e ? atoi(e) : 0; }();
-#ifdef ZS_ROCM_WITH_PERSIST
-  static const int numCUs = [] {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  const unsigned ngroups = (a.nbins + PG_GB - 1) / PG_GB;
-  const unsigned psGrid = ngroups < 2u * (unsigned)numCUs ? ngroups : 2u * (unsigned)numCUs;
-  const PersistArgs pa{a.gridA, a.gridB, a.binStart, a.cellCount, a.nbr, a.staleG, a.counts, a.staleP, a.counts + 32, a.binBase, (int)a.nbins};
-#endif
 #define CALL_G2P2G4(SS, M, LWv, WA, RO)                                                                                               \
   hipLaunchKernelGGL((g2p2g_binned_kernel<SS, M, LWv, WA, RO>), dim3(a.nbins), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,    \
                      a.binStart, a.cellCount, a.nbr, a.staleG, a.counts, a.staleP, a.counts + 32, a.binBase, a.order, a.inDelta);     \
@@ -34,31 +23,12 @@ template <int S> void g2p2g_launch_side(Launch &L, const MpmDev &mp, const Parti
                      (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag);  \
   hipLaunchKernelGGL((stale_scatter_coop_kernel<SS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridB,                  \
                      (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag)
-// persistent role-split kernel (measurement builds only, -DZS_ROCM_WITH_PERSIST: it executes 10 % fewer cycles than the
-// one-workgroup-per-bin form but 9 % more instructions, and the pass is VALU-throughput-bound -- see DESIGN.md)
-#ifdef ZS_ROCM_WITH_PERSIST
-#define ZS_HAVE_PERSIST 1
-#else
-#define ZS_HAVE_PERSIST 0
-#define CALL_G2P2G_PS(SS, M, LWv, WA) (void)0
-#endif
-#ifdef ZS_ROCM_WITH_PERSIST
-#define CALL_G2P2G_PS(SS, M, LWv, WA)                                                                                                 \
-  hipLaunchKernelGGL((g2p2g_persist_kernel<SS, M, LWv, WA>), dim3(psGrid), dim3(512), 0, L.stream, mp, pd, t, pa);                     \
-  hipLaunchKernelGGL((g2p2g_stale_kernel<SS, M>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridA, a.gridB,             \
-                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag);  \
-  hipLaunchKernelGGL((stale_scatter_coop_kernel<SS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, a.gridB,                  \
-                     (const int *)a.staleG, (const int *)a.counts, (const int *)a.staleP, (const int *)(a.counts + 32), a.driftFlag)
-#endif
 #define CALL_G2P2G3(SS, M, LWv)                                   \
   do {                                                            \
     if (a.order) { CALL_G2P2G4(SS, M, LWv, false, true); }        \
     else if (variant == 1) {                                      \
       if (a.writeAll) { CALL_G2P2G4(SS, M, LWv, true, false); }   \
       else { CALL_G2P2G4(SS, M, LWv, false, false); }             \
-    } else if (variant == 3 && ZS_HAVE_PERSIST) {                 \
-      if (a.writeAll) { CALL_G2P2G_PS(SS, M, LWv, true); }        \
-      else { CALL_G2P2G_PS(SS, M, LWv, false); }                  \
     } else if (a.writeAll) { CALL_G2P2G_RS(SS, M, LWv, true); }   \
     else { CALL_G2P2G_RS(SS, M, LWv, false); }                    \
   } while (0)

@@ -19,61 +19,25 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
     const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
-    // cached stress: the one-wave "wide" kernel (measurement builds with -DZS_ROCM_WITH_P2G_SPLIT: ZS_ROCM_P2G_SPLIT=1 selects the r01
-    // four-wave channel split for comparison)
-#ifdef ZS_ROCM_WITH_P2G_SPLIT
-    static const bool split4 = [] { const char *e = getenv("ZS_ROCM_P2G_SPLIT"); return e && e[0] == '1'; }();
-#else
-    constexpr bool split4 = false;
-#endif
-#ifdef ZS_ROCM_WITH_P2G_HALF  // measurement builds: ZS_ROCM_P2G_KERNEL=half selects two waves per bin (p2g_half_kernel)
-    static const bool halfKernel = [] { const char *e = getenv("ZS_ROCM_P2G_KERNEL"); return e && e[0] == 'h'; }();
-    if (kmodel == MPM_CACHED_STRESS && !split4 && halfKernel) {
-#define CALL_P2G_HALF(S, M, LWv)                                                                                                        \
-  hipLaunchKernelGGL((p2g_half_kernel<S, LWv>), dim3(nbins), dim3(128), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale,   \
-                     staleCount);                                                                                                       \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
-      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_HALF, 4, 0);
-      else ZSR_DISPATCH_LW(lw, CALL_P2G_HALF, 8, 0);
-      return;
-    }
-#endif
-#ifdef ZS_ROCM_WITH_P2G_RS  // measurement builds: ZS_ROCM_P2G_KERNEL=rs selects loader waves + channel-set consumer waves (p2g_rs_kernel)
-    static const bool rsKernel = [] { const char *e = getenv("ZS_ROCM_P2G_KERNEL"); return e && e[0] == 'r'; }();
-    if (kmodel == MPM_CACHED_STRESS && !split4 && rsKernel) {
-#define CALL_P2G_RS(S, M, LWv)                                                                                                          \
-  hipLaunchKernelGGL((p2g_rs_kernel<S, LWv>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale,     \
-                     staleCount);                                                                                                       \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
-      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_RS, 4, 0);
-      else ZSR_DISPATCH_LW(lw, CALL_P2G_RS, 8, 0);
-      return;
-    }
-#endif
-    if (kmodel == MPM_CACHED_STRESS && !split4) {
+    if (kmodel == MPM_CACHED_STRESS) {  // cached stress: the "wide" kernel, one wave per bin
+      // bins per workgroup = waves that share one flush arena (8^3 blocks only; see p2g_wide_kernel).  ZS_ROCM_P2G_GROUP = 1 | 2 | 4
+      // overrides the default for A/B runs.
+      static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 4; }();
+#define CALL_P2G_WIDE_G(S, LWv, Gv)                                                                                                     \
+  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
+                     nbr, stale, staleCount)
 #define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
-  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, stale, \
-                     staleCount);                                                                                                      \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
+  do {                                                                                                                                  \
+    if (S == 8 && group == 4) { CALL_P2G_WIDE_G(8, LWv, 4); }                                                                            \
+    else if (S == 8 && group == 2) { CALL_P2G_WIDE_G(8, LWv, 2); }                                                                       \
+    else { CALL_P2G_WIDE_G(S, LWv, 1); }                                                                                                \
+    hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid,            \
+                       (const int *)stale, (const int *)staleCount);                                                                    \
+  } while (0)
       if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
       else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
       return;
     }
-#ifdef ZS_ROCM_WITH_P2G_SPLIT
-    if (kmodel == MPM_CACHED_STRESS) {
-#define CALL_P2G_SPLIT(S, M, LWv)                                                                                                      \
-  hipLaunchKernelGGL((p2g_binned_split_kernel<S, LWv>), dim3(nbins), dim3(256), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr, \
-                     stale, staleCount);                                                                                               \
-  hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid, (const int *)stale,  \
-                     (const int *)staleCount)
-      if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 4, 0);
-      else ZSR_DISPATCH_LW(lw, CALL_P2G_SPLIT, 8, 0);
-      return;
-    }
-#endif
 #define CALL_P2G_BINNED3(S, M, LWv)                                                                                                  \
   hipLaunchKernelGGL((p2g_binned_kernel<S, M, LWv>), dim3(nbins), dim3(64), 0, L.stream, mp, pd, t, grid, binStart, cellCount, nbr,   \
                      stale, staleCount);                                                                                             \

@@ -361,9 +361,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0;
 #endif
-#ifdef ZS_X_PRIO
-  __builtin_amdgcn_s_setprio(ZS_X_PRIO);
-#endif
   for (int it = 0; it <= nchunks; ++it) {
     SLP_T0(tIt);
     if (it < nchunks) {
@@ -413,20 +410,12 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
           const float pm = cur.m;
           float plj = 0.f;
           if constexpr (DP) plj = cur.logJp;
-#ifdef ZS_X_NOMOVE
-          const bool moved = false;
-#else
           const bool moved = nc[0] != cx || nc[1] != cy || nc[2] != cz;
-#endif
           // X - floor(X - 0.5) rounded up to 1.5, or X - 0.5 rounded up to an integer and left it below 0.5 (|X| < 1 only): the reference
           // applies base_node to the local position once more and takes the weights of d0 -+ 1 on the unchanged corner
           // (InterpolationKernel.hpp:108 on simulation/Utils.hpp:59-60; make_arena restates it).  The lane = cell consumers take the staged
           // lpn as d0; such a particle is scattered through the consumers' list instead, which folds d0 as the reference does.
-#ifdef ZS_X_NOEDGE  // measurement / test-of-the-test build: the consumers take every staged lpn as d0
-          const bool edge = false;
-#else
           const bool edge = !(lpn[0] >= 0.5f && lpn[0] < 1.5f && lpn[1] >= 0.5f && lpn[1] < 1.5f && lpn[2] >= 0.5f && lpn[2] < 1.5f);
-#endif
           if (W == 0) SLP_ADD(5, tIt);  // [5] producer: start of the iteration -> mover block (record wait, gather, advance)
           SLP_T0(tMv);
           bool outbox = false;   // it gets an outbox record (new cell in a neighbour bin: slot_rehome_kernel finds its slot; or fallback scatter)
@@ -463,14 +452,12 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                 A.status[1] = 1;  // cell full: the particle is scattered but has no new slot
                 keep = true;
               }
-#ifndef ZS_X_NOINBIN
               const unsigned q = edge ? (unsigned)SL_ARRQ : atomicAdd(&arrCnt[par][dl], 1u);
               if (q < (unsigned)SL_ARRQ) {  // the lane of the new cell scatters it (arrival queue of the chunk)
                 viaX = false;
                 staged = true;
                 arrQ[par][dl][q] = (unsigned short)((grp % SL_NG) * 64 + lane);
               }
-#endif
             } else {
               const int dbin = nbrBin[code];
               if (dbin >= 0) {
@@ -528,7 +515,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
               atomicAdd(sent, 1);
             }
           } else {
-#ifndef ZS_X_NOLOWER
             {
               // A stayer that holds the TOP round of its cell while a round below is free re-homes downwards: the rounds of a bin are set by
               // the highest occupied round of its cells, and a particle that once sat on top of a crowd keeps the bin tall long after the
@@ -547,7 +533,6 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
                 }
               }
             }
-#endif
             pstore_state<LW, FLUID>(ps.F, o, F);
             pstore<LW, 3>(ps.pos, o, pos);
             if (WRITE_ALL) {
@@ -578,7 +563,11 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             }
             if (!moved || home || keep) {
               if constexpr (DP) pstore1<LW>(ps.logJp, o, lj);
-              if (WRITE_ALL) pstore<LW, 9>(ps.stress, o, PF);
+              if (WRITE_ALL) {
+                float S[STRESS_N];
+                stress_pack(PF, S);
+                pstore<LW, STRESS_N>(ps.stress, o, S);
+              }
               if (moved || lowered) pstore1<LW>(ps.mass, o, pm);
             }
           }
@@ -651,11 +640,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
       const int par = (it - 1) % 3;
       const int produced = 256 * it < total ? 256 * it : total;
       const unsigned qn = arrCnt[par][lane];
-#ifdef ZS_X_NOARR
-      const int na = 0;
-#else
       const int na = qn < (unsigned)SL_ARRQ ? (int)qn : SL_ARRQ;
-#endif
       int ai = 0;
       if (CS == 0) arrCnt[(it + 1) % 3][lane] = 0u;  // the counters the NEXT chunk will use (last read one iteration ago)
 #pragma unroll 1
@@ -685,11 +670,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
           const unsigned p = arrQ[par][lane][ai++];
           spos = (int)(p >> 6) * (G2P2G_NF * 64) + (int)(p & 63u);
         }
-#ifdef ZS_X_HALFCONS  // measurement only: every second consumer iteration dropped (how much of the step is the consumers' VALU work?)
-        if (spos >= 0 && (r & 1)) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
-#else
         if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
-#endif
         if (CS == 0) SLP_PUT(15, 1);  // [15] consumer: loop iterations (rounds + extra rounds for arrivals)
       }
       if (CS == 0) SLP_ADD(13, tIt);  // [13] consumer: rounds loop (incl. in-bin arrivals)
@@ -712,11 +693,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
           wb[q] = sel[q] == 1 ? -1.f : 0.5f;
           xo[q] = (float)sel[q] * mp.dx;
         }
-#ifdef ZS_X_NOXQ
-        if (false) {
-#else
         if (node < 27 && nx > 0) {
-#endif
 #pragma unroll 1
           for (int k = half; k < nx; k += 2) {
             const unsigned e = xq[par][k];
@@ -752,11 +729,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
                   if (!S::STRESS) t += st[(4 + d) * 64];  // v_d + (C . xi), the association of P2G.hpp:112
                   val = Wm * t;
                 }
-#ifndef ZS_X_NOXATOMIC
                 if (val != 0.f) unsafeAtomicAdd(gp + q * NC, val);
-#else
-                if (val == 1234.5f) A.status[7] = cell;
-#endif
               }
             } else if (S::MASS) {
               A.status[2] = 1;  // mass for a node whose block is not in the partition
@@ -791,16 +764,7 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   if (CS == 0) SLP_ADD(9, tFl);
 }
 
-#ifdef ZS_SLOT_WITH_FLAT  // measurement builds only: every wave produces, then consumes (9 % slower, see the header)
-#include "../../tools/measure/mpm_slotted_flat.hpp"
-#endif
-#ifdef ZS_SLOT_WITH_NC  // measurement builds only: consumers as 2 node halves x 2 channel groups
-#include "../../tools/measure/slot_consumer_nc.hpp"
-#endif
-#ifdef ZS_SLOT_WITH_NS  // measurement builds only: node-split consumers + list wave (see the header for what was measured)
-#include "../../tools/measure/slot_consumer_ns.hpp"
-#endif
-template <int SIDE, int SMODEL, bool WRITE_ALL, bool NS, bool FLAT = false, bool NCSPLIT = false>
+template <int SIDE, int SMODEL, bool WRITE_ALL>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
@@ -859,55 +823,15 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   }
   __syncthreads();  // the table is complete
   if (w == 0) SLP_ADD(1, tStart);
-#ifdef ZS_SLOT_WITH_FLAT
-  if constexpr (FLAT) {
-    if (w == 0) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 1) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 2) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 3) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 4) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 4>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 5) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 5>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else if (w == 6) g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 6>(mp, ps, geo, bin, mask, total, lane, sh, A);
-    else g2p2g_slot_flat<SIDE, SMODEL, WRITE_ALL, 7>(mp, ps, geo, bin, mask, total, lane, sh, A);
-  } else
-#endif
   if (w == 0) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 0>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 1) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 1>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 2) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 2>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
   else if (w == 3) g2p2g_slot_producer<SIDE, SMODEL, WRITE_ALL, 3>(mp, ps, geo, bin, total, lane, nchunks, sh, A);
-#ifdef ZS_SLOT_WITH_NC
-  else if constexpr (NCSPLIT) {
-    if (w == 4) g2p2g_slot_consumer_nc<SIDE, 0, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else if (w == 5) g2p2g_slot_consumer_nc<SIDE, 1, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else if (w == 6) g2p2g_slot_consumer_nc<SIDE, 0, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else g2p2g_slot_consumer_nc<SIDE, 1, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
-  }
-#endif
-#ifdef ZS_SLOT_WITH_NS
-  else if constexpr (NS) {
-    if (w == 4) g2p2g_slot_consumer_ns<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else if (w == 5) g2p2g_slot_consumer_ns<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else if (w == 6) g2p2g_slot_consumer_ns<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
-    else g2p2g_slot_lister<SIDE>(mp, geo, lane, nchunks, sh, A);
-  }
-#endif
   else {
     if (w == 4) g2p2g_slot_consumer<SIDE, 0>(mp, geo, mask, total, lane, nchunks, sh, A);
     else if (w == 5) g2p2g_slot_consumer<SIDE, 1>(mp, geo, mask, total, lane, nchunks, sh, A);
     else if (w == 6) g2p2g_slot_consumer<SIDE, 2>(mp, geo, mask, total, lane, nchunks, sh, A);
     else g2p2g_slot_consumer<SIDE, 3>(mp, geo, mask, total, lane, nchunks, sh, A);
-  }
-  if constexpr (NS) {
-    if (w < 4) {
-#pragma unroll 1
-      for (int s3 = 0; s3 < 3; ++s3) __syncthreads();  // the consumers' three flush stages
-    }
-  }
-  if constexpr (NCSPLIT) {
-    if (w < 4) {
-      __syncthreads();  // the consumers' two flush stages
-      __syncthreads();
-    }
   }
   SLP_T0(tTail);
   __syncthreads();  // all channel sets are in the arena
@@ -1018,7 +942,11 @@ static __global__ __launch_bounds__(256) void slot_rehome_kernel(ParticlesDev ps
       }
       pstore<LW, 3>(ps.vel, o, v);
       pstore<LW, 9>(ps.C, o, C);
-      pstore<LW, 9>(ps.stress, o, PF);
+      {
+        float S[STRESS_N];
+        stress_pack(PF, S);
+        pstore<LW, STRESS_N>(ps.stress, o, S);
+      }
     }
   }
 #pragma unroll
@@ -1155,36 +1083,10 @@ int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
   const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
   const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap,
                    st->blockEdge};
-#ifdef ZS_SLOT_WITH_NS
-#define ZS_SLOT_NS_AVAILABLE 1
-#else
-#define ZS_SLOT_NS_AVAILABLE 0
-#endif
-  // measurement builds (-DZS_SLOT_WITH_NS): ZS_ROCM_SLOT_CONSUMERS=nodes selects the node-split consumers + list wave
-#ifdef ZS_SLOT_WITH_FLAT
-#define ZS_SLOT_FLAT_AVAILABLE 1
-#else
-#define ZS_SLOT_FLAT_AVAILABLE 0
-#endif
-  // measurement builds (-DZS_SLOT_WITH_FLAT): ZS_ROCM_SLOT_SCHEDULE=flat -- every wave produces, then consumes (tools/measure/mpm_slotted_flat.hpp)
-  static const bool flat = [] { const char *e = getenv("ZS_ROCM_SLOT_SCHEDULE"); return e && e[0] == 'f'; }();
-#ifdef ZS_SLOT_WITH_NC
-#define ZS_SLOT_NC_AVAILABLE 1
-#else
-#define ZS_SLOT_NC_AVAILABLE 0
-#endif
-  static const bool halves = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'h'; }();
-  static const bool nodeSplit = [] { const char *e = getenv("ZS_ROCM_SLOT_CONSUMERS"); return e && e[0] == 'n'; }();
 #define CALL_SLOT3(SS, M, WA)                                                                                                          \
   do {                                                                                                                                  \
     if (nbins) {                                                                                                                       \
-      if (ZS_SLOT_NS_AVAILABLE && nodeSplit)                                                                                            \
-        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, ZS_SLOT_NS_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
-      else if (ZS_SLOT_NC_AVAILABLE && halves)                                                                                          \
-        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false, false, ZS_SLOT_NC_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
-      else if (ZS_SLOT_FLAT_AVAILABLE && flat)                                                                                          \
-        hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false, ZS_SLOT_FLAT_AVAILABLE != 0>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A); \
-      else hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                 \
+      hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                            \
     }                                                                                                                                  \
     if (finish)                                                                                                                         \
       hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 32)),         \

@@ -32,11 +32,12 @@ class MpmTransfer:
         self.nF = 1 if self.fluid else 9        # channels of the deformation state: J or F
         self.nchn = 16 + self.nF + (1 if model in HAS_LOGJP else 0)
         self.off = {"m": 0, "x": 1, "v": 4, "C": 7, "F": 16, "logJp": 25}
-        # cache_stress: 9 extra channels "PF" hold P F^T vol, written by G2P (and update_stress), read by P2G
+        # cache_stress: 6 extra channels "PF" hold the symmetric P F^T vol {xx, xy, xz, yy, yz, zz}, written by G2P (and update_stress),
+        # read by P2G
         self.cache_stress = bool(cache_stress)
         if self.cache_stress:
             self.off["PF"] = self.nchn
-            self.nchn += 9
+            self.nchn += 6
         self.aos = bool(aos)  # AoS storage (the zs::Particles / zs::Vector<vec<T,N>> form) instead of the AoSoA TileVector
         if self.aos:
             self.L = 1
@@ -103,7 +104,7 @@ class MpmTransfer:
             lj = torch.zeros(self.n) if logJp is None else torch.as_tensor(logJp, dtype=torch.float32)
             cols.append(lj.reshape(self.n, 1))
         if self.cache_stress:
-            cols.append(torch.zeros(self.n, 9))
+            cols.append(torch.zeros(self.n, 6))
         aos = torch.cat([c.to(self.device) for c in cols], dim=1).contiguous()
         lib().zs_rocm_tv_from_aos_f32(self.pol.handle, aos.data_ptr(), self.n, self.nchn, self.L, self.buf.data_ptr())
         self.pol.syncCtx()
@@ -170,7 +171,7 @@ class MpmTransfer:
     def rebin(self, inputs_only=False):
         """particle -> block binning + physical reorder of the AoSoA buffer (count / scan / distribute).
         inputs_only: carry only m, x, F (or J) and logJp -- everything a fused G2P2G step reads; v, C and the cached stress are
-        outputs of that step (recomputed from the grid), so between fused steps they need not be moved (14 instead of 35
+        outputs of that step (recomputed from the grid), so between fused steps they need not be moved (14 instead of 32
         channels for the sand column).  Do not use it before p2g() / g2p() or before reading v, C, stress."""
         L = lib()
         if self.order is None or self.order.numel() != self.n:
