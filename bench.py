@@ -267,7 +267,7 @@ def main():
     mt = MpmTransfer(pol, n_local, dx, dt, model=model, side=a.side, volume=vol, lane_width=a.lane_width, device=device,
                      cache_stress=not a.no_cache_stress)
     if mt.cache_stress:
-        aos = torch.cat([aos, torch.zeros(n_local, 9, dtype=torch.float32, device=device)], dim=1).contiguous()
+        aos = torch.cat([aos, torch.zeros(n_local, mt.nchn - aos.shape[1], dtype=torch.float32, device=device)], dim=1).contiguous()  # the cached stress channels
     lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n_local, mt.nchn, mt.L, mt.buf.data_ptr())
     torch.cuda.synchronize()
     del aos

@@ -272,7 +272,7 @@ def _id_box_step(pol, oracle, model, grid_n, cells, drift, box_lo, steps_before,
     del cell, inb
     vol = dx ** 3 / 8
     mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
-    aos = torch.cat([aos, torch.zeros(n, 9, dtype=torch.float32, device=dev)], dim=1).contiguous()
+    aos = torch.cat([aos, torch.zeros(n, mt.nchn - aos.shape[1], dtype=torch.float32, device=dev)], dim=1).contiguous()
     import zpc_amd
     zpc_amd.lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n, mt.nchn, mt.L, mt.buf.data_ptr())
     pol.syncCtx()
@@ -420,7 +420,7 @@ def test_config4_sand_64m_identities_survive_400_steps_and_repartitions(pol):
     del cell, inb
     vol = dx ** 3 / 8
     mt = MpmTransfer(pol, n, dx, dt, model=model, side=side, volume=vol, cache_stress=True)
-    aos = torch.cat([aos, torch.zeros(n, 9, dtype=torch.float32, device=dev)], dim=1).contiguous()
+    aos = torch.cat([aos, torch.zeros(n, mt.nchn - aos.shape[1], dtype=torch.float32, device=dev)], dim=1).contiguous()
     zpc_amd.lib().zs_rocm_tv_from_aos_f32(pol.handle, aos.data_ptr(), n, mt.nchn, mt.L, mt.buf.data_ptr())
     pol.syncCtx()
     del aos

@@ -1,6 +1,9 @@
 // Does zs::sort of 16-byte struct keys depend on what an earlier kernel left in private (scratch) memory?
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include tools/repro/scratch_then_sort.hip -L zpc_amd/lib -lzsrocm -Wl,-rpath,'$ORIGIN' -o zpc_amd/lib/scratch_then_sort
-//   zpc_amd/lib/scratch_then_sort <fill value, hex> [n]
+//   zpc_amd/lib/scratch_then_sort <fill value, hex> [n] [words of private array in the first kernel: 4 | 12 | 24 | 96] [sync between: 0 | 1]
+// r04: the first kernel's private array is now a parameter -- the two failing builds of r03 used LESS scratch per lane (48-88 B) than the
+// struct-key merge kernels that follow (176 B), i.e. the queue's scratch allocation had to GROW between the two; the r03 version of this
+// tool dirtied 384 B per lane, more than anything behind it, and could not see that case.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -11,11 +14,11 @@
 using namespace zs;
 
 // fills a private array that has to live in scratch (dynamic indexing), and reads it back so that nothing is optimised away
-__global__ __launch_bounds__(1024) void dirty_scratch(unsigned fill, int rot, unsigned *sink) {
-  volatile unsigned a[96];
-  for (int i = 0; i < 96; ++i) a[(i + rot + threadIdx.x) % 96] = fill + i;
+template <int W> __global__ __launch_bounds__(1024) void dirty_scratch(unsigned fill, int rot, unsigned *sink) {
+  volatile unsigned a[W];
+  for (int i = 0; i < W; ++i) a[(i + rot + threadIdx.x) % W] = fill + i;
   unsigned s = 0;
-  for (int i = 0; i < 96; ++i) s += a[(i * 7 + rot) % 96];
+  for (int i = 0; i < W; ++i) s += a[(i * 7 + rot) % W];
   if (s == 12345u) sink[0] = s;
 }
 
@@ -32,8 +35,13 @@ int main(int argc, char **argv) {
   auto pol = rocm_exec();
   unsigned *sink;
   (void)hipMalloc((void **)&sink, 4);
-  hipLaunchKernelGGL(dirty_scratch, dim3(1024), dim3(1024), 0, (hipStream_t)pol.getStream(), fill, 3, sink);
-  (void)hipDeviceSynchronize();
+  const int words = argc > 3 ? atoi(argv[3]) : 96, syncBetween = argc > 4 ? atoi(argv[4]) : 1;
+  hipStream_t st = (hipStream_t)pol.getStream();
+  if (words == 4) hipLaunchKernelGGL(dirty_scratch<4>, dim3(1024), dim3(1024), 0, st, fill, 3, sink);
+  else if (words == 12) hipLaunchKernelGGL(dirty_scratch<12>, dim3(1024), dim3(1024), 0, st, fill, 3, sink);
+  else if (words == 24) hipLaunchKernelGGL(dirty_scratch<24>, dim3(1024), dim3(1024), 0, st, fill, 3, sink);
+  else if (words == 96) hipLaunchKernelGGL(dirty_scratch<96>, dim3(1024), dim3(1024), 0, st, fill, 3, sink);
+  if (syncBetween) (void)hipDeviceSynchronize();
   std::vector<Key> hs(n);
   unsigned s = 12345u;
   for (int i = 0; i < n; ++i) {
@@ -53,7 +61,7 @@ int main(int argc, char **argv) {
       if (first < 0) first = i;
       ++bad;
     }
-  std::printf("fill %08x n %d: %d mismatches", fill, n, bad);
+  std::printf("fill %08x n %d first-kernel private words %d sync %d: %d mismatches", fill, n, words, syncBetween, bad);
   if (bad) std::printf(" (first at %d: got d %g tag %d pad %d, want d %g tag %d)", first, rs[first].d, rs[first].tag, rs[first].pad, hs[first].d, hs[first].tag);
   std::printf("\n");
   return bad ? 1 : 0;

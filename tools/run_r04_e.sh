@@ -6,15 +6,16 @@ cd $R
 export TMPDIR=/tmp
 P2G="python $R/bench.py --compact --unfused --drift 0,0,0 --no-at-rest --no-cpu-baseline --steps 10 --warmup 3"
 pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); r=d["roofline"]; print("%-28s ms/step %.3f launch_ms %.3f frac %.3f g2p_ms" % (sys.argv[1], d["ms_per_step"], r["launch_ms"], r["frac"]), r.get("g2p",{}).get("launch_ms"))'
-timeout 900 python -m pytest tests/test_mpm_gpu.py tests/test_c2_gpu.py tests/test_dist_gpu.py -x -q -m gpu > $O/t_mpm.log 2>&1; echo "mpm tests rc=$?" >> $O/summary.txt
+timeout 900 python -m pytest tests/test_mpm_gpu.py tests/test_c2_gpu.py tests/test_dist_gpu.py -x -q -m gpu > $O/t_mpm.log 2>&1; rc=$?; echo "mpm tests rc=$rc" >> $O/summary.txt
+if [ $rc != 0 ]; then tail -30 $O/t_mpm.log; exit 1; fi
 for g in 1 2 4; do
   for rep in 1 2; do
-    ZS_ROCM_P2G_GROUP=$g timeout 300 $P2G 2> $O/p2g_g$g.err | tee $O/p2g_g$g.json | python -c "$pick" p2g_group$g >> $O/summary.txt
+    ZS_ROCM_P2G_GROUP=$g timeout 120 $P2G 2> $O/p2g_g$g.err | tee $O/p2g_g$g.json | python -c "$pick" p2g_group$g >> $O/summary.txt
   done
 done
 for lib in nt sc; do
   for g in 1 4; do
-    ZS_ROCM_LIB=$R/zpc_amd/lib/ablate/libzsrocm_$lib.so ZS_ROCM_P2G_GROUP=$g timeout 300 $P2G 2> $O/p2g_${lib}_g$g.err | tee $O/p2g_${lib}_g$g.json | python -c "$pick" p2g_${lib}_group$g >> $O/summary.txt
+    ZS_ROCM_LIB=$R/zpc_amd/lib/ablate/libzsrocm_$lib.so ZS_ROCM_P2G_GROUP=$g timeout 120 $P2G 2> $O/p2g_${lib}_g$g.err | tee $O/p2g_${lib}_g$g.json | python -c "$pick" p2g_${lib}_group$g >> $O/summary.txt
   done
 done
 cd /tmp

@@ -442,6 +442,98 @@ __global__ __launch_bounds__(256) void lbvh_self_query_packed_kernel(const LbvhP
     cacheCounts[k] = c;
   }
 }
+// The same pass with ONE walk per wave (r04).  The 64 leaves of a wave are neighbours in node (Morton) order, so their walks visit
+// largely the same nodes; done lane by lane every visit is a divergent 32-byte fetch (10 M leaves x ~80 nodes: the count pass moved
+// ~50 GB through the L2 request path and ran at its pace).  Here the wave walks the UNION of its lanes' walks in pre-order: `cur` is
+// wave-uniform (the node is fetched once, by scalar loads), lane j takes part in a visit iff cur == next_j, its own next node.  At a
+// trunk node a lane descends (cur + 1) on overlap and escapes (aux) otherwise -- exactly LBvhView::self_iter_neighbors'
+// (Bvh.hpp:697-750) per-leaf walk, so every leaf reports the same ids in the same order.  The next node of the wave is the minimum
+// of the lanes' next nodes, and needs no reduction: if a lane descends it is cur + 1; otherwise every lane at cur escapes to the same
+// E = aux(cur), lanes that escaped earlier wait at some X >= E (cur lies inside the subtree they skipped), and lanes that have not
+// started yet wait at their leaves, which come in lane order -- so it is min(E, start of the first lane not started yet).
+// SFETCH: the node through the scalar cache (s_load_dwordx8) or, false, through the vector path (every lane loads the same 32 bytes: one
+// request per wave, cached in the CU's L1)
+template <bool FILL, bool SFETCH>
+__global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPackedNode *__restrict__ nodes, int numNodes, int numLeaves,
+                                                                   const int *__restrict__ leafInds, int *counts, const int *offsets, int *pairs,
+                                                                   int *cache, int *cacheCounts, int useCache) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = k < numLeaves;
+  const int start = valid ? leafInds[k] : 0x7fffffff;
+  LbvhPackedNode me{};
+  if (valid) me = nodes[start];
+  const int self = me.aux;
+  int *dst = nullptr;
+  bool need = valid;
+  if constexpr (FILL) {
+    if (valid) {
+      dst = pairs + 2 * (size_t)offsets[k];
+      if (useCache) {
+        const int cc = cacheCounts[k];
+        if (cc <= LBVH_HIT_CACHE) {
+          for (int j = 0; j < cc; ++j) {
+            dst[2 * j] = self;
+            dst[2 * j + 1] = cache[(size_t)j * numLeaves + k];
+          }
+          need = false;
+        }
+      }
+    }
+  }
+  int next = need ? start : 0x7fffffff;  // the walk starts AT the leaf, which reports itself first (skipped below)
+  int c = 0;
+  unsigned long long pending = __ballot(need);  // lanes that have not started yet, in lane (= leaf = node) order
+  int nextStart = 0x7fffffff;
+  if (pending) {
+    const int l = __ffsll((long long)pending) - 1;
+    nextStart = __builtin_amdgcn_readlane(start, l);
+  }
+  int cur = nextStart;
+  while (cur < numNodes) {
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (cur == nextStart) {  // the first pending lane starts here: the next one in line
+      pending &= pending - 1;
+      nextStart = 0x7fffffff;
+      if (pending) nextStart = __builtin_amdgcn_readlane(start, __ffsll((long long)pending) - 1);
+    }
+    // the whole node in ONE scalar load (eight dwords); no short-circuit in the overlap test: a second, dependent load group under
+    // a branch would double the latency of a step
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    v8i raw;
+    if constexpr (SFETCH) raw = *reinterpret_cast<const v8i *>(nodes + cur);
+    else {
+      int vcur = cur;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(vcur) : "s"(cur));  // a VGPR copy the compiler cannot prove uniform: vector loads
+      raw = *reinterpret_cast<const v8i *>(nodes + vcur);
+    }
+    LbvhPackedNode n;
+    n.lo[0] = __int_as_float(raw[0]); n.lo[1] = __int_as_float(raw[1]); n.lo[2] = __int_as_float(raw[2]);
+    n.hi[0] = __int_as_float(raw[3]); n.hi[1] = __int_as_float(raw[4]); n.hi[2] = __int_as_float(raw[5]);
+    n.level = raw[6]; n.aux = raw[7];
+    const bool active = next == cur;
+    const bool ov = (int)!(me.lo[0] > n.hi[0] || me.hi[0] < n.lo[0]) & (int)!(me.lo[1] > n.hi[1] || me.hi[1] < n.lo[1]) &
+                    (int)!(me.lo[2] > n.hi[2] || me.hi[2] < n.lo[2]);
+    const bool leaf = n.level == 0;  // wave-uniform
+    if (leaf && active && ov && n.aux != self) {
+      if constexpr (FILL) {
+        dst[2 * c] = self;
+        dst[2 * c + 1] = n.aux;
+      } else {
+        if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = n.aux;
+      }
+      ++c;
+    }
+    const bool down = active && (leaf || ov);
+    const int esc = n.aux < 0 ? numNodes : n.aux;  // (trunk nodes only; a leaf always continues at cur + 1)
+    if (active) next = down ? cur + 1 : esc;
+    if (__ballot(down)) cur = cur + 1;
+    else cur = esc < nextStart ? esc : nextStart;
+  }
+  if (!FILL && valid) {
+    counts[k] = c;
+    cacheCounts[k] = c;
+  }
+}
 static const LbvhPackedNode *lbvh_packed(Launch &L, const zs_rocm_lbvh &b) {
   if (b.packedCap < b.numNodes) {
     (void)hipFree(b.packed);
@@ -586,17 +678,38 @@ void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, i
     ZSR_CHECK(hipMalloc((void **)&b->hitCounts, b->numLeaves * sizeof(int)));
     b->hitCacheLeaves = b->numLeaves;
   }
-  hipLaunchKernelGGL((lbvh_self_query_packed_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
-                     b->hitCache, b->hitCounts, 0);
+  // A/B runs: ZS_ROCM_LBVH_SELF = l (one walk per leaf, the r03 kernel) | v (wave walk, vector fetch) | default: wave walk, scalar fetch
+  static const char mode = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e ? e[0] : 's'; }();
+  if (b->numNodes > 2 && mode == 'v')
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false, false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
+                       b->hitCache, b->hitCounts, 0);
+  else if (b->numNodes > 2 && mode != 'l')
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false, true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
+                       b->hitCache, b->hitCounts, 0);
+  else
+    hipLaunchKernelGGL((lbvh_self_query_packed_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
+                       b->hitCache, b->hitCounts, 0);
   b->hitCacheValid = true;  // until the next build / refit
 }
 void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const int *offsets, int *pairs) {
   Launch L(pol, "lbvh_self_query_fill");
   if (!b->numLeaves) return;
-  hipLaunchKernelGGL((lbvh_self_query_packed_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                     (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
-                     b->hitCacheValid ? 1 : 0);
+  static const char mode = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e ? e[0] : 's'; }();
+  if (b->numNodes > 2 && mode == 'v')
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true, false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
+                       b->hitCacheValid ? 1 : 0);
+  else if (b->numNodes > 2 && mode != 'l')
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true, true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
+                       b->hitCacheValid ? 1 : 0);
+  else
+    hipLaunchKernelGGL((lbvh_self_query_packed_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
+                       b->hitCacheValid ? 1 : 0);
 }
 
 }  // extern "C"
