@@ -164,6 +164,19 @@ def generate_particles(box_lo, box_hi, dx, seed, device, model):
     return aos
 
 
+def _same_code(j):
+    """a PMC traffic figure belongs to this run only if the kernels it was collected on still have the same machine code: the json
+    names the object file and a kernel-name regex and carries tools/kernel_hash.py's fingerprint of them (collected by the refresh
+    script on the GPU box from the same build)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_hash
+        want = j.get("code_hash")
+        return bool(want) and kernel_hash.combined(os.path.join(ROOT, j["code_object"]), j["code_regex"]) == want
+    except Exception:
+        return False
+
+
 def cpu_baseline(sample, dx, dt, model, side, vol):
     """OpenMP port of the reference's OmpExecutionPolicy P2G+G2P (oracle/mpm.c) on a bounded sample of the workload."""
     import subprocess
@@ -763,7 +776,7 @@ def main():
             try:
                 j = json.load(open(pmc))
                 if (j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model
-                        and j.get("cache_stress", False) == mt.cache_stress):
+                        and j.get("cache_stress", False) == mt.cache_stress and _same_code(j)):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -821,7 +834,8 @@ def main():
             if os.path.exists(pmcf) and (a.slotted == moving):
                 try:
                     j = json.load(open(pmcf))
-                    if j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model and j.get("kernel") == fkernel:
+                    if (j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model and j.get("kernel") == fkernel
+                            and _same_code(j)):
                         ftraffic = j.get("hbm_bytes_per_launch")   # (a figure collected for another kernel generation is not this run's traffic)
                 except Exception:
                     pass

@@ -20,9 +20,10 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
     const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
     if (kmodel == MPM_CACHED_STRESS) {  // cached stress: the "wide" kernel, one wave per bin
-      // bins per workgroup = waves that share one flush arena (8^3 blocks only; see p2g_wide_kernel).  ZS_ROCM_P2G_GROUP = 1 | 2 | 4
-      // overrides the default for A/B runs.
-      static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 4; }();
+      // bins per workgroup = waves that share one flush arena (8^3 blocks only; see p2g_wide_kernel).  Measured at 64 Mi particles
+      // (profiles/r04_p2g.md): 1.74 / 1.71 / 1.72 ms for 1 / 2 / 4 with 1.73 / -- / 1.04 GB written: the time no longer follows the
+      // traffic, so the default is the pair (least coupling between waves).  ZS_ROCM_P2G_GROUP = 1 | 2 | 4 overrides it for A/B runs.
+      static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 2; }();
 #define CALL_P2G_WIDE_G(S, LWv, Gv)                                                                                                     \
   hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
                      nbr, stale, staleCount)
