@@ -99,6 +99,34 @@ def test_iter_neighbors_matches_oracle_order_and_brute_force(pol, oracle, n, dup
     oracle.orc_lbvh_destroy(b)
 
 
+def test_bulk_iter_neighbors_many_queries_in_random_order(pol, oracle):
+    """50 000 queries in random order, some far outside the tree's box (no hits), some large (many hits): per query the same ids in the
+    same order as the oracle's walk (Bvh.hpp:661-693), written to the query's own slot."""
+    from zpc_amd.containers import LBvh
+    n, nq = 40_000, 50_000
+    bv = lbvh_boxes(n, 977, 1)
+    b, ref = oracle_lbvh(oracle, bv)
+    bvh = LBvh()
+    bvh.build(pol, torch.from_numpy(bv).cuda())
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, n, nq)
+    q = bv[src] + rng.normal(0, 0.004, (nq, 1)).astype(np.float32)
+    q[::97] += np.float32(3.0)          # far outside the whole box: no hits
+    q[1::89, 3:] += np.float32(0.05)    # large boxes: many hits
+    q = np.ascontiguousarray(q.astype(np.float32))
+    offsets, ids = bvh.query(pol, torch.from_numpy(q).cuda())
+    pol.syncCtx()
+    off, ids = offsets.cpu().numpy(), ids.cpu().numpy()
+    assert off[nq] == ids.shape[0] and (np.diff(off) >= 0).all()
+    assert (np.diff(off)[::97] == 0).all()
+    out = np.zeros(n, np.int32)
+    oracle.orc_lbvh_iter_neighbors.restype = C.c_size_t
+    for k in list(range(0, nq, 23)) + list(range(1, nq, 89))[:200]:
+        cnt = oracle.orc_lbvh_iter_neighbors(b, q[k].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        assert np.array_equal(ids[off[k]:off[k + 1]], out[:cnt]), k
+    oracle.orc_lbvh_destroy(b)
+
+
 @pytest.mark.parametrize("n,dup", [(1, 0), (2, 0), (3000, 0), (40_000, 1)])
 def test_self_collision_broadphase_matches_oracle_walk_and_brute_force(pol, oracle, n, dup):
     """zs_rocm_lbvh_self_query_{count,fill}: self_iter_neighbors over every leaf; per leaf the same ids in the same order as the

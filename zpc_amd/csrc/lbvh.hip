@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void lbvh_query_packed_kernel(const LbvhPacked
   });
   if (!FILL) counts[q] = c;
 }
-constexpr int LBVH_HIT_CACHE = 16;
+constexpr int LBVH_HIT_CACHE = 32;
 // FILL = false: count pass; also remembers the first LBVH_HIT_CACHE hits of every leaf (cache[j * numLeaves + k]) and its count.
 // FILL = true: leaves whose hits all fit into the cache are copied from it, the others walk again.
 template <bool FILL>
@@ -451,80 +451,94 @@ __global__ __launch_bounds__(256) void lbvh_self_query_packed_kernel(const LbvhP
 // of the lanes' next nodes, and needs no reduction: if a lane descends it is cur + 1; otherwise every lane at cur escapes to the same
 // E = aux(cur), lanes that escaped earlier wait at some X >= E (cur lies inside the subtree they skipped), and lanes that have not
 // started yet wait at their leaves, which come in lane order -- so it is min(E, start of the first lane not started yet).
-// SFETCH: the node through the scalar cache (s_load_dwordx8) or, false, through the vector path (every lane loads the same 32 bytes: one
-// request per wave, cached in the CU's L1)
-template <bool FILL, bool SFETCH>
+// The node is fetched through the scalar cache (one s_load_dwordx8 per step).  Measured alternatives (profiles/r04_lbvh.md): node pairs
+// per s_load_dwordx16 (3.30 vs 2.95 ms), the vector path with a wave-uniform address (3.84 ms), 2 / 4 / 8 independent walks per wave
+// with their fetches issued together (3.37 / 3.51 / 4.47 ms: the pass is bound by the instruction stream of the steps -- ~40 mostly
+// scalar, mostly dependent instructions each -- not by the latency of one chain), and the same kernel over external queries sorted by
+// the Morton code of their centres (3.0 vs 1.7 ms for 1 M queries with 15.6 hits each: their unions are too long).
+// FILL: leaves whose hits all fit the count pass's cache (LBVH_HIT_CACHE = 32: 99.998 % of the leaves of BASELINE config 5) are copied from
+// it by the whole wave in output order; the others walk again.
+template <bool FILL>
 __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPackedNode *__restrict__ nodes, int numNodes, int numLeaves,
                                                                    const int *__restrict__ leafInds, int *counts, const int *offsets, int *pairs,
                                                                    int *cache, int *cacheCounts, int useCache) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef int v8i __attribute__((ext_vector_type(8)));
+  constexpr int NONE = 0x7fffffff;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
   const bool valid = k < numLeaves;
-  const int start = valid ? leafInds[k] : 0x7fffffff;
+  const int start = valid ? leafInds[k] : NONE;
   LbvhPackedNode me{};
   if (valid) me = nodes[start];
   const int self = me.aux;
   int *dst = nullptr;
   bool need = valid;
   if constexpr (FILL) {
-    if (valid) {
-      dst = pairs + 2 * (size_t)offsets[k];
-      if (useCache) {
-        const int cc = cacheCounts[k];
-        if (cc <= LBVH_HIT_CACHE) {
-          for (int j = 0; j < cc; ++j) {
-            dst[2 * j] = self;
-            dst[2 * j + 1] = cache[(size_t)j * numLeaves + k];
+    const int off = valid ? offsets[k] : 0;
+    if (valid) dst = pairs + 2 * (size_t)off;
+    if (useCache) {
+      // position p of the wave's contiguous output range belongs to the last leaf whose offset is <= p (leaves without hits share their
+      // successor's offset); 8-byte stores to consecutive pairs instead of every lane writing its own short run
+      const int cc = valid ? cacheCounts[k] : 0;
+      need = valid && cc > LBVH_HIT_CACHE;
+      const int nv = __popcll(__ballot(valid));  // valid lanes are a prefix of the wave
+      if (nv) {
+        const int base = __builtin_amdgcn_readlane(off, 0), end = __builtin_amdgcn_readlane(off + cc, nv - 1);
+        const int k0 = k - lane;
+        for (int p0 = base; p0 < end; p0 += 64) {  // (wave-uniform trip count: the shuffles below need every lane)
+          const int pp = p0 + lane;
+          int loI = 0, hiI = nv - 1;
+#pragma unroll
+          for (int it = 0; it < 6; ++it) {
+            const int mid = (loI + hiI + 1) >> 1;
+            const int om = __shfl(off, mid, 64);
+            if (om <= pp) loI = mid;
+            else hiI = mid - 1;
           }
-          need = false;
+          const int oOff = __shfl(off, loI, 64), oCc = __shfl(cc, loI, 64), oSelf = __shfl(self, loI, 64);
+          if (pp < end && oCc <= LBVH_HIT_CACHE) {
+            int2 pr;
+            pr.x = oSelf;
+            pr.y = cache[(size_t)(pp - oOff) * numLeaves + (size_t)(k0 + loI)];
+            *reinterpret_cast<int2 *>(pairs + 2 * (size_t)pp) = pr;
+          }
         }
       }
     }
   }
-  int next = need ? start : 0x7fffffff;  // the walk starts AT the leaf, which reports itself first (skipped below)
+  int next = need ? start : NONE;  // the walk starts AT the leaf, which reports itself first (skipped below)
   int c = 0;
   unsigned long long pending = __ballot(need);  // lanes that have not started yet, in lane (= leaf = node) order
-  int nextStart = 0x7fffffff;
-  if (pending) {
-    const int l = __ffsll((long long)pending) - 1;
-    nextStart = __builtin_amdgcn_readlane(start, l);
-  }
+  int nextStart = NONE;
+  if (pending) nextStart = __builtin_amdgcn_readlane(start, __ffsll((long long)pending) - 1);
   int cur = nextStart;
   while (cur < numNodes) {
     cur = __builtin_amdgcn_readfirstlane(cur);
     if (cur == nextStart) {  // the first pending lane starts here: the next one in line
       pending &= pending - 1;
-      nextStart = 0x7fffffff;
+      nextStart = NONE;
       if (pending) nextStart = __builtin_amdgcn_readlane(start, __ffsll((long long)pending) - 1);
     }
     // the whole node in ONE scalar load (eight dwords); no short-circuit in the overlap test: a second, dependent load group under
     // a branch would double the latency of a step
-    typedef int v8i __attribute__((ext_vector_type(8)));
-    v8i raw;
-    if constexpr (SFETCH) raw = *reinterpret_cast<const v8i *>(nodes + cur);
-    else {
-      int vcur = cur;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(vcur) : "s"(cur));  // a VGPR copy the compiler cannot prove uniform: vector loads
-      raw = *reinterpret_cast<const v8i *>(nodes + vcur);
-    }
-    LbvhPackedNode n;
-    n.lo[0] = __int_as_float(raw[0]); n.lo[1] = __int_as_float(raw[1]); n.lo[2] = __int_as_float(raw[2]);
-    n.hi[0] = __int_as_float(raw[3]); n.hi[1] = __int_as_float(raw[4]); n.hi[2] = __int_as_float(raw[5]);
-    n.level = raw[6]; n.aux = raw[7];
+    const v8i raw = *reinterpret_cast<const v8i *>(nodes + cur);
+    const float nlo0 = __int_as_float(raw[0]), nlo1 = __int_as_float(raw[1]), nlo2 = __int_as_float(raw[2]);
+    const float nhi0 = __int_as_float(raw[3]), nhi1 = __int_as_float(raw[4]), nhi2 = __int_as_float(raw[5]);
+    const int level = raw[6], aux = raw[7];
     const bool active = next == cur;
-    const bool ov = (int)!(me.lo[0] > n.hi[0] || me.hi[0] < n.lo[0]) & (int)!(me.lo[1] > n.hi[1] || me.hi[1] < n.lo[1]) &
-                    (int)!(me.lo[2] > n.hi[2] || me.hi[2] < n.lo[2]);
-    const bool leaf = n.level == 0;  // wave-uniform
-    if (leaf && active && ov && n.aux != self) {
+    const bool ov = (int)!(me.lo[0] > nhi0 || me.hi[0] < nlo0) & (int)!(me.lo[1] > nhi1 || me.hi[1] < nlo1) &
+                    (int)!(me.lo[2] > nhi2 || me.hi[2] < nlo2);
+    const bool leaf = level == 0;  // wave-uniform
+    if (leaf && active && ov && aux != self) {
       if constexpr (FILL) {
         dst[2 * c] = self;
-        dst[2 * c + 1] = n.aux;
+        dst[2 * c + 1] = aux;
       } else {
-        if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = n.aux;
+        if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = aux;
       }
       ++c;
     }
     const bool down = active && (leaf || ov);
-    const int esc = n.aux < 0 ? numNodes : n.aux;  // (trunk nodes only; a leaf always continues at cur + 1)
+    const int esc = aux < 0 ? numNodes : aux;  // (trunk nodes only; a leaf always continues at cur + 1)
     if (active) next = down ? cur + 1 : esc;
     if (__ballot(down)) cur = cur + 1;
     else cur = esc < nextStart ? esc : nextStart;
@@ -678,14 +692,10 @@ void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, i
     ZSR_CHECK(hipMalloc((void **)&b->hitCounts, b->numLeaves * sizeof(int)));
     b->hitCacheLeaves = b->numLeaves;
   }
-  // A/B runs: ZS_ROCM_LBVH_SELF = l (one walk per leaf, the r03 kernel) | v (wave walk, vector fetch) | default: wave walk, scalar fetch
-  static const char mode = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e ? e[0] : 's'; }();
-  if (b->numNodes > 2 && mode == 'v')
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false, false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
-                       b->hitCache, b->hitCounts, 0);
-  else if (b->numNodes > 2 && mode != 'l')
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false, true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+  // A/B runs: ZS_ROCM_LBVH_SELF=l selects the one-walk-per-leaf kernel of r03
+  static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
+  if (b->numNodes > 2 && !perLeaf)
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
                        b->hitCache, b->hitCounts, 0);
   else
@@ -697,13 +707,9 @@ void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, i
 void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const int *offsets, int *pairs) {
   Launch L(pol, "lbvh_self_query_fill");
   if (!b->numLeaves) return;
-  static const char mode = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e ? e[0] : 's'; }();
-  if (b->numNodes > 2 && mode == 'v')
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true, false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
-                       (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
-                       b->hitCacheValid ? 1 : 0);
-  else if (b->numNodes > 2 && mode != 'l')
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true, true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+  static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
+  if (b->numNodes > 2 && !perLeaf)
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
                        b->hitCacheValid ? 1 : 0);
   else

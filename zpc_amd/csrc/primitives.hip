@@ -1113,8 +1113,13 @@ __device__ __forceinline__ void rs_coop_lsd(RsLds<K, PAIR> &S, const K *src, con
 
 // One bucket of c <= MAXI * 1024 keys: into registers (positions stay (wave, item, lane)-ordered), LSD passes over the bits [sbit, top)
 // through LDS, out.
+#ifdef ZS_RS_NOINLINE  // repro builds only (tools/repro/): a real call with a stack in the finish kernel, one of the two r03 builds behind the "scratch trap"
+#define ZS_RS_BUCKET_INLINE __noinline__
+#else
+#define ZS_RS_BUCKET_INLINE __forceinline__
+#endif
 template <class K, bool PAIR, int MAXI>
-__device__ __forceinline__ void rs_finish_bucket(unsigned (*cnt)[256], unsigned *sWave2, K *keyS, int *valS, const K *bk, const int *bv, K *ok,
+__device__ ZS_RS_BUCKET_INLINE void rs_finish_bucket(unsigned (*cnt)[256], unsigned *sWave2, K *keyS, int *valS, const K *bk, const int *bv, K *ok,
                                                  int *ov, unsigned c, int sbit, int top) {
   constexpr int NW = RSS_NW, BLOCK = RSS_BLOCK;
   const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
