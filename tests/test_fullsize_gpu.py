@@ -233,7 +233,9 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     # the trimmed sums (bench.py: particles with a velocity-gradient entry beyond 8 rms are left out: what a hit of the arena's rounding
     # case leaves behind, and the two edge particles of the column that carry such entries in every run) must agree, and few may be trimmed
     ta, tb = a["checksum_trimmed"], b["checksum_trimmed"]
-    assert ta["trimmed_particles"] <= 512 and tb["trimmed_particles"] <= 512, (ta["trimmed_particles"], tb["trimmed_particles"])
+    # bound tied to measurements: 11 (slotted) and 76 (compact) particles were trimmed in the r03 runs, of 67 M; a defect that touches more
+    # than a couple of hundred particles must not hide behind the filter
+    assert ta["trimmed_particles"] <= 200 and tb["trimmed_particles"] <= 200, (ta["trimmed_particles"], tb["trimmed_particles"])
     _same_state(ta["sums"], tb["sums"], n, 1e-4, 3e-4)
     m = 1000.0 * (1.0 / 512) ** 3 / 8
     assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
