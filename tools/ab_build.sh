@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-r
 objs=$(ls zpc_amd/lib/obj/*.o)
 for f in "$@"; do
   b=$(basename $f .hip)
-  fl="$FLAGS"; case $b in mpm*) fl="$fl -fno-slp-vectorize";; lbvh|collider) fl="$fl -ffp-contract=off";; esac
+  fl="$FLAGS"; case $b in mpm_g2p) fl="$fl -fno-slp-vectorize -DZS_PSTORE_NT";; mpm*) fl="$fl -fno-slp-vectorize";; lbvh|collider) fl="$fl -ffp-contract=off";; esac
   /opt/rocm/bin/hipcc $fl $extra -c zpc_amd/csrc/$b.hip -o zpc_amd/lib/ablate/$name/$b.o &
   objs=$(echo "$objs" | grep -v "/$b.o")
 done

@@ -394,13 +394,17 @@ __global__ void tv_scatter_rows_kernel(const float *aos, size_t m, int C, int lb
 
 // BASELINE config 2 "TileVector AoSoA load/store": read every channel of every element, scale, write back.
 // The buffer of whole tiles is contiguous, so the AoSoA sweep is a flat 16-byte-per-lane stream.
-__global__ __launch_bounds__(256) void tv_scale_kernel(float4 *buf, size_t nvec, float alpha) {
+// NT: non-temporal stores for buffers of >= 128 MB (a template parameter: see scan_kernel in primitives.hip)
+template <bool NT> __global__ __launch_bounds__(256) void tv_scale_kernel(float4 *buf, size_t nvec, float alpha) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 *b = reinterpret_cast<f4 *>(buf);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nvec; i += stride) {
-    float4 v = buf[i];
-    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-    buf[i] = v;
+    f4 v = b[i];
+    v *= alpha;
+    if constexpr (NT) __builtin_nontemporal_store(v, b + i);
+    else b[i] = v;
   }
 }
 
@@ -686,7 +690,8 @@ void zs_rocm_tv_scale_f32(zs_rocm_policy *pol, float *tv, size_t n, int C, int L
   size_t nvec = total / 4;                                       // L >= 8 -> total % 4 == 0
   if (!nvec) return;
   unsigned grid = (unsigned)std::min<size_t>(ceil_div(nvec, 256), 256 * 16);
-  hipLaunchKernelGGL(tv_scale_kernel, dim3(grid), dim3(256), 0, L.stream, (float4 *)tv, nvec, alpha);
+  if (nvec * sizeof(float4) >= ((size_t)128 << 20)) hipLaunchKernelGGL(tv_scale_kernel<true>, dim3(grid), dim3(256), 0, L.stream, (float4 *)tv, nvec, alpha);
+  else hipLaunchKernelGGL(tv_scale_kernel<false>, dim3(grid), dim3(256), 0, L.stream, (float4 *)tv, nvec, alpha);
 }
 void zs_rocm_tv_gather_rows_f32(zs_rocm_policy *pol, const float *tv, const int *map, size_t m, int C, int Lw, float *aos) {
   Launch L(pol, "tv_gather_rows");

@@ -496,10 +496,11 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
           }
           const int oOff = __shfl(off, loI, 64), oCc = __shfl(cc, loI, 64), oSelf = __shfl(self, loI, 64);
           if (pp < end && oCc <= LBVH_HIT_CACHE) {
-            int2 pr;
+            typedef int i2 __attribute__((ext_vector_type(2)));
+            i2 pr;
             pr.x = oSelf;
             pr.y = cache[(size_t)(pp - oOff) * numLeaves + (size_t)(k0 + loI)];
-            *reinterpret_cast<int2 *>(pairs + 2 * (size_t)pp) = pr;
+            __builtin_nontemporal_store(pr, reinterpret_cast<i2 *>(pairs + 2 * (size_t)pp));  // the pair list is written once, streamed
           }
         }
       }

@@ -537,12 +537,22 @@ template <int LW, int N> __device__ __forceinline__ void pstore(const Port<float
   if constexpr (LW != 0) {
     float *b = p.base + o.o;
 #pragma unroll
-    for (int d = 0; d < N; ++d) b[d * LW] = v[d];
+    for (int d = 0; d < N; ++d) {
+#ifdef ZS_PSTORE_NT  // measurement builds: particle state written with non-temporal stores
+      __builtin_nontemporal_store(v[d], b + d * LW);
+#else
+      b[d * LW] = v[d];
+#endif
+    }
   } else
     store_attr<N>(p, o.o, v);
 }
 template <int LW> __device__ __forceinline__ void pstore1(const Port<float> &p, POff<LW> o, float v) {
+#ifdef ZS_PSTORE_NT
+  if constexpr (LW != 0) __builtin_nontemporal_store(v, p.base + o.o);
+#else
   if constexpr (LW != 0) p.base[o.o] = v;
+#endif
   else p.base[p.off(o.o)] = v;
 }
 // deformation state of a particle: F (9 components) for the solids, the volume ratio J = component 0 of the same attribute

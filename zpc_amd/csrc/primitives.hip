@@ -179,7 +179,7 @@ template <class T> struct Desc<T, 8> {
 // element tiles cap a 64M-element scan at ~0.18 ms of pure ticket time (measured 2.2 TB/s); small inputs keep 2 rows
 // so that a 1M-element scan still spreads over all 256 CUs.  512 threads x 8 rows instead of 256 x 16 (same tile): half
 // the registers per thread and twice the loads in flight per tile, 3.0 -> 3.35 TB/s at 64 M (1024 x 4: the same).
-template <int OP, class T, bool EXCL, int SCAN_ROWS>
+template <int OP, class T, bool EXCL, int SCAN_ROWS, bool NTSTORE>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(Port<const T> in, Port<T> out, size_t n, T init, void *descMem,
                                                           size_t layoutTiles, unsigned *ticket, unsigned gen, unsigned ticketBase) {
   constexpr int V = 16 / sizeof(T);
@@ -303,11 +303,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(Port<const T> in, Port
     const size_t e0 = tileBase + (size_t)k * ROWW + (size_t)t * V;
     const bool ovec = out.contiguous() && (((uintptr_t)(out.base + out.idx)) % 16 == 0);
     if (full && ovec) {
-      struct alignas(16) Vec { T v[V]; };
-      Vec q;
+      // large outputs (>= 128 MB: beyond what the memory-side cache keeps for the next kernel anyway) are written with non-temporal
+      // stores: 64 M ints 0.147 -> 0.125 ms; 16 M unchanged; non-temporal LOADS of the input measured slower with them (0.137)
+      typedef T VecT __attribute__((ext_vector_type(V)));
+      VecT q;
 #pragma unroll
-      for (int j = 0; j < V; ++j) q.v[j] = y[j];
-      *reinterpret_cast<Vec *>(out.base + out.idx + e0) = q;
+      for (int j = 0; j < V; ++j) q[j] = y[j];
+      // (a template parameter, not a run-time flag: the compiler merges the two stores of a run-time branch into a plain one)
+      if constexpr (NTSTORE) __builtin_nontemporal_store(q, reinterpret_cast<VecT *>(out.base + out.idx + e0));
+      else *reinterpret_cast<VecT *>(out.base + out.idx + e0) = q;
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j)
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(Port<const T> in, Port
 
 template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
   constexpr size_t TILE = (size_t)SCAN_BLOCK * (16 / sizeof(T)) * ROWS;
+  const int ntStore = n * sizeof(T) >= ((size_t)128 << 20) ? 1 : 0;
   const size_t numTiles = (n + TILE - 1) / TILE;
   const size_t dbytes = Desc<T>::bytes(numTiles);
   if (numTiles <= kCtlScanTiles) {
@@ -326,8 +331,12 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
     bool wrapped;
     char *ctl = L.scan_control(numTiles, gen, base, wrapped);
     if (wrapped) ZSR_CHECK(hipMemsetAsync(ctl, 0, kCtlTicket, L.stream));  // generation wrap: start over from clean descriptors
-    hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
-                       (void *)(ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(ctl + kCtlTicket), gen, base);
+    if (ntStore)
+      hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS, true>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                         (void *)(ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(ctl + kCtlTicket), gen, base);
+    else
+      hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS, false>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                         (void *)(ctl + (sizeof(T) == 8 ? kCtlDesc8 : 0)), kCtlScanTiles, (unsigned *)(ctl + kCtlTicket), gen, base);
     // The host's shadow of the ticket counter was advanced for this launch.  A launch that never ran leaves the device counter behind
     // it, and every later scan on the stream would derive wrong tile numbers: report, and bring both back to a clean control block.
     // (One stream must not be driven by two host threads at once -- reservation and launch are not one atomic step -- nor be captured
@@ -341,8 +350,12 @@ template <int OP, class T, bool EXCL, int ROWS> static void scan_launch(Launch &
   char *mem = (char *)L.temp(dbytes + 256);
   ZSR_CHECK(hipMemsetAsync(mem, 0, dbytes + 256, L.stream));  // descriptors + ticket re-initialised every call
   unsigned *ticket = (unsigned *)(mem + dbytes);
-  hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
-                     (void *)mem, numTiles, ticket, 0u, 0u);
+  if (ntStore)
+    hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS, true>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                       (void *)mem, numTiles, ticket, 0u, 0u);
+  else
+    hipLaunchKernelGGL((scan_kernel<OP, T, EXCL, ROWS, false>), dim3((unsigned)numTiles), dim3(SCAN_BLOCK), 0, L.stream, in, out, n, init,
+                       (void *)mem, numTiles, ticket, 0u, 0u);
 }
 template <int OP, class T, bool EXCL> static void scan_impl(Launch &L, Port<const T> in, size_t n, Port<T> out, T init) {
   if (n == 0) return;
@@ -640,6 +653,8 @@ __global__ __launch_bounds__(BLOCK) void radix_onesweep_kernel(Port<const K> kin
       const K kk = keyS[lp];
       const unsigned d = KeyBits<K>::digit(kk, st, mask);
       const unsigned dst = globalStart[d] + lp;
+      // (non-temporal stores of these 4-byte run pieces were measured: 64 M keys 0.94 -> 1.02 ms, pairs 1.26 -> 2.06 ms -- they defeat
+      // the write combining in L2; non-temporal loads of the pass input: keys 0.88, pairs 1.36 ms: not adopted either)
       ko[dst] = kk;
       if constexpr (PAIR) vo[dst] = valS[lp];
     }
