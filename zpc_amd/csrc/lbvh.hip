@@ -89,12 +89,23 @@ __global__ __launch_bounds__(BOX_BLOCK) void lbvh_box_reduce_kernel(const AABB3 
     partial[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
   }
 }
-__global__ void lbvh_box_final_kernel(const float *partial, int nblocks, float *out) {
-  const int c = threadIdx.x;
-  if (c >= 6) return;
-  float r = partial[c];
-  for (int b = 1; b < nblocks; ++b) r = c < 3 ? fminf(r, partial[(size_t)b * 6 + c]) : fmaxf(r, partial[(size_t)b * 6 + c]);
-  out[c] = r;
+__global__ void lbvh_box_final_kernel(const float *partial, int nblocks, float *out) {  // one wave
+  const int lane = threadIdx.x;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = lane; b < nblocks; b += 64)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], partial[(size_t)b * 6 + d]);
+      hi[d] = fmaxf(hi[d], partial[(size_t)b * 6 + 3 + d]);
+    }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], shfl_down(lo[d], o));
+      hi[d] = fmaxf(hi[d], shfl_down(hi[d], o));
+    }
+  if (lane == 0)
+    for (int d = 0; d < 3; ++d) { out[d] = lo[d]; out[3 + d] = hi[d]; }
 }
 // morton code of every box centre in the unit cube of the whole box (what zs::LBvh's build computes, Bvh.hpp:177-188)
 __global__ __launch_bounds__(256) void lbvh_morton_kernel(const AABB3 *bvs, int n, const float *whole, unsigned *mcs, int *indices) {
@@ -301,6 +312,84 @@ __global__ __launch_bounds__(256) void lbvh_refit_kernel(int numLeaves, const AA
     }
     store_box_agent(orderedBvs + node, bv);
     node = parents[node];
+  }
+}
+// The same refit, windowed (r04).  In the pre-order layout the subtree of node p occupies the positions [p, esc(p)), so a workgroup that
+// owns a window [P0, P1) of positions can finish every subtree that lies inside it on its own: boxes, arrival flags and the topology of
+// the window live in LDS, and only the nodes whose subtree sticks out of the window (p < P0 or esc(p) > P1: ~1 % of the nodes at 2048
+// positions per window) take the global arrival flags and agent-scope box accesses of lbvh_refit_kernel.  A lane that leaves the local
+// domain first publishes the box it carries (agent-scope store), then signs in at the parent's global flag like any other lane.
+// Same min / max merges in the same pairs: the boxes are bit-identical to the unwindowed kernel's (and the reference's, Bvh.hpp:469-492).
+template <int LBVH_RW, int LBVH_RT>
+__global__ __launch_bounds__(LBVH_RT) void lbvh_refit_window_kernel(int numNodes, const AABB3 *primBvs, AABB3 *orderedBvs, const int *auxIndices,
+                                                                    const int *parents, const int *levels, int *gflags) {
+  __shared__ float sb[6][LBVH_RW];
+  __shared__ int sf[LBVH_RW];       // low two bits: arrivals (2 = merged here); bit 2: box already published by an agent-scope store
+  __shared__ int sPar[LBVH_RW], sAux[LBVH_RW];
+  __shared__ unsigned char sTrunk[LBVH_RW];
+  const int t = threadIdx.x;
+  const int P0 = blockIdx.x * LBVH_RW, P1 = P0 + LBVH_RW < numNodes ? P0 + LBVH_RW : numNodes, cntW = P1 - P0;
+  for (int i = t; i < cntW; i += LBVH_RT) {
+    sf[i] = 0;
+    sPar[i] = parents[P0 + i];
+    sAux[i] = auxIndices[P0 + i];
+    sTrunk[i] = levels[P0 + i] != 0;
+  }
+  __syncthreads();
+  for (int i = t; i < cntW; i += LBVH_RT) {
+    if (sTrunk[i]) continue;  // trunk nodes are reached by climbing
+    AABB3 cur = primBvs[sAux[i]];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sb[d][i] = cur.lo[d]; sb[3 + d][i] = cur.hi[d]; }
+    int child = P0 + i;
+    int node = sPar[i];
+    bool waiting = false;  // first to arrive at a local node: the sibling's lane carries on
+    while (node >= P0) {   // (node < P0, incl. -1 above the root: not local)
+      const int a = sAux[node - P0];
+      if ((a < 0 ? numNodes : a) > P1) break;  // its subtree sticks out of the window
+      __threadfence_block();                     // the box of `child` is in LDS before this lane signs in
+      if ((atomicAdd(&sf[node - P0], 1) & 3) == 0) { waiting = true; break; }
+      __threadfence_block();                     // ... and the sibling's box is read after its lane signed in
+      const int lc = node + 1 - P0;
+      const int rc = (sTrunk[lc] ? sAux[lc] : lc + 1 + P0) - P0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        cur.lo[d] = fminf(sb[d][lc], sb[d][rc]);
+        cur.hi[d] = fmaxf(sb[3 + d][lc], sb[3 + d][rc]);
+        sb[d][node - P0] = cur.lo[d];
+        sb[3 + d][node - P0] = cur.hi[d];
+      }
+      child = node;
+      node = sPar[node - P0];
+    }
+    if (waiting || node == -1) continue;  // (node == -1: the root was merged here -- the whole tree is one window)
+    // leaving the local domain: publish the carried box, then the global walk of lbvh_refit_kernel
+    store_box_agent(orderedBvs + child, cur);
+    atomicOr(&sf[child - P0], 4);
+    while (node != -1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (atomicCAS(&gflags[node], 0, 1) == 0) break;
+      const int lc = node + 1;
+      const int rc = levels[lc] ? auxIndices[lc] : lc + 1;
+      AABB3 L, R;
+      load_box2_agent(orderedBvs + lc, orderedBvs + rc, L, R);
+      AABB3 bv;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        bv.lo[d] = fminf(L.lo[d], R.lo[d]);
+        bv.hi[d] = fmaxf(L.hi[d], R.hi[d]);
+      }
+      store_box_agent(orderedBvs + node, bv);
+      node = parents[node];
+    }
+  }
+  __syncthreads();
+  // the window's finished boxes that nobody published yet: leaves and the trunk nodes merged here
+  float *out = reinterpret_cast<float *>(orderedBvs + P0);
+  for (int e = t; e < cntW * 6; e += LBVH_RT) {
+    const int i = e / 6, c = e - 6 * i;
+    const int f = sf[i];
+    if ((!sTrunk[i] || (f & 3) == 2) && !(f & 4)) out[e] = sb[c][i];
   }
 }
 __global__ __launch_bounds__(256) void lbvh_small_kernel(int n, const AABB3 *primBvs, AABB3 *orderedBvs, int *leafInds, int *auxIndices,
@@ -604,8 +693,20 @@ static void lbvh_refit_impl(Launch &L, zs_rocm_lbvh &b, const AABB3 *primBvs) {
   }
   int *flags = (int *)L.temp(sizeof(int) * b.numNodes);
   ZSR_CHECK(hipMemsetAsync(flags, 0, sizeof(int) * b.numNodes, L.stream));
-  hipLaunchKernelGGL(lbvh_refit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, primBvs, b.orderedBvs, b.auxIndices, b.leafInds,
-                     b.parents, b.levels, flags);
+  static const bool plain = [] { const char *e = getenv("ZS_ROCM_LBVH_REFIT"); return e && e[0] == 'p'; }();  // A/B runs: the unwindowed kernel
+  if (plain)
+    hipLaunchKernelGGL(lbvh_refit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, primBvs, b.orderedBvs, b.auxIndices, b.leafInds,
+                       b.parents, b.levels, flags);
+  else {
+    static const int shape = [] { const char *e = getenv("ZS_ROCM_LBVH_REFIT"); return e && e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 1; }();
+#define ZSR_REFIT_W(RW, RT)                                                                                                              \
+  hipLaunchKernelGGL((lbvh_refit_window_kernel<RW, RT>), dim3(ceil_div(b.numNodes, RW)), dim3(RT), 0, L.stream, (int)b.numNodes, primBvs,  \
+                     b.orderedBvs, b.auxIndices, b.parents, b.levels, flags)
+    if (shape == 2) ZSR_REFIT_W(1024, 512);
+    else if (shape == 3) ZSR_REFIT_W(2048, 512);
+    else if (shape == 4) ZSR_REFIT_W(1024, 1024);
+    else ZSR_REFIT_W(2048, 1024);
+  }
 }
 
 }  // namespace zsr
