@@ -525,7 +525,9 @@ template <int LW, int N> __device__ __forceinline__ void pload(const Port<float>
   if constexpr (LW != 0) {
     const float *b = p.base + o.o;
 #pragma unroll
-    for (int d = 0; d < N; ++d) out[d] = b[d * LW];
+    for (int d = 0; d < N; ++d) {
+      out[d] = b[d * LW];
+    }
   } else
     load_attr<N>(p, o.o, out);
 }
