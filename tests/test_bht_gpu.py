@@ -239,3 +239,36 @@ def test_gpu_overfull_table_reports_like_the_reference(pol):
     failed = r == np.iinfo(np.int32).min
     assert failed.any() and (q[failed] == -1).all()                                   # reported, and really not stored
     assert np.unique(keys[q >= 0], axis=0).shape[0] == cnt and (r[q < 0] < -1).all()   # every key is either stored or was reported
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 4])
+def test_order_morton_renumbers_along_the_z_curve(pol, dim):
+    """zs_rocm_order_morton__bht_*: the same key set, numbered in ascending Morton code of (key - min key) (64 / dim bits per component,
+    component 0 most significant inside a bit group); queries return the new numbers."""
+    from zpc_amd.containers import Bht
+    g = np.random.default_rng(31 + dim)
+    keys = np.unique(g.integers(-300, 700, (6000, dim), dtype=np.int32), axis=0)
+    g.shuffle(keys)
+    n = keys.shape[0]
+    tab = Bht(dim, n)
+    ret = torch.empty(n, dtype=torch.int32, device="cuda")
+    tab.insert(pol, torch.from_numpy(keys).cuda().data_ptr(), n, ret.data_ptr())
+    pol.syncCtx()
+    assert tab.size() == n
+    tab.order_morton(pol)
+    pol.syncCtx()
+    act = _d2h(tab.view().activeKeys, n * dim * 4).reshape(n, dim)
+    assert set(map(tuple, act)) == set(map(tuple, keys))
+    rel = (act.astype(np.int64) - keys.min(0).astype(np.int64)).astype(np.uint64)
+    bits = 64 // dim
+    code = np.zeros(n, dtype=object)
+    for i in range(n):
+        c = 0
+        for d in range(dim):
+            v = int(rel[i, d])
+            for b in range(min(bits, 32)):
+                c |= ((v >> b) & 1) << (b * dim + (dim - 1 - d))
+        code[i] = c
+    assert all(code[i] <= code[i + 1] for i in range(n - 1))
+    tab.query(pol, torch.from_numpy(act.copy()).cuda().data_ptr(), n, ret.data_ptr())
+    assert np.array_equal(ret.cpu().numpy(), np.arange(n))
