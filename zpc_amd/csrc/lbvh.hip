@@ -320,14 +320,47 @@ __global__ __launch_bounds__(256) void lbvh_refit_kernel(int numLeaves, const AA
 // positions per window) take the global arrival flags and agent-scope box accesses of lbvh_refit_kernel.  A lane that leaves the local
 // domain first publishes the box it carries (agent-scope store), then signs in at the parent's global flag like any other lane.
 // Same min / max merges in the same pairs: the boxes are bit-identical to the unwindowed kernel's (and the reference's, Bvh.hpp:469-492).
+// A lane that leaves the local domain does not walk on inside this kernel (ten or twenty dependent agent-scope round trips would keep its
+// whole 1024-thread workgroup resident: measured, half of the kernel's time): it publishes its box and leaves the node in the window's
+// hand-over list (LBVH_RL entries per window; a full list falls back to walking here); lbvh_refit_upper_kernel continues from the lists.
+constexpr int LBVH_RL = 128;
+__device__ __forceinline__ void lbvh_refit_global_walk(int node, AABB3 *orderedBvs, const int *auxIndices, const int *parents, const int *levels,
+                                                       int *gflags) {
+  while (node != -1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's box is at the coherence point before it signs in
+    if (atomicCAS(&gflags[node], 0, 1) == 0) break;     // first to arrive: the sibling will do the merge
+    const int lc = node + 1;
+    const int rc = levels[lc] ? auxIndices[lc] : lc + 1;
+    AABB3 L, R;
+    load_box2_agent(orderedBvs + lc, orderedBvs + rc, L, R);
+    AABB3 bv;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      bv.lo[d] = fminf(L.lo[d], R.lo[d]);
+      bv.hi[d] = fmaxf(L.hi[d], R.hi[d]);
+    }
+    store_box_agent(orderedBvs + node, bv);
+    node = parents[node];
+  }
+}
+__global__ __launch_bounds__(256) void lbvh_refit_upper_kernel(int nWindows, const int *listCount, const int *list, AABB3 *orderedBvs,
+                                                               const int *auxIndices, const int *parents, const int *levels, int *gflags) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = idx / LBVH_RL, k = idx - w * LBVH_RL;
+  if (w >= nWindows || k >= listCount[w]) return;
+  lbvh_refit_global_walk(list[idx], orderedBvs, auxIndices, parents, levels, gflags);  // (the entry is the first node above the window's domain)
+}
 template <int LBVH_RW, int LBVH_RT>
 __global__ __launch_bounds__(LBVH_RT) void lbvh_refit_window_kernel(int numNodes, const AABB3 *primBvs, AABB3 *orderedBvs, const int *auxIndices,
-                                                                    const int *parents, const int *levels, int *gflags) {
+                                                                    const int *parents, const int *levels, int *gflags, int *listCount,
+                                                                    int *list) {
   __shared__ float sb[6][LBVH_RW];
   __shared__ int sf[LBVH_RW];       // low two bits: arrivals (2 = merged here); bit 2: box already published by an agent-scope store
   __shared__ int sPar[LBVH_RW], sAux[LBVH_RW];
   __shared__ unsigned char sTrunk[LBVH_RW];
+  __shared__ int sList;
   const int t = threadIdx.x;
+  if (t == 0) sList = 0;
   const int P0 = blockIdx.x * LBVH_RW, P1 = P0 + LBVH_RW < numNodes ? P0 + LBVH_RW : numNodes, cntW = P1 - P0;
   for (int i = t; i < cntW; i += LBVH_RT) {
     sf[i] = 0;
@@ -336,11 +369,19 @@ __global__ __launch_bounds__(LBVH_RT) void lbvh_refit_window_kernel(int numNodes
     sTrunk[i] = levels[P0 + i] != 0;
   }
   __syncthreads();
+  // the leaves' boxes first (a random gather from the primitive array: all of a lane's requests in flight together), then the climbs
+  for (int i = t; i < cntW; i += LBVH_RT) {
+    if (sTrunk[i]) continue;
+    const AABB3 b = primBvs[sAux[i]];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sb[d][i] = b.lo[d]; sb[3 + d][i] = b.hi[d]; }
+  }
+  __syncthreads();
   for (int i = t; i < cntW; i += LBVH_RT) {
     if (sTrunk[i]) continue;  // trunk nodes are reached by climbing
-    AABB3 cur = primBvs[sAux[i]];
+    AABB3 cur;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { sb[d][i] = cur.lo[d]; sb[3 + d][i] = cur.hi[d]; }
+    for (int d = 0; d < 3; ++d) { cur.lo[d] = sb[d][i]; cur.hi[d] = sb[3 + d][i]; }
     int child = P0 + i;
     int node = sPar[i];
     bool waiting = false;  // first to arrive at a local node: the sibling's lane carries on
@@ -363,25 +404,13 @@ __global__ __launch_bounds__(LBVH_RT) void lbvh_refit_window_kernel(int numNodes
       node = sPar[node - P0];
     }
     if (waiting || node == -1) continue;  // (node == -1: the root was merged here -- the whole tree is one window)
-    // leaving the local domain: publish the carried box, then the global walk of lbvh_refit_kernel
+
+    // leaving the local domain: publish the carried box and hand the walk over
     store_box_agent(orderedBvs + child, cur);
     atomicOr(&sf[child - P0], 4);
-    while (node != -1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (atomicCAS(&gflags[node], 0, 1) == 0) break;
-      const int lc = node + 1;
-      const int rc = levels[lc] ? auxIndices[lc] : lc + 1;
-      AABB3 L, R;
-      load_box2_agent(orderedBvs + lc, orderedBvs + rc, L, R);
-      AABB3 bv;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        bv.lo[d] = fminf(L.lo[d], R.lo[d]);
-        bv.hi[d] = fmaxf(L.hi[d], R.hi[d]);
-      }
-      store_box_agent(orderedBvs + node, bv);
-      node = parents[node];
-    }
+    const int slot = atomicAdd(&sList, 1);
+    if (slot < LBVH_RL) list[(size_t)blockIdx.x * LBVH_RL + slot] = node;
+    else lbvh_refit_global_walk(node, orderedBvs, auxIndices, parents, levels, gflags);
   }
   __syncthreads();
   // the window's finished boxes that nobody published yet: leaves and the trunk nodes merged here
@@ -391,6 +420,7 @@ __global__ __launch_bounds__(LBVH_RT) void lbvh_refit_window_kernel(int numNodes
     const int f = sf[i];
     if ((!sTrunk[i] || (f & 3) == 2) && !(f & 4)) out[e] = sb[c][i];
   }
+  if (t == 0) listCount[blockIdx.x] = sList < LBVH_RL ? sList : LBVH_RL;
 }
 __global__ __launch_bounds__(256) void lbvh_small_kernel(int n, const AABB3 *primBvs, AABB3 *orderedBvs, int *leafInds, int *auxIndices,
                                                          int *parents, int *levels) {
@@ -698,14 +728,13 @@ static void lbvh_refit_impl(Launch &L, zs_rocm_lbvh &b, const AABB3 *primBvs) {
     hipLaunchKernelGGL(lbvh_refit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, n, primBvs, b.orderedBvs, b.auxIndices, b.leafInds,
                        b.parents, b.levels, flags);
   else {
-    static const int shape = [] { const char *e = getenv("ZS_ROCM_LBVH_REFIT"); return e && e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : 1; }();
-#define ZSR_REFIT_W(RW, RT)                                                                                                              \
-  hipLaunchKernelGGL((lbvh_refit_window_kernel<RW, RT>), dim3(ceil_div(b.numNodes, RW)), dim3(RT), 0, L.stream, (int)b.numNodes, primBvs,  \
-                     b.orderedBvs, b.auxIndices, b.parents, b.levels, flags)
-    if (shape == 2) ZSR_REFIT_W(1024, 512);
-    else if (shape == 3) ZSR_REFIT_W(2048, 512);
-    else if (shape == 4) ZSR_REFIT_W(1024, 1024);
-    else ZSR_REFIT_W(2048, 1024);
+    constexpr int RW = 2048, RT = 1024;  // (1024 / 512: the same time; 2048 / 512 and 1024 / 1024: slower -- profiles/r04_lbvh.md)
+    const int nWindows = (int)ceil_div(b.numNodes, RW);
+    int *listCount = (int *)L.temp(sizeof(int) * nWindows), *list = (int *)L.temp(sizeof(int) * (size_t)nWindows * LBVH_RL);
+    hipLaunchKernelGGL((lbvh_refit_window_kernel<RW, RT>), dim3(nWindows), dim3(RT), 0, L.stream, (int)b.numNodes, primBvs, b.orderedBvs,
+                       b.auxIndices, b.parents, b.levels, flags, listCount, list);
+    hipLaunchKernelGGL(lbvh_refit_upper_kernel, dim3(ceil_div((size_t)nWindows * LBVH_RL, 256)), dim3(256), 0, L.stream, nWindows,
+                       (const int *)listCount, (const int *)list, b.orderedBvs, b.auxIndices, b.parents, b.levels, flags);
   }
 }
 
