@@ -848,6 +848,11 @@ void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const f
   hipLaunchKernelGGL((lbvh_query_packed_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
                      (const AABB3 *)queryBvs, nq, (int *)nullptr, offsets, out, perm);
 }
+// one wave per workgroup: the walks of neighbouring waves differ in length, and a long one would keep the other wave slots of its
+// workgroup idle (count pass 2.97 -> 2.85 ms; 128 threads: 2.95)
+#ifndef LBVH_SELF_BLOCK
+#define LBVH_SELF_BLOCK 64
+#endif
 void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, int *counts) {
   Launch L(pol, "lbvh_self_query_count");
   if (!b->numLeaves) return;
@@ -860,7 +865,7 @@ void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, i
   // A/B runs: ZS_ROCM_LBVH_SELF=l selects the one-walk-per-leaf kernel of r03
   static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
   if (b->numNodes > 2 && !perLeaf)
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false>), dim3(ceil_div(b->numLeaves, LBVH_SELF_BLOCK)), dim3(LBVH_SELF_BLOCK), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
                        b->hitCache, b->hitCounts, 0);
   else
@@ -874,7 +879,7 @@ void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, co
   if (!b->numLeaves) return;
   static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
   if (b->numNodes > 2 && !perLeaf)
-    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true>), dim3(ceil_div(b->numLeaves, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b),
+    hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true>), dim3(ceil_div(b->numLeaves, LBVH_SELF_BLOCK)), dim3(LBVH_SELF_BLOCK), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
                        b->hitCacheValid ? 1 : 0);
   else
