@@ -820,6 +820,9 @@ void zs_rocm_lbvh_total_box(zs_rocm_policy *pol, const zs_rocm_lbvh *b, float *b
   hipLaunchKernelGGL(lbvh_box_reduce_kernel, dim3(1), dim3(BOX_BLOCK), 0, L.stream, b->orderedBvs, b->numLeaves, partial, 0);
   hipLaunchKernelGGL(lbvh_box_final_kernel, dim3(1), dim3(64), 0, L.stream, partial, 1, box6Dev);
 }
+#ifndef LBVH_QUERY_BLOCK
+#define LBVH_QUERY_BLOCK 256
+#endif
 // bulk iter_neighbors: >= 16384 queries are walked in Morton order of their centres (codes + one pair sort: ~0.1 ms per million);
 // ZS_ROCM_LBVH_QUERY=u keeps the caller's order (A/B runs).  nullptr: caller's order.
 static const int *lbvh_query_order(Launch &L, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq) {
@@ -837,7 +840,7 @@ void zs_rocm_lbvh_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const 
   if (!nq) return;
   if (!b->numLeaves) { ZSR_CHECK(hipMemsetAsync(counts, 0, nq * sizeof(int), L.stream)); return; }
   const int *perm = lbvh_query_order(L, b, queryBvs, nq);
-  hipLaunchKernelGGL((lbvh_query_packed_kernel<false>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
+  hipLaunchKernelGGL((lbvh_query_packed_kernel<false>), dim3(ceil_div(nq, LBVH_QUERY_BLOCK)), dim3(LBVH_QUERY_BLOCK), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
                      (const AABB3 *)queryBvs, nq, counts, (const int *)nullptr, (int *)nullptr, perm);
 }
 void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const float *queryBvs, size_t nq, const int *offsets, int *out) {
@@ -845,7 +848,7 @@ void zs_rocm_lbvh_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, const f
   if (!nq) return;
   if (!b->numLeaves) return;
   const int *perm = lbvh_query_order(L, b, queryBvs, nq);
-  hipLaunchKernelGGL((lbvh_query_packed_kernel<true>), dim3(ceil_div(nq, 256)), dim3(256), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
+  hipLaunchKernelGGL((lbvh_query_packed_kernel<true>), dim3(ceil_div(nq, LBVH_QUERY_BLOCK)), dim3(LBVH_QUERY_BLOCK), 0, L.stream, lbvh_packed(L, *b), (int)b->numNodes,
                      (const AABB3 *)queryBvs, nq, (int *)nullptr, offsets, out, perm);
 }
 // one wave per workgroup: the walks of neighbouring waves differ in length, and a long one would keep the other wave slots of its
