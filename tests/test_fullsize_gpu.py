@@ -53,6 +53,29 @@ def test_config1_primitives_at_1m_ints(pol):
     assert np.array_equal(out.cpu().numpy(), np.sort(a))
 
 
+def test_scans_above_128_mb_take_the_streaming_store_path(pol):
+    """Outputs of >= 128 MB are written with non-temporal stores (r04): exclusive and inclusive scans of 40 M + 1 ints (ragged last tile)
+    and 20 M + 3 int64 values, out of place and in place, bit-exact against numpy's wrapping cumsum."""
+    import zpc_amd as zs
+    g = np.random.default_rng(23)
+    a = g.integers(-2 ** 31, 2 ** 31 - 1, 40_000_001, dtype=np.int64).astype(np.int32)
+    d = torch.from_numpy(a).cuda()
+    out = torch.empty_like(d)
+    inc = np.cumsum(a, dtype=np.int64).astype(np.int32)
+    zs.exclusive_scan(pol, d, out)
+    assert np.array_equal(out.cpu().numpy(), inc - a)
+    zs.inclusive_scan(pol, d, out)
+    assert np.array_equal(out.cpu().numpy(), inc)
+    zs.exclusive_scan(pol, d, d, init=5)
+    assert np.array_equal(d.cpu().numpy(), (inc - a + np.int32(5)).astype(np.int32))
+    del d, out
+    b = g.integers(-2 ** 62, 2 ** 62, 20_000_003, dtype=np.int64)
+    db = torch.from_numpy(b).cuda()
+    ob = torch.empty_like(db)
+    zs.inclusive_scan(pol, db, ob)
+    assert np.array_equal(ob.cpu().numpy(), np.cumsum(b))
+
+
 def test_config2_bht_16m_keys(pol, oracle):
     """BASELINE config 2: bht build over 16 M random cells (10.6 M distinct).  With the reference's sizing (2 next_2pow(n) slots in
     buckets of 16, 15 usable) and its universal hash, a few dozen keys find all three of their buckets full: the reference's insert
