@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256) void lbvh_pack_kernel(LBvhDev bvh, LbvhPackedN
   for (int d = 0; d < 3; ++d) { n.lo[d] = b.lo[d]; n.hi[d] = b.hi[d]; }
   n.level = bvh.numNodes > 2 ? bvh.levels[i] : 0;
   n.aux = bvh.numNodes > 2 ? bvh.auxIndices[i] : i;
+  if (bvh.numNodes > 2 && n.level != 0 && n.aux < 0) n.aux = bvh.numNodes;  // escape index behind the last subtree: one past the end
   out[i] = n;
 }
 // the reference's stack-less walk over packed nodes: at a trunk node an overlap descends to the left child (node + 1), a miss
@@ -643,28 +644,34 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
     }
     // the whole node in ONE scalar load (eight dwords); no short-circuit in the overlap test: a second, dependent load group under
     // a branch would double the latency of a step
-    const v8i raw = *reinterpret_cast<const v8i *>(nodes + cur);
+    // (the scalar unit sets the pace of this loop -- eight waves per SIMD, ~25 scalar instructions a step: a 32-bit byte offset instead
+    // of a sign-extended 64-bit index, the escape index of the last subtree stored as numNodes by the pack kernel, and the leaf's hit
+    // test under a scalar branch each take instructions off it)
+    const v8i raw = *reinterpret_cast<const v8i *>(reinterpret_cast<const char *>(nodes) + ((unsigned)cur << 5));
     const float nlo0 = __int_as_float(raw[0]), nlo1 = __int_as_float(raw[1]), nlo2 = __int_as_float(raw[2]);
     const float nhi0 = __int_as_float(raw[3]), nhi1 = __int_as_float(raw[4]), nhi2 = __int_as_float(raw[5]);
     const int level = raw[6], aux = raw[7];
     const bool active = next == cur;
     const bool ov = (int)!(me.lo[0] > nhi0 || me.hi[0] < nlo0) & (int)!(me.lo[1] > nhi1 || me.hi[1] < nlo1) &
                     (int)!(me.lo[2] > nhi2 || me.hi[2] < nlo2);
-    const bool leaf = level == 0;  // wave-uniform
-    if (leaf && active && ov && aux != self) {
-      if constexpr (FILL) {
-        dst[2 * c] = self;
-        dst[2 * c + 1] = aux;
-      } else {
-        if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = aux;
+    if (__builtin_amdgcn_readfirstlane(level) == 0) {  // a leaf (wave-uniform branch): report it, continue at cur + 1
+      if (active && ov && aux != self) {
+        if constexpr (FILL) {
+          dst[2 * c] = self;
+          dst[2 * c + 1] = aux;
+        } else {
+          if (c < LBVH_HIT_CACHE) cache[(size_t)c * numLeaves + k] = aux;
+        }
+        ++c;
       }
-      ++c;
+      if (active) next = cur + 1;
+      cur = cur + 1;  // (some lane is always at a leaf the wave visits)
+    } else {             // a trunk node: descend on overlap, escape otherwise (aux = the escape index; numNodes behind the last subtree)
+      const bool down = active && ov;
+      if (active) next = down ? cur + 1 : aux;
+      if (__ballot(down)) cur = cur + 1;
+      else cur = aux < nextStart ? aux : nextStart;
     }
-    const bool down = active && (leaf || ov);
-    const int esc = aux < 0 ? numNodes : aux;  // (trunk nodes only; a leaf always continues at cur + 1)
-    if (active) next = down ? cur + 1 : esc;
-    if (__ballot(down)) cur = cur + 1;
-    else cur = esc < nextStart ? esc : nextStart;
   }
   if (!FILL && valid) {
     counts[k] = c;
