@@ -443,14 +443,18 @@ ZS_ROCM_EXPORT int zs_rocm_lbvh_refit(zs_rocm_policy *, zs_rocm_lbvh *, const fl
 ZS_ROCM_EXPORT void zs_rocm_lbvh_total_box(zs_rocm_policy *, const zs_rocm_lbvh *, float *box6);
 /* bulk LBvhView::iter_neighbors (:644-680): counts[q] = number of primitives whose box overlaps queryBvs[q]; then, with
  * offsets = exclusive_scan(counts), out[offsets[q] ...] = their ids in traversal order */
+/* (r04: 16384 or more queries are walked in Morton order of their centres -- codes + one pair sort inside the call; every query's
+ * result still goes to its own slot, hits in the walk's order) */
 ZS_ROCM_EXPORT void zs_rocm_lbvh_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, int *counts);
 ZS_ROCM_EXPORT void zs_rocm_lbvh_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const float *queryBvs, size_t nq, const int *offsets,
                                             int *out);
 /* self-collision broadphase (LBvhView::self_iter_neighbors, container/Bvh.hpp:695-728, driven over every leaf): thread k walks
  * from the k-th leaf in node order; counts[k] = overlapping leaves AFTER it (the leaf itself is skipped), so every unordered
  * pair of overlapping primitives appears exactly once.  fill: pairs[2*(offsets[k]+c)] = {primitive of leaf k, other primitive}.
- * The count pass remembers the first 16 hits of every leaf inside the LBvh object; a fill pass on the unchanged tree copies
- * them instead of walking again (the memory is released with the object, invalidated by build / refit). */
+ * The count pass remembers the first 32 hits of every leaf inside the LBvh object (132 B per leaf: 1.3 GB for 10 M leaves, allocated on
+ * the first self query); a fill pass on the unchanged tree copies them instead of walking again (the memory is released with the
+ * object, invalidated by build / refit).  `pairs` must be 8-byte aligned (any hipMalloc'ed array is).  r04: one walk per WAVE over the
+ * union of its 64 leaves' walks; every leaf still reports the same ids in the same order. */
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, int *counts /* [numLeaves] */);
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const int *offsets, int *pairs);
 
