@@ -2224,70 +2224,92 @@ template <int CS> struct ConsumerSet {  // CS 0: m + mv_x, 1: mv_y + mv_z, 2: f_
   static constexpr int D0 = CS == 0 ? 0 : (CS == 1 ? 1 : (CS == 2 ? 0 : 2));  // first direction; the second is D0 + 1
   static constexpr int CH0 = CS == 0 ? 0 : (CS == 1 ? 2 : (CS == 2 ? 4 : 6));  // first grid channel of the set
 };
+// Staged record of the role-split kernels (r05, "Q form"): what a particle adds to node (a, b, c) of its stencil in vector channel j is
+//   W_abc (alpha_j + (a - 1) bx_j + (b - 1) by_j + (c - 1) bz_j),
+// alpha = the channel's value at the CENTRE node of the stencil, b. = its change per node step -- momentum d (P2G.hpp:112-119):
+// alpha = m (v_d + C[d, :] . (dx - lp)), b_k = m C[d + 3 k] dx; force d (:104-110): alpha = kscale (P F^T)[d, :] . (dx - lp),
+// b_k = kscale (P F^T)[d + 3 k] dx.  The producer (lane = particle, every lane busy) forms the 24 coefficients once; the four
+// consumers (lane = cell, a third of the lanes idle, everything repeated per channel set) no longer rebuild the offsets x_i - x_p and
+// the products C . (x_i - x_p) per node: 766 -> 585 VALU instructions per consumed round.
+//   [0] m, [1..3] d0 = x'/dx - base node (local position in cells, [0.5, 1.5)), [4 + 4 j + {0, 1, 2, 3}] = alpha, bx, by, bz of
+//   channel j = mv_x, mv_y, mv_z, f_x, f_y, f_z
+constexpr int G2P2G_QF = 28;
+__device__ __forceinline__ void stage_qform(const MpmDev &mp, float *st, float pm, const float (&lpn)[3], const float (&vel)[3], const float (&C)[9],
+                                            const float (&PF)[9]) {
+  const float dxi = 1.0f / mp.dx;
+  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  float lc[3];  // centre node - particle
+#pragma unroll
+  for (int k = 0; k < 3; ++k) lc[k] = fmaf(-lpn[k], mp.dx, mp.dx);
+  st[0] = pm;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) st[(1 + d) * 64] = lpn[d];
+  const float pmdx = pm * mp.dx, ksdx = kscale * mp.dx;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float *q = st + (4 + 4 * d) * 64;
+    q[0] = pm * (vel[d] + (C[d] * lc[0] + C[3 + d] * lc[1] + C[6 + d] * lc[2]));
+    q[64] = pmdx * C[d];
+    q[128] = pmdx * C[3 + d];
+    q[192] = pmdx * C[6 + d];
+    float *g = st + (16 + 4 * d) * 64;
+    g[0] = kscale * (PF[d] * lc[0] + PF[3 + d] * lc[1] + PF[6 + d] * lc[2]);
+    g[64] = ksdx * PF[d];
+    g[128] = ksdx * PF[3 + d];
+    g[192] = ksdx * PF[6 + d];
+  }
+}
 template <int CS>
-__device__ __forceinline__ void g2p2g_consume_set(const MpmDev &mp, const float *st, int lane, float kscale,
-                                                  float (&acc)[27][ConsumerSet<CS>::NA]) {
-  // written for a small live set (the 54 accumulators leave ~70 registers at four waves per SIMD): offsets are re-derived from
-  // the local position where they are used, the x- and y-terms are folded into one running value per (a, b)
+__device__ __forceinline__ void g2p2g_consume_set(const MpmDev &mp, const float *st, int lane, float (&acc)[27][ConsumerSet<CS>::NA]) {
   using S = ConsumerSet<CS>;
   auto f = [&](int k) { return st[k * 64 + lane]; };
-  // staged slots 1..3: lpn = x'/dx - base node of the particle's NEW position (the producer has it from its moved-out-of-the-cell
-  // test; a staged particle sits in this lane's cell, so lpn is in [0.5, 1.5) and make_arena's d0 == lpn): the four consumers
-  // do not repeat the floor / re-centering arithmetic
-  constexpr int cb = S::STRESS ? 16 : 7;
-  // every staged value of the set first (12 LDS reads in one go), then the arithmetic: one LDS latency per particle instead of four
-  float d0s[3], c0[S::NV], c1[S::NV], c2s[S::NV], vs[S::NV];
+  // every staged value of the set first (LDS reads in one go), then the arithmetic: one LDS latency per particle
+  float d0s[3], al[S::NV], bx[S::NV], by[S::NV], bz[S::NV];
 #pragma unroll
   for (int d = 0; d < 3; ++d) d0s[d] = f(1 + d);
-  const float scale = S::STRESS ? kscale : f(0);
+  float pm = 0.f;
+  if constexpr (S::MASS) pm = f(0);
 #pragma unroll
   for (int j = 0; j < S::NV; ++j) {
-    const int d = S::D0 + j;
-    c0[j] = f(cb + d);
-    c1[j] = f(cb + 3 + d);
-    c2s[j] = f(cb + 6 + d);
-    vs[j] = S::STRESS ? 0.f : f(4 + d);
+    const int q = 4 + 4 * ((S::STRESS ? 3 : 0) + S::D0 + j);
+    al[j] = f(q);
+    bx[j] = f(q + 1);
+    by[j] = f(q + 2);
+    bz[j] = f(q + 3);
   }
   asm volatile("" ::: "memory");  // (keeps the compiler from sinking the reads back between the fmas)
-  Arena ar;
+  float w[3][3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const float d0 = d0s[d];
-    ar.w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
+    w[d][0] = 0.5f * (1.5f - d0) * (1.5f - d0);
     const float d1 = d0 - 1.0f;
-    ar.w[d][1] = 0.75f - d1 * d1;
+    w[d][1] = 0.75f - d1 * d1;
     const float zz = 0.5f + d1;
-    ar.w[d][2] = 0.5f * zz * zz;
-    ar.lp[d] = d0 * mp.dx;
-  }
-  float wzs[3], Pz[S::NV][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) wzs[k] = ar.w[2][k] * scale;
-#pragma unroll
-  for (int j = 0; j < S::NV; ++j) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Pz[j][k] = fmaf(c2s[j], (float)k * mp.dx - ar.lp[2], vs[j]);
+    w[d][2] = 0.5f * zz * zz;
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float x0 = (float)a * mp.dx - ar.lp[0];
-    float Pxa[S::NV];
+    float qa[S::NV];
 #pragma unroll
-    for (int j = 0; j < S::NV; ++j) Pxa[j] = c0[j] * x0;
+    for (int j = 0; j < S::NV; ++j) qa[j] = a == 0 ? al[j] - bx[j] : (a == 1 ? al[j] : al[j] + bx[j]);
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
-      const float x1 = (float)bb * mp.dx - ar.lp[1];
-      const float wxy = ar.w[0][a] * ar.w[1][bb];
-      float q[S::NV];
+      const float wxy = w[0][a] * w[1][bb];
+      const float W0 = wxy * w[2][0], W1 = wxy * w[2][1], W2 = wxy * w[2][2];
+      auto &A0 = acc[(a * 3 + bb) * 3], &A1 = acc[(a * 3 + bb) * 3 + 1], &A2 = acc[(a * 3 + bb) * 3 + 2];
+      if constexpr (S::MASS) {
+        A0[0] = fmaf(W0, pm, A0[0]);
+        A1[0] = fmaf(W1, pm, A1[0]);
+        A2[0] = fmaf(W2, pm, A2[0]);
+      }
 #pragma unroll
-      for (int j = 0; j < S::NV; ++j) q[j] = fmaf(c1[j], x1, Pxa[j]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float Ws = wxy * wzs[c];
-        auto &A = acc[(a * 3 + bb) * 3 + c];
-        if constexpr (S::MASS) A[0] += Ws;
-#pragma unroll
-        for (int j = 0; j < S::NV; ++j) A[(S::MASS ? 1 : 0) + j] = fmaf(Ws, q[j] + Pz[j][c], A[(S::MASS ? 1 : 0) + j]);
+      for (int j = 0; j < S::NV; ++j) {
+        const float qab = bb == 0 ? qa[j] - by[j] : (bb == 1 ? qa[j] : qa[j] + by[j]);
+        constexpr int o = S::MASS ? 1 : 0;
+        A0[o + j] = fmaf(W0, qab - bz[j], A0[o + j]);
+        A1[o + j] = fmaf(W1, qab, A1[o + j]);
+        A2[o + j] = fmaf(W2, qab + bz[j], A2[o + j]);
       }
     }
   }
@@ -2314,7 +2336,7 @@ __device__ __forceinline__ void g2p2g_rs_consumer(const MpmDev &mp, int lane, in
       for (int rr = 0; rr < 4; ++rr) {
         const unsigned long long vm = smask[par * 4 + rr];
         if (vm == 0ull) continue;
-        if ((vm >> lane) & 1ull) g2p2g_consume_set<CS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_NF * 64), lane, kscale, acc);
+        if ((vm >> lane) & 1ull) g2p2g_consume_set<CS>(mp, stage + (size_t)(par * 4 + rr) * (G2P2G_QF * 64), lane, acc);
       }
     }
     __syncthreads();
@@ -2391,7 +2413,7 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
   for (int it = 0; it <= nchunks; ++it) {
     if (it < nchunks) {
       const int par = it & 1;
-      float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_NF * 64);
+      float *myStage = stage + (size_t)(par * 4 + W) * (G2P2G_QF * 64);
       cur = nxt;
       has0 = has1;
       i0 = i1;
@@ -2468,15 +2490,7 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
             }
           } else {
             valid = true;
-            myStage[0 * 64 + lane] = cur.m;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
+            stage_qform(mp, myStage + lane, cur.m, lpn, vel, C, PF);
           }
         }
       }
@@ -2509,7 +2523,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float varena[3 * AL::CH];
   __shared__ float parena[7 * AL::CH];
-  __shared__ float stage[2 * 4 * G2P2G_NF * 64];
+  __shared__ float stage[2 * 4 * G2P2G_QF * 64];
   __shared__ unsigned long long smask[2 * 4];
   __shared__ int mq[G2P2G_MQ_CAP];
   __shared__ int mqCount;

@@ -205,6 +205,9 @@ template <int SIDE> __device__ __forceinline__ int neighbour_bin(const int *nbr2
 //     plain LDS read-add-write: latency-bound, 6 us per workgroup.)  The record's new home is found by slot_rehome_kernel after the
 //     step: one thread per record, ticket from the destination cell's global counter, rounds above the in-bin arrivals.
 // Departures and ticket counts are folded into the occupancy words by slot_commit_kernel.
+#ifndef ZS_PROD_XLIST
+#define ZS_PROD_XLIST 1  // the list of the last chunk is scattered by the (then idle) producer waves
+#endif
 constexpr int SL_NG = 9;       // staged entry groups of 64: a chunk being produced (4) + the chunk being consumed (4) + a straddling round
 constexpr int SL_KMAX = 32;    // rounds per bin the 32-bit occupancy words allow
 #ifndef ZS_SL_ARRQ
@@ -222,7 +225,7 @@ __device__ __forceinline__ int nth_low_bit(unsigned w, unsigned t) {
 struct SlotShared {  // views of the kernel's LDS arrays
   float *varena;                     // [3 * ArenaLds::CH] node velocities of the bin
   float *parena;                     // [7 * ArenaLds::CH] the bin's P2G arena
-  float *stage;                      // [SL_NG * G2P2G_NF * 64]
+  float *stage;                      // [SL_NG * G2P2G_QF * 64]
   unsigned long long *smask;         // [SL_NG]
   unsigned short *tab;               // [SL_KMAX * 64] entry -> round * 64 + cell
   unsigned *mask0;                   // [64] occupancy of the bin's cells at the start of the step
@@ -303,6 +306,66 @@ __device__ __forceinline__ void outbox_scatter_global(const MpmDev &mp, const Bi
   }
 }
 
+// Movers whose new cell is not a lane of this bin (or whose cell's arrival queue was full), and stayers whose local position rounded
+// onto 1.5: the channels of set CS of their 27 node terms straight to the grid.  Two list entries per pass: lane = (entry parity,
+// stencil node); the channels of the set are a compile-time loop, so only the node's weight formula (alpha + beta (s d0 + t)^2 per
+// axis) and its offset from the centre node are per-lane constants.  Staged record: stage_qform.
+template <int SIDE, int CS>
+__device__ __forceinline__ void slot_xlist_scatter(const MpmDev &mp, const BinGeom<SIDE> &geo, const float *stage, const unsigned *xq, int nx, int lane,
+                                                   const int *nbrBlk, const SlotArgs &A) {
+  using S = ConsumerSet<CS>;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  const int node = lane & 31, half = lane >> 5;
+  if (node >= 27 || nx <= 0) return;
+  const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
+  float ws[3], wt[3], wa[3], wb[3], oc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    ws[q] = sel[q] == 0 ? -1.f : 1.f;
+    wt[q] = sel[q] == 0 ? 1.5f : (sel[q] == 1 ? -1.f : -0.5f);
+    wa[q] = sel[q] == 1 ? 0.75f : 0.f;
+    wb[q] = sel[q] == 1 ? -1.f : 0.5f;
+    oc[q] = (float)(sel[q] - 1);
+  }
+#ifdef ZS_ABL_NOXLIST
+  return;
+#endif
+#pragma unroll 1
+  for (int k = half; k < nx; k += 2) {
+    const unsigned e = xq[k];
+    const float *st = stage + (size_t)((e & 1023u) >> 6) * (G2P2G_QF * 64) + (e & 63u);
+    float Wt = 1.f;
+    int g[3], code = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float d0 = st[(1 + q) * 64];
+      const float u = fmaf(ws[q], d0 - floorf(d0 - 0.5f), wt[q]);  // the reference's second base_node (see `edge` in the producer)
+      Wt *= fmaf(wb[q], u * u, wa[q]);
+      g[q] = (int)((e >> (10 + 3 * q)) & 7u) - 1 + geo.o[q] + sel[q];
+      code = code * 3 + 1 + (g[q] >= SIDE ? 1 : 0) - (g[q] < 0 ? 1 : 0);
+    }
+    const int bn = nbrBlk[code];
+    if (bn >= 0) {
+      const int cell = ((g[0] & (SIDE - 1)) * SIDE + (g[1] & (SIDE - 1))) * SIDE + (g[2] & (SIDE - 1));
+      float *gp = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + cell;
+#pragma unroll
+      for (int q = 0; q < S::NA; ++q) {
+        float val;
+        if (S::MASS && q == 0) {
+          val = Wt * st[0];  // mass
+        } else {
+          const float *c = st + (4 + 4 * ((S::STRESS ? 3 : 0) + S::D0 + q - (S::MASS ? 1 : 0))) * 64;
+          val = Wt * fmaf(c[192], oc[2], fmaf(c[128], oc[1], fmaf(c[64], oc[0], c[0])));
+        }
+        if (val != 0.f) unsafeAtomicAdd(gp + q * NC, val);
+      }
+    } else if (S::MASS) {
+      A.status[2] = 1;  // mass for a node whose block is not in the partition
+    }
+  }
+}
+
+
 // producer wave W (0..3): entries [64 (4c + W), +64) of every chunk c
 template <int SIDE, int SMODEL, bool WRITE_ALL, int W>
 __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, int bin, int total,
@@ -361,12 +424,12 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0;
 #endif
-  for (int it = 0; it <= nchunks; ++it) {
+  for (int it = 0; it < nchunks; ++it) {
     SLP_T0(tIt);
-    if (it < nchunks) {
+    {
       const int grp = 4 * it + W;
       const int par = it % 3;
-      float *myStage = stage + (size_t)(grp % SL_NG) * (G2P2G_NF * 64);
+      float *myStage = stage + (size_t)(grp % SL_NG) * (G2P2G_QF * 64);
       cur = nxt;
       has0 = has1;
       i0 = i1;
@@ -410,12 +473,20 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
           const float pm = cur.m;
           float plj = 0.f;
           if constexpr (DP) plj = cur.logJp;
+#ifdef ZS_ABL_NOMOVE
+          const bool moved = false;
+#else
           const bool moved = nc[0] != cx || nc[1] != cy || nc[2] != cz;
+#endif
           // X - floor(X - 0.5) rounded up to 1.5, or X - 0.5 rounded up to an integer and left it below 0.5 (|X| < 1 only): the reference
           // applies base_node to the local position once more and takes the weights of d0 -+ 1 on the unchanged corner
           // (InterpolationKernel.hpp:108 on simulation/Utils.hpp:59-60; make_arena restates it).  The lane = cell consumers take the staged
           // lpn as d0; such a particle is scattered through the consumers' list instead, which folds d0 as the reference does.
+#ifdef ZS_ABL_NOMOVE
+          const bool edge = false;
+#else
           const bool edge = !(lpn[0] >= 0.5f && lpn[0] < 1.5f && lpn[1] >= 0.5f && lpn[1] < 1.5f && lpn[2] >= 0.5f && lpn[2] < 1.5f);
+#endif
           if (W == 0) SLP_ADD(5, tIt);  // [5] producer: start of the iteration -> mover block (record wait, gather, advance)
           SLP_T0(tMv);
           bool outbox = false;   // it gets an outbox record (new cell in a neighbour bin: slot_rehome_kernel finds its slot; or fallback scatter)
@@ -550,7 +621,11 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
           }
           {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
             float lj = plj;
+#ifdef ZS_ABL_NOSVD
+            for (int d = 0; d < 9; ++d) PF[d] = F[d] * mp.mat.volume;
+#else
             model_stress<SMODEL>(mp.mat, lj, F, PF, C);
+#endif
             if (outbox) {
               if (rec) {
                 rec[0] = pm;
@@ -576,15 +651,7 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
             // reuses their registers for the SVD at once and waits for the particle stores just issued (s_waitcnt vmcnt(1)
             // in front of the SVD: 2 ms per 64 Mi particles)
             valid = !moved && !byList;  // an in-bin mover is consumed by the lane of its NEW cell (arrival queue), not by the lane of its entry
-            myStage[0 * 64 + lane] = pm;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(1 + d) * 64 + lane] = lpn[d];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) myStage[(4 + d) * 64 + lane] = vel[d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) myStage[(7 + d) * 64 + lane] = C[d];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) myStage[(16 + d) * 64 + lane] = PF[d];
+            stage_qform(mp, myStage + lane, pm, lpn, vel, C, PF);
           }
         }
       }
@@ -593,11 +660,20 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
         if (lane == 0) smask[grp % SL_NG] = vm;
       }
     }
-    if (it < nchunks) SLP_ACC(tWork, tIt);
+    SLP_ACC(tWork, tIt);
     SLP_T0(tB);
     __syncthreads();
-    if (it < nchunks) SLP_ACC(tBar, tB);
-    else if (W == 0) SLP_ADD(6, tB);
+    SLP_ACC(tBar, tB);
+  }
+  {  // nothing left to produce (the consumers accumulate the rounds of the last chunk): the last chunk's global-atomic list
+    SLP_T0(tB);
+    if (ZS_PROD_XLIST && nchunks > 0) {
+      const int par = (nchunks - 1) % 3;
+      const int nx = xCnt[par] < (unsigned)SL_XQ ? (int)xCnt[par] : SL_XQ;
+      slot_xlist_scatter<SIDE, W>(mp, geo, stage, xq[par], nx, lane, sh.nbrBlk, A);
+    }
+    __syncthreads();
+    if (W == 0) SLP_ADD(6, tB);
   }
   if (W == 0) {
     SLP_PUT(3, tWork);
@@ -612,8 +688,6 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   using S = ConsumerSet<CS>;
   using AL = ArenaLds;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);
   const unsigned long long lt = lanemask_lt();
   const float *const stage = sh.stage;
   const unsigned long long *const smask = sh.smask;
@@ -628,7 +702,6 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   for (int k = 0; k < 27; ++k)
 #pragma unroll
     for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
-  for (int k = (int)threadIdx.x - 256; k < 7 * AL::CH; k += 256) parena[k] = 0.f;  // the four consumer waves clear the bin's arena
   __syncthreads();  // (the producers fill the velocity arena meanwhile)
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0;
@@ -661,82 +734,25 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
           if (has) {
             const int e = off + __popcll(occ & lt);
             const int grp = (e >> 6) % SL_NG, pos = e & 63;
-            if ((smask[grp] >> pos) & 1ull) spos = grp * (G2P2G_NF * 64) + pos;
+            if ((smask[grp] >> pos) & 1ull) spos = grp * (G2P2G_QF * 64) + pos;
           }
           off += cnt;
           ++r;
         }
         if (spos < 0 && pend) {  // a lane without a particle of its own in this round takes an arrival
           const unsigned p = arrQ[par][lane][ai++];
-          spos = (int)(p >> 6) * (G2P2G_NF * 64) + (int)(p & 63u);
+          spos = (int)(p >> 6) * (G2P2G_QF * 64) + (int)(p & 63u);
         }
-        if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, kscale, acc);
+        if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, acc);
         if (CS == 0) SLP_PUT(15, 1);  // [15] consumer: loop iterations (rounds + extra rounds for arrivals)
       }
       if (CS == 0) SLP_ADD(13, tIt);  // [13] consumer: rounds loop (incl. in-bin arrivals)
       SLP_T0(tX);
-      // movers of the chunk whose new cell is not a lane of this bin (or whose cell's arrival queue was full): this set's channels
-      // of their 27 node terms straight to the grid.  Two list entries per pass: lane = (entry parity, stencil node); the channels of
-      // the set are a compile-time loop, so only the node's weight formula (alpha + beta (s d0 + t)^2 per axis) is a per-lane constant
+      // movers of the chunk whose new cell is not a lane of this bin (or whose cell's arrival queue was full): slot_xlist_scatter.  The
+      // list of the LAST chunk is taken by the producer waves, which have nothing left to produce in that iteration
       const int nx = xCnt[par] < (unsigned)SL_XQ ? (int)xCnt[par] : SL_XQ;
       if (CS == 0 && lane == 0) xCnt[(it + 1) % 3] = 0u;
-      {
-        constexpr int NC = SIDE * SIDE * SIDE;
-        const int node = lane & 31, half = lane >> 5;
-        const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
-        float ws[3], wt[3], wa[3], wb[3], xo[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          ws[q] = sel[q] == 0 ? -1.f : 1.f;
-          wt[q] = sel[q] == 0 ? 1.5f : (sel[q] == 1 ? -1.f : -0.5f);
-          wa[q] = sel[q] == 1 ? 0.75f : 0.f;
-          wb[q] = sel[q] == 1 ? -1.f : 0.5f;
-          xo[q] = (float)sel[q] * mp.dx;
-        }
-        if (node < 27 && nx > 0) {
-#pragma unroll 1
-          for (int k = half; k < nx; k += 2) {
-            const unsigned e = xq[par][k];
-            const float *st = stage + (size_t)((e & 1023u) >> 6) * (G2P2G_NF * 64) + (e & 63u);
-            float Wt = 1.f, xi[3];
-            int g[3], code = 0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              const float d0 = st[(1 + q) * 64];
-              const float u = fmaf(ws[q], d0 - floorf(d0 - 0.5f), wt[q]);  // the reference's second base_node (see `edge` in the producer)
-              Wt *= fmaf(wb[q], u * u, wa[q]);
-              xi[q] = fmaf(-mp.dx, d0, xo[q]);
-              g[q] = (int)((e >> (10 + 3 * q)) & 7u) - 1 + geo.o[q] + sel[q];
-              code = code * 3 + 1 + (g[q] >= SIDE ? 1 : 0) - (g[q] < 0 ? 1 : 0);
-            }
-            const int bn = nbrBlk[code];
-            if (bn >= 0) {
-              const int cell = ((g[0] & (SIDE - 1)) * SIDE + (g[1] & (SIDE - 1))) * SIDE + (g[2] & (SIDE - 1));
-              float *gp = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + cell;
-              const float Wm = Wt * (S::STRESS ? kscale : st[0]);
-#pragma unroll
-              for (int q = 0; q < S::NA; ++q) {
-                float val;
-                if (S::MASS && q == 0) {
-                  val = Wm;  // mass
-                } else {
-                  // momentum d: m (v_d + C[., d] . xi); force d: -dt Dinv (P F^T[., d] . xi)
-                  const int d = S::D0 + q - (S::MASS ? 1 : 0);
-                  const int iC = (S::STRESS ? 16 : 7) + d;
-                  float t = st[iC * 64] * xi[0];
-                  t = fmaf(st[(iC + 3) * 64], xi[1], t);
-                  t = fmaf(st[(iC + 6) * 64], xi[2], t);
-                  if (!S::STRESS) t += st[(4 + d) * 64];  // v_d + (C . xi), the association of P2G.hpp:112
-                  val = Wm * t;
-                }
-                if (val != 0.f) unsafeAtomicAdd(gp + q * NC, val);
-              }
-            } else if (S::MASS) {
-              A.status[2] = 1;  // mass for a node whose block is not in the partition
-            }
-          }
-        }
-      }
+      if (!ZS_PROD_XLIST || it < nchunks) slot_xlist_scatter<SIDE, CS>(mp, geo, stage, xq[par], nx, lane, nbrBlk, A);
       if (CS == 0) {
         SLP_ADD(14, tX);  // [14] consumer: global-atomic list
         SLP_PUT(12, nx);  // [12] entries of the list
@@ -753,6 +769,9 @@ __device__ __forceinline__ void g2p2g_slot_consumer(const MpmDev &mp, const BinG
   }
   SLP_T0(tFl);
   // the set's channels of the bin's arena belong to this wave alone; phases ordered inside the wave (see g2p2g_body)
+  // (the arena lives in the staging ring, which nobody reads after the loop's last barrier: cleared here, by the wave that owns the channels)
+  for (int k = lane; k < S::NA * AL::CH; k += 64) parena[(size_t)S::CH0 * AL::CH + k] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   float *a0 = parena + (size_t)S::CH0 * AL::CH + AL::at(cx, cy, cz);
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -769,8 +788,8 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
   using AL = ArenaLds;
   constexpr int NC = SIDE * SIDE * SIDE;
   __shared__ float s_varena[3 * AL::CH];
-  __shared__ float s_parena[7 * AL::CH];
-  __shared__ float s_stage[SL_NG * G2P2G_NF * 64];
+  __shared__ float s_stage[SL_NG * G2P2G_QF * 64];
+  float *const s_parena = s_stage;  // the bin's P2G arena (7 * AL::CH floats) is filled after the last chunk has been consumed: it shares the ring
   __shared__ unsigned long long s_smask[SL_NG];
   __shared__ unsigned short s_tab[SL_KMAX * 64];
   __shared__ unsigned s_mask0[64], s_clr[64], s_arrLocal[64], s_arrCnt[3][64];
@@ -847,21 +866,6 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
     if (s_sent) atomicAdd(&A.status[SL_SENT + (bin & (SL_NCTR - 1))], s_sent);
     if (s_homed) atomicAdd(&A.status[SL_DELIVERED + (bin & (SL_NCTR - 1))], s_homed);
   }
-  if (s_xOver > 0) {  // (rare) a chunk had more than SL_XQ movers for the consumers' list: their full records -> grid, all eight waves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have reached L2 ...
-    __syncthreads();                                    // ... and so have everybody else's
-    const int oc = s_outCount < A.cap ? s_outCount : A.cap;
-    constexpr int RB = SL_NG * G2P2G_NF * 64 / SL_REC;  // records per batch: the whole staging ring is free now
-    for (int j0 = 0; j0 < oc; j0 += RB) {
-      const int nb = oc - j0 < RB ? oc - j0 : RB;
-      const float *src = A.moverRec + ((size_t)bin * A.cap + (size_t)j0) * SL_REC;
-      // agent-scope loads: served by L2, where the stores are (never by an L1 line of this CU)
-      for (int k = tid; k < nb * SL_REC; k += 512) s_stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      outbox_scatter_global<SIDE>(mp, geo, s_stage, nb, w, lane, s_nbrBlk, A.gridB, A.status);
-      __syncthreads();
-    }
-  }
   if (tid < 216) {
     const int x = tid / 36, y = (tid / 6) % 6, z = tid % 6;
     int slot, cell;
@@ -877,6 +881,21 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slot_kernel(MpmDev mp, Pa
       }
     } else if (a[0] != 0.f) {
       A.status[2] = 1;  // mass for a node whose block is not in the partition
+    }
+  }
+  if (s_xOver > 0) {  // (rare) a chunk had more than SL_XQ movers for the consumers' list: their full records -> grid, all eight waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have reached L2 ...
+    __syncthreads();                                    // ... and so have everybody else's (and the arena, which shares the ring, has been flushed)
+    const int oc = s_outCount < A.cap ? s_outCount : A.cap;
+    constexpr int RB = SL_NG * G2P2G_QF * 64 / SL_REC;  // records per batch: the whole staging ring is free now
+    for (int j0 = 0; j0 < oc; j0 += RB) {
+      const int nb = oc - j0 < RB ? oc - j0 : RB;
+      const float *src = A.moverRec + ((size_t)bin * A.cap + (size_t)j0) * SL_REC;
+      // agent-scope loads: served by L2, where the stores are (never by an L1 line of this CU)
+      for (int k = tid; k < nb * SL_REC; k += 512) s_stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      outbox_scatter_global<SIDE>(mp, geo, s_stage, nb, w, lane, s_nbrBlk, A.gridB, A.status);
+      __syncthreads();
     }
   }
   if (w == 0) {
