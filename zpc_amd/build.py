@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # per-file flags.  mpm.hip: the SLP vectoriser packs independent scalar f32 ops of the per-lane 3x3 SVD / stencil code
 # into v_pk_*_f32 (same FLOP rate as two scalar ops on CDNA4) and pays ~25 % extra v_mov to form the register pairs:
 # 901 -> 772 instructions and ~2390 -> ~1540 issue cycles for the SVD alone (MI355X guide, 5.6: "an anti-lever").
-EXTRA_FLAGS = {"mpm_slotted.hip": ["-fno-slp-vectorize"], "mpm.hip": ["-fno-slp-vectorize"], "mpm_p2g.hip": ["-fno-slp-vectorize"], "mpm_g2p.hip": ["-fno-slp-vectorize", "-DZS_PSTORE_NT"],  # G2P's particle state (124 B per particle, written once per step) by non-temporal stores: 3.43 -> 3.11 ms at 64 Mi particles; no effect on the fused kernels (measured)
+EXTRA_FLAGS = {"mpm_slotted.hip": ["-fno-slp-vectorize"], "mpm_slotblk.hip": ["-fno-slp-vectorize"], "mpm.hip": ["-fno-slp-vectorize"], "mpm_p2g.hip": ["-fno-slp-vectorize"], "mpm_g2p.hip": ["-fno-slp-vectorize", "-DZS_PSTORE_NT"],  # G2P's particle state (124 B per particle, written once per step) by non-temporal stores: 3.43 -> 3.11 ms at 64 Mi particles; no effect on the fused kernels (measured)
                "mpm_c2.hip": ["-fno-slp-vectorize"],
                "mpm_fused.hip": ["-fno-slp-vectorize"], "mpm_fused4.hip": ["-fno-slp-vectorize"], "mpm_fused8.hip": ["-fno-slp-vectorize"],
                # morton codes must round like the reference's scalar code (no fused centre/offset arithmetic)

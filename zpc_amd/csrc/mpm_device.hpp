@@ -932,6 +932,13 @@ struct ArenaLds {
   __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
 };
 
+// LDS arena of one 8^3 block: 10^3 nodes (the block's cells + the two node layers of the quadratic stencil), dense
+struct ArenaBlk {
+  static constexpr int W = 10;
+  static constexpr int SY = 10, SX = 100, CH = 1000;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+
 // geometry of bin `bin`: grid block, origin of the bin inside the block (cells), origin in world cells
 template <int SIDE> struct BinGeom {
   int block, o[3], org[3];
@@ -1681,6 +1688,8 @@ __device__ __forceinline__ void g2p_gather_factorized(const MpmDev &mp, const Ar
   for (int d = 0; d < 9; ++d) C[d] = B[d % 3][d / 3] * D_inv;  // C[d] += W v_i[d%3] xixp[d/3] D_inv (G2P.hpp:65)
 }
 
+struct ArenaLds;
+template <class AL>
 __device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar, const float *a0, float D_inv, float (&vel)[3],
                                                float (&C)[9]);
 
@@ -1744,7 +1753,7 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
       } else if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
         // another cell of the same bin (the particle moved since the last re-bin): its nodes are in the LDS arena
         float vel[3], C[9];
-        g2p_gather_lds(mp, ar, arena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+        g2p_gather_lds<AL>(mp, ar, arena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
         g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
       } else {
         stale[atomicAdd(staleCount, 1)] = i0;  // outside the bin: exact path (hash queries)
@@ -1789,9 +1798,9 @@ constexpr int G2P2G_MQ_CAP = 512;  // in-bin movers a workgroup can take through
 
 // gather of g2p_gather_factorized with the node velocities read from the LDS arena (81 ds_read per particle; the fused
 // kernel is VALU-bound and needs the 81 VGPRs a register-resident copy would cost for its P2G stencil)
+template <class AL>
 __device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar, const float *a0, float D_inv, float (&vel)[3],
                                                float (&C)[9]) {
-  using AL = ArenaLds;
   float xz[3], xy[3], xx[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -1988,7 +1997,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
         if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
       } else {
         float vel[3], C[9];
-        g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+        g2p_gather_lds<AL>(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
         const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
         float pos[3];
 #pragma unroll
@@ -2432,7 +2441,7 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
           if ((unsigned)(ocx + 4) >= 12u || (unsigned)(ocy + 4) >= 12u || (unsigned)(ocz + 4) >= 12u) staleGCount[8] = 1;
         } else {
           float vel[3], C[9];
-          g2p_gather_lds(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+          g2p_gather_lds<AL>(mp, ar, varena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
           const POff<LW> o = particle_offset<LW>(ps.pos.chns, (size_t)i0);
           float pos[3];
 #pragma unroll

@@ -1,0 +1,455 @@
+// mpm_slotblk.hip -- the fused G2P2G step on slotted storage with ONE WORKGROUP PER 8^3 GRID BLOCK (r05).
+//
+// Why.  g2p2g_slot_kernel (mpm_slotted.hip) gives every bin (4^3 cells, ~512 particles = 1.9 chunks of 256) a workgroup of its own: a
+// producer -> consumer pipeline that is filled and drained once per bin, in front of it a head (occupancy words, entry table, velocity
+// arena: three dependent memory round trips) and behind it a tail (arena flush, grid atomics).  The cycle stamps of that kernel
+// (profiles/r05_slot_probe.md) put head + drain + flush + tail at half of a workgroup's life; the two workgroups of a CU overlap them only by
+// chance.  Here the 8 bins of a block are one pipeline:
+//   * the chunk sequence runs through all bins of the block (bin 0 chunk 0, bin 0 chunk 1, bin 1 chunk 0, ...): producers prefetch the
+//     records of chunk g + 1 -- whichever bin it belongs to -- while they compute chunk g; the consumers flush a bin's accumulators and
+//     send its arena to the grid while the producers are already in the next bin.  Fill and drain are paid once per block;
+//   * head once per block: the occupancy words of all 8 bins in one load, ONE velocity arena of 10^3 nodes for the whole block
+//     (12 KB; the bins' own 6^3 arenas overlap by half);
+//   * the staging ring holds ONE chunk (+ the group a round may straddle): 5 groups of 64 records instead of 9 (35 KB, which is what pays
+//     for the block arena).  A producer waits, right before it stages, until all four consumers have counted the previous chunk done (an
+//     LDS counter, no barrier: the consumers finish a chunk in half the time the producers need for the next); one barrier per chunk
+//     hands the staged chunk over;
+//   * per-bin state (entry table, tickets, departures, outbox count, neighbour bins) is double-buffered by bin parity; the entry table
+//     of a bin is built two chunks ahead by the producers, a finished bin's claim words are written out one chunk later.
+// The per-particle code (slot_produce_entry), the consumers' accumulation (g2p2g_consume_set), the mover protocol, slot_rehome_kernel
+// and slot_commit_kernel are those of mpm_slotted.hip; results differ only in summation order.
+#include "mpm_slot.hpp"
+
+namespace zsr {
+
+constexpr int SB_NG = 5;       // ring: the four groups of a chunk + the group a straddling round keeps alive
+constexpr int SB_MAXCH = 64;   // chunks per block: 8 bins x (32 rounds x 64 cells / 256)
+
+struct SubGeom {  // what the shared scatter helpers need of a bin: origin inside the block, origin in world cells
+  int o[3], org[3];
+};
+__device__ __forceinline__ SubGeom sub_geom(const int (&borg)[3], int b) {
+  SubGeom g;
+  g.o[0] = ((b >> 2) & 1) * 4;
+  g.o[1] = ((b >> 1) & 1) * 4;
+  g.o[2] = (b & 1) * 4;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g.org[d] = borg[d] + g.o[d];
+  return g;
+}
+
+struct BlkShared {
+  float *varena, *parena, *stage;
+  unsigned long long *smask;
+  unsigned short (*tab)[SL_KMAX * 64];       // [2]
+  unsigned (*masks)[64];                     // [8]
+  unsigned (*clr)[64], (*arrLocal)[64];      // [2]
+  unsigned (*arrCnt)[64];                    // [3]
+  unsigned short (*arrQ)[64][SL_ARRQ];       // [3]
+  unsigned *xCnt;                            // [3]
+  unsigned (*xq)[SL_XQ];                     // [3]
+  int *nbrBlk, (*nbrBin)[27], *nbr8;
+  int (*cnt)[4];                             // [2]: outCount, sent, homed, xOver of the bin of that parity
+  int *total, *gbase, *nch, *binQ, *oc;      // [8] per bin: occupied slots, first chunk number, chunks, position among the block's non-empty bins,
+                                             // outbox records (after the bin has been finished)
+  unsigned char *chBin, *chIdx;              // [SB_MAXCH] chunk -> bin of the block, chunk number inside the bin
+  unsigned *done;                            // consumer waves x chunks consumed
+  int *sums;                                 // [0] sent, [1] homed, [2] bins whose outbox holds records that still have to be scattered
+};
+
+// entry table of one bin: round-major enumeration of its occupied slots; wave w of nw writes the rows of rounds = w mod nw
+__device__ __forceinline__ void blk_build_tab(unsigned mask, int lane, int w, int nw, unsigned short *tab) {
+  unsigned any = mask;
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) any |= (unsigned)__shfl_xor((int)any, sft, 64);
+  const int nrounds = any ? 32 - __clz((int)any) : 0;
+  const unsigned long long lt = lanemask_lt();
+  int total = 0;
+  for (int r = 0; r < nrounds; ++r) {
+    const bool has = (mask >> r) & 1u;
+    const unsigned long long occ = __ballot(has);
+    if ((r % nw) == w && has) tab[total + __popcll(occ & lt)] = (unsigned short)(r * 64 + lane);
+    total += __popcll(occ);
+  }
+}
+// the 27 bins around bin b of this block (direction code (dx + 1) 9 + (dy + 1) 3 + dz + 1), from the block's 27 neighbour blocks
+__device__ __forceinline__ int blk_neighbour_bin(const int *nbrBlk, int blk, int b, int code) {
+  if (code == 13) return blk * 8 + b;
+  const int dd[3] = {code / 9 - 1, (code / 3) % 3 - 1, code % 3 - 1};
+  int sx[3] = {((b >> 2) & 1) + dd[0], ((b >> 1) & 1) + dd[1], (b & 1) + dd[2]}, bo[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    bo[d] = sx[d] < 0 ? -1 : (sx[d] > 1 ? 1 : 0);
+    sx[d] &= 1;
+  }
+  const int nb = nbrBlk[(bo[0] + 1) * 9 + (bo[1] + 1) * 3 + (bo[2] + 1)];
+  return nb < 0 ? -1 : nb * 8 + ((sx[0] * 2 + sx[1]) * 2 + sx[2]);
+}
+
+// a finished bin (all of its chunks produced by all producer waves): departures and in-bin arrivals of its cells for slot_rehome_kernel /
+// slot_commit_kernel, its outbox count; the parity's counters are zero again.  One wave, lane = cell.
+__device__ __forceinline__ void blk_finish_bin(const BlkShared &sh, const SlotArgs &A, int bin0, int b, int lane) {
+  const int qp = sh.binQ[b] & 1, bin = bin0 + b;
+  const unsigned c = sh.clr[qp][lane], nl = sh.arrLocal[qp][lane];
+  if (c) A.claim[((size_t)A.nbinsAll + (size_t)bin) * 64 + lane] = c;
+  if (nl) A.claim[(size_t)bin * 64 + lane] = nl << 16;  // (the low half -- arrivals from other bins -- is counted by slot_rehome_kernel)
+  sh.clr[qp][lane] = 0u;
+  sh.arrLocal[qp][lane] = 0u;
+  if (lane == 0) {
+    const int oc = sh.cnt[qp][0] < A.cap ? sh.cnt[qp][0] : A.cap;
+    A.moverCount[bin] = oc;
+    sh.oc[b] = oc;
+    sh.sums[0] += sh.cnt[qp][1];
+    sh.sums[1] += sh.cnt[qp][2];
+    if (sh.cnt[qp][3] > 0) sh.sums[2] |= 1 << b;
+    sh.cnt[qp][0] = sh.cnt[qp][1] = sh.cnt[qp][2] = sh.cnt[qp][3] = 0;
+  }
+}
+
+// producer wave W (0..3): entries [64 (4 c + W), +64) of every chunk c of every bin of the block
+template <int SMODEL, bool WRITE_ALL, int W>
+__device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDev &ps, const int (&borg)[3], int blk, int lane, int G,
+                                             const BlkShared &sh, const SlotArgs &A) {
+  constexpr int LW = 64;
+  constexpr bool DP = model_uses_logjp(SMODEL);
+  constexpr bool FLUID = model_is_fluid(SMODEL);
+  const int bin0 = blk * 8;
+  const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
+  RecG<LW, DP, FLUID> cur, nxt;
+  bool has0 = false, has1 = false;
+  size_t i0 = 0, i1 = 0;
+  unsigned code0 = 0, code1 = 0;
+  {
+    const int b = sh.chBin[0];
+    const int j = 64 * W + lane;
+    has1 = j < sh.total[b];
+    if (has1) {
+      code1 = sh.tab[sh.binQ[b] & 1][j];
+      i1 = ((size_t)(bin0 + b) * (size_t)A.K + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
+      nxt.load(ps, i1);
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    const int b = sh.chBin[g];
+    const int qp = sh.binQ[b] & 1;
+    const int grp = 4 * g + W, slot = grp % SB_NG, par = g % 3;
+    float *myStage = sh.stage + (size_t)slot * (G2P2G_QF * 64);
+    cur = nxt;
+    has0 = has1;
+    i0 = i1;
+    code0 = code1;
+    has1 = false;
+    if (g + 1 < G) {  // the records of the next chunk (this bin's or the next bin's): in flight during this chunk
+      const int b1 = sh.chBin[g + 1];
+      const int j1 = 256 * (int)sh.chIdx[g + 1] + 64 * W + lane;
+      has1 = j1 < sh.total[b1];
+      if (has1) {
+        code1 = sh.tab[sh.binQ[b1] & 1][j1];
+        i1 = ((size_t)(bin0 + b1) * (size_t)A.K + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
+        nxt.load(ps, i1);
+      }
+    }
+    // per-bin state around the bin boundaries (every buffer named here is dead for its previous owner: see the file comment)
+    if (g > 0 && sh.chIdx[g] == 0 && W == 0) blk_finish_bin(sh, A, bin0, sh.chBin[g - 1], lane);  // the bin that ended with chunk g - 1
+    if (g + 1 < G && sh.chIdx[g + 1] == 0 && W == 1 && lane < 27) {                                 // neighbour bins of the bin that starts with chunk g + 1
+      const int b1 = sh.chBin[g + 1];
+      sh.nbrBin[sh.binQ[b1] & 1][lane] = blk_neighbour_bin(sh.nbrBlk, blk, b1, lane);
+    }
+    if (g + 2 < G && sh.chIdx[g + 2] == 0) {  // entry table of the bin that starts with chunk g + 2 (its first records are requested at the top of g + 1)
+      const int b2 = sh.chBin[g + 2];
+      blk_build_tab(sh.masks[b2][lane], lane, W, 4, sh.tab[sh.binQ[b2] & 1]);
+    }
+    const SubGeom sg = sub_geom(borg, b);
+    const SlotBinView bv{bin0 + b, {sg.org[0], sg.org[1], sg.org[2]}, (size_t)(bin0 + b) * (size_t)A.K, kmask,
+                         sh.varena + ArenaBlk::at(sg.o[0], sg.o[1], sg.o[2]), sh.masks[b], sh.clr[qp], sh.arrLocal[qp], sh.nbrBin[qp],
+                         &sh.cnt[qp][0], &sh.cnt[qp][1], &sh.cnt[qp][2], &sh.cnt[qp][3]};
+    // the ring slot this wave stages into was last read by the consumers of chunk g - 1 (its groups 0..2, or the straddle group of
+    // chunk g - 2, consumed with chunk g - 1): all four consumer waves have counted that chunk done
+    auto ringFree = [&] {
+      while (__hip_atomic_load(sh.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)g) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    bool valid = false;
+    if (has0)
+      valid = slot_produce_entry<8, SMODEL, WRITE_ALL, ArenaBlk>(mp, ps, cur, code0, i0, lane, (unsigned)(slot * 64 + lane), myStage + lane, bv, A,
+                                                                 sh.arrCnt[par], sh.arrQ[par], &sh.xCnt[par], sh.xq[par], ringFree);
+    ringFree();
+    {
+      const unsigned long long vm = __ballot(valid);
+      if (lane == 0) sh.smask[slot] = vm;
+    }
+    __syncthreads();  // chunk g is staged
+  }
+  __syncthreads();  // the consumers have accumulated the last chunk and flushed the last bin
+  if (W == 0) blk_finish_bin(sh, A, bin0, sh.chBin[G - 1], lane);
+}
+
+// consumer wave of channel set CS: lane = cell of the current bin; chunk g is consumed while the producers work on chunk g + 1
+template <int CS>
+__device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)[3], int blk, int lane, int G, const BlkShared &sh, const SlotArgs &A) {
+  using S = ConsumerSet<CS>;
+  using AL = ArenaLds;
+  constexpr int NC = 512;
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const unsigned long long lt = lanemask_lt();
+  const float *const stage = sh.stage;
+  float acc[27][S::NA];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
+  unsigned mask = 0u;
+  int r = 0, off = 0;  // next round to consume, entry number of its first particle
+  for (int g = 0; g < G; ++g) {
+    __syncthreads();  // chunk g is staged
+    const int b = sh.chBin[g], c = sh.chIdx[g], total = sh.total[b], par = g % 3;
+    const int gb = 4 * sh.gbase[b];  // ring group number of the bin's entry 0
+    if (c == 0) {
+      r = 0;
+      off = 0;
+      mask = sh.masks[b][lane];
+    }
+    const int produced = 256 * (c + 1) < total ? 256 * (c + 1) : total;
+    const unsigned qn = sh.arrCnt[par][lane];
+    const int na = qn < (unsigned)SL_ARRQ ? (int)qn : SL_ARRQ;
+    int ai = 0;
+    if (CS == 0) sh.arrCnt[(g + 2) % 3][lane] = 0u;  // the counters chunk g + 2 will use (last read with chunk g - 1, which every consumer has left)
+#pragma unroll 1
+    for (;;) {
+      bool roundOk = false, has = false;
+      unsigned long long occ = 0ull;
+      int cnt = 0;
+      if (off < total) {
+        has = (mask >> r) & 1u;
+        occ = __ballot(has);
+        cnt = __popcll(occ);
+        roundOk = off + cnt <= produced;  // else: the round's last entries belong to the chunk in production
+      }
+      const bool pend = ai < na;
+      if (!roundOk && __ballot(pend) == 0ull) break;
+      int spos = -1;
+      if (roundOk) {
+        if (has) {
+          const int e = off + __popcll(occ & lt);
+          const int slot = (gb + (e >> 6)) % SB_NG, pos = e & 63;
+          if ((sh.smask[slot] >> pos) & 1ull) spos = slot * (G2P2G_QF * 64) + pos;
+        }
+        off += cnt;
+        ++r;
+      }
+      if (spos < 0 && pend) {  // a lane without a particle of its own in this round takes an arrival
+        const unsigned p = sh.arrQ[par][lane][ai++];
+        spos = (int)(p >> 6) * (G2P2G_QF * 64) + (int)(p & 63u);
+      }
+      if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, acc);
+    }
+    {
+      const int nx = sh.xCnt[par] < (unsigned)SL_XQ ? (int)sh.xCnt[par] : SL_XQ;
+      if (CS == 0 && lane == 0) sh.xCnt[(g + 2) % 3] = 0u;
+      const SubGeom sg = sub_geom(borg, b);
+      slot_xlist_scatter<8, CS>(mp, sg, stage, sh.xq[par], nx, lane, sh.nbrBlk, A);
+    }
+    // this wave has read what it needs of chunk g: the producers may stage chunk g + 1 over it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(sh.done, 1u);
+    if (c == sh.nch[b] - 1) {
+      // last chunk of the bin: the set's channels of the bin's arena belong to this wave alone -- clear, add the 27 register planes
+      // (phases ordered inside the wave), send the arena's nodes to the grid; no other wave is involved
+      float *const pa = sh.parena + (size_t)S::CH0 * AL::CH;
+      for (int k = lane; k < S::NA * AL::CH; k += 64) pa[k] = 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      float *a0 = pa + AL::at(cx, cy, cz);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        float *gp = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+        for (int q = 0; q < S::NA; ++q) {
+          gp[q * AL::CH] += acc[k][q];
+          acc[k][q] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      const SubGeom sg = sub_geom(borg, b);
+      for (int n = lane; n < 216; n += 64) {
+        const int x = n / 36, y = (n / 6) % 6, z = n % 6;
+        int slot, cell;
+        arena_to_grid<8>(sg.o, x, y, z, slot, cell);
+        const int bn = sh.nbr8[slot];
+        const float *a = pa + AL::at(x, y, z);
+        if (bn >= 0) {
+          float *gq = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + cell;
+#pragma unroll
+          for (int q = 0; q < S::NA; ++q) {
+            const float v = a[q * AL::CH];
+            if (v != 0.f) unsafeAtomicAdd(gq + q * NC, v);
+          }
+        } else if (S::MASS && a[0] != 0.f) {
+          A.status[2] = 1;  // mass for a node whose block is not in the partition
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the arena is cleared again for the next bin only after these reads)
+    }
+  }
+  __syncthreads();  // the last bin is flushed
+}
+
+template <int SMODEL, bool WRITE_ALL>
+static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
+  using AL = ArenaLds;
+  constexpr int NC = 512;
+  __shared__ float s_varena[3 * ArenaBlk::CH];
+  __shared__ float s_parena[7 * AL::CH];
+  __shared__ float s_stage[SB_NG * G2P2G_QF * 64];
+  __shared__ unsigned long long s_smask[SB_NG];
+  __shared__ unsigned short s_tab[2][SL_KMAX * 64];
+  __shared__ unsigned s_masks[8][64];
+  __shared__ unsigned s_clr[2][64], s_arrLocal[2][64], s_arrCnt[3][64];
+  __shared__ unsigned short s_arrQ[3][64][SL_ARRQ];
+  __shared__ unsigned s_xCnt[3], s_xq[3][SL_XQ];
+  __shared__ int s_nbrBlk[27], s_nbrBin[2][27], s_nbr8[8];
+  __shared__ int s_cnt[2][4];
+  __shared__ int s_total[8], s_gbase[8], s_nch[8], s_binQ[8], s_oc[8];
+  __shared__ unsigned char s_chBin[SB_MAXCH], s_chIdx[SB_MAXCH];
+  __shared__ unsigned s_done;
+  __shared__ int s_sums[3], s_G;
+  const BlkShared sh{s_varena, s_parena, s_stage, s_smask, s_tab, s_masks, s_clr, s_arrLocal, s_arrCnt, s_arrQ, s_xCnt, s_xq, s_nbrBlk, s_nbrBin, s_nbr8,
+                     s_cnt, s_total, s_gbase, s_nch, s_binQ, s_oc, s_chBin, s_chIdx, &s_done, s_sums};
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int blk = (int)xcd_chunked(blockIdx.x, gridDim.x) + A.binBase / 8;
+  const int bin0 = blk * 8;
+  // occupancy of the block's 8 bins: wave w <-> bin w
+  const unsigned mask = A.cellMask[(size_t)(bin0 + w) * 64 + lane];
+  s_masks[w][lane] = mask;
+  {
+    int n = __popc(mask);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) n += __shfl_xor(n, sft, 64);
+    if (lane == 0) s_total[w] = n;
+  }
+  if (tid < 128) {
+    s_clr[tid >> 6][tid & 63] = 0u;
+    s_arrLocal[tid >> 6][tid & 63] = 0u;
+  }
+  if (tid < 192) s_arrCnt[tid >> 6][tid & 63] = 0u;
+  if (tid < 3) {
+    s_xCnt[tid] = 0u;
+    s_sums[tid] = 0;
+  }
+  if (tid < 8) (&s_cnt[0][0])[tid] = 0;
+  if (tid == 0) s_done = 0u;
+  if (tid >= 64 && tid < 64 + 27) s_nbrBlk[tid - 64] = A.nbr27[(size_t)blk * 27 + (tid - 64)];
+  if (tid >= 96 && tid < 104) s_nbr8[tid - 96] = A.nbr[(size_t)blk * 8 + (tid - 96)];
+  int borg[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) borg[d] = t.activeKeys[3 * (size_t)blk + d] * (8 / mp.kscale);
+  __syncthreads();
+  if (tid == 0) {  // the block's chunk sequence
+    int G = 0, q = 0;
+    for (int b = 0; b < 8; ++b) {
+      const int nch = (s_total[b] + 255) >> 8;
+      s_nch[b] = nch;
+      s_gbase[b] = G;
+      s_binQ[b] = q;
+      s_oc[b] = 0;
+      if (nch) ++q;
+      for (int c = 0; c < nch; ++c) {
+        s_chBin[G] = (unsigned char)b;
+        s_chIdx[G] = (unsigned char)c;
+        ++G;
+      }
+    }
+    s_G = G;
+    // early warning of the closed-loop re-partition: the block holds particles and a block within {-1..2}^3 of it is missing
+    if (G && A.blockEdge && A.blockEdge[blk]) A.status[3] = 1;
+  }
+  // the block's velocity arena: 10^3 nodes of grid A (this block and the 7 blocks at offsets {0,1}^3)
+  for (int n = tid; n < 1000; n += 512) {
+    const int x = n / 100, y = (n / 10) % 10, z = n % 10;
+    const int slot = ((x >= 8) << 2) | ((y >= 8) << 1) | (z >= 8);
+    const int cell = ((x & 7) * 8 + (y & 7)) * 8 + (z & 7);
+    const int bn = s_nbr8[slot];
+    float *a = s_varena + ArenaBlk::at(x, y, z);
+    const float *g = A.gridA + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) a[ch * ArenaBlk::CH] = bn >= 0 ? g[ch * NC] : 0.f;
+  }
+  __syncthreads();
+  const int G = s_G;
+  if (tid < 8 && s_total[tid] == 0) A.moverCount[bin0 + tid] = 0;
+  if (G == 0) return;
+  {  // entry tables and neighbour bins of the bins of chunks 0 and 1 (all eight waves; later ones: the producers, two chunks ahead)
+    const int b0 = s_chBin[0];
+    blk_build_tab(s_masks[b0][lane], lane, w, 8, s_tab[s_binQ[b0] & 1]);
+    if (tid < 27) s_nbrBin[s_binQ[b0] & 1][tid] = blk_neighbour_bin(s_nbrBlk, blk, b0, tid);
+    if (G > 1 && s_chIdx[1] == 0) {
+      const int b1 = s_chBin[1];
+      blk_build_tab(s_masks[b1][lane], lane, w, 8, s_tab[s_binQ[b1] & 1]);
+      if (tid >= 64 && tid < 64 + 27) s_nbrBin[s_binQ[b1] & 1][tid - 64] = blk_neighbour_bin(s_nbrBlk, blk, b1, tid - 64);
+    }
+  }
+  __syncthreads();
+  if (w == 0) blk_producer<SMODEL, WRITE_ALL, 0>(mp, ps, borg, blk, lane, G, sh, A);
+  else if (w == 1) blk_producer<SMODEL, WRITE_ALL, 1>(mp, ps, borg, blk, lane, G, sh, A);
+  else if (w == 2) blk_producer<SMODEL, WRITE_ALL, 2>(mp, ps, borg, blk, lane, G, sh, A);
+  else if (w == 3) blk_producer<SMODEL, WRITE_ALL, 3>(mp, ps, borg, blk, lane, G, sh, A);
+  else {
+    if (w == 4) blk_consumer<0>(mp, borg, blk, lane, G, sh, A);
+    else if (w == 5) blk_consumer<1>(mp, borg, blk, lane, G, sh, A);
+    else if (w == 6) blk_consumer<2>(mp, borg, blk, lane, G, sh, A);
+    else blk_consumer<3>(mp, borg, blk, lane, G, sh, A);
+  }
+  __syncthreads();  // the last bin is finished (blk_finish_bin by producer wave 0)
+  if (tid == 0) {
+    // movers sent / re-homed: running sums spread over SL_NCTR words (one device-wide word serves ~90 atomics per microsecond)
+    if (s_sums[0]) atomicAdd(&A.status[SL_SENT + (blk & (SL_NCTR - 1))], s_sums[0]);
+    if (s_sums[1]) atomicAdd(&A.status[SL_DELIVERED + (blk & (SL_NCTR - 1))], s_sums[1]);
+  }
+  if (s_sums[2]) {  // (rare) a chunk had more than SL_XQ movers for the consumers' list: the flagged records of those bins -> grid, all eight waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have reached L2 ...
+    __syncthreads();                                    // ... and so have everybody else's
+    constexpr int RB = SB_NG * G2P2G_QF * 64 / SL_REC;  // records per batch: the staging ring is free now
+    for (int b = 0; b < 8; ++b) {
+      if (!((s_sums[2] >> b) & 1)) continue;
+      const SubGeom sg = sub_geom(borg, b);
+      const int oc = s_oc[b];
+      for (int j0 = 0; j0 < oc; j0 += RB) {
+        const int nb = oc - j0 < RB ? oc - j0 : RB;
+        const float *src = A.moverRec + ((size_t)(bin0 + b) * A.cap + (size_t)j0) * SL_REC;
+        // agent-scope loads: served by L2, where the stores are (never by an L1 line of this CU)
+        for (int k = tid; k < nb * SL_REC; k += 512) s_stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        outbox_scatter_global<8>(mp, sg, s_stage, nb, w, lane, s_nbrBlk, A.gridB, A.status);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+template <int M, bool WA> static void launch_blk(hipStream_t stream, unsigned nblk, const MpmDev &mp, const ParticlesDev &pd, const BhtDev &t, const SlotArgs &A) {
+  hipLaunchKernelGGL((g2p2g_slotblk_kernel<M, WA>), dim3(nblk), dim3(512), 0, stream, mp, pd, t, A);
+}
+
+// launched by zs_rocm_mpm_g2p2g_slots (mpm_slotted.hip) for 8^3 blocks: blocks [A.binBase / 8, + A.nbins / 8)
+void launch_g2p2g_slotblk(hipStream_t stream, int model, bool writeAll, const MpmDev &mp, const ParticlesDev &pd, const BhtDev &t, const SlotArgs &A) {
+  const unsigned nblk = (unsigned)(A.nbins / 8);
+  if (!nblk) return;
+#define ZSR_BLK(M)                                        \
+  case M:                                                 \
+    if (writeAll) launch_blk<M, true>(stream, nblk, mp, pd, t, A); \
+    else launch_blk<M, false>(stream, nblk, mp, pd, t, A);         \
+    break;
+  switch (model) {
+#ifdef ZS_SLOT_FAST_BUILD
+    default: launch_blk<ZS_MPM_DRUCKER_PRAGER, false>(stream, nblk, mp, pd, t, A); break;
+#else
+    ZSR_BLK(ZS_MPM_FIXED_COROTATED)
+    ZSR_BLK(ZS_MPM_DRUCKER_PRAGER)
+    ZSR_BLK(ZS_MPM_VONMISES_FIXED_COROTATED)
+    ZSR_BLK(ZS_MPM_NACC)
+    ZSR_BLK(ZS_MPM_EQUATION_OF_STATE)
+#endif
+  }
+#undef ZSR_BLK
+}
+
+}  // namespace zsr
