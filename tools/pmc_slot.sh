@@ -7,7 +7,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$R/gpurun_out/pmc_$tag/$name
   mkdir -p $out
-  timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot_kernel|mover_pull_kernel" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-at-rest > $out/bench.json 2> $out/stderr.txt
+  timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-at-rest > $out/bench.json 2> $out/stderr.txt
   f=$(find $out -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -59,13 +59,11 @@ struct BlkShared {
 
 // entry table of one bin: round-major enumeration of its occupied slots; wave w of nw writes the rows of rounds = w mod nw
 __device__ __forceinline__ void blk_build_tab(unsigned mask, int lane, int w, int nw, unsigned short *tab) {
-  unsigned any = mask;
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) any |= (unsigned)__shfl_xor((int)any, sft, 64);
-  const int nrounds = any ? 32 - __clz((int)any) : 0;
   const unsigned long long lt = lanemask_lt();
   int total = 0;
-  for (int r = 0; r < nrounds; ++r) {
+#pragma unroll 1
+  for (int r = 0; r < SL_KMAX; ++r) {  // (ballots only: no cross-lane data movement, nothing that waits for the record loads in flight)
+    if (__ballot((mask >> r) != 0u) == 0ull) break;
     const bool has = (mask >> r) & 1u;
     const unsigned long long occ = __ballot(has);
     if ((r % nw) == w && has) tab[total + __popcll(occ & lt)] = (unsigned short)(r * 64 + lane);
@@ -115,6 +113,9 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
   constexpr bool FLUID = model_is_fluid(SMODEL);
   const int bin0 = blk * 8;
   const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
+#ifdef ZS_BLK_PRIO
+  __builtin_amdgcn_s_setprio(ZS_BLK_PRIO);
+#endif
   RecG<LW, DP, FLUID> cur, nxt;
   bool has0 = false, has1 = false;
   size_t i0 = 0, i1 = 0;
@@ -129,7 +130,12 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
       nxt.load(ps, i1);
     }
   }
+  __syncthreads();  // every producer has read the first bin's entry table (iteration 0 may rebuild that buffer for the bin of chunk 2)
+#ifdef ZS_SLOT_PROBE
+  unsigned long long tWork = 0, tBar = 0, tRing = 0;
+#endif
   for (int g = 0; g < G; ++g) {
+    SLP_T0(tIt);
     const int b = sh.chBin[g];
     const int qp = sh.binQ[b] & 1;
     const int grp = 4 * g + W, slot = grp % SB_NG, par = g % 3;
@@ -173,14 +179,27 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
     if (has0)
       valid = slot_produce_entry<8, SMODEL, WRITE_ALL, ArenaBlk>(mp, ps, cur, code0, i0, lane, (unsigned)(slot * 64 + lane), myStage + lane, bv, A,
                                                                  sh.arrCnt[par], sh.arrQ[par], &sh.xCnt[par], sh.xq[par], ringFree);
+    SLP_T0(tR);
     ringFree();
+    SLP_ACC(tRing, tR);
     {
       const unsigned long long vm = __ballot(valid);
       if (lane == 0) sh.smask[slot] = vm;
     }
+    SLP_ACC(tWork, tIt);
+    SLP_T0(tB);
     __syncthreads();  // chunk g is staged
+    SLP_ACC(tBar, tB);
   }
+  SLP_T0(tF);
   __syncthreads();  // the consumers have accumulated the last chunk and flushed the last bin
+  if (W == 0) {
+    SLP_ADD(6, tF);
+    SLP_PUT(3, tWork);
+    SLP_PUT(4, tBar);
+    SLP_PUT(2, tRing);
+    SLP_PUT(5, G);
+  }
   if (W == 0) blk_finish_bin(sh, A, bin0, sh.chBin[G - 1], lane);
 }
 
@@ -200,8 +219,15 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     for (int q = 0; q < S::NA; ++q) acc[k][q] = 0.f;
   unsigned mask = 0u;
   int r = 0, off = 0;  // next round to consume, entry number of its first particle
+  __syncthreads();  // (the producers' first record requests are out)
+#ifdef ZS_SLOT_PROBE
+  unsigned long long tWork = 0, tBar = 0, tFlush = 0;
+#endif
   for (int g = 0; g < G; ++g) {
+    SLP_T0(tB);
     __syncthreads();  // chunk g is staged
+    SLP_ACC(tBar, tB);
+    SLP_T0(tIt);
     const int b = sh.chBin[g], c = sh.chIdx[g], total = sh.total[b], par = g % 3;
     const int gb = 4 * sh.gbase[b];  // ring group number of the bin's entry 0
     if (c == 0) {
@@ -241,7 +267,11 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
         const unsigned p = sh.arrQ[par][lane][ai++];
         spos = (int)(p >> 6) * (G2P2G_QF * 64) + (int)(p & 63u);
       }
+#ifdef ZS_ABL_HALFCONS
+      if (spos >= 0 && (r & 1)) g2p2g_consume_set<CS>(mp, stage, spos, acc);
+#else
       if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, acc);
+#endif
     }
     {
       const int nx = sh.xCnt[par] < (unsigned)SL_XQ ? (int)sh.xCnt[par] : SL_XQ;
@@ -252,6 +282,8 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     // this wave has read what it needs of chunk g: the producers may stage chunk g + 1 over it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicAdd(sh.done, 1u);
+    SLP_ACC(tWork, tIt);
+    SLP_T0(tFl);
     if (c == sh.nch[b] - 1) {
       // last chunk of the bin: the set's channels of the bin's arena belong to this wave alone -- clear, add the 27 register planes
       // (phases ordered inside the wave), send the arena's nodes to the grid; no other wave is involved
@@ -289,8 +321,16 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the arena is cleared again for the next bin only after these reads)
     }
+    SLP_ACC(tFlush, tFl);
   }
+  SLP_T0(tE);
   __syncthreads();  // the last bin is flushed
+  if (CS == 0) {
+    SLP_PUT(7, tWork);
+    SLP_PUT(8, tBar);
+    SLP_PUT(9, tFlush);
+    SLP_ADD(10, tE);
+  }
 }
 
 template <int SMODEL, bool WRITE_ALL>
@@ -317,6 +357,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int blk = (int)xcd_chunked(blockIdx.x, gridDim.x) + A.binBase / 8;
   const int bin0 = blk * 8;
+  SLP_T0(tStart);
   // occupancy of the block's 8 bins: wave w <-> bin w
   const unsigned mask = A.cellMask[(size_t)(bin0 + w) * 64 + lane];
   s_masks[w][lane] = mask;
@@ -388,6 +429,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
     }
   }
   __syncthreads();
+  if (w == 0) SLP_ADD(1, tStart);
   if (w == 0) blk_producer<SMODEL, WRITE_ALL, 0>(mp, ps, borg, blk, lane, G, sh, A);
   else if (w == 1) blk_producer<SMODEL, WRITE_ALL, 1>(mp, ps, borg, blk, lane, G, sh, A);
   else if (w == 2) blk_producer<SMODEL, WRITE_ALL, 2>(mp, ps, borg, blk, lane, G, sh, A);
@@ -399,6 +441,10 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
     else blk_consumer<3>(mp, borg, blk, lane, G, sh, A);
   }
   __syncthreads();  // the last bin is finished (blk_finish_bin by producer wave 0)
+  if (w == 0) {
+    SLP_ADD(0, tStart);
+    SLP_PUT(11, 1);
+  }
   if (tid == 0) {
     // movers sent / re-homed: running sums spread over SL_NCTR words (one device-wide word serves ~90 atomics per microsecond)
     if (s_sums[0]) atomicAdd(&A.status[SL_SENT + (blk & (SL_NCTR - 1))], s_sums[0]);
@@ -453,3 +499,14 @@ void launch_g2p2g_slotblk(hipStream_t stream, int model, bool writeAll, const Mp
 }
 
 }  // namespace zsr
+
+#if defined(ZS_SLOT_PROBE) && defined(ZS_SLOT_PROBE_BLK)  // measurement-only build: read (and clear) the phase stamps of g2p2g_slotblk_kernel
+extern "C" void zs_rocm_slot_probe(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_slot_probe), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(zsr::g_slot_probe), z, sizeof(z));
+  }
+}
+#endif

@@ -336,7 +336,7 @@ using namespace zsr;
 
 extern "C" {
 
-#ifdef ZS_SLOT_PROBE  // measurement-only build: read (and clear) the phase stamps of g2p2g_slot_kernel
+#if defined(ZS_SLOT_PROBE) && !defined(ZS_SLOT_PROBE_BLK)  // measurement-only build: read (and clear) the phase stamps of g2p2g_slot_kernel
 void zs_rocm_slot_probe(unsigned long long *out16, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_slot_probe), sizeof(unsigned long long) * 16);
