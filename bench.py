@@ -231,6 +231,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if a.same_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        # fail fast and loudly: a rank without a GPU of its own would share device 0 and RCCL would hang or refuse later
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) are visible -- run --gpus N on a node with N GPUs (or --same-device for validation)"
+                         % (int(os.environ.get("RANK", "0")), local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -270,6 +274,12 @@ def main():
             comm = NativeComm(rank, world, local_rank, dist)
         except RuntimeError as e:  # (ncclCommInitRank is collective: it fails on every rank or on none)
             print("[bench] native RCCL communicator unavailable (%s): exchange steps go through torch.distributed" % e, file=sys.stderr)
+        if comm is not None:
+            cc = lib().zs_rocm_dist_comm_count(comm._h)
+            if cc != world:
+                raise SystemExit("rank %d: RCCL reports ncclCommCount = %d for --gpus %d" % (rank, cc, world))
+            if rank == 0:
+                print("[bench] RCCL communicator: ncclCommCount = %d, %d GPU(s) visible" % (cc, torch.cuda.device_count()), file=sys.stderr)
     max_vel = torch.zeros(1, dtype=torch.float32, device=device)
     aos = generate_particles(lo, hi, dx, 1234, device, model)
     drift_v = [float(x) for x in a.drift.split(",")]
@@ -453,8 +463,9 @@ def main():
             g2p_ev.append((e2, e3))
 
     fused_ev = []
-    from zpc_amd.mpm import HipEvents
+    from zpc_amd.mpm import HipEvents, StepBreakdown
     hip_events = HipEvents()
+    breakdown = StepBreakdown() if (world > 1 or proxy) else None   # where a rank's step time goes (events inside zs_rocm_mpm_step_slotted)
 
     ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
 
@@ -471,7 +482,8 @@ def main():
             mt.step_slotted((0.0, -9.8, 0.0), None if a.no_cfl else max_vel, write_all=write_all,
                             n_boundary=n_boundary if (overlap and halo is not None) else 0, comm=comm, plan=halo if comm is not None else None,
                             comm_pol=pol_comm if overlap else None, collider=floor, halo_grid=proxy_grid,
-                            events=hip_events.pair() if timed else None)
+                            events=hip_events.pair() if timed else None,
+                            breakdown=breakdown.next() if (timed and breakdown is not None) else None)
             return
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
@@ -710,8 +722,23 @@ def main():
         nt = torch.tensor([n_local], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(nt)
         n_total = int(nt.item())
+    rank_breakdown = None
+    if breakdown is not None and breakdown.steps:
+        bs = breakdown.summary()
+        names = [k for k, _, _ in StepBreakdown.STRETCHES]
+        vals = torch.tensor([bs[k] if bs[k] is not None else 0.0 for k in names], dtype=torch.float64, device=comm_dev)
+        vmax, vsum = vals.clone(), vals.clone()
+        if dist is not None:
+            dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(vsum)
+        rank_breakdown = {"max_over_ranks": {k: float(vmax[i]) for i, k in enumerate(names)},
+                          "mean_over_ranks": {k: float(vsum[i]) / max(world, 1) for i, k in enumerate(names)},
+                          "note": "HIP events recorded inside zs_rocm_mpm_step_slotted (zs_rocm_mpm_step.evBreakdown), mean over the timed steps: "
+                                  "boundary range | interior range + re-home + commit | main stream waiting for the exchange | grid update | CFL "
+                                  "allreduce(max); exchange_side_stream_ms = pack + grouped ncclSend/ncclRecv + unpack-add on the side stream "
+                                  "(overlaps the interior range)"}
     slot_stats = None
-    if a.slotted and a.slot_stats:
+    if a.slotted:
         # occupancy of the slotted storage at the end of the run: rounds a bin's producers walk (highest occupied round + 1, in chunks of
         # four) against the particles it holds
         m = mt.cell_mask.view(mt.nbins, 64).to(torch.int64) & 0xFFFFFFFF
@@ -749,11 +776,23 @@ def main():
         thr2 = 64.0 * float(c2.sum()) / max(9 * n_local, 1)
         keep = valid & ~((c2 > thr2).any(dim=1, keepdim=True))
         cs_trim = torch.cat([(v * keep).sum(dim=(0, 2)), ((v * keep) ** 2).sum(dim=(0, 2)), (valid & ~keep).sum().double().view(1)]).to(comm_dev)
+        # where the trimmed particles are: the highest one (cells above the column's foot) and how many of them sit on the column's
+        # side faces (the two edge particles every run trims)
+        trimmed = (valid & ~keep)
+        ty = torch.where(trimmed[:, 0, :], v[:, 2, :] / dx - glo[1], torch.full_like(v[:, 2, :], -1.0))
+        cx, cz = v[:, 1, :] / dx, v[:, 3, :] / dx
+        on_side = trimmed[:, 0, :] & ((cx < glo[0] + 1.5) | (cx > ghi[0] - 1.5) | (cz < glo[2] + 1.5) | (cz > ghi[2] - 1.5))
+        tinfo = torch.stack([ty.max(), on_side.sum().double()]).to(comm_dev)
         if dist is not None:
             dist.all_reduce(cs)
             dist.all_reduce(cs_trim)
+            tmax = tinfo[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tinfo)
+            tinfo[0] = tmax[0]
         checksum = [float(x) for x in cs.cpu()]
         checksum_trim = [float(x) for x in cs_trim.cpu()]
+        trim_info = [float(x) for x in tinfo.cpu()]
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
@@ -826,10 +865,12 @@ def main():
             fmin = (56.0 + 52.0 if model == 1 else 52.0 + 48.0) + 1.5 + 7.0
             fach = fb * n_local / (fused_ms * 1e-3) / 1e9
             ftraffic = None
-            # PMC traffic of the kernels this run used: slotted storage under motion (pmc_g2p2g.json, tools/refresh_r02.sh) or the
+            # PMC traffic of the kernels this run used: slotted storage under motion (pmc_g2p2g.json, tools/refresh_r05.sh) or the
             # compact-storage kernel at rest (pmc_g2p2g_compact.json); no figure was collected for the other combinations
             moving = any(abs(x) > 0 for x in drift_v)
-            fkernel = "g2p2g_slot_kernel + slot_rehome_kernel + slot_commit_kernel" if a.slotted else "g2p2g_rs_kernel"
+            per_bin = a.side != 8 or (os.environ.get("ZS_ROCM_SLOT_PERBIN", "0") not in ("", "0"))
+            fkernel = (("g2p2g_slot_kernel" if per_bin else "g2p2g_slotblk_kernel") + " + slot_rehome_kernel + slot_commit_kernel") if a.slotted else "g2p2g_rs_kernel"
+            fvalu = None
             pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json" if (a.slotted and moving) else "pmc_g2p2g_compact.json")
             if os.path.exists(pmcf) and (a.slotted == moving):
                 try:
@@ -837,6 +878,15 @@ def main():
                     if (j.get("particles") == n_local and j.get("side") == a.side and j.get("model") == a.model and j.get("kernel") == fkernel
                             and _same_code(j)):
                         ftraffic = j.get("hbm_bytes_per_launch")   # (a figure collected for another kernel generation is not this run's traffic)
+                        if j.get("valu_insts_per_launch"):
+                            # the other roofline: VALU issue.  insts = SQ_INSTS_VALU of the step's kernels; busy = SQ_ACTIVE_INST_VALU x 4 /
+                            # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); algorithmic = the same kernels' SQ_INSTS_VALU on the column at rest
+                            # (no movers, every cell 8 particles: what the arithmetic of G2P + model + P2G costs with this kernel body)
+                            fvalu = {"insts_per_launch": j["valu_insts_per_launch"], "busy_frac": j.get("valu_busy_frac"),
+                                     "algorithmic_insts": j.get("valu_insts_at_rest"),
+                                     "frac": (j["valu_insts_at_rest"] / j["valu_insts_per_launch"]) if j.get("valu_insts_at_rest") else None,
+                                     "ns_per_inst_per_simd": fused_ms * 1e6 * 1024 / j["valu_insts_per_launch"],
+                                     "source": j.get("source")}
                 except Exception:
                     pass
             out["config"]["workload"] = out["config"]["workload"].replace("step = grid reset + P2G + grid update + G2P",
@@ -849,6 +899,13 @@ def main():
                                        "(traffic < algorithmic bytes) and is bound by instruction issue and the waves' own chains, not by HBM "
                                        "(profiles/r03_pmc_g2p2g.md, r03_slot_probe.md); "
                                        "launch_ms = HIP-event time of the fused launches of one step (slotted: main kernel + re-home + commit kernels)"}
+            out["roofline"]["hbm_frac"] = fach / HBM_PEAK_GBS
+            if fvalu is not None:
+                out["roofline"]["valu"] = fvalu
+                # the binding roofline is the one the kernel sits closer to: fraction of the HBM peak its algorithmic bytes reach, against
+                # the fraction of its issued VALU instructions that are algorithmic (both "useful work / what the unit was asked to do")
+                if fvalu.get("busy_frac") and fvalu["busy_frac"] > fach / HBM_PEAK_GBS:
+                    out["roofline"]["bound"] = "valu"
         # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
         # bytes over HIP-event time, after the timed region)
         try:
@@ -885,9 +942,15 @@ def main():
             pass
         if checksum is not None:
             out["checksum"] = checksum
-            out["checksum_trimmed"] = {"sums": checksum_trim[:-1], "trimmed_particles": int(checksum_trim[-1])}
+            out["checksum_trimmed"] = {"sums": checksum_trim[:-1], "trimmed_particles": int(checksum_trim[-1]),
+                                       "trimmed_max_y_cells": trim_info[0], "trimmed_edge_particles": int(trim_info[1])}
         if slot_stats is not None:
             out["slot_stats"] = slot_stats
+        if rank_breakdown is not None:
+            out["rank_breakdown"] = rank_breakdown
+        if comm is not None:
+            out["config"]["nccl_comm_count"] = int(lib().zs_rocm_dist_comm_count(comm._h))
+            out["config"]["gpus_visible"] = torch.cuda.device_count()
         if world == 1 and a.slotted and not a.no_at_rest and any(abs(x) > 0 for x in drift_v):
             # secondary numbers: the same column at rest (no movers) -- short sub-runs of this script after the timed region
             import subprocess
@@ -917,6 +980,32 @@ def main():
                 out["secondary"]["unfused_at_rest"] = {"ms_per_step": j3["ms_per_step"], "p2g_ms": r3["launch_ms"], "p2g_frac": r3["frac"],
                                                        "g2p_ms": r3["g2p"]["launch_ms"],
                                                        "g2p_frac": r3["g2p"]["achieved"] / HBM_PEAK_GBS}
+                # what the 0.5x of the stand-alone P2G does and does not contain: (a) the reference-order P2G, constitutive update inside
+                # (--no-cache-stress); (b) the unfused step P2G + G2P as a whole, which is where the moved SVD is paid
+                j4 = sub(["--compact", "--unfused", "--no-cache-stress"])
+                r4 = j4["roofline"]
+                step_bytes = (r3["bytes_per_particle"] + r3["g2p"]["bytes_per_particle"]) * r3["particles_per_launch"]
+                out["p2g_standalone"].update({
+                    "reference_order_frac": r4["frac"], "reference_order_ms": r4["launch_ms"],
+                    "unfused_step_frac": step_bytes / ((r3["launch_ms"] + r3["g2p"]["launch_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "unfused_step_ms": r3["launch_ms"] + r3["g2p"]["launch_ms"],
+                    "frac_of_measured_read": (r3["achieved"] / out["roofline"]["measured_read"]) if out["roofline"].get("measured_read") else None,
+                    "note": "HIP-event time of the P2G launch alone (grid reset and update outside), column at rest, compact binned storage. "
+                            "frac: cached stress -- the constitutive update (SVD + return mapping) runs in the tail of the previous G2P, so this is "
+                            "P2G without its ALU (107 B/particle: SURVEY 8(d)); reference_order_frac: the same launch with the update inside, as "
+                            "P2G.hpp orders it; unfused_step_frac: P2G + G2P launches together (where the moved update is paid); "
+                            "frac_of_measured_read: against this box's read-only stream rate instead of the nominal 8 TB/s"})
+                # the headline over a long window: steps 100-200 of a 200-step run (fresh storage flatters the first steps)
+                js = sub(["--drift", ",".join(str(x) for x in drift_v), "--steps", "100", "--warmup", "100"])
+                out["secondary"]["sustained"] = {"ms_per_step": js["ms_per_step"], "roofline_frac": js["roofline"]["frac"], "steps": "100-200 of a 200-step run",
+                                                 "repartitions": js["config"].get("repartitions"),
+                                                 "mean_rounds": (js.get("slot_stats") or {}).get("mean_rounds")}
+                # BASELINE config 3: MLS-MPM elastic jello, 8 M particles, 256^3 sparse grid
+                jc = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-at-rest", "--no-cpu-baseline", "--cells", "100,100,100", "--model", "jello",
+                                     "--grid", "256"], capture_output=True, text=True, timeout=600)
+                jc = json.loads([l for l in jc.stdout.splitlines() if l.startswith("{")][-1])
+                out["secondary"]["config3_jello_8M"] = {"ms_per_step": jc["ms_per_step"], "value": jc["value"], "roofline_frac": jc["roofline"]["frac"],
+                                                        "workload": jc["config"]["workload"].split(";")[0]}
             except Exception as e:
                 out["config"]["at_rest_ms_per_step"] = None
                 print("at-rest runs failed: %r" % (e,), file=sys.stderr)

@@ -453,7 +453,8 @@ ZS_ROCM_EXPORT void zs_rocm_lbvh_query_fill(zs_rocm_policy *, const zs_rocm_lbvh
  * pair of overlapping primitives appears exactly once.  fill: pairs[2*(offsets[k]+c)] = {primitive of leaf k, other primitive}.
  * The count pass remembers the first 32 hits of every leaf inside the LBvh object (132 B per leaf: 1.3 GB for 10 M leaves, allocated on
  * the first self query); a fill pass on the unchanged tree copies them instead of walking again (the memory is released with the
- * object, invalidated by build / refit).  `pairs` must be 8-byte aligned (any hipMalloc'ed array is).  r04: one walk per WAVE over the
+ * object, invalidated by build / refit).  `pairs` must be 8-byte aligned (any hipMalloc'ed array is).  `offsets` may be any per-leaf start
+ * (the exclusive scan of `counts` is the fast case: a wave then writes its leaves' runs as one contiguous stream).  r04: one walk per WAVE over the
  * union of its 64 leaves' walks; every leaf still reports the same ids in the same order. */
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_count(zs_rocm_policy *, const zs_rocm_lbvh *, int *counts /* [numLeaves] */);
 ZS_ROCM_EXPORT void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *, const zs_rocm_lbvh *, const int *offsets, int *pairs);
@@ -724,6 +725,9 @@ ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_reorder_range(zs_rocm_policy *, const zs_ro
                                                    const unsigned *cellCount, const int *nbr, int writeAll, size_t blockBegin,
                                                    size_t blockEnd, int *driftFlag);
 ZS_ROCM_EXPORT void zs_rocm_mpm_update_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles);
+/* channels the library expects behind zs_rocm_particles.stress (6 since r04; 9 before): a caller that allocates the attribute checks this
+ * once -- a 9-channel attribute handed to a 6-channel library would be misread silently */
+ZS_ROCM_EXPORT int zs_rocm_mpm_stress_channels(void);
 /* per-particle constitutive update alone (physics/ConstitutiveModel_Vol_dP.hpp:10-47,246-326):
  * PF[9n] AoS out; F (and logJp) updated in place for plastic models.  Test/diagnostic entry point. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_stress(zs_rocm_policy *, const zs_rocm_mpm_params *, float *F, float *logJp, size_t n, float *PF);
@@ -756,6 +760,8 @@ ZS_ROCM_EXPORT zs_rocm_dist *zs_rocm_dist_create(int rank, int world, const void
 ZS_ROCM_EXPORT void zs_rocm_dist_destroy(zs_rocm_dist *);
 ZS_ROCM_EXPORT int zs_rocm_dist_rank(const zs_rocm_dist *);
 ZS_ROCM_EXPORT int zs_rocm_dist_world(const zs_rocm_dist *);
+/* ncclCommCount of the communicator (-1: no communicator): zs_rocm_dist_create already fails when it differs from `world` */
+ZS_ROCM_EXPORT int zs_rocm_dist_comm_count(const zs_rocm_dist *);
 ZS_ROCM_EXPORT int zs_rocm_dist_halo_exchange(zs_rocm_dist *, zs_rocm_policy *, float *grid, int side, int chn0, int nchn, const int *blocks,
                                               size_t totalBlocks, int npeers, const int *peerRank, const size_t *peerOffset,
                                               const size_t *peerCount, float *sendbuf, float *recvbuf);
@@ -809,7 +815,15 @@ typedef struct zs_rocm_mpm_step {
   zs_rocm_policy *commPolicy;
   float *haloGrid;
   void *evTransferBegin, *evTransferEnd; /* hipEvent_t or NULL: recorded on the policy's stream around the transfer kernels (timing) */
+  void **evBreakdown;                    /* NULL, or ZS_ROCM_STEP_EVENTS hipEvent_t (timing enabled, created on the policy's device) recorded along
+                                            the step -- on the policy's stream: [0] start, [1] boundary range done, [2] interior range + re-home +
+                                            commit done, [5] exchange waited for, [6] grid update done, [7] CFL allreduce done; on commPolicy's
+                                            stream: [3] exchange started, [4] exchange done (without overlap [3], [4] are recorded on the policy's
+                                            stream around the exchange and [1] == [0]).  A rank's step time splits into
+                                            boundary [0,1], interior [1,2], waiting for the exchange [2,5], grid update [5,6], allreduce [6,7];
+                                            the exchange itself is [3,4] */
 } zs_rocm_mpm_step;
+#define ZS_ROCM_STEP_EVENTS 8
 ZS_ROCM_EXPORT int zs_rocm_mpm_step_slotted(zs_rocm_policy *, const zs_rocm_mpm_step *);
 
 #ifdef __cplusplus

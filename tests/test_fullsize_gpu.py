@@ -104,7 +104,9 @@ def test_config2_bht_16m_keys(pol, oracle):
     qi, r = q.cpu().numpy(), ret.cpu().numpy()
     size = tab.size()
     lost = ndist - size
-    assert 0 <= lost <= 2 * olost + 16, (lost, olost)
+    print("bht 16 M keys: %d distinct, lost by the sequential oracle %d, lost by the GPU build %d" % (ndist, olost, lost))
+    # the parallel build may lose a few keys more than the sequential one (probe sequences truncated by concurrent winners), never many
+    assert 0 <= lost <= olost + 8, (lost, olost)
     v = tab.view()
     succ = np.empty(1, np.int32)
     C.CDLL("libamdhip64.so").hipMemcpy(succ.ctypes.data_as(C.c_void_p), C.c_void_p(v.success), C.c_size_t(4), 2)
@@ -259,6 +261,27 @@ def test_config4_sand_64m_slotted_24_moving_steps_equal_compact_with_rebins():
     # bound tied to measurements: 11 (slotted) and 76 (compact) particles were trimmed in the r03 runs, of 67 M; a defect that touches more
     # than a couple of hundred particles must not hide behind the filter
     assert ta["trimmed_particles"] <= 200 and tb["trimmed_particles"] <= 200, (ta["trimmed_particles"], tb["trimmed_particles"])
+    _same_state(ta["sums"], tb["sums"], n, 1e-4, 3e-4)
+    m = 1000.0 * (1.0 / 512) ** 3 / 8
+    assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m
+
+
+def test_config4_sand_64m_on_the_floor_two_storages_agree_outside_the_foot_layer():
+    """BASELINE's geometry proper: the column stands ON y = 0 (--lift 0).  There the reference's arena has local positions that round
+    to exactly 1.5 next to the origin; a particle that hits the case is weighted a cell off by the reference and by us alike, and what it
+    leaves behind differs between two runs only in the column's foot layer.  12 moving steps, slotted against compact storage: the
+    trimmed sums agree, few particles are trimmed, and every trimmed particle lies within the lowest three cell layers."""
+    base = ["--steps", "12", "--warmup", "0", "--no-cpu-baseline", "--checksum", "--no-at-rest", "--lift", "0"]
+    a = _bench(base)
+    b = _bench(base + ["--compact", "--rebin-check", "2"])
+    n = 67_108_864
+    assert a["config"]["particles"] == n and a["hip_error"] == 0 and b["hip_error"] == 0
+    ta, tb = a["checksum_trimmed"], b["checksum_trimmed"]
+    print("un-lifted column: trimmed", ta["trimmed_particles"], tb["trimmed_particles"], "highest trimmed particle (cells above y = 0)",
+          ta["trimmed_max_y_cells"], tb["trimmed_max_y_cells"])
+    assert ta["trimmed_particles"] <= 200 and tb["trimmed_particles"] <= 200
+    for t in (ta, tb):
+        assert t["trimmed_particles"] == 0 or t["trimmed_max_y_cells"] <= 3.0 or t["trimmed_edge_particles"] == t["trimmed_particles"], t
     _same_state(ta["sums"], tb["sums"], n, 1e-4, 3e-4)
     m = 1000.0 * (1.0 / 512) ** 3 / 8
     assert abs(a["checksum"][0] - n * np.float32(m)) <= 1e-9 * n * m

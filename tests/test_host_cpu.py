@@ -220,6 +220,31 @@ def test_native_halo_plan_matches_the_python_plan():
             assert blocks.shape[0] == off
 
 
+def test_halo_plan_of_the_full_column_on_2x2x2_ranks():
+    """BASELINE config 4's decomposition: the 128 x 512 x 128-cell column at dx = 1/512 on 8 ranks as 2 x 2 x 2.
+    Every rank's partition = the blocks of its particles' base nodes, EnlargeSparsity{0, 2} (simulation/sparsity/SparsityOp.hpp:89-115), plus
+    `margin` blocks of travel room.  The native plan (zs_rocm_halo_plan_from_keys) gives every rank 7 peers; the ghost-block sums of one
+    exchange are 25.6 MB with the reference's partition (margin 0) and 72.5 MB with the one block of travel room the slotted storage
+    runs with (bench.py --margin 1) -- the figures DESIGN 7 quotes."""
+    from zpc_amd.dist import cell_box, halo_plan_from_keys, set_split_dims, split_dims
+    side = 8
+    glo = ((512 - 128) // 2 // side * side, 0, (512 - 128) // 2 // side * side)
+    ghi = (glo[0] + 128, 512, glo[2] + 128)
+    assert tuple(split_dims(8)) == (2, 2, 2)
+
+    def keys(rank, margin):
+        lo, hi = cell_box(rank, 8, glo, ghi, align=side)
+        b0 = [(lo[d] - 1) // side - margin for d in range(3)]          # base nodes of the particles in cells [lo, hi): lo - 1 .. hi - 1
+        b1 = [(hi[d] - 1) // side + 1 + margin for d in range(3)]
+        return np.stack(np.meshgrid(*[np.arange(b0[d], b1[d] + 1) for d in range(3)], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    for margin, mb in ((0, 25.6), (1, 72.5)):
+        allk = [keys(r, margin) for r in range(8)]
+        for r in range(8):
+            peers, blocks = halo_plan_from_keys(allk, r)
+            assert len(peers) == 7 and sorted(p for p, _, _ in peers) == [q for q in range(8) if q != r]
+            assert abs(blocks.shape[0] * 7 * side ** 3 * 4 / 1e6 - mb) < 0.1, (margin, r, blocks.shape[0])
+
+
 def test_small_input_sort_kernels_use_no_scratch_memory(tmp_path):
     """The three kernels of the small-input radix sort must not use private (scratch) memory in any instantiation: two builds that did
     (a __noinline__ device function; spilled VGPRs) sorted correctly but made a later, unrelated kernel on the same queue return wrong

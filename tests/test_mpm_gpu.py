@@ -783,6 +783,119 @@ def test_slotted_uneven_cells_many_sparse_rounds_vs_oracle(pol, oracle, side):
     assert np.abs(d["F"] - Fo[o]).max() <= 5e-5
 
 
+def _slot_census(mt):
+    """(tags, cells): mass tag and the world cell of every occupied slot of the slotted storage, from the occupancy words and the block keys"""
+    side, K = mt.side, mt.K
+    bpb = (side // 4) ** 3
+    masks = mt.cell_mask.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    keys = mt.active_keys() * (1 if mt.key_is_origin else side)      # block origin in cells
+    buf = mt.buf.view(mt.nbins * K, mt.nchn, 64).cpu().numpy()
+    tags, cells, where = [], [], []
+    for c in np.nonzero(masks)[0]:
+        b, lane = divmod(int(c), 64)
+        blk, sub = divmod(b, bpb)
+        o = np.array([((sub >> 2) & 1) * 4, ((sub >> 1) & 1) * 4, (sub & 1) * 4]) if side == 8 else np.zeros(3, int)
+        cell = keys[blk] + o + np.array([lane >> 4, (lane >> 2) & 3, lane & 3])
+        for r in range(K):
+            if (masks[c] >> r) & 1:
+                row = buf[b * K + r]
+                tags.append(row[0, lane])
+                cells.append(cell)
+                where.append((b, r, lane, row[1:4, lane].copy()))
+    return np.array(tags, np.float32), np.array(cells), where
+
+
+@pytest.mark.parametrize("side", [8, 4])
+def test_slotted_downward_rehome_with_simultaneous_arrivals(pol, oracle, side):
+    """The stayer that holds the top round of a cell re-homes into a lower free round IN THE SAME STEP in which other particles arrive in
+    that cell from a neighbour cell of the bin (both draw tickets of the cell's counter: mpm_slot.hpp, `lowered`).  Construction: a
+    uniform drift of 0.3 cell per step; cell A = cell (1,1,1) of a bin holds leavers (near its +x face) in its low rounds and stayers
+    above them; the cell before it holds particles that cross into A one step later.  After step 1 cell A has holes below its top round,
+    in step 2 the top stayer is lowered while four particles arrive.  Checked: every particle is stored exactly once under the cell of
+    its base node, the occupancy words say so, nobody is lost, and the particle state follows the oracle."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-3
+    v0 = np.array([0.3 * dx / dt, 0.0, 0.0], np.float32)
+    org = np.array([16, 16, 16]) * 1.0                               # a block corner (cells); base node of x is floor(x/dx - 0.5)
+    g = rng(4321 + side)
+
+    def in_cell(cx, lx, k):                                          # k particles with base node (cx, 1, 1) + org, local x in lx
+        p = np.empty((k, 3))
+        p[:, 0] = org[0] + cx + 0.5 + g.uniform(lx[0], lx[1], k)
+        p[:, 1:] = org[1:] + 1 + 0.5 + g.uniform(0.2, 0.8, (k, 2))
+        return p
+    # cell A = (1,1,1): leaver, stayer, leaver, stayer, leaver, stayer (slot_particles hands out rounds in this order)
+    a = np.empty((6, 3))
+    a[0::2] = in_cell(1, (0.80, 0.95), 3)                           # cross into (2,1,1) in step 1
+    a[1::2] = in_cell(1, (0.05, 0.30), 3)                           # still in A after two steps
+    b = in_cell(0, (0.45, 0.65), 4)                                  # cell (0,1,1): in A after step 2, not after step 1
+    filler = np.concatenate([in_cell(cx, (0.1, 0.9), 3) for cx in (2, 3, 4, 5)])   # company, so that the grid around A carries mass
+    pos = (np.concatenate([a, b, filler]) * dx).astype(np.float32)
+    n = pos.shape[0]
+    mass = (1000.0 * dx ** 3 / 8 * (1 + 1e-2 * np.arange(1, n + 1) / n)).astype(np.float32)
+    vel = np.tile(v0, (n, 1)).astype(np.float32)
+    Cm = np.zeros((n, 9), np.float32)
+    F = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    vol = dx ** 3 / 8
+    om = OracleMpm(oracle, 0, dx, dt, side, vol)
+    mt = MpmTransfer(pol, n, dx, dt, model=0, side=side, volume=vol, cache_stress=True)
+    mt.upload(mass, pos, vel, Cm, F)
+    mt.build_partition(64, margin=1)
+    om.adopt_partition(mt.active_keys())
+    om.p2g(mass, pos, vel, Cm, F)
+    mt.rebin()
+    mt.update_stress()
+    mt.clear_grid()
+    mt.p2g()
+    om.grid_update((0.0, 0.0, 0.0))
+    mt.grid_update((0.0, 0.0, 0.0))
+    mt.slot(K=24, outbox_cap=64)
+    cellA = (org + np.array([1, 1, 1])).astype(int)
+    po, vo, Co, Fo = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+    seen_lowering = False
+    for step in range(3):
+        tags0, cells0, where0 = _slot_census(mt)
+        inA0 = {float(t): w[1] for t, c, w in zip(tags0, cells0, where0) if (c == cellA).all()}   # tag -> round, before the step
+        om.g2p(po, vo, Co, Fo)
+        om.grid[:] = 0
+        om.p2g(mass, po, vo, Co, Fo)
+        mt.g2p2g(write_all=(step == 2))
+        pol.syncCtx()
+        st = mt.check_slots()
+        tags, cells, where = _slot_census(mt)
+        # every particle once, under the cell of its base node
+        assert tags.shape[0] == n and len(set(tags.tolist())) == n and set(tags.tolist()) == set(mass.tolist())
+        base = np.floor(np.array([w[3] for w in where]) / dx - 0.5).astype(int)
+        assert np.array_equal(base, cells)
+        o = {float(t): i for i, t in enumerate(mass)}
+        want = np.floor(po[[o[float(t)] for t in tags]] / dx - 0.5).astype(int)
+        assert np.array_equal(cells, want)
+        inA = {float(t): w[1] for t, c, w in zip(tags, cells, where) if (c == cellA).all()}
+        if step == 0:
+            # the three leavers are gone, the stayers sit above the holes they left
+            assert len(inA) == 3 and max(inA.values()) > 2, inA
+        if step == 1:
+            arrivals = [t for t in inA if t not in inA0]
+            stayers = {t: (inA0[t], inA[t]) for t in inA if t in inA0}
+            assert len(arrivals) == 4 and len(stayers) == 3, (inA0, inA)
+            top = max(stayers, key=lambda t: stayers[t][0])
+            seen_lowering = stayers[top][1] != stayers[top][0]                      # the top stayer changed its round in this step ...
+            assert all(stayers[t][0] == stayers[t][1] for t in stayers if t != top)  # ... the others kept theirs
+            assert len(set(inA.values())) == 7                                       # seven particles, seven different rounds
+        ga = mt.grid.cpu().numpy().reshape(om.grid.shape)
+        scale = np.abs(om.grid).max(axis=(0, 2)) + 1e-30
+        scale = np.maximum(scale, 1e-4 * scale[1])   # (F = I: the force channels are rounding noise of a zero stress, measured against the momentum)
+        assert (np.abs(ga - om.grid).max(axis=(0, 2)) <= 3e-4 * scale).all(), (step, np.abs(ga - om.grid).max(axis=(0, 2)) / scale)
+        om.grid_update((0.0, 0.0, 0.0))
+        mt.grid_update((0.0, 0.0, 0.0))
+    assert seen_lowering
+    d = _by_mass(mt.download())
+    oi = _id_order(mass, po)
+    assert np.array_equal(d["m"], mass[oi])
+    assert np.abs(d["x"] - po[oi]).max() <= 2e-6
+    assert np.abs(d["v"] - vo[oi]).max() <= 2e-4 * np.abs(vo).max()
+
+
 @pytest.mark.parametrize("storage", ["unfused", "compact", "slotted"])
 def test_local_position_that_rounds_up_to_one_and_a_half_follows_the_reference(pol, oracle, storage):
     """The reference takes a quadratic arena's weights from localPos - base_node(localPos) although localPos is already relative to the base

@@ -70,7 +70,7 @@ class MpmStep(C.Structure):
                 ("nblocks", C.c_size_t), ("storage", C.c_void_p), ("writeAll", C.c_int), ("extf", C.c_float * 3),
                 ("maxVelSqr", C.c_void_p), ("collider", C.c_void_p), ("nBoundary", C.c_size_t), ("dist", C.c_void_p),
                 ("plan", C.c_void_p), ("commPolicy", C.c_void_p), ("haloGrid", C.c_void_p), ("evTransferBegin", C.c_void_p),
-                ("evTransferEnd", C.c_void_p)]
+                ("evTransferEnd", C.c_void_p), ("evBreakdown", C.POINTER(C.c_void_p))]
 
 
 class MpmParams(C.Structure):
@@ -130,6 +130,8 @@ def _declare(L):
     L.zs_rocm_dist_destroy.argtypes = [vp]
     L.zs_rocm_dist_rank.argtypes = [vp]
     L.zs_rocm_dist_world.argtypes = [vp]
+    L.zs_rocm_dist_comm_count.argtypes = [vp]
+    L.zs_rocm_dist_comm_count.restype = C.c_int
     L.zs_rocm_dist_halo_exchange.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, i32, vp, vp, vp, vp, vp]
     L.zs_rocm_dist_allreduce_f32.argtypes = [vp, vp, vp, sz, i32]
     L.zs_rocm_dist_allreduce_i64.argtypes = [vp, vp, vp, sz, i32]

@@ -89,7 +89,28 @@ zs_rocm_dist *zs_rocm_dist_create(int rank, int world, const void *uniqueId, int
     delete d;
     return nullptr;
   }
+  // fail fast and loudly when the communicator is not the one the caller asked for (a launcher that started fewer ranks, two ranks on
+  // one id slot): every later collective would hang or exchange with the wrong peer
+  int count = -1, urank = -1, cudev = -1;
+  (void)ncclCommCount(d->comm, &count);
+  (void)ncclCommUserRank(d->comm, &urank);
+  (void)ncclCommCuDevice(d->comm, &cudev);
+  if (count != world || urank != rank) {
+    fprintf(stderr, "[zs_rocm] dist_create: RCCL communicator has %d ranks (asked for %d), this rank is %d (asked for %d), device %d\n", count, world,
+            urank, rank, cudev);
+    (void)ncclCommAbort(d->comm);
+    delete d;
+    return nullptr;
+  }
+  if (getenv("ZS_ROCM_DIST_VERBOSE"))
+    fprintf(stderr, "[zs_rocm] dist_create: rank %d of ncclCommCount = %d on HIP device %d\n", urank, count, cudev);
   return d;
+}
+// ncclCommCount of the communicator (what RCCL itself says the world is), or -1
+int zs_rocm_dist_comm_count(const zs_rocm_dist *d) {
+  int count = -1;
+  if (!d || !d->comm || ncclCommCount(d->comm, &count) != ncclSuccess) return -1;
+  return count;
 }
 void zs_rocm_dist_destroy(zs_rocm_dist *d) {
   if (!d) return;
@@ -397,16 +418,27 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
     Launch L(pol, "step: event");
     ZSR_CHECK(hipEventRecord((hipEvent_t)ev, L.stream));
   };
+  auto bd = [&](int k, zs_rocm_policy *on) {  // breakdown event k on `on`'s stream
+    if (!a->evBreakdown || !a->evBreakdown[k]) return;
+    Launch L(on, "step: breakdown event");
+    ZSR_CHECK(hipEventRecord((hipEvent_t)a->evBreakdown[k], L.stream));
+  };
   stamp(a->evTransferBegin);
+  bd(0, pol);
   if (overlap) {
     zs_rocm_halo_plan *p = a->plan;
-    if (!p->evBoundary) {
+    if (!p->evBoundary || !p->evDone) {  // (each creation checked by itself: a plan with only one of the two must not be used)
       DeviceGuard guard(p->device);
-      ZSR_CHECK(hipEventCreateWithFlags(&p->evBoundary, hipEventDisableTiming));
-      ZSR_CHECK(hipEventCreateWithFlags(&p->evDone, hipEventDisableTiming));
+      if (!p->evBoundary && hipEventCreateWithFlags(&p->evBoundary, hipEventDisableTiming) != hipSuccess) p->evBoundary = nullptr;
+      if (!p->evDone && hipEventCreateWithFlags(&p->evDone, hipEventDisableTiming) != hipSuccess) p->evDone = nullptr;
+      if (!p->evBoundary || !p->evDone) {
+        report_error(hipErrorOutOfMemory, "step_slotted: could not create the overlap events", __FILE__, __LINE__);
+        return -1;
+      }
     }
     rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, a->nBoundary, 0);
-    if (rc) return rc;
+    if (rc) return rc;  // (nothing of the step has been committed: the range ran with finish = 0 and bad arguments fail before any launch)
+    bd(1, pol);
     {
       Launch L(pol, "step: boundary done");
       ZSR_CHECK(hipEventRecord(p->evBoundary, L.stream));
@@ -415,32 +447,44 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
       Launch C(a->commPolicy, "step: exchange start");
       ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evBoundary, 0));
     }
-    rc = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, 7);
+    bd(3, a->commPolicy);
+    const int rcx = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, 7);
+    bd(4, a->commPolicy);
     {
       Launch C(a->commPolicy, "step: exchange done");
       ZSR_CHECK(hipEventRecord(p->evDone, C.stream));
     }
-    if (rc) return rc;
+    // the second range ALWAYS runs, with its finish pass (re-home + commit): a failed exchange must not leave outbox records, claim words
+    // and mover counts of the boundary range uncommitted -- the slot storage stays consistent, the error is returned afterwards
     rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 1);
-    if (rc) return rc;
+    bd(2, pol);
     stamp(a->evTransferEnd);
     {
       Launch L(pol, "step: wait for the exchange");
       ZSR_CHECK(hipStreamWaitEvent(L.stream, p->evDone, 0));
     }
+    bd(5, pol);
+    if (rcx || rc) return rcx ? rcx : rc;
   } else {
+    bd(1, pol);
     rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, nb, 1);
     if (rc) return rc;
+    bd(2, pol);
     stamp(a->evTransferEnd);
+    bd(3, pol);
     if (exchange) {
       rc = zs_rocm_dist_halo_plan_exchange(a->plan, a->dist, pol, hgrid, 0, 7);
       if (rc) return rc;
     }
+    bd(4, pol);
+    bd(5, pol);
   }
   if (a->maxVelSqr) zs_rocm_memset(pol, a->maxVelSqr, 0, sizeof(float));
   zs_rocm_mpm_grid_update(pol, a->params, a->gridB, nb, a->extf, a->maxVelSqr);
   if (a->collider) zs_rocm_mpm_apply_boundary(pol, a->params, a->table, a->gridB, nb, a->collider);
+  bd(6, pol);
   if (a->dist && a->maxVelSqr) rc = zs_rocm_dist_allreduce_f32(a->dist, pol, a->maxVelSqr, 1, 1);
+  bd(7, pol);
   return rc;
 }
 

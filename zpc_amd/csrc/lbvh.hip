@@ -604,7 +604,17 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
       const int cc = valid ? cacheCounts[k] : 0;
       need = valid && cc > LBVH_HIT_CACHE;
       const int nv = __popcll(__ballot(valid));  // valid lanes are a prefix of the wave
-      if (nv) {
+      // the cooperative copy below needs the wave's ranges back to back in leaf order (offsets = exclusive scan of the counts, which is
+      // what every caller of the count pass builds); any other `offsets` (padded, permuted): every leaf copies its own run
+      const int prevEnd = __shfl_up(off + cc, 1, 64);
+      const bool contiguous = __ballot(valid && lane > 0 && off != prevEnd) == 0ull;
+      if (!contiguous) {
+        if (valid && cc <= LBVH_HIT_CACHE)
+          for (int c2 = 0; c2 < cc; ++c2) {
+            dst[2 * c2] = self;
+            dst[2 * c2 + 1] = cache[(size_t)c2 * numLeaves + (size_t)k];
+          }
+      } else if (nv) {
         const int base = __builtin_amdgcn_readlane(off, 0), end = __builtin_amdgcn_readlane(off + cc, nv - 1);
         const int k0 = k - lane;
         for (int p0 = base; p0 < end; p0 += 64) {  // (wave-uniform trip count: the shuffles below need every lane)
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
             else hiI = mid - 1;
           }
           const int oOff = __shfl(off, loI, 64), oCc = __shfl(cc, loI, 64), oSelf = __shfl(self, loI, 64);
-          if (pp < end && oCc <= LBVH_HIT_CACHE) {
+          if (pp < end && oCc <= LBVH_HIT_CACHE && pp - oOff < oCc) {
             typedef int i2 __attribute__((ext_vector_type(2)));
             i2 pr;
             pr.x = oSelf;
@@ -874,7 +884,8 @@ void zs_rocm_lbvh_self_query_count(zs_rocm_policy *pol, const zs_rocm_lbvh *b, i
   }
   // A/B runs: ZS_ROCM_LBVH_SELF=l selects the one-walk-per-leaf kernel of r03
   static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
-  if (b->numNodes > 2 && !perLeaf)
+  // (the wave walk addresses nodes by a 32-bit byte offset, node << 5: trees of 2^27 nodes and more take the per-leaf kernel)
+  if (b->numNodes > 2 && b->numNodes < (1u << 27) && !perLeaf)
     hipLaunchKernelGGL((lbvh_self_query_wave_kernel<false>), dim3(ceil_div(b->numLeaves, LBVH_SELF_BLOCK)), dim3(LBVH_SELF_BLOCK), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, counts, (const int *)nullptr, (int *)nullptr,
                        b->hitCache, b->hitCounts, 0);
@@ -888,7 +899,7 @@ void zs_rocm_lbvh_self_query_fill(zs_rocm_policy *pol, const zs_rocm_lbvh *b, co
   Launch L(pol, "lbvh_self_query_fill");
   if (!b->numLeaves) return;
   static const bool perLeaf = [] { const char *e = getenv("ZS_ROCM_LBVH_SELF"); return e && e[0] == 'l'; }();
-  if (b->numNodes > 2 && !perLeaf)
+  if (b->numNodes > 2 && b->numNodes < (1u << 27) && !perLeaf)
     hipLaunchKernelGGL((lbvh_self_query_wave_kernel<true>), dim3(ceil_div(b->numLeaves, LBVH_SELF_BLOCK)), dim3(LBVH_SELF_BLOCK), 0, L.stream, lbvh_packed(L, *b),
                        (int)b->numNodes, (int)b->numLeaves, (const int *)b->leafInds, (int *)nullptr, offsets, pairs, b->hitCache, b->hitCounts,
                        b->hitCacheValid ? 1 : 0);

@@ -215,6 +215,7 @@ void zs_rocm_mpm_grid_update(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, f
 
 
 
+int zs_rocm_mpm_stress_channels(void) { return STRESS_N; }
 void zs_rocm_mpm_update_stress(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps) {
   Launch L(pol, "update_stress");
   if (!ps.n || !ps.stress.base) return;

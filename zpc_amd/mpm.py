@@ -35,6 +35,8 @@ class MpmTransfer:
         # cache_stress: 6 extra channels "PF" hold the symmetric P F^T vol {xx, xy, xz, yy, yz, zz}, written by G2P (and update_stress),
         # read by P2G
         self.cache_stress = bool(cache_stress)
+        if self.cache_stress and lib().zs_rocm_mpm_stress_channels() != 6:
+            raise RuntimeError("libzsrocm expects %d channels in particles.stress, this mirror allocates 6" % lib().zs_rocm_mpm_stress_channels())
         if self.cache_stress:
             self.off["PF"] = self.nchn
             self.nchn += 6
@@ -270,6 +272,9 @@ class MpmTransfer:
         """Fold the status words of the slotted step into slot_record (and clear them on the device); strict: raise if a capacity
         overflowed, a storage invariant broke or a mover was not re-homed.  Returns the period's first 8 words ([5], [6]: movers
         sent / re-homed).  Word [3] (early warning: re-partition soon) never raises -- see repartition_requested()."""
+        # the steps in flight (on the policy's stream, which need not be torch's current one) must have finished before the words are
+        # read AND before they are zeroed: a flag or a mover count written in between would be erased without reaching slot_record
+        self.pol.syncCtx()
         st = [int(v) for v in self.slot_status.cpu().numpy()]
         st[5], st[6] = sum(st[8:264]), sum(st[264:520])  # the counters are spread over 256 words each
         self._zero(self.slot_status)
@@ -456,7 +461,7 @@ class MpmTransfer:
                 between()
 
     def step_slotted(self, extf=(0.0, 0.0, 0.0), max_vel=None, write_all=False, n_boundary=0, comm=None, plan=None, comm_pol=None,
-                     collider=None, halo_grid=None, events=None):
+                     collider=None, halo_grid=None, events=None, breakdown=None):
         """One whole sub-step on slotted storage behind ONE C-ABI call (zs_rocm_mpm_step_slotted): second grid := 0, fused G2P2G over the
         boundary blocks [0, n_boundary) then the interior, ghost-block exchange of `plan` on comm_pol's stream overlapping the interior,
         grid update (+ collider), CFL allreduce(max) of max_vel.  The grids swap: self.grid is the new one afterwards.
@@ -484,6 +489,7 @@ class MpmTransfer:
         a.commPolicy = comm_pol.handle if comm_pol is not None else None
         a.haloGrid = halo_grid.data_ptr() if halo_grid is not None else None
         a.evTransferBegin, a.evTransferEnd = (events[0], events[1]) if events is not None else (None, None)   # raw hipEvent_t (HipEvents)
+        a.evBreakdown = breakdown if breakdown is not None else None   # (C.c_void_p * ZS_ROCM_STEP_EVENTS) of raw hipEvent_t (StepBreakdown.next())
         if lib().zs_rocm_mpm_step_slotted(self.pol.handle, C.byref(a)) != 0:
             raise RuntimeError("zs_rocm_mpm_step_slotted failed")
         self.grid, self.grid2 = dst, src
@@ -575,6 +581,49 @@ class HipEvents:
             for a, b in self.pairs:
                 self.hip.hipEventDestroy(a)
                 self.hip.hipEventDestroy(b)
+        except Exception:
+            pass
+
+
+class StepBreakdown:
+    """zs_rocm_mpm_step.evBreakdown: ZS_ROCM_STEP_EVENTS raw hipEvent_t per recorded step; after a synchronisation, the mean time of every
+    stretch of a rank's step (ms): where a multi-GPU step's time goes (boundary range, interior range, the exchange on the side stream,
+    waiting for it, grid update, CFL allreduce)."""
+    NEV = 8
+    STRETCHES = (("boundary_range_ms", 0, 1), ("interior_range_ms", 1, 2), ("wait_for_exchange_ms", 2, 5), ("grid_update_ms", 5, 6),
+                 ("cfl_allreduce_ms", 6, 7), ("exchange_side_stream_ms", 3, 4), ("step_ms", 0, 7))
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.steps = []
+
+    def next(self):
+        arr = (C.c_void_p * self.NEV)()
+        for k in range(self.NEV):
+            e = C.c_void_p()
+            if self.hip.hipEventCreate(C.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            arr[k] = e
+        self.steps.append(arr)
+        return arr
+
+    def summary(self):
+        out = {}
+        for name, i, j in self.STRETCHES:
+            v = []
+            for arr in self.steps:
+                ms = C.c_float(0)
+                if self.hip.hipEventElapsedTime(C.byref(ms), C.c_void_p(arr[i]), C.c_void_p(arr[j])) == 0:
+                    v.append(ms.value)
+            out[name] = (sum(v) / len(v)) if v else None
+        return out
+
+    def __del__(self):
+        try:
+            for arr in self.steps:
+                for k in range(self.NEV):
+                    self.hip.hipEventDestroy(C.c_void_p(arr[k]))
         except Exception:
             pass
 
