@@ -371,6 +371,7 @@ template <class T, int N> struct small_vec {
   ZS_FUNCTION T &operator[](int i) { return v[i]; }
   ZS_FUNCTION const T &operator[](int i) const { return v[i]; }
   ZS_FUNCTION T &operator()(int i) { return v[i]; }
+  ZS_FUNCTION const T &operator()(int i) const { return v[i]; }
 };
 // zs::ndrange<d>(n) (ZpcIterator.hpp): the index tuples of {0..n-1}^d, first index slowest -- `for (auto loc : ndrange<3>(3))` walks a
 // stencil in the order the transfers use (simulation/transfer/P2G.hpp:106, P2C2G.hpp:79); get<I>(loc) or loc[I] reads a component
@@ -700,6 +701,9 @@ template <execspace_e space, int dim, class T, int Side> SparseGridView<dim, T, 
 template <execspace_e space> LBvhView view(const LBvh &b) { return b.view(); }
 template <execspace_e space, class C> auto proxy(C &c) { return view<space>(c); }
 template <execspace_e space, class T, int L> auto proxy(std::initializer_list<const char *> l, TileVector<T, L> &v) { return view<space>(l, v); }
+}  // namespace zs
+#include "structures.hpp"  // zs::Particles / ParticlesView, zs::Grids / GridsView
+namespace zs {
 
 // ------------------------------------------------------------------------------------ launch kernels
 namespace detail {

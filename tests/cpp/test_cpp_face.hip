@@ -208,6 +208,101 @@ int main(int argc, char **argv) {
     });
     CHECK(std::abs(sum.getVal() - (0.5f * n + (float)n * (n - 1) / 2)) < 1.0f);
   }
+  // ---- zs::Particles / ParticlesView and zs::Grids / GridsView (geometry/Structurefree.hpp:21-300, geometry/Structure.hpp:131-265, 811-1090):
+  // the containers the reference's transfer functors take (simulation/transfer/P2G.hpp:27-49), used the way those functors use them
+  {
+    using pars_t = Particles<float, 3>;
+    using grids_t = Grids<float, 3, 4>;
+    const int n = 4096, nblocks = 8;   // a 2 x 2 x 2 arrangement of 4^3 blocks: block (bx, by, bz) has number (bx * 2 + by) * 2 + bz
+    const float dx = 0.125f;
+    pars_t pars(n, memsrc_e::um, 0);
+    pars.addAttr("m", attrib_e::scalar);
+    pars.addAttr("v", attrib_e::vector);
+    pars.addAttr("F", attrib_e::matrix);
+    pars.addAttr("C", attrib_e::matrix);
+    pars.addAttr("logJp", attrib_e::scalar);
+    CHECK(pars.size() == (size_t)n && pars.hasAttr("F") && !pars.hasAttr("J") && pars.space() == memsrc_e::um);
+    CHECK(pars_t::get_attribute_enum(pars.attr("C")) == attrib_e::matrix && &pars.addAttr("v", attrib_e::vector) == &pars.attr("v"));
+    pol(range(n), [pv = proxy<space>(pars), dx] ZS_LAMBDA(long long i) mutable {
+      pv.mass(i) = 1.0f + (float)(i % 7);
+      // a lattice of 16^3 points, half a cell off the nodes, inside the 8^3-cell box
+      pv.pos(i) = pars_t::TV{{((float)(i % 16) * 0.5f + 0.25f) * dx, ((float)((i / 16) % 16) * 0.5f + 0.25f) * dx, ((float)(i / 256) * 0.5f + 0.25f) * dx}};
+      pv.vel(i) = pars_t::TV{{1.f, -2.f, 0.5f}};
+      auto &F = pv.F(i);
+      for (int d = 0; d < 9; ++d) F(d) = (d & 3) ? 0.f : 1.f;
+      pv.C(i) = pars_t::TM{};
+      pv.logJp(i) = 0.f;
+    });
+    {
+      const zs_rocm_particles ports = pars.ports();  // the same memory as the C ABI sees it: AoS iterator ports
+      CHECK(ports.pos.base == (float *)pars.attrVector("x").data() && ports.pos.numChns == 3 && ports.pos.tileMask == 0 && ports.F.numChns == 9 &&
+            ports.mass.base == pars.attrScalar("m").data() && ports.n == (size_t)n);
+      const auto X = pars.retrievePositions();
+      CHECK(X.size() == (size_t)n && std::abs(X[17][0] - (1 * 0.5f + 0.25f) * dx) < 1e-7f && std::abs(X[17][1] - (1 * 0.5f + 0.25f) * dx) < 1e-7f);
+    }
+    grids_t grids({{"m", 1}, {"v", 3}}, dx, nblocks, memsrc_e::um, 0);
+    CHECK(grids.numBlocks() == (size_t)nblocks && grids_t::block_space() == 64 && grids.grid(collocated_c).numChannels() == 4 &&
+          grids.numCells() == (size_t)nblocks * 64 * 4 && grids.grid().hasProperty("v") && !grids.grid().hasProperty("rhs"));
+    grids.grid(collocated_c).blocks.reset(0);
+    using gv_t = GridsView<space, grids_t>;
+    {
+      constexpr auto c = gv_t::coord_to_cellid(vec<int, 3>{{1, 2, 3}});
+      static_assert(c == (1 * 4 + 2) * 4 + 3, "");
+      const auto back = gv_t::cellid_to_coord(c);
+      CHECK(back[0] == 1 && back[1] == 2 && back[2] == 3 && gv_t::global_coord_to_cellid(vec<int, 3>{{5, -2, 11}}) == (1 * 4 + 2) * 4 + 3);
+    }
+    // a nearest-node splat written like the reference's P2GTransfer::operator() (P2G.hpp:51-125): particles.pos / mass / vel, the
+    // collocated grid of `grids`, a block by number, cell ids from local coordinates
+    pol(range(n), [particles = proxy<space>(pars), grids = proxy<space>(grids), dx] ZS_LAMBDA(long long parid) mutable {
+      const auto pos = particles.pos(parid);
+      const auto vel = particles.vel(parid);
+      const float mass = particles.mass(parid);
+      vec<int, 3> coord{}, blockid{}, local{};
+      for (int d = 0; d < 3; ++d) {
+        coord[d] = (int)(pos[d] / dx);
+        blockid[d] = coord[d] / gv_t::side_length;
+        local[d] = coord[d] % gv_t::side_length;
+      }
+      const size_t blockno = (size_t)((blockid[0] * 2 + blockid[1]) * 2 + blockid[2]);
+      auto grid = grids.grid(collocated_c);
+      auto grid_block = grid.block(blockno);
+      atomic_add(exec_rocm, &grid_block(0, local), mass);
+      for (int d = 0; d < 3; ++d) atomic_add(exec_rocm, &grid("v", blockno, local) + d * gv_t::block_space(), mass * vel[d]);
+    });
+    pol(Collapse{nblocks, grids_t::block_space()}, [grids = proxy<space>(grids)] ZS_LAMBDA(int bi, int ci) mutable {  // momentum -> velocity
+      auto block = grids[bi];
+      const float m = block(0, ci);
+      if (m > 0.f) {
+        auto mv = block.pack<3>(1, ci);
+        block.set<3>("v", ci, vec<float, 3>{{mv[0] / m, mv[1] / m, mv[2] / m}});
+      }
+    });
+    double msum = 0, want = 0;
+    for (int i = 0; i < n; ++i) want += 1.0 + (i % 7);
+    const float *g = grids.grid().data();
+    bool vel_ok = true;
+    for (int b = 0; b < nblocks; ++b)
+      for (int c = 0; c < 64; ++c) {
+        const float m = g[((size_t)b * 4 + 0) * 64 + c];
+        msum += m;
+        CHECK(m > 0.f);  // eight particles per cell
+        vel_ok = vel_ok && std::abs(g[((size_t)b * 4 + 1) * 64 + c] - 1.f) < 1e-5f && std::abs(g[((size_t)b * 4 + 2) * 64 + c] + 2.f) < 1e-5f &&
+                 std::abs(g[((size_t)b * 4 + 3) * 64 + c] - 0.5f) < 1e-5f;
+      }
+    CHECK(std::abs(msum - want) < 1e-3 * want && vel_ok);
+    // the const views and the host-side container operations
+    const pars_t &cpars = pars;
+    auto cpv = proxy<space>(cpars);
+    CHECK(cpv.size() == (size_t)n && cpv.mass(3) == 4.0f && cpv.F(5)(4) == 1.f);
+    pars_t more(16, memsrc_e::um, 0);
+    more.addAttr("m", attrib_e::scalar);
+    pars.append(more);
+    CHECK(pars.size() == (size_t)n + 16 && pars.attrScalar("m").size() == (size_t)n + 16);
+    pars.resize(n);
+    CHECK(pars.attrMatrix("F").size() == (size_t)n);
+    grids.align(grid_e::staggered);
+    CHECK(grids.grid(staggered_c).numBlocks() == (size_t)nblocks);
+  }
   // ---- reduce over a TileVector channel through the iterator ABI (main.cu:7-32)
   for (int n : {1, 2, 7, 16, 128, 1024, 200000}) {
     TileVector<int, 32> tv({{"a", 3}, {"b", 2}, {"c", 1}}, n, memsrc_e::um);

@@ -884,7 +884,7 @@ def test_slotted_downward_rehome_with_simultaneous_arrivals(pol, oracle, side):
             assert len(set(inA.values())) == 7                                       # seven particles, seven different rounds
         ga = mt.grid.cpu().numpy().reshape(om.grid.shape)
         scale = np.abs(om.grid).max(axis=(0, 2)) + 1e-30
-        scale = np.maximum(scale, 1e-4 * scale[1])   # (F = I: the force channels are rounding noise of a zero stress, measured against the momentum)
+        scale = np.maximum(scale, 1e-2 * scale[1])   # (F = I: the force channels (an impulse, like the momentum) are rounding noise of a zero stress)
         assert (np.abs(ga - om.grid).max(axis=(0, 2)) <= 3e-4 * scale).all(), (step, np.abs(ga - om.grid).max(axis=(0, 2)) / scale)
         om.grid_update((0.0, 0.0, 0.0))
         mt.grid_update((0.0, 0.0, 0.0))

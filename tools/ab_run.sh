@@ -7,7 +7,7 @@ for n in "$@"; do
 import sys, json
 l = [x for x in sys.stdin if x.startswith('{')]
 d = json.loads(l[-1]) if l else {}
-print('%-16s ms_per_step %.3f launch_ms %.3f movers %.0f' % ('$n', d.get('ms_per_step', -1), d.get('roofline', {}).get('launch_ms', -1), d.get('config', {}).get('movers_per_step_rank0', -1)), d.get('slot_stats', ''))"
+print('%-16s ms_per_step %.3f launch_ms %.3f movers %.0f' % ('$n', d.get('ms_per_step', -1), d.get('roofline', {}).get('launch_ms', -1), (d.get('config', {}).get('movers_per_step_rank0') or -1)), d.get('slot_stats', ''))"
     [ -s /tmp/ab_err.txt ] && grep -v amdgpu.ids /tmp/ab_err.txt | tail -3
   done
 done

@@ -1238,7 +1238,59 @@ template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const Particl
   else return 0;
 }
 
-// one particle record (LDS row layout of p2gw_issue) -> the lane's 27 x 7 register stencil
+// one particle record (LDS row layout of p2gw_issue) -> the lane's 27 x 7 register stencil.
+// r05, "Q form" (see stage_qform): per vector channel the value at the stencil's centre node and its change per node step,
+//   momentum d: alpha = m (v_d + C[d, :] . (dx - lp)), b_k = m dx C[d + 3 k];  force d: alpha = kscale S[d, :] . (dx - lp), b_k = kscale dx S[d, k]
+// (S = the symmetric P F^T vol), then per node W_abc (alpha + (a - 1) bx + (b - 1) by + (c - 1) bz): the offsets x_i - x_p and the products
+// C (x_i - x_p) are no longer rebuilt per node, and ONE weight product W_abc serves all seven channels.
+#ifndef ZS_P2GW_CLASSIC
+__device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
+  const float m = rec[0];
+  float lc[3];  // centre node - particle
+#pragma unroll
+  for (int k = 0; k < 3; ++k) lc[k] = mp.dx - ar.lp[k];
+  float al[6], bx[6], by[6], bz[6];
+  {
+    const float mdx = m * mp.dx, ksdx = kscale * mp.dx;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = rec[(4 + d) * 64], c0 = rec[(7 + d) * 64], c1 = rec[(10 + d) * 64], c2 = rec[(13 + d) * 64];
+      al[d] = m * (v + (c0 * lc[0] + c1 * lc[1] + c2 * lc[2]));
+      bx[d] = mdx * c0;
+      by[d] = mdx * c1;
+      bz[d] = mdx * c2;
+      // row d of the symmetric P F^T vol {xx, xy, xz, yy, yz, zz} (rows 16..21 of the record)
+      const float s0 = rec[(16 + d) * 64], s1 = rec[(16 + (d == 0 ? 1 : d == 1 ? 3 : 4)) * 64], s2 = rec[(16 + (d == 0 ? 2 : d == 1 ? 4 : 5)) * 64];
+      al[3 + d] = kscale * (s0 * lc[0] + s1 * lc[1] + s2 * lc[2]);
+      bx[3 + d] = ksdx * s0;
+      by[3 + d] = ksdx * s1;
+      bz[3 + d] = ksdx * s2;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float qa[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) qa[j] = a == 0 ? al[j] - bx[j] : (a == 1 ? al[j] : al[j] + bx[j]);
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float wxy = ar.w[0][a] * ar.w[1][bb];
+      const float W0 = wxy * ar.w[2][0], W1 = wxy * ar.w[2][1], W2 = wxy * ar.w[2][2];
+      float(&A0)[7] = acc[(a * 3 + bb) * 3], (&A1)[7] = acc[(a * 3 + bb) * 3 + 1], (&A2)[7] = acc[(a * 3 + bb) * 3 + 2];
+      A0[0] = fmaf(W0, m, A0[0]);
+      A1[0] = fmaf(W1, m, A1[0]);
+      A2[0] = fmaf(W2, m, A2[0]);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float qab = bb == 0 ? qa[j] - by[j] : (bb == 1 ? qa[j] : qa[j] + by[j]);
+        A0[1 + j] = fmaf(W0, qab - bz[j], A0[1 + j]);
+        A1[1 + j] = fmaf(W1, qab, A1[1 + j]);
+        A2[1 + j] = fmaf(W2, qab + bz[j], A2[1 + j]);
+      }
+    }
+  }
+}
+#else
 __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
   const float m = rec[0];
   float xo[3][3];
@@ -1309,6 +1361,7 @@ __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &a
       }
   }
 }
+#endif
 
 // LDS arena shared by the G bins of one workgroup of p2g_wide_kernel: G = 1 one bin (6^3 nodes, ArenaLds), G = 2 the two bins of a
 // block that are neighbours in z (4 x 4 x 8 cells, 6 x 6 x 10 nodes), G = 4 the four bins of a half block (4 x 8 x 8 cells, 6 x 10 x 10
