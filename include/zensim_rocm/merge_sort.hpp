@@ -45,7 +45,10 @@ __device__ __forceinline__ void serial_merge(const K *s, const V *sv, int ai, in
   for (int i = 0; i < MS_ITEMS; ++i) {
     if (i < nout) {
       const bool takeA = bi >= bend || (ai < aend && !comp(kb, ka));
-      rk[i] = takeA ? ka : kb;
+      // (two assignments, not `rk[i] = takeA ? ka : kb`: the select of a struct-typed key kept rk[] in private memory -- 176 B of scratch per
+      // lane for a 16-byte key; with plain assignments the array is promoted to registers and no merge kernel uses scratch)
+      if (takeA) rk[i] = ka;
+      else rk[i] = kb;
       if constexpr (PAIR) rv[i] = sv[takeA ? ai : bi];
       if (takeA) {
         ++ai;

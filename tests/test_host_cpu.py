@@ -268,3 +268,28 @@ def test_small_input_sort_kernels_use_no_scratch_memory(tmp_path):
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
         assert re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk).group(1) == "false", name.group(1)
     assert seen >= 12  # hist x 4 key types, split and finish x 4 key types x {keys, pairs} (minus duplicates the linker folds)
+
+
+def test_merge_sort_kernels_of_the_cpp_face_use_no_scratch_memory(tmp_path):
+    """The merge sort instantiated by the C++ face's test program -- int keys, pairs, and a 16-byte struct key with a user comparator --
+    keeps its per-lane run in registers: r03 / r04 carried a "scratch trap" (a kernel with private memory followed by
+    the struct-key merge kernels, 176 B of scratch per lane, returned wrong results in two builds that could not be reproduced later).
+    r05 removed the private memory from the merge kernels (merge_sort.hpp: serial_merge); this keeps it removed."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "zpc_amd", "lib", "test_cpp_face")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("test program or llvm tools not present")
+    fat, co = str(tmp_path / "p.fat"), str(tmp_path / "p.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", exe, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                           "--output=" + co, "--unbundle"])
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    seen = 0
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name or "zs_rocm_ms" not in name.group(1):
+            continue
+        seen += 1
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
+    assert seen >= 6  # tile sort, partition and merge kernels for int keys, pairs and the struct key

@@ -65,8 +65,8 @@ def build_cpp_face_test(verbose=True):
     (include/zensim_rocm/zs_rocm.hpp) -- proves that the face compiles with hipcc and links libzsrocm.so."""
     src = os.path.join(ROOT, "tests", "cpp", "test_cpp_face.hip")
     out = os.path.join(LIBDIR, "test_cpp_face")
-    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "bht_device.hpp"), os.path.join(ROOT, "include", "zensim_rocm", "sparse_grid.hpp"),
-            os.path.join(ROOT, "include", "zensim_rocm", "collider_device.hpp"), LIB]
+    face = os.path.join(ROOT, "include", "zensim_rocm")
+    deps = [src, LIB] + [os.path.join(face, f) for f in os.listdir(face) if f.endswith(".hpp")]
     if os.path.exists(src) and any(_newer(d, out) for d in deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "include"), src,
                "-L", LIBDIR, "-lzsrocm", "-Wl,-rpath,$ORIGIN", "-o", out]
@@ -80,7 +80,8 @@ def build_ofb_test(verbose=True):
     """tests/cpp/test_ofb.hip: the C++ face compiled with ZS_ENABLE_OFB_ACCESS_CHECK=1 (the reference's bounds-check build option)."""
     src = os.path.join(ROOT, "tests", "cpp", "test_ofb.hip")
     out = os.path.join(LIBDIR, "test_ofb")
-    deps = [src, os.path.join(ROOT, "include", "zensim_rocm", "zs_rocm.hpp"), LIB]
+    face = os.path.join(ROOT, "include", "zensim_rocm")
+    deps = [src, LIB] + [os.path.join(face, f) for f in os.listdir(face) if f.endswith(".hpp")]
     if os.path.exists(src) and any(_newer(d, out) for d in deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-L", LIBDIR, "-lzsrocm",
                "-Wl,-rpath,$ORIGIN", "-o", out]
