@@ -1,9 +1,9 @@
 #!/bin/bash
-# One GPU call that regenerates the measurements profiles/r04_* and profiles/pmc_*.json are written from (default bench = slotted storage,
-# moving column).  Copy gpurun_out/r04/{pmc_g2p2g.json,pmc_p2g.json} to profiles/ by hand afterwards (only gpurun_out/ travels back).
+# One GPU call that regenerates the measurements profiles/r05_* and profiles/pmc_*.json are written from (default bench = slotted storage,
+# moving column).  Copy gpurun_out/r05/{pmc_g2p2g.json,pmc_p2g.json} to profiles/ by hand afterwards (only gpurun_out/ travels back).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r04; rm -rf $O; mkdir -p $O
+O=$R/gpurun_out/r05; rm -rf $O; mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline --no-at-rest"
 P2G="$B --compact --unfused --drift 0,0,0 --steps 8 --warmup 2"
 # 1. kernel-trace stats of the default (moving) bench and of the unfused at-rest run
@@ -24,7 +24,8 @@ pmc() {  # pmc <name> <kernel regex> <command...>
     find $out -name '*.csv' -size +8M -delete
   done
 }
-pmc fused "g2p2g_slot_kernel|slot_rehome_kernel|slot_commit_kernel" $B --steps 20 --warmup 2
+pmc fused "g2p2g_slot|slot_rehome_kernel|slot_commit_kernel" $B --steps 20 --warmup 2
+pmc fusedrest "g2p2g_slot|slot_rehome_kernel|slot_commit_kernel" $B --steps 10 --warmup 2 --drift 0,0,0
 pmc p2g "p2g_wide_kernel" $P2G
 python3 - $O $R <<'PY'
 import csv, glob, os, sys, collections, json
@@ -32,11 +33,12 @@ O, R = sys.argv[1], sys.argv[2]
 sys.path.insert(0, os.path.join(R, "tools"))
 import kernel_hash
 def collect(name, keys):
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for f in glob.glob(os.path.join(O, "pmc_" + name, "*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = next((k for k in keys if k in r["Kernel_Name"]), None)
-            if k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if k: acc[k][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])   # (rows of one dispatch are summed)
+    acc = {k: {c: [per[d] for d in sorted(per)] for c, per in cs.items()} for k, cs in acc.items()}
     summ, lines = {}, []
     for k in acc:
         m = {c: sum(v[-3:]) / len(v[-3:]) for c, v in acc[k].items()}   # the last launches (steady state)
@@ -48,15 +50,24 @@ def collect(name, keys):
         lines += ["## %s" % k, "| counter | value |", "|---|---|"] + ["| %s | %.6g |" % (c, m[c]) for c in sorted(m)] + [""]
     open(os.path.join(O, "pmc_%s.md" % name), "w").write("\n".join(lines) + "\n")
     return summ
-s = collect("fused", ("g2p2g_slot_kernel", "slot_rehome_kernel", "slot_commit_kernel"))
-if "hbm_bytes_per_launch" in s.get("g2p2g_slot_kernel", {}):
-    rx = r"g2p2g_slot_kernel<8, 1, false>|slot_rehome_kernel<false, true, false>|slot_commit_kernel"
-    tot = sum(s.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in ("g2p2g_slot_kernel", "slot_rehome_kernel", "slot_commit_kernel"))
-    json.dump({"kernel": "g2p2g_slot_kernel + slot_rehome_kernel + slot_commit_kernel", "particles": 67108864, "side": 8, "model": "sand", "cache_stress": True,
-               "hbm_bytes_per_launch": tot, "main_kernel_bytes": s["g2p2g_slot_kernel"]["hbm_bytes_per_launch"],
+KS = ("g2p2g_slotblk_kernel", "slot_rehome_kernel", "slot_commit_kernel")
+s = collect("fused", KS)
+r = collect("fusedrest", KS)
+main = s.get("g2p2g_slotblk_kernel", {})
+if "hbm_bytes_per_launch" in main:
+    rx = r"g2p2g_slotblk_kernel<1, false>"
+    obj = "zpc_amd/lib/obj/mpm_slotblk.o"
+    tot = sum(s.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in KS)
+    valu = sum(s.get(k, {}).get("SQ_INSTS_VALU", 0.0) for k in KS)
+    valu_rest = sum(r.get(k, {}).get("SQ_INSTS_VALU", 0.0) for k in KS) or None
+    busy = main["SQ_ACTIVE_INST_VALU"] * 4 / (main["GRBM_GUI_ACTIVE"] / 8 * 1024) if "GRBM_GUI_ACTIVE" in main and "SQ_ACTIVE_INST_VALU" in main else None
+    json.dump({"kernel": "g2p2g_slotblk_kernel + slot_rehome_kernel + slot_commit_kernel", "particles": 67108864, "side": 8, "model": "sand", "cache_stress": True,
+               "hbm_bytes_per_launch": tot, "main_kernel_bytes": main["hbm_bytes_per_launch"],
                "hbm_read_bytes": sum(s.get(k, {}).get("hbm_read_bytes_corrected", 0.0) for k in s), "hbm_write_bytes": sum(s.get(k, {}).get("hbm_write_bytes", 0.0) for k in s),
-               "code_object": "zpc_amd/lib/obj/mpm_slotted.o", "code_regex": rx, "code_hash": kernel_hash.combined(os.path.join(R, "zpc_amd/lib/obj/mpm_slotted.o"), rx),
-               "source": "tools/refresh_r04.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read correction x2)"},
+               "valu_insts_per_launch": valu, "valu_insts_at_rest": valu_rest, "valu_busy_frac": busy,
+               "sq_wave_cycles": main.get("SQ_WAVE_CYCLES"), "sq_wait_any": main.get("SQ_WAIT_ANY"), "grbm_gui_active": main.get("GRBM_GUI_ACTIVE"),
+               "code_object": obj, "code_regex": rx, "code_hash": kernel_hash.combined(os.path.join(R, obj), rx),
+               "source": "tools/refresh_r05.sh (rocprofv3 --pmc, separate passes per counter group; FETCH_SIZE x 2 on gfx950; valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); valu_insts_at_rest = the same kernels on the column at rest)"},
               open(os.path.join(O, "pmc_g2p2g.json"), "w"), indent=1)
 s = collect("p2g", ("p2g_wide_kernel",))
 if "hbm_bytes_per_launch" in s.get("p2g_wide_kernel", {}):
@@ -65,7 +76,7 @@ if "hbm_bytes_per_launch" in s.get("p2g_wide_kernel", {}):
     json.dump({"kernel": "p2g_wide", "particles": 67108864, "side": 8, "model": "sand", "cache_stress": True, "hbm_bytes_per_launch": m["hbm_bytes_per_launch"],
                "hbm_read_bytes": m["hbm_read_bytes_corrected"], "hbm_write_bytes": m["hbm_write_bytes"],
                "code_object": "zpc_amd/lib/obj/mpm_p2g.o", "code_regex": rx, "code_hash": kernel_hash.combined(os.path.join(R, "zpc_amd/lib/obj/mpm_p2g.o"), rx),
-               "source": "tools/refresh_r04.sh"}, open(os.path.join(O, "pmc_p2g.json"), "w"), indent=1)
+               "source": "tools/refresh_r05.sh"}, open(os.path.join(O, "pmc_p2g.json"), "w"), indent=1)
 PY
 cd $R
 # 3. bench lines
@@ -75,6 +86,8 @@ $B --compact --drift 0,0,0 > $O/bench_n1_compact_at_rest.json 2>/dev/null
 $B --compact --unfused --drift 0,0,0 > $O/bench_n1_unfused_at_rest.json 2>/dev/null
 $B --cells 100,100,100 --model jello --grid 256 > $O/bench_config3_jello_8M.json 2>/dev/null
 $B --steps 40 --warmup 5 --cells 64,256,64 > $O/eighth_plain.json 2>/dev/null
-$B --steps 40 --warmup 5 --cells 64,256,64 --rank-proxy 8 > $O/proxy8.json 2>/dev/null
+$B --steps 40 --warmup 5 --cells 64,256,64 --rank-proxy 8 2>/dev/null | grep '^{' > $O/proxy8.json
+$B --steps 3000 --warmup 3 --slot-stats 2>/dev/null | grep '^{' > $O/bench_soak3000.json
+ZS_ROCM_SLOT_PERBIN=1 $B 2>/dev/null | grep '^{' > $O/bench_n1_perbin_kernel.json
 python tools/bench_prims.py --json $O/prims.json > $O/prims.txt 2>&1
 tail -c 400 $O/bench_n1.json
