@@ -104,6 +104,76 @@ __device__ __forceinline__ void blk_finish_bin(const BlkShared &sh, const SlotAr
   }
 }
 
+// P2G arena of ONE bin in the block kernel: 8^3 nodes = the bin's 6^3 stencil nodes + one layer around them, origin at the bin's node -1.
+// A mover whose new cell lies in a neighbour bin (base node -1 .. 4 per axis) has its 27 nodes inside, so its grid terms are added HERE
+// (plain LDS read-add-write) and reach the grid with the bin's one flush -- instead of 189 global float atomics per mover (0.4 ms and
+// 1.8 GB of write-through sectors per step of the 64 Mi-particle column).  Strides: for a fixed stencil offset the 64 cells of a bin land
+// on 32 distinct banks per 32-lane half (z + 8 y + 68 x: x adds 4 mod 32).
+struct ArenaBin8 {
+  static constexpr int W = 8;
+  static constexpr int SY = 8, SX = 68, CH = W * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+
+// The chunk's list (movers into neighbour bins, arrival-queue overflow, stayers whose local position rounded onto 1.5): the channels of
+// set CS of their 27 node terms into the bin's 8^3 arena `pa` (this wave's channels).  Two list entries per pass, lane = (entry parity,
+// stencil node); the two entries of a pass may share nodes, so the halves do their read-add-write one after the other (LDS operations of
+// a wave execute in order).  Weights and staged record as slot_xlist_scatter.
+template <int CS>
+__device__ __forceinline__ void blk_xlist_lds(const float *stage, const unsigned *xq, int nx, int lane, float *pa) {
+  using S = ConsumerSet<CS>;
+  using A8 = ArenaBin8;
+  const int node = lane & 31, half = lane >> 5;
+  if (nx <= 0) return;
+  const int sel[3] = {node / 9, (node / 3) % 3, node % 3};
+  float ws[3], wt[3], wa[3], wb[3], oc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    ws[q] = sel[q] == 0 ? -1.f : 1.f;
+    wt[q] = sel[q] == 0 ? 1.5f : (sel[q] == 1 ? -1.f : -0.5f);
+    wa[q] = sel[q] == 1 ? 0.75f : 0.f;
+    wb[q] = sel[q] == 1 ? -1.f : 0.5f;
+    oc[q] = (float)(sel[q] - 1);
+  }
+#pragma unroll 1
+  for (int k0 = 0; k0 < nx; k0 += 2) {
+    const int k = k0 + half;
+    const bool act = node < 27 && k < nx;
+    float val[S::NA];
+    int an = 0;
+    if (act) {
+      const unsigned e = xq[k];
+      const float *st = stage + (size_t)((e & 1023u) >> 6) * (G2P2G_QF * 64) + (e & 63u);
+      float Wt = 1.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float d0 = st[(1 + q) * 64];
+        const float u = fmaf(ws[q], d0 - floorf(d0 - 0.5f), wt[q]);  // the reference's second base_node (see `edge` in the producer)
+        Wt *= fmaf(wb[q], u * u, wa[q]);
+      }
+      // (the entry carries new cell + 1 per axis = the arena coordinate of the stencil's node 0)
+      an = A8::at((int)((e >> 10) & 7u) + sel[0], (int)((e >> 13) & 7u) + sel[1], (int)((e >> 16) & 7u) + sel[2]);
+#pragma unroll
+      for (int q = 0; q < S::NA; ++q) {
+        if (S::MASS && q == 0) {
+          val[q] = Wt * st[0];  // mass
+        } else {
+          const float *c = st + (4 + 4 * ((S::STRESS ? 3 : 0) + S::D0 + q - (S::MASS ? 1 : 0))) * 64;
+          val[q] = Wt * fmaf(c[192], oc[2], fmaf(c[128], oc[1], fmaf(c[64], oc[0], c[0])));
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (act && half == h) {
+#pragma unroll
+        for (int q = 0; q < S::NA; ++q) pa[q * A8::CH + an] += val[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
 // producer wave W (0..3): entries [64 (4 c + W), +64) of every chunk c of every bin of the block
 template <int SMODEL, bool WRITE_ALL, int W>
 __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDev &ps, const int (&borg)[3], int blk, int lane, int G,
@@ -207,11 +277,12 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
 template <int CS>
 __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)[3], int blk, int lane, int G, const BlkShared &sh, const SlotArgs &A) {
   using S = ConsumerSet<CS>;
-  using AL = ArenaLds;
+  using AL = ArenaBin8;
   constexpr int NC = 512;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const unsigned long long lt = lanemask_lt();
   const float *const stage = sh.stage;
+  float *const pa = sh.parena + (size_t)S::CH0 * AL::CH;  // this wave's channels of the bin's arena
   float acc[27][S::NA];
 #pragma unroll
   for (int k = 0; k < 27; ++k)
@@ -234,6 +305,8 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
       r = 0;
       off = 0;
       mask = sh.masks[b][lane];
+      for (int k = lane; k < S::NA * AL::CH; k += 64) pa[k] = 0.f;  // the bin's arena (this wave's channels): the chunk lists add into it first
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     const int produced = 256 * (c + 1) < total ? 256 * (c + 1) : total;
     const unsigned qn = sh.arrCnt[par][lane];
@@ -276,8 +349,7 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     {
       const int nx = sh.xCnt[par] < (unsigned)SL_XQ ? (int)sh.xCnt[par] : SL_XQ;
       if (CS == 0 && lane == 0) sh.xCnt[(g + 2) % 3] = 0u;
-      const SubGeom sg = sub_geom(borg, b);
-      slot_xlist_scatter<8, CS>(mp, sg, stage, sh.xq[par], nx, lane, sh.nbrBlk, A);
+      blk_xlist_lds<CS>(stage, sh.xq[par], nx, lane, pa);
     }
     // this wave has read what it needs of chunk g: the producers may stage chunk g + 1 over it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -285,12 +357,9 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     SLP_ACC(tWork, tIt);
     SLP_T0(tFl);
     if (c == sh.nch[b] - 1) {
-      // last chunk of the bin: the set's channels of the bin's arena belong to this wave alone -- clear, add the 27 register planes
-      // (phases ordered inside the wave), send the arena's nodes to the grid; no other wave is involved
-      float *const pa = sh.parena + (size_t)S::CH0 * AL::CH;
-      for (int k = lane; k < S::NA * AL::CH; k += 64) pa[k] = 0.f;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      float *a0 = pa + AL::at(cx, cy, cz);
+      // last chunk of the bin: the set's channels of the bin's arena belong to this wave alone -- add the 27 register planes on top of
+      // the lists' terms (phases ordered inside the wave), send the arena's nodes to the grid; no other wave is involved
+      float *a0 = pa + AL::at(cx + 1, cy + 1, cz + 1);
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
         float *gp = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
@@ -302,14 +371,14 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
       const SubGeom sg = sub_geom(borg, b);
-      for (int n = lane; n < 216; n += 64) {
-        const int x = n / 36, y = (n / 6) % 6, z = n % 6;
-        int slot, cell;
-        arena_to_grid<8>(sg.o, x, y, z, slot, cell);
-        const int bn = sh.nbr8[slot];
+      for (int n = lane; n < 512; n += 64) {
+        const int x = n >> 6, y = (n >> 3) & 7, z = n & 7;
+        const int g[3] = {sg.o[0] - 1 + x, sg.o[1] - 1 + y, sg.o[2] - 1 + z};  // node in cells of this block: -1 .. 10
+        const int code = ((g[0] < 0 ? 0 : (g[0] >= 8 ? 2 : 1)) * 3 + (g[1] < 0 ? 0 : (g[1] >= 8 ? 2 : 1))) * 3 + (g[2] < 0 ? 0 : (g[2] >= 8 ? 2 : 1));
+        const int bn = sh.nbrBlk[code];
         const float *a = pa + AL::at(x, y, z);
         if (bn >= 0) {
-          float *gq = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + cell;
+          float *gq = A.gridB + ((size_t)bn * 7 + S::CH0) * NC + (((g[0] & 7) * 8 + (g[1] & 7)) * 8 + (g[2] & 7));
 #pragma unroll
           for (int q = 0; q < S::NA; ++q) {
             const float v = a[q * AL::CH];
@@ -338,7 +407,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   using AL = ArenaLds;
   constexpr int NC = 512;
   __shared__ float s_varena[3 * ArenaBlk::CH];
-  __shared__ float s_parena[7 * AL::CH];
+  __shared__ float s_parena[7 * ArenaBin8::CH];
   __shared__ float s_stage[SB_NG * G2P2G_QF * 64];
   __shared__ unsigned long long s_smask[SB_NG];
   __shared__ unsigned short s_tab[2][SL_KMAX * 64];
