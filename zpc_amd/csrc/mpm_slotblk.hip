@@ -15,7 +15,9 @@
 //     LDS counter, no barrier: the consumers finish a chunk in half the time the producers need for the next); one barrier per chunk
 //     hands the staged chunk over;
 //   * per-bin state (entry table, tickets, departures, outbox count, neighbour bins) is double-buffered by bin parity; the entry table
-//     of a bin is built two chunks ahead by the producers, a finished bin's claim words are written out one chunk later.
+//     of a bin is built two chunks ahead by the producers, a finished bin's claim words are written out one chunk later;
+//   * the bin's P2G arena has 8^3 nodes (ArenaBin8): a mover into a neighbour bin adds its 27 node terms there (plain LDS
+//     read-add-write) and they reach the grid with the bin's one flush -- no global atomics per mover.
 // The per-particle code (slot_produce_entry), the consumers' accumulation (g2p2g_consume_set), the mover protocol, slot_rehome_kernel
 // and slot_commit_kernel are those of mpm_slotted.hip; results differ only in summation order.
 #include "mpm_slot.hpp"
@@ -404,7 +406,6 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
 
 template <int SMODEL, bool WRITE_ALL>
 static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, SlotArgs A) {
-  using AL = ArenaLds;
   constexpr int NC = 512;
   __shared__ float s_varena[3 * ArenaBlk::CH];
   __shared__ float s_parena[7 * ArenaBin8::CH];
