@@ -524,6 +524,11 @@ def main():
         nonlocal halo, nblocks, migrated
         from zpc_amd.dist import migrate_particles
         moved = (0, 0)
+        if inplace_remap:
+            # single rank, slotted storage: the partition follows the particles without touching one (new partition from the occupancy
+            # words, populated bins move as whole tile rows, the velocity grid is carried over): ~4 ms instead of ~50
+            nblocks = mt.repartition_slotted(margin=a.margin, strict=(a.repartition == "closed" and not os.environ.get("ZS_BENCH_ABLATION")))
+            return moved
         if mt.slotted:
             # occupied slots -> compact buffer (the step before a re-map stored v, C and the stress as well).  The period's status words
             # are checked and folded into mt.slot_record first, and the particle count must be unchanged: nothing is ever dropped
@@ -539,6 +544,8 @@ def main():
         migrated += moved[0]
         return moved
 
+    # re-partition in place (zs_rocm_mpm_reslot) where particles cannot change owner and no boundary-first block numbering is needed
+    inplace_remap = a.slotted and a.fused and world == 1 and not proxy and not os.environ.get("ZS_BENCH_FULL_REMAP")
     if a.fused:
         if a.unbinned or not mt.cache_stress:
             raise SystemExit("--fused needs the binned path with cached stress")
@@ -602,7 +609,7 @@ def main():
             remap_now = (K > 0 and (done + 1) % K == 0) or (next_remap is not None and done + 1 >= next_remap) or pending_remap
             ts = time.perf_counter()
             if a.fused:
-                step(timed, remap_now)  # the step before a re-map materialises v, C, stress of every particle
+                step(timed, remap_now and not inplace_remap)  # the step before a FULL re-map materialises v, C, stress of every particle
             else:
                 step(timed)
             if timed:
@@ -843,7 +850,8 @@ def main():
                        "movers_per_step_rank0": movers_per_step, "partition_margin_blocks": a.margin if a.slotted else 0,
                        "repartition_trigger": (("closed loop: status word [3] of the slotted step, polled every %d steps" % poll_iv) if closed_loop
                                                else ("every %d steps" % K if K else ("open loop (drift + gravity)" if a.slotted else "none"))),
-                       "repartition_steps": remap_steps[:64], "slot_record_rank0": slot_record,
+                       "repartition_steps": remap_steps[:64], "repartition_kind": ("in place (zs_rocm_mpm_reslot: bins move as whole tile rows)" if inplace_remap else "full (unslot, partition, re-bin, prime, slot)"),
+                       "slot_record_rank0": slot_record,
                        "step_call": ("one C-ABI call per step (zs_rocm_mpm_step_slotted)" if one_call else "python: one call per kernel / exchange"),
                        "host_step_call_us_per_step": host_step_s[0] / a.steps * 1e6,   # time the host spends inside the step's call(s)
                        # wall clock until the last step was enqueued: includes the closed-loop poll, which waits for the status copy of

@@ -678,6 +678,19 @@ typedef struct zs_rocm_slot_storage {
  * edge == 0 can move into any neighbouring block and still scatter its whole stencil) */
 ZS_ROCM_EXPORT void zs_rocm_mpm_partition_edge(zs_rocm_policy *, const zs_rocm_bht_3 *, unsigned char *edge /* [nblocks] */, int keyStride,
                                                int lo, int hi);
+/* Re-partition of slotted storage in place (r05; no reference counterpart -- the reference never orders particles): the partition a fused time
+ * loop runs on has to follow the particles (closed-loop trigger: status word [3]).  (1) the reference's ComputeSparsity
+ * (simulation/sparsity/SparsityOp.hpp:65-86) taken from the occupancy words instead of the particle positions -- a particle is stored under the
+ * cell of its base node -- into `newTab` (a freshly reset table); enlarge it with zs_rocm_mpm_enlarge_sparsity as usual.  (2) every bin that
+ * holds particles moves, as whole tile rows, to the number its block has in `newTab`; `newMask` and (optionally) `newGrid` -- the node
+ * velocities the next step gathers from -- are written for the whole new partition.  No particle is read, re-binned or re-slotted:
+ * ~4 ms instead of ~50 ms per re-partition of the 64 Mi-particle column.  Buffers: newBuf = nbins(new) * K * 64 * C floats, newMask = nbins(new) * 64 words,
+ * newGrid = nblocks(new) * 7 * side^3 floats.  Returns 0 / -1 (bad arguments); status[2] if a populated block is missing from `newTab`. */
+ZS_ROCM_EXPORT void zs_rocm_mpm_slot_compute_sparsity(zs_rocm_policy *, const zs_rocm_bht_3 *oldTab, const unsigned *cellMask, size_t nblocksOld,
+                                                      int side, int keyIsOrigin, zs_rocm_bht_3 *newTab);
+ZS_ROCM_EXPORT int zs_rocm_mpm_reslot(zs_rocm_policy *, const zs_rocm_bht_3 *oldTab, const zs_rocm_bht_3 *newTab, int side, int K, int C,
+                                      const float *oldBuf, float *newBuf, const unsigned *oldMask, unsigned *newMask, const float *oldGrid,
+                                      float *newGrid, int *status);
 /* the step over blocks [blockBegin, blockEnd) on the storage `st` (see zs_rocm_mpm_g2p2g_slotted_range for finish) */
 ZS_ROCM_EXPORT int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *, const zs_rocm_mpm_params *, zs_rocm_particles, const zs_rocm_bht_3 *,
                                            const float *gridA, float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll,

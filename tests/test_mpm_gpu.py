@@ -1099,8 +1099,11 @@ def test_slotted_full_destination_cell_in_another_bin_returns_the_mover(pol):
     assert full, "no cell overflowed: the test does not test"
 
 
-def test_slotted_closed_loop_repartition_vs_oracle(pol, oracle):
-    """70 slotted steps of a cloud moving 0.3 cell per step (21 cells of travel through a partition with one block of margin), re-partitioned
+@pytest.mark.parametrize("inplace", [False, True])
+def test_slotted_closed_loop_repartition_vs_oracle(pol, oracle, inplace):
+    """(inplace: the partition follows the particles through zs_rocm_mpm_slot_compute_sparsity + zs_rocm_mpm_reslot -- bins move as whole
+    tile rows, the velocity grid is carried over, no particle is read -- instead of unslot / partition / re-bin / prime / slot.)
+    70 slotted steps of a cloud moving 0.3 cell per step (21 cells of travel through a partition with one block of margin), re-partitioned
     whenever the step's own status word [3] asks for it (poll_repartition: asynchronous copy, one polling interval of lag) -- the
     bench's closed loop.  The oracle's g2p -> p2g sequence runs beside it on the same partitions; after the last step every particle
     agrees, no flag other than the early warning was ever raised, and at least two re-partitions happened."""
@@ -1123,10 +1126,13 @@ def test_slotted_closed_loop_repartition_vs_oracle(pol, oracle):
         om.grid[:] = 0
         om.p2g(mass, po, vo, Co, Fo, None)
         om.grid_update((0.0, -9.8, 0.0))
-        mt.g2p2g(write_all=pending or step == 69)
+        mt.g2p2g(write_all=(pending and not inplace) or step == 69)
         mt.grid_update((0.0, -9.8, 0.0))
         if pending:
-            _repartition(mt, pol, 1, 24, 512, strict=True)
+            if inplace:
+                mt.repartition_slotted(margin=1, strict=True)
+            else:
+                _repartition(mt, pol, 1, 24, 512, strict=True)
             # the oracle moves to the same partition: its grid is a function of the particles it holds
             om.adopt_partition(mt.active_keys())
             om.grid[:] = 0

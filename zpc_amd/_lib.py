@@ -364,6 +364,9 @@ def _declare_containers(L):
     L.zs_rocm_mpm_g2p2g_slots.argtypes = [vp, PP, Particles, vp, vp, vp, sz, C.POINTER(SlotStorage), i32, sz, sz, i32]
     L.zs_rocm_mpm_g2p2g_slots.restype = i32
     L.zs_rocm_mpm_partition_edge.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.zs_rocm_mpm_slot_compute_sparsity.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+    L.zs_rocm_mpm_reslot.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.zs_rocm_mpm_reslot.restype = i32
     L.zs_rocm_mpm_step_slotted.argtypes = [vp, C.POINTER(MpmStep)]
     L.zs_rocm_mpm_step_slotted.restype = i32
     L.zs_rocm_dist_halo_plan_from_lists.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),

@@ -330,6 +330,68 @@ static __global__ __launch_bounds__(256) void slot_commit_kernel(unsigned *cellM
   claim[ncells + c] = 0u;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ re-partition in place
+// ComputeSparsity (simulation/sparsity/SparsityOp.hpp:65-86) from the occupancy words: a particle is stored under the cell c of its base node, the
+// reference inserts the block of (base node + 1 - 2) = c - 1 per axis -- no particle is read.  One thread per cell of the old partition.
+template <int SIDE>
+static __global__ __launch_bounds__(256) void slot_sparsity_kernel(BhtDev oldT, const unsigned *cellMask, size_t ncells, int kscale, BhtDev newT) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = c < ncells && cellMask[c] != 0u;
+  int b[3] = {0, 0, 0};
+  if (valid) {
+    const size_t bin = c >> 6;
+    const int lane = (int)(c & 63), blk = (int)(bin / bins_per_block<SIDE>()), sub = (int)(bin % bins_per_block<SIDE>());
+    const int o[3] = {SIDE == 4 ? 0 : ((sub >> 2) & 1) * 4, SIDE == 4 ? 0 : ((sub >> 1) & 1) * 4, SIDE == 4 ? 0 : (sub & 1) * 4};
+    const int l[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b[d] = floordiv(oldT.activeKeys[3 * (size_t)blk + d] * (SIDE / kscale) + o[d] + l[d] - 1, SIDE) * kscale;
+  }
+  const int px = shfl_up(b[0], 1), py = shfl_up(b[1], 1), pz = shfl_up(b[2], 1);
+  const bool pvalid = shfl_up((int)valid, 1) != 0;
+  const bool dup = lane_id() != 0 && pvalid && px == b[0] && py == b[1] && pz == b[2];
+  if (valid && !dup) bht_insert<3>(newT, b);
+}
+// map[i] = number of old block i in the new partition (-1: not there)
+static __global__ __launch_bounds__(256) void reslot_map_kernel(BhtDev oldT, int nOld, BhtDev newT, int *map) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= nOld) return;
+  const int k[3] = {oldT.activeKeys[3 * (size_t)i], oldT.activeKeys[3 * (size_t)i + 1], oldT.activeKeys[3 * (size_t)i + 2]};
+  map[i] = bht_query<3>(newT, k);
+}
+// one workgroup per old bin: its occupancy words and its occupied rounds (whole tile rows: rounds x C channels x 64 lanes are contiguous)
+// move to the bin's place in the new partition
+static __global__ __launch_bounds__(256) void reslot_move_kernel(const int *map, int bpb, int K, int C, const float4 *oldBuf, float4 *newBuf,
+                                                                 const unsigned *oldMask, unsigned *newMask, int *status) {
+  const size_t bin = blockIdx.x;
+  __shared__ unsigned sAny;
+  if (threadIdx.x == 0) sAny = 0u;
+  __syncthreads();
+  const unsigned m = threadIdx.x < 64 ? oldMask[bin * 64 + threadIdx.x] : 0u;
+  if (m) atomicOr(&sAny, m);
+  __syncthreads();
+  const unsigned any = sAny;
+  if (!any) return;
+  const int nb = map[bin / bpb];
+  if (nb < 0) {
+    if (threadIdx.x == 0) status[2] = 1;  // a block that holds particles is not in the new partition (cannot happen with slot_sparsity + enlarge)
+    return;
+  }
+  const size_t nbin = (size_t)nb * bpb + bin % bpb;
+  if (threadIdx.x < 64) newMask[nbin * 64 + threadIdx.x] = m;
+  const int rounds = 32 - __clz((int)any);
+  const size_t per = (size_t)K * C * 16, cnt = (size_t)rounds * C * 16;  // float4 per bin / to copy
+  const float4 *src = oldBuf + bin * per;
+  float4 *dst = newBuf + nbin * per;
+  for (size_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+}
+// grid blocks (7 channels x side^3 cells) of the old partition -> their place in the new one
+static __global__ __launch_bounds__(256) void reslot_grid_kernel(const int *map, int nOld, int blockFloats4, const float4 *oldGrid, float4 *newGrid) {
+  const int b = blockIdx.x;
+  const int nb = map[b];
+  if (nb < 0) return;
+  for (int i = threadIdx.x; i < blockFloats4; i += 256) newGrid[(size_t)nb * blockFloats4 + i] = oldGrid[(size_t)b * blockFloats4 + i];
+}
+
 }  // namespace zsr
 
 using namespace zsr;
@@ -507,6 +569,43 @@ void zs_rocm_mpm_partition_edge(zs_rocm_policy *pol, const zs_rocm_bht_3 *tab, u
   if (!nb) return;
   hipLaunchKernelGGL(partition_edge_kernel, dim3(ceil_div((size_t)nb, 256)), dim3(256), 0, L.stream, tab->t.dev(), nb, edge,
                      keyStride > 0 ? keyStride : 1, lo, hi);
+}
+
+// ---- re-partition of slotted storage without touching a particle.  (1) zs_rocm_mpm_slot_compute_sparsity: the reference's ComputeSparsity
+// over the cells that hold particles (from the occupancy words) into `newTab` (reset by the caller); the caller then enlarges it
+// (zs_rocm_mpm_enlarge_sparsity) exactly as for a fresh partition.  (2) zs_rocm_mpm_reslot: every bin that holds particles moves, as
+// whole tile rows, to the number its block has in `newTab`; newMask / newGrid (optional: the grid of node velocities the next fused step
+// gathers from) are written for the whole new partition (zero where nothing was).  Returns 0, -1 on bad arguments; status[2] is set if a
+// populated block is missing from the new partition.
+void zs_rocm_mpm_slot_compute_sparsity(zs_rocm_policy *pol, const zs_rocm_bht_3 *oldTab, const unsigned *cellMask, size_t nblocksOld, int side,
+                                       int keyIsOrigin, zs_rocm_bht_3 *newTab) {
+  Launch L(pol, "slot_compute_sparsity");
+  if (!nblocksOld || (side != 4 && side != 8)) return;
+  const size_t ncells = nblocksOld * (side == 4 ? 1 : 8) * 64;
+  if (side == 4)
+    hipLaunchKernelGGL((slot_sparsity_kernel<4>), dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, oldTab->t.dev(), cellMask, ncells, keyIsOrigin ? side : 1, newTab->t.dev());
+  else
+    hipLaunchKernelGGL((slot_sparsity_kernel<8>), dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, oldTab->t.dev(), cellMask, ncells, keyIsOrigin ? side : 1, newTab->t.dev());
+}
+int zs_rocm_mpm_reslot(zs_rocm_policy *pol, const zs_rocm_bht_3 *oldTab, const zs_rocm_bht_3 *newTab, int side, int K, int C, const float *oldBuf,
+                       float *newBuf, const unsigned *oldMask, unsigned *newMask, const float *oldGrid, float *newGrid, int *status) {
+  if ((side != 4 && side != 8) || K < 1 || K > 32 || C < 1 || !oldBuf || !newBuf || !oldMask || !newMask || !status) return -1;
+  Launch L(pol, "reslot");
+  const int nOld = bht_size(oldTab->t, L.stream), nNew = bht_size(newTab->t, L.stream);
+  if (!nOld || !nNew) return 0;
+  const int bpb = side == 4 ? 1 : 8;
+  int *map = (int *)L.temp(sizeof(int) * (size_t)nOld);
+  hipLaunchKernelGGL(reslot_map_kernel, dim3(ceil_div((size_t)nOld, 256)), dim3(256), 0, L.stream, oldTab->t.dev(), nOld, newTab->t.dev(), map);
+  ZSR_CHECK(hipMemsetAsync(newMask, 0, sizeof(unsigned) * (size_t)nNew * bpb * 64, L.stream));
+  hipLaunchKernelGGL(reslot_move_kernel, dim3((unsigned)((size_t)nOld * bpb)), dim3(256), 0, L.stream, (const int *)map, bpb, K, C,
+                     reinterpret_cast<const float4 *>(oldBuf), reinterpret_cast<float4 *>(newBuf), oldMask, newMask, status);
+  if (oldGrid && newGrid) {
+    const size_t bf = (size_t)7 * side * side * side;
+    ZSR_CHECK(hipMemsetAsync(newGrid, 0, sizeof(float) * bf * (size_t)nNew, L.stream));
+    hipLaunchKernelGGL(reslot_grid_kernel, dim3((unsigned)nOld), dim3(256), 0, L.stream, (const int *)map, nOld, (int)(bf / 4),
+                       reinterpret_cast<const float4 *>(oldGrid), reinterpret_cast<float4 *>(newGrid));
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -242,6 +242,53 @@ class MpmTransfer:
                                         self.mover_dest.data_ptr(), self.mover_rec.data_ptr(), self.outbox_cap, self.slot_status.data_ptr(),
                                         self.block_edge.data_ptr())
 
+    def repartition_slotted(self, margin=0, strict=True):
+        """Re-partition IN PLACE (zs_rocm_mpm_slot_compute_sparsity + enlarge + zs_rocm_mpm_reslot): the new partition is the reference's
+        ComputeSparsity + EnlargeSparsity over the cells that hold particles (taken from the occupancy words: no particle is read), every
+        populated bin moves as whole tile rows to its block's new number, the grid of node velocities (self.grid: what the next fused step
+        gathers from) is carried over.  Single rank only (particles do not change owner).  Returns the new number of blocks."""
+        assert self.slotted and self.L == 64
+        L = lib()
+        self.check_slots(strict=strict)                      # fold the period's status words into slot_record first
+        old_table, old_nblocks = self.table, self.nblocks
+        new_table = Bht(3, max(int(old_nblocks * 1.5) + 64, 4096))
+        L.zs_rocm_mpm_slot_compute_sparsity(self.pol.handle, old_table.handle, self.cell_mask.data_ptr(), old_nblocks, self.side,
+                                            int(self.key_is_origin), new_table.handle)
+        m = int(margin)
+        lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
+        L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, new_table.handle, lo, hi, self.kstride)
+        self.pol.syncCtx()
+        nb = new_table.size()
+        bpb = (self.side // 4) ** 3
+        nbins = nb * bpb
+        nc = self.side ** 3
+        sbuf = torch.empty(nbins * self.K * 64 * self.nchn, dtype=torch.float32, device=self.device)
+        mask = torch.empty(nbins * 64, dtype=torch.int32, device=self.device)
+        grid = torch.empty(nb * 7 * nc, dtype=torch.float32, device=self.device)
+        if L.zs_rocm_mpm_reslot(self.pol.handle, old_table.handle, new_table.handle, self.side, self.K, self.nchn, self.buf.data_ptr(),
+                                sbuf.data_ptr(), self.cell_mask.data_ptr(), mask.data_ptr(), self.grid.data_ptr(), grid.data_ptr(),
+                                self.slot_status.data_ptr()) != 0:
+            raise RuntimeError("zs_rocm_mpm_reslot refused its arguments")
+        self.table, self.nblocks, self.nbins, self.n_slots = new_table, nb, nbins, nbins * self.K * 64
+        self.buf, self.cell_mask, self.grid, self.grid2 = sbuf, mask, grid, None
+        self.nbr = torch.empty(nb * 8, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr(), self.kstride)
+        self.nbr27 = torch.empty(nb * 27, dtype=torch.int32, device=self.device)
+        L.zs_rocm_mpm_build_neighbors27(self.pol.handle, self.table.handle, self.nbr27.data_ptr(), self.kstride)
+        self.block_edge = torch.empty(max(nb, 1), dtype=torch.uint8, device=self.device)
+        L.zs_rocm_mpm_partition_edge(self.pol.handle, self.table.handle, self.block_edge.data_ptr(), self.kstride, -1, 2)
+        self.mover_count = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 0) // 4, dtype=torch.int32, device=self.device)
+        self.mover_dest = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 1) // 4, dtype=torch.int32, device=self.device)
+        self.mover_rec = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 2) // 4, dtype=torch.float32, device=self.device)
+        self._edge_host = self._edge_event = None
+        self.slot_storage = SlotStorage(self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(), self.nbr27.data_ptr(), self.mover_count.data_ptr(),
+                                        self.mover_dest.data_ptr(), self.mover_rec.data_ptr(), self.outbox_cap, self.slot_status.data_ptr(),
+                                        self.block_edge.data_ptr())
+        self.pol.syncCtx()
+        if int(self.slot_status[2].item()):
+            raise RuntimeError("repartition_slotted: a populated block is missing from the new partition")
+        return nb
+
     def _compact_copy(self):
         """(compact TileVector buffer of the occupied slots in slot order, particle count)"""
         L = lib()
