@@ -552,6 +552,8 @@ def main():
         prime_grid()
         if a.slotted:
             mt.slot(K=a.slot_rounds, outbox_cap=a.outbox_cap)
+            if inplace_remap:
+                mt.reserve_repartition_buffers()   # (setup, untimed: the second slot buffer a re-partition in place moves the bins into)
         unfused_step = step
         step = lambda timed, write_all=False, reorder=False: step_fused(timed, write_all, reorder)
     def barrier():

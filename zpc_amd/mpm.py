@@ -242,6 +242,29 @@ class MpmTransfer:
                                         self.mover_dest.data_ptr(), self.mover_rec.data_ptr(), self.outbox_cap, self.slot_status.data_ptr(),
                                         self.block_edge.data_ptr())
 
+    def _backing(self, name, numel, dtype, zero=False, spare=False):
+        """a view of `numel` elements of a grow-only backing tensor kept under `name`: a re-partition every ~100 steps must not pay a
+        hipMalloc of tens of GB each time (0.5-1 s for the 43 GB slot buffer of the 64 Mi-particle column)"""
+        pool = self.__dict__.setdefault("_pool", {})
+        t = pool.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(int(numel * (1.25 if spare else 1.0)) + 64, dtype=dtype, device=self.device)
+            pool[name] = t
+        v = t[:numel]
+        if zero:
+            self._zero(v)
+        return v
+
+    def reserve_repartition_buffers(self, growth=1.25):
+        """allocate, outside any timed region, what repartition_slotted() will need: the second slot buffer (the two are used in turns)
+        and the per-partition arrays, sized for a partition `growth` times today's"""
+        assert self.slotted
+        n = int(self.buf.numel() * growth)
+        pool = self.__dict__.setdefault("_pool", {})
+        if "slots_alt" not in pool or pool["slots_alt"].numel() < n:
+            pool["slots_alt"] = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.pol.syncCtx()
+
     def repartition_slotted(self, margin=0, strict=True):
         """Re-partition IN PLACE (zs_rocm_mpm_slot_compute_sparsity + enlarge + zs_rocm_mpm_reslot): the new partition is the reference's
         ComputeSparsity + EnlargeSparsity over the cells that hold particles (taken from the occupancy words: no particle is read), every
@@ -262,24 +285,36 @@ class MpmTransfer:
         bpb = (self.side // 4) ** 3
         nbins = nb * bpb
         nc = self.side ** 3
-        sbuf = torch.empty(nbins * self.K * 64 * self.nchn, dtype=torch.float32, device=self.device)
-        mask = torch.empty(nbins * 64, dtype=torch.int32, device=self.device)
-        grid = torch.empty(nb * 7 * nc, dtype=torch.float32, device=self.device)
+        # the two slot buffers are used in turns (the one being left becomes the spare)
+        pool = self.__dict__.setdefault("_pool", {})
+        need = nbins * self.K * 64 * self.nchn
+        alt = pool.get("slots_alt")
+        if alt is None or alt.numel() < need:
+            alt = torch.empty(int(need * 1.1), dtype=torch.float32, device=self.device)
+        sbuf = alt[:need]
+        old_store = pool.get("slots_cur", self.buf)
+        flip = self.__dict__.get("_flip", 0) ^ 1
+        self._flip = flip
+        mask = self._backing("mask%d" % flip, nbins * 64, torch.int32)
+        grid = self._backing("grid%d" % flip, nb * 7 * nc, torch.float32)
         if L.zs_rocm_mpm_reslot(self.pol.handle, old_table.handle, new_table.handle, self.side, self.K, self.nchn, self.buf.data_ptr(),
                                 sbuf.data_ptr(), self.cell_mask.data_ptr(), mask.data_ptr(), self.grid.data_ptr(), grid.data_ptr(),
                                 self.slot_status.data_ptr()) != 0:
             raise RuntimeError("zs_rocm_mpm_reslot refused its arguments")
+        self.pol.syncCtx()                                   # the old buffers are read until here
+        pool["slots_cur"], pool["slots_alt"] = alt, old_store
         self.table, self.nblocks, self.nbins, self.n_slots = new_table, nb, nbins, nbins * self.K * 64
-        self.buf, self.cell_mask, self.grid, self.grid2 = sbuf, mask, grid, None
-        self.nbr = torch.empty(nb * 8, dtype=torch.int32, device=self.device)
+        self.buf, self.cell_mask, self.grid = sbuf, mask, grid
+        self.grid2 = self._backing("gridB%d" % flip, nb * 7 * nc, torch.float32, zero=True)
+        self.nbr = self._backing("nbr", nb * 8, torch.int32, spare=True)
         L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr(), self.kstride)
-        self.nbr27 = torch.empty(nb * 27, dtype=torch.int32, device=self.device)
+        self.nbr27 = self._backing("nbr27", nb * 27, torch.int32, spare=True)
         L.zs_rocm_mpm_build_neighbors27(self.pol.handle, self.table.handle, self.nbr27.data_ptr(), self.kstride)
-        self.block_edge = torch.empty(max(nb, 1), dtype=torch.uint8, device=self.device)
+        self.block_edge = self._backing("edge", max(nb, 1), torch.uint8, spare=True)
         L.zs_rocm_mpm_partition_edge(self.pol.handle, self.table.handle, self.block_edge.data_ptr(), self.kstride, -1, 2)
-        self.mover_count = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 0) // 4, dtype=torch.int32, device=self.device)
-        self.mover_dest = torch.zeros(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 1) // 4, dtype=torch.int32, device=self.device)
-        self.mover_rec = torch.empty(L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 2) // 4, dtype=torch.float32, device=self.device)
+        self.mover_count = self._backing("mcount", L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 0) // 4, torch.int32, zero=True, spare=True)
+        self.mover_dest = self._backing("mdest", L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 1) // 4, torch.int32, zero=True, spare=True)  # claim words: zero between steps
+        self.mover_rec = self._backing("mrec", L.zs_rocm_mpm_slot_outbox_bytes(nbins, self.outbox_cap, 2) // 4, torch.float32, spare=True)
         self._edge_host = self._edge_event = None
         self.slot_storage = SlotStorage(self.cell_mask.data_ptr(), self.K, self.nbr.data_ptr(), self.nbr27.data_ptr(), self.mover_count.data_ptr(),
                                         self.mover_dest.data_ptr(), self.mover_rec.data_ptr(), self.outbox_cap, self.slot_status.data_ptr(),
