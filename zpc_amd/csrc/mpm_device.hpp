@@ -1243,7 +1243,6 @@ template <int LW> __device__ __forceinline__ size_t p2gw_tile_base(const Particl
 //   momentum d: alpha = m (v_d + C[d, :] . (dx - lp)), b_k = m dx C[d + 3 k];  force d: alpha = kscale S[d, :] . (dx - lp), b_k = kscale dx S[d, k]
 // (S = the symmetric P F^T vol), then per node W_abc (alpha + (a - 1) bx + (b - 1) by + (c - 1) bz): the offsets x_i - x_p and the products
 // C (x_i - x_p) are no longer rebuilt per node, and ONE weight product W_abc serves all seven channels.
-#ifndef ZS_P2GW_CLASSIC
 __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
   const float m = rec[0];
   float lc[3];  // centre node - particle
@@ -1290,78 +1289,6 @@ __device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &a
     }
   }
 }
-#else
-__device__ __forceinline__ void p2gw_accumulate(const MpmDev &mp, const Arena &ar, const float *rec, float kscale, float (&acc)[27][7]) {
-  const float m = rec[0];
-  float xo[3][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) xo[d][k] = (float)k * mp.dx - ar.lp[d];
-  {  // ---- mass + momentum: W m (v + C (xi - xp))
-    float Px[3][3], Py[3][3], Pz[3][3], wzm[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float v = rec[(4 + d) * 64], c0 = rec[(7 + d) * 64], c1 = rec[(10 + d) * 64], c2 = rec[(13 + d) * 64];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Px[k][d] = c0 * xo[0][k];
-        Py[k][d] = c1 * xo[1][k];
-        Pz[k][d] = fmaf(c2, xo[2][k], v);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wzm[k] = ar.w[2][k] * m;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float wxy = ar.w[0][a] * ar.w[1][bb];
-        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float Wm = wxy * wzm[c];
-          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
-          A[0] += Wm;
-          A[1] = fmaf(Wm, q0 + Pz[c][0], A[1]);
-          A[2] = fmaf(Wm, q1 + Pz[c][1], A[2]);
-          A[3] = fmaf(Wm, q2 + Pz[c][2], A[3]);
-        }
-      }
-  }
-  {  // ---- stress: W kscale (P F^T vol) (xi - xp)
-    float Px[3][3], Py[3][3], Pz[3][3], wzk[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      // row d of the symmetric P F^T vol {xx, xy, xz, yy, yz, zz} (rows 16..21 of the record)
-      const float c0 = rec[(16 + d) * 64], c1 = rec[(16 + (d == 0 ? 1 : d == 1 ? 3 : 4)) * 64], c2 = rec[(16 + (d == 0 ? 2 : d == 1 ? 4 : 5)) * 64];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Px[k][d] = c0 * xo[0][k];
-        Py[k][d] = c1 * xo[1][k];
-        Pz[k][d] = c2 * xo[2][k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wzk[k] = ar.w[2][k] * kscale;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float wxy = ar.w[0][a] * ar.w[1][bb];
-        const float q0 = Px[a][0] + Py[bb][0], q1 = Px[a][1] + Py[bb][1], q2 = Px[a][2] + Py[bb][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float Wk = wxy * wzk[c];
-          float(&A)[7] = acc[(a * 3 + bb) * 3 + c];
-          A[4] = fmaf(Wk, q0 + Pz[c][0], A[4]);
-          A[5] = fmaf(Wk, q1 + Pz[c][1], A[5]);
-          A[6] = fmaf(Wk, q2 + Pz[c][2], A[6]);
-        }
-      }
-  }
-}
-#endif
 
 // LDS arena shared by the G bins of one workgroup of p2g_wide_kernel: G = 1 one bin (6^3 nodes, ArenaLds), G = 2 the two bins of a
 // block that are neighbours in z (4 x 4 x 8 cells, 6 x 6 x 10 nodes), G = 4 the four bins of a half block (4 x 8 x 8 cells, 6 x 10 x 10

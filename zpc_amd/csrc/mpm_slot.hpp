@@ -443,11 +443,7 @@ __device__ __forceinline__ bool slot_produce_entry(const MpmDev &mp, const Parti
     }
     {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
       float lj = plj;
-#ifdef ZS_ABL_NOSVD
-      for (int d = 0; d < 9; ++d) PF[d] = F[d] * mp.mat.volume;
-#else
       model_stress<SMODEL>(mp.mat, lj, F, PF, C);
-#endif
       if (outbox) {
         if (rec) {
           rec[0] = pm;

@@ -185,9 +185,6 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
   constexpr bool FLUID = model_is_fluid(SMODEL);
   const int bin0 = blk * 8;
   const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
-#ifdef ZS_BLK_PRIO
-  __builtin_amdgcn_s_setprio(ZS_BLK_PRIO);
-#endif
   RecG<LW, DP, FLUID> cur, nxt;
   bool has0 = false, has1 = false;
   size_t i0 = 0, i1 = 0;
@@ -342,11 +339,7 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
         const unsigned p = sh.arrQ[par][lane][ai++];
         spos = (int)(p >> 6) * (G2P2G_QF * 64) + (int)(p & 63u);
       }
-#ifdef ZS_ABL_HALFCONS
-      if (spos >= 0 && (r & 1)) g2p2g_consume_set<CS>(mp, stage, spos, acc);
-#else
       if (spos >= 0) g2p2g_consume_set<CS>(mp, stage, spos, acc);
-#endif
     }
     {
       const int nx = sh.xCnt[par] < (unsigned)SL_XQ ? (int)sh.xCnt[par] : SL_XQ;
