@@ -672,7 +672,7 @@ def main():
     slot_probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_slot_probe")  # -DZS_PROBE build of mpm_slotted.hip
     if probe or slot_probe:
         import ctypes
-        pv = (ctypes.c_ulonglong * 16)()
+        pv = (ctypes.c_ulonglong * 32)()
         (lib().zs_rocm_slot_probe if slot_probe else lib().zs_rocm_debug_probe)(pv, 1)
     t0 = time.perf_counter()
     run_steps(a.steps, True)
@@ -686,6 +686,10 @@ def main():
                  "cons barrier wait", "cons flush", "tail", "wgs", "list entries", "cons: rounds loop", "cons: atomic list", "cons: loop iterations"]
         print("slot probe (cycles per sampled workgroup; 100 MHz s_memtime ticks x ?): " +
               "  ".join("%s=%.0f" % (names[k], pv[k] / wgs) for k in range(16) if k != 11) + "  wgs=%d" % wgs, file=sys.stderr)
+        if any(pv[k] for k in range(16, 32)):  # block kernel: the producer wave's chunk iteration by segment
+            seg = ["top of iteration (hand-over, prefetch, tables)", "arena + gather", "advection + F", "movers + stores", "constitutive update",
+                   "tail stores", "ring wait", "staging", "vmcnt(0) before the barrier"]
+            print("producer segments (cycles per sampled workgroup): " + "  ".join("%s=%.0f" % (seg[k], pv[16 + k] / wgs) for k in range(9)), file=sys.stderr)
     if probe:
         lib().zs_rocm_debug_probe(pv, 0)
         wgs = max(int(pv[7]), 1)

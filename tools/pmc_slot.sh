@@ -3,11 +3,14 @@
 tag=${1:-x}; steps=${2:-40}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+# counter groups: $PMC_GROUPS (semicolon separated) or the default two
+DEF="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY;SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+IFS=';' read -ra GROUPS_ <<< "${PMC_GROUPS:-$DEF}"
+for grp in "${GROUPS_[@]}"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$R/gpurun_out/pmc_$tag/$name
   mkdir -p $out
-  timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-at-rest > $out/bench.json 2> $out/stderr.txt
+  timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "g2p2g_slot" --pmc $grp --output-format csv -d $out -o pmc -- python $R/bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-at-rest $PMC_BENCH_FLAGS > $out/bench.json 2> $out/stderr.txt
   f=$(find $out -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

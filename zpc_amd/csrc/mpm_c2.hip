@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void c2_particle_kernel(MpmDev mp, ParticlesDe
   // records are laid out in bucket order (a bucket's particles are one contiguous run); the particle attributes are read in storage
   // order (coalesced AoSoA rows) and the 64-byte record is the scattered access
   const size_t slot = (size_t)slotOf[i];
-  const float dx = mp.dx, dxi = 1.0f / dx;
+  const float dx = mp.dx, dxi = mp.dxi;
   float pos[3], vel[3] = {0.f, 0.f, 0.f}, C[9], Q[9], Dinv[3];
   load_attr<3>(ps.pos, i, pos);
   load_attr<9>(ps.C, i, C);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void p2c2g_cell_kernel(MpmDev mp, BhtDev t, C2
   __shared__ int2 range[NH];
   __shared__ unsigned long long octs[NH];
   const int b = blockIdx.x;
-  const float dx = mp.dx, dxi = 1.0f / dx;
+  const float dx = mp.dx, dxi = mp.dxi;
   int org[3];
   c2_cell_coord<SIDE>(t, b, 0, mp.kscale, org);
   for (int h = threadIdx.x; h < NH; h += blockDim.x) {
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(128) void p2c2g_cell8_kernel(MpmDev mp, BhtDev t, C
   __shared__ int2 range[NB * NH];
   __shared__ unsigned long long octs[NB * NH];
   const int b0 = blockIdx.x * NB;
-  const float dx = mp.dx, dxi = 1.0f / dx;
+  const float dx = mp.dx, dxi = mp.dxi;
   for (int h = threadIdx.x; h < NB * NH; h += TPB) {
     const int b = b0 + h / NH, hh = h % NH;
     int2 r = make_int2(0, 0);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void g2c2p_particle_kernel(MpmDev mp, Particle
   constexpr int NC = SIDE * SIDE * SIDE;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
-  const float dx = mp.dx, dxi = 1.0f / dx;
+  const float dx = mp.dx, dxi = mp.dxi;
   float pos[3], v[3] = {0.f, 0.f, 0.f}, B[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   load_attr<3>(ps.pos, i, pos);
   if constexpr (!STEP) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void pre_g2c2p_kernel(ParticlesDev ps) {  // G
 template <bool FLUID> __global__ __launch_bounds__(256) void post_g2c2p_kernel(MpmDev mp, ParticlesDev ps) {  // G2C2P.hpp:235-270
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
-  const float dx = mp.dx, dxi = 1.0f / dx;
+  const float dx = mp.dx, dxi = mp.dxi;
   float pos[3], vel[3], C[9], oldF[9], F[9];
   load_attr<3>(ps.pos, i, pos);
   load_attr<3>(ps.vel, i, vel);

@@ -218,6 +218,12 @@ struct Material {
   float bm, xi, Msqr;          // NACC: bulk modulus NACCConfig::bulk(), hardening factor, M^2
   int hardeningOn;
   float bulk, viscosity;       // EquationOfState
+  // derived on the host once (make_dev) so that the kernels find them in SGPRs: computed per wave they are loop invariants the compiler
+  // hoists into VGPRs, and in the 128-register fused kernels every such register is a spill (r05: scratch reloads behind the record
+  // prefetch = a full memory latency per chunk)
+  float smu;                   // 2 mu
+  float dpCoef;                // DruckerPrager: (3 lam + 2 mu) / (2 mu)
+  float expCohesion;           // DruckerPrager: exp(cohesion)
 };
 
 // compute_stress_fixedcorotated (cuda/physics/ConstitutiveModel.hpp:10-47).  The reference forms P = U diag(Phat) V^T and
@@ -247,7 +253,7 @@ template <bool WRITE_F>
 __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, float (&F)[9], float (&PF)[9]) {
   float U[3][3], S[3], V[3][3], B[3][3];
   svd3_core<WRITE_F, false>(F, U, S, V, B);
-  const float smu = 2.f * m.mu;
+  const float smu = m.smu;
   float eps[3], NS[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -264,13 +270,13 @@ __device__ __forceinline__ void stress_sand(const Material &m, float &logJp, flo
   bool newF = false;
   float Hs[3] = {0.f, 0.f, 0.f};  // log of the projected singular values
   if (tr >= 0.f) {  // case II: cone tip
-    NS[0] = NS[1] = NS[2] = expf(m.cohesion);
+    NS[0] = NS[1] = NS[2] = m.expCohesion;
     Hs[0] = Hs[1] = Hs[2] = m.cohesion;
     newF = true;
     if (m.volCorrection) logJp = m.beta * sum_eps + logJp;
   } else if (m.mu != 0.f) {
     logJp = 0.f;
-    const float dg = ehn + (3.f * m.lam + smu) / smu * tr * m.yieldSurface;
+    const float dg = ehn + m.dpCoef * tr * m.yieldSurface;
     float H[3];
     if (dg <= 0.f) {  // case I: inside the cone
 #pragma unroll
@@ -467,6 +473,9 @@ __device__ __forceinline__ void model_stress(const Material &m, float &logJp, fl
 }
 
 // ======================================================================================= arena
+// node k (0, 1, 2) of the stencil minus the local position, k dx - lp -- written without the product (k dx is a loop invariant the compiler
+// would keep in a VGPR; 2 dx is exact, so the fma returns the same bits, and 0 dx - lp = -lp up to the sign of a zero)
+__device__ __forceinline__ float node_off(float dx, int k, float lp) { return k == 0 ? -lp : (k == 1 ? dx - lp : fmaf(2.f, dx, -lp)); }
 // LocalArena<collocated, quadratic> (simulation/Utils.hpp:47-75, InterpolationKernel.hpp:47-55,93-130)
 struct Arena {
   int corner[3];
@@ -476,8 +485,7 @@ struct Arena {
 // X = pos * (1/dx): the reference divides (simulation/Utils.hpp:52-55); the product differs by <= 1 ulp, which moves
 // a weight by O(1e-7) and never changes which bin a particle is stored in because the binning kernel uses this
 // same expression.
-__device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Arena &a) {
-  const float dxinv = 1.0f / dx;
+__device__ __forceinline__ void make_arena(float dx, float dxinv, const float (&pos)[3], Arena &a) {
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const float X = pos[d] * dxinv;
@@ -493,6 +501,7 @@ __device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Aren
     a.lp[d] = lpn * dx;
   }
 }
+__device__ __forceinline__ void make_arena(float dx, const float (&pos)[3], Arena &a) { make_arena(dx, 1.0f / dx, pos, a); }
 
 __device__ __forceinline__ int floordiv(int a, int b) { return (a + (a < 0 ? -b + 1 : 0)) / b; }
 
@@ -610,6 +619,8 @@ struct MpmDev {
   Material mat;
   int model;
   float dx, dt;
+  float dxi, D_inv;  // 1 / dx, 4 / dx^2 (host-derived: see Material)
+  float fscale, fscaleDx;  // -dt D_inv (contrib = -dt D_inv P F^T vol, P2G.hpp:105), and that times dx
   int kscale;  // partition keys are block coordinates (1: Grids + HashTable/bht convention) or block ORIGINS in cells
                // (SIDE: SparseGrid convention, geometry/SparseGrid.hpp:305-309)
 };
@@ -874,7 +885,7 @@ __device__ __forceinline__ void p2g_scatter_global(const MpmDev &mp, const Parti
   const float mass = ps.mass.base[ps.mass.off(i)];
   particle_contrib<MODEL>(mp, ps, i, D_inv, contrib);
   Arena ar;
-  make_arena(mp.dx, pos, ar);
+  make_arena(mp.dx, mp.dxi, pos, ar);
   int loc[3], key[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -919,7 +930,7 @@ template <int SIDE, int MODEL>
 static __global__ __launch_bounds__(256) void p2g_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
-  const float dxi = 1.0f / mp.dx;
+  const float dxi = mp.dxi;
   p2g_scatter_global<SIDE, MODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
 }
 
@@ -1021,8 +1032,8 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
 
   float *a0 = arena + AL::at(cx, cy, cz);
   __syncthreads();
@@ -1046,7 +1057,7 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
       if (has1) nxt.load(ps, (size_t)i1);  // in flight while the current round is computed
       if (has0) {
         Arena ar;
-        make_arena(mp.dx, cur.pos, ar);
+        make_arena(mp.dx, mp.dxi, cur.pos, ar);
         if (ar.corner[0] - geo.org[0] != cx || ar.corner[1] - geo.org[1] != cy || ar.corner[2] - geo.org[2] != cz) {
           stale[atomicAdd(staleCount, 1)] = i0;  // left its cell since the last re-binning: exact path afterwards
         } else {
@@ -1114,7 +1125,7 @@ static __global__ __launch_bounds__(64, 2) void p2g_binned_kernel(MpmDev mp, Par
       if (has1) nxt.load(ps, (size_t)i1);
       if (has0) {
         Arena ar;
-        make_arena(mp.dx, cur.pos, ar);
+        make_arena(mp.dx, mp.dxi, cur.pos, ar);
         if (ar.corner[0] - geo.org[0] == cx && ar.corner[1] - geo.org[1] == cy && ar.corner[2] - geo.org[2] == cz) {
           float contrib[9];
           if constexpr (MODEL == MPM_CACHED_STRESS) {
@@ -1338,8 +1349,8 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
   const BinGeom<SIDE> geo(t, bin, mp.kscale);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const unsigned cnt = start == end ? 0u : cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);  // contrib = -dt D_inv (P F^T vol)
+  const float dxi = mp.dxi;
+  const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
   float acc[27][7];
 #pragma unroll
   for (int k = 0; k < 27; ++k)
@@ -1384,7 +1395,7 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
       const float *rec = pbuf[slot] + lane;
       const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
       Arena ar;
-      make_arena(mp.dx, pos, ar);
+      make_arena(mp.dx, mp.dxi, pos, ar);
       const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
       if (ocx == cx && ocy == cy && ocz == cz) {
         p2gw_accumulate(mp, ar, rec, kscale, acc);
@@ -1437,7 +1448,7 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
 #pragma unroll
       for (int d = 0; d < 9; ++d) PF[d] *= kscale;
       Arena ar;
-      make_arena(mp.dx, pos, ar);
+      make_arena(mp.dx, mp.dxi, pos, ar);
       float *b0 = arena + AL::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1] + ay, ar.corner[2] - geo.org[2] + az);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -1482,7 +1493,7 @@ template <int SIDE, int MODEL>
 static __global__ __launch_bounds__(256) void p2g_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *stale,
                                                         const int *staleCount) {
   const int n = *staleCount;
-  const float dxi = 1.0f / mp.dx;
+  const float dxi = mp.dxi;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
     p2g_scatter_global<SIDE, MODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
 }
@@ -1572,7 +1583,7 @@ __device__ __forceinline__ void g2p_gather_global(const MpmDev &mp, const Partic
   float pos[3];
   load_attr<3>(ps.pos, i, pos);
   Arena ar;
-  make_arena(mp.dx, pos, ar);
+  make_arena(mp.dx, mp.dxi, pos, ar);
   int loc[3], key[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -1621,7 +1632,7 @@ template <int SIDE, int SMODEL>
 static __global__ __launch_bounds__(256) void g2p_global_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ps.n) return;
-  const float dxi = 1.0f / mp.dx;
+  const float dxi = mp.dxi;
   g2p_gather_global<SIDE, SMODEL>(mp, ps, i, t, grid, 4.f * dxi * dxi);
 }
 
@@ -1633,9 +1644,9 @@ __device__ __forceinline__ void g2p_gather_factorized(const MpmDev &mp, const Ar
   float xz[3], xy[3], xx[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
-    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
-    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
+    xx[k] = ar.w[0][k] * node_off(mp.dx, k, ar.lp[0]);
+    xy[k] = ar.w[1][k] * node_off(mp.dx, k, ar.lp[1]);
+    xz[k] = ar.w[2][k] * node_off(mp.dx, k, ar.lp[2]);
   }
   float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // B[j][k]
 #pragma unroll
@@ -1710,8 +1721,8 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
     }
   }
   const unsigned cnt = cellCount[(size_t)bin * 64 + lane];
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
   RoundWalk walk(cnt, start);
   int i0, i1;
   bool any, any1;
@@ -1724,7 +1735,7 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
     if (has1) nxt.load(ps, (size_t)i1);
     if (has0) {
       Arena ar;
-      make_arena(mp.dx, cur.pos, ar);
+      make_arena(mp.dx, mp.dxi, cur.pos, ar);
       const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
       if (ocx == cx && ocy == cy && ocz == cz) {
         float vel[3], C[9];
@@ -1750,7 +1761,7 @@ template <int SIDE, int SMODEL>
 static __global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *stale,
                                                         const int *staleCount) {
   const int n = *staleCount;
-  const float dxi = 1.0f / mp.dx;
+  const float dxi = mp.dxi;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
     g2p_gather_global<SIDE, SMODEL>(mp, ps, (size_t)stale[j], t, grid, 4.f * dxi * dxi);
 }
@@ -1784,9 +1795,9 @@ __device__ __forceinline__ void g2p_gather_lds(const MpmDev &mp, const Arena &ar
   float xz[3], xy[3], xx[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    xx[k] = ar.w[0][k] * ((float)k * mp.dx - ar.lp[0]);
-    xy[k] = ar.w[1][k] * ((float)k * mp.dx - ar.lp[1]);
-    xz[k] = ar.w[2][k] * ((float)k * mp.dx - ar.lp[2]);
+    xx[k] = ar.w[0][k] * node_off(mp.dx, k, ar.lp[0]);
+    xy[k] = ar.w[1][k] * node_off(mp.dx, k, ar.lp[1]);
+    xz[k] = ar.w[2][k] * node_off(mp.dx, k, ar.lp[2]);
   }
   float B[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1839,7 +1850,7 @@ __device__ __forceinline__ void g2p2g_consume(const MpmDev &mp, const float *st,
   auto f = [&](int k) { return st[k * 64 + lane]; };
   const float pos[3] = {f(1), f(2), f(3)};
   Arena ar;
-  make_arena(mp.dx, pos, ar);
+  make_arena(mp.dx, mp.dxi, pos, ar);
   float xo[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -1917,9 +1928,9 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
   constexpr int NCH = STRESS ? 3 : 4;
   constexpr int R0 = (W & 1) * 2;  // first of this wave's two staged rounds in phase 2
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
-  const float kscale = -mp.dt * D_inv;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
+  const float kscale = mp.fscale;
   const float *v0 = varena + AL::at(cx, cy, cz);
   float acc[27][NCH];
 #pragma unroll
@@ -1959,7 +1970,7 @@ __device__ __forceinline__ void g2p2g_body(const MpmDev &mp, const ParticlesDev 
     bool valid = false;
     if (has0) {
       Arena ar;
-      make_arena(mp.dx, cur.pos, ar);
+      make_arena(mp.dx, mp.dxi, cur.pos, ar);
       // the particle's cell relative to the bin.  Anywhere inside the bin the node velocities are in the LDS arena, so a
       // particle that has wandered into a neighbouring cell of the same bin is still gathered here; only one that is outside
       // the bin altogether takes the exact path (hash queries into grid A)
@@ -2119,8 +2130,8 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
       __syncthreads();
     }
     const int nm = mqCount < G2P2G_MQ_CAP ? mqCount : G2P2G_MQ_CAP;  // the body ended with a barrier
-    const float dxi = 1.0f / mp.dx;
-    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    const float dxi = mp.dxi;
+    const float kscale = mp.fscale;
     for (int q = tid; q < nm; q += 256) {
       const size_t i = (size_t)mq[q];
       auto cload = [&](const Port<float> &p, int comp) {
@@ -2139,7 +2150,7 @@ static __global__ __launch_bounds__(256) void g2p2g_binned_kernel(MpmDev mp, Par
         stress_unpack(S, PF);
       }
       Arena ar;
-      make_arena(mp.dx, pos, ar);
+      make_arena(mp.dx, mp.dxi, pos, ar);
       const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
       if ((unsigned)kx >= 4u || (unsigned)ky >= 4u || (unsigned)kz >= 4u) {
         // the queueing test rounds pos * (1/dx) - 0.5 in one step, make_arena in two: on an exact cell face they can disagree
@@ -2225,15 +2236,15 @@ template <int CS> struct ConsumerSet {  // CS 0: m + mv_x, 1: mv_y + mv_z, 2: f_
 constexpr int G2P2G_QF = 28;
 __device__ __forceinline__ void stage_qform(const MpmDev &mp, float *st, float pm, const float (&lpn)[3], const float (&vel)[3], const float (&C)[9],
                                             const float (&PF)[9]) {
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  const float dxi = mp.dxi;
+  const float kscale = mp.fscale;
   float lc[3];  // centre node - particle
 #pragma unroll
   for (int k = 0; k < 3; ++k) lc[k] = fmaf(-lpn[k], mp.dx, mp.dx);
   st[0] = pm;
 #pragma unroll
   for (int d = 0; d < 3; ++d) st[(1 + d) * 64] = lpn[d];
-  const float pmdx = pm * mp.dx, ksdx = kscale * mp.dx;
+  const float pmdx = pm * mp.dx, ksdx = mp.fscaleDx;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     float *q = st + (4 + 4 * d) * 64;
@@ -2309,8 +2320,8 @@ __device__ __forceinline__ void g2p2g_rs_consumer(const MpmDev &mp, int lane, in
   using S = ConsumerSet<CS>;
   using AL = ArenaLds;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  const float dxi = mp.dxi;
+  const float kscale = mp.fscale;
   float acc[27][S::NA];
 #pragma unroll
   for (int k = 0; k < 27; ++k)
@@ -2350,8 +2361,8 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool FLUID = model_is_fluid(SMODEL);
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
   RoundWalk walk(cnt, start);
   auto next_chunk = [&](int &idx, bool &has) {
     has = false;
@@ -2414,7 +2425,7 @@ __device__ __forceinline__ void g2p2g_rs_producer(const MpmDev &mp, const Partic
       bool valid = false;
       if (has0) {
         Arena ar;
-        make_arena(mp.dx, cur.pos, ar);
+        make_arena(mp.dx, mp.dxi, cur.pos, ar);
         const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
         if ((unsigned)ocx >= 4u || (unsigned)ocy >= 4u || (unsigned)ocz >= 4u) {
           staleG[atomicAdd(staleGCount, 1)] = i0;  // outside the bin: exact gather + scatter afterwards
@@ -2557,8 +2568,8 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
       __syncthreads();
     }
     const int nm = mqCount < G2P2G_MQ_CAP ? mqCount : G2P2G_MQ_CAP;
-    const float dxi = 1.0f / mp.dx;
-    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    const float dxi = mp.dxi;
+    const float kscale = mp.fscale;
     for (int q = tid; q < nm; q += 512) {
       const size_t i = (size_t)mq[q];
       auto cload = [&](const Port<float> &p, int comp) {
@@ -2577,7 +2588,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_rs_kernel(MpmDev mp, Part
         stress_unpack(S, PF);
       }
       Arena ar;
-      make_arena(mp.dx, pos, ar);
+      make_arena(mp.dx, mp.dxi, pos, ar);
       const int kx = ar.corner[0] - geo.org[0], ky = ar.corner[1] - geo.org[1], kz = ar.corner[2] - geo.org[2];
       if ((unsigned)kx >= 4u || (unsigned)ky >= 4u || (unsigned)kz >= 4u) {
         staleP[atomicAdd(stalePCount, 1)] = (int)i;
@@ -2636,8 +2647,8 @@ static __global__ __launch_bounds__(256) void g2p2g_stale_kernel(MpmDev mp, Part
     atomicAdd(&driftFlag[1], ng + np);
     if (staleGCount[9]) driftFlag[2] = 1;
   }
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
   // queue G only: exact gather + update; the scatter of both queues follows in stale_scatter_coop_kernel
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ng; j += gridDim.x * blockDim.x)
     g2p_gather_global<SIDE, SMODEL>(mp, ps, (size_t)staleG[j], t, gridA, D_inv);
@@ -2654,8 +2665,8 @@ static __global__ __launch_bounds__(256) void stale_scatter_coop_kernel(MpmDev m
   const int n0 = *na, n = n0 + *nb;
   const int sub = threadIdx.x & 31;
   const int ngrp = (int)((gridDim.x * blockDim.x) >> 5);
-  const float dxi = 1.0f / mp.dx;
-  const float kscale = -mp.dt * (4.f * dxi * dxi);
+  const float dxi = mp.dxi;
+  const float kscale = mp.fscale;
   const int a = sub / 9, b = (sub / 3) % 3, c = sub % 3;  // lanes 27-31 idle
   for (int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5); j < n; j += ngrp) {
     const size_t i = (size_t)(j < n0 ? qa[j] : qb[j - n0]);
@@ -2672,7 +2683,7 @@ static __global__ __launch_bounds__(256) void stale_scatter_coop_kernel(MpmDev m
 #pragma unroll
     for (int d = 0; d < 9; ++d) contrib[d] = contrib[d] * kscale;
     Arena ar;
-    make_arena(mp.dx, pos, ar);
+    make_arena(mp.dx, mp.dxi, pos, ar);
     int loc[3], key[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -2822,6 +2833,14 @@ static MpmDev make_dev(const zs_rocm_mpm_params *p) {
   d.mat.bulk = p->bulk;
   d.mat.viscosity = p->viscosity;
   d.kscale = p->keyIsOrigin ? p->side : 1;
+  // derived values, in the float arithmetic the kernels used to repeat (IEEE division; fma where the device contracted)
+  d.dxi = 1.0f / d.dx;
+  d.D_inv = 4.f * d.dxi * d.dxi;
+  d.fscale = -d.dt * d.D_inv;
+  d.fscaleDx = d.fscale * d.dx;
+  d.mat.smu = 2.f * d.mat.mu;
+  d.mat.dpCoef = fmaf(3.f, d.mat.lam, d.mat.smu) / d.mat.smu;
+  d.mat.expCohesion = expf(d.mat.cohesion);
   return d;
 }
 static ParticlesDev make_particles(const zs_rocm_particles &p) {

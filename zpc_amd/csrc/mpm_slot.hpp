@@ -13,17 +13,21 @@ constexpr int SL_REC = 48;    // floats per outbox record (192 bytes = three 64-
 constexpr int SLR_DCELL = 14, SLR_FLAG = 15, SLR_V = 16, SLR_C = 19, SLR_PF = 28;
 
 #ifdef ZS_SLOT_PROBE  // measurement-only build (tools/ablate_slot.sh PROBE): cycle stamps of a workgroup's phases, summed over sampled workgroups
-static __device__ unsigned long long g_slot_probe[16];
+static __device__ unsigned long long g_slot_probe[32];
 #define SLP_SAMPLED ((blockIdx.x & 63) == 0)
 #define SLP_T0(name) const unsigned long long name = __builtin_readcyclecounter()
 #define SLP_ADD(slot, t0) do { if ((threadIdx.x & 63) == 0 && SLP_SAMPLED) atomicAdd(&g_slot_probe[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
 #define SLP_ACC(var, t0) var += __builtin_readcyclecounter() - (t0)
 #define SLP_PUT(slot, v) do { if ((threadIdx.x & 63) == 0 && SLP_SAMPLED) atomicAdd(&g_slot_probe[slot], (unsigned long long)(v)); } while (0)
+#define SLP_SEG(k) do { if (seg) { const unsigned long long tn_ = __builtin_readcyclecounter(); seg[k] += tn_ - tseg_; tseg_ = tn_; } } while (0)
+#define SLP_SEG0() unsigned long long tseg_ = __builtin_readcyclecounter()
 #else
 #define SLP_T0(name) do { } while (0)
 #define SLP_ADD(slot, t0) do { } while (0)
 #define SLP_ACC(var, t0) do { } while (0)
 #define SLP_PUT(slot, v) do { } while (0)
+#define SLP_SEG(k) do { } while (0)
+#define SLP_SEG0() do { } while (0)
 #endif
 
 struct SlotArgs {
@@ -152,8 +156,8 @@ __device__ __forceinline__ void scatter_node_task(const MpmDev &mp, int node, in
     val = Wt * fm() * (fv(d) + (fC(d) * xi[0] + fC(3 + d) * xi[1] + fC(6 + d) * xi[2]));
   } else {
     const int d = ch - 4;
-    const float dxi = 1.0f / mp.dx;
-    const float kscale = -mp.dt * (4.f * dxi * dxi);
+    const float dxi = mp.dxi;
+    const float kscale = mp.fscale;
     val = (fP(d) * kscale * xi[0] + fP(3 + d) * kscale * xi[1] + fP(6 + d) * kscale * xi[2]) * Wt;
   }
   const int bn = nbrBlk[code];
@@ -170,7 +174,7 @@ __device__ __forceinline__ void scatter_node_task(const MpmDev &mp, int node, in
 template <int SIDE, class GEO>
 __device__ __forceinline__ void outbox_scatter_global(const MpmDev &mp, const GEO &geo, const float *recs, int n, int w, int lane,
                                                       const int *nbrBlk, float *gridB, int *status) {
-  const float dxi = 1.0f / mp.dx;
+  const float dxi = mp.dxi;
 #pragma unroll 1
   for (int q = 0;; ++q) {
     const int j = w + 8 * (q / 3), p = q % 3;
@@ -271,23 +275,26 @@ struct SlotBinView {
 template <int SIDE, int SMODEL, bool WRITE_ALL, class VA, class REC, class WAIT>
 __device__ __forceinline__ bool slot_produce_entry(const MpmDev &mp, const ParticlesDev &ps, const REC &cur, unsigned code0, size_t i0, int lane,
                                                    unsigned spos, float *myStage, const SlotBinView &bv, const SlotArgs &A, unsigned *arrCnt,
-                                                   unsigned short (*arrQ)[SL_ARRQ], unsigned *xCnt, unsigned *xq, WAIT beforeStage) {
+                                                   unsigned short (*arrQ)[SL_ARRQ], unsigned *xCnt, unsigned *xq, WAIT beforeStage,
+                                                   unsigned long long *seg = nullptr) {  // seg: probe builds only (cycles per segment)
   constexpr int LW = 64;
+  SLP_SEG0();
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool FLUID = model_is_fluid(SMODEL);
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
   bool valid = false;
   const int cell = (int)(code0 & 63u), r = (int)(code0 >> 6);
   const int cx = cell >> 4, cy = (cell >> 2) & 3, cz = cell & 3;
   Arena ar;
-  make_arena(mp.dx, cur.pos, ar);
+  make_arena(mp.dx, mp.dxi, cur.pos, ar);
   const int ocx = ar.corner[0] - bv.org[0], ocy = ar.corner[1] - bv.org[1], ocz = ar.corner[2] - bv.org[2];
   if (ocx != cx || ocy != cy || ocz != cz) {
     A.status[4] = 1;  // the storage invariant is broken (the caller moved particles without re-slotting them)
   } else {
     float vel[3], C[9];
     g2p_gather_lds<VA>(mp, ar, bv.va + VA::at(ocx, ocy, ocz), D_inv, vel, C);
+    SLP_SEG(0);  // arena set-up + gather
     float pos[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) pos[d] = cur.pos[d] + vel[d] * mp.dt;
@@ -302,6 +309,7 @@ __device__ __forceinline__ bool slot_produce_entry(const MpmDev &mp, const Parti
       nc[d] = (int)fl - bv.org[d];
       lpn[d] = X - fl;
     }
+    SLP_SEG(1);  // advection, F update, new base node
     const float pm = cur.m;
     float plj = 0.f;
     if constexpr (DP) plj = cur.logJp;
@@ -441,9 +449,11 @@ __device__ __forceinline__ bool slot_produce_entry(const MpmDev &mp, const Parti
         }
       }
     }
+    SLP_SEG(2);  // tickets / queues / records of the movers, the particle's stores
     {  // the plastic models may project the local copy of F (the stored / recorded F is the unprojected one, P2G.hpp:101)
       float lj = plj;
       model_stress<SMODEL>(mp.mat, lj, F, PF, C);
+      SLP_SEG(3);  // constitutive update
       if (outbox) {
         if (rec) {
           rec[0] = pm;
@@ -464,13 +474,16 @@ __device__ __forceinline__ bool slot_produce_entry(const MpmDev &mp, const Parti
         if (moved || lowered) pstore1<LW>(ps.mass, o, pm);
       }
     }
+    SLP_SEG(4);  // logJp / stress / mass stores, record tail
     if (staged) {
       // staged AFTER the constitutive update, as in g2p2g_rs_producer: with m, x', v', C' dead before it the compiler
       // reuses their registers for the SVD at once and waits for the particle stores just issued (s_waitcnt vmcnt(1)
       // in front of the SVD: 2 ms per 64 Mi particles)
       valid = !moved && !byList;  // an in-bin mover is consumed by the lane of its NEW cell (arrival queue), not by the lane of its entry
       beforeStage();
+      SLP_SEG(5);  // wait for the ring slot
       stage_qform(mp, myStage, pm, lpn, vel, C, PF);
+      SLP_SEG(6);  // staging
     }
   }
   return valid;
@@ -485,8 +498,8 @@ __device__ __forceinline__ void g2p2g_slot_producer(const MpmDev &mp, const Part
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool FLUID = model_is_fluid(SMODEL);
   constexpr int NC = SIDE * SIDE * SIDE;
-  const float dxi = 1.0f / mp.dx;
-  const float D_inv = 4.f * dxi * dxi;
+  const float dxi = mp.dxi;
+  const float D_inv = mp.D_inv;
   const size_t rowBase = (size_t)bin * (size_t)A.K;
   const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
   float *const varena = sh.varena, *const stage = sh.stage;

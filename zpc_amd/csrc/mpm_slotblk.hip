@@ -55,9 +55,32 @@ struct BlkShared {
   int *total, *gbase, *nch, *binQ, *oc;      // [8] per bin: occupied slots, first chunk number, chunks, position among the block's non-empty bins,
                                              // outbox records (after the bin has been finished)
   unsigned char *chBin, *chIdx;              // [SB_MAXCH] chunk -> bin of the block, chunk number inside the bin
+  const unsigned *desc;                      // [SB_MAXCH + 3] desc[g + 1] = packed descriptor of chunk g (ChunkDesc), zero outside [0, G)
   unsigned *done;                            // consumer waves x chunks consumed
   int *sums;                                 // [0] sent, [1] homed, [2] bins whose outbox holds records that still have to be scattered
 };
+
+// Everything the chunk loop needs to know about a chunk, in one word: the loops read desc[g .. g + 3] (chunks g - 1 .. g + 2) in ONE LDS access
+// and keep the fields in SGPRs.  (Read field by field -- chBin[g], then binQ / total / gbase / nch of that bin, for three chunks -- the top of
+// a producer iteration was ~20 dependent LDS round trips behind the consumers' traffic: 4.1 k of its 17 k cycles, r05 stamps.)
+struct ChunkDesc {
+  unsigned w;
+  __device__ static unsigned pack(int b, int c, int qp, bool last, int total, int gbase) {
+    return (unsigned)b | ((unsigned)c << 3) | ((unsigned)(qp & 1) << 7) | ((unsigned)last << 8) | ((unsigned)total << 9) | ((unsigned)gbase << 21) | (1u << 31);
+  }
+  __device__ int bin() const { return (int)(w & 7u); }             // bin of the block
+  __device__ int idx() const { return (int)((w >> 3) & 15u); }     // chunk number inside the bin
+  __device__ int qp() const { return (int)((w >> 7) & 1u); }       // parity of the bin among the block's non-empty bins
+  __device__ bool last() const { return (w >> 8) & 1u; }           // last chunk of its bin
+  __device__ int total() const { return (int)((w >> 9) & 4095u); } // occupied slots of the bin
+  __device__ int gbase() const { return (int)((w >> 21) & 127u); } // number of the bin's first chunk
+};
+__device__ __forceinline__ void blk_chunk_descs(const unsigned *desc, int g, ChunkDesc (&d)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k].w = desc[g + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k].w = (unsigned)__builtin_amdgcn_readfirstlane((int)d[k].w);
+}
 
 // entry table of one bin: round-major enumeration of its occupied slots; wave w of nw writes the rows of rounds = w mod nw
 __device__ __forceinline__ void blk_build_tab(unsigned mask, int lane, int w, int nw, unsigned short *tab) {
@@ -88,8 +111,8 @@ __device__ __forceinline__ int blk_neighbour_bin(const int *nbrBlk, int blk, int
 
 // a finished bin (all of its chunks produced by all producer waves): departures and in-bin arrivals of its cells for slot_rehome_kernel /
 // slot_commit_kernel, its outbox count; the parity's counters are zero again.  One wave, lane = cell.
-__device__ __forceinline__ void blk_finish_bin(const BlkShared &sh, const SlotArgs &A, int bin0, int b, int lane) {
-  const int qp = sh.binQ[b] & 1, bin = bin0 + b;
+__device__ __forceinline__ void blk_finish_bin(const BlkShared &sh, const SlotArgs &A, int bin0, int b, int qp, int lane) {
+  const int bin = bin0 + b;
   const unsigned c = sh.clr[qp][lane], nl = sh.arrLocal[qp][lane];
   if (c) A.claim[((size_t)A.nbinsAll + (size_t)bin) * 64 + lane] = c;
   if (nl) A.claim[(size_t)bin * 64 + lane] = nl << 16;  // (the low half -- arrivals from other bins -- is counted by slot_rehome_kernel)
@@ -176,10 +199,12 @@ __device__ __forceinline__ void blk_xlist_lds(const float *stage, const unsigned
   }
 }
 
-// producer wave W (0..3): entries [64 (4 c + W), +64) of every chunk c of every bin of the block
-template <int SMODEL, bool WRITE_ALL, int W>
+// producer wave W (0..3): entries [64 (4 c + W), +64) of every chunk c of every bin of the block.  W is a wave-uniform RUNTIME value: one
+// copy of the 17 KB producer body for the four waves (as a template parameter the kernel carried four: 87 KB of code, 70 KB of it hot in
+// every chunk -- more than the instruction cache two CUs share)
+template <int SMODEL, bool WRITE_ALL>
 __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDev &ps, const int (&borg)[3], int blk, int lane, int G,
-                                             const BlkShared &sh, const SlotArgs &A) {
+                                             const BlkShared &sh, const SlotArgs &A, const int W) {
   constexpr int LW = 64;
   constexpr bool DP = model_uses_logjp(SMODEL);
   constexpr bool FLUID = model_is_fluid(SMODEL);
@@ -187,52 +212,58 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
   const unsigned kmask = A.K >= 32 ? 0xffffffffu : ((1u << A.K) - 1u);
   RecG<LW, DP, FLUID> cur, nxt;
   bool has0 = false, has1 = false;
-  size_t i0 = 0, i1 = 0;
-  unsigned code0 = 0, code1 = 0;
+  unsigned code0 = 0, code1 = 0;  // round * 64 + cell of the entry (its element index is rebuilt from it where needed: two VGPRs less across the loop)
+  auto elem = [&](int b, unsigned code) { return ((size_t)(bin0 + b) * (size_t)A.K + (size_t)(code >> 6)) * 64 + (size_t)(code & 63u); };
   {
-    const int b = sh.chBin[0];
+    ChunkDesc d[4];
+    blk_chunk_descs(sh.desc, 0, d);
+    const int b = d[1].bin();
     const int j = 64 * W + lane;
-    has1 = j < sh.total[b];
+    has1 = j < d[1].total();
     if (has1) {
-      code1 = sh.tab[sh.binQ[b] & 1][j];
-      i1 = ((size_t)(bin0 + b) * (size_t)A.K + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
-      nxt.load(ps, i1);
+      code1 = sh.tab[d[1].qp()][j];
+      nxt.load(ps, elem(b, code1));
     }
   }
   __syncthreads();  // every producer has read the first bin's entry table (iteration 0 may rebuild that buffer for the bin of chunk 2)
 #ifdef ZS_SLOT_PROBE
-  unsigned long long tWork = 0, tBar = 0, tRing = 0;
+  unsigned long long tWork = 0, tBar = 0, tRing = 0, tPre = 0, segv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long *const seg = segv;
+#else
+  unsigned long long *const seg = nullptr;
 #endif
   for (int g = 0; g < G; ++g) {
     SLP_T0(tIt);
-    const int b = sh.chBin[g];
-    const int qp = sh.binQ[b] & 1;
+    ChunkDesc d[4];  // chunks g - 1, g, g + 1, g + 2
+    blk_chunk_descs(sh.desc, g, d);
+    const int b = d[1].bin();
+    const int qp = d[1].qp();
     const int grp = 4 * g + W, slot = grp % SB_NG, par = g % 3;
     float *myStage = sh.stage + (size_t)slot * (G2P2G_QF * 64);
     cur = nxt;
     has0 = has1;
-    i0 = i1;
     code0 = code1;
     has1 = false;
     if (g + 1 < G) {  // the records of the next chunk (this bin's or the next bin's): in flight during this chunk
-      const int b1 = sh.chBin[g + 1];
-      const int j1 = 256 * (int)sh.chIdx[g + 1] + 64 * W + lane;
-      has1 = j1 < sh.total[b1];
+      const int b1 = d[2].bin();
+      const int j1 = 256 * d[2].idx() + 64 * W + lane;
+      has1 = j1 < d[2].total();
       if (has1) {
-        code1 = sh.tab[sh.binQ[b1] & 1][j1];
-        i1 = ((size_t)(bin0 + b1) * (size_t)A.K + (size_t)(code1 >> 6)) * 64 + (size_t)(code1 & 63u);
-        nxt.load(ps, i1);
+        code1 = sh.tab[d[2].qp()][j1];
+        nxt.load(ps, elem(b1, code1));
       }
     }
     // per-bin state around the bin boundaries (every buffer named here is dead for its previous owner: see the file comment)
-    if (g > 0 && sh.chIdx[g] == 0 && W == 0) blk_finish_bin(sh, A, bin0, sh.chBin[g - 1], lane);  // the bin that ended with chunk g - 1
-    if (g + 1 < G && sh.chIdx[g + 1] == 0 && W == 1 && lane < 27) {                                 // neighbour bins of the bin that starts with chunk g + 1
-      const int b1 = sh.chBin[g + 1];
-      sh.nbrBin[sh.binQ[b1] & 1][lane] = blk_neighbour_bin(sh.nbrBlk, blk, b1, lane);
+    if (g > 0 && d[1].idx() == 0 && W == 0) blk_finish_bin(sh, A, bin0, d[0].bin(), d[0].qp(), lane);  // the bin that ended with chunk g - 1
+    if (g + 1 < G && d[2].idx() == 0 && W == 1 && lane < 27) {                                          // neighbour bins of the bin that starts with chunk g + 1
+      const int b1 = d[2].bin();
+      int l = lane;
+      asm volatile("" : "+v"(l));  // (keeps the decode of the direction code inside this rare branch: hoisted out of the chunk loop it is three spilled VGPRs)
+      sh.nbrBin[d[2].qp()][l] = blk_neighbour_bin(sh.nbrBlk, blk, b1, l);
     }
-    if (g + 2 < G && sh.chIdx[g + 2] == 0) {  // entry table of the bin that starts with chunk g + 2 (its first records are requested at the top of g + 1)
-      const int b2 = sh.chBin[g + 2];
-      blk_build_tab(sh.masks[b2][lane], lane, W, 4, sh.tab[sh.binQ[b2] & 1]);
+    if (g + 2 < G && d[3].idx() == 0) {  // entry table of the bin that starts with chunk g + 2 (its first records are requested at the top of g + 1)
+      const int b2 = d[3].bin();
+      blk_build_tab(sh.masks[b2][lane], lane, W, 4, sh.tab[d[3].qp()]);
     }
     const SubGeom sg = sub_geom(borg, b);
     const SlotBinView bv{bin0 + b, {sg.org[0], sg.org[1], sg.org[2]}, (size_t)(bin0 + b) * (size_t)A.K, kmask,
@@ -245,9 +276,10 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     bool valid = false;
+    SLP_ACC(tPre, tIt);
     if (has0)
-      valid = slot_produce_entry<8, SMODEL, WRITE_ALL, ArenaBlk>(mp, ps, cur, code0, i0, lane, (unsigned)(slot * 64 + lane), myStage + lane, bv, A,
-                                                                 sh.arrCnt[par], sh.arrQ[par], &sh.xCnt[par], sh.xq[par], ringFree);
+      valid = slot_produce_entry<8, SMODEL, WRITE_ALL, ArenaBlk>(mp, ps, cur, code0, elem(b, code0), lane, (unsigned)(slot * 64 + lane), myStage + lane, bv, A,
+                                                                 sh.arrCnt[par], sh.arrQ[par], &sh.xCnt[par], sh.xq[par], ringFree, seg);
     SLP_T0(tR);
     ringFree();
     SLP_ACC(tRing, tR);
@@ -256,6 +288,13 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
       if (lane == 0) sh.smask[slot] = vm;
     }
     SLP_ACC(tWork, tIt);
+#ifdef ZS_SLOT_PROBE
+    {  // how long do the acknowledgements of this iteration's stores (and the next chunk's records) take from here?
+      SLP_T0(tV);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      SLP_ACC(segv[7], tV);
+    }
+#endif
     SLP_T0(tB);
     __syncthreads();  // chunk g is staged
     SLP_ACC(tBar, tB);
@@ -268,8 +307,17 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
     SLP_PUT(4, tBar);
     SLP_PUT(2, tRing);
     SLP_PUT(5, G);
+#ifdef ZS_SLOT_PROBE
+    SLP_PUT(16, tPre);
+    for (int k = 0; k < 7; ++k) SLP_PUT(17 + k, segv[k]);
+    SLP_PUT(24, segv[7]);
+#endif
   }
-  if (W == 0) blk_finish_bin(sh, A, bin0, sh.chBin[G - 1], lane);
+  if (W == 0) {
+    ChunkDesc d[4];
+    blk_chunk_descs(sh.desc, G - 1, d);
+    blk_finish_bin(sh, A, bin0, d[1].bin(), d[1].qp(), lane);
+  }
 }
 
 // consumer wave of channel set CS: lane = cell of the current bin; chunk g is consumed while the producers work on chunk g + 1
@@ -298,8 +346,10 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     __syncthreads();  // chunk g is staged
     SLP_ACC(tBar, tB);
     SLP_T0(tIt);
-    const int b = sh.chBin[g], c = sh.chIdx[g], total = sh.total[b], par = g % 3;
-    const int gb = 4 * sh.gbase[b];  // ring group number of the bin's entry 0
+    ChunkDesc d[4];
+    blk_chunk_descs(sh.desc, g, d);
+    const int b = d[1].bin(), c = d[1].idx(), total = d[1].total(), par = g % 3;
+    const int gb = 4 * d[1].gbase();  // ring group number of the bin's entry 0
     if (c == 0) {
       r = 0;
       off = 0;
@@ -351,7 +401,7 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     if (lane == 0) atomicAdd(sh.done, 1u);
     SLP_ACC(tWork, tIt);
     SLP_T0(tFl);
-    if (c == sh.nch[b] - 1) {
+    if (d[1].last()) {
       // last chunk of the bin: the set's channels of the bin's arena belong to this wave alone -- add the 27 register planes on top of
       // the lists' terms (phases ordered inside the wave), send the arena's nodes to the grid; no other wave is involved
       float *a0 = pa + AL::at(cx + 1, cy + 1, cz + 1);
@@ -413,10 +463,11 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   __shared__ int s_cnt[2][4];
   __shared__ int s_total[8], s_gbase[8], s_nch[8], s_binQ[8], s_oc[8];
   __shared__ unsigned char s_chBin[SB_MAXCH], s_chIdx[SB_MAXCH];
+  __shared__ unsigned s_desc[SB_MAXCH + 4];
   __shared__ unsigned s_done;
   __shared__ int s_sums[3], s_G;
   const BlkShared sh{s_varena, s_parena, s_stage, s_smask, s_tab, s_masks, s_clr, s_arrLocal, s_arrCnt, s_arrQ, s_xCnt, s_xq, s_nbrBlk, s_nbrBin, s_nbr8,
-                     s_cnt, s_total, s_gbase, s_nch, s_binQ, s_oc, s_chBin, s_chIdx, &s_done, s_sums};
+                     s_cnt, s_total, s_gbase, s_nch, s_binQ, s_oc, s_chBin, s_chIdx, s_desc, &s_done, s_sums};
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int blk = (int)xcd_chunked(blockIdx.x, gridDim.x) + A.binBase / 8;
   const int bin0 = blk * 8;
@@ -459,9 +510,12 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
       for (int c = 0; c < nch; ++c) {
         s_chBin[G] = (unsigned char)b;
         s_chIdx[G] = (unsigned char)c;
+        s_desc[G + 1] = ChunkDesc::pack(b, c, s_binQ[b], c == nch - 1, s_total[b], s_gbase[b]);
         ++G;
       }
     }
+    s_desc[0] = 0u;
+    for (int k = G + 1; k < G + 4 && k < SB_MAXCH + 4; ++k) s_desc[k] = 0u;
     s_G = G;
     // early warning of the closed-loop re-partition: the block holds particles and a block within {-1..2}^3 of it is missing
     if (G && A.blockEdge && A.blockEdge[blk]) A.status[3] = 1;
@@ -493,10 +547,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   }
   __syncthreads();
   if (w == 0) SLP_ADD(1, tStart);
-  if (w == 0) blk_producer<SMODEL, WRITE_ALL, 0>(mp, ps, borg, blk, lane, G, sh, A);
-  else if (w == 1) blk_producer<SMODEL, WRITE_ALL, 1>(mp, ps, borg, blk, lane, G, sh, A);
-  else if (w == 2) blk_producer<SMODEL, WRITE_ALL, 2>(mp, ps, borg, blk, lane, G, sh, A);
-  else if (w == 3) blk_producer<SMODEL, WRITE_ALL, 3>(mp, ps, borg, blk, lane, G, sh, A);
+  if (w < 4) blk_producer<SMODEL, WRITE_ALL>(mp, ps, borg, blk, lane, G, sh, A, __builtin_amdgcn_readfirstlane(w));
   else {
     if (w == 4) blk_consumer<0>(mp, borg, blk, lane, G, sh, A);
     else if (w == 5) blk_consumer<1>(mp, borg, blk, lane, G, sh, A);
@@ -566,9 +617,9 @@ void launch_g2p2g_slotblk(hipStream_t stream, int model, bool writeAll, const Mp
 #if defined(ZS_SLOT_PROBE) && defined(ZS_SLOT_PROBE_BLK)  // measurement-only build: read (and clear) the phase stamps of g2p2g_slotblk_kernel
 extern "C" void zs_rocm_slot_probe(unsigned long long *out16, int reset) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_slot_probe), sizeof(unsigned long long) * 16);
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_slot_probe), sizeof(unsigned long long) * 32);  // (the block kernel's reader: 32 slots)
   if (reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(zsr::g_slot_probe), z, sizeof(z));
   }
 }
