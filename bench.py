@@ -688,8 +688,9 @@ def main():
               "  ".join("%s=%.0f" % (names[k], pv[k] / wgs) for k in range(16) if k != 11) + "  wgs=%d" % wgs, file=sys.stderr)
         if any(pv[k] for k in range(16, 32)):  # block kernel: the producer wave's chunk iteration by segment
             seg = ["top of iteration (hand-over, prefetch, tables)", "arena + gather", "advection + F", "movers + stores", "constitutive update",
-                   "tail stores", "ring wait", "staging", "vmcnt(0) before the barrier"]
-            print("producer segments (cycles per sampled workgroup): " + "  ".join("%s=%.0f" % (seg[k], pv[16 + k] / wgs) for k in range(9)), file=sys.stderr)
+                   "tail stores", "ring wait", "staging", "vmcnt(0) before the barrier", "top: descriptors + hand-over", "top: record requests",
+                   "top: finish_bin / neighbour bins", "top: entry table"]
+            print("producer segments (cycles per sampled workgroup): " + "  ".join("%s=%.0f" % (seg[k], pv[16 + k] / wgs) for k in range(13)), file=sys.stderr)
     if probe:
         lib().zs_rocm_debug_probe(pv, 0)
         wgs = max(int(pv[7]), 1)

@@ -55,7 +55,7 @@ struct BlkShared {
   int *total, *gbase, *nch, *binQ, *oc;      // [8] per bin: occupied slots, first chunk number, chunks, position among the block's non-empty bins,
                                              // outbox records (after the bin has been finished)
   unsigned char *chBin, *chIdx;              // [SB_MAXCH] chunk -> bin of the block, chunk number inside the bin
-  const unsigned *desc;                      // [SB_MAXCH + 3] desc[g + 1] = packed descriptor of chunk g (ChunkDesc), zero outside [0, G)
+  const unsigned *desc;                      // [SB_MAXCH + 5] desc[g + 1] = packed descriptor of chunk g (ChunkDesc), zero outside [0, G)
   unsigned *done;                            // consumer waves x chunks consumed
   int *sums;                                 // [0] sent, [1] homed, [2] bins whose outbox holds records that still have to be scattered
 };
@@ -75,11 +75,11 @@ struct ChunkDesc {
   __device__ int total() const { return (int)((w >> 9) & 4095u); } // occupied slots of the bin
   __device__ int gbase() const { return (int)((w >> 21) & 127u); } // number of the bin's first chunk
 };
-__device__ __forceinline__ void blk_chunk_descs(const unsigned *desc, int g, ChunkDesc (&d)[4]) {
+template <int N> __device__ __forceinline__ void blk_chunk_descs(const unsigned *desc, int g, ChunkDesc (&d)[N]) {  // d[k] = chunk g - 1 + k
 #pragma unroll
-  for (int k = 0; k < 4; ++k) d[k].w = desc[g + k];
+  for (int k = 0; k < N; ++k) d[k].w = desc[g + k];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) d[k].w = (unsigned)__builtin_amdgcn_readfirstlane((int)d[k].w);
+  for (int k = 0; k < N; ++k) d[k].w = (unsigned)__builtin_amdgcn_readfirstlane((int)d[k].w);
 }
 
 // entry table of one bin: round-major enumeration of its occupied slots; wave w of nw writes the rows of rounds = w mod nw
@@ -110,23 +110,28 @@ __device__ __forceinline__ int blk_neighbour_bin(const int *nbrBlk, int blk, int
 }
 
 // a finished bin (all of its chunks produced by all producer waves): departures and in-bin arrivals of its cells for slot_rehome_kernel /
-// slot_commit_kernel, its outbox count; the parity's counters are zero again.  One wave, lane = cell.
+// slot_commit_kernel, its outbox count; the parity's counters are zero again.  One wave, lane = cell; every LDS read is issued before the
+// first use (ONE round trip: as a chain of lane-0 reads this was 4.9 k cycles per bin on the producers' critical path, r05 stamps).
 __device__ __forceinline__ void blk_finish_bin(const BlkShared &sh, const SlotArgs &A, int bin0, int b, int qp, int lane) {
   const int bin = bin0 + b;
   const unsigned c = sh.clr[qp][lane], nl = sh.arrLocal[qp][lane];
+  const int cv = sh.cnt[qp][lane & 3];  // outCount, sent, homed, xOver
   if (c) A.claim[((size_t)A.nbinsAll + (size_t)bin) * 64 + lane] = c;
   if (nl) A.claim[(size_t)bin * 64 + lane] = nl << 16;  // (the low half -- arrivals from other bins -- is counted by slot_rehome_kernel)
   sh.clr[qp][lane] = 0u;
   sh.arrLocal[qp][lane] = 0u;
+  const int c0 = __builtin_amdgcn_readlane(cv, 0), c1 = __builtin_amdgcn_readlane(cv, 1), c2 = __builtin_amdgcn_readlane(cv, 2),
+            c3 = __builtin_amdgcn_readlane(cv, 3);
   if (lane == 0) {
-    const int oc = sh.cnt[qp][0] < A.cap ? sh.cnt[qp][0] : A.cap;
+    const int oc = c0 < A.cap ? c0 : A.cap;
     A.moverCount[bin] = oc;
     sh.oc[b] = oc;
-    sh.sums[0] += sh.cnt[qp][1];
-    sh.sums[1] += sh.cnt[qp][2];
-    if (sh.cnt[qp][3] > 0) sh.sums[2] |= 1 << b;
-    sh.cnt[qp][0] = sh.cnt[qp][1] = sh.cnt[qp][2] = sh.cnt[qp][3] = 0;
   }
+  if (lane < 3) {  // sums: sent, homed, bins whose outbox holds records that still have to be scattered (one bit per bin: + is |)
+    const int add = lane == 0 ? c1 : (lane == 1 ? c2 : (c3 > 0 ? 1 << b : 0));
+    if (add) atomicAdd(&sh.sums[lane], add);
+  }
+  if (lane < 4) sh.cnt[qp][lane] = 0;
 }
 
 // P2G arena of ONE bin in the block kernel: 8^3 nodes = the bin's 6^3 stencil nodes + one layer around them, origin at the bin's node -1.
@@ -215,7 +220,7 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
   unsigned code0 = 0, code1 = 0;  // round * 64 + cell of the entry (its element index is rebuilt from it where needed: two VGPRs less across the loop)
   auto elem = [&](int b, unsigned code) { return ((size_t)(bin0 + b) * (size_t)A.K + (size_t)(code >> 6)) * 64 + (size_t)(code & 63u); };
   {
-    ChunkDesc d[4];
+    ChunkDesc d[2];
     blk_chunk_descs(sh.desc, 0, d);
     const int b = d[1].bin();
     const int j = 64 * W + lane;
@@ -229,12 +234,18 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0, tRing = 0, tPre = 0, segv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long *const seg = segv;
+  unsigned long long topv[4] = {0, 0, 0, 0}, tTop = 0;
+#define SLP_TOP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); topv[k] += tn_ - tTop; tTop = tn_; } while (0)
 #else
+#define SLP_TOP(k) do { } while (0)
   unsigned long long *const seg = nullptr;
 #endif
   for (int g = 0; g < G; ++g) {
     SLP_T0(tIt);
-    ChunkDesc d[4];  // chunks g - 1, g, g + 1, g + 2
+#ifdef ZS_SLOT_PROBE
+    tTop = tIt;
+#endif
+    ChunkDesc d[3];  // chunks g - 1, g, g + 1
     blk_chunk_descs(sh.desc, g, d);
     const int b = d[1].bin();
     const int qp = d[1].qp();
@@ -244,6 +255,7 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
     has0 = has1;
     code0 = code1;
     has1 = false;
+    SLP_TOP(0);  // descriptors, hand-over
     if (g + 1 < G) {  // the records of the next chunk (this bin's or the next bin's): in flight during this chunk
       const int b1 = d[2].bin();
       const int j1 = 256 * d[2].idx() + 64 * W + lane;
@@ -253,18 +265,9 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
         nxt.load(ps, elem(b1, code1));
       }
     }
-    // per-bin state around the bin boundaries (every buffer named here is dead for its previous owner: see the file comment)
-    if (g > 0 && d[1].idx() == 0 && W == 0) blk_finish_bin(sh, A, bin0, d[0].bin(), d[0].qp(), lane);  // the bin that ended with chunk g - 1
-    if (g + 1 < G && d[2].idx() == 0 && W == 1 && lane < 27) {                                          // neighbour bins of the bin that starts with chunk g + 1
-      const int b1 = d[2].bin();
-      int l = lane;
-      asm volatile("" : "+v"(l));  // (keeps the decode of the direction code inside this rare branch: hoisted out of the chunk loop it is three spilled VGPRs)
-      sh.nbrBin[d[2].qp()][l] = blk_neighbour_bin(sh.nbrBlk, blk, b1, l);
-    }
-    if (g + 2 < G && d[3].idx() == 0) {  // entry table of the bin that starts with chunk g + 2 (its first records are requested at the top of g + 1)
-      const int b2 = d[3].bin();
-      blk_build_tab(sh.masks[b2][lane], lane, W, 4, sh.tab[d[3].qp()]);
-    }
+    SLP_TOP(1);  // record requests
+    // (per-bin state around the bin boundaries -- a finished bin's counters, the next bins' entry tables and neighbour bins -- is kept by the
+    // consumer waves, which have the time: see blk_consumer)
     const SubGeom sg = sub_geom(borg, b);
     const SlotBinView bv{bin0 + b, {sg.org[0], sg.org[1], sg.org[2]}, (size_t)(bin0 + b) * (size_t)A.K, kmask,
                          sh.varena + ArenaBlk::at(sg.o[0], sg.o[1], sg.o[2]), sh.masks[b], sh.clr[qp], sh.arrLocal[qp], sh.nbrBin[qp],
@@ -311,12 +314,8 @@ __device__ __forceinline__ void blk_producer(const MpmDev &mp, const ParticlesDe
     SLP_PUT(16, tPre);
     for (int k = 0; k < 7; ++k) SLP_PUT(17 + k, segv[k]);
     SLP_PUT(24, segv[7]);
+    for (int k = 0; k < 2; ++k) SLP_PUT(25 + k, topv[k]);
 #endif
-  }
-  if (W == 0) {
-    ChunkDesc d[4];
-    blk_chunk_descs(sh.desc, G - 1, d);
-    blk_finish_bin(sh, A, bin0, d[1].bin(), d[1].qp(), lane);
   }
 }
 
@@ -338,6 +337,24 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
   unsigned mask = 0u;
   int r = 0, off = 0;  // next round to consume, entry number of its first particle
   __syncthreads();  // (the producers' first record requests are out)
+  // Per-bin state, kept by the consumers (off the producers' critical path; every buffer named here is dead for its previous owner, see the
+  // file comment).  In iteration g, i.e. between the barriers "chunk g staged" and "chunk g + 1 staged", while the producers work on
+  // chunk g + 1:
+  //   * entry table of the bin that starts with chunk g + 3 (its first records are requested at the top of the producers' iteration g + 2;
+  //     the table of the bin two bins earlier, same parity, was last read at the top of their iteration g at the latest), all four waves;
+  //   * neighbour bins of the bin that starts with chunk g + 2 (used by the producers from their iteration g + 2 on), wave of set 2;
+  //   * the counters of the bin that ENDS with chunk g (all of it was produced before the barrier "chunk g staged"; the parity's next
+  //     owner starts with chunk g + 2 at the earliest), wave of set 3.
+  // The kernel head has done the bins that start with chunks 0 and 1; the one that starts with chunk 2 is "iteration -1", here.
+  auto binState = [&](int g, const ChunkDesc &c2, const ChunkDesc &c3) {  // c2 / c3: chunks g + 2 / g + 3
+    if (g + 3 < G && c3.idx() == 0) blk_build_tab(sh.masks[c3.bin()][lane], lane, CS, 4, sh.tab[c3.qp()]);
+    if (CS == 2 && g >= 0 && g + 2 < G && c2.idx() == 0 && lane < 27) sh.nbrBin[c2.qp()][lane] = blk_neighbour_bin(sh.nbrBlk, blk, c2.bin(), lane);
+  };
+  {
+    ChunkDesc d[5];
+    blk_chunk_descs(sh.desc, -1 + 1, d);  // chunks -1 .. 3
+    binState(-1, d[2], d[3]);
+  }
 #ifdef ZS_SLOT_PROBE
   unsigned long long tWork = 0, tBar = 0, tFlush = 0;
 #endif
@@ -346,7 +363,7 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     __syncthreads();  // chunk g is staged
     SLP_ACC(tBar, tB);
     SLP_T0(tIt);
-    ChunkDesc d[4];
+    ChunkDesc d[5];  // chunks g - 1 .. g + 3
     blk_chunk_descs(sh.desc, g, d);
     const int b = d[1].bin(), c = d[1].idx(), total = d[1].total(), par = g % 3;
     const int gb = 4 * d[1].gbase();  // ring group number of the bin's entry 0
@@ -399,6 +416,8 @@ __device__ __forceinline__ void blk_consumer(const MpmDev &mp, const int (&borg)
     // this wave has read what it needs of chunk g: the producers may stage chunk g + 1 over it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicAdd(sh.done, 1u);
+    binState(g, d[3], d[4]);
+    if (CS == 3 && d[1].last()) blk_finish_bin(sh, A, blk * 8, b, d[1].qp(), lane);
     SLP_ACC(tWork, tIt);
     SLP_T0(tFl);
     if (d[1].last()) {
@@ -463,7 +482,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   __shared__ int s_cnt[2][4];
   __shared__ int s_total[8], s_gbase[8], s_nch[8], s_binQ[8], s_oc[8];
   __shared__ unsigned char s_chBin[SB_MAXCH], s_chIdx[SB_MAXCH];
-  __shared__ unsigned s_desc[SB_MAXCH + 4];
+  __shared__ unsigned s_desc[SB_MAXCH + 5];
   __shared__ unsigned s_done;
   __shared__ int s_sums[3], s_G;
   const BlkShared sh{s_varena, s_parena, s_stage, s_smask, s_tab, s_masks, s_clr, s_arrLocal, s_arrCnt, s_arrQ, s_xCnt, s_xq, s_nbrBlk, s_nbrBin, s_nbr8,
@@ -515,7 +534,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
       }
     }
     s_desc[0] = 0u;
-    for (int k = G + 1; k < G + 4 && k < SB_MAXCH + 4; ++k) s_desc[k] = 0u;
+    for (int k = G + 1; k < G + 5; ++k) s_desc[k] = 0u;
     s_G = G;
     // early warning of the closed-loop re-partition: the block holds particles and a block within {-1..2}^3 of it is missing
     if (G && A.blockEdge && A.blockEdge[blk]) A.status[3] = 1;
@@ -554,7 +573,7 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
     else if (w == 6) blk_consumer<2>(mp, borg, blk, lane, G, sh, A);
     else blk_consumer<3>(mp, borg, blk, lane, G, sh, A);
   }
-  __syncthreads();  // the last bin is finished (blk_finish_bin by producer wave 0)
+  __syncthreads();  // the last bin is finished (blk_finish_bin by the consumer wave of set 3)
   if (w == 0) {
     SLP_ADD(0, tStart);
     SLP_PUT(11, 1);
