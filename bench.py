@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK_CYCLES = 2.2     # shader cycles per VALU instruction a SIMD reaches on independent v_fma_f32 with >= 2 resident waves (tools/valu_issue_bench.hip, r05)
+VALU_ISSUE_MIX_CYCLES = 2.9      # the same for the fused step's own SVD + return-mapping instruction mix at 4 waves per SIMD (tools/svd_issue_bench.hip, r05)
 P2G_BYTES = {0: 107.0, 1: 115.0}  # algorithmic B/particle: 100 B particle read + 7 B grid (+8 B logJp r/w)
 G2P_BYTES = 145.5
 YIELD_SURFACE = 0.816496580927726 * 2.0 * 0.5 / (3.0 - 0.5)
@@ -894,10 +896,18 @@ def main():
                             and _same_code(j)):
                         ftraffic = j.get("hbm_bytes_per_launch")   # (a figure collected for another kernel generation is not this run's traffic)
                         if j.get("valu_insts_per_launch"):
-                            # the other roofline: VALU issue.  insts = SQ_INSTS_VALU of the step's kernels; busy = SQ_ACTIVE_INST_VALU x 4 /
-                            # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); algorithmic = the same kernels' SQ_INSTS_VALU on the column at rest
-                            # (no movers, every cell 8 particles: what the arithmetic of G2P + model + P2G costs with this kernel body)
-                            fvalu = {"insts_per_launch": j["valu_insts_per_launch"], "busy_frac": j.get("valu_busy_frac"),
+                            # the other roofline: VALU issue.  insts = SQ_INSTS_VALU of the step's kernels; cycles_per_inst = shader cycles a
+                            # SIMD spent per VALU instruction of the main kernel (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / SQ_INSTS_VALU);
+                            # issue_peak = what a SIMD of this chip issues with >= 2 resident waves: 2.2 cycles per independent v_fma_f32
+                            # (tools/valu_issue_bench.hip; one wave alone: 4.6), 2.9 for the instruction mix of this kernel's 3x3 SVD +
+                            # return mapping at 4 waves per SIMD (tools/svd_issue_bench.hip: v_cndmask / v_cmp / v_max issue at 4 cycles,
+                            # transcendentals at 8); algorithmic = the same kernels' SQ_INSTS_VALU on the column at rest
+                            cpi = j.get("valu_cycles_per_inst_per_simd")
+                            fvalu = {"insts_per_launch": j["valu_insts_per_launch"],
+                                     "cycles_per_inst_per_simd": cpi,
+                                     "issue_peak_cycles_per_inst": VALU_ISSUE_PEAK_CYCLES, "issue_mix_cycles_per_inst": VALU_ISSUE_MIX_CYCLES,
+                                     "issue_frac": (VALU_ISSUE_PEAK_CYCLES / cpi) if cpi else None,
+                                     "issue_frac_of_mix_rate": (VALU_ISSUE_MIX_CYCLES / cpi) if cpi else None,
                                      "algorithmic_insts": j.get("valu_insts_at_rest"),
                                      "frac": (j["valu_insts_at_rest"] / j["valu_insts_per_launch"]) if j.get("valu_insts_at_rest") else None,
                                      "ns_per_inst_per_simd": fused_ms * 1e6 * 1024 / j["valu_insts_per_launch"],
@@ -917,9 +927,9 @@ def main():
             out["roofline"]["hbm_frac"] = fach / HBM_PEAK_GBS
             if fvalu is not None:
                 out["roofline"]["valu"] = fvalu
-                # the binding roofline is the one the kernel sits closer to: fraction of the HBM peak its algorithmic bytes reach, against
-                # the fraction of its issued VALU instructions that are algorithmic (both "useful work / what the unit was asked to do")
-                if fvalu.get("busy_frac") and fvalu["busy_frac"] > fach / HBM_PEAK_GBS:
+                # the binding roofline is the one the kernel sits closer to: the fraction of the HBM peak its algorithmic bytes reach, against
+                # the fraction of the SIMDs' VALU issue rate its instruction stream reaches
+                if fvalu.get("issue_frac") and fvalu["issue_frac"] > fach / HBM_PEAK_GBS:
                     out["roofline"]["bound"] = "valu"
         # the measured device-copy ceiling of THIS box beside the nominal peak (1 GiB device-to-device copies, read + write
         # bytes over HIP-event time, after the timed region)

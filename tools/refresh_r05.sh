@@ -60,14 +60,15 @@ if "hbm_bytes_per_launch" in main:
     tot = sum(s.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in KS)
     valu = sum(s.get(k, {}).get("SQ_INSTS_VALU", 0.0) for k in KS)
     valu_rest = sum(r.get(k, {}).get("SQ_INSTS_VALU", 0.0) for k in KS) or None
-    busy = main["SQ_ACTIVE_INST_VALU"] * 4 / (main["GRBM_GUI_ACTIVE"] / 8 * 1024) if "GRBM_GUI_ACTIVE" in main and "SQ_ACTIVE_INST_VALU" in main else None
+    # shader cycles one SIMD spent per VALU instruction of the main kernel (GRBM_GUI_ACTIVE counts every XCD: / 8; 1024 SIMDs)
+    cpi = (main["GRBM_GUI_ACTIVE"] / 8 * 1024) / main["SQ_INSTS_VALU"] if "GRBM_GUI_ACTIVE" in main and main.get("SQ_INSTS_VALU") else None
     json.dump({"kernel": "g2p2g_slotblk_kernel + slot_rehome_kernel + slot_commit_kernel", "particles": 67108864, "side": 8, "model": "sand", "cache_stress": True,
                "hbm_bytes_per_launch": tot, "main_kernel_bytes": main["hbm_bytes_per_launch"],
                "hbm_read_bytes": sum(s.get(k, {}).get("hbm_read_bytes_corrected", 0.0) for k in s), "hbm_write_bytes": sum(s.get(k, {}).get("hbm_write_bytes", 0.0) for k in s),
-               "valu_insts_per_launch": valu, "valu_insts_at_rest": valu_rest, "valu_busy_frac": busy,
+               "valu_insts_per_launch": valu, "valu_insts_at_rest": valu_rest, "valu_cycles_per_inst_per_simd": cpi,
                "sq_wave_cycles": main.get("SQ_WAVE_CYCLES"), "sq_wait_any": main.get("SQ_WAIT_ANY"), "grbm_gui_active": main.get("GRBM_GUI_ACTIVE"),
                "code_object": obj, "code_regex": rx, "code_hash": kernel_hash.combined(os.path.join(R, obj), rx),
-               "source": "tools/refresh_r05.sh (rocprofv3 --pmc, separate passes per counter group; FETCH_SIZE x 2 on gfx950; valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); valu_insts_at_rest = the same kernels on the column at rest)"},
+               "source": "tools/refresh_r05.sh (rocprofv3 --pmc, separate passes per counter group; FETCH_SIZE x 2 on gfx950; valu_cycles_per_inst_per_simd = GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / SQ_INSTS_VALU of the main kernel; valu_insts_at_rest = the same kernels on the column at rest)"},
               open(os.path.join(O, "pmc_g2p2g.json"), "w"), indent=1)
 s = collect("p2g", ("p2g_wide_kernel",))
 if "hbm_bytes_per_launch" in s.get("p2g_wide_kernel", {}):
