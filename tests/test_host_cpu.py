@@ -293,3 +293,34 @@ def test_merge_sort_kernels_of_the_cpp_face_use_no_scratch_memory(tmp_path):
         seen += 1
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
     assert seen >= 6  # tile sort, partition and merge kernels for int keys, pairs and the struct key
+
+
+def test_block_kernel_of_the_fused_step_keeps_its_chunk_loop_free_of_scratch(tmp_path):
+    """g2p2g_slotblk_kernel runs at 128 VGPRs (two workgroups of 8 waves per CU).  Until r05's second pass 12-14 hoisted loop invariants did
+    not fit and were reloaded from scratch inside the chunk loop: on gfx9 loads and stores share vmcnt, so every such reload waited for the
+    record prefetch of the next chunk and for the particle stores (profiles/r05_block_kernel.md, section 7: 6.52 -> 6.33 ms/step once they
+    were gone).  The solid models' instantiations must stay at zero private memory, and the kernel's code must stay one producer body
+    (the wave number is a run-time value: 54 KB, not 87-94 KB)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "zpc_amd", "lib", "obj", "mpm_slotblk.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("object file or llvm tools not present")
+    fat, co = str(tmp_path / "p.fat"), str(tmp_path / "p.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                           "--output=" + co, "--unbundle"])
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    seen = 0
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        m = name and re.search(r"g2p2g_slotblk_kernelILi(\d)ELb", name.group(1))
+        if not m or int(m.group(1)) > 3:  # 0 fixed-corotated, 1 DruckerPrager, 2 von Mises, 3 NACC (4 = the fluid: not covered)
+            continue
+        seen += 1
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 128, name.group(1)
+    assert seen == 8  # four models x {write everything, write the step's state only}
+    syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-sW", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    sizes = [int(l.split()[2]) for l in syms.splitlines() if "g2p2g_slotblk_kernelILi1ELb0" in l and " FUNC " in l]
+    assert sizes and max(sizes) < 64 * 1024, sizes
