@@ -14,8 +14,14 @@
 //     for the block arena).  A producer waits, right before it stages, until all four consumers have counted the previous chunk done (an
 //     LDS counter, no barrier: the consumers finish a chunk in half the time the producers need for the next); one barrier per chunk
 //     hands the staged chunk over;
-//   * per-bin state (entry table, tickets, departures, outbox count, neighbour bins) is double-buffered by bin parity; the entry table
-//     of a bin is built two chunks ahead by the producers, a finished bin's claim words are written out one chunk later;
+//   * per-bin state (entry table, tickets, departures, outbox count, neighbour bins) is double-buffered by bin parity and kept by the
+//     CONSUMER waves, which have the time: the entry table of a bin is built three chunks ahead, its neighbour bins two chunks ahead,
+//     a finished bin's claim words are written out with its last chunk (blk_consumer spells out when each buffer is free); everything
+//     the loops need to know about a chunk sits in one packed word (ChunkDesc), read once per iteration into SGPRs;
+//   * 128 VGPRs and NO scratch: the uniform constants of the per-particle code come from the host (MpmDev::dxi, D_inv, fscale;
+//     Material::smu, dpCoef, expCohesion -- kernel arguments live in SGPRs), one producer body serves the four producer waves.  On gfx9
+//     loads and stores share vmcnt, so a spill reload inside the chunk loop waits for the record prefetch of the next chunk and for the
+//     particle stores just issued (profiles/r05_block_kernel.md, section 7; tests/test_host_cpu.py keeps it that way);
 //   * the bin's P2G arena has 8^3 nodes (ArenaBin8): a mover into a neighbour bin adds its 27 node terms there (plain LDS
 //     read-add-write) and they reach the grid with the bin's one flush -- no global atomics per mover.
 // The per-particle code (slot_produce_entry), the consumers' accumulation (g2p2g_consume_set), the mover protocol, slot_rehome_kernel
