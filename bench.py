@@ -672,15 +672,26 @@ def main():
     barrier()
     probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_debug_probe")  # measurement builds only (-DZS_PROBE, tools/ab_build.sh)
     slot_probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_slot_probe")  # -DZS_PROBE build of mpm_slotted.hip
+    p2g_probe = os.environ.get("ZS_ROCM_PROBE") and hasattr(lib(), "zs_rocm_p2g_probe")  # -DZS_PROBE_P2G build of mpm_p2g.hip
     if probe or slot_probe:
         import ctypes
         pv = (ctypes.c_ulonglong * 32)()
         (lib().zs_rocm_slot_probe if slot_probe else lib().zs_rocm_debug_probe)(pv, 1)
+    if p2g_probe:
+        import ctypes
+        ppv = (ctypes.c_ulonglong * 16)()
+        lib().zs_rocm_p2g_probe(ppv, 1)
     t0 = time.perf_counter()
     run_steps(a.steps, True)
     host_enqueue_s = time.perf_counter() - t0   # when the last step was enqueued (== elapsed once the launch queue is full)
     barrier()
     elapsed = time.perf_counter() - t0
+    if p2g_probe:
+        lib().zs_rocm_p2g_probe(ppv, 0)
+        nw = max(int(ppv[8]), 1)
+        names = ["life", "head", "stream", "stream: in vmcnt waits", "barrier + arena clear", "27 phases", "post-pass + atomics issued", "atomics drained"]
+        print("p2g probe (s_memtime ticks per sampled wave): " + "  ".join("%s=%.0f" % (names[k], ppv[k] / nw) for k in range(8)) +
+              "  rounds=%.2f  waves=%d" % (ppv[9] / nw, nw), file=sys.stderr)
     if slot_probe:
         lib().zs_rocm_slot_probe(pv, 0)
         wgs = max(int(pv[11]), 1)

@@ -1318,123 +1318,18 @@ template <> struct ArenaLdsG<4> {
   __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
 };
 
-// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of P2GW_NF x 256 B per wave).
-// G = bins (= waves) per workgroup.  Every wave streams its own bin exactly as a one-wave workgroup would (nothing is shared while the
-// records flow); what the G waves share is the flush: their register stencils go into ONE arena and the workgroup issues one set of
-// global float atomics for it.  The atomics are what the kernel writes (every atomic instruction writes the 32-byte sectors it touches
-// through to memory, whatever the launch order: profiles/r04_launch_order.md), and neighbouring bins' aprons overlap: per 8^3 block
-// 8 x 7 x 36 rows x 1.5 sectors = 3024 sector writes with G = 1, 2016 with G = 2 (a row of 10 z-nodes = the block's own 32-byte row + 8
-// bytes of the next block's), 1680 with G = 4.
-template <int SIDE, int LW, int DEPTH, int G>
-static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
-                                                           const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
-  static_assert(G == 1 || (SIDE == 8 && (G == 2 || G == 4)), "G bins of one block");
+// tail shared by the wide P2G kernels: the queued in-bin movers go into the arena by LDS atomics (same values as the exact path), then
+// the arena goes to the grid -- origin of the workgroup's arena inside its block = the origin of its first bin
+template <int SIDE, int G>
+__device__ __forceinline__ void p2gw_movers_and_flush(const MpmDev &mp, const ParticlesDev &ps, const BinGeom<SIDE> &geo, float *arena, const int *mqw,
+                                                      int mqCountW, int lane, int ay, int az, const int *nbr, float *grid) {
   using AL = ArenaLdsG<G>;
   constexpr int NC = SIDE * SIDE * SIDE;
-  constexpr int NB = DEPTH + 1;
-  constexpr int WBUF = NB * P2GW_NF * 64;  // floats of record buffers per wave
-  // the record buffers and the flush arena are never live at the same time: one LDS region serves both
-  constexpr int LDSF = G * WBUF > 7 * AL::CH ? G * WBUF : 7 * AL::CH;
-  __shared__ float lds[LDSF];
-  __shared__ int mq[G][P2GW_MQ_CAP];  // particles that sit in another cell of their bin (moved since the last re-bin)
-  __shared__ int mqCount[G];
-  const int w = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (w in an SGPR)
-  const int bin0 = (int)xcd_chunked(blockIdx.x, gridDim.x) * G, bin = bin0 + w;
-  if (binStart[bin0] == binStart[bin0 + G]) return;  // none of the G bins holds a particle (workgroup-uniform)
-  float *arena = lds;
-  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds + w * WBUF);
-  const int start = binStart[bin], end = binStart[bin + 1];
-  if (lane == 0) mqCount[w] = 0;
-  __syncthreads();
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-  const unsigned cnt = start == end ? 0u : cellCount[(size_t)bin * 64 + lane];
-  const float dxi = mp.dxi;
-  const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
-  float acc[27][7];
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
-  // two walks over the same counts: `lead` runs DEPTH rounds ahead and issues the loads, `walk` consumes
-  const size_t tileBase = p2gw_tile_base<LW>(ps, start);
-  RoundWalk lead(cnt, start), walk(cnt, start);
-  int li;
-  bool lany = true;
-  int issued = 0;  // rounds issued and not yet consumed (wave-uniform)
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (lany) {
-      const bool lh = lead.next(li, lany);
-      if (lany) {
-        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[d % NB], tileBase);
-        ++issued;
-      }
-    }
-  }
-  int slot = 0, lslot = DEPTH % NB;
-  int i0;
-  bool any;
-  bool has0 = walk.next(i0, any);
-  while (any) {
-    if (lany) {
-      const bool lh = lead.next(li, lany);
-      if (lany) {
-        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[lslot], tileBase);
-        lslot = lslot + 1 == NB ? 0 : lslot + 1;
-        ++issued;
-      }
-    }
-    // wait until only the records issued AFTER the current one are still in flight
-    // (a record is P2GW_NF loads; vmcnt holds 6 bits: two records in flight is the most that can be told apart)
-    static_assert(2 * P2GW_NF <= 63, "vmcnt range");
-    if (issued >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P2GW_NF) : "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2GW_NF) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has0) {
-      const float *rec = pbuf[slot] + lane;
-      const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
-      Arena ar;
-      make_arena(mp.dx, mp.dxi, pos, ar);
-      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
-      if (ocx == cx && ocy == cy && ocz == cz) {
-        p2gw_accumulate(mp, ar, rec, kscale, acc);
-      } else {
-        // another cell of the same bin: queued for the post-pass into the arena; outside the bin: exact path afterwards
-        bool queued = false;
-        if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
-          const int q = atomicAdd(&mqCount[w], 1);
-          if (q < P2GW_MQ_CAP) {
-            mq[w][q] = i0;
-            queued = true;
-          }
-        }
-        if (!queued) stale[atomicAdd(staleCount, 1)] = i0;
-      }
-    }
-    --issued;
-    slot = slot + 1 == NB ? 0 : slot + 1;
-    has0 = walk.next(i0, any);
-  }
-  __syncthreads();  // every record of every wave has been consumed: the region becomes the arena
-  for (int k = threadIdx.x; k < 7 * AL::CH; k += 64 * G) arena[k] = 0.f;
-  __syncthreads();
-  // this bin's corner inside the workgroup's arena: the G bins differ in z (G = 2) or in y and z (G = 4)
-  const int ay = G == 4 ? (w >> 1) * 4 : 0, az = G == 1 ? 0 : (w & 1) * 4;
-  float *a0 = arena + AL::at(cx, cy + ay, cz + az);
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases: in a phase the 64 G lanes of the workgroup own 64 G distinct nodes
-    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) g[ch * AL::CH] += acc[k][ch];
-    if constexpr (G == 1) __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
-    else __syncthreads();
-  }
-  __syncthreads();
+  const float kscale = mp.fscale;
   {  // post-pass: the queued in-bin particles, one lane each, added to the arena with LDS atomics (same values as the exact path)
-    const int nm = mqCount[w] < P2GW_MQ_CAP ? mqCount[w] : P2GW_MQ_CAP;
+    const int nm = mqCountW < P2GW_MQ_CAP ? mqCountW : P2GW_MQ_CAP;
     for (int q = lane; q < nm; q += 64) {
-      const size_t i = (size_t)mq[w][q];
+      const size_t i = (size_t)mqw[q];
       float pos[3], vel[3], C[9], PF[9];
       load_attr<3>(ps.pos, i, pos);
       load_attr<3>(ps.vel, i, vel);
@@ -1486,6 +1381,483 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
       }
     }
   }
+}
+
+#ifdef ZS_PROBE_P2G  // measurement-only build (tools/ab_build.sh): s_memtime stamps of a wave's phases in p2g_wide_kernel, summed over the sampled waves
+__device__ unsigned long long g_p2g_probe[16];
+#define P2G_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define P2G_STAMP(slot, dt) do { if (pSample) atomicAdd(&g_p2g_probe[slot], (unsigned long long)(dt)); } while (0)
+#else
+#define P2G_NOW() 0ull
+#define P2G_STAMP(slot, dt) do { } while (0)
+#endif
+// DEPTH = rounds of records in flight ahead of the one being computed (DEPTH + 1 LDS buffers of P2GW_NF x 256 B per wave).
+// G = bins (= waves) per workgroup.  Every wave streams its own bin exactly as a one-wave workgroup would (nothing is shared while the
+// records flow); what the G waves share is the flush: their register stencils go into ONE arena and the workgroup issues one set of
+// global float atomics for it.  The atomics are what the kernel writes (every atomic instruction writes the 32-byte sectors it touches
+// through to memory, whatever the launch order: profiles/r04_launch_order.md), and neighbouring bins' aprons overlap: per 8^3 block
+// 8 x 7 x 36 rows x 1.5 sectors = 3024 sector writes with G = 1, 2016 with G = 2 (a row of 10 z-nodes = the block's own 32-byte row + 8
+// bytes of the next block's), 1680 with G = 4.
+template <int SIDE, int LW, int DEPTH, int G>
+static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+                                                           const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  static_assert(G == 1 || (SIDE == 8 && (G == 2 || G == 4)), "G bins of one block");
+  using AL = ArenaLdsG<G>;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  constexpr int NB = DEPTH + 1;
+  constexpr int WBUF = NB * P2GW_NF * 64;  // floats of record buffers per wave
+  // the record buffers and the flush arena are never live at the same time: one LDS region serves both
+  constexpr int LDSF = G * WBUF > 7 * AL::CH ? G * WBUF : 7 * AL::CH;
+  __shared__ float lds[LDSF];
+  __shared__ int mq[G][P2GW_MQ_CAP];  // particles that sit in another cell of their bin (moved since the last re-bin)
+  __shared__ int mqCount[G];
+  const int w = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (w in an SGPR)
+  const int bin0 = (int)xcd_chunked(blockIdx.x, gridDim.x) * G, bin = bin0 + w;
+#ifdef ZS_PROBE_P2G
+  const bool pSample = lane == 0 && (blockIdx.x & 15) == 0;
+  const unsigned long long tp0 = P2G_NOW();
+  unsigned long long tpWait = 0, tpRounds = 0;
+#endif
+  if (binStart[bin0] == binStart[bin0 + G]) return;  // none of the G bins holds a particle (workgroup-uniform)
+  float *arena = lds;
+  float(*pbuf)[P2GW_NF * 64] = reinterpret_cast<float(*)[P2GW_NF * 64]>(lds + w * WBUF);
+  const int start = binStart[bin], end = binStart[bin + 1];
+  if (lane == 0) mqCount[w] = 0;
+  __syncthreads();
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const unsigned cnt = start == end ? 0u : cellCount[(size_t)bin * 64 + lane];
+  const float dxi = mp.dxi;
+  const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
+  float acc[27][7];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
+  // two walks over the same counts: `lead` runs DEPTH rounds ahead and issues the loads, `walk` consumes
+  const size_t tileBase = p2gw_tile_base<LW>(ps, start);
+  RoundWalk lead(cnt, start), walk(cnt, start);
+  int li;
+  bool lany = true;
+  int issued = 0;  // rounds issued and not yet consumed (wave-uniform)
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (lany) {
+      const bool lh = lead.next(li, lany);
+      if (lany) {
+        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[d % NB], tileBase);
+        ++issued;
+      }
+    }
+  }
+  int slot = 0, lslot = DEPTH % NB;
+  int i0;
+  bool any;
+  bool has0 = walk.next(i0, any);
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp1 = P2G_NOW();  // head done: counts known, first DEPTH rounds requested
+#endif
+  while (any) {
+    if (lany) {
+      const bool lh = lead.next(li, lany);
+      if (lany) {
+        p2gw_issue<LW>(ps, (size_t)li, lh, pbuf[lslot], tileBase);
+        lslot = lslot + 1 == NB ? 0 : lslot + 1;
+        ++issued;
+      }
+    }
+    // wait until only the records issued AFTER the current one are still in flight
+    // (a record is P2GW_NF loads; vmcnt holds 6 bits: two records in flight is the most that can be told apart)
+    static_assert(2 * P2GW_NF <= 63, "vmcnt range");
+#ifdef ZS_PROBE_P2G
+    const unsigned long long tw0 = P2G_NOW();
+#endif
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P2GW_NF) : "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2GW_NF) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ZS_PROBE_P2G
+    tpWait += P2G_NOW() - tw0;
+    ++tpRounds;
+#endif
+    if (has0) {
+      const float *rec = pbuf[slot] + lane;
+      const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
+      Arena ar;
+      make_arena(mp.dx, mp.dxi, pos, ar);
+      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+      if (ocx == cx && ocy == cy && ocz == cz) {
+        p2gw_accumulate(mp, ar, rec, kscale, acc);
+      } else {
+        // another cell of the same bin: queued for the post-pass into the arena; outside the bin: exact path afterwards
+        bool queued = false;
+        if ((unsigned)ocx < 4u && (unsigned)ocy < 4u && (unsigned)ocz < 4u) {
+          const int q = atomicAdd(&mqCount[w], 1);
+          if (q < P2GW_MQ_CAP) {
+            mq[w][q] = i0;
+            queued = true;
+          }
+        }
+        if (!queued) stale[atomicAdd(staleCount, 1)] = i0;
+      }
+    }
+    --issued;
+    slot = slot + 1 == NB ? 0 : slot + 1;
+    has0 = walk.next(i0, any);
+  }
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp2 = P2G_NOW();  // stream done
+#endif
+  __syncthreads();  // every record of every wave has been consumed: the region becomes the arena
+  for (int k = threadIdx.x; k < 7 * AL::CH; k += 64 * G) arena[k] = 0.f;
+  __syncthreads();
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp3 = P2G_NOW();  // waited for the other waves, arena cleared
+#endif
+  // this bin's corner inside the workgroup's arena: the G bins differ in z (G = 2) or in y and z (G = 4)
+  const int ay = G == 4 ? (w >> 1) * 4 : 0, az = G == 1 ? 0 : (w & 1) * 4;
+  float *a0 = arena + AL::at(cx, cy + ay, cz + az);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {  // 27 conflict-free phases: in a phase the 64 G lanes of the workgroup own 64 G distinct nodes
+    float *g = a0 + AL::at(k / 9, (k / 3) % 3, k % 3);
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) g[ch * AL::CH] += acc[k][ch];
+    if constexpr (G == 1) __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+    else __syncthreads();
+  }
+  __syncthreads();
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp4 = P2G_NOW();  // 27 phases done
+#endif
+  p2gw_movers_and_flush<SIDE, G>(mp, ps, geo, arena, mq[w], mqCount[w], lane, ay, az, nbr, grid);
+#ifdef ZS_PROBE_P2G
+  {
+    const unsigned long long tp5 = P2G_NOW();  // atomics issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tp6 = P2G_NOW();
+    P2G_STAMP(0, tp6 - tp0);   // life of the wave
+    P2G_STAMP(1, tp1 - tp0);   // head: bin range, cell counts, block key, first requests
+    P2G_STAMP(2, tp2 - tp1);   // record stream (all rounds)
+    P2G_STAMP(3, tpWait);      // ... of which inside s_waitcnt vmcnt
+    P2G_STAMP(4, tp3 - tp2);   // barrier with the group's other waves + arena clear
+    P2G_STAMP(5, tp4 - tp3);   // 27 register -> arena phases
+    P2G_STAMP(6, tp5 - tp4);   // movers' post-pass + arena -> grid atomics issued
+    P2G_STAMP(7, tp6 - tp5);   // atomics drained
+    P2G_STAMP(8, 1);           // sampled waves
+    P2G_STAMP(9, tpRounds);    // rounds
+  }
+#endif
+}
+
+// ---- tile-stream variant of the wide P2G (LW = 64 only): the record loads are decoupled from the rounds.
+// A bin's particles are the contiguous range [start, end) of the compact order, i.e. the tiles start / 64 .. (end - 1) / 64 of the AoSoA
+// container.  The wave requests WHOLE TILES (22 rows x 256 B by 6 - 8 `global_load_lds_dwordx4` of 1 KiB each instead of 22 dword
+// requests per round of ~42 particles: an LDS-direct load costs the wave tens of cycles of issue whatever its width) into a ring of NB tile buffers as soon as
+// the bin's range is known -- before its cell counts arrive, so the head of a wave is ONE memory round trip instead of two -- and a
+// round's lane reads its particle at ring position (index mod 64) of tile (index / 64).  A tile buffer is re-requested when the walk has
+// passed the tile's last particle: NB - 1 tiles (1.5 - 3 rounds) stay in flight ahead of the round being accumulated.
+// One request = one `global_load_lds_dwordx4`: lane l moves 16 bytes from (row base + 16 l) to (LDS base + 16 l), i.e. FOUR consecutive
+// 256-byte channel rows of the tile per wave-instruction (1 KiB), and the instruction offset advances both addresses.  MERGED: the host
+// found m, x, v, C in 16 adjacent channels (the layout of zpc_amd.mpm and of the reference's particles TileVector {m, x, v, C, ...}):
+// 4 + 2 requests per tile; otherwise one base per attribute, 8 requests (the last of an attribute with the lanes of its remaining rows).
+template <int ROW0, int N>
+__device__ __forceinline__ void p2gt_issue_attr(const Port<float> &p, size_t tb, int lane, float *buf) {
+  // (the two readfirstlanes keep the tile's base an SGPR pair: without them the loop-invariant p.base + lane offset is hoisted as a
+  // 64-bit VGPR address per attribute and the accumulators spill)
+  const unsigned long long ub = (unsigned long long)(p.base + tb);
+  const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub);
+  const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(sb) + (size_t)((unsigned)lane * 16u));
+  auto *l = (__attribute__((address_space(3))) void *)(buf + ROW0 * 64);
+  constexpr int FULL = N / 4, REST = N % 4;
+  if constexpr (FULL > 0) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+  if constexpr (FULL > 1) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+  if constexpr (FULL > 2) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+  if constexpr (FULL > 3) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+  static_assert(FULL <= 4, "up to 16 + 3 rows per base");
+  if constexpr (REST > 0)
+    if (lane < REST * 16) __builtin_amdgcn_global_load_lds(g, l, 16, FULL * 1024, 0);
+}
+template <bool MERGED> constexpr int p2gt_requests() { return MERGED ? 4 + (STRESS_N + 3) / 4 : 1 + 1 + 1 + 3 + (STRESS_N + 3) / 4; }
+template <bool MERGED>
+__device__ __forceinline__ void p2gt_issue(const ParticlesDev &ps, int tile, int lane, float *buf) {
+  const size_t tb = (size_t)tile * (size_t)ps.pos.chns * 64;  // element offset of the tile (wave-uniform)
+  if constexpr (MERGED) {
+    p2gt_issue_attr<0, 16>(ps.mass, tb, lane, buf);
+  } else {
+    p2gt_issue_attr<0, 1>(ps.mass, tb, lane, buf);
+    p2gt_issue_attr<1, 3>(ps.pos, tb, lane, buf);
+    p2gt_issue_attr<4, 3>(ps.vel, tb, lane, buf);
+    p2gt_issue_attr<7, 9>(ps.C, tb, lane, buf);
+  }
+  p2gt_issue_attr<16, STRESS_N>(ps.stress, tb, lane, buf);
+}
+
+template <int SIDE, int NB, int G, bool MERGED>
+static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, float *grid, const int *binStart,
+                                                           const unsigned *cellCount, const int *nbr, int *stale, int *staleCount) {
+  static_assert(G == 1 || (SIDE == 8 && (G == 2 || G == 4)), "G bins of one block");
+  constexpr int NL = p2gt_requests<MERGED>();  // load instructions per tile
+  static_assert((NB - 1) * NL <= 63, "vmcnt range");
+  using AL = ArenaLdsG<G>;
+  constexpr int NC = SIDE * SIDE * SIDE;
+  constexpr int TILEF = P2GW_NF * 64;     // floats of one tile buffer
+  constexpr int WBUF = NB * TILEF;        // ... of a wave's ring
+  constexpr int LDSF = G * WBUF > 7 * AL::CH ? G * WBUF : 7 * AL::CH;  // ring and flush arena are never live at the same time
+  __shared__ float lds[LDSF];
+  __shared__ int mq[G][P2GW_MQ_CAP];
+  __shared__ int mqCount[G];
+  const int w = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int bin0 = (int)xcd_chunked(blockIdx.x, gridDim.x) * G, bin = bin0 + w;
+#ifdef ZS_PROBE_P2G
+  const bool pSample = lane == 0 && (blockIdx.x & 15) == 0;
+  const unsigned long long tp0 = P2G_NOW();
+  unsigned long long tpWait = 0, tpRounds = 0;
+#endif
+  // the G + 1 range words of the workgroup's bins and this wave's cell counts are requested together
+  int bs[G + 1];
+#pragma unroll
+  for (int k = 0; k <= G; ++k) bs[k] = binStart[bin0 + k];
+  int start = bs[0], end = bs[1];
+#pragma unroll
+  for (int k = 1; k < G; ++k)
+    if (w == k) start = bs[k], end = bs[k + 1];
+  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];  // (all zero for an empty bin)
+  float *arena = lds;
+  float *ring = lds + w * WBUF;
+  const int tile0 = start >> 6, tileEnd = (end + 63) >> 6;  // the bin's tiles (none if start == end)
+  int tIssue = tile0;  // next tile to request; its buffer is ring[(tIssue - tile0) % NB] = islot
+  int islot = 0;
+  auto request = [&]() {
+    p2gt_issue<MERGED>(ps, tIssue, lane, ring + islot * TILEF);
+    ++tIssue;
+    islot = islot + 1 == NB ? 0 : islot + 1;
+  };
+  if (start != end) {
+#pragma unroll 1
+    for (int k = 0; k < NB; ++k)
+      if (tIssue < tileEnd) request();
+  }
+  if (bs[0] == bs[G]) return;  // none of the G bins holds a particle (workgroup-uniform)
+  if (lane == 0) mqCount[w] = 0;  // (only this wave touches mq[w] / mqCount[w]: its LDS operations execute in order)
+  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  // the block's 8 neighbour numbers {+0, +1}^3 for the flush: wave-uniform, requested now (scalar loads) instead of one dependent
+  // vector load per flushed node at the end of the wave's life
+  int nbs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) nbs[k] = __builtin_amdgcn_readfirstlane(nbr[(size_t)geo.block * 8 + k]);  // (SGPRs)
+  const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
+  float acc[27][7];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
+  int base = start;      // first particle of the round (wave-uniform)
+  int tDone = tile0;     // tiles below have arrived
+  int cslot = 0;         // ring slot of tile base / 64
+  unsigned r = 0;
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp1 = P2G_NOW();
+#endif
+  bool has = cnt > r;
+  unsigned long long m = __ballot(has);
+  while (m != 0ull) {
+    const int nr = __popcll(m);
+    const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int tb = base >> 6, tLast = (base + nr - 1) >> 6;
+    // a tile buffer is free once the walk has passed the tile: tile tIssue - NB was left when base reached (tIssue - NB + 1) * 64
+    if (tIssue < tileEnd && tb > tIssue - NB) request();
+#ifdef ZS_P2GT_LOOPSYNC
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#ifdef ZS_PROBE_P2G
+    const unsigned long long tw0 = P2G_NOW();
+#endif
+    if (tLast >= tDone) {
+      const int ahead = tIssue - 1 - tLast;  // requested tiles the round does not need yet
+      if (NB >= 4 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 4 ? 3 * NL : 0) : "memory");
+      else if (NB >= 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tDone = tLast + 1;
+    }
+#ifdef ZS_PROBE_P2G
+    tpWait += P2G_NOW() - tw0;
+    ++tpRounds;
+#endif
+    if (has) {
+      const int nslot = cslot + 1 == NB ? 0 : cslot + 1;
+      const float *rec = ring + ((p >> 6) == tb ? cslot : nslot) * TILEF + (p & 63);
+      const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
+      Arena ar;
+      make_arena(mp.dx, mp.dxi, pos, ar);
+      const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
+      const bool inBin = (unsigned)(ocx | ocy | ocz) < 4u;  // all three in 0..3
+      if (inBin && ((ocx << 4) | (ocy << 2) | ocz) == lane) {  // lane = cell: (x, y, z) = (lane >> 4, (lane >> 2) & 3, lane & 3)
+        p2gw_accumulate(mp, ar, rec, kscale, acc);
+      } else {
+        bool queued = false;
+        if (inBin) {
+          const int q = atomicAdd(&mqCount[w], 1);
+          if (q < P2GW_MQ_CAP) {
+            mq[w][q] = p;
+            queued = true;
+          }
+        }
+        if (!queued) stale[atomicAdd(staleCount, 1)] = p;
+      }
+    }
+    base += nr;
+    if ((base >> 6) != tb) cslot = cslot + 1 == NB ? 0 : cslot + 1;
+    ++r;
+    has = cnt > r;
+    m = __ballot(has);
+  }
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp2 = P2G_NOW();
+#endif
+  // ---- tail.  Every tile the wave requested has been consumed, so its ring is free: it becomes the wave's PRIVATE 6^3 arena.  No
+  // other wave touches it until the group's barrier below, and a wave's LDS operations execute in order, so the 27 x 7
+  // read-add-write steps need no barrier and no wait between phases: the read of (phase k + 1, channel c) is issued right behind
+  // the write of (phase k, channel c) and its latency is covered by the six other channels' steps.
+  using AP = ArenaLds;
+  static_assert(7 * AP::CH <= WBUF && (7 * AP::CH) % 4 == 0 && WBUF % 4 == 0, "private arena inside the wave's ring, 16-byte clears");
+  float *priv = ring;
+  for (int k = lane * 4; k < 7 * AP::CH; k += 256) *reinterpret_cast<float4 *>(priv + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+#define P2GT_LDS_ORDER()                                   \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+  P2GT_LDS_ORDER();
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp3 = P2G_NOW();
+#endif
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  {
+    float *a0 = priv + AP::at(cx, cy, cz);
+    float v[7];
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) v[ch] = a0[ch * AP::CH];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      float *g = a0 + AP::at(k / 9, (k / 3) % 3, k % 3);
+      float *gn = a0 + AP::at((k + 1) / 9, ((k + 1) / 3) % 3, (k + 1) % 3);
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        g[ch * AP::CH] = v[ch] + acc[k][ch];
+        P2GT_LDS_ORDER();
+        if (k + 1 < 27) v[ch] = gn[ch * AP::CH];
+      }
+    }
+  }
+  {  // the queued in-bin movers, one lane each, by LDS atomics into the private arena (same values as the exact path)
+    const int nm = mqCount[w] < P2GW_MQ_CAP ? mqCount[w] : P2GW_MQ_CAP;
+    for (int q = lane; q < nm; q += 64) {
+      const size_t i = (size_t)mq[w][q];
+      float pos[3], vel[3], C[9], PF[9];
+      load_attr<3>(ps.pos, i, pos);
+      load_attr<3>(ps.vel, i, vel);
+      load_attr<9>(ps.C, i, C);
+      {
+        float S[STRESS_N];
+        load_attr<STRESS_N>(ps.stress, i, S);
+        stress_unpack(S, PF);
+      }
+      const float pm = ps.mass.base[ps.mass.off(i)];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) PF[d] *= kscale;
+      Arena ar;
+      make_arena(mp.dx, mp.dxi, pos, ar);
+      float *b0 = priv + AP::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1], ar.corner[2] - geo.org[2]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
+            const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
+            float *g = b0 + AP::at(a, b, c);
+            atomicAdd(g, W * pm);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              atomicAdd(g + (1 + d) * AP::CH, W * pm * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
+              atomicAdd(g + (4 + d) * AP::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
+            }
+          }
+    }
+  }
+  if constexpr (G == 1) P2GT_LDS_ORDER();
+  else __syncthreads();  // the G private arenas are complete
+#undef P2GT_LDS_ORDER
+#ifdef ZS_PROBE_P2G
+  const unsigned long long tp4 = P2G_NOW();
+#endif
+  // flush.  The group's nodes (6 x 6 x 6 G: the bins differ in z (G = 2) or in y and z (G = 4)) go to the grid once each: an apron
+  // node between two (four) bins is the sum of what their private arenas hold for it.
+  {
+    const int wy = G == 4 ? (w >> 1) * 4 : 0, wz = G == 1 ? 0 : (w & 1) * 4;
+    const int o0[3] = {geo.o[0], geo.o[1] - wy, geo.o[2] - wz};  // origin of the group inside its block = the origin of its first bin
+    constexpr int NODES = AL::WX * AL::WY * AL::WZ, ITER = (NODES + 64 * G - 1) / (64 * G);
+    float val[ITER][7];
+    int goff[ITER];  // element offset of the node's first channel in the grid, -1: no such block / no such node
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {  // every LDS read of the flush first ...
+      const int node = (int)threadIdx.x + it * 64 * G;
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) val[it][ch] = 0.f;
+      goff[it] = -1;
+      if (node < NODES) {
+        const int x = node / (AL::WY * AL::WZ), y = (node / AL::WZ) % AL::WY, z = node % AL::WZ;
+        int slot2, cell;
+        arena_to_grid<SIDE>(o0, x, y, z, slot2, cell);
+        const int b01 = (slot2 & 1) ? nbs[1] : nbs[0], b23 = (slot2 & 1) ? nbs[3] : nbs[2], b45 = (slot2 & 1) ? nbs[5] : nbs[4],
+                  b67 = (slot2 & 1) ? nbs[7] : nbs[6];
+        const int b03 = (slot2 & 2) ? b23 : b01, b47 = (slot2 & 2) ? b67 : b45;
+        const int bn = (slot2 & 4) ? b47 : b03;
+        if (bn >= 0) goff[it] = bn * (7 * NC) + cell;
+#pragma unroll
+        for (int gy = 0; gy < (G == 4 ? 2 : 1); ++gy)
+#pragma unroll
+          for (int gz = 0; gz < (G == 1 ? 1 : 2); ++gz) {
+            const int ly = y - 4 * gy, lz = z - 4 * gz;
+            if ((unsigned)ly < 6u && (unsigned)lz < 6u) {
+              const float *a = lds + (gy * 2 + gz) * WBUF + AP::at(x, ly, lz);
+#pragma unroll
+              for (int ch = 0; ch < 7; ++ch) val[it][ch] += a[ch * AP::CH];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)  // ... then the float atomics
+      if (goff[it] >= 0) {
+        float *g = grid + (size_t)(unsigned)goff[it];
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch)
+          if (val[it][ch] != 0.f) unsafeAtomicAdd(g + ch * NC, val[it][ch]);
+      }
+  }
+#ifdef ZS_P2GT_ENDWAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef ZS_PROBE_P2G
+  {
+    const unsigned long long tp5 = P2G_NOW();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tp6 = P2G_NOW();
+    P2G_STAMP(0, tp6 - tp0);
+    P2G_STAMP(1, tp1 - tp0);
+    P2G_STAMP(2, tp2 - tp1);
+    P2G_STAMP(3, tpWait);
+    P2G_STAMP(4, tp3 - tp2);
+    P2G_STAMP(5, tp4 - tp3);
+    P2G_STAMP(6, tp5 - tp4);
+    P2G_STAMP(7, tp6 - tp5);
+    P2G_STAMP(8, 1);
+    P2G_STAMP(9, tpRounds);
+  }
+#endif
 }
 
 // exact path for the queued particles (persistent grid-stride over a device-side count)

@@ -24,12 +24,42 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
       // (profiles/r04_p2g.md): 1.74 / 1.71 / 1.72 ms for 1 / 2 / 4 with 1.73 / -- / 1.04 GB written: the time no longer follows the
       // traffic, so the default is the pair (least coupling between waves).  ZS_ROCM_P2G_GROUP = 1 | 2 | 4 overrides it for A/B runs.
       static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 2; }();
+      // m, x, v, C in 16 adjacent channels of one TileVector (lw == 64 already says: same tiles, same channel count, 16-byte aligned rows)
+      const bool merged = lw == 64 && (const float *)ps.pos.base == (const float *)ps.mass.base + 64 &&
+                          (const float *)ps.vel.base == (const float *)ps.mass.base + 4 * 64 && (const float *)ps.C.base == (const float *)ps.mass.base + 7 * 64;
+      const bool aligned16 = ((((uintptr_t)ps.mass.base) | ((uintptr_t)ps.pos.base) | ((uintptr_t)ps.vel.base) | ((uintptr_t)ps.C.base) | ((uintptr_t)ps.stress.base)) & 15u) == 0;
+      static const bool tileStreamEnv = [] { const char *e = getenv("ZS_ROCM_P2G_TILE"); return !e || atoi(e) != 0; }();
+#ifndef ZS_P2GW_DEPTH
+#define ZS_P2GW_DEPTH 1  // rounds of records requested ahead of the one being accumulated
+#endif
 #define CALL_P2G_WIDE_G(S, LWv, Gv)                                                                                                     \
-  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
+  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, ZS_P2GW_DEPTH, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
                      nbr, stale, staleCount)
+#ifdef ZS_PROBE_P2G  // measurement builds: extra dynamic LDS per workgroup lowers the occupancy (ZS_ROCM_P2G_DYNLDS bytes)
+      static const int p2gtDynLds = [] { const char *e = getenv("ZS_ROCM_P2G_DYNLDS"); return e ? atoi(e) : 0; }();
+#define P2GT_DYN_LDS p2gtDynLds
+#else
+#define P2GT_DYN_LDS 0
+#endif
+#ifndef ZS_P2GT_NB
+#define ZS_P2GT_NB 3  // tile buffers per wave of the tile-stream kernel
+#endif
+#define CALL_P2G_TILE_GM(S, Gv, Mv)                                                                                                     \
+  hipLaunchKernelGGL((p2g_tile_kernel<S, ZS_P2GT_NB, Gv, Mv>), dim3(nbins / Gv), dim3(64 * Gv), P2GT_DYN_LDS, L.stream, mp, pd, t, grid, binStart,  \
+                     cellCount, nbr, stale, staleCount)
+#define CALL_P2G_TILE_G(S, Gv)                                                                                                          \
+  do {                                                                                                                                  \
+    if (merged) { CALL_P2G_TILE_GM(S, Gv, true); }                                                                                      \
+    else { CALL_P2G_TILE_GM(S, Gv, false); }                                                                                            \
+  } while (0)
 #define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
   do {                                                                                                                                  \
-    if (S == 8 && group == 4) { CALL_P2G_WIDE_G(8, LWv, 4); }                                                                            \
+    if (LWv == 64 && tileStreamEnv && aligned16) {                                                                                                      \
+      if (S == 8 && group == 4) { CALL_P2G_TILE_G(8, 4); }                                                                               \
+      else if (S == 8 && group == 2) { CALL_P2G_TILE_G(8, 2); }                                                                          \
+      else { CALL_P2G_TILE_G(S, 1); }                                                                                                   \
+    }                                                                                                                                   \
+    else if (S == 8 && group == 4) { CALL_P2G_WIDE_G(8, LWv, 4); }                                                                       \
     else if (S == 8 && group == 2) { CALL_P2G_WIDE_G(8, LWv, 2); }                                                                       \
     else { CALL_P2G_WIDE_G(S, LWv, 1); }                                                                                                \
     hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid,            \
@@ -52,5 +82,16 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     ZSR_DISPATCH_SIDE_MODEL(p->side, kmodel, CALL_P2G_GLOBAL);
   }
 }
+
+#ifdef ZS_PROBE_P2G  // measurement-only build: read and clear the phase stamps of p2g_wide_kernel
+void zs_rocm_p2g_probe(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zsr::g_p2g_probe), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(zsr::g_p2g_probe), z, sizeof(z));
+  }
+}
+#endif
 
 }  // extern "C"
