@@ -219,6 +219,98 @@ template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev 
   return ret;
 }
 
+// ---- cooperative forms (BHTView::tile_insert / tile_query, Bht.hpp:547-608, 703-736): the lanes of a tile carry the SAME key and
+// examine one bucket together -- lane r takes slot r (16-byte / 8-byte / 4-byte agent-scope load: a 16-slot bucket of 3-D keys is one
+// 256-byte request), ballots find a match and the number of occupied slots, rank 0 claims slot [load] (buckets fill from slot 0, as
+// in the reference: `load` = popc of the non-empty slots is the first empty one) and a lost race re-reads the bucket.
+// Tile: thread_rank(), size() / num_threads(), ballot(pred) with bit r = rank r, any(pred), shfl(v, srcRank) -- a cooperative-groups
+// thread_block_tile<B> or BhtWaveTile below.  A tile narrower than the bucket walks it in pieces of its own width.
+struct BhtWaveTile {  // B consecutive lanes of a wavefront, B a power of two <= 64
+  int base, width;
+  __device__ __forceinline__ BhtWaveTile(int widthPow2) : base((int)(threadIdx.x & 63) & ~(widthPow2 - 1)), width(widthPow2) {}
+  __device__ __forceinline__ int thread_rank() const { return (int)(threadIdx.x & 63) - base; }
+  __device__ __forceinline__ int size() const { return width; }
+  __device__ __forceinline__ unsigned long long ballot(int pred) const {
+    return (__ballot(pred) >> base) & (width == 64 ? ~0ull : ((1ull << width) - 1ull));
+  }
+  __device__ __forceinline__ int any(int pred) const { return ballot(pred) != 0ull; }
+  template <class T> __device__ __forceinline__ T shfl(T v, int srcRank) const { return __shfl(v, base + srcRank); }
+};
+// returns the claimed slot (>= 0, same value on every lane; rank 0 made the claim), -1 when the key is present, BHT_FAIL on overflow
+template <int DIM, class Tile> __device__ __forceinline__ int bht_tile_find_or_claim(const BhtDev &t, const int *key, Tile &tile) {
+  if (t.numBuckets == 0) return BHT_FAIL;
+  const int B = (int)t.bucket, rank = (int)tile.thread_rank(), ts = (int)tile.size();
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * t.bucket;
+  for (int iter = 0; iter < 3;) {
+    int load = 0;
+    bool found = false, busy = false;
+    for (int off = 0; off < B; off += ts) {
+      const bool mine = off + rank < B;
+      const int st = mine ? bht_probe<DIM>(t, bucket + (unsigned)(off + rank), key) : 0;
+      found = found || tile.any(mine && st == 1);
+      busy = busy || tile.any(mine && st == 2);
+      load += __popcll(tile.ballot(mine && st != 0));
+    }
+    if (busy) continue;     // a slot is being written (it may become this key): look again
+    if (found) return -1;   // sentinel_v: already present
+    if (load <= B - 2) {    // threshold = B - 2 (Bht.hpp:34)
+      int ok = 0;
+      if (rank == 0) ok = bht_claim<DIM>(t, bucket + (unsigned)load, key) ? 1 : 0;
+      if (tile.shfl(ok, 0)) return (int)(bucket + (unsigned)load);
+      // by the time, position [load] was already filled (Bht.hpp:571): re-read the bucket
+    } else {
+      ++iter;
+      if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * t.bucket;
+      else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * t.bucket;
+    }
+  }
+  if (rank == 0) *t.success = 0;
+  return BHT_FAIL;
+}
+// BHTView::tile_insert (Bht.hpp:547-608): every lane returns the index (only the inserting call returns a fresh one), -1 if present
+template <int DIM, class Tile>
+__device__ __forceinline__ int bht_tile_insert(const BhtDev &t, const int *key, Tile &tile, int insertion_index = -1, bool enqueue = true) {
+  const int slot = bht_tile_find_or_claim<DIM>(t, key, tile);
+  if (slot < 0) return slot;
+  int no = insertion_index;
+  if (tile.thread_rank() == 0) {
+    if (insertion_index == -1) no = (int)atomicAdd((unsigned *)t.cnt, 1u);
+    no = bht_commit<DIM>(t, slot, key, no, enqueue);
+  }
+  return tile.shfl(no, 0);
+}
+// BHTView::tile_query (Bht.hpp:703-736): plain loads, table must be quiescent
+template <int DIM, bool RETSLOT = false, class Tile> __device__ __forceinline__ int bht_tile_query(const BhtDev &t, const int *key, Tile &tile) {
+  if (t.numBuckets == 0) return RETSLOT ? 0x7fffffff : -1;
+  constexpr int KS = bht_kstride<DIM>();
+  const int B = (int)t.bucket, rank = (int)tile.thread_rank(), ts = (int)tile.size();
+  unsigned bucket = bht_hash<DIM>(t.hf[0], t.hf[1], key) % t.numBuckets * t.bucket;
+  for (int iter = 0; iter < 3;) {
+    for (int off = 0; off < B; off += ts) {
+      bool eq = false;
+      if (off + rank < B) {
+        const int *s = t.keys + (size_t)(bucket + (unsigned)(off + rank)) * KS;
+        if constexpr (DIM >= 3) {
+          const bht_int4 v = *reinterpret_cast<const bht_int4 *>(s);
+          eq = v.x == key[0] && v.y == key[1] && v.z == key[2] && (DIM == 3 || v.w == key[DIM - 1]);
+        } else if constexpr (DIM == 2) {
+          eq = s[0] == key[0] && s[1] == key[1];
+        } else
+          eq = s[0] == key[0];
+      }
+      const unsigned long long m = tile.ballot(eq);
+      if (m) {
+        const int loc = off + __ffsll((long long)m) - 1;
+        return RETSLOT ? (int)(bucket + (unsigned)loc) : t.indices[bucket + (unsigned)loc];
+      }
+    }
+    ++iter;
+    if (iter == 1) bucket = bht_hash<DIM>(t.hf[2], t.hf[3], key) % t.numBuckets * t.bucket;
+    else if (iter == 2) bucket = bht_hash<DIM>(t.hf[4], t.hf[5], key) % t.numBuckets * t.bucket;
+  }
+  return RETSLOT ? 0x7fffffff : -1;
+}
+
 // BHTView::query (Bht.hpp:667-698): plain loads, table must be quiescent.  RETSLOT: slot instead of index.
 template <int DIM, bool RETSLOT = false> __device__ __forceinline__ int bht_query(const BhtDev &t, const int *key) {
   if (t.numBuckets == 0) return RETSLOT ? 0x7fffffff : -1;

@@ -69,6 +69,48 @@ namespace detail {
   template <class T> struct op_code<getmax<T>> { static constexpr int value = 3; };
 }  // namespace detail
 
+// ------------------------------------------------------------------------------------ zs::tuple (ZpcTuple.hpp:119-365)
+// The parameter pack of pol(range, params, f) travels to the device BY VALUE as a kernel argument (cuda/execution/ExecutionPolicy.cuh:
+// 281-322), so it is an aggregate of its elements: one indexed holder per element, reached by get<I>() / zs::get<I>(t) / structured
+// bindings.  make_tuple decays its arguments like the reference's (arrays and functions excepted: not kernel arguments).
+namespace detail {
+  template <std::size_t I, class T> struct tuple_slot { T v; };
+  template <class Seq, class... Ts> struct tuple_slots;
+  template <std::size_t... Is, class... Ts> struct tuple_slots<std::index_sequence<Is...>, Ts...> : tuple_slot<Is, Ts>... {
+    constexpr tuple_slots() = default;
+    template <class... Us, std::enable_if_t<sizeof...(Us) == sizeof...(Ts) && (sizeof...(Us) > 0), int> = 0>
+    ZS_FUNCTION constexpr tuple_slots(Us &&...us) : tuple_slot<Is, Ts>{static_cast<Us &&>(us)}... {}
+  };
+  template <std::size_t I, class T> ZS_FUNCTION constexpr T &slot_of(tuple_slot<I, T> &s) { return s.v; }
+  template <std::size_t I, class T> ZS_FUNCTION constexpr const T &slot_of(const tuple_slot<I, T> &s) { return s.v; }
+  template <std::size_t I, class T> T slot_type(const tuple_slot<I, T> &);
+}  // namespace detail
+template <class... Ts> struct tuple : detail::tuple_slots<std::index_sequence_for<Ts...>, Ts...> {
+  using base_t = detail::tuple_slots<std::index_sequence_for<Ts...>, Ts...>;
+  static constexpr std::size_t tuple_size = sizeof...(Ts);
+  constexpr tuple() = default;
+  template <class... Us, std::enable_if_t<sizeof...(Us) == sizeof...(Ts) && (sizeof...(Us) > 0), int> = 0>
+  ZS_FUNCTION constexpr tuple(Us &&...us) : base_t(static_cast<Us &&>(us)...) {}
+  template <std::size_t I> ZS_FUNCTION constexpr auto &get() { return detail::slot_of<I>(*this); }
+  template <std::size_t I> ZS_FUNCTION constexpr const auto &get() const { return detail::slot_of<I>(*this); }
+};
+template <class... Ts> tuple(Ts...) -> tuple<Ts...>;
+template <class... Args> ZS_FUNCTION constexpr tuple<std::decay_t<Args>...> make_tuple(Args &&...args) {
+  return tuple<std::decay_t<Args>...>(static_cast<Args &&>(args)...);
+}
+template <std::size_t I, class... Ts> ZS_FUNCTION constexpr auto &get(tuple<Ts...> &t) { return t.template get<I>(); }
+template <std::size_t I, class... Ts> ZS_FUNCTION constexpr const auto &get(const tuple<Ts...> &t) { return t.template get<I>(); }
+template <class T> struct tuple_size;
+template <class... Ts> struct tuple_size<tuple<Ts...>> : std::integral_constant<std::size_t, sizeof...(Ts)> {};
+template <class T> inline constexpr std::size_t tuple_size_v = tuple_size<T>::value;
+template <std::size_t I, class T> struct tuple_element;
+template <std::size_t I, class... Ts> struct tuple_element<I, tuple<Ts...>> {
+  using type = decltype(detail::slot_type<I>(std::declval<const tuple<Ts...> &>()));
+};
+template <std::size_t I, class T> using tuple_element_t = typename tuple_element<I, T>::type;
+template <class T> struct is_tuple : std::false_type {};
+template <class... Ts> struct is_tuple<tuple<Ts...>> : std::true_type {};
+
 // ------------------------------------------------------------------------------------ ranges (ZpcIterator.hpp:504-704)
 template <int N> struct CollapseN { long long n[N]; };
 struct Collapse {
@@ -565,18 +607,14 @@ template <int dim> struct BHTView {  // BHTView (Bht.hpp:403-1072): insert / que
   __device__ __forceinline__ int query(const small_vec<int, dim> &key) const { return zsr::bht_query<dim>(t, key.v); }
   __device__ __forceinline__ int entry(const small_vec<int, dim> &key) const { return zsr::bht_query<dim, true>(t, key.v); }  // slot (:700-731)
   __device__ __forceinline__ int size() const { return *t.cnt; }
-  // tile_insert / tile_query (Bht.hpp:562-605, :734-776): every lane of the tile carries the same key and gets the same answer.  The
-  // reference lets the tile's lanes probe one B-slot bucket together; here rank 0 runs the lock-free probe (one 16-byte load per
-  // slot, bht_device.hpp) and the tile shares its result.  Tile = any cooperative-groups tile (thread_rank(), shfl()).
-  template <class Tile> __device__ __forceinline__ int tile_insert(Tile &tile, const small_vec<int, dim> &key) const {
-    int r = 0;
-    if (tile.thread_rank() == 0) r = insert(key);
-    return tile.shfl(r, 0);
+  // tile_insert / tile_query (Bht.hpp:547-608, 703-736): every lane of the tile carries the same key and gets the same answer; the
+  // tile's lanes examine one bucket together (lane r = slot r, ballots for match / first empty slot, rank 0 claims: bht_device.hpp).
+  // Tile = a cooperative-groups thread_block_tile (thread_rank(), size(), ballot(), any(), shfl()).
+  template <class Tile> __device__ __forceinline__ int tile_insert(Tile &tile, const small_vec<int, dim> &key, int index = -1, bool enqueue = true) const {
+    return zsr::bht_tile_insert<dim>(t, key.v, tile, index, enqueue);
   }
   template <class Tile> __device__ __forceinline__ int tile_query(Tile &tile, const small_vec<int, dim> &key) const {
-    int r = 0;
-    if (tile.thread_rank() == 0) r = query(key);
-    return tile.shfl(r, 0);
+    return zsr::bht_tile_query<dim>(t, key.v, tile);
   }
   int *_activeKeys() const { return t.activeKeys; }
 };
@@ -827,17 +865,12 @@ struct RocmExecutionPolicy {
     if constexpr (is_zip_iterator<It>::value) launch_zip(r.begin(), (long long)(r.end() - r.begin()), std::forward<F>(f));
     else launch_zip(zip_iterator<It>{{r.begin()}}, (long long)(r.end() - r.begin()), std::forward<F>(f));
   }
+  // params: zs::tuple / zs::make_tuple(...) as in the reference (ExecutionPolicy.cuh:281-322, 458-535); std::tuple is accepted too
+  template <class It, class... Ps, class F> void operator()(const iterator_range<It> &r, const tuple<Ps...> &params, F &&f) const {
+    launch_params(r, params, std::forward<F>(f));
+  }
   template <class It, class... Ps, class F> void operator()(const iterator_range<It> &r, const std::tuple<Ps...> &params, F &&f) const {
-    const long long n = (long long)(r.end() - r.begin());
-    if (n <= 0) return;
-    const int bs = _block > 0 ? _block : 256;
-    if constexpr (is_zip_iterator<It>::value)
-      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, It, std::tuple<Ps...>>), dim3((unsigned)((n + bs - 1) / bs)), dim3(bs),
-                         _shmem, (hipStream_t)getStream(), n, f, r.begin(), params);
-    else
-      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, zip_iterator<It>, std::tuple<Ps...>>), dim3((unsigned)((n + bs - 1) / bs)),
-                         dim3(bs), _shmem, (hipStream_t)getStream(), n, f, zip_iterator<It>{{r.begin()}}, params);
-    finish();
+    launch_params(r, params, std::forward<F>(f));
   }
   template <class T, class F> void operator()(Vector<T> &v, F &&f) const { (*this)(range(v), std::forward<F>(f)); }
   // pol(Collapse{...}, f)
@@ -876,6 +909,38 @@ struct RocmExecutionPolicy {
   template <class K> void radix_sort_pair(const K *kin, const int *vin, K *kout, int *vout, std::size_t n, int sbit = 0,
                                           int ebit = sizeof(K) * 8) const {
     call_sort(kin, vin, kout, vout, n, sbit, ebit);
+  }
+
+  // the same over ANY random-access device iterators (execution/ExecutionPolicy.hpp:765-781 take iterators: Vector / TileVector-channel
+  // begin(), strided views): non-contiguous ranges are staged through this policy's stream-ordered temporaries like the scans below
+  template <class InIt, class OutIt, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+  void radix_sort(InIt first, InIt last, OutIt d_first, int sbit = 0,
+                  int ebit = (int)sizeof(std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>) * 8) const {
+    using K = std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>;
+    const std::size_t n = (std::size_t)(last - first);
+    if (!n) return;
+    K *in = stage_in<K>(first, n), *out = (K *)zs_rocm_policy_temporary(_h, n * sizeof(K));
+    radix_sort((const K *)in, (const K *)in + n, out, sbit, ebit);
+    stage_out(out, d_first, n);
+    zs_rocm_policy_temporary_free(_h, out);
+    zs_rocm_policy_temporary_free(_h, in);
+    finish();
+  }
+  template <class KIn, class VIn, class KOut, class VOut, class Tn,
+            std::enable_if_t<!(std::is_pointer_v<KIn> && std::is_pointer_v<VIn> && std::is_pointer_v<KOut> && std::is_pointer_v<VOut>) && std::is_integral_v<Tn>, int> = 0>
+  void radix_sort_pair(KIn keysIn, VIn valsIn, KOut keysOut, VOut valsOut, Tn count, int sbit = 0,
+                       int ebit = (int)sizeof(std::remove_cv_t<std::remove_reference_t<decltype(keysIn[0])>>) * 8) const {
+    using K = std::remove_cv_t<std::remove_reference_t<decltype(keysIn[0])>>;
+    static_assert(sizeof(std::remove_reference_t<decltype(valsIn[0])>) == sizeof(int), "4-byte values (the C ABI sorts (key, int) pairs)");
+    const std::size_t n = (std::size_t)count;
+    if (!n) return;
+    K *kin = stage_in<K>(keysIn, n), *kout = (K *)zs_rocm_policy_temporary(_h, n * sizeof(K));
+    int *vin = stage_in<int>(valsIn, n), *vout = (int *)zs_rocm_policy_temporary(_h, n * sizeof(int));
+    radix_sort_pair((const K *)kin, (const int *)vin, kout, vout, n, sbit, ebit);
+    stage_out(kout, keysOut, n);
+    stage_out(vout, valsOut, n);
+    for (void *q : {(void *)vout, (void *)vin, (void *)kout, (void *)kin}) zs_rocm_policy_temporary_free(_h, q);
+    finish();
   }
 
   // merge_sort / merge_sort_pair with a user comparator (cuda/execution/ExecutionPolicy.cuh:698-752): stable, in place;
@@ -935,6 +1000,18 @@ struct RocmExecutionPolicy {
   }
 
 private:
+  template <class It, class Params, class F> void launch_params(const iterator_range<It> &r, const Params &params, F &&f) const {
+    const long long n = (long long)(r.end() - r.begin());
+    if (n <= 0) return;
+    const int bs = _block > 0 ? _block : 256;
+    if constexpr (is_zip_iterator<It>::value)
+      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, It, Params>), dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), _shmem,
+                         (hipStream_t)getStream(), n, f, r.begin(), params);
+    else
+      hipLaunchKernelGGL((detail::range_launch_with_params<std::decay_t<F>, zip_iterator<It>, Params>), dim3((unsigned)((n + bs - 1) / bs)), dim3(bs),
+                         _shmem, (hipStream_t)getStream(), n, f, zip_iterator<It>{{r.begin()}}, params);
+    finish();
+  }
   template <class ZI, class F> void launch_zip(ZI it, long long n, F &&f) const {
     if (n <= 0) return;
     const int bs = _block > 0 ? _block : 256;
@@ -1009,6 +1086,17 @@ template <class K> void radix_sort(const RocmExecutionPolicy &pol, const K *firs
 template <class K> void radix_sort_pair(const RocmExecutionPolicy &pol, const K *kin, const int *vin, K *kout, int *vout, std::size_t n, int sbit = 0,
                                         int ebit = sizeof(K) * 8) {
   pol.radix_sort_pair(kin, vin, kout, vout, n, sbit, ebit);
+}
+template <class InIt, class OutIt, std::enable_if_t<!(std::is_pointer_v<InIt> && std::is_pointer_v<OutIt>), int> = 0>
+void radix_sort(const RocmExecutionPolicy &pol, InIt first, InIt last, OutIt d_first, int sbit = 0,
+                int ebit = (int)sizeof(std::remove_cv_t<std::remove_reference_t<decltype(first[0])>>) * 8) {
+  pol.radix_sort(first, last, d_first, sbit, ebit);
+}
+template <class KIn, class VIn, class KOut, class VOut, class Tn,
+          std::enable_if_t<!(std::is_pointer_v<KIn> && std::is_pointer_v<VIn> && std::is_pointer_v<KOut> && std::is_pointer_v<VOut>) && std::is_integral_v<Tn>, int> = 0>
+void radix_sort_pair(const RocmExecutionPolicy &pol, KIn keysIn, VIn valsIn, KOut keysOut, VOut valsOut, Tn count, int sbit = 0,
+                     int ebit = (int)sizeof(std::remove_cv_t<std::remove_reference_t<decltype(keysIn[0])>>) * 8) {
+  pol.radix_sort_pair(keysIn, valsIn, keysOut, valsOut, count, sbit, ebit);
 }
 
 template <class KeyIter, class Comp = less<void>> void merge_sort(const RocmExecutionPolicy &pol, KeyIter first, KeyIter last, Comp comp = {}) {
@@ -1099,3 +1187,9 @@ template <class T, int L> template <class Pol> void TileVector<T, L>::reset(cons
 }
 
 }  // namespace zs
+
+// structured bindings for zs::tuple: auto [a, b] = zs::make_tuple(...)
+namespace std {
+template <class... Ts> struct tuple_size<zs::tuple<Ts...>> : integral_constant<size_t, sizeof...(Ts)> {};
+template <size_t I, class... Ts> struct tuple_element<I, zs::tuple<Ts...>> { using type = zs::tuple_element_t<I, zs::tuple<Ts...>>; };
+}  // namespace std

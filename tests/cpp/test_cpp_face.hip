@@ -868,6 +868,34 @@ int main(int argc, char **argv) {
     bool sok = true;
     for (size_t i = 0; i < 3000; ++i) { sok = sok && sc[i] == run; run += (int)(i % 7); }
     CHECK(sok);
+    // iterator-taking radix sorts (execution/ExecutionPolicy.hpp:765-781): a TileVector channel in, a Vector out; pairs with an index channel
+    for (size_t i = 0; i < 3000; ++i) tiv(0, i) = (int)((i * 2654435761u) % 100003u) - 50000, tiv(1, i) = (int)i;
+    Vector<int> so(3000, memsrc_e::um), vo(3000, memsrc_e::um);
+    radix_sort(pol, ti.begin("k"), ti.end("k"), so.begin());
+    bool rok = true;
+    for (size_t i = 1; i < 3000; ++i) rok = rok && so[i - 1] <= so[i];
+    CHECK(rok);
+    radix_sort_pair(pol, ti.begin("k"), ti.begin("pad"), so.begin(), vo.begin(), 3000);
+    for (size_t i = 0; i < 3000; ++i) rok = rok && so[i] == tiv(0, (size_t)vo[i]) && (i == 0 || so[i - 1] <= so[i]);
+    CHECK(rok);
+    // zs::tuple / zs::make_tuple / zs::get as the parameter pack of pol(range, params, f) (cuda/execution/ExecutionPolicy.cuh:281-322)
+    {
+      constexpr auto tp = zs::make_tuple(2, 0.25f, 'c');
+      static_assert(zs::tuple_size_v<std::decay_t<decltype(tp)>> == 3 && std::is_same_v<zs::tuple_element_t<1, std::decay_t<decltype(tp)>>, float>);
+      static_assert(zs::get<0>(tp) == 2 && tp.get<2>() == 'c' && std::is_trivially_copyable_v<std::decay_t<decltype(tp)>>);
+      auto [ta, tb, tc] = tp;
+      CHECK(ta == 2 && tb == 0.25f && tc == 'c');
+      Vector<float> pa(n), pb(n);
+      pol(enumerate(pa, pb), [] ZS_LAMBDA(long long i, float &x, float &y) { x = (float)i; y = 1.f; });
+      pol(zip(pa, pb), zs::make_tuple(0.5f, 3), [] ZS_LAMBDA(float &x, const float &y, const zs::tuple<float, int> &p) {
+        x = x * zs::get<0>(p) + y * (float)zs::get<1>(p);
+      });
+      pol(enumerate(pa), zs::make_tuple(7.f), [] ZS_LAMBDA(long long i, float &x, zs::tuple<float> p) { x += p.get<0>() * (float)(i & 1); });
+      auto ph = pa.clone(memsrc_e::um);
+      bool pok = true;
+      for (size_t i = 0; i < n; i += 101) pok = pok && ph[i] == 0.5f * (float)i + 3.f + 7.f * (float)(i & 1);
+      CHECK(pok);
+    }
     // Vector{allocator, n} / get_memory_source / MemoryLocation
     Vector<double> vd{get_memory_source(memsrc_e::um, 0), 16};
     CHECK(vd.size() == 16 && vd.memspace() == memsrc_e::um);

@@ -953,13 +953,15 @@ struct ArenaBlk {
 // geometry of bin `bin`: grid block, origin of the bin inside the block (cells), origin in world cells
 template <int SIDE> struct BinGeom {
   int block, o[3], org[3];
-  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin, int kscale) {
+  __device__ __forceinline__ explicit BinGeom(int bin) {  // block and origin inside it; the caller fills org
     constexpr int BPB = bins_per_block<SIDE>();
     block = bin / BPB;
     const int sub = bin % BPB;
     o[0] = SIDE == 4 ? 0 : ((sub >> 2) & 1) * 4;
     o[1] = SIDE == 4 ? 0 : ((sub >> 1) & 1) * 4;
     o[2] = SIDE == 4 ? 0 : (sub & 1) * 4;
+  }
+  __device__ __forceinline__ BinGeom(const BhtDev &t, int bin, int kscale) : BinGeom(bin) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) org[d] = t.activeKeys[3 * (size_t)block + d] * (SIDE / kscale) + o[d];
   }
@@ -1559,23 +1561,44 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
 // 256-byte channel rows of the tile per wave-instruction (1 KiB), and the instruction offset advances both addresses.  MERGED: the host
 // found m, x, v, C in 16 adjacent channels (the layout of zpc_amd.mpm and of the reference's particles TileVector {m, x, v, C, ...}):
 // 4 + 2 requests per tile; otherwise one base per attribute, 8 requests (the last of an attribute with the lanes of its remaining rows).
+// The requests are inline assembly on purpose: for the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read that
+// follows an LDS-direct load it cannot tell apart (SIInsertWaitcnts: any DS read may alias a pending LDS-DMA write), i.e. in front of
+// the first record read of EVERY round -- the ring would never hold a tile in flight.  The kernel orders reads behind arrivals itself
+// (the vmcnt switch in front of a round), so the compiler must not know these are loads into LDS.  M0 = LDS base of the request.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void p2gt_dma4(unsigned long long sbase, unsigned voff, unsigned ldsAddr) {  // one dword per lane
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsAddr) : "memory", "m0");
+}
+template <int OFF0, int CNT> __device__ __forceinline__ void p2gt_dma16_run(unsigned long long sbase, unsigned voff, unsigned ldsAddr) {
+  // CNT requests 1 KiB apart (global and LDS address advance together through the instruction offset), one M0 write
+  static_assert(CNT >= 1 && CNT <= 4, "instruction offsets up to 3072");
+  if constexpr (CNT == 1)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(ldsAddr), "n"(OFF0) : "memory", "m0");
+  else if constexpr (CNT == 2)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" ::"v"(voff), "s"(sbase), "s"(ldsAddr),
+                 "n"(OFF0), "n"(OFF0 + 1024) : "memory", "m0");
+  else if constexpr (CNT == 3)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%5" ::"v"(voff),
+                 "s"(sbase), "s"(ldsAddr), "n"(OFF0), "n"(OFF0 + 1024), "n"(OFF0 + 2048) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%5\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:%6" ::"v"(voff), "s"(sbase), "s"(ldsAddr), "n"(OFF0), "n"(OFF0 + 1024), "n"(OFF0 + 2048), "n"(OFF0 + 3072) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 template <int ROW0, int N>
 __device__ __forceinline__ void p2gt_issue_attr(const Port<float> &p, size_t tb, int lane, float *buf) {
-  // (the two readfirstlanes keep the tile's base an SGPR pair: without them the loop-invariant p.base + lane offset is hoisted as a
-  // 64-bit VGPR address per attribute and the accumulators spill)
+  // wave-uniform row base in an SGPR pair + one 32-bit lane offset
   const unsigned long long ub = (unsigned long long)(p.base + tb);
   const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub);
-  const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(sb) + (size_t)((unsigned)lane * 16u));
-  auto *l = (__attribute__((address_space(3))) void *)(buf + ROW0 * 64);
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(buf + ROW0 * 64);
   constexpr int FULL = N / 4, REST = N % 4;
-  if constexpr (FULL > 0) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-  if constexpr (FULL > 1) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-  if constexpr (FULL > 2) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-  if constexpr (FULL > 3) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
   static_assert(FULL <= 4, "up to 16 + 3 rows per base");
+  if constexpr (FULL > 0) p2gt_dma16_run<0, FULL>(sb, voff, l);
   if constexpr (REST > 0)
-    if (lane < REST * 16) __builtin_amdgcn_global_load_lds(g, l, 16, FULL * 1024, 0);
+    if (lane < REST * 16) p2gt_dma16_run<FULL * 1024, 1>(sb, voff, l);
 }
 template <bool MERGED> constexpr int p2gt_requests() { return MERGED ? 4 + (STRESS_N + 3) / 4 : 1 + 1 + 1 + 3 + (STRESS_N + 3) / 4; }
 template <bool MERGED>
@@ -1606,6 +1629,7 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
   __shared__ float lds[LDSF];
   __shared__ int mq[G][P2GW_MQ_CAP];
   __shared__ int mqCount[G];
+  __shared__ unsigned cntLds[G][64];
   const int w = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bin0 = (int)xcd_chunked(blockIdx.x, gridDim.x) * G, bin = bin0 + w;
 #ifdef ZS_PROBE_P2G
@@ -1621,7 +1645,15 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
 #pragma unroll
   for (int k = 1; k < G; ++k)
     if (w == k) start = bs[k], end = bs[k + 1];
-  const unsigned cnt = cellCount[(size_t)bin * 64 + lane];  // (all zero for an empty bin)
+  // the wave's cell counts (all zero for an empty bin) come through LDS like the tiles, requested in front of them: a load into a
+  // register that the compiler tracks would get its `s_waitcnt vmcnt(n)` computed without the tile requests behind it (i.e. wait for
+  // every tile requested so far), and one it does not track could be copied before it has landed
+  {
+    const unsigned long long cb = (unsigned long long)(cellCount + (size_t)bin * 64);
+    const unsigned long long scb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cb >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cb);
+    p2gt_dma4(scb, (unsigned)lane * 4u, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)cntLds[w]);
+  }
   float *arena = lds;
   float *ring = lds + w * WBUF;
   const int tile0 = start >> 6, tileEnd = (end + 63) >> 6;  // the bin's tiles (none if start == end)
@@ -1639,12 +1671,18 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
   }
   if (bs[0] == bs[G]) return;  // none of the G bins holds a particle (workgroup-uniform)
   if (lane == 0) mqCount[w] = 0;  // (only this wave touches mq[w] / mqCount[w]: its LDS operations execute in order)
-  const BinGeom<SIDE> geo(t, bin, mp.kscale);
+  BinGeom<SIDE> geo(bin);
+  {  // the block's key by scalar loads (constant address space + uniform address)
+    const auto *ak = reinterpret_cast<const __attribute__((address_space(4))) int *>(reinterpret_cast<unsigned long long>(t.activeKeys));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) geo.org[d] = ak[3 * (size_t)geo.block + d] * (SIDE / mp.kscale) + geo.o[d];
+  }
   // the block's 8 neighbour numbers {+0, +1}^3 for the flush: wave-uniform, requested now (scalar loads) instead of one dependent
   // vector load per flushed node at the end of the wave's life
   int nbs[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) nbs[k] = __builtin_amdgcn_readfirstlane(nbr[(size_t)geo.block * 8 + k]);  // (SGPRs)
+  for (int k = 0; k < 8; ++k)  // (constant address space + uniform address = s_load: vmcnt stays the record requests' own)
+    nbs[k] = reinterpret_cast<const __attribute__((address_space(4))) int *>(reinterpret_cast<unsigned long long>(nbr))[(size_t)geo.block * 8 + k];
   const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
   float acc[27][7];
 #pragma unroll
@@ -1658,6 +1696,14 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
 #ifdef ZS_PROBE_P2G
   const unsigned long long tp1 = P2G_NOW();
 #endif
+  {  // the cell counts were requested before the first tiles: they have arrived once at most the tiles' requests are outstanding
+    const int req = tIssue - tile0;
+    if (req >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 3 ? 3 * NL : 0) : "memory");
+    else if (req == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+    else if (req == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned cnt = cntLds[w][lane];
   bool has = cnt > r;
   unsigned long long m = __ballot(has);
   while (m != 0ull) {
