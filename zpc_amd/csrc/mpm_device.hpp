@@ -1550,6 +1550,14 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
 #endif
 }
 
+// private flush arena of one wave of p2g_tile_kernel: 6^3 nodes, one float4 per node and plane (plane 0: m, mv; plane 1: f), strides in
+// nodes z + 12 y + 72 x: a 16-byte access of the wave is served in four passes of 16 lanes = the 4 x 4 (y, z) cells of one x, and
+// 12 y + z (+ a phase offset) takes 16 distinct values mod 16 there -- no bank conflict in any of the 27 phases.
+struct ArenaPriv {
+  static constexpr int SY = 12, SX = 72, PLANE = 6 * SX;
+  __device__ static constexpr int at(int x, int y, int z) { return x * SX + y * SY + z; }
+};
+
 // ---- tile-stream variant of the wide P2G (LW = 64 only): the record loads are decoupled from the rounds.
 // A bin's particles are the contiguous range [start, end) of the compact order, i.e. the tiles start / 64 .. (end - 1) / 64 of the AoSoA
 // container.  The wave requests WHOLE TILES (22 rows x 256 B by 6 - 8 `global_load_lds_dwordx4` of 1 KiB each instead of 22 dword
@@ -1730,7 +1738,9 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
     tpWait += P2G_NOW() - tw0;
     ++tpRounds;
 #endif
-    if (has) {
+    {
+      // every lane reads "its" record (a lane without a particle in this round reads some record of the ring: never used) so that the
+      // round has ONE divergent region, the accumulation; movers are rare and sit behind a wave-uniform branch
       const int nslot = cslot + 1 == NB ? 0 : cslot + 1;
       const float *rec = ring + ((p >> 6) == tb ? cslot : nslot) * TILEF + (p & 63);
       const float pos[3] = {rec[1 * 64], rec[2 * 64], rec[3 * 64]};
@@ -1738,18 +1748,20 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
       make_arena(mp.dx, mp.dxi, pos, ar);
       const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
       const bool inBin = (unsigned)(ocx | ocy | ocz) < 4u;  // all three in 0..3
-      if (inBin && ((ocx << 4) | (ocy << 2) | ocz) == lane) {  // lane = cell: (x, y, z) = (lane >> 4, (lane >> 2) & 3, lane & 3)
-        p2gw_accumulate(mp, ar, rec, kscale, acc);
-      } else {
-        bool queued = false;
-        if (inBin) {
-          const int q = atomicAdd(&mqCount[w], 1);
-          if (q < P2GW_MQ_CAP) {
-            mq[w][q] = p;
-            queued = true;
+      const bool own = has && inBin && ((ocx << 4) | (ocy << 2) | ocz) == lane;  // lane = cell: (x, y, z) = (lane >> 4, (lane >> 2) & 3, lane & 3)
+      if (own) p2gw_accumulate(mp, ar, rec, kscale, acc);
+      if (__ballot(has && !own) != 0ull) {  // some particle has left the cell it is stored under (wave-uniform, rare)
+        if (has && !own) {
+          bool queued = false;
+          if (inBin) {  // another cell of the same bin: queued for the post-pass into the arena; outside the bin: exact path afterwards
+            const int q = atomicAdd(&mqCount[w], 1);
+            if (q < P2GW_MQ_CAP) {
+              mq[w][q] = p;
+              queued = true;
+            }
           }
+          if (!queued) stale[atomicAdd(staleCount, 1)] = p;
         }
-        if (!queued) stale[atomicAdd(staleCount, 1)] = p;
       }
     }
     base += nr;
@@ -1761,14 +1773,14 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
 #ifdef ZS_PROBE_P2G
   const unsigned long long tp2 = P2G_NOW();
 #endif
-  // ---- tail.  Every tile the wave requested has been consumed, so its ring is free: it becomes the wave's PRIVATE 6^3 arena.  No
-  // other wave touches it until the group's barrier below, and a wave's LDS operations execute in order, so the 27 x 7
-  // read-add-write steps need no barrier and no wait between phases: the read of (phase k + 1, channel c) is issued right behind
-  // the write of (phase k, channel c) and its latency is covered by the six other channels' steps.
-  using AP = ArenaLds;
-  static_assert(7 * AP::CH <= WBUF && (7 * AP::CH) % 4 == 0 && WBUF % 4 == 0, "private arena inside the wave's ring, 16-byte clears");
-  float *priv = ring;
-  for (int k = lane * 4; k < 7 * AP::CH; k += 256) *reinterpret_cast<float4 *>(priv + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- tail.  Every tile the wave requested has been consumed, so its ring is free: it becomes the wave's PRIVATE 6^3 arena, two
+  // planes of one float4 per node ({m, mv} and {f, -}: ArenaPriv).  No other wave touches it until the group's barrier below, and a
+  // wave's LDS operations execute in order, so the 27 read-add-write phases need no barrier and no wait for a write: the 16-byte read
+  // of (phase k + 1, plane p) is issued right behind the write of (phase k, plane p).
+  using AP = ArenaPriv;
+  static_assert(2 * AP::PLANE * 4 <= WBUF && WBUF % 4 == 0, "private arena inside the wave's ring, 16-byte accesses");
+  float4 *priv = reinterpret_cast<float4 *>(ring);
+  for (int k = lane; k < 2 * AP::PLANE; k += 64) priv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #define P2GT_LDS_ORDER()                                   \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -1778,22 +1790,19 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
 #ifdef ZS_PROBE_P2G
   const unsigned long long tp3 = P2G_NOW();
 #endif
-  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   {
-    float *a0 = priv + AP::at(cx, cy, cz);
-    float v[7];
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) v[ch] = a0[ch * AP::CH];
+    float4 *a0 = priv + AP::at(lane >> 4, (lane >> 2) & 3, lane & 3);
+    float4 va = a0[0], vb = a0[AP::PLANE];
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
-      float *g = a0 + AP::at(k / 9, (k / 3) % 3, k % 3);
-      float *gn = a0 + AP::at((k + 1) / 9, ((k + 1) / 3) % 3, (k + 1) % 3);
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        g[ch * AP::CH] = v[ch] + acc[k][ch];
-        P2GT_LDS_ORDER();
-        if (k + 1 < 27) v[ch] = gn[ch * AP::CH];
-      }
+      float4 *g = a0 + AP::at(k / 9, (k / 3) % 3, k % 3);
+      float4 *gn = a0 + AP::at((k + 1) / 9, ((k + 1) / 3) % 3, (k + 1) % 3);
+      g[0] = make_float4(va.x + acc[k][0], va.y + acc[k][1], va.z + acc[k][2], va.w + acc[k][3]);
+      P2GT_LDS_ORDER();
+      if (k + 1 < 27) va = gn[0];
+      g[AP::PLANE] = make_float4(vb.x + acc[k][4], vb.y + acc[k][5], vb.z + acc[k][6], 0.f);
+      P2GT_LDS_ORDER();
+      if (k + 1 < 27) vb = gn[AP::PLANE];
     }
   }
   {  // the queued in-bin movers, one lane each, by LDS atomics into the private arena (same values as the exact path)
@@ -1814,7 +1823,7 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
       for (int d = 0; d < 9; ++d) PF[d] *= kscale;
       Arena ar;
       make_arena(mp.dx, mp.dxi, pos, ar);
-      float *b0 = priv + AP::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1], ar.corner[2] - geo.org[2]);
+      float *b0 = reinterpret_cast<float *>(priv + AP::at(ar.corner[0] - geo.org[0], ar.corner[1] - geo.org[1], ar.corner[2] - geo.org[2]));
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1823,12 +1832,12 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
           for (int c = 0; c < 3; ++c) {
             const float W = ar.w[0][a] * ar.w[1][b] * ar.w[2][c];
             const float x0 = (float)a * mp.dx - ar.lp[0], x1 = (float)b * mp.dx - ar.lp[1], x2 = (float)c * mp.dx - ar.lp[2];
-            float *g = b0 + AP::at(a, b, c);
+            float *g = b0 + 4 * AP::at(a, b, c);
             atomicAdd(g, W * pm);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-              atomicAdd(g + (1 + d) * AP::CH, W * pm * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
-              atomicAdd(g + (4 + d) * AP::CH, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
+              atomicAdd(g + 1 + d, W * pm * (vel[d] + (C[d] * x0 + C[3 + d] * x1 + C[6 + d] * x2)));
+              atomicAdd(g + 4 * AP::PLANE + d, (PF[d] * x0 + PF[3 + d] * x1 + PF[6 + d] * x2) * W);
             }
           }
     }
@@ -1845,13 +1854,12 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
     const int wy = G == 4 ? (w >> 1) * 4 : 0, wz = G == 1 ? 0 : (w & 1) * 4;
     const int o0[3] = {geo.o[0], geo.o[1] - wy, geo.o[2] - wz};  // origin of the group inside its block = the origin of its first bin
     constexpr int NODES = AL::WX * AL::WY * AL::WZ, ITER = (NODES + 64 * G - 1) / (64 * G);
-    float val[ITER][7];
+    float4 va[ITER], vb[ITER];
     int goff[ITER];  // element offset of the node's first channel in the grid, -1: no such block / no such node
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {  // every LDS read of the flush first ...
       const int node = (int)threadIdx.x + it * 64 * G;
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch) val[it][ch] = 0.f;
+      va[it] = vb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       goff[it] = -1;
       if (node < NODES) {
         const int x = node / (AL::WY * AL::WZ), y = (node / AL::WZ) % AL::WY, z = node % AL::WZ;
@@ -1868,9 +1876,10 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
           for (int gz = 0; gz < (G == 1 ? 1 : 2); ++gz) {
             const int ly = y - 4 * gy, lz = z - 4 * gz;
             if ((unsigned)ly < 6u && (unsigned)lz < 6u) {
-              const float *a = lds + (gy * 2 + gz) * WBUF + AP::at(x, ly, lz);
-#pragma unroll
-              for (int ch = 0; ch < 7; ++ch) val[it][ch] += a[ch * AP::CH];
+              const float4 *a = reinterpret_cast<const float4 *>(lds + (gy * 2 + gz) * WBUF) + AP::at(x, ly, lz);
+              const float4 pa = a[0], pb = a[AP::PLANE];
+              va[it] = make_float4(va[it].x + pa.x, va[it].y + pa.y, va[it].z + pa.z, va[it].w + pa.w);
+              vb[it] = make_float4(vb[it].x + pb.x, vb[it].y + pb.y, vb[it].z + pb.z, 0.f);
             }
           }
       }
@@ -1879,9 +1888,10 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
     for (int it = 0; it < ITER; ++it)  // ... then the float atomics
       if (goff[it] >= 0) {
         float *g = grid + (size_t)(unsigned)goff[it];
+        const float val[7] = {va[it].x, va[it].y, va[it].z, va[it].w, vb[it].x, vb[it].y, vb[it].z};
 #pragma unroll
         for (int ch = 0; ch < 7; ++ch)
-          if (val[it][ch] != 0.f) unsafeAtomicAdd(g + ch * NC, val[it][ch]);
+          if (val[ch] != 0.f) unsafeAtomicAdd(g + ch * NC, val[ch]);
       }
   }
 #ifdef ZS_P2GT_ENDWAIT
