@@ -252,6 +252,58 @@ def test_aos_particles(pol, oracle, binned):
     assert np.abs(out[:, 25] - lj_o[inv]).max() < 2e-5
 
 
+@pytest.mark.parametrize("side", [4, 8])
+@pytest.mark.parametrize("variant", ["tile_merged", "tile_separate_bases", "wide_32_lanes"])
+def test_cached_stress_p2g_kernel_variants_vs_oracle(pol, oracle, variant, side):
+    """The stand-alone P2G with cached stress has three kernels behind zs_rocm_mpm_p2g: p2g_tile_kernel with m, x, v, C in 16 adjacent
+    channels (4 + 2 tile requests), the same with one base per attribute (8 requests: here the mass port points into a second
+    TileVector of the same layout), and p2g_wide_kernel for 32-lane tiles.  All three against the oracle's P2G (P2G.hpp:38-116), on a
+    cloud whose particles have moved since it was binned (in-bin movers: LDS post-pass; out-of-bin movers: exact path)."""
+    from zpc_amd.mpm import MpmTransfer, Particles
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(9, dx, 2, seed=57 + side)
+    n = pos.shape[0]
+    vol = dx ** 3 / 8
+    mt = MpmTransfer(pol, n, dx, dt, model=0, side=side, volume=vol, cache_stress=True, lane_width=32 if variant == "wide_32_lanes" else 64)
+    mt.upload(mass, pos, vel, Cm, F)
+    om = OracleMpm(oracle, 0, dx, dt, side, vol)
+    assert mt.build_partition(n) == om.build_partition(pos, n)
+    mt.rebin()
+    mt.update_stress()
+    # move a sixth of the cloud's inner particles by up to 1.2 cells AFTER binning (two cells from its faces: they stay inside the partition)
+    r = rng(59)
+    lo, hi = pos.min(0) + 2 * dx, pos.max(0) - 2 * dx
+    moved = (r.random(n) < 0.17) & ((pos >= lo) & (pos <= hi)).all(1)
+    assert moved.sum() > 100
+    pos2 = pos.copy()
+    pos2[moved] += (r.random((moved.sum(), 3)).astype(np.float32) - 0.5) * 2.4 * dx
+    order = mt.order.cpu().numpy()
+    d = mt.download()
+    d["x"] = pos2[order]
+    a = np.concatenate([d["m"][:, None], d["x"], d["v"], d["C"], d["F"]], axis=1)
+    cols = torch.zeros(n, mt.nchn, dtype=torch.float32, device="cuda")
+    cols[:, :a.shape[1]] = torch.from_numpy(a).cuda()
+    stress = torch.empty(n, mt.nchn, dtype=torch.float32, device="cuda")
+    lib = __import__("zpc_amd").lib()
+    lib.zs_rocm_tv_to_aos_f32(pol.handle, mt.buf.data_ptr(), n, mt.nchn, mt.L, stress.data_ptr())
+    pol.syncCtx()
+    cols[:, mt.off["PF"]:mt.off["PF"] + 6] = stress[:, mt.off["PF"]:mt.off["PF"] + 6]
+    lib.zs_rocm_tv_from_aos_f32(pol.handle, cols.data_ptr(), n, mt.nchn, mt.L, mt.buf.data_ptr())
+    pol.syncCtx()
+    parts = mt.particles()
+    if variant == "tile_separate_bases":
+        other = mt.buf.clone()   # same layout, another allocation: the mass port no longer sits 64 floats in front of x
+        parts = Particles(mt._port("m", other), parts.pos, parts.vel, parts.C, parts.F, parts.logJp, parts.stress, parts.n)
+    mt.clear_grid()
+    lib.zs_rocm_mpm_p2g(pol.handle, C.byref(mt.params), parts, mt.table.handle, mt.grid.data_ptr(), mt.nblocks, mt.bin_start.data_ptr(),
+                        mt.cell_count.data_ptr(), mt.nbr.data_ptr())
+    pol.syncCtx()
+    om.p2g(mass, pos2, vel, Cm, F)
+    _compare_grids(mt.grid_by_key(), om.grid_by_key(), 2e-4)
+    g = np.stack(list(mt.grid_by_key().values()))
+    assert abs(g[:, 0].sum() - mass.sum()) < 1e-4 * mass.sum()
+
+
 @pytest.mark.parametrize("model", [0, 1, 2, 3])
 @pytest.mark.parametrize("side", [4, 8])
 def test_cached_stress_matches_recompute_over_steps(pol, oracle, model, side):

@@ -19,31 +19,31 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     int *staleCount = stale + ps.n + 32;
     ZSR_CHECK(hipMemsetAsync(staleCount, 0, sizeof(int), L.stream));
     const int lw = uniform_lane_width(ps, model_uses_logjp(p->model) && kmodel != MPM_CACHED_STRESS, kmodel == MPM_CACHED_STRESS);
-    if (kmodel == MPM_CACHED_STRESS) {  // cached stress: the "wide" kernel, one wave per bin
-      // bins per workgroup = waves that share one flush arena (8^3 blocks only; see p2g_wide_kernel).  Measured at 64 Mi particles
-      // (profiles/r04_p2g.md): 1.74 / 1.71 / 1.72 ms for 1 / 2 / 4 with 1.73 / -- / 1.04 GB written: the time no longer follows the
-      // traffic, so the default is the pair (least coupling between waves).  ZS_ROCM_P2G_GROUP = 1 | 2 | 4 overrides it for A/B runs.
-      static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 2; }();
-      // m, x, v, C in 16 adjacent channels of one TileVector (lw == 64 already says: same tiles, same channel count, 16-byte aligned rows)
+    if (kmodel == MPM_CACHED_STRESS) {  // cached stress: one wave per bin, the lane's 27 x 7 node sums in registers
+      // Two bins (z-neighbours of an 8^3 block) per workgroup share one flush (see p2g_tile_kernel / p2g_wide_kernel): measured at
+      // 64 Mi particles 1 / 2 / 4 bins per workgroup 1.67 / 1.45-1.50 / 1.50-1.54 ms (profiles/r06_p2g.md).
+      // p2g_tile_kernel needs one TileVector<f32, 64> layout for all attributes and 16-byte aligned channel rows; `merged`: m, x, v, C in
+      // 16 adjacent channels (the layout of zpc_amd.mpm and of the reference's particles {m, x, v, C, ...}).  Anything else (32-lane
+      // tiles, AoS / mixed iterators) takes p2g_wide_kernel.
       const bool merged = lw == 64 && (const float *)ps.pos.base == (const float *)ps.mass.base + 64 &&
                           (const float *)ps.vel.base == (const float *)ps.mass.base + 4 * 64 && (const float *)ps.C.base == (const float *)ps.mass.base + 7 * 64;
       const bool aligned16 = ((((uintptr_t)ps.mass.base) | ((uintptr_t)ps.pos.base) | ((uintptr_t)ps.vel.base) | ((uintptr_t)ps.C.base) | ((uintptr_t)ps.stress.base)) & 15u) == 0;
-      static const bool tileStreamEnv = [] { const char *e = getenv("ZS_ROCM_P2G_TILE"); return !e || atoi(e) != 0; }();
-#ifndef ZS_P2GW_DEPTH
-#define ZS_P2GW_DEPTH 1  // rounds of records requested ahead of the one being accumulated
-#endif
-#define CALL_P2G_WIDE_G(S, LWv, Gv)                                                                                                     \
-  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, ZS_P2GW_DEPTH, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
-                     nbr, stale, staleCount)
-#ifdef ZS_PROBE_P2G  // measurement builds: extra dynamic LDS per workgroup lowers the occupancy (ZS_ROCM_P2G_DYNLDS bytes)
+#ifdef ZS_P2G_AB  // measurement builds (tools/ab_build.sh): bins per workgroup / kernel choice / occupancy from the environment
+      static const int group = [] { const char *e = getenv("ZS_ROCM_P2G_GROUP"); const int g = e ? atoi(e) : 0; return g == 1 || g == 2 || g == 4 ? g : 2; }();
+      static const bool tileStream = [] { const char *e = getenv("ZS_ROCM_P2G_TILE"); return !e || atoi(e) != 0; }();
       static const int p2gtDynLds = [] { const char *e = getenv("ZS_ROCM_P2G_DYNLDS"); return e ? atoi(e) : 0; }();
 #define P2GT_DYN_LDS p2gtDynLds
 #else
+      constexpr int group = 2;
+      constexpr bool tileStream = true;
 #define P2GT_DYN_LDS 0
 #endif
 #ifndef ZS_P2GT_NB
-#define ZS_P2GT_NB 3  // tile buffers per wave of the tile-stream kernel
+#define ZS_P2GT_NB 3  // tile buffers per wave of the tile-stream kernel (2: 1.60 ms, 3: 1.50 ms, 4: 1.71 ms -- LDS then holds 6 waves per CU)
 #endif
+#define CALL_P2G_WIDE_G(S, LWv, Gv)                                                                                                     \
+  hipLaunchKernelGGL((p2g_wide_kernel<S, LWv, 1, Gv>), dim3(nbins / Gv), dim3(64 * Gv), 0, L.stream, mp, pd, t, grid, binStart, cellCount, \
+                     nbr, stale, staleCount)
 #define CALL_P2G_TILE_GM(S, Gv, Mv)                                                                                                     \
   hipLaunchKernelGGL((p2g_tile_kernel<S, ZS_P2GT_NB, Gv, Mv>), dim3(nbins / Gv), dim3(64 * Gv), P2GT_DYN_LDS, L.stream, mp, pd, t, grid, binStart,  \
                      cellCount, nbr, stale, staleCount)
@@ -52,19 +52,28 @@ void zs_rocm_mpm_p2g(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_p
     if (merged) { CALL_P2G_TILE_GM(S, Gv, true); }                                                                                      \
     else { CALL_P2G_TILE_GM(S, Gv, false); }                                                                                            \
   } while (0)
+#ifdef ZS_P2G_AB
+#define CALL_P2G_GROUPS(CALLG, S, ...)                                                                                                  \
+  do {                                                                                                                                  \
+    if (S == 8 && group == 4) { CALLG(8, ##__VA_ARGS__, 4); }                                                                            \
+    else if (S == 8 && group == 2) { CALLG(8, ##__VA_ARGS__, 2); }                                                                       \
+    else { CALLG(S, ##__VA_ARGS__, 1); }                                                                                                \
+  } while (0)
+#else
+#define CALL_P2G_GROUPS(CALLG, S, ...)                                                                                                  \
+  do {                                                                                                                                  \
+    if (S == 8) { CALLG(8, ##__VA_ARGS__, 2); }                                                                                          \
+    else { CALLG(S, ##__VA_ARGS__, 1); }                                                                                                \
+  } while (0)
+#endif
 #define CALL_P2G_WIDE(S, M, LWv)                                                                                                       \
   do {                                                                                                                                  \
-    if (LWv == 64 && tileStreamEnv && aligned16) {                                                                                                      \
-      if (S == 8 && group == 4) { CALL_P2G_TILE_G(8, 4); }                                                                               \
-      else if (S == 8 && group == 2) { CALL_P2G_TILE_G(8, 2); }                                                                          \
-      else { CALL_P2G_TILE_G(S, 1); }                                                                                                   \
-    }                                                                                                                                   \
-    else if (S == 8 && group == 4) { CALL_P2G_WIDE_G(8, LWv, 4); }                                                                       \
-    else if (S == 8 && group == 2) { CALL_P2G_WIDE_G(8, LWv, 2); }                                                                       \
-    else { CALL_P2G_WIDE_G(S, LWv, 1); }                                                                                                \
+    if (LWv == 64 && tileStream && aligned16) CALL_P2G_GROUPS(CALL_P2G_TILE_G, S);                                                      \
+    else CALL_P2G_GROUPS(CALL_P2G_WIDE_G, S, LWv);                                                                                      \
     hipLaunchKernelGGL((p2g_stale_kernel<S, MPM_CACHED_STRESS>), dim3(STALE_BLOCKS), dim3(256), 0, L.stream, mp, pd, t, grid,            \
                        (const int *)stale, (const int *)staleCount);                                                                    \
   } while (0)
+      (void)group;
       if (p->side == 4) ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 4, 0);
       else ZSR_DISPATCH_LW(lw, CALL_P2G_WIDE, 8, 0);
       return;
