@@ -896,7 +896,7 @@ def main():
             # PMC traffic of the kernels this run used: slotted storage under motion (pmc_g2p2g.json, tools/refresh_r05.sh) or the
             # compact-storage kernel at rest (pmc_g2p2g_compact.json); no figure was collected for the other combinations
             moving = any(abs(x) > 0 for x in drift_v)
-            per_bin = a.side != 8 or (os.environ.get("ZS_ROCM_SLOT_PERBIN", "0") not in ("", "0"))
+            per_bin = a.side != 8   # 4^3 blocks: one workgroup per bin (= block); 8^3 blocks: one workgroup per block
             fkernel = (("g2p2g_slot_kernel" if per_bin else "g2p2g_slotblk_kernel") + " + slot_rehome_kernel + slot_commit_kernel") if a.slotted else "g2p2g_rs_kernel"
             fvalu = None
             pmcf = os.path.join(ROOT, "profiles", "pmc_g2p2g.json" if (a.slotted and moving) else "pmc_g2p2g_compact.json")

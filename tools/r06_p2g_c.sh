@@ -1,5 +1,5 @@
 #!/bin/bash
-# r06: p2g_tile_kernel A/B (product build, 1 / 2 / 4 bins per workgroup, stamps)
+# r06: p2g_tile_kernel A/B: product build, measurement builds $EXTRA (1 / 2 / 4 bins per workgroup through ZS_P2G_AB builds), stamps
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=$R/gpurun_out/r06c; mkdir -p $O
 timeout 900 python -m pytest tests/test_mpm_gpu.py -x -q -m gpu 2>&1 | tail -3
@@ -13,7 +13,7 @@ l=[x for x in sys.stdin if x.startswith('{')]; d=json.loads(l[-1]); r=d.get('roo
 print('${n:-product} G=$g $tag', 'p2g launch ms %.4f frac %.4f step %.3f' % (r.get('launch_ms',-1), r.get('frac',-1), d.get('ms_per_step',-1)))"
   grep "p2g probe" $O/err_${n:-product}_${g}_$tag.txt
 }
-for g in 2 4 1; do run "" $g a; run "" $g b; done
-for n in $EXTRA; do run $n 2 a; run $n 2 b; done
+run "" 2 a; run "" 2 b
+for n in $EXTRA; do for g in ${GROUPS_AB:-2}; do run $n $g a; run $n $g b; done; done
 export ZS_ROCM_PROBE=1
 for g in 2 4; do run p2gprobe $g a; done

@@ -1550,6 +1550,104 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_wide_kernel(MpmDev mp, P
 #endif
 }
 
+// The lane's 27 x 7 node sums of p2g_tile_kernel with the six vector channels as three register PAIRS per node, {mv_x, mv_y},
+// {mv_z, f_x}, {f_y, f_z}: the Q-form accumulation then issues one v_pk_add_f32 / v_pk_fma_f32 where p2gw_accumulate issues two scalar
+// instructions (the node's weight is broadcast from the low half of its pair: op_sel_hi:[0,1,1]).  A wave issues one instruction every
+// ~5 cycles whatever it is (profiles/r02_valu_opcode_rates.md) and this kernel has two waves per SIMD, so its record stream is bound by
+// the NUMBER of instructions a wave issues, not by the VALU rate (where a packed instruction costs 1.7 scalar ones: r03, fused kernels).
+// Each half is the same IEEE operation as the scalar form; the products are formed in the same order as in p2gw_accumulate.
+typedef float p2g_f2 __attribute__((ext_vector_type(2)));
+struct P2GAccPk {
+  float m[27];
+  p2g_f2 q[27][3];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      m[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) q[k][j] = p2g_f2{0.f, 0.f};
+    }
+  }
+  __device__ __forceinline__ float get(int k, int ch) const { return ch == 0 ? m[k] : (((ch - 1) & 1) ? q[k][(ch - 1) >> 1].y : q[k][(ch - 1) >> 1].x); }
+};
+// `own` false: the lane adds zeros (its record and its weights are replaced by zeros first: they may be anything, NaN included) -- the
+// accumulation is NOT a divergent region, whose join would copy every register pair.
+__device__ __forceinline__ void p2gw_accumulate_pk(const MpmDev &mp, const Arena &ar0, const float *rec0, float kscale, bool own, P2GAccPk &A) {
+  Arena ar;
+  float recv[P2GW_NF];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    ar.lp[d] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ar.w[d][k] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < P2GW_NF; ++r) recv[r] = 0.f;
+  if (own) {  // ONE divergent region: the record's reads and the copies of the weights
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      ar.lp[d] = ar0.lp[d];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ar.w[d][k] = ar0.w[d][k];
+    }
+    recv[0] = rec0[0];
+#pragma unroll
+    for (int r = 4; r < P2GW_NF; ++r) recv[r] = rec0[r * 64];
+  }
+  struct { const float *v; __device__ __forceinline__ float operator[](int i) const { return v[i / 64]; } } rec{recv};
+  const float m = rec[0];
+  float lc[3];  // centre node - particle
+#pragma unroll
+  for (int k = 0; k < 3; ++k) lc[k] = mp.dx - ar.lp[k];
+  float al[6], bx[6], by[6], bz[6];
+  {
+    const float mdx = m * mp.dx, ksdx = kscale * mp.dx;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = rec[(4 + d) * 64], c0 = rec[(7 + d) * 64], c1 = rec[(10 + d) * 64], c2 = rec[(13 + d) * 64];
+      al[d] = m * (v + (c0 * lc[0] + c1 * lc[1] + c2 * lc[2]));
+      bx[d] = mdx * c0;
+      by[d] = mdx * c1;
+      bz[d] = mdx * c2;
+      const float s0 = rec[(16 + d) * 64], s1 = rec[(16 + (d == 0 ? 1 : d == 1 ? 3 : 4)) * 64], s2 = rec[(16 + (d == 0 ? 2 : d == 1 ? 4 : 5)) * 64];
+      al[3 + d] = kscale * (s0 * lc[0] + s1 * lc[1] + s2 * lc[2]);
+      bx[3 + d] = ksdx * s0;
+      by[3 + d] = ksdx * s1;
+      bz[3 + d] = ksdx * s2;
+    }
+  }
+  p2g_f2 alp[3], bxp[3], byp[3], bzp[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    alp[j] = p2g_f2{al[2 * j], al[2 * j + 1]};
+    bxp[j] = p2g_f2{bx[2 * j], bx[2 * j + 1]};
+    byp[j] = p2g_f2{by[2 * j], by[2 * j + 1]};
+    bzp[j] = p2g_f2{bz[2 * j], bz[2 * j + 1]};
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    p2g_f2 qa[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) qa[j] = a == 0 ? alp[j] - bxp[j] : (a == 1 ? alp[j] : alp[j] + bxp[j]);
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float wxy = ar.w[0][a] * ar.w[1][bb];
+      const float W0 = wxy * ar.w[2][0], W1 = wxy * ar.w[2][1], W2 = wxy * ar.w[2][2];
+      const int k0 = (a * 3 + bb) * 3;
+      A.m[k0] = fmaf(W0, m, A.m[k0]);
+      A.m[k0 + 1] = fmaf(W1, m, A.m[k0 + 1]);
+      A.m[k0 + 2] = fmaf(W2, m, A.m[k0 + 2]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const p2g_f2 qab = bb == 0 ? qa[j] - byp[j] : (bb == 1 ? qa[j] : qa[j] + byp[j]);
+        A.q[k0][j] = __builtin_elementwise_fma((p2g_f2)(W0), qab - bzp[j], A.q[k0][j]);
+        A.q[k0 + 1][j] = __builtin_elementwise_fma((p2g_f2)(W1), qab, A.q[k0 + 1][j]);
+        A.q[k0 + 2][j] = __builtin_elementwise_fma((p2g_f2)(W2), qab + bzp[j], A.q[k0 + 2][j]);
+      }
+    }
+  }
+}
+
 // private flush arena of one wave of p2g_tile_kernel: 6^3 nodes, one float4 per node and plane (plane 0: m, mv; plane 1: f), strides in
 // nodes z + 12 y + 72 x: a 16-byte access of the wave is served in four passes of 16 lanes = the 4 x 4 (y, z) cells of one x, and
 // 12 y + z (+ a phase offset) takes 16 distinct values mod 16 there -- no bank conflict in any of the 27 phases.
@@ -1692,11 +1790,16 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
   for (int k = 0; k < 8; ++k)  // (constant address space + uniform address = s_load: vmcnt stays the record requests' own)
     nbs[k] = reinterpret_cast<const __attribute__((address_space(4))) int *>(reinterpret_cast<unsigned long long>(nbr))[(size_t)geo.block * 8 + k];
   const float kscale = mp.fscale;  // contrib = -dt D_inv (P F^T vol)
-  float acc[27][7];
+#ifdef ZS_P2GT_SCALAR  // measurement builds: the scalar accumulation of p2g_wide_kernel
+  struct { float a[27][7]; __device__ __forceinline__ float get(int k, int ch) const { return a[k][ch]; } } acc;
 #pragma unroll
   for (int k = 0; k < 27; ++k)
 #pragma unroll
-    for (int ch = 0; ch < 7; ++ch) acc[k][ch] = 0.f;
+    for (int ch = 0; ch < 7; ++ch) acc.a[k][ch] = 0.f;
+#else
+  P2GAccPk acc;
+  acc.clear();
+#endif
   int base = start;      // first particle of the round (wave-uniform)
   int tDone = tile0;     // tiles below have arrived
   int cslot = 0;         // ring slot of tile base / 64
@@ -1749,7 +1852,11 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
       const int ocx = ar.corner[0] - geo.org[0], ocy = ar.corner[1] - geo.org[1], ocz = ar.corner[2] - geo.org[2];
       const bool inBin = (unsigned)(ocx | ocy | ocz) < 4u;  // all three in 0..3
       const bool own = has && inBin && ((ocx << 4) | (ocy << 2) | ocz) == lane;  // lane = cell: (x, y, z) = (lane >> 4, (lane >> 2) & 3, lane & 3)
-      if (own) p2gw_accumulate(mp, ar, rec, kscale, acc);
+#ifdef ZS_P2GT_SCALAR
+      if (own) p2gw_accumulate(mp, ar, rec, kscale, acc.a);
+#else
+      p2gw_accumulate_pk(mp, ar, rec, kscale, own, acc);
+#endif
       if (__ballot(has && !own) != 0ull) {  // some particle has left the cell it is stored under (wave-uniform, rare)
         if (has && !own) {
           bool queued = false;
@@ -1797,10 +1904,10 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
     for (int k = 0; k < 27; ++k) {
       float4 *g = a0 + AP::at(k / 9, (k / 3) % 3, k % 3);
       float4 *gn = a0 + AP::at((k + 1) / 9, ((k + 1) / 3) % 3, (k + 1) % 3);
-      g[0] = make_float4(va.x + acc[k][0], va.y + acc[k][1], va.z + acc[k][2], va.w + acc[k][3]);
+      g[0] = make_float4(va.x + acc.get(k, 0), va.y + acc.get(k, 1), va.z + acc.get(k, 2), va.w + acc.get(k, 3));
       P2GT_LDS_ORDER();
       if (k + 1 < 27) va = gn[0];
-      g[AP::PLANE] = make_float4(vb.x + acc[k][4], vb.y + acc[k][5], vb.z + acc[k][6], 0.f);
+      g[AP::PLANE] = make_float4(vb.x + acc.get(k, 4), vb.y + acc.get(k, 5), vb.z + acc.get(k, 6), 0.f);
       P2GT_LDS_ORDER();
       if (k + 1 < 27) vb = gn[AP::PLANE];
     }

@@ -624,15 +624,11 @@ void launch_g2p2g_slotblk(hipStream_t stream, int model, bool writeAll, const Mp
     else launch_blk<M, false>(stream, nblk, mp, pd, t, A);         \
     break;
   switch (model) {
-#ifdef ZS_SLOT_FAST_BUILD
-    default: launch_blk<ZS_MPM_DRUCKER_PRAGER, false>(stream, nblk, mp, pd, t, A); break;
-#else
     ZSR_BLK(ZS_MPM_FIXED_COROTATED)
     ZSR_BLK(ZS_MPM_DRUCKER_PRAGER)
     ZSR_BLK(ZS_MPM_VONMISES_FIXED_COROTATED)
     ZSR_BLK(ZS_MPM_NACC)
     ZSR_BLK(ZS_MPM_EQUATION_OF_STATE)
-#endif
   }
 #undef ZSR_BLK
 }

@@ -500,45 +500,27 @@ int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
   const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
   const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap,
                    st->blockEdge};
-#define CALL_SLOT3(SS, M, WA)                                                                                                          \
-  do {                                                                                                                                  \
-    if (nbins) {                                                                                                                       \
-      hipLaunchKernelGGL((g2p2g_slot_kernel<SS, M, WA>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);                            \
-    }                                                                                                                                  \
-    if (finish)                                                                                                                         \
-      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 32)),         \
-                         dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
-                         outboxCap, (size_t)nbinsAll, K, status);                                                                       \
+#define CALL_REHOME3(M, WA)                                                                                                              \
+  hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 32)), dim3(256), 0,  \
+                     L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, outboxCap,        \
+                     (size_t)nbinsAll, K, status)
+#define CALL_REHOME(SS, M)                      \
+  do {                                          \
+    if (writeAll) { CALL_REHOME3(M, true); }    \
+    else { CALL_REHOME3(M, false); }            \
   } while (0)
-#define CALL_SLOT(SS, M)                       \
-  do {                                         \
-    if (writeAll) { CALL_SLOT3(SS, M, true); } \
-    else { CALL_SLOT3(SS, M, false); }         \
-  } while (0)
-  // 8^3 blocks: one workgroup per block (mpm_slotblk.hip); ZS_ROCM_SLOT_PERBIN=1 keeps the workgroup-per-bin kernel (A/B runs), which is
-  // also what 4^3 blocks (bin == block) use
-  static const bool perBin = getenv("ZS_ROCM_SLOT_PERBIN") && atoi(getenv("ZS_ROCM_SLOT_PERBIN")) != 0;
-  if (p->side == 8 && !perBin) {
+  // 8^3 blocks: one workgroup per block (mpm_slotblk.hip); 4^3 blocks (bin == block): one workgroup per bin (g2p2g_slot_kernel<4, ...>)
+  if (p->side == 8) {
     if (nbins) launch_g2p2g_slotblk(L.stream, p->model, writeAll != 0, mp, pd, t, A);
-#define CALL_REHOME(SS, M)                                                                                                               \
-  do {                                                                                                                                  \
-    if (writeAll)                                                                                                                       \
-      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), true>), dim3(ceil_div((size_t)nbinsAll, 32)),      \
-                         dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
-                         outboxCap, (size_t)nbinsAll, K, status);                                                                       \
-    else                                                                                                                                \
-      hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), false>), dim3(ceil_div((size_t)nbinsAll, 32)),     \
-                         dim3(256), 0, L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, \
-                         outboxCap, (size_t)nbinsAll, K, status);                                                                       \
+  } else if (nbins) {
+#define CALL_SLOT4(SS, M)                                                                                                  \
+  do {                                                                                                                     \
+    if (writeAll) hipLaunchKernelGGL((g2p2g_slot_kernel<4, M, true>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);  \
+    else hipLaunchKernelGGL((g2p2g_slot_kernel<4, M, false>), dim3(nbins), dim3(512), 0, L.stream, mp, pd, t, A);          \
   } while (0)
-    if (finish) ZSR_DISPATCH_SIDE_PURE(p->side, p->model, CALL_REHOME);
-  } else {
-#ifdef ZS_SLOT_FAST_BUILD  // experiments: one instantiation (sand, 8^3 blocks)
-    CALL_SLOT3(8, 1, false);
-#else
-    ZSR_DISPATCH_SIDE_PURE(p->side, p->model, CALL_SLOT);
-#endif
+    ZSR_DISPATCH_PURE_(4, p->model, CALL_SLOT4)
   }
+  if (finish) ZSR_DISPATCH_PURE_(0, p->model, CALL_REHOME)
   if (finish) {
     const size_t ncells = (size_t)nbinsAll * 64;
     hipLaunchKernelGGL(slot_commit_kernel, dim3(ceil_div(ncells, 256)), dim3(256), 0, L.stream, cellMask, claim, ncells, K);
