@@ -197,19 +197,38 @@ def cpu_baseline(sample, dx, dt, model, side, vol):
     mass, pos, vel = aos[:, 0].copy(), aos[:, 1:4].copy(), aos[:, 4:7].copy()
     Cm, F = aos[:, 7:16].copy(), aos[:, 16:25].copy()
     lj = np.zeros(n, np.float32)
-    om = OracleMpm(o, model, dx, dt, side, vol, nthreads=nth)
-    om.build_partition(pos, max(1024, n // 64))
-    reps, t_total = 0, 0.0
-    while t_total < 8.0 and reps < 20:
-        om.grid[:] = 0
-        t0 = time.perf_counter()
-        om.p2g(mass, pos, vel, Cm, F, lj)
-        om.grid_update((0.0, -9.8, 0.0))
-        om.g2p(pos, vel, Cm, F)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    return {"value": n * reps / t_total, "unit": "particle*steps/s", "cores": cores, "threads": nth, "kind": "port",
-            "sample": "%d particles of the same sand column, %d steps (P2G + grid update + G2P), oracle/mpm.c OpenMP port" % (n, reps)}
+    def steps_per_second(threads, budget_s, max_reps):
+        """median over the timed steps after ONE discarded warm-up step; (particle*steps/s, timed steps)"""
+        om = OracleMpm(o, model, dx, dt, side, vol, nthreads=threads)
+        om.build_partition(pos, max(1024, n // 64))
+        p, v, c, f = pos.copy(), vel.copy(), Cm.copy(), F.copy()
+        times, spent = [], 0.0
+        for rep in range(max_reps + 1):
+            om.grid[:] = 0
+            t0 = time.perf_counter()
+            om.p2g(mass, p, v, c, f, lj)
+            om.grid_update((0.0, -9.8, 0.0))
+            om.g2p(p, v, c, f)
+            dt_s = time.perf_counter() - t0
+            if rep:  # (step 0: thread pool start-up, first touch of the grid)
+                times.append(dt_s)
+                spent += dt_s
+            if rep >= 5 and spent >= budget_s:
+                break
+        return n / float(np.median(times)), len(times)
+    val, reps = steps_per_second(nth, 8.0, 20)
+    # the port's P2G is a CAS loop on shared grid nodes and stops scaling long before the box's core count (BASELINE.md 2): the same
+    # sample at a few smaller thread counts, the best of them beside the reference's own default (hardware_concurrency() - 1)
+    best_val, best_thr = val, nth
+    for thr in (8, 16, 32, 64, 128):
+        if thr < nth:
+            v2, _ = steps_per_second(thr, 1.5, 5)
+            if v2 > best_val:
+                best_val, best_thr = v2, thr
+    return {"value": val, "unit": "particle*steps/s", "cores": cores, "threads": nth, "kind": "port",
+            "best_threads": best_thr, "best_threads_value": best_val,
+            "sample": "%d particles of the same sand column, median of %d steps after one discarded warm-up step (P2G + grid update + G2P), "
+                      "oracle/mpm.c OpenMP port; best_threads: the same sample at 8 / 16 / 32 / 64 / 128 threads (5 steps each)" % (n, reps)}
 
 
 def main():

@@ -196,8 +196,9 @@ __device__ __forceinline__ int bht_insert(const BhtDev &t, const int *key, int i
 // the dense indices of all slots claimed by the workgroup are taken with ONE atomic on cnt (a single device-wide
 // counter saturates at ~90 atomics/us on MI355X: 10M distinct keys would spend > 2 ms there even wave-aggregated).
 // `smem` = 2 + blockDim/64 unsigned of LDS.
-template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev &t, const int *key, bool valid, unsigned *smem) {
-  const int slot = valid ? bht_find_or_claim<DIM>(t, key) : -1;
+// second half of the bulk forms: the dense indices of all slots claimed by the workgroup with ONE atomic on cnt; `slot` = what
+// bht_find_or_claim / bht_tile_find_or_claim returned for this thread's key (-1 / BHT_FAIL: nothing to commit)
+template <int DIM> __device__ __forceinline__ int bht_commit_block(const BhtDev &t, const int *key, int slot, unsigned *smem) {
   const bool won = slot >= 0;
   const unsigned long long m = __ballot(won);
   const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
@@ -217,6 +218,9 @@ template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev 
   if (won) ret = bht_commit<DIM>(t, slot, key, (int)(smem[0] + smem[2 + w] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))), true);
   __syncthreads();
   return ret;
+}
+template <int DIM> __device__ __forceinline__ int bht_insert_block(const BhtDev &t, const int *key, bool valid, unsigned *smem) {
+  return bht_commit_block<DIM>(t, key, valid ? bht_find_or_claim<DIM>(t, key) : -1, smem);
 }
 
 // ---- cooperative forms (BHTView::tile_insert / tile_query, Bht.hpp:547-608, 703-736): the lanes of a tile carry the SAME key and
@@ -251,7 +255,7 @@ template <int DIM, class Tile> __device__ __forceinline__ int bht_tile_find_or_c
       busy = busy || tile.any(mine && st == 2);
       load += __popcll(tile.ballot(mine && st != 0));
     }
-    if (busy) continue;     // a slot is being written (it may become this key): look again
+    if (busy) continue;  // a slot is being written (it may become this key): look again
     if (found) return -1;   // sentinel_v: already present
     if (load <= B - 2) {    // threshold = B - 2 (Bht.hpp:34)
       int ok = 0;
@@ -278,6 +282,27 @@ __device__ __forceinline__ int bht_tile_insert(const BhtDev &t, const int *key, 
     no = bht_commit<DIM>(t, slot, key, no, enqueue);
   }
   return tile.shfl(no, 0);
+}
+// Bulk form of the cooperative insert for kernels in which every thread of the workgroup holds one key (threads without: valid =
+// false): the wave's 64 keys are taken in B rounds by its 64 / B tiles -- in round r tile j inserts the key of lane r (64 / B) + j --
+// and each lane gets the claim of its own key back.  Follow with bht_commit_block.
+template <int DIM> __device__ __forceinline__ int bht_find_or_claim_tiled(const BhtDev &t, const int *key, bool valid) {
+  const int B = (int)t.bucket, lane = (int)(threadIdx.x & 63), per = 64 / B;
+  BhtWaveTile tile(B);
+  int mine = -1;
+#pragma unroll 1
+  for (int r = 0; r < B; ++r) {
+    const int owner = r * per + lane / B;
+    int k[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) k[d] = __shfl(key[d], owner);
+    const int kv = __shfl((int)valid, owner);
+    int s = -1;
+    if (kv) s = bht_tile_find_or_claim<DIM>(t, k, tile);
+    const int got = __shfl(s, (lane % per) * B);  // (every lane of a tile holds the tile's answer)
+    if (lane / per == r) mine = got;
+  }
+  return mine;
 }
 // BHTView::tile_query (Bht.hpp:703-736): plain loads, table must be quiescent
 template <int DIM, bool RETSLOT = false, class Tile> __device__ __forceinline__ int bht_tile_query(const BhtDev &t, const int *key, Tile &tile) {

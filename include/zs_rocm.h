@@ -755,6 +755,8 @@ ZS_ROCM_EXPORT void zs_rocm_svd3(zs_rocm_policy *, const float *F, size_t n, flo
  * rank = (r0 * dims[1] + r1) * dims[2] + r2 */
 ZS_ROCM_EXPORT void zs_rocm_mpm_owner_rank(zs_rocm_policy *, zs_rocm_attr pos, size_t n, float dx, const int lo[3], const int hi[3],
                                            const int dims[3], int align, int *owner);
+/* counts[r] (device, `world` ints, world <= 1024) = number of entries of owner[0 .. n) equal to r */
+ZS_ROCM_EXPORT void zs_rocm_mpm_owner_counts(zs_rocm_policy *, const int *owner, size_t n, int world, int *counts);
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_pack(zs_rocm_policy *, const float *grid, const int *blocks, size_t nb, int side,
                                           int chn0, int nchn, float *buf);
 ZS_ROCM_EXPORT void zs_rocm_mpm_halo_unpack(zs_rocm_policy *, float *grid, const int *blocks, size_t nb, int side,

@@ -105,16 +105,39 @@ def test_config2_bht_16m_keys(pol, oracle):
     size = tab.size()
     lost = ndist - size
     print("bht 16 M keys: %d distinct, lost by the sequential oracle %d, lost by the GPU build %d" % (ndist, olost, lost))
-    # the parallel build may lose a few keys more than the sequential one (probe sequences truncated by concurrent winners), never many:
-    # 67-72 against the oracle's 66 over 20 runs of the r05 build (insertion order differs from run to run); one run of the full suite went
-    # past 74
-    assert 0 <= lost <= olost + 16, (lost, olost)
+    # The parallel build inserts in another order than the sequential oracle, so WHICH keys find their buckets full differs from run to
+    # run and no bound on the count says anything about the keys.  What Bht.hpp:490-541 promises is checked instead, further down: a
+    # key fails only if each of its three buckets is full (more than B - 2 = 14 slots taken: 15 foreign keys) and does not hold it.
+    assert lost >= 0
     v = tab.view()
     succ = np.empty(1, np.int32)
     C.CDLL("libamdhip64.so").hipMemcpy(succ.ctypes.data_as(C.c_void_p), C.c_void_p(v.success), C.c_size_t(4), 2)
     assert (succ[0] == 0) == (lost > 0)
     failed = r < -1                                                   # failure_token_v: reported, never silent
     assert np.unique(packed[failed]).shape[0] == lost and (qi[failed] < 0).all()
+    if lost:  # every failed key: its three buckets in the FINAL table are full of other keys (nothing is ever removed from a bucket)
+        hip = C.CDLL("libamdhip64.so")
+        B, PRIME = 16, np.uint64(4294967291)
+        fk = keys[failed][np.unique(packed[failed], return_index=True)[1]].astype(np.int64)
+
+        def h1(hx, hy, k):  # universal_hash (py_interop/HashUtils.hpp:23-43): ((hx ^ k) + hy) mod 2^32, then mod prime
+            return (((np.uint64(hx) ^ (k.astype(np.uint64) & np.uint64(0xffffffff))) + np.uint64(hy)) & np.uint64(0xffffffff)) % PRIME
+
+        def hkey(hx, hy):   # folded with hash_combine (math/Hash.hpp:19-28), 32-bit arithmetic
+            ret = h1(hx, hy, fk[:, 0])
+            for d in (1, 2):
+                vv = h1(hx, hy, fk[:, d])
+                ret = (ret ^ ((vv + np.uint64(0x9e3779b9) + (ret << np.uint64(6)) + (ret >> np.uint64(2))) & np.uint64(0xffffffff))) & np.uint64(0xffffffff)
+            return ret
+        slot = np.empty(B * 4, np.int32)
+        for hx, hy in ((v.hf0x, v.hf0y), (v.hf1x, v.hf1y), (v.hf2x, v.hf2y)):
+            bucket = (hkey(hx, hy) % np.uint64(v.numBuckets)).astype(np.int64) * B
+            for j in range(fk.shape[0]):
+                hip.hipMemcpy(slot.ctypes.data_as(C.c_void_p), C.c_void_p(v.keys + int(bucket[j]) * 16), C.c_size_t(slot.nbytes), 2)
+                sl = slot.reshape(B, 4)[:, :3]
+                taken = ~(sl == 0x3f3f3f3f).all(1)
+                assert taken.sum() >= B - 1, (fk[j], int(taken.sum()))             # load > threshold = B - 2 (Bht.hpp:34, :517)
+                assert not (sl[taken] == fk[j]).all(1).any(), fk[j]                # ... and none of them is the key itself
     stored = qi >= 0
     assert stored.sum() == n - np.isin(packed, np.unique(packed[failed])).sum()
     assert qi[stored].max() == size - 1 and (r >= 0).sum() == size   # one winner per stored key

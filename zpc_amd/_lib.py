@@ -355,6 +355,8 @@ def _declare_containers(L):
     L.zs_rocm_mpm_build_neighbors.argtypes = [vp, vp, vp, i32]
     L.zs_rocm_mpm_p2g.argtypes = [vp, PP, Particles, vp, vp, sz, vp, vp, vp]
     L.zs_rocm_mpm_owner_rank.argtypes = [vp, Port, sz, f32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]
+    L.zs_rocm_mpm_owner_counts.argtypes = [vp, vp, sz, i32, vp]
+    L.zs_rocm_mpm_owner_counts.restype = None
     L.zs_rocm_mpm_g2p2g.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32]
     L.zs_rocm_mpm_g2p2g_range.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, vp, vp, i32, sz, sz, vp]
     L.zs_rocm_mpm_g2p2g_slotted.argtypes = [vp, PP, Particles, vp, vp, vp, sz, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]

@@ -91,6 +91,19 @@ template <int DIM> __global__ __launch_bounds__(1024) void bht_insert_kernel(Bht
   int r = bht_insert_block<DIM>(t, key, valid, smem);
   if (valid && ret) ret[i] = r;
 }
+// the same with the cooperative probe (lanes of a tile examine one bucket together: bht_tile_find_or_claim)
+template <int DIM> __global__ __launch_bounds__(256) void bht_insert_tile_kernel(BhtDev t, const int *keys, size_t n, int *ret) {
+  __shared__ unsigned smem[2 + 4];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int key[DIM] = {};
+  if (valid) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) key[d] = keys[i * DIM + d];
+  }
+  const int r = bht_commit_block<DIM>(t, key, bht_find_or_claim_tiled<DIM>(t, key, valid), smem);
+  if (valid && ret) ret[i] = r;
+}
 // assign: table := {keys[i] -> i} (what a partition built elsewhere, e.g. a zs::HashTable's _activeKeys, needs to be used
 // by the binned transfers); cnt = n
 template <int DIM> __global__ __launch_bounds__(256) void bht_assign_kernel(BhtDev t, const int *keys, int n) {
@@ -148,6 +161,13 @@ template <int DIM> __global__ void bht_gather_comp_kernel(const int *activeKeys,
 template <int DIM> static void bht_insert_many(zs_rocm_policy *pol, BhtHost &t, const int *keys, size_t n, int *ret) {
   Launch L(pol, "bht_insert");
   if (!n) return;
+#ifdef ZS_BHT_AB  // measurement builds: ZS_ROCM_BHT_TILE=1 builds with the cooperative probe (profiles/r06_bht.md)
+  static const bool tiled = getenv("ZS_ROCM_BHT_TILE") && atoi(getenv("ZS_ROCM_BHT_TILE")) != 0;
+  if (tiled) {
+    hipLaunchKernelGGL((bht_insert_tile_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.dev(), keys, n, ret);
+    return;
+  }
+#endif
   hipLaunchKernelGGL((bht_insert_kernel<DIM>), dim3(ceil_div(n, 1024)), dim3(1024), 0, L.stream, t.dev(), keys, n, ret);
 }
 template <int DIM> static void bht_query_many(zs_rocm_policy *pol, const BhtHost &t, const int *keys, size_t n, int *ret) {

@@ -256,6 +256,15 @@ void zs_rocm_mpm_owner_rank(zs_rocm_policy *pol, zs_rocm_attr pos, size_t n, flo
   sp.align = align < 1 ? 1 : align;
   hipLaunchKernelGGL(owner_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, make_port<float>(pos), n, 1.0f / dx, sp, owner);
 }
+// counts[r] = number of i with owner[i] == r, r in [0, world) (world <= 1024): how many particles a migration sends to each rank
+void zs_rocm_mpm_owner_counts(zs_rocm_policy *pol, const int *owner, size_t n, int world, int *counts) {
+  Launch L(pol, "owner_counts");
+  if (world < 1 || world > 1024) return;
+  ZSR_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)world, L.stream));
+  if (!n) return;
+  const unsigned blocks = ceil_div(n, 256 * 16) < 2048u ? ceil_div(n, 256 * 16) : 2048u;
+  hipLaunchKernelGGL(owner_count_kernel, dim3(blocks), dim3(256), sizeof(int) * (size_t)world, L.stream, owner, n, world, counts);
+}
 void zs_rocm_mpm_halo_pack(zs_rocm_policy *pol, const float *grid, const int *blocks, size_t nb, int side, int chn0, int nchn, float *buf) {
   Launch L(pol, "halo_pack");
   const int nc = side * side * side;

@@ -3322,6 +3322,19 @@ static __global__ __launch_bounds__(256) void owner_rank_kernel(Port<float> pos,
   }
   owner[i] = (rc[0] * sp.dims[1] + rc[1]) * sp.dims[2] + rc[2];
 }
+// per-workgroup LDS histogram of the owner ranks, one global atomic per (workgroup, rank that occurs)
+static __global__ __launch_bounds__(256) void owner_count_kernel(const int *owner, size_t n, int world, int *counts) {
+  extern __shared__ int ocHist[];
+  for (int r = threadIdx.x; r < world; r += 256) ocHist[r] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int o = owner[i];
+    if ((unsigned)o < (unsigned)world) atomicAdd(&ocHist[o], 1);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < world; r += 256)
+    if (ocHist[r]) atomicAdd(&counts[r], ocHist[r]);
+}
 static __global__ void halo_pack_kernel(const float *grid, const int *blocks, size_t nb, int nc, int chn0, int nchn, float *buf) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)nchn * nc;

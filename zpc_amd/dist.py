@@ -344,8 +344,10 @@ def migrate_particles(mt, pol, dist, rank, world_size, glo, ghi, align, to_comm=
     bits = max(1, (world_size - 1).bit_length())
     if n:
         radix_sort_pair(pol, owner, ids, so, order, n=n, sbit=0, ebit=bits)  # stable: ids ascend inside a destination
+    cnt_dev = torch.empty(world_size, dtype=torch.int32, device=dev)
+    L.zs_rocm_mpm_owner_counts(pol.handle, owner.data_ptr(), n, world_size, cnt_dev.data_ptr())  # (the library's own count, on the policy's stream)
     pol.syncCtx()
-    counts = torch.bincount(so[:n].long(), minlength=world_size).cpu().tolist() if n else [0] * world_size
+    counts = cnt_dev.cpu().tolist()
     starts = [0]
     for c in counts:
         starts.append(starts[-1] + c)
