@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
     ap.add_argument("--slot-stats", action="store_true", help="report the occupancy statistics of the slotted storage after the run")
     ap.add_argument("--checksum", action="store_true", help="print global sums of particle state after the run (N-rank vs 1-rank check)")
+    ap.add_argument("--tag-mass", action="store_true",
+                    help="every particle's mass carries its number in the global box (tests: per-particle comparison of runs on different rank counts)")
+    ap.add_argument("--dump-state", type=str, default="",
+                    help="after the run every rank writes its particles (m, x, v, C, F, logJp) to <prefix>.rank<r>.npz")
     ap.add_argument("--compact", action="store_true",
                     help="compact round-robin particle order + re-bin controller (round 1's storage) instead of the slotted storage "
                          "the fused step keeps valid by itself (zpc_amd/csrc/mpm_slotted.hip)")
@@ -133,7 +137,7 @@ def _hash_normal(gid, stream):
     return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * 3.141592653589793 * u2)
 
 
-def generate_particles(box_lo, box_hi, dx, seed, device, model):
+def generate_particles(box_lo, box_hi, dx, seed, device, model, tag_box=None):
     """8 particles per cell on a jittered 2x2x2 sub-lattice, generated on the device in chunks.
     Returns AoS [n, C] float32: m, x3, v3, C9, F9, (logJp).  Values depend only on the global particle id."""
     ext = [box_hi[d] - box_lo[d] for d in range(3)]
@@ -156,6 +160,10 @@ def generate_particles(box_lo, box_hi, dx, seed, device, model):
         aos[s:e, 2] = ((cy * 2 + sy).double() + 0.5 + (_hash_uniform(gid, 1) - 0.5) * 0.8).float() * h
         aos[s:e, 3] = ((cz * 2 + sz).double() + 0.5 + (_hash_uniform(gid, 2) - 0.5) * 0.8).float() * h
         aos[s:e, 0] = 1000.0 * dx ** 3 / 8
+        if tag_box is not None:  # --tag-mass: the mass carries the particle's number in the GLOBAL box (exact for < 2^22 particles)
+            tlo, text = tag_box
+            tid = (((cx - tlo[0]) * text[1] + (cy - tlo[1])) * text[2] + (cz - tlo[2])) * 8 + sub
+            aos[s:e, 0] = ((1000.0 * dx ** 3 / 8) * (1.0 + tid.double() * 2.0 ** -22)).float()
         for k in range(3):
             aos[s:e, 4 + k] = (0.05 * _hash_normal(gid, 3 + k)).float()
         for k in range(9):
@@ -302,7 +310,9 @@ def main():
             if rank == 0:
                 print("[bench] RCCL communicator: ncclCommCount = %d, %d GPU(s) visible" % (cc, torch.cuda.device_count()), file=sys.stderr)
     max_vel = torch.zeros(1, dtype=torch.float32, device=device)
-    aos = generate_particles(lo, hi, dx, 1234, device, model)
+    if a.tag_mass and ext[0] * ext[1] * ext[2] * 8 >= 1 << 22:
+        raise SystemExit("--tag-mass numbers the particles in the mantissa of their mass: fewer than 2^22 of them")
+    aos = generate_particles(lo, hi, dx, 1234, device, model, tag_box=(glo, ext) if a.tag_mass else None)
     drift_v = [float(x) for x in a.drift.split(",")]
     for k in range(3):
         if drift_v[k] != 0.0:
@@ -728,7 +738,7 @@ def main():
         wgs = max(int(pv[7]), 1)
         print("probe (cycles per workgroup, 100 MHz-agnostic s_memtime ticks): " +
               " ".join("[%d]=%.0f" % (k, pv[k] / wgs / (4 if k in (0, 1, 4, 5, 6) else 8)) for k in range(7)) + " wgs=%d" % wgs, file=sys.stderr)
-    if a.fused and a.checksum:
+    if a.fused and (a.checksum or a.dump_state):
         step_fused(False, write_all=True)  # untimed: materialise v, C, stress of every particle for the checksum
         torch.cuda.synchronize()
     err = lib().zs_rocm_last_error(-1)
@@ -800,6 +810,9 @@ def main():
         slot_stats = {"bins_occupied": int(occ.sum()), "mean_rounds": float(rounds[occ].mean()), "mean_chunk_rounds": float((torch.ceil(rounds[occ] / 4) * 4).mean()),
                       "mean_particles_per_bin_div64": float(per_bin[occ].mean() / 64), "max_rounds": int(rounds.max()),
                       "mean_max_cell_count": float(cnt.max(dim=1).values.float()[occ].mean())}
+    if a.dump_state:
+        dd = mt.download()
+        np.savez(a.dump_state + ".rank%d.npz" % rank, **dd)
     checksum = checksum_trim = None
     if a.checksum:
         # order-independent global sums of the particle state (float64): equal for any number of ranks up to rounding

@@ -65,6 +65,27 @@ def test_n_ranks_reproduce_single_rank(n, extra):
     assert out["hip_error"] == 0
 
 
+def test_eight_ranks_2x2x2_match_single_rank_particle_by_particle(tmp_path):
+    """2 x 2 x 2 decomposition of the default (slotted, moving) step against the single-rank run, PER PARTICLE: every particle carries its
+    number in its mass (--tag-mass), every rank dumps its particles (--dump-state), and the eight dumps together must be the single-rank
+    state -- same particles (nobody lost, nobody twice), same position / velocity / deformation up to the summation order of the float
+    atomics.  (Channel sums, which the other tests compare, would let a permutation or two cancelling errors pass.)"""
+    args = ["--cells", "32,48,32", "--steps", "6", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--tag-mass", "--no-at-rest"]
+    _run(1, args + ["--dump-state", str(tmp_path / "one")])
+    _run(8, args + ["--decomp", "2x2x2", "--dump-state", str(tmp_path / "eight")])
+    ref = dict(np.load(str(tmp_path / "one") + ".rank0.npz"))
+    parts = [dict(np.load(str(tmp_path / "eight") + ".rank%d.npz" % r)) for r in range(8)]
+    assert all(p["m"].shape[0] > 0 for p in parts)  # every rank owns a share
+    got = {k: np.concatenate([p[k] for p in parts]) for k in ref}
+    assert got["m"].shape[0] == ref["m"].shape[0]
+    o1, o8 = np.argsort(ref["m"], kind="stable"), np.argsort(got["m"], kind="stable")
+    assert np.array_equal(ref["m"][o1], got["m"][o8]) and np.unique(ref["m"]).shape[0] == ref["m"].shape[0]   # the same set of distinct particles
+    vs = np.abs(ref["v"]).max()
+    for k, tol in (("x", 2e-6), ("v", 2e-4 * vs), ("F", 2e-5), ("logJp", 2e-5)):
+        if k in ref:
+            assert np.abs(ref[k][o1] - got[k][o8]).max() <= tol, (k, np.abs(ref[k][o1] - got[k][o8]).max())
+
+
 @pytest.mark.parametrize("n,extra", [(2, []), (4, []), (2, ["--unfused"])])
 def test_particle_migration_between_ranks(n, extra):
     """The column drifts upwards at 0.35 cell per step; every 3 steps particles are handed to the rank that now owns their
