@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
     ap.add_argument("--slot-stats", action="store_true", help="report the occupancy statistics of the slotted storage after the run")
     ap.add_argument("--checksum", action="store_true", help="print global sums of particle state after the run (N-rank vs 1-rank check)")
+    ap.add_argument("--halo-channels", type=int, default=4, choices=[4, 7],
+                    help="grid channels of a ghost block that travel between ranks: 4 = {m, mv}, all a step reads of a ghost block (grid update: "
+                         "v = mv / m + g dt; G2P gathers v -- GridOp.hpp:90-104); 7 = the rhs channels too")
     ap.add_argument("--tag-mass", action="store_true",
                     help="every particle's mass carries its number in the global box (tests: per-particle comparison of runs on different rank counts)")
     ap.add_argument("--dump-state", type=str, default="",
@@ -347,7 +350,7 @@ def main():
     def make_pack(p):
         def pack(blocks, nb, buf):
             d = dev_buf(buf)
-            lib().zs_rocm_mpm_halo_pack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr())
+            lib().zs_rocm_mpm_halo_pack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, a.halo_channels, d.data_ptr())
             if d is not buf:
                 buf.copy_(d)  # gloo validation path: stage through host memory
         return pack
@@ -357,7 +360,7 @@ def main():
             d = dev_buf(buf)
             if d is not buf:
                 d.copy_(buf)
-            lib().zs_rocm_mpm_halo_unpack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, 7, d.data_ptr(), 2)
+            lib().zs_rocm_mpm_halo_unpack(p.handle, mt.grid.data_ptr(), blocks.data_ptr(), nb, a.side, 0, a.halo_channels, d.data_ptr(), 2)
         return unpack_add
 
     pack, unpack_add = make_pack(pol), make_unpack(pol)
@@ -368,7 +371,7 @@ def main():
         if halo is None:
             return
         if comm is not None:
-            halo.exchange_native(comm, pol_comm if on_comm_stream else pol, proxy_grid if proxy else mt.grid, a.side)
+            halo.exchange_native(comm, pol_comm if on_comm_stream else pol, proxy_grid if proxy else mt.grid, a.side, 0, a.halo_channels)
         elif on_comm_stream:
             halo.exchange(pack_c, unpack_add_c)
         else:
@@ -455,7 +458,7 @@ def main():
                 return r.cpu().numpy()
 
             h = HaloExchange(dist, rank, world, my_keys, lookup, lambda x: torch.from_numpy(x).to(device),
-                             lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), 7 * nc, all_keys=all_keys)
+                             lambda m: torch.empty(max(m, 1), dtype=torch.float32, device=comm_dev), a.halo_channels * nc, all_keys=all_keys)
         return nb_, h
 
     t0 = time.perf_counter()
@@ -514,7 +517,7 @@ def main():
                             n_boundary=n_boundary if (overlap and halo is not None) else 0, comm=comm, plan=halo if comm is not None else None,
                             comm_pol=pol_comm if overlap else None, collider=floor, halo_grid=proxy_grid,
                             events=hip_events.pair() if timed else None,
-                            breakdown=breakdown.next() if (timed and breakdown is not None) else None)
+                            breakdown=breakdown.next() if (timed and breakdown is not None) else None, halo_channels=a.halo_channels)
             return
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
@@ -890,7 +893,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
-                       "halo_bytes_per_step_rank0": (halo.bytes_per_exchange if halo and halo.peers else 0),
+                       "halo_bytes_per_step_rank0": ((halo.bytes_per_exchange * a.halo_channels // 7 if comm is not None else halo.bytes_per_exchange) if halo and halo.peers else 0),
+                       "halo_channels": a.halo_channels,
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": K, "repartitions": remaps[0], "migrated_rank0": migrated,

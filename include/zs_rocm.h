@@ -837,6 +837,10 @@ typedef struct zs_rocm_mpm_step {
                                             stream around the exchange and [1] == [0]).  A rank's step time splits into
                                             boundary [0,1], interior [1,2], waiting for the exchange [2,5], grid update [5,6], allreduce [6,7];
                                             the exchange itself is [3,4] */
+  int haloChannels;                      /* grid channels [0, haloChannels) of the shared blocks are exchanged; 0 = all 7.  4 = {m, mv}: all a step
+                                            ever reads of a ghost block -- the grid update forms v = mv / m + extf dt and G2P gathers v, exactly as
+                                            ComputeGridBlockVelocity / G2PTransfer of the reference do (simulation/grid/GridOp.hpp:90-104); the rhs
+                                            channels 4..6 of a shared block then keep this rank's partial sums */
 } zs_rocm_mpm_step;
 #define ZS_ROCM_STEP_EVENTS 8
 ZS_ROCM_EXPORT int zs_rocm_mpm_step_slotted(zs_rocm_policy *, const zs_rocm_mpm_step *);

@@ -411,6 +411,8 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
   zs_rocm_memset(pol, a->gridB, 0, gridBytes);
   float *const hgrid = a->haloGrid ? a->haloGrid : a->gridB;
   const bool exchange = a->dist && a->plan && a->plan->total;
+  if (a->haloChannels < 0 || a->haloChannels > 7) return -1;
+  const int hch = a->haloChannels ? a->haloChannels : 7;
   const bool overlap = exchange && a->commPolicy && a->nBoundary > 0 && a->nBoundary < nb;
   int rc = 0;
   auto stamp = [&](void *ev) {
@@ -448,7 +450,7 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
       ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evBoundary, 0));
     }
     bd(3, a->commPolicy);
-    const int rcx = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, 7);
+    const int rcx = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, hch);
     bd(4, a->commPolicy);
     {
       Launch C(a->commPolicy, "step: exchange done");
@@ -473,7 +475,7 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
     stamp(a->evTransferEnd);
     bd(3, pol);
     if (exchange) {
-      rc = zs_rocm_dist_halo_plan_exchange(a->plan, a->dist, pol, hgrid, 0, 7);
+      rc = zs_rocm_dist_halo_plan_exchange(a->plan, a->dist, pol, hgrid, 0, hch);
       if (rc) return rc;
     }
     bd(4, pol);
