@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK_CYCLES = 2.2     # shader cycles per VALU instruction a SIMD reaches on independent v_fma_f32 with >= 2 resident waves (tools/valu_issue_bench.hip, r05)
+# counted floor of the fused step's wave-level VALU instructions per 64 particles, by model index (0 FixedCorotated, 1 DruckerPrager): gather 290 +
+# advection / F update / SVD / model (700 | 860) + Q-form staging 150 + P2G accumulate of the four channel sets at full lane occupancy 628
+VALU_FLOOR_PER_64 = {0: 290.0 + 700.0 + 150.0 + 628.0, 1: 290.0 + 860.0 + 150.0 + 628.0}
 VALU_ISSUE_MIX_CYCLES = 2.9      # the same for the fused step's own SVD + return-mapping instruction mix at 4 waves per SIMD (tools/svd_issue_bench.hip, r05)
 P2G_BYTES = {0: 107.0, 1: 115.0}  # algorithmic B/particle: 100 B particle read + 7 B grid (+8 B logJp r/w)
 G2P_BYTES = 145.5
@@ -955,8 +958,14 @@ def main():
                                      "issue_peak_cycles_per_inst": VALU_ISSUE_PEAK_CYCLES, "issue_mix_cycles_per_inst": VALU_ISSUE_MIX_CYCLES,
                                      "issue_frac": (VALU_ISSUE_PEAK_CYCLES / cpi) if cpi else None,
                                      "issue_frac_of_mix_rate": (VALU_ISSUE_MIX_CYCLES / cpi) if cpi else None,
-                                     "algorithmic_insts": j.get("valu_insts_at_rest"),
-                                     "frac": (j["valu_insts_at_rest"] / j["valu_insts_per_launch"]) if j.get("valu_insts_at_rest") else None,
+                                     # a COUNTED floor, not another run of the same kernel: wave-level VALU instructions per 64 particles of the
+                                     # stages a fused step cannot do without, every lane busy -- G2P gather by sum factorisation 290, advection + F
+                                     # update + 3x3 SVD + return mapping 860 (DruckerPrager; FixedCorotated 700), Q-form staging 150, P2G accumulate
+                                     # of the four channel sets at full lane occupancy 628
+                                     "algorithmic_insts": VALU_FLOOR_PER_64[model] * n_local / 64.0,
+                                     "algorithmic_insts_per_64_particles": VALU_FLOOR_PER_64[model],
+                                     "frac": VALU_FLOOR_PER_64[model] * n_local / 64.0 / j["valu_insts_per_launch"],
+                                     "insts_at_rest": j.get("valu_insts_at_rest"),   # the same kernels on the column at rest (no movers, no holes)
                                      "ns_per_inst_per_simd": fused_ms * 1e6 * 1024 / j["valu_insts_per_launch"],
                                      "source": j.get("source")}
                 except Exception:

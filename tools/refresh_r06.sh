@@ -3,11 +3,11 @@
 # moving column).  Copy gpurun_out/r06/{pmc_g2p2g.json,pmc_p2g.json} to profiles/ by hand afterwards (only gpurun_out/ travels back).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r06; rm -rf $O; mkdir -p $O
+O=$R/gpurun_out/r06; [ -z "$ONLY" ] && rm -rf $O; mkdir -p $O   # ONLY=p2g: just the stand-alone P2G passes (after a change of that kernel alone)
 B="python $R/bench.py --no-cpu-baseline --no-at-rest"
 P2G="$B --compact --unfused --drift 0,0,0 --steps 8 --warmup 2"
 # 1. kernel-trace stats of the default (moving) bench and of the unfused at-rest run
-for tag in moving unfused; do
+for tag in $([ "$ONLY" = p2g ] && echo unfused || echo moving unfused); do
   cmd="$B --steps 10 --warmup 3"; [ $tag = unfused ] && cmd="$P2G"
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats_$tag -o r -- $cmd > $O/stats_${tag}_bench.json 2> $O/stats_${tag}_stderr.txt
   db=$(find $O/stats_$tag -name '*.db' | head -1)
@@ -24,8 +24,10 @@ pmc() {  # pmc <name> <kernel regex> <command...>
     find $out -name '*.csv' -size +8M -delete
   done
 }
+if [ "$ONLY" != p2g ]; then
 pmc fused "g2p2g_slot|slot_rehome_kernel|slot_commit_kernel" $B --steps 20 --warmup 2
 pmc fusedrest "g2p2g_slot|slot_rehome_kernel|slot_commit_kernel" $B --steps 10 --warmup 2 --drift 0,0,0
+fi
 pmc p2g "p2g_tile_kernel" $P2G
 python3 - $O $R <<'PY'
 import csv, glob, os, sys, collections, json
@@ -80,6 +82,7 @@ if "hbm_bytes_per_launch" in s.get("p2g_tile_kernel", {}):
                "source": "tools/refresh_r06.sh"}, open(os.path.join(O, "pmc_p2g.json"), "w"), indent=1)
 PY
 cd $R
+[ "$ONLY" = p2g ] && { $B --compact --unfused --drift 0,0,0 > $O/bench_n1_unfused_at_rest.json 2>/dev/null; exit 0; }
 # 3. bench lines
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 $B --drift 0,0,0 > $O/bench_n1_at_rest.json 2>/dev/null

@@ -1707,18 +1707,24 @@ __device__ __forceinline__ void p2gt_issue_attr(const Port<float> &p, size_t tb,
     if (lane < REST * 16) p2gt_dma16_run<FULL * 1024, 1>(sb, voff, l);
 }
 template <bool MERGED> constexpr int p2gt_requests() { return MERGED ? 4 + (STRESS_N + 3) / 4 : 1 + 1 + 1 + 3 + (STRESS_N + 3) / 4; }
+// [lo, hi): the particles of the tile that belong to this bin (0, 64 for an inner tile).  A lane moves the 4 particles 4 (lane mod 16) ...
+// + 3 of a row; lanes whose four lie outside the range stay out of ALL the tile's requests, so that a 128-byte line of a boundary tile that
+// only the neighbouring bin needs is not fetched here as well (the whole-tile form read 4 % more than the records: profiles/r06_pmc_p2g.md).
 template <bool MERGED>
-__device__ __forceinline__ void p2gt_issue(const ParticlesDev &ps, int tile, int lane, float *buf) {
+__device__ __forceinline__ void p2gt_issue(const ParticlesDev &ps, int tile, int lo, int hi, int lane, float *buf) {
   const size_t tb = (size_t)tile * (size_t)ps.pos.chns * 64;  // element offset of the tile (wave-uniform)
-  if constexpr (MERGED) {
-    p2gt_issue_attr<0, 16>(ps.mass, tb, lane, buf);
-  } else {
-    p2gt_issue_attr<0, 1>(ps.mass, tb, lane, buf);
-    p2gt_issue_attr<1, 3>(ps.pos, tb, lane, buf);
-    p2gt_issue_attr<4, 3>(ps.vel, tb, lane, buf);
-    p2gt_issue_attr<7, 9>(ps.C, tb, lane, buf);
+  const int pl = (lane & 15) * 4;
+  if (pl + 3 >= lo && pl < hi) {
+    if constexpr (MERGED) {
+      p2gt_issue_attr<0, 16>(ps.mass, tb, lane, buf);
+    } else {
+      p2gt_issue_attr<0, 1>(ps.mass, tb, lane, buf);
+      p2gt_issue_attr<1, 3>(ps.pos, tb, lane, buf);
+      p2gt_issue_attr<4, 3>(ps.vel, tb, lane, buf);
+      p2gt_issue_attr<7, 9>(ps.C, tb, lane, buf);
+    }
+    p2gt_issue_attr<16, STRESS_N>(ps.stress, tb, lane, buf);
   }
-  p2gt_issue_attr<16, STRESS_N>(ps.stress, tb, lane, buf);
 }
 
 template <int SIDE, int NB, int G, bool MERGED>
@@ -1766,7 +1772,8 @@ static __global__ __launch_bounds__(64 * G, 2) void p2g_tile_kernel(MpmDev mp, P
   int tIssue = tile0;  // next tile to request; its buffer is ring[(tIssue - tile0) % NB] = islot
   int islot = 0;
   auto request = [&]() {
-    p2gt_issue<MERGED>(ps, tIssue, lane, ring + islot * TILEF);
+    const int lo = tIssue == tile0 ? (start & 63) : 0, hi = tIssue == tileEnd - 1 ? end - (tIssue << 6) : 64;
+    p2gt_issue<MERGED>(ps, tIssue, lo, hi, lane, ring + islot * TILEF);
     ++tIssue;
     islot = islot + 1 == NB ? 0 : islot + 1;
   };
