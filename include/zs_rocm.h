@@ -685,7 +685,10 @@ ZS_ROCM_EXPORT void zs_rocm_mpm_partition_edge(zs_rocm_policy *, const zs_rocm_b
  * holds particles moves, as whole tile rows, to the number its block has in `newTab`; `newMask` and (optionally) `newGrid` -- the node
  * velocities the next step gathers from -- are written for the whole new partition.  No particle is read, re-binned or re-slotted:
  * ~4 ms instead of ~50 ms per re-partition of the 64 Mi-particle column.  Buffers: newBuf = nbins(new) * K * 64 * C floats, newMask = nbins(new) * 64 words,
- * newGrid = nblocks(new) * 7 * side^3 floats.  Returns 0 / -1 (bad arguments); status[2] if a populated block is missing from `newTab`. */
+ * newGrid = nblocks(new) * 7 * side^3 floats.  Returns 0 / -1 (bad arguments); status[2] if a populated block is missing from `newTab`.
+ * Only the slots that `newMask` selects are written in newBuf: every other row keeps whatever the buffer held (zs_rocm_mpm_slot_particles
+ * zero-fills empty slots, this call does not) -- after a re-partition in place "a slot is defined iff its occupancy bit is set" is the
+ * storage's invariant; every kernel of the path reads masked slots only. */
 ZS_ROCM_EXPORT void zs_rocm_mpm_slot_compute_sparsity(zs_rocm_policy *, const zs_rocm_bht_3 *oldTab, const unsigned *cellMask, size_t nblocksOld,
                                                       int side, int keyIsOrigin, zs_rocm_bht_3 *newTab);
 ZS_ROCM_EXPORT int zs_rocm_mpm_reslot(zs_rocm_policy *, const zs_rocm_bht_3 *oldTab, const zs_rocm_bht_3 *newTab, int side, int K, int C,
@@ -811,7 +814,11 @@ ZS_ROCM_EXPORT zs_rocm_halo_plan *zs_rocm_dist_halo_plan_from_lists(zs_rocm_dist
  * the boundary range, overlapping the interior; grid update of gridB (extf, maxVelSqr) [+ collider]; allreduce(max) of maxVelSqr.  Nothing
  * of the caller runs between the kernels.  dist / plan / commPolicy / maxVelSqr / collider / haloGrid may be NULL (single rank: no exchange).
  * haloGrid: the grid whose shared blocks are exchanged (NULL: gridB).  The reference's building blocks for such a schedule are
- * pol.device(i) / .stream(i) / .listen() (cuda/execution/ExecutionPolicy.cuh:364-399). */
+ * pol.device(i) / .stream(i) / .listen() (cuda/execution/ExecutionPolicy.cuh:364-399).
+ * A non-zero return is FATAL for the object being stepped: when the exchange fails in the overlapped schedule the particle side of the step
+ * has still been committed (both ranges ran, re-home and commit included, so that the slot storage stays consistent) but gridB has neither
+ * been completed nor updated -- the particles are one step ahead of the grids.  Do not retry the step (it would advance the particles
+ * twice) and do not continue from this state. */
 typedef struct zs_rocm_mpm_step {
   const zs_rocm_mpm_params *params;
   zs_rocm_particles particles;

@@ -179,6 +179,13 @@ class Bht:
     def size(self):
         return getattr(lib(), "container_size__" + self.s)(self._h)
 
+    def success(self):
+        """the table's `success` word (Bht.hpp:536-541: cleared by an insert that found its three buckets full / by the proximity guard)"""
+        v = self.view()
+        w = C.c_int(0)
+        C.CDLL("libamdhip64.so").hipMemcpy(C.byref(w), C.c_void_p(v.success), C.c_size_t(4), 2)
+        return bool(w.value)
+
     def tableSize(self):
         return getattr(lib(), "container_capacity__" + self.s)(self._h)
 

@@ -136,6 +136,7 @@ class MpmTransfer:
         L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
                                        int(self.key_is_origin))
         m = int(margin)
+        self.partition_margin = m   # (repartition_slotted() keeps the same travel room unless told otherwise)
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
@@ -265,8 +266,10 @@ class MpmTransfer:
             pool["slots_alt"] = torch.empty(n, dtype=torch.float32, device=self.device)
         self.pol.syncCtx()
 
-    def repartition_slotted(self, margin=0, strict=True):
-        """Re-partition IN PLACE (zs_rocm_mpm_slot_compute_sparsity + enlarge + zs_rocm_mpm_reslot): the new partition is the reference's
+    def repartition_slotted(self, margin=None, strict=True):
+        """(margin: None = the travel room build_partition() was given.  After this call only the slots the occupancy words select are defined in
+        self.buf -- the spare buffer is not cleared: include/zs_rocm.h, zs_rocm_mpm_reslot.)
+        Re-partition IN PLACE (zs_rocm_mpm_slot_compute_sparsity + enlarge + zs_rocm_mpm_reslot): the new partition is the reference's
         ComputeSparsity + EnlargeSparsity over the cells that hold particles (taken from the occupancy words: no particle is read), every
         populated bin moves as whole tile rows to its block's new number, the grid of node velocities (self.grid: what the next fused step
         gathers from) is carried over.  Single rank only (particles do not change owner).  Returns the new number of blocks."""
@@ -274,14 +277,19 @@ class MpmTransfer:
         L = lib()
         self.check_slots(strict=strict)                      # fold the period's status words into slot_record first
         old_table, old_nblocks = self.table, self.nblocks
-        new_table = Bht(3, max(int(old_nblocks * 1.5) + 64, 4096))
+        m = int(getattr(self, "partition_margin", 0) if margin is None else margin)   # default: the travel room build_partition() gave
+        # capacity: the enlarged partition has at most (3 + 2 m)^3 blocks per populated block (a bound, never reached by a bulk of particles);
+        # a cloud that keeps its shape needs about what it had.  Twice the old count + slack, and the table says if that was not enough.
+        new_table = Bht(3, max(2 * int(old_nblocks) + 64, 4096))
         L.zs_rocm_mpm_slot_compute_sparsity(self.pol.handle, old_table.handle, self.cell_mask.data_ptr(), old_nblocks, self.side,
                                             int(self.key_is_origin), new_table.handle)
-        m = int(margin)
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, new_table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
         nb = new_table.size()
+        if not new_table.success() or nb == 0:   # nothing of this object has been replaced yet: the caller can still unslot() and re-partition the long way
+            raise RuntimeError("repartition_slotted: the new partition did not fit its table (%d blocks, capacity for %d)"
+                               % (nb, max(2 * int(old_nblocks) + 64, 4096)))
         bpb = (self.side // 4) ** 3
         nbins = nb * bpb
         nc = self.side ** 3
@@ -292,7 +300,9 @@ class MpmTransfer:
         if alt is None or alt.numel() < need:
             alt = torch.empty(int(need * 1.1), dtype=torch.float32, device=self.device)
         sbuf = alt[:need]
-        old_store = pool.get("slots_cur", self.buf)
+        # the buffer being left is whatever self.buf is a view of NOW (after an unslot() / slot() cycle "slots_cur" would name a buffer that is
+        # no longer in use, and the live one would be dropped instead of parked)
+        old_store = self.buf._base if self.buf._base is not None else self.buf
         flip = self.__dict__.get("_flip", 0) ^ 1
         self._flip = flip
         mask = self._backing("mask%d" % flip, nbins * 64, torch.int32)
@@ -573,8 +583,13 @@ class MpmTransfer:
         a.haloChannels = int(halo_channels)   # 4: only {m, mv} of the ghost blocks travel (all a step reads of them); 7: the rhs channels too
         a.evTransferBegin, a.evTransferEnd = (events[0], events[1]) if events is not None else (None, None)   # raw hipEvent_t (HipEvents)
         a.evBreakdown = breakdown if breakdown is not None else None   # (C.c_void_p * ZS_ROCM_STEP_EVENTS) of raw hipEvent_t (StepBreakdown.next())
+        if getattr(self, "_poisoned", False):
+            raise RuntimeError("this MpmTransfer is poisoned: an earlier zs_rocm_mpm_step_slotted failed after committing the particle side of its step")
         if lib().zs_rocm_mpm_step_slotted(self.pol.handle, C.byref(a)) != 0:
-            raise RuntimeError("zs_rocm_mpm_step_slotted failed")
+            # (include/zs_rocm.h: the storage has been committed, the grids have not -- the particles are one step ahead; neither a retry nor a
+            # continuation is valid)
+            self._poisoned = True
+            raise RuntimeError("zs_rocm_mpm_step_slotted failed: the step is half applied (particles advanced, grids not): this object cannot be stepped again")
         self.grid, self.grid2 = dst, src
 
     def margin_violated(self):
