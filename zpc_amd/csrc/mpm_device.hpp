@@ -2299,6 +2299,61 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
   }
 }
 
+// ---- G2P with lane = PARTICLE (r06).  g2p_binned_kernel maps lane = cell so that a lane keeps its cell's 27 x 3 node velocities in
+// registers -- and then runs the 860-instruction constitutive update at the lane occupancy of the rounds (~70 %: the fullest cell of a
+// bin sets the number of rounds).  Here a workgroup owns a grid block: its particles are ONE contiguous range of the compact order
+// (bins of a block are consecutive), the waves take them 64 at a time (every lane busy, loads and stores fully coalesced), and a
+// particle gathers from the block's velocity arena in LDS at its own cell (sum-factorised, g2p_gather_lds).  A particle that moved to
+// another cell of the block since the last re-bin needs nothing special; one outside the block's cells takes the exact path.
+template <int SIDE> struct ArenaOfBlock { using type = ArenaBlk; };
+template <> struct ArenaOfBlock<4> { using type = ArenaLds; };
+template <int SIDE, int SMODEL, int LW>
+static __global__ __launch_bounds__(SIDE == 8 ? 256 : 64) void g2p_packed_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid,
+                                                                              const int *binStart, const int *nbr, int *stale, int *staleCount) {
+  using AL = typename ArenaOfBlock<SIDE>::type;
+  constexpr int NC = SIDE * SIDE * SIDE, W = SIDE + 2, NT = SIDE == 8 ? 256 : 64, BPB = bins_per_block<SIDE>();
+  __shared__ float arena[3 * AL::CH];
+  const int blk = (int)blockIdx.x;
+  const int start = binStart[blk * BPB], end = binStart[blk * BPB + BPB];
+  if (start == end) return;
+  int borg[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) borg[d] = t.activeKeys[3 * (size_t)blk + d] * (SIDE / mp.kscale);
+  for (int node = threadIdx.x; node < W * W * W; node += NT) {
+    const int x = node / (W * W), y = (node / W) % W, z = node % W;
+    const int slot = ((x >= SIDE) << 2) | ((y >= SIDE) << 1) | (z >= SIDE);
+    const int cell = ((x & (SIDE - 1)) * SIDE + (y & (SIDE - 1))) * SIDE + (z & (SIDE - 1));
+    const int bn = nbr[(size_t)blk * 8 + slot];
+    float *a = arena + AL::at(x, y, z);
+    const float *g = grid + ((size_t)(bn < 0 ? 0 : bn) * 7 + 1) * NC + cell;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) a[ch * AL::CH] = bn >= 0 ? g[ch * NC] : 0.f;
+  }
+  __syncthreads();
+  const float D_inv = mp.D_inv;
+  RecB<model_is_fluid(SMODEL) ? MPM_FLUID_NO_STRESS : ZS_MPM_FIXED_COROTATED, LW> cur, nxt;
+  int i0 = start + (int)threadIdx.x;
+  if (i0 < end) cur.load(ps, (size_t)i0);
+  while (i0 - (int)(threadIdx.x & 63) < end) {  // (wave-uniform: the chunk holds at least one particle)
+    const int i1 = i0 + NT;
+    if (i1 < end) nxt.load(ps, (size_t)i1);   // the wave's next chunk, in flight during this one
+    if (i0 < end) {
+      Arena ar;
+      make_arena(mp.dx, mp.dxi, cur.pos, ar);
+      const int ocx = ar.corner[0] - borg[0], ocy = ar.corner[1] - borg[1], ocz = ar.corner[2] - borg[2];
+      if ((unsigned)ocx < (unsigned)SIDE && (unsigned)ocy < (unsigned)SIDE && (unsigned)ocz < (unsigned)SIDE) {
+        float vel[3], C[9];
+        g2p_gather_lds<AL>(mp, ar, arena + AL::at(ocx, ocy, ocz), D_inv, vel, C);
+        g2p_finish_loaded<SIDE, SMODEL, LW>(mp, ps, (size_t)i0, cur.pos, cur.F, vel, C);
+      } else {
+        stale[atomicAdd(staleCount, 1)] = i0;  // the base node lies outside the block's cells: exact path (hash queries)
+      }
+    }
+    cur = nxt;
+    i0 = i1;
+  }
+}
+
 template <int SIDE, int SMODEL>
 static __global__ __launch_bounds__(256) void g2p_stale_kernel(MpmDev mp, ParticlesDev ps, BhtDev t, const float *grid, const int *stale,
                                                         const int *staleCount) {
