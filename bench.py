@@ -916,7 +916,7 @@ def main():
                        # wall clock until the last step was enqueued: includes the closed-loop poll, which waits for the status copy of
                        # two steps earlier (so this follows the device time; the host cost proper is host_step_call_us_per_step)
                        "host_enqueue_us_per_step": host_enqueue_s / a.steps * 1e6},
-            "roofline": {"bound": "hbm", "kernel": ("p2g_global_kernel" if a.unbinned else (("p2g_tile_kernel" if a.lane_width == 64 else "p2g_wide_kernel") if mt.cache_stress else "p2g_binned_kernel")),
+            "roofline": {"bound": "hbm", "kernel": ("p2g_global_kernel" if a.unbinned else (("p2g_tile_kernel" if a.lane_width == 64 else "p2g_wide_kernel") if mt.cache_stress else ("update_stress_kernel + p2g_tile_kernel" if a.lane_width == 64 else "p2g_binned_kernel"))),
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_particle": p2g_bytes, "particles_per_launch": n_local, "launch_ms": p2g_ms,
                          "constitutive_update": "tail of previous G2P (particles.stress)" if mt.cache_stress else "inside P2G",

@@ -1712,7 +1712,9 @@ template <bool MERGED> constexpr int p2gt_requests() { return MERGED ? 4 + (STRE
 // only the neighbouring bin needs is not fetched here as well (the whole-tile form read 4 % more than the records: profiles/r06_pmc_p2g.md).
 template <bool MERGED>
 __device__ __forceinline__ void p2gt_issue(const ParticlesDev &ps, int tile, int lo, int hi, int lane, float *buf) {
-  const size_t tb = (size_t)tile * (size_t)ps.pos.chns * 64;  // element offset of the tile (wave-uniform)
+  // element offset of the tile (wave-uniform); the stress attribute may live in a TileVector of its own (another channel count: the
+  // reference-order P2G keeps it in a temporary, see zs_rocm_mpm_p2g)
+  const size_t tb = (size_t)tile * (size_t)ps.pos.chns * 64, tbs = (size_t)tile * (size_t)ps.stress.chns * 64;
   const int pl = (lane & 15) * 4;
   if (pl + 3 >= lo && pl < hi) {
     if constexpr (MERGED) {
@@ -1723,7 +1725,7 @@ __device__ __forceinline__ void p2gt_issue(const ParticlesDev &ps, int tile, int
       p2gt_issue_attr<4, 3>(ps.vel, tb, lane, buf);
       p2gt_issue_attr<7, 9>(ps.C, tb, lane, buf);
     }
-    p2gt_issue_attr<16, STRESS_N>(ps.stress, tb, lane, buf);
+    p2gt_issue_attr<16, STRESS_N>(ps.stress, tbs, lane, buf);
   }
 }
 
