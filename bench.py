@@ -859,6 +859,8 @@ def main():
         checksum_trim = [float(x) for x in cs_trim.cpu()]
         trim_info = [float(x) for x in tinfo.cpu()]
     p2g_ms = float(np.mean([x.elapsed_time(y) for x, y in p2g_ev])) if p2g_ev else 0.0
+    if os.environ.get("ZS_BENCH_PER_STEP") and rank == 0 and p2g_ev:
+        print("per-step p2g ms:", " ".join("%.4f" % x.elapsed_time(y) for x, y in p2g_ev), "| g2p ms:", " ".join("%.4f" % x.elapsed_time(y) for x, y in g2p_ev), file=sys.stderr)
     g2p_ms = float(np.mean([x.elapsed_time(y) for x, y in g2p_ev])) if g2p_ev else 0.0
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in fused_ev])) if fused_ev else 0.0
     if one_call and hip_events.pairs:
@@ -1051,11 +1053,12 @@ def main():
                                     "at_rest_compact": {"ms_per_step": j2["ms_per_step"], "roofline_frac": j2["roofline"]["frac"],
                                                         "note": "particles at rest, dense binned storage: the r01 headline workload"}}
                 # ... and the transfers as separate kernels: the stand-alone P2G is the kernel north_star sets its 0.60 target on
-                j3 = sub(["--compact", "--unfused"])
+                # (8 untimed steps first: the P2G launch needs ~5 steps to settle -- 1.48, 1.46, 1.44, 1.43, then 1.42 ms on the same box, ZS_BENCH_PER_STEP=1)
+                j3 = sub(["--compact", "--unfused", "--warmup", "8", "--steps", "12"])
                 r3 = j3["roofline"]
                 out["p2g_standalone"] = {"kernel": r3["kernel"], "ms": r3["launch_ms"], "bytes_per_particle": r3["bytes_per_particle"],
                                          "achieved_GBps": r3["achieved"], "frac": r3["frac"], "particles": r3["particles_per_launch"],
-                                         "target_frac": 0.60,
+                                         "target_frac": 0.60, "steps": j3["steps"], "warmup": j3["warmup"],
                                          "note": "HIP-event time of the P2G launch alone (grid reset and update outside), column at rest, "
                                                  "compact binned storage, cached stress (107 B/particle: SURVEY 8(d))"}
                 out["secondary"]["unfused_at_rest"] = {"ms_per_step": j3["ms_per_step"], "p2g_ms": r3["launch_ms"], "p2g_frac": r3["frac"],
@@ -1063,7 +1066,7 @@ def main():
                                                        "g2p_frac": r3["g2p"]["achieved"] / HBM_PEAK_GBS}
                 # what the 0.5x of the stand-alone P2G does and does not contain: (a) the reference-order P2G, constitutive update inside
                 # (--no-cache-stress); (b) the unfused step P2G + G2P as a whole, which is where the moved SVD is paid
-                j4 = sub(["--compact", "--unfused", "--no-cache-stress"])
+                j4 = sub(["--compact", "--unfused", "--no-cache-stress", "--warmup", "8", "--steps", "12"])
                 r4 = j4["roofline"]
                 step_bytes = (r3["bytes_per_particle"] + r3["g2p"]["bytes_per_particle"]) * r3["particles_per_launch"]
                 out["p2g_standalone"].update({

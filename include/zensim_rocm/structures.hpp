@@ -154,75 +154,65 @@ protected:
   std::map<std::string, Attribute> _attributes;
 };
 
-template <execspace_e space, class ParticlesT, class = void> struct ParticlesView {  // :236-285
+// ParticlesView (geometry/Structurefree.hpp:226-330): the accessor names below are the interface transfer functors are written against
+// (mass / pos / vel / Dinv / J / F / C / B / logJp / size); the storage behind them is this backend's own -- one table of attribute base
+// pointers filled from the container by name, shared by the mutable and the const view.
+namespace detail {
+  enum particle_attr : int { pa_m, pa_x, pa_v, pa_dinv, pa_j, pa_f, pa_c, pa_logjp, pa_count };
+  template <class Byte> struct particle_attr_table {
+    Byte *slot[pa_count] = {};
+    std::size_t count = 0;
+    particle_attr_table() = default;
+    template <class ParticlesT> explicit particle_attr_table(ParticlesT &particles) : count(particles.size()) {
+      static constexpr const char *names[pa_count] = {"m", "x", "v", "Dinv", "J", "F", "C", "logJp"};
+      for (int k = 0; k < pa_count; ++k) slot[k] = (Byte *)particles.getAttrAddress(names[k]);
+    }
+    template <class E> ZS_FUNCTION E &at(int k, std::size_t i) const { return reinterpret_cast<E *>(slot[k])[i]; }
+  };
+}  // namespace detail
+template <execspace_e space, class ParticlesT, class = void> struct ParticlesView {
   using T = typename ParticlesT::T;
   using TV = typename ParticlesT::TV;
   using TM = typename ParticlesT::TM;
   static constexpr int dim = ParticlesT::dim;
   using size_type = typename ParticlesT::size_type;
   ParticlesView() = default;
-  explicit ParticlesView(ParticlesT &particles)
-      : _M{(T *)particles.getAttrAddress("m")}, _X{(TV *)particles.getAttrAddress("x")}, _V{(TV *)particles.getAttrAddress("v")},
-        _Dinv{(TV *)particles.getAttrAddress("Dinv")}, _J{(T *)particles.getAttrAddress("J")}, _F{(TM *)particles.getAttrAddress("F")},
-        _C{(TM *)particles.getAttrAddress("C")}, _logJp{(T *)particles.getAttrAddress("logJp")}, _particleCount{particles.size()} {}
-  ZS_FUNCTION T &mass(size_type i) { return _M[i]; }
-  ZS_FUNCTION T mass(size_type i) const { return _M[i]; }
-  ZS_FUNCTION TV &pos(size_type i) { return _X[i]; }
-  ZS_FUNCTION const TV &pos(size_type i) const { return _X[i]; }
-  ZS_FUNCTION TV &vel(size_type i) { return _V[i]; }
-  ZS_FUNCTION const TV &vel(size_type i) const { return _V[i]; }
-  ZS_FUNCTION TV &Dinv(size_type i) { return _Dinv[i]; }
-  ZS_FUNCTION const TV &Dinv(size_type i) const { return _Dinv[i]; }
-  ZS_FUNCTION T &J(size_type i) { return _J[i]; }                // deformation for water
-  ZS_FUNCTION const T &J(size_type i) const { return _J[i]; }
-  ZS_FUNCTION TM &F(size_type i) { return _F[i]; }               // deformation for solid
-  ZS_FUNCTION const TM &F(size_type i) const { return _F[i]; }
-  ZS_FUNCTION TM &C(size_type i) { return _C[i]; }               // for apic transfer only
-  ZS_FUNCTION const TM &C(size_type i) const { return _C[i]; }
-  ZS_FUNCTION TM &B(size_type i) { return _C[i]; }
-  ZS_FUNCTION const TM &B(size_type i) const { return _C[i]; }
-  ZS_FUNCTION T &logJp(size_type i) { return _logJp[i]; }        // plasticity
-  ZS_FUNCTION const T &logJp(size_type i) const { return _logJp[i]; }
-  ZS_FUNCTION size_type size() const noexcept { return _particleCount; }
+  explicit ParticlesView(ParticlesT &particles) : _tab(particles) {}
+  ZS_FUNCTION T &mass(size_type i) const { return _tab.template at<T>(detail::pa_m, i); }
+  ZS_FUNCTION TV &pos(size_type i) const { return _tab.template at<TV>(detail::pa_x, i); }
+  ZS_FUNCTION TV &vel(size_type i) const { return _tab.template at<TV>(detail::pa_v, i); }
+  ZS_FUNCTION TV &Dinv(size_type i) const { return _tab.template at<TV>(detail::pa_dinv, i); }
+  ZS_FUNCTION T &J(size_type i) const { return _tab.template at<T>(detail::pa_j, i); }          // volume ratio (EquationOfState fluid)
+  ZS_FUNCTION TM &F(size_type i) const { return _tab.template at<TM>(detail::pa_f, i); }        // deformation gradient (solids)
+  ZS_FUNCTION TM &C(size_type i) const { return _tab.template at<TM>(detail::pa_c, i); }        // affine velocity field of the APIC transfer
+  ZS_FUNCTION TM &B(size_type i) const { return C(i); }                                         // (the reference aliases B to C)
+  ZS_FUNCTION T &logJp(size_type i) const { return _tab.template at<T>(detail::pa_logjp, i); }  // plastic volume (DruckerPrager / NACC)
+  ZS_FUNCTION size_type size() const noexcept { return (size_type)_tab.count; }
 
-protected:
-  T *_M;
-  TV *_X, *_V, *_Dinv;
-  T *_J;
-  TM *_F, *_C;
-  T *_logJp;
-  size_type _particleCount;
+private:
+  detail::particle_attr_table<char> _tab;
 };
-template <execspace_e space, class ParticlesT> struct ParticlesView<space, const ParticlesT> {  // :287-330
+template <execspace_e space, class ParticlesT> struct ParticlesView<space, const ParticlesT> {
   using T = typename ParticlesT::T;
   using TV = typename ParticlesT::TV;
   using TM = typename ParticlesT::TM;
   static constexpr int dim = ParticlesT::dim;
   using size_type = typename ParticlesT::size_type;
   ParticlesView() = default;
-  explicit ParticlesView(const ParticlesT &particles)
-      : _M{(const T *)particles.getAttrAddress("m")}, _X{(const TV *)particles.getAttrAddress("x")}, _V{(const TV *)particles.getAttrAddress("v")},
-        _Dinv{(const TV *)particles.getAttrAddress("Dinv")}, _J{(const T *)particles.getAttrAddress("J")},
-        _F{(const TM *)particles.getAttrAddress("F")}, _C{(const TM *)particles.getAttrAddress("C")},
-        _logJp{(const T *)particles.getAttrAddress("logJp")}, _particleCount{particles.size()} {}
-  ZS_FUNCTION T mass(size_type i) const { return _M[i]; }
-  ZS_FUNCTION const TV &pos(size_type i) const { return _X[i]; }
-  ZS_FUNCTION const TV &vel(size_type i) const { return _V[i]; }
-  ZS_FUNCTION const TV &Dinv(size_type i) const { return _Dinv[i]; }
-  ZS_FUNCTION const T &J(size_type i) const { return _J[i]; }
-  ZS_FUNCTION const TM &F(size_type i) const { return _F[i]; }
-  ZS_FUNCTION const TM &C(size_type i) const { return _C[i]; }
-  ZS_FUNCTION const TM &B(size_type i) const { return _C[i]; }
-  ZS_FUNCTION const T &logJp(size_type i) const { return _logJp[i]; }
-  ZS_FUNCTION size_type size() const noexcept { return _particleCount; }
+  explicit ParticlesView(const ParticlesT &particles) : _tab(particles) {}
+  ZS_FUNCTION T mass(size_type i) const { return _tab.template at<const T>(detail::pa_m, i); }
+  ZS_FUNCTION const TV &pos(size_type i) const { return _tab.template at<const TV>(detail::pa_x, i); }
+  ZS_FUNCTION const TV &vel(size_type i) const { return _tab.template at<const TV>(detail::pa_v, i); }
+  ZS_FUNCTION const TV &Dinv(size_type i) const { return _tab.template at<const TV>(detail::pa_dinv, i); }
+  ZS_FUNCTION const T &J(size_type i) const { return _tab.template at<const T>(detail::pa_j, i); }
+  ZS_FUNCTION const TM &F(size_type i) const { return _tab.template at<const TM>(detail::pa_f, i); }
+  ZS_FUNCTION const TM &C(size_type i) const { return _tab.template at<const TM>(detail::pa_c, i); }
+  ZS_FUNCTION const TM &B(size_type i) const { return C(i); }
+  ZS_FUNCTION const T &logJp(size_type i) const { return _tab.template at<const T>(detail::pa_logjp, i); }
+  ZS_FUNCTION size_type size() const noexcept { return (size_type)_tab.count; }
 
-protected:
-  const T *_M;
-  const TV *_X, *_V, *_Dinv;
-  const T *_J;
-  const TM *_F, *_C;
-  const T *_logJp;
-  size_type _particleCount;
+private:
+  detail::particle_attr_table<const char> _tab;
 };
 template <execspace_e space, class V, int d> ParticlesView<space, Particles<V, d>> proxy(Particles<V, d> &p) { return ParticlesView<space, Particles<V, d>>{p}; }
 template <execspace_e space, class V, int d> ParticlesView<space, const Particles<V, d>> proxy(const Particles<V, d> &p) {

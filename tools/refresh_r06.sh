@@ -41,6 +41,8 @@ def collect(name, keys):
             k = next((k for k in keys if k in r["Kernel_Name"]), None)
             if k: acc[k][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])   # (rows of one dispatch are summed)
     acc = {k: {c: [per[d] for d in sorted(per)] for c, per in cs.items()} for k, cs in acc.items()}
+    if not acc:   # (ONLY=p2g on a fresh box: no passes of this group here -- leave earlier summaries alone)
+        return {}
     summ, lines = {}, []
     for k in acc:
         m = {c: sum(v[-3:]) / len(v[-3:]) for c, v in acc[k].items()}   # the last launches (steady state)
