@@ -324,3 +324,44 @@ def test_block_kernel_of_the_fused_step_keeps_its_chunk_loop_free_of_scratch(tmp
     syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-sW", co], stdout=subprocess.PIPE, check=True).stdout.decode()
     sizes = [int(l.split()[2]) for l in syms.splitlines() if "g2p2g_slotblk_kernelILi1ELb0" in l and " FUNC " in l]
     assert sizes and max(sizes) < 64 * 1024, sizes
+
+
+def test_tile_kernel_of_the_standalone_p2g_keeps_its_accumulators_in_registers_and_its_requests_in_assembly(tmp_path):
+    """p2g_tile_kernel (the kernel north_star's 0.60 is measured on) holds 27 x 7 node sums per lane at two waves per SIMD: one spilled
+    register puts scratch traffic into the record stream.  And its tile requests must reach the object as the inline-assembly
+    `global_load_lds_dwordx4`: through the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of every round's first LDS read and the
+    ring never holds a tile in flight (profiles/r06_p2g.md: 1.65 against 1.50 ms) -- so inside the record loop no `s_waitcnt vmcnt(0)` may sit
+    directly in front of a `ds_read`."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "zpc_amd", "lib", "obj", "mpm_p2g.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("object file or llvm tools not present")
+    fat, co = str(tmp_path / "p.fat"), str(tmp_path / "p.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                           "--output=" + co, "--unbundle"])
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    seen = 0
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name or "p2g_tile_kernel" not in name.group(1):
+            continue
+        seen += 1
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name.group(1)
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name.group(1)
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 256, name.group(1)
+    assert seen >= 4  # 8^3 blocks (two bins per workgroup) and 4^3 blocks, merged and per-attribute requests
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], stdout=subprocess.PIPE, check=True).stdout.decode()
+    m = re.search(r"<_ZN3zsrL15p2g_tile_kernelILi8ELi3ELi2ELb1E[^>]*>:\n(.*?)s_endpgm", dis, re.S)
+    assert m, "p2g_tile_kernel<8, 3, 2, true> not found"
+    lines = [l.split("//")[0].strip() for l in m.group(1).splitlines() if l.strip()]
+    req = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+    assert len(req) == 12, len(req)  # 4 + 2 requests per tile, at the head of the wave and inside the record loop
+    loop = lines[req[6]:]
+    first_flush = next(i for i, l in enumerate(loop) if l.startswith("ds_write_b128"))   # the arena clear: the record loop ends before it
+    for i, l in enumerate(loop[:first_flush]):
+        if l.startswith("ds_read"):
+            prev = next(x for x in reversed(loop[:i]) if not x.startswith("s_nop"))
+            assert not prev.startswith("s_waitcnt vmcnt(0)"), "a vmcnt(0) sits in front of an LDS read of the record loop"
+
