@@ -99,6 +99,9 @@ def parse():
                     help="every particle's mass carries its number in the global box (tests: per-particle comparison of runs on different rank counts)")
     ap.add_argument("--dump-state", type=str, default="",
                     help="after the run every rank writes its particles (m, x, v, C, F, logJp) to <prefix>.rank<r>.npz")
+    ap.add_argument("--block-order", type=str, default="holders_lex", choices=["insertion", "holders_lex", "lex", "morton"],
+                    help="numbering of the partition's blocks (MpmTransfer.build_partition): holders_lex = blocks with particles in "
+                         "lexicographic key order, apron blocks behind them; insertion = the hash table's race (the reference's)")
     ap.add_argument("--compact", action="store_true",
                     help="compact round-robin particle order + re-bin controller (round 1's storage) instead of the slotted storage "
                          "the fused step keeps valid by itself (zpc_amd/csrc/mpm_slotted.hip)")
@@ -400,7 +403,7 @@ def main():
         numbered first; bins; ghost-block lists"""
         nonlocal n_boundary, proxy_grid
         from zpc_amd.dist import gather_block_keys, near_shared_mask
-        nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0)
+        nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0, order=a.block_order)
         all_keys = None
         if world > 1 and (overlap or comm is None):
             all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
@@ -899,7 +902,7 @@ def main():
             "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": ((halo.bytes_per_exchange * a.halo_channels // 7 if comm is not None else halo.bytes_per_exchange) if halo and halo.peers else 0),
-                       "halo_channels": a.halo_channels,
+                       "halo_channels": a.halo_channels, "block_order": getattr(mt, "block_order", None),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": K, "repartitions": remaps[0], "migrated_rank0": migrated,
@@ -1040,7 +1043,7 @@ def main():
             try:
                 cmd = [sys.executable, os.path.abspath(__file__), "--drift", "0,0,0", "--no-at-rest", "--no-cpu-baseline", "--steps", "10",
                        "--warmup", "3", "--grid", str(a.grid), "--cells", a.cells, "--model", a.model, "--side", str(a.side),
-                       "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin)]
+                       "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin), "--block-order", a.block_order]
 
                 def sub(extra):
                     r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)

@@ -1205,3 +1205,41 @@ def test_slotted_closed_loop_repartition_vs_oracle(pol, oracle, inplace):
     assert np.abs(d["x"] - po[o]).max() <= 2e-5
     assert np.abs(d["v"] - vo[o]).max() <= 1e-3 * np.abs(vo).max()
     assert np.abs(d["F"] - Fo[o]).max() <= 5e-4
+
+
+@pytest.mark.parametrize("side", [4, 8])
+def test_block_numbering_orders_of_the_partition(pol, oracle, side):
+    """build_partition(order=...): every order numbers the same set of blocks; holders_lex (the default) puts the blocks that hold particles
+    first in lexicographic key order with the apron blocks behind them; lex sorts every block; the P2G grid is the same by key
+    (zs::bht leaves the numbering to the race of the inserting threads, Bht.hpp insert: any numbering is a valid one)."""
+    from zpc_amd.mpm import MpmTransfer
+    dx, dt = 1.0 / 64, 1e-4
+    mass, pos, vel, Cm, F = make_cloud(11, dx, 2, seed=77 + side)
+    n = pos.shape[0]
+    # the block of each particle's stencil base (ComputeSparsity, SparsityOp.hpp:75-84: offset -2, displacement 0.5), in float32 like the kernel
+    base = np.floor(pos.astype(np.float32) * np.float32(1.0 / dx) + np.float32(0.5)).astype(np.int64) - 2
+    holders = {tuple(int(c) for c in k) for k in base // side}
+    grids, keysets = {}, {}
+    for order in ("insertion", None, "holders_lex", "lex", "morton"):
+        mt = MpmTransfer(pol, n, dx, dt, model=0, side=side, volume=dx ** 3 / 8, lane_width=64)
+        mt.upload(mass, pos, vel, Cm, F)
+        nb = mt.build_partition(n, order=order)
+        keys = [tuple(int(c) for c in k) for k in mt.active_keys()]
+        assert len(set(keys)) == nb
+        keysets[order] = set(keys)
+        if order in (None, "holders_lex"):
+            assert mt.block_order == "holders_lex"
+            h = len(holders)
+            assert set(keys[:h]) == holders and keys[:h] == sorted(keys[:h])
+        if order == "lex":
+            assert keys == sorted(keys)
+        mt.rebin()
+        mt.clear_grid()
+        mt.p2g()
+        pol.syncCtx()
+        grids[order] = mt.grid_by_key()
+    assert all(ks == keysets["insertion"] for ks in keysets.values())
+    for order in (None, "holders_lex", "lex", "morton"):
+        _compare_grids(grids[order], grids["insertion"], 1e-5)
+    with pytest.raises(ValueError):
+        mt.build_partition(n, order="hilbert")

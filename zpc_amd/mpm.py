@@ -128,26 +128,67 @@ class MpmTransfer:
         return out
 
     # ------------------------------------------------------------------ partition (SparsityCompute.tpp:5-24)
-    def build_partition(self, expected_blocks, margin=0):
+    def build_partition(self, expected_blocks, margin=0, order=None):
         """ComputeSparsity + EnlargeSparsity{0, 2} (the reference's partition); margin = m enlarges by m more blocks on every side
-        (lo = -m, hi = 2 + m): room for the particles to travel m blocks before the partition has to be rebuilt"""
+        (lo = -m, hi = 2 + m): room for the particles to travel m blocks before the partition has to be rebuilt.
+
+        order = how the blocks are numbered (the reference leaves it to the race of the inserting threads):
+          "insertion"         the table's own dense indices (the race)
+          None / "holders_lex" the blocks that hold particles in lexicographic key order, the apron blocks behind them (in the order
+                              of their race: they hold no particle, the per-block kernels leave them at once)
+          "lex"               every block in lexicographic key order
+          "morton"            every block along the Z-order curve
+        The numbering changes no result, only which workgroups run side by side (profiles/r06_p2g.md, section 4)."""
+        import os
+        order = os.environ.get("ZS_ROCM_CANONICAL_PARTITION") or order or "holders_lex"   # (the variable: tools/r06_order.sh's A/B)
+        if order not in ("insertion", "holders_lex", "lex", "morton"):
+            raise ValueError(f"build_partition: unknown block order {order!r}")
         self.table = Bht(3, int(expected_blocks))
         L = lib()
         L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
                                        int(self.key_is_origin))
+        if order == "holders_lex":  # (the apron blocks are inserted after this and keep the indices behind the holders)
+            self.pol.syncCtx()
+            self.table.canonicalize(self.pol)
+        xp = os.environ.get("ZS_ROCM_HOLDER_ORDER")   # measurement only (tools/r06_order2.sh): "120" = axis 1 most significant, then 2, then 0;
+        if xp:                                        # "120:2,4,4" = the same inside and across tiles of 2 x 4 x 4 blocks; "m" = Z-order curve
+            import ctypes
+            self.pol.syncCtx()
+            n0 = self.table.size()
+            v = self.table.view()
+            k = torch.empty(n0 * 3, dtype=torch.int32, device=self.device)
+            ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.activeKeys), ctypes.c_size_t(n0 * 12), 3)
+            k = k.view(n0, 3).to(torch.int64) // self.kstride
+            k = k - k.min(dim=0).values
+            if xp == "m":
+                code = torch.zeros(n0, dtype=torch.int64, device=self.device)
+                for bit in range(16):
+                    for d in range(3):
+                        code |= ((k[:, d] >> bit) & 1) << (3 * bit + (2 - d))
+            else:
+                ax = [int(c) for c in xp[:3]]
+                t = [int(c) for c in xp.split(":")[1].split(",")] if ":" in xp else [1, 1, 1]
+                code = torch.zeros(n0, dtype=torch.int64, device=self.device)
+                for d in ax:
+                    code = code * 4096 + k[:, d] // t[d]
+                for d in ax:
+                    code = code * t[d] + k[:, d] % t[d]
+            perm = torch.argsort(code).to(torch.int32).contiguous()
+            torch.cuda.synchronize()
+            self.table.reorder(self.pol, perm.data_ptr(), scatter=False)
+            self.pol.syncCtx()
         m = int(margin)
         self.partition_margin = m   # (repartition_slotted() keeps the same travel room unless told otherwise)
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
-        import os
-        order = os.environ.get("ZS_ROCM_CANONICAL_PARTITION", "")
-        if order == "morton":  # block numbers along the Z-order curve of the block keys
+        if order == "morton":
             self.table.order_morton(self.pol)
             self.pol.syncCtx()
-        elif order:  # block numbers = lexicographic rank of the keys (reproducible across runs)
+        elif order == "lex":
             self.table.canonicalize(self.pol)
             self.pol.syncCtx()
+        self.block_order = order
         self.nblocks = self.table.size()
         self.slotted = False
         nc = self.side ** 3
@@ -283,6 +324,9 @@ class MpmTransfer:
         new_table = Bht(3, max(2 * int(old_nblocks) + 64, 4096))
         L.zs_rocm_mpm_slot_compute_sparsity(self.pol.handle, old_table.handle, self.cell_mask.data_ptr(), old_nblocks, self.side,
                                             int(self.key_is_origin), new_table.handle)
+        if getattr(self, "block_order", "insertion") == "holders_lex":   # the numbering build_partition() was asked for
+            self.pol.syncCtx()
+            new_table.canonicalize(self.pol)
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, new_table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
