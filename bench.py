@@ -95,6 +95,11 @@ def parse():
     ap.add_argument("--halo-channels", type=int, default=4, choices=[4, 7],
                     help="grid channels of a ghost block that travel between ranks: 4 = {m, mv}, all a step reads of a ghost block (grid update: "
                          "v = mv / m + g dt; G2P gathers v -- GridOp.hpp:90-104); 7 = the rhs channels too")
+    ap.add_argument("--range-schedule", type=str, default="auto", choices=["auto", "in-turn", "side-by-side", "one-launch"],
+                    help="multi-GPU step (zs_rocm_mpm_step.rangeSchedule): in-turn = boundary blocks' launch, then the interior launch, on the compute "
+                         "stream; side-by-side = the boundary launch on the exchange stream next to the interior launch; one-launch = one launch "
+                         "over all blocks whose boundary workgroups count themselves off, a gate kernel on the exchange stream waits for the "
+                         "count (8^3 blocks).  auto: one-launch for 8^3 blocks, in-turn for 4^3")
     ap.add_argument("--tag-mass", action="store_true",
                     help="every particle's mass carries its number in the global box (tests: per-particle comparison of runs on different rank counts)")
     ap.add_argument("--dump-state", type=str, default="",
@@ -342,6 +347,7 @@ def main():
     comm_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
     pol_comm = zpc_amd.rocm_exec().sync(False).external_stream(comm_stream.cuda_stream) if overlap else pol
     one_call = a.slotted and not a.py_step and (world == 1 or comm is not None)   # the step behind zs_rocm_mpm_step_slotted
+    range_schedule = {"auto": 2 if a.side == 8 else 0, "in-turn": 0, "side-by-side": 1, "one-launch": 2}[a.range_schedule]
     proxy_grid = None
     ev_boundary, ev_comm = torch.cuda.Event(), torch.cuda.Event()
     n_boundary = 0
@@ -523,7 +529,8 @@ def main():
                             n_boundary=n_boundary if (overlap and halo is not None) else 0, comm=comm, plan=halo if comm is not None else None,
                             comm_pol=pol_comm if overlap else None, collider=floor, halo_grid=proxy_grid,
                             events=hip_events.pair() if timed else None,
-                            breakdown=breakdown.next() if (timed and breakdown is not None) else None, halo_channels=a.halo_channels)
+                            breakdown=breakdown.next() if (timed and breakdown is not None) else None, halo_channels=a.halo_channels,
+                            range_schedule=range_schedule)
             return
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
@@ -903,6 +910,7 @@ def main():
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": ((halo.bytes_per_exchange * a.halo_channels // 7 if comm is not None else halo.bytes_per_exchange) if halo and halo.peers else 0),
                        "halo_channels": a.halo_channels, "block_order": getattr(mt, "block_order", None),
+                       "step_schedule": (("ranges in turn", "ranges side by side", "one launch + gate")[range_schedule] if (one_call and overlap) else "one range"),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
                        "rebin_ms_once": rebin_ms, "migrate_every": K, "repartitions": remaps[0], "migrated_rank0": migrated,

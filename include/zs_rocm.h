@@ -848,8 +848,23 @@ typedef struct zs_rocm_mpm_step {
                                             ever reads of a ghost block -- the grid update forms v = mv / m + extf dt and G2P gathers v, exactly as
                                             ComputeGridBlockVelocity / G2PTransfer of the reference do (simulation/grid/GridOp.hpp:90-104); the rhs
                                             channels 4..6 of a shared block then keep this rank's partial sums */
+  int rangeSchedule;                     /* overlapped schedule only (commPolicy set, 0 < nBoundary < nblocks): how the boundary blocks' sums get to
+                                            the exchange stream early.
+                                            ZS_ROCM_RANGES_IN_TURN (0): two launches on the policy's stream, boundary range then interior range.
+                                            ZS_ROCM_RANGES_SIDE_BY_SIDE (1): the boundary range on commPolicy's stream (give it the higher
+                                            priority) in front of the exchange, the interior range on the policy's stream at the same time; re-home /
+                                            commit wait for both.  The interior's workgroups fill the CUs the boundary range's last workgroups
+                                            leave idle, but the two launches share the CUs: the boundary range ends later than it would alone.
+                                            ZS_ROCM_RANGES_ONE_LAUNCH (2; 8^3 blocks): ONE launch over all blocks -- workgroups are dispatched in
+                                            block order, the boundary blocks come first -- whose boundary workgroups count themselves off on a
+                                            device word; a one-wave gate kernel on commPolicy's stream waits for the count and the exchange runs
+                                            behind it.  No launch boundary inside the step: no tail, no sharing.
+                                            evBreakdown[1] (boundary done) is recorded on commPolicy's stream for 1 and 2; [0,1] and [0,2] overlap. */
 } zs_rocm_mpm_step;
 #define ZS_ROCM_STEP_EVENTS 8
+#define ZS_ROCM_RANGES_IN_TURN 0
+#define ZS_ROCM_RANGES_SIDE_BY_SIDE 1
+#define ZS_ROCM_RANGES_ONE_LAUNCH 2
 ZS_ROCM_EXPORT int zs_rocm_mpm_step_slotted(zs_rocm_policy *, const zs_rocm_mpm_step *);
 
 #ifdef __cplusplus

@@ -179,6 +179,28 @@ def test_slotted_default_n_ranks_reproduce_single_rank(n, extra):
     assert out["hip_error"] == 0 and ref["hip_error"] == 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--drift", "3,-4,2", "--outbox-cap", "512"]])
+def test_range_schedules_of_the_step_call_agree(extra):
+    """zs_rocm_mpm_step.rangeSchedule: the boundary blocks' range and the interior range in turn | side by side on two streams | ONE launch
+    whose boundary workgroups count themselves off for a gate kernel on the exchange stream (the default for 8^3 blocks).  On one GPU
+    through bench.py's rank proxy (the 8-rank schedule with RCCL at world size 1, exchange into a scratch grid): the same particle state
+    after 12 steps as the plain single-rank step, movers crossing between the two ranges included."""
+    args = ["--cells", "24,48,24", "--steps", "12", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--checksum", "--no-at-rest"] + extra
+    ref = _run(1, args)
+    assert ref["config"]["movers_per_step_rank0"] > 0 and ref["config"]["step_schedule"] == "one range"
+    for sched, name in (("in-turn", "ranges in turn"), ("side-by-side", "ranges side by side"), ("one-launch", "one launch + gate"), ("auto", "one launch + gate")):
+        out = _run(1, args + ["--rank-proxy", "8", "--range-schedule", sched])
+        assert out["hip_error"] == 0 and out["config"]["halo_overlap"] and 0 < out["config"]["boundary_blocks_rank0"] < out["config"]["grid_blocks_rank0"]
+        assert out["config"]["step_schedule"] == name
+        a, b = np.array(ref["checksum"]), np.array(out["checksum"])
+        nch = len(a) // 2
+        scale = np.sqrt(ref["config"]["particles"] * np.maximum(a[nch:], 1e-30))
+        assert (np.abs(a[:nch] - b[:nch]) <= 2e-5 * scale + 1e-12).all(), (sched, np.abs(a[:nch] - b[:nch]) / scale)
+        assert (np.abs(a[nch:] - b[nch:]) <= 1e-4 * np.abs(a[nch:]) + 1e-12).all(), sched
+        bdn = out["rank_breakdown"]["max_over_ranks"]
+        assert bdn["both_ranges_ms"] > 0 and bdn["boundary_range_ms"] > 0 and bdn["exchange_side_stream_ms"] > 0
+
+
 def test_native_rccl_exchange_steps_on_one_gpu():
     """tools/rccl_native_selftest.py: zs_rocm_dist_* (RCCL called from libzsrocm.so, no torch.distributed anywhere) with world size 1
     and this rank as its own peer -- communicator, allreduce sum / max / min, counts all-to-all, uneven all-to-all, ghost-block

@@ -142,6 +142,11 @@ template <class T> inline Port<T> contiguous_port(T *p) { return Port<T>{p, 0u, 
 
 inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// zs_rocm_mpm_g2p2g_slots with the boundary signal (signal == NULL: none): mpm_slotted.hip, used by dist.hip's one-launch step
+int mpm_g2p2g_slots_signal(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                           float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll, size_t blockBegin, size_t blockEnd, int finish,
+                           unsigned long long *signal, size_t signalBlocks);
+
 }  // namespace zsr
 
 // ------------------------------------------------------------------------------------ device helpers

@@ -206,6 +206,9 @@ size_t zs_rocm_halo_plan_from_keys(const int *keysAll, const size_t *counts, int
 
 struct zs_rocm_halo_plan {
   hipEvent_t evBoundary = nullptr, evDone = nullptr;  // the overlapped step's two hand-overs between the compute and the exchange stream
+  hipEvent_t evReady = nullptr;                       // ... and, with the two ranges side by side, the start of the exchange stream's range
+  unsigned long long *signal = nullptr;               // one-launch schedule: running count of finished boundary workgroups (device) ...
+  unsigned long long signalTarget = 0;                // ... and what it reads when the boundary blocks of every step so far are done
   int device = 0, side = 0, npeers = 0;
   size_t total = 0;
   std::vector<int> peerRank;
@@ -312,6 +315,8 @@ void zs_rocm_dist_halo_plan_destroy(zs_rocm_halo_plan *p) {
   if (!p) return;
   DeviceGuard guard(p->device);
   if (p->evBoundary) (void)hipEventDestroy(p->evBoundary);
+  if (p->evReady) (void)hipEventDestroy(p->evReady);
+  if (p->signal) (void)hipFree(p->signal);
   if (p->evDone) (void)hipEventDestroy(p->evDone);
   if (p->blocks) (void)hipFree(p->blocks);
   if (p->sendbuf) (void)hipFree(p->sendbuf);
@@ -390,6 +395,21 @@ int zs_rocm_dist_barrier(zs_rocm_dist *d, zs_rocm_policy *pol) {
   return 0;
 }
 
+}  // extern "C"
+// The gate of the one-launch schedule: ONE wave on the exchange stream that sleeps until the running count of finished boundary workgroups
+// reaches `target`.  The launch that counts has been enqueued (on another stream) before the gate is, and a one-thread gate keeps no CU
+// from it, so the count always arrives; should it not (a bug), the gate traps after ~10 s of the 100 MHz wall clock rather than hang the
+// queue: the process then fails with a HIP error.
+static __global__ void step_gate_kernel(const unsigned long long *signal, unsigned long long target) {
+  const unsigned long long t0 = wall_clock64();
+  // (relaxed: what is waited for are device-wide atomic adds, and the kernels behind the gate start with their own acquire)
+  while (__hip_atomic_load(signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();
+  }
+}
+extern "C" {
+
 // ---------------------------------------------------------------------------------------------------------------- one step, one call
 // The whole sub-step of the slotted MPM path behind ONE C-ABI call: no host code of the caller runs between the kernels, so a C++ host
 //  and bench.py enqueue a step for the price of one call -- at 8 ranks a rank's step is ~1 ms and a Python loop of ~8
@@ -412,6 +432,8 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
   float *const hgrid = a->haloGrid ? a->haloGrid : a->gridB;
   const bool exchange = a->dist && a->plan && a->plan->total;
   if (a->haloChannels < 0 || a->haloChannels > 7) return -1;
+  if (a->rangeSchedule < ZS_ROCM_RANGES_IN_TURN || a->rangeSchedule > ZS_ROCM_RANGES_ONE_LAUNCH) return -1;
+  if (a->rangeSchedule == ZS_ROCM_RANGES_ONE_LAUNCH && side != 8) return -1;   // (the 4^3-block kernel does not count its workgroups off)
   const int hch = a->haloChannels ? a->haloChannels : 7;
   const bool overlap = exchange && a->commPolicy && a->nBoundary > 0 && a->nBoundary < nb;
   int rc = 0;
@@ -438,16 +460,59 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
         return -1;
       }
     }
-    rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, a->nBoundary, 0);
-    if (rc) return rc;  // (nothing of the step has been committed: the range ran with finish = 0 and bad arguments fail before any launch)
-    bd(1, pol);
-    {
-      Launch L(pol, "step: boundary done");
-      ZSR_CHECK(hipEventRecord(p->evBoundary, L.stream));
-    }
-    {
-      Launch C(a->commPolicy, "step: exchange start");
-      ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evBoundary, 0));
+    const int sched = a->rangeSchedule;
+    if (sched == ZS_ROCM_RANGES_ONE_LAUNCH) {
+      // ONE launch over all blocks; its boundary workgroups (dispatched first: block order) count themselves off on p->signal, the gate kernel
+      // on the exchange stream returns when the count says that the boundary blocks of this step are done
+      if (!p->signal) {
+        DeviceGuard guard(p->device);
+        if (hipMalloc((void **)&p->signal, sizeof(unsigned long long)) != hipSuccess) {
+          p->signal = nullptr;
+          report_error(hipErrorOutOfMemory, "step_slotted: could not allocate the boundary signal", __FILE__, __LINE__);
+          return -1;
+        }
+        Launch L(pol, "step: boundary signal := 0");   // (on the stream of the launch that counts)
+        ZSR_CHECK(hipMemsetAsync(p->signal, 0, sizeof(unsigned long long), L.stream));
+        p->signalTarget = 0;
+      }
+      rc = mpm_g2p2g_slots_signal(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, nb, 1, p->signal, a->nBoundary);
+      if (rc) return rc;  // (bad arguments fail before any launch: nothing has been counted)
+      p->signalTarget += a->nBoundary;
+      {
+        Launch C(a->commPolicy, "step: gate");
+        hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, C.stream, (const unsigned long long *)p->signal, p->signalTarget);
+      }
+      bd(1, a->commPolicy);
+    } else {
+      const bool sideBySide = sched == ZS_ROCM_RANGES_SIDE_BY_SIDE;
+      zs_rocm_policy *const bpol = sideBySide ? a->commPolicy : pol;   // the stream the boundary range runs on
+      if (sideBySide) {  // gridB has been cleared (and gridA written) on the policy's stream: the other stream starts behind that
+        if (!p->evReady) {
+          DeviceGuard guard(p->device);
+          if (hipEventCreateWithFlags(&p->evReady, hipEventDisableTiming) != hipSuccess) {
+            p->evReady = nullptr;
+            report_error(hipErrorOutOfMemory, "step_slotted: could not create the overlap events", __FILE__, __LINE__);
+            return -1;
+          }
+        }
+        {
+          Launch L(pol, "step: grids ready");
+          ZSR_CHECK(hipEventRecord(p->evReady, L.stream));
+        }
+        Launch C(a->commPolicy, "step: boundary range start");
+        ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evReady, 0));
+      }
+      rc = zs_rocm_mpm_g2p2g_slots(bpol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, a->nBoundary, 0);
+      if (rc) return rc;  // (nothing of the step has been committed: the range ran with finish = 0 and bad arguments fail before any launch)
+      bd(1, bpol);
+      {
+        Launch L(bpol, "step: boundary done");
+        ZSR_CHECK(hipEventRecord(p->evBoundary, L.stream));
+      }
+      if (!sideBySide) {
+        Launch C(a->commPolicy, "step: exchange start");
+        ZSR_CHECK(hipStreamWaitEvent(C.stream, p->evBoundary, 0));
+      }
     }
     bd(3, a->commPolicy);
     const int rcx = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, hch);
@@ -458,7 +523,17 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
     }
     // the second range ALWAYS runs, with its finish pass (re-home + commit): a failed exchange must not leave outbox records, claim words
     // and mover counts of the boundary range uncommitted -- the slot storage stays consistent, the error is returned afterwards
-    rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 1);
+    if (sched == ZS_ROCM_RANGES_IN_TURN) {
+      rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 1);
+    } else if (sched == ZS_ROCM_RANGES_SIDE_BY_SIDE) {  // the interior range next to the boundary range; the finish pass needs the outbox records of both
+      rc = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, a->nBoundary, nb, 0);
+      {
+        Launch L(pol, "step: wait for the boundary range");
+        ZSR_CHECK(hipStreamWaitEvent(L.stream, p->evBoundary, 0));
+      }
+      const int rcf = zs_rocm_mpm_g2p2g_slots(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, nb, nb, 1);
+      if (!rc) rc = rcf;
+    }
     bd(2, pol);
     stamp(a->evTransferEnd);
     {

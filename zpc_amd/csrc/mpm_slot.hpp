@@ -48,6 +48,8 @@ struct SlotArgs {
   int binBase, nbins, nbinsAll;
   int cap;              // outbox records per bin and step (caller's choice: a bin holds 512 particles at 8 per cell)
   const unsigned char *blockEdge;  // [nblocks] or NULL: 1 = a block of {-1..2}^3 around this one is not in the partition (zs_rocm_mpm_partition_edge)
+  unsigned long long *signal;      // NULL, or a running count: every workgroup of the blocks [0, signalBlocks) adds 1 when its grid sums are in L2
+  int signalBlocks;                // (8^3 blocks only: the multi-GPU step's exchange stream starts behind the boundary blocks of ONE launch, dist.hip)
 };
 
 constexpr int SL_NCTR = 256, SL_SENT = 8, SL_DELIVERED = 8 + SL_NCTR;  // layout of the status words (zs_rocm.h: ZS_ROCM_SLOT_STATUS_WORDS)

@@ -559,7 +559,10 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   __syncthreads();
   const int G = s_G;
   if (tid < 8 && s_total[tid] == 0) A.moverCount[bin0 + tid] = 0;
-  if (G == 0) return;
+  if (G == 0) {  // (an empty block has no grid sums: it reports at once)
+    if (A.signal && blk < A.signalBlocks && tid == 0) atomicAdd(A.signal, 1ull);
+    return;
+  }
   {  // entry tables and neighbour bins of the bins of chunks 0 and 1 (all eight waves; later ones: the producers, two chunks ahead)
     const int b0 = s_chBin[0];
     blk_build_tab(s_masks[b0][lane], lane, w, 8, s_tab[s_binQ[b0] & 1]);
@@ -607,6 +610,13 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
         __syncthreads();
       }
     }
+  }
+  if (A.signal && blk < A.signalBlocks) {  // (workgroup-uniform) one of the blocks whose grid sums somebody is waiting for
+    // this wave's atomic adds to grid B have been performed (they are device-wide operations: nothing of them sits in this XCD's L2, so
+    // no release fence -- an agent-scope fence writes the whole L2 back, and a thousand workgroups doing that cost a third of the step) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // ... and every wave's
+    if (tid == 0) atomicAdd(A.signal, 1ull);
   }
 }
 

@@ -476,7 +476,17 @@ size_t zs_rocm_mpm_slot_list(zs_rocm_policy *pol, const unsigned *cellMask, size
 int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
                             const float *gridA, float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll,
                             size_t blockBegin, size_t blockEnd, int finish) {
+  return zsr::mpm_g2p2g_slots_signal(pol, p, ps, tab, gridA, gridB, nblocks, st, writeAll, blockBegin, blockEnd, finish, nullptr, 0);
+}
+}  // extern "C"
+namespace zsr {
+// ... and with `signal`: every workgroup of the blocks [0, signalBlocks) of the range adds 1 to *signal when its sums have reached grid B
+// (8^3 blocks only; zs_rocm_mpm_step_slotted's one-launch schedule waits for the count on its exchange stream)
+int mpm_g2p2g_slots_signal(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab, const float *gridA,
+                           float *gridB, size_t nblocks, const zs_rocm_slot_storage *st, int writeAll, size_t blockBegin, size_t blockEnd, int finish,
+                           unsigned long long *signal, size_t signalBlocks) {
   if (!st) return -1;
+  if (signal && p->side != 8) return -1;
   unsigned *const cellMask = st->cellMask;
   const int K = st->K, outboxCap = st->outboxCap;
   const int *const nbr = st->nbr, *const nbr27 = st->nbr27;
@@ -499,7 +509,7 @@ int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
   const unsigned nbinsAll = (unsigned)(nblocks * bpb);
   const unsigned nbins = blockBegin < blockEnd ? (unsigned)((blockEnd - blockBegin) * bpb) : 0u;
   const SlotArgs A{gridA, gridB, cellMask, K, nbr, nbr27, moverCount, claim, moverRec, status, (int)(blockBegin * bpb), (int)nbins, (int)nbinsAll, outboxCap,
-                   st->blockEdge};
+                   st->blockEdge, signal, (int)signalBlocks};
 #define CALL_REHOME3(M, WA)                                                                                                              \
   hipLaunchKernelGGL((slot_rehome_kernel<model_is_fluid(M), model_uses_logjp(M), WA>), dim3(ceil_div((size_t)nbinsAll, 32)), dim3(256), 0,  \
                      L.stream, pd, (const unsigned *)cellMask, claim, (const int *)moverCount, (const float *)moverRec, outboxCap,        \
@@ -527,6 +537,8 @@ int zs_rocm_mpm_g2p2g_slots(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs
   }
   return 0;
 }
+}  // namespace zsr
+extern "C" {
 
 int zs_rocm_mpm_g2p2g_slotted_range(zs_rocm_policy *pol, const zs_rocm_mpm_params *p, zs_rocm_particles ps, const zs_rocm_bht_3 *tab,
                                     const float *gridA, float *gridB, size_t nblocks, unsigned *cellMask, int K, const int *nbr, const int *nbr27,

@@ -597,7 +597,7 @@ class MpmTransfer:
                 between()
 
     def step_slotted(self, extf=(0.0, 0.0, 0.0), max_vel=None, write_all=False, n_boundary=0, comm=None, plan=None, comm_pol=None,
-                     collider=None, halo_grid=None, events=None, breakdown=None, halo_channels=7):
+                     collider=None, halo_grid=None, events=None, breakdown=None, halo_channels=7, range_schedule=0):
         """One whole sub-step on slotted storage behind ONE C-ABI call (zs_rocm_mpm_step_slotted): second grid := 0, fused G2P2G over the
         boundary blocks [0, n_boundary) then the interior, ghost-block exchange of `plan` on comm_pol's stream overlapping the interior,
         grid update (+ collider), CFL allreduce(max) of max_vel.  The grids swap: self.grid is the new one afterwards.
@@ -625,6 +625,7 @@ class MpmTransfer:
         a.commPolicy = comm_pol.handle if comm_pol is not None else None
         a.haloGrid = halo_grid.data_ptr() if halo_grid is not None else None
         a.haloChannels = int(halo_channels)   # 4: only {m, mv} of the ghost blocks travel (all a step reads of them); 7: the rhs channels too
+        a.rangeSchedule = int(range_schedule)   # RANGES_IN_TURN / _SIDE_BY_SIDE / _ONE_LAUNCH (include/zs_rocm.h, zs_rocm_mpm_step.rangeSchedule)
         a.evTransferBegin, a.evTransferEnd = (events[0], events[1]) if events is not None else (None, None)   # raw hipEvent_t (HipEvents)
         a.evBreakdown = breakdown if breakdown is not None else None   # (C.c_void_p * ZS_ROCM_STEP_EVENTS) of raw hipEvent_t (StepBreakdown.next())
         if getattr(self, "_poisoned", False):
@@ -727,13 +728,17 @@ class HipEvents:
             pass
 
 
+RANGES_IN_TURN, RANGES_SIDE_BY_SIDE, RANGES_ONE_LAUNCH = 0, 1, 2   # ZS_ROCM_RANGES_*: zs_rocm_mpm_step.rangeSchedule
+
+
 class StepBreakdown:
     """zs_rocm_mpm_step.evBreakdown: ZS_ROCM_STEP_EVENTS raw hipEvent_t per recorded step; after a synchronisation, the mean time of every
     stretch of a rank's step (ms): where a multi-GPU step's time goes (boundary range, interior range, the exchange on the side stream,
     waiting for it, grid update, CFL allreduce)."""
     NEV = 8
     STRETCHES = (("boundary_range_ms", 0, 1), ("interior_range_ms", 1, 2), ("wait_for_exchange_ms", 2, 5), ("grid_update_ms", 5, 6),
-                 ("cfl_allreduce_ms", 6, 7), ("exchange_side_stream_ms", 3, 4), ("step_ms", 0, 7))
+                 ("cfl_allreduce_ms", 6, 7), ("exchange_side_stream_ms", 3, 4), ("step_ms", 0, 7),
+                 ("both_ranges_ms", 0, 2))   # (ranges side by side: [0,1] and [0,2] overlap, interior_range_ms = [1,2] is only the rest)
 
     def __init__(self):
         self.hip = C.CDLL("libamdhip64.so")
