@@ -523,6 +523,13 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
 #pragma unroll
   for (int d = 0; d < 3; ++d) borg[d] = t.activeKeys[3 * (size_t)blk + d] * (8 / mp.kscale);
   __syncthreads();
+  if ((s_total[0] | s_total[1] | s_total[2] | s_total[3] | s_total[4] | s_total[5] | s_total[6] | s_total[7]) == 0) {
+    // an empty block (the partition's apron: a quarter to a half of all blocks) leaves before it gathers a velocity arena; it has no grid
+    // sums, so it reports to the one-launch schedule's counter at once
+    if (tid < 8) A.moverCount[bin0 + tid] = 0;
+    if (A.signal && blk < A.signalBlocks && tid == 0) atomicAdd(A.signal, 1ull);
+    return;
+  }
   if (tid == 0) {  // the block's chunk sequence
     int G = 0, q = 0;
     for (int b = 0; b < 8; ++b) {
@@ -559,10 +566,6 @@ static __global__ __launch_bounds__(512, 4) void g2p2g_slotblk_kernel(MpmDev mp,
   __syncthreads();
   const int G = s_G;
   if (tid < 8 && s_total[tid] == 0) A.moverCount[bin0 + tid] = 0;
-  if (G == 0) {  // (an empty block has no grid sums: it reports at once)
-    if (A.signal && blk < A.signalBlocks && tid == 0) atomicAdd(A.signal, 1ull);
-    return;
-  }
   {  // entry tables and neighbour bins of the bins of chunks 0 and 1 (all eight waves; later ones: the producers, two chunks ahead)
     const int b0 = s_chBin[0];
     blk_build_tab(s_masks[b0][lane], lane, w, 8, s_tab[s_binQ[b0] & 1]);
