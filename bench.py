@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--block-order", type=str, default="holders_lex", choices=["insertion", "holders_lex", "lex", "morton"],
                     help="numbering of the partition's blocks (MpmTransfer.build_partition): holders_lex = blocks with particles in "
                          "lexicographic key order, apron blocks behind them; insertion = the hash table's race (the reference's)")
+    ap.add_argument("--block-axes", type=str, default="auto",
+                    help="holders_lex / lex: the block key's components from most to least significant, e.g. 0,2,1 (the last one changes fastest "
+                         "along the numbering).  auto: slotted storage -- the column's longest axis last (fused block kernel: -1.3 %%); else 0,1,2")
     ap.add_argument("--compact", action="store_true",
                     help="compact round-robin particle order + re-bin controller (round 1's storage) instead of the slotted storage "
                          "the fused step keeps valid by itself (zpc_amd/csrc/mpm_slotted.hip)")
@@ -409,7 +412,12 @@ def main():
         numbered first; bins; ghost-block lists"""
         nonlocal n_boundary, proxy_grid
         from zpc_amd.dist import gather_block_keys, near_shared_mask
-        nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0, order=a.block_order)
+        if a.block_axes == "auto":
+            longest = max(range(3), key=lambda d: ext[d])
+            block_axes = ([d for d in range(3) if d != longest] + [longest]) if a.slotted else [0, 1, 2]
+        else:
+            block_axes = [int(x) for x in a.block_axes.split(",")]
+        nb_ = mt.build_partition(max(4096, mt.n // 128), margin=a.margin if a.slotted else 0, order=a.block_order, axes=block_axes)
         all_keys = None
         if world > 1 and (overlap or comm is None):
             all_keys = gather_block_keys(dist, world, mt.active_keys(), comm_dev)
@@ -909,7 +917,7 @@ def main():
             "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": ((halo.bytes_per_exchange * a.halo_channels // 7 if comm is not None else halo.bytes_per_exchange) if halo and halo.peers else 0),
-                       "halo_channels": a.halo_channels, "block_order": getattr(mt, "block_order", None),
+                       "halo_channels": a.halo_channels, "block_order": getattr(mt, "block_order", None), "block_axes": list(getattr(mt, "block_axes", None) or (0, 1, 2)),
                        "step_schedule": (("ranges in turn", "ranges side by side", "one launch + gate")[range_schedule] if (one_call and overlap) else "one range"),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,
@@ -1051,7 +1059,7 @@ def main():
             try:
                 cmd = [sys.executable, os.path.abspath(__file__), "--drift", "0,0,0", "--no-at-rest", "--no-cpu-baseline", "--steps", "10",
                        "--warmup", "3", "--grid", str(a.grid), "--cells", a.cells, "--model", a.model, "--side", str(a.side),
-                       "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin), "--block-order", a.block_order]
+                       "--slot-rounds", str(a.slot_rounds), "--outbox-cap", str(a.outbox_cap), "--margin", str(a.margin), "--block-order", a.block_order, "--block-axes", a.block_axes]
 
                 def sub(extra):
                     r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)

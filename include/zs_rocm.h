@@ -369,6 +369,10 @@ typedef struct {
   /* (B) canonical form for bit-exact comparison (SURVEY.md 8a note): sort active keys               \
      lexicographically and renumber */                                                                  \
   ZS_ROCM_EXPORT void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *);  \
+  /* ... with the significance of the key's components chosen: axes = a permutation of 0 .. D-1 (host array), axes[0] \
+     the most significant component, axes[D-1] the one that changes fastest along the numbering; NULL = 0, 1, ..       \
+     Returns 0, -1 if axes is not a permutation */                                                                     \
+  ZS_ROCM_EXPORT int zs_rocm_canonicalize_axes__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *, const int *axes);  \
   /* (B) renumber the active keys along the Z-order (Morton) curve of (key - min key): consecutive  \
      entries are spatial neighbours -- the launch order the per-block MPM kernels want (no reference  \
      counterpart: the reference's numbering is insertion order, Bht.hpp:612-664, and any numbering is \

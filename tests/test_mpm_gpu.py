@@ -1243,3 +1243,13 @@ def test_block_numbering_orders_of_the_partition(pol, oracle, side):
         _compare_grids(grids[order], grids["insertion"], 1e-5)
     with pytest.raises(ValueError):
         mt.build_partition(n, order="hilbert")
+    # the significance of the key's components: (0, 2, 1) = x, then z, y fastest
+    nb = mt.build_partition(n, order="lex", axes=(0, 2, 1))
+    keys = [tuple(int(c) for c in k) for k in mt.active_keys()]
+    assert set(keys) == keysets["insertion"] and keys == sorted(keys, key=lambda k: (k[0], k[2], k[1]))
+    mt.build_partition(n, axes=(2, 0, 1))
+    keys = [tuple(int(c) for c in k) for k in mt.active_keys()]
+    h = len(holders)
+    assert set(keys[:h]) == holders and keys[:h] == sorted(keys[:h], key=lambda k: (k[2], k[0], k[1])) and mt.block_axes == (2, 0, 1)
+    with pytest.raises(ValueError):
+        mt.build_partition(n, axes=(0, 0, 1))

@@ -222,21 +222,31 @@ template <int DIM> static void bht_reorder_impl(Launch &L, BhtHost &t, const int
 }
 
 // canonical numbering: active keys in lexicographic order (component 0 most significant), LSD over components
-template <int DIM> static void bht_canonicalize(zs_rocm_policy *pol, BhtHost &t) {
+// axes: NULL, or a permutation of 0 .. DIM-1 -- axes[0] is the most significant component of the comparison, axes[DIM-1] the one that
+// changes fastest along the numbering
+template <int DIM> static int bht_canonicalize(zs_rocm_policy *pol, BhtHost &t, const int *axes = nullptr) {
+  int ax[DIM];
+  unsigned seen = 0u;
+  for (int d = 0; d < DIM; ++d) {
+    ax[d] = axes ? axes[d] : d;
+    if (ax[d] < 0 || ax[d] >= DIM || ((seen >> ax[d]) & 1u)) return -1;
+    seen |= 1u << ax[d];
+  }
   Launch L(pol, "bht_canonicalize");
   const int n = bht_size(t, L.stream);
-  if (n <= 1) return;
+  if (n <= 1) return 0;
   int *perm[2] = {(int *)L.temp(sizeof(int) * n), (int *)L.temp(sizeof(int) * n)};
   unsigned *comp = (unsigned *)L.temp(sizeof(unsigned) * n), *sorted = (unsigned *)L.temp(sizeof(unsigned) * n);
   hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, perm[0], n);
   int cur = 0;
   for (int d = DIM - 1; d >= 0; --d) {
     hipLaunchKernelGGL((bht_gather_comp_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.activeKeys, perm[cur], n,
-                       d, comp);
+                       ax[d], comp);
     radix_sort_pair_u32(L, comp, perm[cur], sorted, perm[cur ^ 1], (size_t)n, 0, 32);
     cur ^= 1;
   }
   bht_reorder_impl<DIM>(L, t, perm[cur], /*scatter=*/false, n);  // new key i = old key perm[i]
+  return 0;
 }
 
 // Morton numbering: active keys along the Z-order curve of (key - min key).  Consecutive numbers are spatial neighbours in every
@@ -363,6 +373,9 @@ extern "C" {
   }                                                                                                         \
   void zs_rocm_canonicalize__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
     bht_canonicalize<D>(pol, b->t);                                                                         \
+  }                                                                                                         \
+  int zs_rocm_canonicalize_axes__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *axes) {  \
+    return bht_canonicalize<D>(pol, b->t, axes);                                                            \
   }                                                                                                         \
   void zs_rocm_order_morton__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
     bht_order_morton<D>(pol, b->t);                                                                         \

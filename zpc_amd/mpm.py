@@ -128,7 +128,7 @@ class MpmTransfer:
         return out
 
     # ------------------------------------------------------------------ partition (SparsityCompute.tpp:5-24)
-    def build_partition(self, expected_blocks, margin=0, order=None):
+    def build_partition(self, expected_blocks, margin=0, order=None, axes=None):
         """ComputeSparsity + EnlargeSparsity{0, 2} (the reference's partition); margin = m enlarges by m more blocks on every side
         (lo = -m, hi = 2 + m): room for the particles to travel m blocks before the partition has to be rebuilt.
 
@@ -138,7 +138,10 @@ class MpmTransfer:
                               of their race: they hold no particle, the per-block kernels leave them at once)
           "lex"               every block in lexicographic key order
           "morton"            every block along the Z-order curve
-        The numbering changes no result, only which workgroups run side by side (profiles/r06_p2g.md, section 4)."""
+        axes (holders_lex / lex): the key components from most to least significant, default (0, 1, 2); the last one changes fastest
+        along the numbering.  The fused block kernel runs 1.3 % faster with the cloud's longest axis last (bench.py passes that).
+        The numbering changes no result beyond the order of the atomic sums, only which workgroups run side by side
+        (profiles/r06_p2g.md, section 4b)."""
         import os
         order = os.environ.get("ZS_ROCM_CANONICAL_PARTITION") or order or "holders_lex"   # (the variable: tools/r06_order.sh's A/B)
         if order not in ("insertion", "holders_lex", "lex", "morton"):
@@ -149,7 +152,7 @@ class MpmTransfer:
                                        int(self.key_is_origin))
         if order == "holders_lex":  # (the apron blocks are inserted after this and keep the indices behind the holders)
             self.pol.syncCtx()
-            self.table.canonicalize(self.pol)
+            self.table.canonicalize(self.pol, axes)
         xp = os.environ.get("ZS_ROCM_HOLDER_ORDER")   # measurement only (tools/r06_order2.sh): "120" = axis 1 most significant, then 2, then 0;
         if xp:                                        # "120:2,4,4" = the same inside and across tiles of 2 x 4 x 4 blocks; "m" = Z-order curve
             import ctypes
@@ -186,9 +189,9 @@ class MpmTransfer:
             self.table.order_morton(self.pol)
             self.pol.syncCtx()
         elif order == "lex":
-            self.table.canonicalize(self.pol)
+            self.table.canonicalize(self.pol, axes)
             self.pol.syncCtx()
-        self.block_order = order
+        self.block_order, self.block_axes = order, (tuple(axes) if axes is not None else None)
         self.nblocks = self.table.size()
         self.slotted = False
         nc = self.side ** 3
@@ -326,7 +329,7 @@ class MpmTransfer:
                                             int(self.key_is_origin), new_table.handle)
         if getattr(self, "block_order", "insertion") == "holders_lex":   # the numbering build_partition() was asked for
             self.pol.syncCtx()
-            new_table.canonicalize(self.pol)
+            new_table.canonicalize(self.pol, getattr(self, "block_axes", None))
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, new_table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
