@@ -170,13 +170,17 @@ class MpmTransfer:
                         code |= ((k[:, d] >> bit) & 1) << (3 * bit + (2 - d))
             else:
                 ax = [int(c) for c in xp[:3]]
-                t = [int(c) for c in xp.split(":")[1].split(",")] if ":" in xp else [1, 1, 1]
+                t = [int(c) for c in xp.rstrip("x").split(":")[1].split(",")] if ":" in xp else [1, 1, 1]
                 code = torch.zeros(n0, dtype=torch.int64, device=self.device)
                 for d in ax:
                     code = code * 4096 + k[:, d] // t[d]
                 for d in ax:
                     code = code * t[d] + k[:, d] % t[d]
             perm = torch.argsort(code).to(torch.int32).contiguous()
+            if xp.endswith("x"):   # XCD k (workgroup number mod 8) walks the k-th contiguous eighth of the sorted holders
+                q = n0 // 8
+                pos = torch.arange(8 * q, device=self.device)
+                perm = torch.cat([perm[(pos % 8) * q + pos // 8], perm[8 * q:]]).contiguous()
             torch.cuda.synchronize()
             self.table.reorder(self.pol, perm.data_ptr(), scatter=False)
             self.pol.syncCtx()
