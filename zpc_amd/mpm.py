@@ -153,37 +153,8 @@ class MpmTransfer:
         if order == "holders_lex":  # (the apron blocks are inserted after this and keep the indices behind the holders)
             self.pol.syncCtx()
             self.table.canonicalize(self.pol, axes)
-        xp = os.environ.get("ZS_ROCM_HOLDER_ORDER")   # measurement only (tools/r06_order2.sh): "120" = axis 1 most significant, then 2, then 0;
-        if xp:                                        # "120:2,4,4" = the same inside and across tiles of 2 x 4 x 4 blocks; "m" = Z-order curve
-            import ctypes
-            self.pol.syncCtx()
-            n0 = self.table.size()
-            v = self.table.view()
-            k = torch.empty(n0 * 3, dtype=torch.int32, device=self.device)
-            ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.activeKeys), ctypes.c_size_t(n0 * 12), 3)
-            k = k.view(n0, 3).to(torch.int64) // self.kstride
-            k = k - k.min(dim=0).values
-            if xp == "m":
-                code = torch.zeros(n0, dtype=torch.int64, device=self.device)
-                for bit in range(16):
-                    for d in range(3):
-                        code |= ((k[:, d] >> bit) & 1) << (3 * bit + (2 - d))
-            else:
-                ax = [int(c) for c in xp[:3]]
-                t = [int(c) for c in xp.rstrip("x").split(":")[1].split(",")] if ":" in xp else [1, 1, 1]
-                code = torch.zeros(n0, dtype=torch.int64, device=self.device)
-                for d in ax:
-                    code = code * 4096 + k[:, d] // t[d]
-                for d in ax:
-                    code = code * t[d] + k[:, d] % t[d]
-            perm = torch.argsort(code).to(torch.int32).contiguous()
-            if xp.endswith("x"):   # XCD k (workgroup number mod 8) walks the k-th contiguous eighth of the sorted holders
-                q = n0 // 8
-                pos = torch.arange(8 * q, device=self.device)
-                perm = torch.cat([perm[(pos % 8) * q + pos // 8], perm[8 * q:]]).contiguous()
-            torch.cuda.synchronize()
-            self.table.reorder(self.pol, perm.data_ptr(), scatter=False)
-            self.pol.syncCtx()
+        if os.environ.get("ZS_ROCM_HOLDER_ORDER"):   # measurement only (tools/r06_order2.sh)
+            self._measurement_holder_order(os.environ["ZS_ROCM_HOLDER_ORDER"])
         m = int(margin)
         self.partition_margin = m   # (repartition_slotted() keeps the same travel room unless told otherwise)
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
@@ -204,6 +175,49 @@ class MpmTransfer:
         L.zs_rocm_mpm_build_neighbors(self.pol.handle, self.table.handle, self.nbr.data_ptr(), self.kstride)
         self.binned = False
         return self.nblocks
+
+    def _measurement_holder_order(self, xp):
+        """MEASUREMENT ONLY (profiles/r06_block_order_*.txt): renumber the blocks that hold particles (the table right after ComputeSparsity).
+        "120" = key axis 1 most significant, then 2, then 0; "120:2,4,4" = the same inside and across tiles of 2 x 4 x 4 blocks; "m" = Z-order
+        curve; suffix "s17": position p holds the (17 p mod n)-th holder of that order; suffix "x": XCD k (workgroup number mod 8) walks the
+        k-th contiguous eighth."""
+        import ctypes
+        self.pol.syncCtx()
+        n0 = self.table.size()
+        v = self.table.view()
+        k = torch.empty(n0 * 3, dtype=torch.int32, device=self.device)
+        ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.activeKeys), ctypes.c_size_t(n0 * 12), 3)
+        k = k.view(n0, 3).to(torch.int64) // self.kstride
+        k = k - k.min(dim=0).values
+        if xp == "m":
+            code = torch.zeros(n0, dtype=torch.int64, device=self.device)
+            for bit in range(16):
+                for d in range(3):
+                    code |= ((k[:, d] >> bit) & 1) << (3 * bit + (2 - d))
+        else:
+            ax = [int(c) for c in xp[:3]]
+            t = [int(c) for c in xp.rstrip("x").split("s")[0].split(":")[1].split(",")] if ":" in xp else [1, 1, 1]
+            code = torch.zeros(n0, dtype=torch.int64, device=self.device)
+            for d in ax:
+                code = code * 4096 + k[:, d] // t[d]
+            for d in ax:
+                code = code * t[d] + k[:, d] % t[d]
+        perm = torch.argsort(code).to(torch.int32).contiguous()
+        if "s" in xp:   # "021s17": position p holds the (17 p mod n)-th holder of the sorted order (n made coprime by dropping a tail)
+            st = int(xp.split("s")[1])
+            import math
+            nn = n0
+            while math.gcd(nn, st) != 1:
+                nn -= 1
+            pos = (torch.arange(nn, device=self.device, dtype=torch.int64) * st) % nn
+            perm = torch.cat([perm[pos], perm[nn:]]).contiguous()
+        if xp.endswith("x"):   # XCD k (workgroup number mod 8) walks the k-th contiguous eighth of the sorted holders
+            q = n0 // 8
+            pos = torch.arange(8 * q, device=self.device)
+            perm = torch.cat([perm[(pos % 8) * q + pos // 8], perm[8 * q:]]).contiguous()
+        torch.cuda.synchronize()
+        self.table.reorder(self.pol, perm.data_ptr(), scatter=False)
+        self.pol.syncCtx()
 
     def adopt_partition(self, active_keys_ptr, nblocks):
         """Use a partition numbered elsewhere -- the `_activeKeys` of a zs::HashTable<i32,3,int> built by
