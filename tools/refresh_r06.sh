@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/r06; [ -z "$ONLY" ] && rm -rf $O; mkdir -p $O   # ONLY=p2g: just the stand-alone P2G passes (after a change of that kernel alone)
-B="python $R/bench.py --no-cpu-baseline --no-at-rest"
+B="timeout 600 python $R/bench.py --no-cpu-baseline --no-at-rest"
 P2G="$B --compact --unfused --drift 0,0,0 --steps 8 --warmup 2"
 # 1. kernel-trace stats of the default (moving) bench and of the unfused at-rest run
 for tag in $([ "$ONLY" = p2g ] && echo unfused || echo moving unfused); do
@@ -86,7 +86,7 @@ PY
 cd $R
 [ "$ONLY" = p2g ] && { $B --compact --unfused --drift 0,0,0 > $O/bench_n1_unfused_at_rest.json 2>/dev/null; exit 0; }
 # 3. bench lines
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 $B --drift 0,0,0 > $O/bench_n1_at_rest.json 2>/dev/null
 $B --compact --drift 0,0,0 > $O/bench_n1_compact_at_rest.json 2>/dev/null
 $B --compact --unfused --drift 0,0,0 > $O/bench_n1_unfused_at_rest.json 2>/dev/null
@@ -94,5 +94,5 @@ $B --cells 100,100,100 --model jello --grid 256 > $O/bench_config3_jello_8M.json
 $B --steps 40 --warmup 5 --cells 64,256,64 > $O/eighth_plain.json 2>/dev/null
 $B --steps 40 --warmup 5 --cells 64,256,64 --rank-proxy 8 2>/dev/null | grep '^{' > $O/proxy8.json
 $B --steps 3000 --warmup 3 --slot-stats 2>/dev/null | grep '^{' > $O/bench_soak3000.json
-python tools/bench_prims.py --json $O/prims.json > $O/prims.txt 2>&1
+timeout 600 python tools/bench_prims.py --json $O/prims.json > $O/prims.txt 2>&1
 tail -c 400 $O/bench_n1.json
