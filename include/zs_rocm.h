@@ -815,7 +815,8 @@ ZS_ROCM_EXPORT zs_rocm_halo_plan *zs_rocm_dist_halo_plan_from_lists(zs_rocm_dist
                                                                     size_t total);
 /* One sub-step of the slotted MPM path in ONE call (zpc_amd/csrc/dist.hip): gridB := 0; fused G2P (gridA) + P2G (gridB) over the boundary
  * blocks [0, nBoundary), then the interior blocks (+ re-home / commit); the ghost-block exchange of the plan on commPolicy's stream behind
- * the boundary range, overlapping the interior; grid update of gridB (extf, maxVelSqr) [+ collider]; allreduce(max) of maxVelSqr.  Nothing
+ * the boundary range, overlapping the interior (rangeSchedule: as two launches, or as one whose boundary workgroups count themselves off);
+ * grid update of gridB (extf, maxVelSqr) [+ collider]; allreduce(max) of maxVelSqr.  Nothing
  * of the caller runs between the kernels.  dist / plan / commPolicy / maxVelSqr / collider / haloGrid may be NULL (single rank: no exchange).
  * haloGrid: the grid whose shared blocks are exchanged (NULL: gridB).  The reference's building blocks for such a schedule are
  * pol.device(i) / .stream(i) / .listen() (cuda/execution/ExecutionPolicy.cuh:364-399).

@@ -186,6 +186,40 @@ def test_abi_struct_layouts_match_the_reference(tmp_path):
     assert C.sizeof(BhtViewLite) == want["BhtViewLite<int,3,int,16>"]["size"]
 
 
+def test_ctypes_mirrors_of_the_mpm_structs_match_the_header(tmp_path):
+    """zpc_amd/_lib.py mirrors the PODs of the MPM path by hand (the tests and bench.py fill them through ctypes): every field of every mirror
+    sits at the offset and has the size the host compiler gives the member of the same name in include/zs_rocm.h, and the structs are
+    as large -- a field added to one side only (zs_rocm_mpm_step grew haloChannels and rangeSchedule in r06) fails here, on CPU."""
+    from zpc_amd import _lib
+    pairs = {"zs_rocm_mpm_step": _lib.MpmStep, "zs_rocm_slot_storage": _lib.SlotStorage, "zs_rocm_mpm_params": _lib.MpmParams,
+             "zs_rocm_particles": _lib.Particles, "zs_rocm_collider": _lib.Collider, "aosoa_iterator_float_1": _lib.Port,
+             "zs_rocm_hashtable_view": _lib.HashTableView, "zs_rocm_lbvh_view": _lib.LBvhView, "zs_rocm_index_buckets_view": _lib.IndexBucketsView}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "zs_rocm.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        src.append('  printf("%s|size|%%zu|0\\n", sizeof(%s));' % (cname, cname))
+        for m, _ in cls._fields_:
+            src.append('  printf("%s|%s|%%zu|%%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));' % (cname, m, cname, m, cname, m))
+    src += ['  return 0;', '}']
+    c = tmp_path / "mirrors.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "mirrors"
+    subprocess.check_call(["gcc", "-std=gnu11", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = {}
+    for line in subprocess.check_output([str(exe)]).decode().splitlines():
+        sname, m, a, b = line.split("|")
+        got.setdefault(sname, {})[m] = [int(a), int(b)]
+    for cname, cls in pairs.items():
+        assert C.sizeof(cls) == got[cname]["size"][0], (cname, C.sizeof(cls), got[cname]["size"][0])
+        for m, _ in cls._fields_:
+            f = getattr(cls, m)
+            assert [f.offset, f.size] == got[cname][m], (cname, m, [f.offset, f.size], got[cname][m])
+    assert _lib.lib is not None and (_lib.MpmStep.rangeSchedule.offset > _lib.MpmStep.haloChannels.offset)
+    from zpc_amd import mpm
+    hdr = open(os.path.join(ROOT, "include", "zs_rocm.h")).read()
+    for name, val in (("ZS_ROCM_RANGES_IN_TURN", mpm.RANGES_IN_TURN), ("ZS_ROCM_RANGES_SIDE_BY_SIDE", mpm.RANGES_SIDE_BY_SIDE), ("ZS_ROCM_RANGES_ONE_LAUNCH", mpm.RANGES_ONE_LAUNCH)):
+        assert "#define %s %d\n" % (name, val) in hdr
+
+
 def test_native_halo_plan_matches_the_python_plan():
     """zs_rocm_halo_plan_from_keys (host part of the native multi-GPU set-up, callable without a GPU) against the numpy construction
     HaloExchange uses: same peers, same per-peer block lists in the same (lexicographic key) order, for every rank of random

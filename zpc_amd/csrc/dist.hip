@@ -420,6 +420,9 @@ extern "C" {
 // and on commPolicy's stream (a second stream), behind the event: pack -> grouped ncclSend / ncclRecv -> atomic unpack-add of the ghost
 // blocks' partial sums (zs_rocm_dist_halo_plan_exchange) -- it overlaps the interior range.  commPolicy == NULL or nBoundary == 0 or
 // == nblocks: one range, exchange on the main stream.  dist == NULL: single rank (no exchange, no allreduce).
+// rangeSchedule (r06) selects how the boundary blocks get ahead: the two launches above (IN_TURN), the boundary launch on commPolicy's
+// stream beside the interior launch (SIDE_BY_SIDE), or ONE launch over all blocks whose boundary workgroups count themselves off for a
+// gate kernel on commPolicy's stream (ONE_LAUNCH; measured in DESIGN.md 7).
 // What the reference offers for this: pol.device(i) + .listen() events between streams (cuda/execution/ExecutionPolicy.cuh:364-399);
 // the schedule itself has no counterpart (zpc has no collective layer).  Returns 0, -1 on bad arguments or an RCCL error.
 int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
