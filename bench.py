@@ -515,6 +515,8 @@ def main():
         if timed:
             e3.record()
             g2p_ev.append((e2, e3))
+        if os.environ.get("ZS_BENCH_GAP_CYCLES"):   # measurement only (profiles/r06_g2p.md): an idle stretch between G2P and the next P2G
+            torch.cuda._sleep(int(os.environ["ZS_BENCH_GAP_CYCLES"]))
 
     fused_ev = []
     from zpc_amd.mpm import HipEvents, StepBreakdown

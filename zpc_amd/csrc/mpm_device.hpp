@@ -2301,7 +2301,8 @@ static __global__ __launch_bounds__(64) void g2p_binned_kernel(MpmDev mp, Partic
   }
 }
 
-// ---- G2P with lane = PARTICLE (r06).  g2p_binned_kernel maps lane = cell so that a lane keeps its cell's 27 x 3 node velocities in
+// ---- G2P with lane = PARTICLE (r06; the kernel zs_rocm_mpm_g2p launches for binned particles).  g2p_binned_kernel (kept for -DZS_G2P_AB
+// comparisons) maps lane = cell so that a lane keeps its cell's 27 x 3 node velocities in
 // registers -- and then runs the 860-instruction constitutive update at the lane occupancy of the rounds (~70 %: the fullest cell of a
 // bin sets the number of rounds).  Here a workgroup owns a grid block: its particles are ONE contiguous range of the compact order
 // (bins of a block are consecutive), the waves take them 64 at a time (every lane busy, loads and stores fully coalesced), and a
