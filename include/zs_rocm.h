@@ -373,6 +373,10 @@ typedef struct {
      the most significant component, axes[D-1] the one that changes fastest along the numbering; NULL = 0, 1, ..       \
      Returns 0, -1 if axes is not a permutation */                                                                     \
   ZS_ROCM_EXPORT int zs_rocm_canonicalize_axes__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *, const int *axes);  \
+  /* ... and only the entries [first, size): the head keeps its numbers (an MPM partition: the blocks that hold particles, numbered \
+     before EnlargeSparsity appended the apron blocks -- sorting the tail makes the whole numbering reproducible) */              \
+  ZS_ROCM_EXPORT int zs_rocm_canonicalize_tail__bht_int_##D##_int_##B(zs_rocm_policy *, zs_rocm_bht_##D *, const int *axes,     \
+                                                                     size_t first);                                             \
   /* (B) renumber the active keys along the Z-order (Morton) curve of (key - min key): consecutive  \
      entries are spatial neighbours -- the launch order the per-block MPM kernels want (no reference  \
      counterpart: the reference's numbering is insertion order, Bht.hpp:612-664, and any numbering is \

@@ -1231,6 +1231,7 @@ def test_block_numbering_orders_of_the_partition(pol, oracle, side):
             assert mt.block_order == "holders_lex"
             h = len(holders)
             assert set(keys[:h]) == holders and keys[:h] == sorted(keys[:h])
+            assert keys[h:] == sorted(keys[h:])   # ... and the apron blocks behind them in key order too: nothing is left to the race
         if order == "lex":
             assert keys == sorted(keys)
         mt.rebin()
@@ -1251,5 +1252,6 @@ def test_block_numbering_orders_of_the_partition(pol, oracle, side):
     keys = [tuple(int(c) for c in k) for k in mt.active_keys()]
     h = len(holders)
     assert set(keys[:h]) == holders and keys[:h] == sorted(keys[:h], key=lambda k: (k[2], k[0], k[1])) and mt.block_axes == (2, 0, 1)
+    assert keys[h:] == sorted(keys[h:], key=lambda k: (k[2], k[0], k[1]))
     with pytest.raises(ValueError):
         mt.build_partition(n, axes=(0, 0, 1))

@@ -313,6 +313,8 @@ def _declare_containers(L):
         getattr(L, "zs_rocm_canonicalize__" + s).argtypes = [vp, vp]
         getattr(L, "zs_rocm_canonicalize_axes__" + s).argtypes = [vp, vp, C.POINTER(C.c_int)]
         getattr(L, "zs_rocm_canonicalize_axes__" + s).restype = i32
+        getattr(L, "zs_rocm_canonicalize_tail__" + s).argtypes = [vp, vp, C.POINTER(C.c_int), sz]
+        getattr(L, "zs_rocm_canonicalize_tail__" + s).restype = i32
         getattr(L, "zs_rocm_order_morton__" + s).argtypes = [vp, vp]
     L.zs_rocm_hashtable_create.argtypes = [i32, sz, i32, i32]
     L.zs_rocm_hashtable_create.restype = vp

@@ -216,13 +216,14 @@ class Bht:
     def reorder(self, pol, map_ptr, scatter=False):
         getattr(lib(), "zs_rocm_reorder__" + self.s)(pol.handle, self._h, map_ptr, int(scatter))
 
-    def canonicalize(self, pol, axes=None):
-        """renumber the entries in lexicographic key order; axes: the components from most to least significant (default 0, 1, ..)"""
-        if axes is None:
+    def canonicalize(self, pol, axes=None, first=0):
+        """renumber the entries in lexicographic key order; axes: the components from most to least significant (default 0, 1, ..);
+        first: the entries [0, first) keep their numbers, only the rest is sorted"""
+        if axes is None and not first:
             getattr(lib(), "zs_rocm_canonicalize__" + self.s)(pol.handle, self._h)
             return
-        axes = [int(a) for a in axes]
-        if len(axes) != self.dim or getattr(lib(), "zs_rocm_canonicalize_axes__" + self.s)(pol.handle, self._h, (C.c_int * self.dim)(*axes)) != 0:
+        axes = [int(a) for a in (axes if axes is not None else range(self.dim))]
+        if len(axes) != self.dim or getattr(lib(), "zs_rocm_canonicalize_tail__" + self.s)(pol.handle, self._h, (C.c_int * self.dim)(*axes), int(first)) != 0:
             raise ValueError("Bht.canonicalize: axes must be a permutation of 0 .. %d" % (self.dim - 1))
 
     def order_morton(self, pol):

@@ -224,7 +224,8 @@ template <int DIM> static void bht_reorder_impl(Launch &L, BhtHost &t, const int
 // canonical numbering: active keys in lexicographic order (component 0 most significant), LSD over components
 // axes: NULL, or a permutation of 0 .. DIM-1 -- axes[0] is the most significant component of the comparison, axes[DIM-1] the one that
 // changes fastest along the numbering
-template <int DIM> static int bht_canonicalize(zs_rocm_policy *pol, BhtHost &t, const int *axes = nullptr) {
+// first: entries [0, first) keep their numbers, only [first, size) are sorted (the apron blocks of an MPM partition behind its holders)
+template <int DIM> static int bht_canonicalize(zs_rocm_policy *pol, BhtHost &t, const int *axes = nullptr, size_t first = 0) {
   int ax[DIM];
   unsigned seen = 0u;
   for (int d = 0; d < DIM; ++d) {
@@ -234,15 +235,17 @@ template <int DIM> static int bht_canonicalize(zs_rocm_policy *pol, BhtHost &t, 
   }
   Launch L(pol, "bht_canonicalize");
   const int n = bht_size(t, L.stream);
-  if (n <= 1) return 0;
+  if (first >= (size_t)n || n - (int)first <= 1) return 0;
+  const int f = (int)first, m = n - f;
   int *perm[2] = {(int *)L.temp(sizeof(int) * n), (int *)L.temp(sizeof(int) * n)};
-  unsigned *comp = (unsigned *)L.temp(sizeof(unsigned) * n), *sorted = (unsigned *)L.temp(sizeof(unsigned) * n);
+  unsigned *comp = (unsigned *)L.temp(sizeof(unsigned) * m), *sorted = (unsigned *)L.temp(sizeof(unsigned) * m);
   hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, perm[0], n);
+  if (f) hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, perm[1], n);  // (the head stays the identity in both)
   int cur = 0;
   for (int d = DIM - 1; d >= 0; --d) {
-    hipLaunchKernelGGL((bht_gather_comp_kernel<DIM>), dim3(ceil_div(n, 256)), dim3(256), 0, L.stream, t.activeKeys, perm[cur], n,
+    hipLaunchKernelGGL((bht_gather_comp_kernel<DIM>), dim3(ceil_div(m, 256)), dim3(256), 0, L.stream, t.activeKeys, perm[cur] + f, m,
                        ax[d], comp);
-    radix_sort_pair_u32(L, comp, perm[cur], sorted, perm[cur ^ 1], (size_t)n, 0, 32);
+    radix_sort_pair_u32(L, comp, perm[cur] + f, sorted, perm[cur ^ 1] + f, (size_t)m, 0, 32);
     cur ^= 1;
   }
   bht_reorder_impl<DIM>(L, t, perm[cur], /*scatter=*/false, n);  // new key i = old key perm[i]
@@ -376,6 +379,9 @@ extern "C" {
   }                                                                                                         \
   int zs_rocm_canonicalize_axes__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *axes) {  \
     return bht_canonicalize<D>(pol, b->t, axes);                                                            \
+  }                                                                                                         \
+  int zs_rocm_canonicalize_tail__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b, const int *axes, size_t first) {  \
+    return bht_canonicalize<D>(pol, b->t, axes, first);                                                     \
   }                                                                                                         \
   void zs_rocm_order_morton__bht_int_##D##_int_##B(zs_rocm_policy *pol, zs_rocm_bht_##D *b) {                \
     bht_order_morton<D>(pol, b->t);                                                                         \

@@ -150,9 +150,12 @@ class MpmTransfer:
         L = lib()
         L.zs_rocm_mpm_compute_sparsity(self.pol.handle, self.table.handle, self._port("x"), self.n, self.params.dx, self.side,
                                        int(self.key_is_origin))
+        n_holders = 0
         if order == "holders_lex":  # (the apron blocks are inserted after this and keep the indices behind the holders)
             self.pol.syncCtx()
             self.table.canonicalize(self.pol, axes)
+            self.pol.syncCtx()
+            n_holders = self.table.size()
         if os.environ.get("ZS_ROCM_HOLDER_ORDER"):   # measurement only (tools/r06_order2.sh)
             self._measurement_holder_order(os.environ["ZS_ROCM_HOLDER_ORDER"])
         m = int(margin)
@@ -160,6 +163,9 @@ class MpmTransfer:
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, self.table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
+        if order == "holders_lex" and not os.environ.get("ZS_ROCM_APRON_RACE"):   # the apron blocks in key order too: the whole numbering is reproducible
+            self.table.canonicalize(self.pol, axes, first=n_holders)                    # (the variable: A/B of profiles/r06_p2g.md, section 4b)
+            self.pol.syncCtx()
         if order == "morton":
             self.table.order_morton(self.pol)
             self.pol.syncCtx()
@@ -348,9 +354,14 @@ class MpmTransfer:
         if getattr(self, "block_order", "insertion") == "holders_lex":   # the numbering build_partition() was asked for
             self.pol.syncCtx()
             new_table.canonicalize(self.pol, getattr(self, "block_axes", None))
+            self.pol.syncCtx()
+            n_holders = new_table.size()
         lo, hi = (C.c_int * 3)(-m, -m, -m), (C.c_int * 3)(2 + m, 2 + m, 2 + m)
         L.zs_rocm_mpm_enlarge_sparsity(self.pol.handle, new_table.handle, lo, hi, self.kstride)
         self.pol.syncCtx()
+        if getattr(self, "block_order", "insertion") == "holders_lex":
+            new_table.canonicalize(self.pol, getattr(self, "block_axes", None), first=n_holders)
+            self.pol.syncCtx()
         nb = new_table.size()
         if not new_table.success() or nb == 0:   # nothing of this object has been replaced yet: the caller can still unslot() and re-partition the long way
             raise RuntimeError("repartition_slotted: the new partition did not fit its table (%d blocks, capacity for %d)"
