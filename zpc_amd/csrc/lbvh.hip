@@ -645,8 +645,7 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
   int nextStart = NONE;
   if (pending) nextStart = __builtin_amdgcn_readlane(start, __ffsll((long long)pending) - 1);
   int cur = nextStart;
-  while (cur < numNodes) {
-    cur = __builtin_amdgcn_readfirstlane(cur);
+  while (cur < numNodes) {  // (cur is wave-uniform by construction and the compiler sees it: it lives in an SGPR -- a readfirstlane here forces a VGPR copy)
     if (cur == nextStart) {  // the first pending lane starts here: the next one in line
       pending &= pending - 1;
       nextStart = NONE;
@@ -662,8 +661,14 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
     const float nhi0 = __int_as_float(raw[3]), nhi1 = __int_as_float(raw[4]), nhi2 = __int_as_float(raw[5]);
     const int level = raw[6], aux = raw[7];
     const bool active = next == cur;
-    const bool ov = (int)!(me.lo[0] > nhi0 || me.hi[0] < nlo0) & (int)!(me.lo[1] > nhi1 || me.hi[1] < nlo1) &
-                    (int)!(me.lo[2] > nhi2 || me.hi[2] < nlo2);
+    // the six interval tests as ONE compare: !(a > b) for every pair  <=>  !(max over the pairs of (a - b) > 0).  Exact: a difference of two
+    // distinct floats is never zero (f32 denormals are kept), inf - inf and NaN operands give NaN, which v_max3 drops as the chained
+    // comparisons ignore them, and an all-NaN maximum fails `> 0` like every `a > b` did.  Six subtractions and two max3 on the vector
+    // unit replace five 64-bit mask ANDs on the scalar unit, which is the unit this loop saturates (one scalar instruction per cycle and CU).
+    const float sep = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(me.lo[0] - nhi0, nlo0 - me.hi[0]), __builtin_fmaxf(me.lo[1] - nhi1, nlo1 - me.hi[1])),
+                                      __builtin_fmaxf(me.lo[2] - nhi2, nlo2 - me.hi[2]));
+    const bool ov = !(sep > 0.f);
+    const unsigned long long downMask = __ballot(active) & __ballot(ov);   // (ballots of two compares: their masks, no materialised booleans)
     if (__builtin_amdgcn_readfirstlane(level) == 0) {  // a leaf (wave-uniform branch): report it, continue at cur + 1
       if (active && ov && aux != self) {
         if constexpr (FILL) {
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256) void lbvh_self_query_wave_kernel(const LbvhPac
     } else {             // a trunk node: descend on overlap, escape otherwise (aux = the escape index; numNodes behind the last subtree)
       const bool down = active && ov;
       if (active) next = down ? cur + 1 : aux;
-      if (__ballot(down)) cur = cur + 1;
+      if (downMask) cur = cur + 1;
       else cur = aux < nextStart ? aux : nextStart;
     }
   }
