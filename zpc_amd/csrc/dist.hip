@@ -474,8 +474,9 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
           report_error(hipErrorOutOfMemory, "step_slotted: could not allocate the boundary signal", __FILE__, __LINE__);
           return -1;
         }
-        Launch L(pol, "step: boundary signal := 0");   // (on the stream of the launch that counts)
+        Launch L(pol, "step: boundary signal := 0");
         ZSR_CHECK(hipMemsetAsync(p->signal, 0, sizeof(unsigned long long), L.stream));
+        ZSR_CHECK(hipStreamSynchronize(L.stream));   // once per plan: the gate on the OTHER stream must never read the word before it is zero
         p->signalTarget = 0;
       }
       rc = mpm_g2p2g_slots_signal(pol, a->params, a->particles, a->table, a->gridA, a->gridB, nb, a->storage, a->writeAll, 0, nb, 1, p->signal, a->nBoundary);
