@@ -100,6 +100,12 @@ def parse():
                          "stream; side-by-side = the boundary launch on the exchange stream next to the interior launch; one-launch = one launch "
                          "over all blocks whose boundary workgroups count themselves off, a gate kernel on the exchange stream waits for the "
                          "count (8^3 blocks).  auto: one-launch for 8^3 blocks, in-turn for 4^3")
+    ap.add_argument("--check-handover", action="store_true",
+                    help="(tests, with --rank-proxy) after every step compare what the exchange stream saw of the shared blocks' mass sums when the exchange "
+                         "started (zs_rocm_mpm_step.handoverSnapshot) with the same blocks after the step: config.handover = steps checked / mismatched")
+    ap.add_argument("--understate-boundary", type=float, default=0.0,
+                    help="(negative control of --check-handover) tell the step that only this share of the boundary blocks is boundary: the exchange "
+                         "starts before the rest is done and the check must see it")
     ap.add_argument("--tag-mass", action="store_true",
                     help="every particle's mass carries its number in the global box (tests: per-particle comparison of runs on different rank counts)")
     ap.add_argument("--dump-state", type=str, default="",
@@ -523,6 +529,8 @@ def main():
     hip_events = HipEvents()
     breakdown = StepBreakdown() if (world > 1 or proxy) else None   # where a rank's step time goes (events inside zs_rocm_mpm_step_slotted)
 
+    handover = {"snap": None, "final": None, "steps": 0, "mismatched_steps": 0, "nonzero": 0}   # --check-handover
+
     ctrl_ev = []  # (start, end) events of the fused launches since the last look of the re-bin controller
 
     def step_fused(timed, write_all=False, reorder=False):
@@ -535,12 +543,32 @@ def main():
         if one_call:
             # grid reset, both block ranges, exchange on the side stream, re-home / commit, grid update, CFL allreduce: ONE call;
             # the library records the event pair around the transfer kernels itself
+            nbd = n_boundary if (overlap and halo is not None) else 0
+            check = a.check_handover and nbd and comm is not None and 0 < nbd < mt.nblocks
+            if check:
+                if a.understate_boundary:   # negative control of the check: the exchange is released when only this share of the boundary blocks is done
+                    nbd = max(1, int(nbd * a.understate_boundary))
+                if handover["snap"] is None or handover["snap"].numel() != halo.total_blocks * nc:
+                    handover["snap"] = torch.zeros(halo.total_blocks * nc, dtype=torch.float32, device=device)
+                    handover["final"] = torch.zeros_like(handover["snap"])
             mt.step_slotted((0.0, -9.8, 0.0), None if a.no_cfl else max_vel, write_all=write_all,
-                            n_boundary=n_boundary if (overlap and halo is not None) else 0, comm=comm, plan=halo if comm is not None else None,
+                            n_boundary=nbd, comm=comm, plan=halo if comm is not None else None,
                             comm_pol=pol_comm if overlap else None, collider=floor, halo_grid=proxy_grid,
                             events=hip_events.pair() if timed else None,
                             breakdown=breakdown.next() if (timed and breakdown is not None) else None, halo_channels=a.halo_channels,
-                            range_schedule=range_schedule)
+                            range_schedule=range_schedule, handover_snapshot=handover["snap"] if check else None)
+            if check:
+                # the mass channel of the shared blocks as the exchange stream saw it when the exchange started against the same blocks after the
+                # step: only boundary blocks write those nodes (and the proxy's exchange goes to a scratch grid), so the two are equal BIT FOR BIT
+                # exactly when the hand-over let the exchange see complete sums
+                torch.cuda.synchronize()
+                lib().zs_rocm_mpm_halo_pack(pol.handle, mt.grid.data_ptr(), lib().zs_rocm_dist_halo_plan_block_list(halo._h), halo.total_blocks, a.side, 0, 1,
+                                            handover["final"].data_ptr())
+                pol.syncCtx()
+                torch.cuda.synchronize()
+                handover["steps"] += 1
+                handover["mismatched_steps"] += int(not torch.equal(handover["snap"], handover["final"]))
+                handover["nonzero"] = max(handover["nonzero"], int((handover["final"] != 0).sum().item()))
             return
         if overlap and halo is not None and 0 < n_boundary < mt.nblocks:
             # boundary blocks first; their ghost sums travel on the communication stream while the interior blocks compute
@@ -919,7 +947,8 @@ def main():
             "config": {"workload": workload,
                        "particles": n_total, "grid_blocks_rank0": nblocks, "decomposition": "x".join(map(str, zpc_amd.dist.split_dims(world))),
                        "halo_bytes_per_step_rank0": ((halo.bytes_per_exchange * a.halo_channels // 7 if comm is not None else halo.bytes_per_exchange) if halo and halo.peers else 0),
-                       "halo_channels": a.halo_channels, "block_order": getattr(mt, "block_order", None), "block_axes": list(getattr(mt, "block_axes", None) or (0, 1, 2)),
+                       "halo_channels": a.halo_channels, "handover": ({k: handover[k] for k in ("steps", "mismatched_steps", "nonzero")} if a.check_handover else None),
+                       "block_order": getattr(mt, "block_order", None), "block_axes": list(getattr(mt, "block_axes", None) or (0, 1, 2)),
                        "step_schedule": (("ranges in turn", "ranges side by side", "one launch + gate")[range_schedule] if (one_call and overlap) else "one range"),
                        "boundary": "plane collider (Separate) at y = 1.5 dx" if a.floor else "none", "rebins": rebins, "halo_overlap": bool(overlap), "exchange": ("rccl via libzsrocm (zs_rocm_dist_*)" if comm is not None else ("torch.distributed/" + a.backend if world > 1 else "none")),
                        "cfl_max_vel_sqr": (None if a.no_cfl else float(max_vel.item())), "boundary_blocks_rank0": n_boundary,

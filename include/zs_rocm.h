@@ -869,6 +869,10 @@ typedef struct zs_rocm_mpm_step {
                                             device word; a one-wave gate kernel on commPolicy's stream waits for the count and the exchange runs
                                             behind it.  No launch boundary inside the step: no tail, no sharing.
                                             evBreakdown[1] (boundary done) is recorded on commPolicy's stream for 1 and 2; [0,1] and [0,2] overlap. */
+  float *handoverSnapshot;               /* NULL, or (test hook, overlapped schedule) plan-blocks x side^3 floats: the MASS channel of gridB's shared blocks, packed like the
+                                            exchange buffer (zs_rocm_mpm_halo_pack, chn0 = 0, nchn = 1) on commPolicy's stream at the moment the exchange starts.  Only the
+                                            boundary blocks write those nodes, so it must equal the same pack taken after the step: the check that the hand-over of a
+                                            schedule lets the exchange see complete sums (tests/test_dist_gpu.py) */
 } zs_rocm_mpm_step;
 #define ZS_ROCM_STEP_EVENTS 8
 #define ZS_ROCM_RANGES_IN_TURN 0

@@ -189,9 +189,13 @@ def test_range_schedules_of_the_step_call_agree(extra):
     ref = _run(1, args)
     assert ref["config"]["movers_per_step_rank0"] > 0 and ref["config"]["step_schedule"] == "one range"
     for sched, name in (("in-turn", "ranges in turn"), ("side-by-side", "ranges side by side"), ("one-launch", "one launch + gate"), ("auto", "one launch + gate")):
-        out = _run(1, args + ["--rank-proxy", "8", "--range-schedule", sched])
+        out = _run(1, args + ["--rank-proxy", "8", "--range-schedule", sched, "--check-handover"])
         assert out["hip_error"] == 0 and out["config"]["halo_overlap"] and 0 < out["config"]["boundary_blocks_rank0"] < out["config"]["grid_blocks_rank0"]
         assert out["config"]["step_schedule"] == name
+        # the hand-over itself: what the exchange stream saw of the shared blocks' mass sums when the exchange started equals, bit for bit, the
+        # same blocks after the step (zs_rocm_mpm_step.handoverSnapshot) -- in every step: the exchange never runs ahead of a boundary block
+        ho = out["config"]["handover"]
+        assert ho["steps"] >= 12 and ho["mismatched_steps"] == 0 and ho["nonzero"] > 1000, (sched, ho)
         a, b = np.array(ref["checksum"]), np.array(out["checksum"])
         nch = len(a) // 2
         scale = np.sqrt(ref["config"]["particles"] * np.maximum(a[nch:], 1e-30))
@@ -199,6 +203,16 @@ def test_range_schedules_of_the_step_call_agree(extra):
         assert (np.abs(a[nch:] - b[nch:]) <= 1e-4 * np.abs(a[nch:]) + 1e-12).all(), sched
         bdn = out["rank_breakdown"]["max_over_ranks"]
         assert bdn["both_ranges_ms"] > 0 and bdn["boundary_range_ms"] > 0 and bdn["exchange_side_stream_ms"] > 0
+    if not extra:
+        # ... and on a box of 1024 blocks with particles (two rounds of the chip's 512 workgroup slots: boundary blocks really finish at different
+        # times), with the negative control: told that only a tenth of the boundary blocks is boundary, a schedule releases the exchange too
+        # early -- and the check sees it
+        big = ["--cells", "64,128,64", "--steps", "6", "--warmup", "0", "--no-cpu-baseline", "--lift", "8", "--no-at-rest", "--rank-proxy", "8", "--check-handover"]
+        for sched in ("in-turn", "one-launch"):
+            good = _run(1, big + ["--range-schedule", sched])["config"]["handover"]
+            assert good["steps"] >= 6 and good["mismatched_steps"] == 0 and good["nonzero"] > 100000, (sched, good)
+            bad = _run(1, big + ["--range-schedule", sched, "--understate-boundary", "0.1"])["config"]["handover"]
+            assert bad["steps"] >= 6 and bad["mismatched_steps"] > 0, (sched, bad)
 
 
 def test_native_rccl_exchange_steps_on_one_gpu():

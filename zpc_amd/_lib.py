@@ -70,7 +70,7 @@ class MpmStep(C.Structure):
                 ("nblocks", C.c_size_t), ("storage", C.c_void_p), ("writeAll", C.c_int), ("extf", C.c_float * 3),
                 ("maxVelSqr", C.c_void_p), ("collider", C.c_void_p), ("nBoundary", C.c_size_t), ("dist", C.c_void_p),
                 ("plan", C.c_void_p), ("commPolicy", C.c_void_p), ("haloGrid", C.c_void_p), ("evTransferBegin", C.c_void_p),
-                ("evTransferEnd", C.c_void_p), ("evBreakdown", C.POINTER(C.c_void_p)), ("haloChannels", C.c_int), ("rangeSchedule", C.c_int)]
+                ("evTransferEnd", C.c_void_p), ("evBreakdown", C.POINTER(C.c_void_p)), ("haloChannels", C.c_int), ("rangeSchedule", C.c_int), ("handoverSnapshot", C.c_void_p)]
 
 
 class MpmParams(C.Structure):

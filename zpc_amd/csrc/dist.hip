@@ -519,6 +519,8 @@ int zs_rocm_mpm_step_slotted(zs_rocm_policy *pol, const zs_rocm_mpm_step *a) {
       }
     }
     bd(3, a->commPolicy);
+    if (a->handoverSnapshot)   // (test hook) what the exchange would read of gridB's shared blocks right now: their mass channel
+      zs_rocm_mpm_halo_pack(a->commPolicy, a->gridB, p->blocks, p->total, p->side, 0, 1, a->handoverSnapshot);
     const int rcx = zs_rocm_dist_halo_plan_exchange(p, a->dist, a->commPolicy, hgrid, 0, hch);
     bd(4, a->commPolicy);
     {

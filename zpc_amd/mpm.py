@@ -629,7 +629,7 @@ class MpmTransfer:
                 between()
 
     def step_slotted(self, extf=(0.0, 0.0, 0.0), max_vel=None, write_all=False, n_boundary=0, comm=None, plan=None, comm_pol=None,
-                     collider=None, halo_grid=None, events=None, breakdown=None, halo_channels=7, range_schedule=0):
+                     collider=None, halo_grid=None, events=None, breakdown=None, halo_channels=7, range_schedule=0, handover_snapshot=None):
         """One whole sub-step on slotted storage behind ONE C-ABI call (zs_rocm_mpm_step_slotted): second grid := 0, fused G2P2G over the
         boundary blocks [0, n_boundary) then the interior, ghost-block exchange of `plan` on comm_pol's stream overlapping the interior,
         grid update (+ collider), CFL allreduce(max) of max_vel.  The grids swap: self.grid is the new one afterwards.
@@ -658,6 +658,7 @@ class MpmTransfer:
         a.haloGrid = halo_grid.data_ptr() if halo_grid is not None else None
         a.haloChannels = int(halo_channels)   # 4: only {m, mv} of the ghost blocks travel (all a step reads of them); 7: the rhs channels too
         a.rangeSchedule = int(range_schedule)   # RANGES_IN_TURN / _SIDE_BY_SIDE / _ONE_LAUNCH (include/zs_rocm.h, zs_rocm_mpm_step.rangeSchedule)
+        a.handoverSnapshot = handover_snapshot.data_ptr() if handover_snapshot is not None else None   # (test hook)
         a.evTransferBegin, a.evTransferEnd = (events[0], events[1]) if events is not None else (None, None)   # raw hipEvent_t (HipEvents)
         a.evBreakdown = breakdown if breakdown is not None else None   # (C.c_void_p * ZS_ROCM_STEP_EVENTS) of raw hipEvent_t (StepBreakdown.next())
         if getattr(self, "_poisoned", False):
